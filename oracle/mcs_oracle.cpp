@@ -1,0 +1,1069 @@
+/*
+ * mcs_oracle.cpp — CPU ORACLE: restatement of the reference hot path.   TEST INFRASTRUCTURE ONLY.
+ *
+ * Follows (file:line relative to /root/reference):
+ *   src/mdBRIEFextractorOct.cpp:134-203 (ctor tables) 221-248 (IC_Angle) 250-301 (pattern rotation)
+ *   303-554 (compute_ORB / compute_dBRIEF / compute_mdBRIEF) 569-861 (oct-tree) 863-976 (cell FAST)
+ *   1158-1201 (pyramid) 1203-1337 (descriptors + operator())
+ *   src/cam_model_omni.cpp:49-67,146-161,163-220   include/cam_model_omni.h:127-145   include/misc.h:33-49,115-122
+ *   src/cMultiFrame.cpp:146-152,342-353   src/cORBmatcher.cpp:46-65,179-323,885-1155,2438-2474   src/misc.cpp:53-69
+ * plus the OpenCV 3.x generic-C++ primitives restated in SURVEY.md Appendix A (OpenCV is not vendored
+ * by the reference and not installed here -> PARITY UNPINNED, see mcs_oracle.h).
+ *
+ * Documented deviations where the reference has undefined / non-deterministic behaviour:
+ *   (1) oct-tree sort ties (pair<int,Node*> compares heap addresses, :782) -> tie broken by node creation
+ *       sequence number (later-created sorts higher).
+ *   (2) descriptor samples that fall outside the 25-px bordered level buffer (out-of-bounds read in the
+ *       reference) are clamped to the buffer.
+ * Build: g++ -O3 -march=native -ffp-contract=off -fopenmp (reference flags CMakeLists.txt:37-38 + no FMA contraction).
+ */
+#include "mcs_oracle.h"
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstddef>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <utility>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using std::ptrdiff_t;
+namespace {
+
+const int PATCH_SIZE = 32;        // mdBRIEFextractorOct.cpp:84
+const int HALF_PATCH_SIZE = 16;   // :85
+const int EDGE_THRESHOLD = 25;    // :86
+const double CV_PI_D = 3.1415926535897932384626433832795;
+const float DEG2RADf = static_cast<float>(CV_PI_D) / 180.f;  // :83
+// include/misc.h:33-41
+const double M_PID_ = 3.1415926535897932384626433832795028841971693993;
+const float M_PIf_ = 3.1415926535897932384626f;
+const double RHOd = 180.0 / M_PID_;
+const float RHOf = 180.0f / M_PIf_;
+
+static const signed char kPattern[2048] = {
+#include "learned_pattern_64_orb.inc"
+};
+
+// ---- A.0 scalars ----
+inline int cvRound_(double v) { return (int)lrint(v); }      // round-half-even in the default FP env
+inline int cvRoundf_(float v) { return (int)lrintf(v); }
+inline int cvFloor_(double v) { int i = (int)v; return i - (i > v); }
+inline int cvCeil_(double v) { int i = (int)v; return i + (i < v); }
+inline short sat_short(float v) { int iv = cvRoundf_(v); return (short)(iv < -32768 ? -32768 : iv > 32767 ? 32767 : iv); }
+
+struct Img {  // bordered level buffer; (0,0) of the ROI is at buf[border*stride+border]
+	int w = 0, h = 0, stride = 0, border = 0;
+	std::vector<uint8_t> buf;
+	void alloc(int w_, int h_, int b) { w = w_; h = h_; border = b; stride = w + 2 * b; buf.assign((size_t)stride * (h + 2 * b), 0); }
+	uint8_t* roi() { return buf.data() + (size_t)border * stride + border; }
+	const uint8_t* roi() const { return buf.data() + (size_t)border * stride + border; }
+};
+
+}  // namespace
+
+extern "C" {
+
+int orc_cvRound(double v) { return cvRound_(v); }
+
+// ---------------------------------------------------------------- E0
+void orc_features_per_level(int nfeatures, float scaleFactor_, int nlevels, int* out) {
+	double scaleFactor = scaleFactor_;  // member is double, ctor arg float (h:340, cpp:147)
+	double factor = (1.0 / scaleFactor);
+	double nDesired = nfeatures * (1 - factor) / (1 - pow(factor, nlevels));
+	int sum = 0;
+	for (int level = 0; level < nlevels - 1; level++) {
+		out[level] = cvRound_(nDesired);
+		sum += out[level];
+		nDesired *= factor;
+	}
+	out[nlevels - 1] = std::max(nfeatures - sum, 0);
+}
+
+void orc_umax(int* umax) {  // cpp:187-202
+	int v, v0, vmax = cvFloor_(HALF_PATCH_SIZE * sqrt(2.f) / 2 + 1);
+	int vmin = cvCeil_(HALF_PATCH_SIZE * sqrt(2.f) / 2);
+	const double hp2 = HALF_PATCH_SIZE * HALF_PATCH_SIZE;
+	for (v = 0; v <= HALF_PATCH_SIZE; ++v) umax[v] = 0;
+	for (v = 0; v <= vmax; ++v) umax[v] = cvRound_(sqrt(hp2 - v * v));
+	for (v = HALF_PATCH_SIZE, v0 = 0; v >= vmin; --v) {
+		while (umax[v0] == umax[v0 + 1]) ++v0;
+		umax[v] = v0;
+		++v0;
+	}
+}
+
+static void scale_tables(float sf_, int nlevels, std::vector<double>& sc, std::vector<double>& inv) {
+	double scaleFactor = sf_;
+	sc.assign(nlevels, 1.0);
+	inv.assign(nlevels, 1.0);
+	for (int i = 1; i < nlevels; i++) sc[i] = sc[i - 1] * scaleFactor;
+	double invScaleFactor = 1.0 / scaleFactor;
+	for (int i = 1; i < nlevels; i++) inv[i] = inv[i - 1] * invScaleFactor;
+}
+
+void orc_level_sizes(int W, int H, float sf, int nlevels, int* w, int* h) {  // cpp:1164-1165
+	std::vector<double> sc, inv;
+	scale_tables(sf, nlevels, sc, inv);
+	for (int l = 0; l < nlevels; ++l) {
+		w[l] = cvRound_((double)W * inv[l]);
+		h[l] = cvRound_((double)H * inv[l]);
+	}
+}
+
+int orc_pattern(int descSize, int* xy) {
+	int npoints = 2 * 8 * descSize;  // cpp:181
+	if (npoints * 2 > 2048) return -1;
+	for (int i = 0; i < 2 * npoints; ++i) xy[i] = kPattern[i];
+	return npoints;
+}
+
+// ---------------------------------------------------------------- A.1 resize INTER_LINEAR (8UC1)
+void orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride) {
+	double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+	double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+	std::vector<int> xofs(dw), yofs(dh);
+	std::vector<short> ialpha(2 * dw), ibeta(2 * dh);
+	int xmax = dw;
+	for (int dx = 0; dx < dw; dx++) {
+		float fx = (float)((dx + 0.5) * scale_x - 0.5);
+		int sx = cvFloor_(fx);
+		fx -= sx;
+		if (sx < 0) { fx = 0; sx = 0; }
+		if (sx + 1 >= sw) {
+			xmax = std::min(xmax, dx);
+			if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+		}
+		xofs[dx] = sx;
+		ialpha[2 * dx] = sat_short((1.f - fx) * 2048);
+		ialpha[2 * dx + 1] = sat_short(fx * 2048);
+	}
+	for (int dy = 0; dy < dh; dy++) {
+		float fy = (float)((dy + 0.5) * scale_y - 0.5);
+		int sy = cvFloor_(fy);
+		fy -= sy;
+		yofs[dy] = sy;
+		ibeta[2 * dy] = sat_short((1.f - fy) * 2048);
+		ibeta[2 * dy + 1] = sat_short(fy * 2048);
+	}
+	std::vector<int> T0(dw), T1(dw);
+	for (int dy = 0; dy < dh; dy++) {
+		int sy0 = yofs[dy];
+		for (int k = 0; k < 2; k++) {
+			int sy = sy0 + k;
+			sy = sy >= 0 ? (sy < sh ? sy : sh - 1) : 0;  // clip(sy, 0, sh)
+			const uint8_t* S = src + (size_t)sy * sstride;
+			int* D = k == 0 ? T0.data() : T1.data();
+			int dx = 0;
+			for (; dx < xmax; dx++) D[dx] = S[xofs[dx]] * ialpha[2 * dx] + S[xofs[dx] + 1] * ialpha[2 * dx + 1];
+			for (; dx < dw; dx++) D[dx] = S[xofs[dx]] * 2048;
+		}
+		short b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+		uint8_t* D = dst + (size_t)dy * dstride;
+		for (int dx = 0; dx < dw; dx++)
+			D[dx] = (uint8_t)((((b0 * (T0[dx] >> 4)) >> 16) + ((b1 * (T1[dx] >> 4)) >> 16) + 2) >> 2);
+	}
+}
+
+// ---------------------------------------------------------------- A.2 resize INTER_NEAREST
+void orc_resize_nearest(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride) {
+	double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+	double ifx = 1. / inv_scale_x, ify = 1. / inv_scale_y;
+	std::vector<int> x_ofs(dw);
+	for (int x = 0; x < dw; x++) x_ofs[x] = std::min(cvFloor_(x * ifx), sw - 1);
+	for (int y = 0; y < dh; y++) {
+		int sy = std::min(cvFloor_(y * ify), sh - 1);
+		for (int x = 0; x < dw; x++) dst[(size_t)y * dstride + x] = src[(size_t)sy * sstride + x_ofs[x]];
+	}
+}
+
+static inline int reflect101(int p, int len) {
+	if (len == 1) return 0;
+	while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * (len - 1) - p; }
+	return p;
+}
+
+// buf is (w+2b) x (h+2b) with the ROI already filled; fill the frame with BORDER_REFLECT_101
+void orc_border_reflect101(uint8_t* buf, int w, int h, int stride, int b) {
+	uint8_t* roi = buf + (size_t)b * stride + b;
+	for (int y = -b; y < h + b; ++y) {
+		int sy = reflect101(y, h);
+		for (int x = -b; x < w + b; ++x) {
+			if (x >= 0 && x < w && y >= 0 && y < h) continue;
+			int sx = reflect101(x, w);
+			roi[(ptrdiff_t)y * stride + x] = roi[(ptrdiff_t)sy * stride + sx];
+		}
+	}
+}
+
+// ---------------------------------------------------------------- A.3 FAST-9/16
+static const int kCircle[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
+                                   {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+static inline void make_offsets(int pixel[25], int stride) {
+	for (int k = 0; k < 16; k++) pixel[k] = kCircle[k][0] + kCircle[k][1] * stride;
+	for (int k = 16; k < 25; k++) pixel[k] = pixel[k - 16];
+}
+
+static int corner_score16(const uint8_t* ptr, const int pixel[25], int threshold) {  // cornerScore<16>
+	const int K = 8, N = K * 3 + 1;
+	int k, v = ptr[0];
+	short d[N];
+	for (k = 0; k < N; k++) d[k] = (short)(v - ptr[pixel[k]]);
+	int a0 = threshold;
+	for (k = 0; k < 16; k += 2) {
+		int a = std::min((int)d[k + 1], (int)d[k + 2]);
+		a = std::min(a, (int)d[k + 3]);
+		if (a <= a0) continue;
+		a = std::min(a, (int)d[k + 4]);
+		a = std::min(a, (int)d[k + 5]);
+		a = std::min(a, (int)d[k + 6]);
+		a = std::min(a, (int)d[k + 7]);
+		a = std::min(a, (int)d[k + 8]);
+		a0 = std::max(a0, std::min(a, (int)d[k]));
+		a0 = std::max(a0, std::min(a, (int)d[k + 9]));
+	}
+	int b0 = -a0;
+	for (k = 0; k < 16; k += 2) {
+		int b = std::max((int)d[k + 1], (int)d[k + 2]);
+		b = std::max(b, (int)d[k + 3]);
+		b = std::max(b, (int)d[k + 4]);
+		b = std::max(b, (int)d[k + 5]);
+		if (b >= b0) continue;
+		b = std::max(b, (int)d[k + 6]);
+		b = std::max(b, (int)d[k + 7]);
+		b = std::max(b, (int)d[k + 8]);
+		b0 = std::min(b0, std::max(b, (int)d[k]));
+		b0 = std::min(b0, std::max(b, (int)d[k + 9]));
+	}
+	threshold = -b0 - 1;
+	return threshold;
+}
+
+int orc_fast_score(const uint8_t* center, int stride, int threshold) {
+	int pixel[25];
+	make_offsets(pixel, stride);
+	return corner_score16(center, pixel, threshold);
+}
+
+// FAST_t<16>(img, kps, threshold, nonmax=true) followed by KeyPointsFilter::runByPixelsMask
+int orc_fast9_16(const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride, int threshold,
+                 orc_keypoint* out, int cap) {
+	const int K = 8, N = 25;
+	int pixel[25];
+	make_offsets(pixel, stride);
+	threshold = std::min(std::max(threshold, 0), 255);
+	uint8_t threshold_tab[512];
+	for (int i = -255; i <= 255; i++) threshold_tab[i + 255] = (uint8_t)(i < -threshold ? 1 : i > threshold ? 2 : 0);
+
+	std::vector<uint8_t> bufv((size_t)w * 3, 0);
+	uint8_t* buf[3] = {bufv.data(), bufv.data() + w, bufv.data() + 2 * w};
+	std::vector<int> cpv((size_t)(w + 1) * 3, 0);
+	int* cpbuf[3] = {cpv.data() + 1, cpv.data() + (w + 1) + 1, cpv.data() + 2 * (w + 1) + 1};
+	int nout = 0;
+
+	for (int i = 3; i < h - 2; i++) {
+		const uint8_t* ptr = img + (size_t)i * stride + 3;
+		uint8_t* curr = buf[(i - 3) % 3];
+		int* cornerpos = cpbuf[(i - 3) % 3];
+		memset(curr, 0, w);
+		int ncorners = 0;
+		if (i < h - 3) {
+			for (int j = 3; j < w - 3; j++, ptr++) {
+				int v = ptr[0];
+				const uint8_t* tab = &threshold_tab[0] - v + 255;
+				int d = tab[ptr[pixel[0]]] | tab[ptr[pixel[8]]];
+				if (d == 0) continue;
+				d &= tab[ptr[pixel[2]]] | tab[ptr[pixel[10]]];
+				d &= tab[ptr[pixel[4]]] | tab[ptr[pixel[12]]];
+				d &= tab[ptr[pixel[6]]] | tab[ptr[pixel[14]]];
+				if (d == 0) continue;
+				d &= tab[ptr[pixel[1]]] | tab[ptr[pixel[9]]];
+				d &= tab[ptr[pixel[3]]] | tab[ptr[pixel[11]]];
+				d &= tab[ptr[pixel[5]]] | tab[ptr[pixel[13]]];
+				d &= tab[ptr[pixel[7]]] | tab[ptr[pixel[15]]];
+				if (d & 1) {
+					int vt = v - threshold, count = 0;
+					for (int k = 0; k < N; k++) {
+						int x = ptr[pixel[k]];
+						if (x < vt) {
+							if (++count > K) {
+								cornerpos[ncorners++] = j;
+								curr[j] = (uint8_t)corner_score16(ptr, pixel, threshold);
+								break;
+							}
+						} else
+							count = 0;
+					}
+				}
+				if (d & 2) {
+					int vt = v + threshold, count = 0;
+					for (int k = 0; k < N; k++) {
+						int x = ptr[pixel[k]];
+						if (x > vt) {
+							if (++count > K) {
+								cornerpos[ncorners++] = j;
+								curr[j] = (uint8_t)corner_score16(ptr, pixel, threshold);
+								break;
+							}
+						} else
+							count = 0;
+					}
+				}
+			}
+		}
+		cornerpos[-1] = ncorners;
+		if (i == 3) continue;
+		const uint8_t* prev = buf[(i - 4 + 3) % 3];
+		const uint8_t* pprev = buf[(i - 5 + 3) % 3];
+		cornerpos = cpbuf[(i - 4 + 3) % 3];
+		ncorners = cornerpos[-1];
+		for (int k = 0; k < ncorners; k++) {
+			int j = cornerpos[k];
+			int score = prev[j];
+			if (score > prev[j + 1] && score > prev[j - 1] && score > pprev[j - 1] && score > pprev[j] &&
+			    score > pprev[j + 1] && score > curr[j - 1] && score > curr[j] && score > curr[j + 1]) {
+				float fx = (float)j, fy = (float)(i - 1);
+				if (mask && mask[(size_t)(int)(fy + 0.5f) * mstride + (int)(fx + 0.5f)] == 0) continue;  // runByPixelsMask
+				if (nout < cap) {
+					orc_keypoint kp = {fx, fy, 7.f, -1.f, (float)score, 0, -1};
+					out[nout] = kp;
+				}
+				nout++;
+			}
+		}
+	}
+	return nout;
+}
+
+// ---------------------------------------------------------------- A.4 5x5 normalised box filter, in place on a ROI
+void orc_box5_inplace(uint8_t* roi, int w, int h, int stride) {
+	std::vector<uint8_t> out((size_t)w * h);
+	for (int y = 0; y < h; ++y)
+		for (int x = 0; x < w; ++x) {
+			int s = 0;
+			for (int dy = -2; dy <= 2; ++dy) {
+				const uint8_t* r = roi + (ptrdiff_t)(y + dy) * stride + x;
+				s += r[-2] + r[-1] + r[0] + r[1] + r[2];
+			}
+			out[(size_t)y * w + x] = (uint8_t)cvRound_(s * (1. / 25));  // saturate_cast<uchar>(sum*scale)
+		}
+	for (int y = 0; y < h; ++y) memcpy(roi + (size_t)y * stride, out.data() + (size_t)y * w, w);
+}
+
+// ---------------------------------------------------------------- A.5 fastAtan2 (degrees)
+float orc_fastAtan2(float y, float x) {
+	const float K = (float)(180 / CV_PI_D);
+	const float p1 = 0.9997878412794807f * K, p3 = -0.3258083974640975f * K, p5 = 0.1555786518463281f * K,
+	            p7 = -0.04432655554792128f * K;
+	float ax = std::abs(x), ay = std::abs(y);
+	float a, c, c2;
+	if (ax >= ay) {
+		c = ay / (ax + (float)DBL_EPSILON);
+		c2 = c * c;
+		a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+	} else {
+		c = ax / (ay + (float)DBL_EPSILON);
+		c2 = c * c;
+		a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+	}
+	if (x < 0) a = 180.f - a;
+	if (y < 0) a = 360.f - a;
+	return a;
+}
+
+// ---------------------------------------------------------------- E5 IC_Angle (cpp:221-248)
+static int g_umax[HALF_PATCH_SIZE + 1];
+static bool g_umax_init = false;
+static const int* umax_table() {
+	if (!g_umax_init) { orc_umax(g_umax); g_umax_init = true; }
+	return g_umax;
+}
+
+float orc_ic_angle(const uint8_t* img, int stride, float ptx, float pty) {
+	const int* u_max = umax_table();
+	int m_01 = 0, m_10 = 0;
+	const uint8_t* center = img + (ptrdiff_t)cvRoundf_(pty) * stride + cvRoundf_(ptx);
+	for (int u = -HALF_PATCH_SIZE; u <= HALF_PATCH_SIZE; ++u) m_10 += u * center[u];
+	for (int v = 1; v <= HALF_PATCH_SIZE; ++v) {
+		int v_sum = 0;
+		int d = u_max[v];
+		for (int u = -d; u <= d; ++u) {
+			int val_plus = center[u + v * stride], val_minus = center[u - v * stride];
+			v_sum += (val_plus - val_minus);
+			m_10 += u * (val_plus + val_minus);
+		}
+		m_01 += v * v_sum;
+	}
+	return orc_fastAtan2((float)m_01, (float)m_10);
+}
+
+// ---------------------------------------------------------------- omni camera model
+static inline double horner(const double* coeffs, int s, double x) {  // misc.h:115-122
+	double res = 0.0;
+	for (int i = s - 1; i >= 0; i--) res = res * x + coeffs[i];
+	return res;
+}
+
+void orc_world2img(const orc_ocam* cam, double x, double y, double z, double* u, double* v) {  // cam_model_omni.cpp:146-161
+	double norm = sqrt(x * x + y * y);
+	if (norm == 0.0) norm = 1e-14;
+	const double theta = atan(-z / norm);
+	const double rho = horner(cam->invP, cam->invP_deg, theta);
+	const double uu = x / norm * rho;
+	const double vv = y / norm * rho;
+	*u = uu * cam->c + vv * cam->d + cam->u0;
+	*v = uu * cam->e + vv + cam->v0;
+}
+
+void orc_img2world(const orc_ocam* cam, double u, double v, double* x_, double* y_, double* z_) {  // :49-67
+	const double invAffine = cam->c - cam->d * cam->e;  // cam_model_omni.h:102
+	const double u_t = u - cam->u0;
+	const double v_t = v - cam->v0;
+	double x = (u_t - cam->d * v_t) / invAffine;
+	double y = (-cam->e * u_t + cam->c * v_t) / invAffine;
+	const double X2 = x * x;
+	const double Y2 = y * y;
+	double z = -horner(cam->p, cam->p_deg, sqrt(X2 + Y2));
+	double norm = sqrt(X2 + Y2 + z * z);
+	*x_ = x / norm;
+	*y_ = y / norm;
+	*z_ = z / norm;
+}
+
+static inline void undistortPointsOcam(const orc_ocam* cam, double ptx, double pty, double scaleF, double* ox, double* oy) {
+	double x, y, z;  // cam_model_omni.h:127-138
+	orc_img2world(cam, ptx, pty, &x, &y, &z);
+	*ox = -x / z * scaleF;
+	*oy = -y / z * scaleF;
+}
+
+void orc_mirror_mask(const orc_ocam* cam, uint8_t* mask) {  // CreateMirrorMask level 0, cam_model_omni.cpp:163-220
+	int w = cam->width, h = cam->height;
+	float u0 = (float)cam->v0;  // sic: names swapped in the reference (:187-188)
+	float v0 = (float)cam->u0;
+	const float offset0 = 22.0f;
+	for (int i = 0; i < h; ++i)
+		for (int j = 0; j < w; ++j) {
+			float ans = sqrtf((float)pow(i - u0, 2) + (float)pow(j - v0, 2));
+			mask[(size_t)i * w + j] = (ans < (u0 + offset0)) ? 255 : 0;
+		}
+}
+
+// ---------------------------------------------------------------- E3/E4 oct-tree
+using std::ptrdiff_t;
+namespace {
+struct Pt2i { int x, y; };
+struct Node {
+	std::vector<orc_keypoint> vKeys;
+	Pt2i UL, UR, BL, BR;
+	std::list<Node>::iterator lit;
+	bool bNoMore = false;
+	long seq = 0;  // creation sequence (deterministic stand-in for the heap address, deviation (1))
+	void DivideNode(Node& n1, Node& n2, Node& n3, Node& n4) const {  // cpp:569-629
+		const int halfX = (int)ceil(static_cast<double>(UR.x - UL.x) / 2.0);
+		const int halfY = (int)ceil(static_cast<double>(BR.y - UL.y) / 2.0);
+		n1.UL = UL;
+		n1.UR = Pt2i{UL.x + halfX, UL.y};
+		n1.BL = Pt2i{UL.x, UL.y + halfY};
+		n1.BR = Pt2i{UL.x + halfX, UL.y + halfY};
+		n2.UL = n1.UR;
+		n2.UR = UR;
+		n2.BL = n1.BR;
+		n2.BR = Pt2i{UR.x, UL.y + halfY};
+		n3.UL = n1.BL;
+		n3.UR = n1.BR;
+		n3.BL = BL;
+		n3.BR = Pt2i{n1.BR.x, BL.y};
+		n4.UL = n3.UR;
+		n4.UR = n2.BR;
+		n4.BL = n3.BR;
+		n4.BR = BR;
+		for (size_t i = 0; i < vKeys.size(); i++) {
+			const orc_keypoint& kp = vKeys[i];
+			if (kp.x < n1.UR.x) {
+				if (kp.y < n1.BR.y) n1.vKeys.push_back(kp);
+				else n3.vKeys.push_back(kp);
+			} else if (kp.y < n1.BR.y)
+				n2.vKeys.push_back(kp);
+			else
+				n4.vKeys.push_back(kp);
+		}
+		if (n1.vKeys.size() == 1) n1.bNoMore = true;
+		if (n2.vKeys.size() == 1) n2.bNoMore = true;
+		if (n3.vKeys.size() == 1) n3.bNoMore = true;
+		if (n4.vKeys.size() == 1) n4.bNoMore = true;
+	}
+};
+typedef std::pair<std::pair<int, long>, Node*> SizeNode;  // ((size, seq), node)
+}  // namespace
+
+static std::vector<orc_keypoint> DistributeOctTree(const std::vector<orc_keypoint>& vToDistributeKeys, int minX, int maxX,
+                                                   int minY, int maxY, int N) {  // cpp:631-861
+	std::vector<orc_keypoint> vResultKeys;
+	const int nIni = cvRound_(static_cast<double>(maxX - minX) / (maxY - minY));
+	if (nIni < 1) return vResultKeys;  // reference divides by zero here; treat as "no keypoints"
+	const double hX = static_cast<double>(maxX - minX) / nIni;
+	std::list<Node> lNodes;
+	std::vector<Node*> vpIniNodes(nIni);
+	long seq = 0;
+	for (int i = 0; i < nIni; i++) {
+		Node ni;
+		ni.UL = Pt2i{(int)(hX * static_cast<double>(i)), 0};
+		ni.UR = Pt2i{(int)(hX * static_cast<double>(i + 1)), 0};
+		ni.BL = Pt2i{ni.UL.x, maxY - minY};
+		ni.BR = Pt2i{ni.UR.x, maxY - minY};
+		ni.seq = seq++;
+		lNodes.push_back(ni);
+		vpIniNodes[i] = &lNodes.back();
+	}
+	for (size_t i = 0; i < vToDistributeKeys.size(); i++) {
+		const orc_keypoint& kp = vToDistributeKeys[i];
+		size_t idx = (size_t)(kp.x / hX);
+		if (idx >= (size_t)nIni) idx = nIni - 1;  // cannot happen for x < maxX-minX; guards UB
+		vpIniNodes[idx]->vKeys.push_back(kp);
+	}
+	std::list<Node>::iterator lit = lNodes.begin();
+	while (lit != lNodes.end()) {
+		if (lit->vKeys.size() == 1) { lit->bNoMore = true; lit++; }
+		else if (lit->vKeys.empty()) lit = lNodes.erase(lit);
+		else lit++;
+	}
+	bool bFinish = false;
+	std::vector<SizeNode> vSizeAndPointerToNode;
+	auto push_child = [&](Node& n, bool countExpand, int& nToExpand) {
+		if (n.vKeys.size() > 0) {
+			n.seq = seq++;
+			lNodes.push_front(n);
+			lNodes.front().lit = lNodes.begin();
+			if (n.vKeys.size() > 1) {
+				if (countExpand) nToExpand++;
+				vSizeAndPointerToNode.push_back(std::make_pair(std::make_pair((int)n.vKeys.size(), lNodes.front().seq), &lNodes.front()));
+			}
+		}
+	};
+	while (!bFinish) {
+		int prevSize = (int)lNodes.size();
+		lit = lNodes.begin();
+		int nToExpand = 0;
+		vSizeAndPointerToNode.clear();
+		while (lit != lNodes.end()) {
+			if (lit->bNoMore) { lit++; continue; }
+			Node n1, n2, n3, n4;
+			lit->DivideNode(n1, n2, n3, n4);
+			push_child(n1, true, nToExpand);
+			push_child(n2, true, nToExpand);
+			push_child(n3, true, nToExpand);
+			push_child(n4, true, nToExpand);
+			lit = lNodes.erase(lit);
+		}
+		if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) {
+			bFinish = true;
+		} else if (((int)lNodes.size() + nToExpand * 3) > N) {
+			while (!bFinish) {
+				prevSize = (int)lNodes.size();
+				std::vector<SizeNode> vPrev = vSizeAndPointerToNode;
+				vSizeAndPointerToNode.clear();
+				std::sort(vPrev.begin(), vPrev.end(),
+				          [](const SizeNode& a, const SizeNode& b) { return a.first < b.first; });
+				for (int j = (int)vPrev.size() - 1; j >= 0; j--) {
+					Node n1, n2, n3, n4;
+					vPrev[j].second->DivideNode(n1, n2, n3, n4);
+					int dummy = 0;
+					push_child(n1, false, dummy);
+					push_child(n2, false, dummy);
+					push_child(n3, false, dummy);
+					push_child(n4, false, dummy);
+					lNodes.erase(vPrev[j].second->lit);
+					if ((int)lNodes.size() >= N) break;
+				}
+				if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) bFinish = true;
+			}
+		}
+	}
+	vResultKeys.reserve(lNodes.size());
+	for (std::list<Node>::iterator it = lNodes.begin(); it != lNodes.end(); it++) {
+		std::vector<orc_keypoint>& vNodeKeys = it->vKeys;
+		orc_keypoint* pKP = &vNodeKeys[0];
+		float maxResponse = pKP->response;
+		for (size_t k = 1; k < vNodeKeys.size(); k++) {
+			if (vNodeKeys[k].response > maxResponse) {
+				pKP = &vNodeKeys[k];
+				maxResponse = vNodeKeys[k].response;
+			}
+		}
+		vResultKeys.push_back(*pKP);
+	}
+	return vResultKeys;
+}
+
+int orc_distribute_octtree(const orc_keypoint* in, int n, int minX, int maxX, int minY, int maxY, int N, orc_keypoint* out,
+                           int cap) {
+	std::vector<orc_keypoint> v(in, in + n);
+	// root iterators are needed for phase-B erase of root nodes: set them
+	std::vector<orc_keypoint> r = DistributeOctTree(v, minX, maxX, minY, maxY, N);
+	int m = (int)r.size();
+	for (int i = 0; i < m && i < cap; ++i) out[i] = r[i];
+	return m;
+}
+
+// ---------------------------------------------------------------- extractor
+struct orc_extractor {
+	orc_params p;
+	std::vector<double> mvScaleFactor, mvInvScaleFactor;
+	std::vector<int> mnFeaturesPerLevel;
+	std::vector<int> pattern;  // x,y interleaved, 2*npoints ints
+	int npoints;
+	std::vector<Img> pyr, maskpyr, pyr_unblurred;
+	bool has_mask = false;
+	std::vector<std::vector<orc_keypoint> > candidates, selected;
+	std::vector<char> blurred;
+};
+
+orc_extractor* orc_extractor_create(const orc_params* p) {
+	if (p->nlevels < 1 || p->descSize < 1 || 2 * 2 * 8 * p->descSize > 2048) return nullptr;
+	if (p->useAgast || p->fastAgastType != 2) return nullptr;  // only FAST TYPE_9_16 (the shipped setting) is restated
+	orc_extractor* e = new orc_extractor;
+	e->p = *p;
+	scale_tables(p->scaleFactor, p->nlevels, e->mvScaleFactor, e->mvInvScaleFactor);
+	e->mnFeaturesPerLevel.resize(p->nlevels);
+	orc_features_per_level(p->nfeatures, p->scaleFactor, p->nlevels, e->mnFeaturesPerLevel.data());
+	e->npoints = 2 * 8 * p->descSize;
+	e->pattern.resize(2 * e->npoints);
+	orc_pattern(p->descSize, e->pattern.data());
+	return e;
+}
+void orc_extractor_destroy(orc_extractor* e) { delete e; }
+
+static void ComputePyramid(orc_extractor* e, const uint8_t* image, int W, int H, int stride, const uint8_t* mask, int mstride) {
+	int nl = e->p.nlevels;
+	e->pyr.assign(nl, Img());
+	e->maskpyr.assign(nl, Img());
+	e->has_mask = mask != nullptr;
+	for (int level = 0; level < nl; ++level) {
+		double scale = e->mvInvScaleFactor[level];
+		int sw = cvRound_((double)W * scale), sh = cvRound_((double)H * scale);
+		Img& L = e->pyr[level];
+		L.alloc(sw, sh, EDGE_THRESHOLD);
+		Img& M = e->maskpyr[level];
+		if (mask) M.alloc(sw, sh, EDGE_THRESHOLD);  // frame stays 0 = BORDER_CONSTANT
+		if (level != 0) {
+			const Img& P = e->pyr[level - 1];
+			orc_resize_linear(P.roi(), P.w, P.h, P.stride, L.roi(), sw, sh, L.stride);
+			if (mask) {
+				const Img& PM = e->maskpyr[level - 1];
+				orc_resize_nearest(PM.roi(), PM.w, PM.h, PM.stride, M.roi(), sw, sh, M.stride);
+			}
+		} else {
+			for (int y = 0; y < H; ++y) memcpy(L.roi() + (size_t)y * L.stride, image + (size_t)y * stride, W);
+			if (mask)
+				for (int y = 0; y < H; ++y) memcpy(M.roi() + (size_t)y * M.stride, mask + (size_t)y * mstride, W);
+		}
+		orc_border_reflect101(L.buf.data(), sw, sh, L.stride, EDGE_THRESHOLD);
+	}
+}
+
+static void ComputeKeyPointsOctTree(orc_extractor* e, std::vector<std::vector<orc_keypoint> >& allKeypoints) {  // cpp:863-976
+	int nl = e->p.nlevels;
+	allKeypoints.assign(nl, std::vector<orc_keypoint>());
+	e->candidates.assign(nl, std::vector<orc_keypoint>());
+	const double W = 30.0;
+	std::vector<orc_keypoint> cell(4096);
+	for (int level = 0; level < nl; ++level) {
+		Img& L = e->pyr[level];
+		Img& M = e->maskpyr[level];
+		const int minBorderX = EDGE_THRESHOLD - 3;
+		const int minBorderY = minBorderX;
+		const int maxBorderX = L.w - EDGE_THRESHOLD + 3;
+		const int maxBorderY = L.h - EDGE_THRESHOLD + 3;
+		std::vector<orc_keypoint> vToDistributeKeys;
+		const double width = (maxBorderX - minBorderX);
+		const double height = (maxBorderY - minBorderY);
+		const int nCols = (int)(width / W);
+		const int nRows = (int)(height / W);
+		if (nCols < 1 || nRows < 1) continue;  // reference would divide by zero; level too small -> no keypoints
+		const int wCell = (int)ceil(width / nCols);
+		const int hCell = (int)ceil(height / nRows);
+		for (int i = 0; i < nRows; i++) {
+			const double iniY = minBorderY + i * hCell;
+			double maxY = iniY + hCell + 6;
+			if (iniY >= maxBorderY - 3) continue;
+			if (maxY > maxBorderY) maxY = maxBorderY;
+			for (int j = 0; j < nCols; j++) {
+				const double iniX = minBorderX + j * wCell;
+				double maxX = iniX + wCell + 6;
+				if (iniX >= maxBorderX - 6) continue;
+				if (maxX > maxBorderX) maxX = maxBorderX;
+				int y0 = (int)iniY, y1 = (int)maxY, x0 = (int)iniX, x1 = (int)maxX;
+				const uint8_t* view = L.roi() + (ptrdiff_t)y0 * L.stride + x0;
+				const uint8_t* mview = e->has_mask ? M.roi() + (ptrdiff_t)y0 * M.stride + x0 : nullptr;
+				int n = orc_fast9_16(view, x1 - x0, y1 - y0, L.stride, mview, M.stride, e->p.fastThreshold, cell.data(),
+				                     (int)cell.size());
+				for (int k = 0; k < n; ++k) {
+					orc_keypoint kp = cell[k];
+					kp.x += j * wCell;
+					kp.y += i * hCell;
+					vToDistributeKeys.push_back(kp);
+				}
+			}
+		}
+		e->candidates[level] = vToDistributeKeys;
+		std::vector<orc_keypoint>& keypoints = allKeypoints[level];
+		keypoints = DistributeOctTree(vToDistributeKeys, minBorderX, maxBorderX, minBorderY, maxBorderY,
+		                              e->mnFeaturesPerLevel[level]);
+		const int scaledPatchSize = (int)(PATCH_SIZE * e->mvScaleFactor[level]);
+		for (size_t i = 0; i < keypoints.size(); ++i) {
+			keypoints[i].x += minBorderX;
+			keypoints[i].y += minBorderY;
+			keypoints[i].octave = level;
+			keypoints[i].size = (float)scaledPatchSize;
+		}
+	}
+	for (int level = 0; level < nl; ++level) {  // computeOrientation, cpp:557-566,974-975
+		Img& L = e->pyr[level];
+		for (auto& kp : allKeypoints[level]) kp.angle = orc_ic_angle(L.roi(), L.stride, kp.x, kp.y);
+	}
+}
+
+static inline uint8_t sample(const Img& L, int row, int col) {  // image.ptr<uchar>(row)[col] on the ROI; deviation (2): clamp
+	int r = row + L.border, c = col + L.border;
+	int bh = L.h + 2 * L.border, bw = L.w + 2 * L.border;
+	r = r < 0 ? 0 : (r >= bh ? bh - 1 : r);
+	c = c < 0 ? 0 : (c >= bw ? bw - 1 : c);
+	return L.buf[(size_t)r * L.stride + c];
+}
+
+static void rotatePattern(const int* pin, int npoints, int* pout, double ax, double ay) {  // cpp:285-301
+	for (int p = 0; p < npoints; ++p) {
+		pout[2 * p] = cvRound_(pin[2 * p] * ax - pin[2 * p + 1] * ay);
+		pout[2 * p + 1] = cvRound_(pin[2 * p] * ay + pin[2 * p + 1] * ax);
+	}
+}
+
+static void rotateAndDistortPattern(double ukx, double uky, const int* pin, int npoints, int* pout, const orc_ocam* cam, double ax,
+                                    double ay) {  // cpp:250-283
+	const double npointsd = static_cast<double>(npoints);
+	std::vector<double> xcoords(npoints), ycoords(npoints);
+	double sumX = 0.0, sumY = 0.0;
+	const double p1 = cam->p[0];
+	for (int p = 0; p < npoints; ++p) {
+		double xr = pin[2 * p] * ax - pin[2 * p + 1] * ay + ukx;
+		double yr = pin[2 * p] * ay + pin[2 * p + 1] * ax + uky;
+		orc_world2img(cam, xr, yr, -p1, &xcoords[p], &ycoords[p]);  // distortPointsOcam, cam_model_omni.h:140-145
+		sumX += xcoords[p];
+		sumY += ycoords[p];
+	}
+	double meanX = sumX / npointsd;
+	double meanY = sumY / npointsd;
+	for (int p = 0; p < npoints; ++p) {
+		pout[2 * p] = cvRound_(xcoords[p] - meanX);
+		pout[2 * p + 1] = cvRound_(ycoords[p] - meanY);
+	}
+}
+
+static void sample_bits(const Img& L, const orc_keypoint& kp, const int* pat, int descsize, uint8_t* out) {
+	int row = cvRoundf_(kp.y), col = cvRoundf_(kp.x);
+	for (int i = 0; i < descsize; ++i, pat += 32) {
+		int val = 0;
+		for (int b = 0; b < 8; ++b) {
+			int t0 = sample(L, row + pat[4 * b + 1], col + pat[4 * b]);
+			int t1 = sample(L, row + pat[4 * b + 3], col + pat[4 * b + 2]);
+			val |= (t0 < t1) << b;
+		}
+		out[i] = (uint8_t)val;
+	}
+}
+
+static void compute_ORB(const Img& L, const orc_keypoint& kp, const orc_extractor* e, uint8_t* desc) {  // cpp:303-354
+	std::vector<int> rot(2 * e->npoints);
+	double angle = static_cast<double>(kp.angle * DEG2RADf);
+	rotatePattern(e->pattern.data(), e->npoints, rot.data(), cos(angle), sin(angle));
+	sample_bits(L, kp, rot.data(), e->p.descSize, desc);
+}
+
+static void compute_dBRIEF(const Img& L, const orc_keypoint& kp, double ukx, double uky, const orc_extractor* e, const orc_ocam* cam,
+                           uint8_t* desc) {  // cpp:356-408
+	std::vector<int> rot(2 * e->npoints);
+	double angle = static_cast<double>(kp.angle * DEG2RADf);
+	rotateAndDistortPattern(ukx, uky, e->pattern.data(), e->npoints, rot.data(), cam, cos(angle), sin(angle));
+	sample_bits(L, kp, rot.data(), e->p.descSize, desc);
+}
+
+static void compute_mdBRIEF(const Img& L, const orc_keypoint& kp, double ukx, double uky, const orc_extractor* e,
+                            const orc_ocam* cam, uint8_t* desc, uint8_t* dmask) {  // cpp:410-554
+	int np = e->npoints, ds = e->p.descSize;
+	std::vector<int> pat(2 * np), m1(2 * np), m2(2 * np);
+	double rot = 20.0 / RHOd;
+	double angle = static_cast<double>(kp.angle / RHOf);
+	double angle1 = angle + rot;
+	double angle2 = angle - rot;
+	rotateAndDistortPattern(ukx, uky, e->pattern.data(), np, pat.data(), cam, cos(angle), sin(angle));
+	rotateAndDistortPattern(ukx, uky, e->pattern.data(), np, m1.data(), cam, cos(angle1), sin(angle1));
+	rotateAndDistortPattern(ukx, uky, e->pattern.data(), np, m2.data(), cam, cos(angle2), sin(angle2));
+	std::vector<uint8_t> d1(ds), d2(ds);
+	sample_bits(L, kp, pat.data(), ds, desc);
+	sample_bits(L, kp, m1.data(), ds, d1.data());
+	sample_bits(L, kp, m2.data(), ds, d2.data());
+	// mask bit = 1 iff both +-20deg tests equal the main test (stable_val == 0), cpp:468-475
+	for (int i = 0; i < ds; ++i) dmask[i] = (uint8_t) ~((desc[i] ^ d1[i]) | (desc[i] ^ d2[i]));
+}
+
+int orc_extract(orc_extractor* e, const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride,
+                const orc_ocam* cam, orc_keypoint* kps, int cap, uint8_t* desc, uint8_t* dmask) {  // operator(), cpp:1244-1337
+	if (!img || w <= 0 || h <= 0) return 0;
+	ComputePyramid(e, img, w, h, stride, mask, mstride);
+	e->pyr_unblurred = e->pyr;
+	std::vector<std::vector<orc_keypoint> > allKeypoints;
+	ComputeKeyPointsOctTree(e, allKeypoints);
+	e->selected = allKeypoints;
+	int nl = e->p.nlevels, ds = e->p.descSize;
+	int nkeypoints = 0;
+	for (int level = 0; level < nl; ++level) nkeypoints += (int)allKeypoints[level].size();
+	if (nkeypoints > cap) return -2;
+	int offset = 0;
+	const double scaleF = cam ? cam->p[0] : 0.0;  // camModel.Get_P().at<double>(0), :1288
+	e->blurred.assign(nl, 0);
+	for (int level = 0; level < nl; ++level) {
+		std::vector<orc_keypoint>& keypoints = allKeypoints[level];
+		int n = (int)keypoints.size();
+		if (n == 0) continue;
+		Img& L = e->pyr[level];
+		orc_box5_inplace(L.roi(), L.w, L.h, L.stride);  // :1301
+		e->blurred[level] = 1;
+		std::vector<double> und(2 * n, 0.0);
+		float scale = (float)e->mvScaleFactor[level];
+		if (e->p.do_dBrief) {
+			for (int i = 0; i < n; ++i)
+				undistortPointsOcam(cam, static_cast<double>(keypoints[i].x * scale), static_cast<double>(keypoints[i].y * scale), scaleF,
+				                    &und[2 * i], &und[2 * i + 1]);
+		}
+		uint8_t* D = desc + (size_t)offset * ds;
+		uint8_t* DM = dmask + (size_t)offset * ds;
+		memset(D, 0, (size_t)n * ds);   // computeDescriptors zero-fills both (:1215-1216)
+		memset(DM, 0, (size_t)n * ds);
+		for (int i = 0; i < n; ++i) {
+			if (e->p.learnMasks) compute_mdBRIEF(L, keypoints[i], und[2 * i], und[2 * i + 1], e, cam, D + (size_t)i * ds, DM + (size_t)i * ds);
+			else if (e->p.do_dBrief) compute_dBRIEF(L, keypoints[i], und[2 * i], und[2 * i + 1], e, cam, D + (size_t)i * ds);
+			else compute_ORB(L, keypoints[i], e, D + (size_t)i * ds);
+		}
+		if (level != 0)
+			for (auto& kp : keypoints) { kp.x *= scale; kp.y *= scale; }
+		for (int i = 0; i < n; ++i) kps[offset + i] = keypoints[i];
+		offset += n;
+	}
+	return nkeypoints;
+}
+
+int orc_tap_level_size(orc_extractor* e, int level, int* w, int* h) {
+	if (level < 0 || level >= (int)e->pyr.size()) return -1;
+	*w = e->pyr[level].w; *h = e->pyr[level].h;
+	return 0;
+}
+int orc_tap_level_image(orc_extractor* e, int level, int blurred, uint8_t* out) {
+	if (level < 0 || level >= (int)e->pyr.size()) return -1;
+	const Img& L = blurred ? e->pyr[level] : e->pyr_unblurred[level];
+	for (int y = 0; y < L.h; ++y) memcpy(out + (size_t)y * L.w, L.roi() + (size_t)y * L.stride, L.w);
+	return blurred ? (int)e->blurred[level] : 1;
+}
+int orc_tap_level_mask(orc_extractor* e, int level, uint8_t* out) {
+	if (level < 0 || level >= (int)e->maskpyr.size() || !e->has_mask) return -1;
+	const Img& L = e->maskpyr[level];
+	for (int y = 0; y < L.h; ++y) memcpy(out + (size_t)y * L.w, L.roi() + (size_t)y * L.stride, L.w);
+	return 0;
+}
+int orc_tap_candidates(orc_extractor* e, int level, orc_keypoint* out, int cap) {
+	if (level < 0 || level >= (int)e->candidates.size()) return -1;
+	int n = (int)e->candidates[level].size();
+	for (int i = 0; i < n && i < cap; ++i) out[i] = e->candidates[level][i];
+	return n;
+}
+int orc_tap_selected(orc_extractor* e, int level, orc_keypoint* out, int cap) {
+	if (level < 0 || level >= (int)e->selected.size()) return -1;
+	int n = (int)e->selected[level].size();
+	for (int i = 0; i < n && i < cap; ++i) out[i] = e->selected[level][i];
+	return n;
+}
+
+void orc_rays(const orc_ocam* cam, const orc_keypoint* kps, int n, double* rays) {  // cMultiFrame.cpp:146-152
+	for (int i = 0; i < n; ++i)
+		orc_img2world(cam, static_cast<double>(kps[i].x), static_cast<double>(kps[i].y), &rays[3 * i], &rays[3 * i + 1], &rays[3 * i + 2]);
+}
+
+int orc_pos_in_grid(const orc_ocam* cam, float x, float y, int* gx, int* gy) {  // cMultiFrame.cpp:342-353 (64x48 grid)
+	const int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64;
+	double wInv = static_cast<double>(FRAME_GRID_COLS) / static_cast<double>(cam->width - 0);
+	double hInv = static_cast<double>(FRAME_GRID_ROWS) / static_cast<double>(cam->height - 0);
+	*gx = cvRound_((x - 0) * wInv);
+	*gy = cvRound_((y - 0) * hInv);
+	if (*gx < 0 || *gx >= FRAME_GRID_COLS || *gy < 0 || *gy >= FRAME_GRID_ROWS) return 0;
+	return 1;
+}
+
+// ---------------------------------------------------------------- matcher
+int orc_dist64(const uint64_t* a, const uint64_t* b, int dim) {  // cORBmatcher.cpp:2438-2450
+	uint64_t dist = 0;
+	for (int d = 0; d < dim / 8; ++d) dist += __builtin_popcountll(a[d] ^ b[d]);
+	return static_cast<int>(dist);
+}
+
+int orc_dist64_masked(const uint64_t* a, const uint64_t* b, const uint64_t* ma, const uint64_t* mb, int dim) {  // :2452-2474
+	uint64_t dist = 0;
+	for (int i = 0; i < dim / 8; ++i) {
+		uint64_t axorb = a[i] ^ b[i];
+		dist += __builtin_popcountll(axorb & ma[i]);
+		dist += __builtin_popcountll(axorb & mb[i]);
+	}
+	return static_cast<int>(dist / 2);
+}
+
+void orc_thresholds(int featDim, int havingMasks, int* th_high, int* th_low) {  // :46-65
+	if (havingMasks) { *th_high = (int)floor(1.5 * featDim); *th_low = (int)floor((double)featDim); }
+	else { *th_high = 3 * featDim; *th_low = 2 * featDim; }
+}
+
+static inline int dist_any(const uint8_t* d1, const uint8_t* m1, int i, const uint8_t* d2, const uint8_t* m2, int j, int dim, int masks) {
+	const uint64_t* a = (const uint64_t*)(d1 + (size_t)i * dim);
+	const uint64_t* b = (const uint64_t*)(d2 + (size_t)j * dim);
+	if (masks) return orc_dist64_masked(a, b, (const uint64_t*)(m1 + (size_t)i * dim), (const uint64_t*)(m2 + (size_t)j * dim), dim);
+	return orc_dist64(a, b, dim);
+}
+
+int orc_search_kf_kf(const uint8_t* d1, const uint8_t* m1, const uint8_t* valid1, int n1, const uint8_t* d2, const uint8_t* m2,
+                     const uint8_t* valid2, int n2, int dim, int havingMasks, double nnratio, int* match12) {  // :885-966
+	int TH_HIGH, TH_LOW;
+	orc_thresholds(dim, havingMasks, &TH_HIGH, &TH_LOW);
+	std::vector<char> vbMatched2(n2, 0);
+	int nmatches = 0;
+	for (int idx1 = 0; idx1 < n1; ++idx1) {
+		match12[idx1] = -1;
+		if (!valid1[idx1]) continue;
+		int bestDist1 = INT_MAX, bestIdx2 = -1, bestDist2 = INT_MAX;
+		for (int idx2 = 0; idx2 < n2; ++idx2) {
+			if (vbMatched2[idx2] || !valid2[idx2]) continue;
+			int dist = dist_any(d1, m1, idx1, d2, m2, idx2, dim, havingMasks);
+			if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+			else if (dist < bestDist2) bestDist2 = dist;
+		}
+		if (bestDist1 < TH_LOW) {
+			if (static_cast<double>(bestDist1) < nnratio * static_cast<double>(bestDist2)) {
+				match12[idx1] = bestIdx2;
+				vbMatched2[bestIdx2] = 1;
+				++nmatches;
+			}
+		}
+	}
+	return nmatches;
+}
+
+int orc_search_kf_f(const uint8_t* dKF, const uint8_t* mKF, const uint8_t* validKF, int nKF, const uint8_t* dF, const uint8_t* mF,
+                    int nF, int dim, int havingMasks, double nnratio, int* matchF) {  // :179-323 without the BoW-node restriction
+	int TH_HIGH, TH_LOW;
+	orc_thresholds(dim, havingMasks, &TH_HIGH, &TH_LOW);
+	for (int j = 0; j < nF; ++j) matchF[j] = -1;
+	int nmatches = 0;
+	for (int iKF = 0; iKF < nKF; ++iKF) {
+		if (!validKF[iKF]) continue;
+		int bestDist1 = INT_MAX, bestIdxF = -1, bestDist2 = INT_MAX;
+		for (int iF = 0; iF < nF; ++iF) {
+			if (matchF[iF] >= 0) continue;
+			int dist = dist_any(dKF, mKF, iKF, dF, mF, iF, dim, havingMasks);
+			if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = iF; }
+			else if (dist < bestDist2) bestDist2 = dist;
+		}
+		if (bestDist1 <= TH_LOW) {
+			if (static_cast<double>(bestDist1) < nnratio * static_cast<double>(bestDist2)) {
+				matchF[bestIdxF] = iKF;
+				++nmatches;
+			}
+		}
+	}
+	return nmatches;
+}
+
+int orc_check_epipolar(const double* ray1, const double* ray2, const double* E, double thresh) {  // misc.cpp:53-69
+	double t[3];
+	for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += ray2[k] * E[3 * k + j]; t[j] = s; }
+	double nom = 0;
+	for (int k = 0; k < 3; ++k) nom += t[k] * ray1[k];
+	double Ex1[3], Etx2[3];
+	for (int i = 0; i < 3; ++i) { double s = 0; for (int k = 0; k < 3; ++k) s += E[3 * i + k] * ray1[k]; Ex1[i] = s; }
+	for (int i = 0; i < 3; ++i) { double s = 0; for (int k = 0; k < 3; ++k) s += E[3 * k + i] * ray2[k]; Etx2[i] = s; }
+	const double den = Ex1[0] * Ex1[0] + Ex1[1] * Ex1[1] + Ex1[2] * Ex1[2] + Etx2[0] * Etx2[0] + Etx2[1] * Etx2[1] + Etx2[2] * Etx2[2];
+	if (den == 0.0) return 0;
+	const double dsqr = (nom * nom) / den;
+	return dsqr < thresh;
+}
+
+int orc_search_triangulation(const uint8_t* d1, const uint8_t* m1, const uint8_t* hasMP1, const int* cam1, const double* rays1, int n1,
+                             const uint8_t* d2, const uint8_t* m2, const uint8_t* hasMP2, const int* cam2, const double* rays2, int n2,
+                             const double* E, int nrCams, int dim, int havingMasks, int* match12) {  // :968-1155 (mbCheckOrientation=false)
+	int TH_HIGH, TH_LOW;
+	orc_thresholds(dim, havingMasks, &TH_HIGH, &TH_LOW);
+	std::vector<char> vbMatched2(n2, 0);
+	int nmatches = 0;
+	for (int idx1 = 0; idx1 < n1; ++idx1) {
+		match12[idx1] = -1;
+		if (hasMP1[idx1]) continue;
+		int camIdx1 = cam1[idx1];
+		std::vector<std::pair<int, size_t> > vDistIndex;
+		for (int idx2 = 0; idx2 < n2; ++idx2) {
+			if (vbMatched2[idx2] || hasMP2[idx2]) continue;
+			if (camIdx1 != cam2[idx2]) continue;
+			int dist = dist_any(d1, m1, idx1, d2, m2, idx2, dim, havingMasks);
+			if (dist > TH_LOW) continue;
+			vDistIndex.push_back(std::make_pair(dist, (size_t)idx2));
+		}
+		if (vDistIndex.empty()) continue;
+		std::sort(vDistIndex.begin(), vDistIndex.end());
+		int BestDist = vDistIndex.front().first;
+		int DistTh = cvRound_(2 * BestDist);
+		for (size_t id = 0; id < vDistIndex.size(); ++id) {
+			if (vDistIndex[id].first > DistTh) break;
+			int currentIdx2 = (int)vDistIndex[id].second;
+			int camIdx2 = cam2[currentIdx2];
+			if (orc_check_epipolar(rays1 + 3 * idx1, rays2 + 3 * currentIdx2, E + 9 * ((size_t)camIdx1 * nrCams + camIdx2), 1e-2)) {
+				vbMatched2[currentIdx2] = 1;
+				match12[idx1] = currentIdx2;
+				nmatches++;
+				break;
+			}
+		}
+	}
+	return nmatches;
+}
+
+// ---------------------------------------------------------------- CPU baseline helper
+int orc_num_threads(void) {
+#ifdef _OPENMP
+	return omp_get_max_threads();
+#else
+	return 1;
+#endif
+}
+
+long orc_extract_many(const orc_params* p, int nimg, const uint8_t* const* imgs, int w, int h, int stride,
+                      const uint8_t* const* masks, const orc_ocam* cams, int threads, orc_keypoint* kps, int cap, int* nkp,
+                      uint8_t* desc, uint8_t* dmask) {
+	long total = 0;
+	if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads) reduction(+ : total)
+	{
+		orc_extractor* e = orc_extractor_create(p);  // one stateful extractor per thread, like one per camera in cMultiFrame.cpp:128-139
+#pragma omp for schedule(dynamic, 1)
+		for (int i = 0; i < nimg; ++i) {
+			int n = orc_extract(e, imgs[i], w, h, stride, masks ? masks[i] : nullptr, w, &cams[i], kps + (size_t)i * cap, cap,
+			                    desc + (size_t)i * cap * p->descSize, dmask + (size_t)i * cap * p->descSize);
+			nkp[i] = n;
+			if (n > 0) total += n;
+		}
+		orc_extractor_destroy(e);
+	}
+	return total;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+/*
+ * mcs_oracle.h — C interface of the CPU ORACLE.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This library is a plain CPU restatement of the reference algorithm
+ * (urbste/MultiCol-SLAM feature front end + brute-force matcher).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and only as the checker /
+ * the timed CPU baseline.  The product (libmcs_hip.so and the host facade) never links or loads it.
+ *
+ * PARITY UNPINNED: the reference ships no tests / golden vectors for this path and cannot be built
+ * here (needs OpenCV >= 3.0 + Pangolin, both absent).  The OpenCV 3.x primitives it calls
+ * (resize, copyMakeBorder, FAST, boxFilter, fastAtan2) are restated from their published generic
+ * C++ algorithm.  Known-answer tests derived by hand from the reference
+ * source pin the restatement (tests/test_oracle_kat.py).
+ */
+#ifndef MCS_ORACLE_H
+#define MCS_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y, size, angle, response; int octave, class_id; } orc_keypoint; /* cv::KeyPoint, 28 B */
+
+typedef struct {
+	double c, d, e, u0, v0;
+	double p[16];    int p_deg;      /* forward poly  (cam_model_omni.h: p)    */
+	double invP[16]; int invP_deg;   /* backward poly (cam_model_omni.h: invP) */
+	int width, height;
+} orc_ocam;
+
+typedef struct {       /* the 13 ctor arguments, include/mdBRIEFextractorOct.h:339-351 */
+	int nfeatures; float scaleFactor; int nlevels; int edgeThreshold; int firstLevel; int scoreType;
+	int patchSize; int fastThreshold; int useAgast; int fastAgastType; int do_dBrief; int learnMasks;
+	int descSize;
+} orc_params;
+
+/* ---- E0 tables ---- */
+void orc_features_per_level(int nfeatures, float scaleFactor, int nlevels, int* out);
+void orc_umax(int* out17);
+void orc_level_sizes(int W, int H, float scaleFactor, int nlevels, int* w, int* h);
+int  orc_pattern(int descSize, int* xy /* 2*16*descSize ints */);
+
+/* ---- OpenCV primitive restatements (Appendix A) ---- */
+void  orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride);
+void  orc_resize_nearest(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride);
+void  orc_border_reflect101(uint8_t* buf, int w, int h, int stride, int border); /* fills the frame of a (w+2b)x(h+2b) buffer */
+int   orc_fast9_16(const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride,
+                   int threshold, orc_keypoint* out, int cap);
+int   orc_fast_score(const uint8_t* center, int stride, int threshold);
+void  orc_box5_inplace(uint8_t* roi, int w, int h, int stride); /* roi sits inside a >=2px frame */
+float orc_fastAtan2(float y, float x);
+int   orc_cvRound(double v);
+float orc_ic_angle(const uint8_t* img, int stride, float ptx, float pty);
+
+/* ---- omni camera model (src/cam_model_omni.cpp) ---- */
+void orc_world2img(const orc_ocam* cam, double x, double y, double z, double* u, double* v);
+void orc_img2world(const orc_ocam* cam, double u, double v, double* x, double* y, double* z);
+void orc_mirror_mask(const orc_ocam* cam, uint8_t* mask /* h*w */);
+
+/* ---- oct-tree (E3/E4) ---- */
+int orc_distribute_octtree(const orc_keypoint* in, int n, int minX, int maxX, int minY, int maxY, int N,
+                           orc_keypoint* out, int cap);
+
+/* ---- extractor (E1..E8) ---- */
+typedef struct orc_extractor orc_extractor;
+orc_extractor* orc_extractor_create(const orc_params* p);
+void orc_extractor_destroy(orc_extractor*);
+/* returns number of keypoints (<= cap) or <0 on error; desc/dmask are nkp x descSize */
+int  orc_extract(orc_extractor*, const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride,
+                 const orc_ocam* cam, orc_keypoint* kps, int cap, uint8_t* desc, uint8_t* dmask);
+/* stage taps of the LAST orc_extract call (for stage-level parity tests) */
+int  orc_tap_level_size(orc_extractor*, int level, int* w, int* h);
+int  orc_tap_level_image(orc_extractor*, int level, int blurred, uint8_t* out /* w*h tight */);
+int  orc_tap_level_mask(orc_extractor*, int level, uint8_t* out);
+int  orc_tap_candidates(orc_extractor*, int level, orc_keypoint* out, int cap); /* pre oct-tree, border-relative */
+int  orc_tap_selected(orc_extractor*, int level, orc_keypoint* out, int cap);   /* post oct-tree+orientation, level coords */
+/* E9: rays + grid */
+void orc_rays(const orc_ocam* cam, const orc_keypoint* kps, int n, double* rays /* 3n */);
+int  orc_pos_in_grid(const orc_ocam* cam, float x, float y, int* gx, int* gy);
+
+/* ---- matcher (M1..M5) ---- */
+int orc_dist64(const uint64_t* a, const uint64_t* b, int dim);
+int orc_dist64_masked(const uint64_t* a, const uint64_t* b, const uint64_t* ma, const uint64_t* mb, int dim);
+void orc_thresholds(int featDim, int havingMasks, int* th_high, int* th_low);
+/* M4: SearchByBoW(KF,KF).  valid1/valid2: 1 = "has good map point".  match12[i] = idx2 or -1. returns nmatches */
+int orc_search_kf_kf(const uint8_t* d1, const uint8_t* m1, const uint8_t* valid1, int n1,
+                     const uint8_t* d2, const uint8_t* m2, const uint8_t* valid2, int n2,
+                     int dim, int havingMasks, double nnratio, int* match12);
+/* M4': SearchByBoW(KF,F) with the BoW restriction removed.  matchF[j] = idxKF or -1 (indexed by FRAME feature) */
+int orc_search_kf_f(const uint8_t* dKF, const uint8_t* mKF, const uint8_t* validKF, int nKF,
+                    const uint8_t* dF, const uint8_t* mF, int nF,
+                    int dim, int havingMasks, double nnratio, int* matchF);
+/* M5: SearchForTriangulationRaw. hasMP: 1 = already has a map point (skipped). E: nrCams*nrCams 3x3 row-major */
+int orc_search_triangulation(const uint8_t* d1, const uint8_t* m1, const uint8_t* hasMP1, const int* cam1, const double* rays1, int n1,
+                             const uint8_t* d2, const uint8_t* m2, const uint8_t* hasMP2, const int* cam2, const double* rays2, int n2,
+                             const double* E, int nrCams, int dim, int havingMasks, int* match12);
+int orc_check_epipolar(const double* ray1, const double* ray2, const double* E12, double thresh);
+
+/* ---- timed CPU baseline helper: extract nimg images (OpenMP over images), returns total keypoints ---- */
+long orc_extract_many(const orc_params* p, int nimg, const uint8_t* const* imgs, int w, int h, int stride,
+                      const uint8_t* const* masks, const orc_ocam* cams, int threads,
+                      orc_keypoint* kps, int cap, int* nkp, uint8_t* desc, uint8_t* dmask);
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
