@@ -1,0 +1,130 @@
+/*
+ * mcs_c.h — C ABI of libmcs_hip.so: the MI355X (gfx950) feature front end + brute-force Hamming matcher
+ * of MultiCol-SLAM.  This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ *
+ * The reference has no FFI for this path; its boundary is three C++ class surfaces.  Each entry point below
+ * names the reference interface it replaces (file:line relative to the reference tree):
+ *
+ *   mcs_extractor_create / _destroy    mdBRIEFextractorOct::mdBRIEFextractorOct   include/mdBRIEFextractorOct.h:339-351, src/mdBRIEFextractorOct.cpp:134-203
+ *   mcs_extract_batch                  mdBRIEFextractorOct::operator()            include/mdBRIEFextractorOct.h:355-361, src/mdBRIEFextractorOct.cpp:1244-1337
+ *                                      (+ rays: the per-camera loop body of cMultiFrame::cMultiFrame, src/cMultiFrame.cpp:128-152)
+ *   mcs_match_topk                     inner loops of cORBmatcher::SearchByBoW(KF,KF) src/cORBmatcher.cpp:885-966,
+ *                                      SearchByBoW(KF,F) :179-323, SearchForTriangulationRaw :968-1155
+ *   mcs_descriptor_distance[_masked]   DescriptorDistance64[_Masked]             src/cORBmatcher.cpp:2438-2474
+ *
+ * The C++ facade with the reference's class names (headers under include/mcs/, namespace MultiColSLAM) sits on top.
+ * Every function returns MCS_OK (0) or a negative error code, never throws, and the caller owns every buffer.
+ * A handle must be used from one host thread at a time (the reference runs one extractor instance per camera
+ * thread, src/cMultiFrame.cpp:128-139).  There is NO CPU fallback: without a usable HIP device every call fails.
+ */
+#ifndef MCS_C_H
+#define MCS_C_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCS_OK 0
+#define MCS_ERR_INVALID (-1)   /* bad argument */
+#define MCS_ERR_HIP (-2)       /* HIP runtime error (mcs_last_error() has the text) */
+#define MCS_ERR_CAPACITY (-3)  /* an output / internal capacity was exceeded */
+#define MCS_ERR_UNSUPPORTED (-4)
+
+#define MCS_MAX_POLY 16
+#define MCS_MAX_LEVELS 16
+
+typedef struct mcs_ctx mcs_ctx;
+typedef struct mcs_extractor mcs_extractor;
+
+/* cv::KeyPoint layout (28 bytes): pt.x pt.y size angle response octave class_id */
+typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } mcs_keypoint;
+
+/* cCamModelGeneral_ (include/cam_model_omni.h:60-110): affine c,d,e, principal point, forward / backward polynomials */
+typedef struct {
+	double c, d, e, u0, v0;
+	double p[MCS_MAX_POLY];    int32_t p_deg;     /* number of forward coefficients (Lafida: 5)  */
+	double invP[MCS_MAX_POLY]; int32_t invP_deg;  /* number of backward coefficients (Lafida: 12) */
+	int32_t width, height;
+} mcs_ocam;
+
+/* the 13 constructor arguments of mdBRIEFextractorOct, same order and meaning (h:339-351) */
+typedef struct {
+	int32_t nfeatures; float scaleFactor; int32_t nlevels; int32_t edgeThreshold; int32_t firstLevel; int32_t scoreType;
+	int32_t patchSize; int32_t fastThreshold; int32_t useAgast; int32_t fastAgastType; int32_t do_dBrief; int32_t learnMasks;
+	int32_t descSize;
+} mcs_extractor_params;
+
+typedef enum { MCS_MEM_HOST = 0, MCS_MEM_DEVICE = 1 } mcs_mem_kind;
+
+const char* mcs_last_error(void);              /* thread-local text of the last failure */
+int mcs_device_count(int* n);
+
+/* One context per (process, GPU).  stream: a hipStream_t to run on (NULL = the context creates its own). */
+int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out);
+int mcs_ctx_destroy(mcs_ctx*);
+int mcs_ctx_synchronize(mcs_ctx*);
+
+/* ------------------------------------------------------------------ extractor
+ * An extractor is built for one image size and a maximum batch (images per launch).  It owns the device pyramid,
+ * candidate and keypoint buffers (sized once; nothing is allocated per call).                                         */
+int mcs_extractor_create(mcs_ctx*, const mcs_extractor_params*, int width, int height, int max_batch, mcs_extractor** out);
+int mcs_extractor_destroy(mcs_extractor*);
+int mcs_extractor_kp_capacity(const mcs_extractor*, int* cap);  /* rows per image in the outputs: nfeatures + 3*nlevels */
+int mcs_extractor_levels(const mcs_extractor*, int* nlevels, int* widths, int* heights, int* features_per_level);
+
+/* Run mdBRIEFextractorOct::operator() on nimg images at once.
+ *   images   nimg rows of `image_stride` bytes each ... image i starts at images + i*image_pitch (w x h, 8UC1)
+ *   masks    same layout (mirror mask level 0; 0 = reject) or NULL for "no mask"
+ *   cams     nimg camera models (needed for dBRIEF/mdBRIEF and rays; may be NULL in ORB mode when rays == NULL)
+ *   kind     where images/masks AND all outputs live (host pointers, or device pointers on the context's GPU)
+ * outputs (row i*cap + k is keypoint k of image i, cap = mcs_extractor_kp_capacity):
+ *   nkp[nimg]  keypoints[nimg*cap]  desc[nimg*cap*descSize]  descmask[nimg*cap*descSize] (zeros unless learnMasks)
+ *   rays[nimg*cap*3] (ImgToWorld of every keypoint, optional)
+ * With kind == DEVICE the call only enqueues work on the context's stream (no host synchronisation).              */
+int mcs_extract_batch(mcs_extractor*, int nimg, const uint8_t* images, size_t image_pitch, int image_stride,
+                      const uint8_t* masks, size_t mask_pitch, int mask_stride, const mcs_ocam* cams, mcs_mem_kind kind,
+                      int32_t* nkp, mcs_keypoint* keypoints, uint8_t* desc, uint8_t* descmask, double* rays);
+
+/* synchronise and report a device-side capacity overflow of earlier DEVICE-kind batches (MCS_OK if none) */
+int mcs_extractor_status(mcs_extractor*);
+
+/* stage taps for stage-level parity tests (device -> host copies of the LAST batch; synchronises) */
+int mcs_extractor_tap_level(mcs_extractor*, int img, int level, int blurred, uint8_t* out /* w*h tight */);
+int mcs_extractor_tap_candidates(mcs_extractor*, int img, int level, uint32_t* out /* x | y<<12 | score<<24, border-relative */, int cap, int* n);
+int mcs_extractor_tap_selected(mcs_extractor*, int img, int level, uint32_t* out, int cap, int* n);
+
+/* ------------------------------------------------------------------ brute-force Hamming matcher
+ * For every query row the K nearest train rows by (distance, train index) among the train rows that are
+ *   valid (t_valid[j] != 0, NULL = all) and, if q_group/t_group are given, have t_group[j] == q_group[i]
+ *   (SearchForTriangulationRaw's same-camera rule, cORBmatcher.cpp:1047).
+ * Queries with q_valid[i] == 0 get count 0.  Distances are DescriptorDistance64 (masks NULL) or
+ * DescriptorDistance64Masked.  out_dist/out_idx are [nq*K] (unused tail: dist = INT32_MAX, idx = -1);
+ * out_count_le[i] = number of eligible train rows with distance <= count_thresh (to detect K overflow).
+ * dim = descriptor bytes (16/32/64).  The greedy, order-dependent part of the reference's searches is host logic
+ * in the facade (include/mcs/cORBmatcher.hpp) on top of these lists.                                                */
+typedef struct {
+	const uint8_t* desc; const uint8_t* mask; const uint8_t* valid; const int32_t* group; int32_t n; int32_t stride;
+} mcs_desc_set;
+int mcs_match_topk(mcs_ctx*, const mcs_desc_set* q, const mcs_desc_set* t, int dim, int K, int count_thresh, mcs_mem_kind kind,
+                   int32_t* out_dist, int32_t* out_idx, int32_t* out_count_le);
+
+/* batched form: nsets independent (query set, train set) pairs of identical shape laid out back to back
+ * (set s starts at base + s*set_pitch rows).  One launch for a whole keyframe database sweep.                  */
+int mcs_match_topk_batched(mcs_ctx*, int nsets, const mcs_desc_set* q, size_t q_set_pitch_rows, const mcs_desc_set* t,
+                           size_t t_set_pitch_rows, int dim, int K, int count_thresh, mcs_mem_kind kind, int32_t* out_dist,
+                           int32_t* out_idx, int32_t* out_count_le);
+
+/* single-pair distances on the device (known-answer / spot checks) */
+int mcs_descriptor_distance(mcs_ctx*, const uint8_t* a, const uint8_t* b, int dim, int* out);
+int mcs_descriptor_distance_masked(mcs_ctx*, const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out);
+
+/* per-kernel device timing of the last mcs_extract_batch / mcs_match_* call on this context, measured with HIP
+ * events on the context's stream when enabled (bench.py's roofline leg).  names: "pyramid","fast","octree","blur","describe","match" */
+int mcs_ctx_enable_timing(mcs_ctx*, int on);
+int mcs_ctx_kernel_ms(mcs_ctx*, const char* name, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

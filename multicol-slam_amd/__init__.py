@@ -1,0 +1,161 @@
+"""multicol-slam_amd — MI355X-native feature front end + brute-force Hamming matcher of MultiCol-SLAM.
+
+Python host side over the C ABI of libmcs_hip.so (hand-written HIP for gfx950).  The class names mirror the
+reference's C++ surface (mdBRIEFextractorOct / ORBextractor, cMultiFrame's extraction part, cORBmatcher); see
+frontend.py.  Import with importlib.import_module("multicol-slam_amd") (the directory name carries a hyphen).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import (KP_DTYPE, MEM_DEVICE, MEM_HOST, DescSet, ExtractorParams, McsError, Ocam, check, lib, make_ocam, np_ptr)
+
+__all__ = ["Context", "Extractor", "McsError", "KP_DTYPE", "make_ocam", "ExtractorParams", "MEM_HOST", "MEM_DEVICE"]
+
+
+class Context:
+    """One per (process, GPU).  stream: raw hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        check(lib().mcs_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.h)))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mcs_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(lib().mcs_ctx_synchronize(self.h))
+
+    def enable_timing(self, on=True):
+        check(lib().mcs_ctx_enable_timing(self.h, int(on)))
+
+    def kernel_ms(self, name):
+        ms = C.c_float()
+        check(lib().mcs_ctx_kernel_ms(self.h, name.encode(), C.byref(ms)))
+        return ms.value
+
+    # ---- matcher primitives (host numpy arrays)
+    def match_topk(self, qd, td, K, count_thresh, qm=None, tm=None, qvalid=None, tvalid=None, qgroup=None, tgroup=None):
+        qd = np.ascontiguousarray(qd, np.uint8)
+        td = np.ascontiguousarray(td, np.uint8)
+        nq, dim = qd.shape
+        q = DescSet(np_ptr(qd), np_ptr(qm), np_ptr(qvalid), np_ptr(qgroup), nq, dim)
+        t = DescSet(np_ptr(td), np_ptr(tm), np_ptr(tvalid), np_ptr(tgroup), td.shape[0], dim)
+        dist = np.zeros((nq, K), np.int32)
+        idx = np.zeros((nq, K), np.int32)
+        cnt = np.zeros(nq, np.int32)
+        check(lib().mcs_match_topk(self.h, C.byref(q), C.byref(t), dim, K, count_thresh, MEM_HOST, np_ptr(dist), np_ptr(idx), np_ptr(cnt)))
+        return dist, idx, cnt
+
+    def descriptor_distance(self, a, b, ma=None, mb=None):
+        out = C.c_int32()
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        if ma is None:
+            check(lib().mcs_descriptor_distance(self.h, np_ptr(a), np_ptr(b), a.size, C.byref(out)))
+        else:
+            ma = np.ascontiguousarray(ma, np.uint8)
+            mb = np.ascontiguousarray(mb, np.uint8)
+            check(lib().mcs_descriptor_distance_masked(self.h, np_ptr(a), np_ptr(b), np_ptr(ma), np_ptr(mb), a.size, C.byref(out)))
+        return out.value
+
+
+class Extractor:
+    """Batched device extractor (C-ABI mcs_extractor): one image size, up to max_batch images per call."""
+
+    def __init__(self, ctx, width, height, max_batch=1, nfeatures=1000, scaleFactor=1.2, nlevels=8, fastThreshold=20,
+                 do_dBrief=0, learnMasks=0, descSize=32, edgeThreshold=25, firstLevel=0, scoreType=0, patchSize=32, useAgast=0,
+                 fastAgastType=2):
+        self.ctx = ctx
+        self.params = ExtractorParams(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, scoreType, patchSize,
+                                      fastThreshold, int(useAgast), fastAgastType, int(do_dBrief), int(learnMasks), descSize)
+        self.h = C.c_void_p()
+        check(lib().mcs_extractor_create(ctx.h, C.byref(self.params), width, height, max_batch, C.byref(self.h)))
+        cap = C.c_int32()
+        check(lib().mcs_extractor_kp_capacity(self.h, C.byref(cap)))
+        self.cap = cap.value
+        self.width, self.height, self.max_batch, self.descSize, self.nlevels = width, height, max_batch, descSize, nlevels
+        nl = C.c_int32()
+        w = (C.c_int32 * 16)()
+        h = (C.c_int32 * 16)()
+        f = (C.c_int32 * 16)()
+        check(lib().mcs_extractor_levels(self.h, C.byref(nl), w, h, f))
+        self.level_sizes = [(w[i], h[i]) for i in range(nl.value)]
+        self.features_per_level = [f[i] for i in range(nl.value)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mcs_extractor_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def extract_host(self, images, masks, cams, want_rays=True):
+        """images: list/array of HxW uint8; masks: same or None; cams: list of Ocam or None.  Returns per-image tuples."""
+        imgs = np.ascontiguousarray(np.stack(images), np.uint8)
+        n, h, w = imgs.shape
+        assert (w, h) == (self.width, self.height)
+        m = None if masks is None else np.ascontiguousarray(np.stack(masks), np.uint8)
+        camarr = None
+        if cams is not None:
+            camarr = (Ocam * n)(*cams)
+        nkp = np.zeros(n, np.int32)
+        kps = np.zeros((n, self.cap), KP_DTYPE)
+        desc = np.zeros((n, self.cap, self.descSize), np.uint8)
+        dmask = np.zeros((n, self.cap, self.descSize), np.uint8)
+        rays = np.zeros((n, self.cap, 3), np.float64) if (want_rays and cams is not None) else None
+        check(lib().mcs_extract_batch(self.h, n, np_ptr(imgs), w * h, w, np_ptr(m), w * h, w, camarr, MEM_HOST, np_ptr(nkp), np_ptr(kps),
+                                      np_ptr(desc), np_ptr(dmask), np_ptr(rays)))
+        out = []
+        for i in range(n):
+            k = int(nkp[i])
+            out.append((kps[i, :k].copy(), desc[i, :k].copy(), dmask[i, :k].copy(), None if rays is None else rays[i, :k].copy()))
+        return out
+
+    def extract_device(self, n, images_ptr, image_pitch, image_stride, masks_ptr, mask_pitch, mask_stride, cams, nkp_ptr, kps_ptr,
+                       desc_ptr, dmask_ptr, rays_ptr):
+        """Raw device pointers (ints); only enqueues on the context's stream."""
+        camarr = None
+        if cams is not None:
+            camarr = cams if isinstance(cams, C.Array) else (Ocam * n)(*cams)
+        check(lib().mcs_extract_batch(self.h, n, C.c_void_p(images_ptr), image_pitch, image_stride,
+                                      C.c_void_p(masks_ptr) if masks_ptr else None, mask_pitch, mask_stride, camarr, MEM_DEVICE,
+                                      C.c_void_p(nkp_ptr), C.c_void_p(kps_ptr), C.c_void_p(desc_ptr), C.c_void_p(dmask_ptr),
+                                      C.c_void_p(rays_ptr) if rays_ptr else None))
+
+    def status(self):
+        check(lib().mcs_extractor_status(self.h))
+
+    # ---- stage taps (parity tests)
+    def tap_level(self, img, level, blurred=False):
+        w, h = self.level_sizes[level]
+        out = np.zeros((h, w), np.uint8)
+        check(lib().mcs_extractor_tap_level(self.h, img, level, int(blurred), np_ptr(out)))
+        return out
+
+    def _tap(self, fn, img, level):
+        buf = np.zeros(1 << 17, np.uint32)
+        n = C.c_int32()
+        check(fn(self.h, img, level, np_ptr(buf), len(buf), C.byref(n)))
+        rec = buf[:n.value]
+        return (rec & 0xFFF).astype(np.int32), ((rec >> 12) & 0xFFF).astype(np.int32), (rec >> 24).astype(np.int32)
+
+    def tap_candidates(self, img, level):
+        return self._tap(lib().mcs_extractor_tap_candidates, img, level)
+
+    def tap_selected(self, img, level):
+        return self._tap(lib().mcs_extractor_tap_selected, img, level)

@@ -1,0 +1,117 @@
+"""ctypes binding of libmcs_hip.so (the C ABI declared in include/mcs_c.h).
+
+The library is the product: if it is missing or no HIP device is usable, everything here raises — there is no
+CPU fallback (the CPU oracle under oracle/ is test infrastructure and is never imported from this package).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcs_hip.so")
+
+MCS_OK, MCS_ERR_INVALID, MCS_ERR_HIP, MCS_ERR_CAPACITY, MCS_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+MEM_HOST, MEM_DEVICE = 0, 1
+MAX_POLY = 16
+
+
+class McsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmcs_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class KeyPoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float), ("response", C.c_float),
+                ("octave", C.c_int32), ("class_id", C.c_int32)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+
+
+class Ocam(C.Structure):
+    _fields_ = [("c", C.c_double), ("d", C.c_double), ("e", C.c_double), ("u0", C.c_double), ("v0", C.c_double),
+                ("p", C.c_double * MAX_POLY), ("p_deg", C.c_int32), ("invP", C.c_double * MAX_POLY), ("invP_deg", C.c_int32),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class ExtractorParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scaleFactor", C.c_float), ("nlevels", C.c_int32), ("edgeThreshold", C.c_int32),
+                ("firstLevel", C.c_int32), ("scoreType", C.c_int32), ("patchSize", C.c_int32), ("fastThreshold", C.c_int32),
+                ("useAgast", C.c_int32), ("fastAgastType", C.c_int32), ("do_dBrief", C.c_int32), ("learnMasks", C.c_int32),
+                ("descSize", C.c_int32)]
+
+
+class DescSet(C.Structure):
+    _fields_ = [("desc", C.c_void_p), ("mask", C.c_void_p), ("valid", C.c_void_p), ("group", C.c_void_p), ("n", C.c_int32),
+                ("stride", C.c_int32)]
+
+
+def make_ocam(cam):
+    o = Ocam()
+    o.c, o.d, o.e, o.u0, o.v0 = cam["c"], cam["d"], cam["e"], cam["u0"], cam["v0"]
+    for i, v in enumerate(cam["p"]):
+        o.p[i] = v
+    o.p_deg = len(cam["p"])
+    for i, v in enumerate(cam["invP"]):
+        o.invP[i] = v
+    o.invP_deg = len(cam["invP"])
+    o.width, o.height = cam["width"], cam["height"]
+    return o
+
+
+EXPORTS = [
+    "mcs_last_error", "mcs_device_count", "mcs_ctx_create", "mcs_ctx_destroy", "mcs_ctx_synchronize", "mcs_extractor_create",
+    "mcs_extractor_destroy", "mcs_extractor_kp_capacity", "mcs_extractor_levels", "mcs_extract_batch", "mcs_extractor_status",
+    "mcs_extractor_tap_level", "mcs_extractor_tap_candidates", "mcs_extractor_tap_selected", "mcs_match_topk",
+    "mcs_match_topk_batched", "mcs_descriptor_distance", "mcs_descriptor_distance_masked", "mcs_ctx_enable_timing",
+    "mcs_ctx_kernel_ms",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libmcs_hip.so (built in-tree by __graft_entry__.build() / make -C csrc).  Fails loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `make -C multicol-slam_amd/csrc` (hipcc, gfx950). "
+                          "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32p = C.c_void_p, C.POINTER(C.c_int32)
+    L.mcs_last_error.restype = C.c_char_p
+    L.mcs_device_count.argtypes = [i32p]
+    L.mcs_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.mcs_ctx_destroy.argtypes = [vp]
+    L.mcs_ctx_synchronize.argtypes = [vp]
+    L.mcs_ctx_enable_timing.argtypes = [vp, C.c_int]
+    L.mcs_ctx_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float)]
+    L.mcs_extractor_create.argtypes = [vp, C.POINTER(ExtractorParams), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.mcs_extractor_destroy.argtypes = [vp]
+    L.mcs_extractor_kp_capacity.argtypes = [vp, i32p]
+    L.mcs_extractor_levels.argtypes = [vp, i32p, i32p, i32p, i32p]
+    L.mcs_extractor_status.argtypes = [vp]
+    L.mcs_extract_batch.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.mcs_extractor_tap_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+    L.mcs_extractor_tap_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, i32p]
+    L.mcs_extractor_tap_selected.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, i32p]
+    L.mcs_match_topk.argtypes = [vp, C.POINTER(DescSet), C.POINTER(DescSet), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.mcs_match_topk_batched.argtypes = [vp, C.c_int, C.POINTER(DescSet), C.c_size_t, C.POINTER(DescSet), C.c_size_t, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.mcs_descriptor_distance.argtypes = [vp, vp, vp, C.c_int, i32p]
+    L.mcs_descriptor_distance_masked.argtypes = [vp, vp, vp, vp, vp, C.c_int, i32p]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != MCS_OK:
+        raise McsError(rc, lib().mcs_last_error().decode("utf-8", "replace"))
+
+
+def np_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,589 @@
+// mcs_capi.hip — C ABI (include/mcs_c.h) of libmcs_hip.so: contexts, extractor construction (host-side tables in the
+// reference's exact float/double steps), batch orchestration on one HIP stream, stage taps, matcher entry points.
+// There is no CPU fallback in this library: every entry point needs a HIP device.
+#include "mcs_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace mcs {
+void upload_describe_tables(const signed char* pattern, const signed char* disc);
+void launch_single_distance(const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out, hipStream_t s);
+static const signed char kPattern[2048] = {
+#include "learned_pattern_64_orb.inc"
+};
+}  // namespace mcs
+
+using namespace mcs;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                       \
+	do {                                                                                                   \
+		hipError_t _e = (expr);                                                                            \
+		if (_e != hipSuccess) return fail(MCS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+	} while (0)
+
+static inline int cvRound_(double v) { return (int)lrint(v); }
+static inline int cvRoundf_(float v) { return (int)lrintf(v); }
+static inline int cvFloor_(double v) { int i = (int)v; return i - (i > v); }
+static inline short sat_short(float v) { int iv = cvRoundf_(v); return (short)(iv < -32768 ? -32768 : iv > 32767 ? 32767 : iv); }
+
+struct Timer { hipEvent_t a = nullptr, b = nullptr; bool used = false; };
+
+struct mcs_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool ownStream = false;
+	bool timing = false;
+	std::map<std::string, Timer> timers;
+	// matcher scratch
+	uint32_t* partial = nullptr; size_t partialCap = 0;
+	int* partialCount = nullptr; size_t partialCountCap = 0;
+	uint8_t* stage = nullptr; size_t stageCap = 0;   // host-kind staging for the matcher
+	int* dscalar = nullptr;
+
+	void tic(const char* name) {
+		if (!timing) return;
+		Timer& t = timers[name];
+		if (!t.a) { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
+		(void)hipEventRecord(t.a, stream);
+	}
+	void toc(const char* name) {
+		if (!timing) return;
+		Timer& t = timers[name];
+		(void)hipEventRecord(t.b, stream);
+		t.used = true;
+	}
+};
+
+struct mcs_extractor {
+	mcs_ctx* ctx = nullptr;
+	mcs_extractor_params params{};
+	int maxBatch = 0;
+	PyrDesc hd{};
+	std::vector<CellInfo> cells;
+	PyrDesc* d_desc = nullptr;
+	CellInfo* d_cells = nullptr;
+	ResizeTap* d_taps = nullptr;
+	short* d_maskMap = nullptr;
+	uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_mask0 = nullptr;
+	uint32_t *d_slots = nullptr, *d_dense = nullptr, *d_sel = nullptr;
+	unsigned short* d_knode = nullptr;
+	int *d_cellCount = nullptr, *d_denseCount = nullptr, *d_selCount = nullptr, *d_status = nullptr;
+	OcamDev* d_cams = nullptr;
+	std::vector<OcamDev> h_cams;
+	// host-kind output staging
+	int* d_nkp = nullptr; mcs_keypoint* d_kps = nullptr; uint8_t *d_odesc = nullptr, *d_omask = nullptr; double* d_rays = nullptr;
+	ExtractBuffers last{};
+	int lastN = 0;
+};
+
+extern "C" {
+
+const char* mcs_last_error(void) { return g_err.c_str(); }
+
+int mcs_device_count(int* n) {
+	if (!n) return fail(MCS_ERR_INVALID, "null");
+	HIPCHK(hipGetDeviceCount(n));
+	return MCS_OK;
+}
+
+int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
+	if (!out) return fail(MCS_ERR_INVALID, "out is null");
+	int n = 0;
+	HIPCHK(hipGetDeviceCount(&n));
+	if (n <= 0 || device < 0 || device >= n) return fail(MCS_ERR_HIP, "no usable HIP device (libmcs_hip has no CPU fallback)");
+	HIPCHK(hipSetDevice(device));
+	mcs_ctx* c = new mcs_ctx;
+	c->device = device;
+	if (hip_stream) c->stream = (hipStream_t)hip_stream;
+	else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownStream = true; }
+	HIPCHK(hipMalloc(&c->dscalar, 64));
+	*out = c;
+	return MCS_OK;
+}
+
+int mcs_ctx_destroy(mcs_ctx* c) {
+	if (!c) return MCS_OK;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	for (auto& kv : c->timers) { if (kv.second.a) { (void)hipEventDestroy(kv.second.a); (void)hipEventDestroy(kv.second.b); } }
+	(void)hipFree(c->partial); (void)hipFree(c->partialCount); (void)hipFree(c->stage); (void)hipFree(c->dscalar);
+	if (c->ownStream) (void)hipStreamDestroy(c->stream);
+	delete c;
+	return MCS_OK;
+}
+
+int mcs_ctx_synchronize(mcs_ctx* c) {
+	if (!c) return fail(MCS_ERR_INVALID, "null ctx");
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return MCS_OK;
+}
+
+int mcs_ctx_enable_timing(mcs_ctx* c, int on) {
+	if (!c) return fail(MCS_ERR_INVALID, "null ctx");
+	c->timing = on != 0;
+	return MCS_OK;
+}
+
+int mcs_ctx_kernel_ms(mcs_ctx* c, const char* name, float* ms) {
+	if (!c || !name || !ms) return fail(MCS_ERR_INVALID, "null");
+	auto it = c->timers.find(name);
+	if (it == c->timers.end() || !it->second.used) return fail(MCS_ERR_INVALID, std::string("no timing for ") + name);
+	HIPCHK(hipEventSynchronize(it->second.b));
+	HIPCHK(hipEventElapsedTime(ms, it->second.a, it->second.b));
+	return MCS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ extractor
+static void build_umax(int* umax) {   // reference src/mdBRIEFextractorOct.cpp:187-202
+	int v, v0, vmax = cvFloor_(kHalfPatch * sqrt(2.f) / 2 + 1);
+	int vmin = (int)ceil(kHalfPatch * sqrt(2.f) / 2);
+	const double hp2 = kHalfPatch * kHalfPatch;
+	for (v = 0; v <= kHalfPatch; ++v) umax[v] = 0;
+	for (v = 0; v <= vmax; ++v) umax[v] = cvRound_(sqrt(hp2 - v * v));
+	for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+		while (umax[v0] == umax[v0 + 1]) ++v0;
+		umax[v] = v0;
+		++v0;
+	}
+}
+
+int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width, int height, int max_batch, mcs_extractor** out) {
+	if (!ctx || !p || !out) return fail(MCS_ERR_INVALID, "null argument");
+	if (p->nlevels < 1 || p->nlevels > MCS_MAX_LEVELS) return fail(MCS_ERR_INVALID, "nlevels out of range");
+	if (p->descSize != 16 && p->descSize != 32 && p->descSize != 64) return fail(MCS_ERR_INVALID, "descSize must be 16, 32 or 64");
+	if (p->useAgast || p->fastAgastType != 2) return fail(MCS_ERR_UNSUPPORTED, "only FAST TYPE_9_16 (fastAgastType 2, useAgast 0) is implemented");
+	if (!(p->scaleFactor > 1.0f)) return fail(MCS_ERR_INVALID, "scaleFactor must be > 1");
+	if (max_batch < 1 || width < 1 || height < 1 || p->nfeatures < 1) return fail(MCS_ERR_INVALID, "bad size");
+	HIPCHK(hipSetDevice(ctx->device));
+
+	mcs_extractor* e = new mcs_extractor;
+	e->ctx = ctx; e->params = *p; e->maxBatch = max_batch;
+	PyrDesc& hd = e->hd;
+	const int nl = p->nlevels;
+	hd.nlevels = nl; hd.width = width; hd.height = height;
+	hd.fastThreshold = std::min(std::max(p->fastThreshold, 0), 255);
+	hd.descSize = p->descSize; hd.npoints = 2 * 8 * p->descSize;
+	hd.mode = p->learnMasks ? 2 : (p->do_dBrief ? 1 : 0);
+	hd.undistort = p->do_dBrief ? 1 : 0;
+
+	// scale tables in double from the FLOAT scale factor (ctor :153-179)
+	std::vector<double> sc(nl, 1.0), inv(nl, 1.0);
+	const double scaleFactor = p->scaleFactor;
+	for (int i = 1; i < nl; i++) sc[i] = sc[i - 1] * scaleFactor;
+	const double invScaleFactor = 1.0 / scaleFactor;
+	for (int i = 1; i < nl; i++) inv[i] = inv[i - 1] * invScaleFactor;
+	std::vector<int> nfeat(nl);
+	{
+		double factor = (1.0 / scaleFactor);
+		double nDesired = p->nfeatures * (1 - factor) / (1 - pow(factor, nl));
+		int sum = 0;
+		for (int level = 0; level < nl - 1; level++) { nfeat[level] = cvRound_(nDesired); sum += nfeat[level]; nDesired *= factor; }
+		nfeat[nl - 1] = std::max(p->nfeatures - sum, 0);
+	}
+
+	std::vector<ResizeTap> taps;
+	std::vector<short> maps;
+	int off = 0, cellBase = 0, slotBase = 0, denseBase = 0, selBase = 0;
+	for (int l = 0; l < nl; ++l) {
+		LevelInfo& L = hd.lv[l];
+		L.w = cvRound_((double)width * inv[l]);
+		L.h = cvRound_((double)height * inv[l]);
+		L.stride = (L.w + 63) / 64 * 64;
+		L.off = off;
+		off += L.stride * L.h;
+		const int minB = kMinBorder, maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
+		const double wd = (maxBX - minB), ht = (maxBY - minB);
+		L.nCols = (int)(wd / (double)kCellW);
+		L.nRows = (int)(ht / (double)kCellW);
+		if (L.nCols < 1 || L.nRows < 1 || L.w - 2 * kMinBorder >= 4096 || L.h - 2 * kMinBorder >= 4096) {
+			delete e;
+			return fail(MCS_ERR_UNSUPPORTED, "image too small for the requested number of levels (a level has no 30-px FAST cell) or too large");
+		}
+		L.wCell = (int)ceil(wd / L.nCols);
+		L.hCell = (int)ceil(ht / L.nRows);
+		L.capc = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
+		L.cellBase = cellBase; L.slotBase = slotBase;
+		for (int i = 0; i < L.nRows; i++)
+			for (int j = 0; j < L.nCols; j++) {
+				CellInfo c{};
+				c.level = (short)l;
+				const double iniY = minB + i * L.hCell, iniX = minB + j * L.wCell;
+				double maxY = iniY + L.hCell + 6, maxX = iniX + L.wCell + 6;
+				bool skip = (iniY >= maxBY - 3) || (iniX >= maxBX - 6);   // :897,906
+				if (maxY > maxBY) maxY = maxBY;
+				if (maxX > maxBX) maxX = maxBX;
+				c.x0 = (short)(iniX + 3); c.y0 = (short)(iniY + 3);
+				c.cw = skip ? 0 : (short)std::max(0, (int)maxX - (int)iniX - 6);
+				c.ch = skip ? 0 : (short)std::max(0, (int)maxY - (int)iniY - 6);
+				c.slot = slotBase + (i * L.nCols + j) * L.capc;
+				e->cells.push_back(c);
+			}
+		cellBase += L.nCols * L.nRows;
+		slotBase += L.nCols * L.nRows * L.capc;
+		L.denseBase = denseBase; L.denseCap = L.nCols * L.nRows * L.capc;
+		denseBase += L.denseCap;
+		L.nfeat = nfeat[l];
+		L.selBase = selBase; L.selCap = std::max(L.nfeat + 3, 4 * kMaxRoots);
+		selBase += L.selCap;
+		// oct-tree roots (:641-661)
+		L.nIni = cvRound_(wd / ht);
+		if (L.nIni < 1 || L.nIni > kMaxRoots || L.nfeat + 3 > 1024) {
+			delete e;
+			return fail(MCS_ERR_UNSUPPORTED, "aspect ratio / features per level outside the oct-tree kernel's capacity (nIni in [1,32], nfeatures_level+3 <= 1024)");
+		}
+		L.hX = wd / L.nIni;
+		for (int i = 0; i <= L.nIni; ++i) L.rootX[i] = (int)(L.hX * static_cast<double>(i));
+		L.scale = (float)sc[l];
+		L.kpSize = (float)(int)(kPatchSize * sc[l]);
+		// resize tables from level l-1 (cv::resize INTER_LINEAR, Appendix A.1) and composed nearest-neighbour maps (A.2)
+		L.tabX = (int)taps.size();
+		if (l > 0) {
+			const LevelInfo& P = hd.lv[l - 1];
+			const double scale_x = 1. / ((double)L.w / P.w), scale_y = 1. / ((double)L.h / P.h);
+			for (int dx = 0; dx < L.w; dx++) {
+				float fx = (float)((dx + 0.5) * scale_x - 0.5);
+				int sx = cvFloor_(fx);
+				fx -= sx;
+				if (sx < 0) { fx = 0; sx = 0; }
+				if (sx >= P.w - 1) { fx = 0; sx = P.w - 1; }
+				ResizeTap t{(short)sx, sat_short((1.f - fx) * 2048), sat_short(fx * 2048), 0};
+				taps.push_back(t);
+			}
+			L.tabY = (int)taps.size();
+			for (int dy = 0; dy < L.h; dy++) {
+				float fy = (float)((dy + 0.5) * scale_y - 0.5);
+				int sy = cvFloor_(fy);
+				fy -= sy;
+				ResizeTap t{(short)sy, sat_short((1.f - fy) * 2048), sat_short(fy * 2048), 0};
+				taps.push_back(t);
+			}
+		} else L.tabY = L.tabX;
+		L.mapX = (int)maps.size();
+		for (int x = 0; x < L.w; ++x) {
+			if (l == 0) maps.push_back((short)x);
+			else {
+				const LevelInfo& P = hd.lv[l - 1];
+				const double ifx = 1. / ((double)L.w / P.w);
+				maps.push_back(maps[P.mapX + std::min(cvFloor_(x * ifx), P.w - 1)]);
+			}
+		}
+		L.mapY = (int)maps.size();
+		for (int y = 0; y < L.h; ++y) {
+			if (l == 0) maps.push_back((short)y);
+			else {
+				const LevelInfo& P = hd.lv[l - 1];
+				const double ify = 1. / ((double)L.h / P.h);
+				maps.push_back(maps[P.mapY + std::min(cvFloor_(y * ify), P.h - 1)]);
+			}
+		}
+	}
+	hd.pyrBytes = off;
+	hd.cellsPerImage = cellBase; hd.slotsPerImage = slotBase; hd.densePerImage = denseBase; hd.selPerImage = selBase;
+	hd.kpCap = p->nfeatures + 3 * nl;
+
+	// orientation disc (IC_Angle rows v = 0, +-1..+-16 with |u| <= umax[|v|], 845 pixels)
+	int umax[kHalfPatch + 1];
+	build_umax(umax);
+	std::vector<signed char> disc;
+	for (int v = -kHalfPatch; v <= kHalfPatch; ++v)
+		for (int u = -umax[std::abs(v)]; u <= umax[std::abs(v)]; ++u) { disc.push_back((signed char)u); disc.push_back((signed char)v); }
+	if (disc.size() != 845 * 2) { delete e; return fail(MCS_ERR_INVALID, "internal: disc size"); }
+	upload_describe_tables(kPattern, disc.data());
+
+	const size_t B = max_batch;
+#define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) { mcs_extractor_destroy(e); return fail(MCS_ERR_HIP, std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(_e)); } } while (0)
+	ALLOC(e->d_desc, sizeof(PyrDesc));
+	ALLOC(e->d_cells, sizeof(CellInfo) * e->cells.size());
+	ALLOC(e->d_taps, sizeof(ResizeTap) * std::max<size_t>(taps.size(), 1));
+	ALLOC(e->d_maskMap, sizeof(short) * maps.size());
+	ALLOC(e->d_pyr, B * hd.pyrBytes);
+	ALLOC(e->d_blur, B * hd.pyrBytes);
+	ALLOC(e->d_mask0, B * (size_t)hd.lv[0].stride * hd.lv[0].h);
+	ALLOC(e->d_slots, B * hd.slotsPerImage * sizeof(uint32_t));
+	ALLOC(e->d_dense, B * hd.densePerImage * sizeof(uint32_t));
+	ALLOC(e->d_knode, B * hd.densePerImage * sizeof(unsigned short));
+	ALLOC(e->d_sel, B * hd.selPerImage * sizeof(uint32_t));
+	ALLOC(e->d_cellCount, B * hd.cellsPerImage * sizeof(int));
+	ALLOC(e->d_denseCount, B * nl * sizeof(int));
+	ALLOC(e->d_selCount, B * nl * sizeof(int));
+	ALLOC(e->d_status, sizeof(int));
+	ALLOC(e->d_cams, B * sizeof(OcamDev));
+	ALLOC(e->d_nkp, B * sizeof(int));
+	ALLOC(e->d_kps, B * hd.kpCap * sizeof(mcs_keypoint));
+	ALLOC(e->d_odesc, B * hd.kpCap * (size_t)hd.descSize);
+	ALLOC(e->d_omask, B * hd.kpCap * (size_t)hd.descSize);
+	ALLOC(e->d_rays, B * hd.kpCap * 3 * sizeof(double));
+#undef ALLOC
+	HIPCHK(hipMemcpy(e->d_desc, &hd, sizeof(PyrDesc), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(e->d_cells, e->cells.data(), sizeof(CellInfo) * e->cells.size(), hipMemcpyHostToDevice));
+	if (!taps.empty()) HIPCHK(hipMemcpy(e->d_taps, taps.data(), sizeof(ResizeTap) * taps.size(), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(e->d_maskMap, maps.data(), sizeof(short) * maps.size(), hipMemcpyHostToDevice));
+	HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
+	HIPCHK(hipMemset(e->d_pyr, 0, B * hd.pyrBytes));
+	HIPCHK(hipMemset(e->d_blur, 0, B * hd.pyrBytes));
+	*out = e;
+	return MCS_OK;
+}
+
+int mcs_extractor_destroy(mcs_extractor* e) {
+	if (!e) return MCS_OK;
+	(void)hipSetDevice(e->ctx->device);
+	(void)hipStreamSynchronize(e->ctx->stream);
+	void* ptrs[] = {e->d_desc, e->d_cells, e->d_taps, e->d_maskMap, e->d_pyr, e->d_blur, e->d_mask0, e->d_slots, e->d_dense, e->d_knode,
+	                e->d_sel, e->d_cellCount, e->d_denseCount, e->d_selCount, e->d_status, e->d_cams, e->d_nkp, e->d_kps, e->d_odesc,
+	                e->d_omask, e->d_rays};
+	for (void* p : ptrs) (void)hipFree(p);
+	delete e;
+	return MCS_OK;
+}
+
+int mcs_extractor_kp_capacity(const mcs_extractor* e, int* cap) {
+	if (!e || !cap) return fail(MCS_ERR_INVALID, "null");
+	*cap = e->hd.kpCap;
+	return MCS_OK;
+}
+
+int mcs_extractor_levels(const mcs_extractor* e, int* nlevels, int* widths, int* heights, int* features_per_level) {
+	if (!e) return fail(MCS_ERR_INVALID, "null");
+	if (nlevels) *nlevels = e->hd.nlevels;
+	for (int l = 0; l < e->hd.nlevels; ++l) {
+		if (widths) widths[l] = e->hd.lv[l].w;
+		if (heights) heights[l] = e->hd.lv[l].h;
+		if (features_per_level) features_per_level[l] = e->hd.lv[l].nfeat;
+	}
+	return MCS_OK;
+}
+
+int mcs_extract_batch(mcs_extractor* e, int nimg, const uint8_t* images, size_t image_pitch, int image_stride, const uint8_t* masks,
+                      size_t mask_pitch, int mask_stride, const mcs_ocam* cams, mcs_mem_kind kind, int32_t* nkp, mcs_keypoint* keypoints,
+                      uint8_t* desc, uint8_t* descmask, double* rays) {
+	if (!e || !images || !nkp || !keypoints || !desc || !descmask) return fail(MCS_ERR_INVALID, "null argument");
+	if (nimg < 1 || nimg > e->maxBatch) return fail(MCS_ERR_INVALID, "nimg exceeds the extractor's max_batch");
+	const PyrDesc& hd = e->hd;
+	if (image_stride < hd.width || (masks && mask_stride < hd.width)) return fail(MCS_ERR_INVALID, "stride smaller than the image width");
+	if (hd.mode != 0 && !cams) return fail(MCS_ERR_INVALID, "dBRIEF/mdBRIEF need camera models");
+	if (rays && !cams) return fail(MCS_ERR_INVALID, "rays need camera models");
+	mcs_ctx* c = e->ctx;
+	hipStream_t s = c->stream;
+	HIPCHK(hipSetDevice(c->device));
+
+	ExtractBuffers b{};
+	b.desc = e->d_desc; b.cells = e->d_cells; b.taps = e->d_taps; b.maskMap = e->d_maskMap;
+	b.pyr = e->d_pyr; b.blur = e->d_blur; b.slots = e->d_slots; b.cellCount = e->d_cellCount; b.dense = e->d_dense; b.knode = e->d_knode;
+	b.denseCount = e->d_denseCount; b.sel = e->d_sel; b.selCount = e->d_selCount; b.status = e->d_status;
+	if (kind == MCS_MEM_HOST) {
+		const LevelInfo& L0 = hd.lv[0];
+		for (int i = 0; i < nimg; ++i)
+			HIPCHK(hipMemcpy2DAsync(e->d_pyr + (size_t)i * hd.pyrBytes + L0.off, L0.stride, images + (size_t)i * image_pitch, image_stride,
+			                        hd.width, hd.height, hipMemcpyHostToDevice, s));
+		b.img0 = e->d_pyr + L0.off; b.img0Pitch = hd.pyrBytes; b.img0Stride = L0.stride;
+		if (masks) {
+			const size_t mp = (size_t)L0.stride * L0.h;
+			for (int i = 0; i < nimg; ++i)
+				HIPCHK(hipMemcpy2DAsync(e->d_mask0 + (size_t)i * mp, L0.stride, masks + (size_t)i * mask_pitch, mask_stride, hd.width, hd.height,
+				                        hipMemcpyHostToDevice, s));
+			b.mask0 = e->d_mask0; b.mask0Pitch = mp; b.mask0Stride = L0.stride;
+		}
+		b.nkp = e->d_nkp; b.kps = e->d_kps; b.out_desc = e->d_odesc; b.out_mask = e->d_omask; b.rays = rays ? e->d_rays : nullptr;
+	} else {
+		b.img0 = images; b.img0Pitch = image_pitch; b.img0Stride = image_stride;
+		b.mask0 = masks; b.mask0Pitch = mask_pitch; b.mask0Stride = mask_stride;
+		b.nkp = nkp; b.kps = keypoints; b.out_desc = desc; b.out_mask = descmask; b.rays = rays;
+	}
+	if (cams) {
+		std::vector<OcamDev> hc(nimg);
+		for (int i = 0; i < nimg; ++i) {
+			const mcs_ocam& m = cams[i];
+			if (m.p_deg < 1 || m.p_deg > MCS_MAX_POLY || m.invP_deg < 1 || m.invP_deg > MCS_MAX_POLY) return fail(MCS_ERR_INVALID, "bad polynomial degree");
+			OcamDev& o = hc[i];
+			memset(&o, 0, sizeof(o));
+			o.c = m.c; o.d = m.d; o.e = m.e; o.u0 = m.u0; o.v0 = m.v0; o.invAffine = m.c - m.d * m.e;
+			for (int k = 0; k < m.p_deg; ++k) o.p[k] = m.p[k];
+			for (int k = 0; k < m.invP_deg; ++k) o.invP[k] = m.invP[k];
+			o.p_deg = m.p_deg; o.invP_deg = m.invP_deg;
+		}
+		if (e->h_cams.size() != hc.size() || memcmp(e->h_cams.data(), hc.data(), sizeof(OcamDev) * hc.size()) != 0) {
+			HIPCHK(hipStreamSynchronize(s));   // the previous batch may still read d_cams
+			HIPCHK(hipMemcpy(e->d_cams, hc.data(), sizeof(OcamDev) * hc.size(), hipMemcpyHostToDevice));
+			e->h_cams = hc;
+		}
+		b.cams = e->d_cams;
+	}
+	c->tic("pyramid"); launch_pyramid(b, hd, nimg, s); c->toc("pyramid");
+	c->tic("fast"); launch_fast(b, hd, nimg, s); c->toc("fast");
+	c->tic("octree"); launch_octree(b, hd, nimg, s); c->toc("octree");
+	c->tic("blur"); launch_blur(b, hd, nimg, s); c->toc("blur");
+	c->tic("describe"); launch_describe(b, hd, nimg, s); c->toc("describe");
+	HIPCHK(hipGetLastError());
+	e->last = b; e->lastN = nimg;
+	if (kind == MCS_MEM_HOST) {
+		const size_t rows = (size_t)nimg * hd.kpCap;
+		HIPCHK(hipMemcpyAsync(nkp, e->d_nkp, nimg * sizeof(int), hipMemcpyDeviceToHost, s));
+		HIPCHK(hipMemcpyAsync(keypoints, e->d_kps, rows * sizeof(mcs_keypoint), hipMemcpyDeviceToHost, s));
+		HIPCHK(hipMemcpyAsync(desc, e->d_odesc, rows * hd.descSize, hipMemcpyDeviceToHost, s));
+		HIPCHK(hipMemcpyAsync(descmask, e->d_omask, rows * hd.descSize, hipMemcpyDeviceToHost, s));
+		if (rays) HIPCHK(hipMemcpyAsync(rays, e->d_rays, rows * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+		int st = 0;
+		HIPCHK(hipMemcpyAsync(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+		HIPCHK(hipStreamSynchronize(s));
+		if (st != 0) { (void)hipMemset(e->d_status, 0, sizeof(int)); return fail(st, "device capacity exceeded during extraction"); }
+	}
+	return MCS_OK;
+}
+
+int mcs_extractor_status(mcs_extractor* e) {
+	if (!e) return fail(MCS_ERR_INVALID, "null");
+	int st = 0;
+	HIPCHK(hipStreamSynchronize(e->ctx->stream));
+	HIPCHK(hipMemcpy(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
+	if (st != 0) { (void)hipMemset(e->d_status, 0, sizeof(int)); return fail(st, "device capacity exceeded during extraction"); }
+	return MCS_OK;
+}
+
+int mcs_extractor_tap_level(mcs_extractor* e, int img, int level, int blurred, uint8_t* out) {
+	if (!e || !out || img < 0 || img >= e->lastN || level < 0 || level >= e->hd.nlevels) return fail(MCS_ERR_INVALID, "bad tap");
+	HIPCHK(hipStreamSynchronize(e->ctx->stream));
+	const LevelInfo& L = e->hd.lv[level];
+	const uint8_t* src; int stride;
+	if (blurred) { src = e->d_blur + (size_t)img * e->hd.pyrBytes + L.off; stride = L.stride; }
+	else src = level_ptr(e->last, e->hd, img, level, &stride);
+	HIPCHK(hipMemcpy2D(out, L.w, src, stride, L.w, L.h, hipMemcpyDeviceToHost));
+	return MCS_OK;
+}
+
+static int tap_list(mcs_extractor* e, int img, int level, const uint32_t* base, const int* counts, int perImage, int lvBase, uint32_t* out,
+                    int cap, int* n) {
+	HIPCHK(hipStreamSynchronize(e->ctx->stream));
+	int cnt = 0;
+	HIPCHK(hipMemcpy(&cnt, counts + (size_t)img * e->hd.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+	*n = cnt;
+	const int m = std::min(cnt, cap);
+	if (m > 0) HIPCHK(hipMemcpy(out, base + (size_t)img * perImage + lvBase, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	return MCS_OK;
+}
+
+int mcs_extractor_tap_candidates(mcs_extractor* e, int img, int level, uint32_t* out, int cap, int* n) {
+	if (!e || !out || !n || img < 0 || img >= e->lastN || level < 0 || level >= e->hd.nlevels) return fail(MCS_ERR_INVALID, "bad tap");
+	return tap_list(e, img, level, e->d_dense, e->d_denseCount, e->hd.densePerImage, e->hd.lv[level].denseBase, out, cap, n);
+}
+
+int mcs_extractor_tap_selected(mcs_extractor* e, int img, int level, uint32_t* out, int cap, int* n) {
+	if (!e || !out || !n || img < 0 || img >= e->lastN || level < 0 || level >= e->hd.nlevels) return fail(MCS_ERR_INVALID, "bad tap");
+	return tap_list(e, img, level, e->d_sel, e->d_selCount, e->hd.selPerImage, e->hd.lv[level].selBase, out, cap, n);
+}
+
+// ------------------------------------------------------------------------------------------------ matcher
+static int ensure(void** p, size_t* cap, size_t need) {
+	if (*cap >= need) return MCS_OK;
+	if (*p) (void)hipFree(*p);
+	*p = nullptr; *cap = 0;
+	size_t want = need + need / 2;
+	HIPCHK(hipMalloc(p, want));
+	*cap = want;
+	return MCS_OK;
+}
+
+int mcs_match_topk_batched(mcs_ctx* c, int nsets, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, int dim, int K,
+                           int count_thresh, mcs_mem_kind kind, int32_t* out_dist, int32_t* out_idx, int32_t* out_count_le) {
+	if (!c || !q || !t || !out_dist || !out_idx || !out_count_le) return fail(MCS_ERR_INVALID, "null argument");
+	if (dim != 16 && dim != 32 && dim != 64) return fail(MCS_ERR_INVALID, "dim must be 16, 32 or 64");
+	if (K != 1 && K != 2 && K != 4 && K != 8 && K != 16 && K != 32) return fail(MCS_ERR_INVALID, "K must be 1,2,4,8,16 or 32");
+	if (nsets < 1 || q->n < 0 || t->n < 0 || t->n >= (1 << 20)) return fail(MCS_ERR_INVALID, "bad set size (train rows must be < 2^20)");
+	if (q->stride < dim || t->stride < dim || (q->stride & 3) || (t->stride & 3)) return fail(MCS_ERR_INVALID, "descriptor stride must be >= dim and a multiple of 4");
+	if ((q->mask == nullptr) != (t->mask == nullptr)) return fail(MCS_ERR_INVALID, "masks must be given for both sets or neither");
+	if (!q->desc || !t->desc) return fail(MCS_ERR_INVALID, "null descriptors");
+	HIPCHK(hipSetDevice(c->device));
+	hipStream_t s = c->stream;
+	MatchArgs a{};
+	a.nq = q->n; a.nt = t->n; a.qstride = q->stride; a.tstride = t->stride; a.qpitch = qpitch; a.tpitch = tpitch;
+	a.nsets = nsets; a.dim = dim; a.K = K; a.countThresh = count_thresh;
+	const size_t outRows = (size_t)nsets * q->n;
+	if (q->n == 0) return MCS_OK;
+	const int qTiles = (q->n + 255) / 256;
+	int splits = (2048 + qTiles * nsets - 1) / (qTiles * nsets);
+	splits = std::max(1, std::min(splits, (t->n + 255) / 256));
+	a.splits = splits;
+	if (int r = ensure((void**)&c->partial, &c->partialCap, outRows * splits * K * sizeof(uint32_t))) return r;
+	if (int r = ensure((void**)&c->partialCount, &c->partialCountCap, outRows * splits * sizeof(int))) return r;
+	a.partial = c->partial; a.partialCount = c->partialCount;
+
+	if (kind == MCS_MEM_DEVICE) {
+		a.qd = q->desc; a.qm = q->mask; a.qvalid = q->valid; a.qgroup = q->group;
+		a.td = t->desc; a.tm = t->mask; a.tvalid = t->valid; a.tgroup = t->group;
+		a.outDist = out_dist; a.outIdx = out_idx; a.outCount = out_count_le;
+		c->tic("match"); launch_match(a, s); c->toc("match");
+		HIPCHK(hipGetLastError());
+		return MCS_OK;
+	}
+	// host pointers: stage everything
+	const size_t qRows = qpitch * (nsets - 1) + q->n, tRows = tpitch * (nsets - 1) + t->n;
+	auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+	size_t need = 0;
+	const size_t oQd = need; need += al(qRows * q->stride);
+	const size_t oQm = need; need += q->mask ? al(qRows * q->stride) : 0;
+	const size_t oQv = need; need += q->valid ? al(qRows) : 0;
+	const size_t oQg = need; need += q->group ? al(qRows * 4) : 0;
+	const size_t oTd = need; need += al(tRows * t->stride);
+	const size_t oTm = need; need += t->mask ? al(tRows * t->stride) : 0;
+	const size_t oTv = need; need += t->valid ? al(tRows) : 0;
+	const size_t oTg = need; need += t->group ? al(tRows * 4) : 0;
+	const size_t oOd = need; need += al(outRows * K * 4);
+	const size_t oOi = need; need += al(outRows * K * 4);
+	const size_t oOc = need; need += al(outRows * 4);
+	if (int r = ensure((void**)&c->stage, &c->stageCap, need)) return r;
+	uint8_t* st = c->stage;
+	HIPCHK(hipMemcpyAsync(st + oQd, q->desc, qRows * q->stride, hipMemcpyHostToDevice, s));
+	if (q->mask) HIPCHK(hipMemcpyAsync(st + oQm, q->mask, qRows * q->stride, hipMemcpyHostToDevice, s));
+	if (q->valid) HIPCHK(hipMemcpyAsync(st + oQv, q->valid, qRows, hipMemcpyHostToDevice, s));
+	if (q->group) HIPCHK(hipMemcpyAsync(st + oQg, q->group, qRows * 4, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(st + oTd, t->desc, tRows * t->stride, hipMemcpyHostToDevice, s));
+	if (t->mask) HIPCHK(hipMemcpyAsync(st + oTm, t->mask, tRows * t->stride, hipMemcpyHostToDevice, s));
+	if (t->valid) HIPCHK(hipMemcpyAsync(st + oTv, t->valid, tRows, hipMemcpyHostToDevice, s));
+	if (t->group) HIPCHK(hipMemcpyAsync(st + oTg, t->group, tRows * 4, hipMemcpyHostToDevice, s));
+	a.qd = st + oQd; a.qm = q->mask ? st + oQm : nullptr; a.qvalid = q->valid ? st + oQv : nullptr; a.qgroup = q->group ? (const int*)(st + oQg) : nullptr;
+	a.td = st + oTd; a.tm = t->mask ? st + oTm : nullptr; a.tvalid = t->valid ? st + oTv : nullptr; a.tgroup = t->group ? (const int*)(st + oTg) : nullptr;
+	a.outDist = (int*)(st + oOd); a.outIdx = (int*)(st + oOi); a.outCount = (int*)(st + oOc);
+	c->tic("match"); launch_match(a, s); c->toc("match");
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(out_dist, st + oOd, outRows * K * 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(out_idx, st + oOi, outRows * K * 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(out_count_le, st + oOc, outRows * 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	return MCS_OK;
+}
+
+int mcs_match_topk(mcs_ctx* c, const mcs_desc_set* q, const mcs_desc_set* t, int dim, int K, int count_thresh, mcs_mem_kind kind,
+                   int32_t* out_dist, int32_t* out_idx, int32_t* out_count_le) {
+	return mcs_match_topk_batched(c, 1, q, 0, t, 0, dim, K, count_thresh, kind, out_dist, out_idx, out_count_le);
+}
+
+static int single_distance(mcs_ctx* c, const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out) {
+	if (!c || !a || !b || !out || (dim != 16 && dim != 32 && dim != 64)) return fail(MCS_ERR_INVALID, "bad argument");
+	HIPCHK(hipSetDevice(c->device));
+	uint8_t* buf = nullptr;
+	HIPCHK(hipMalloc((void**)&buf, 4 * 64));
+	HIPCHK(hipMemcpy(buf, a, dim, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(buf + 64, b, dim, hipMemcpyHostToDevice));
+	if (ma) { HIPCHK(hipMemcpy(buf + 128, ma, dim, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(buf + 192, mb, dim, hipMemcpyHostToDevice)); }
+	launch_single_distance(buf, buf + 64, ma ? buf + 128 : nullptr, ma ? buf + 192 : nullptr, dim, c->dscalar, c->stream);
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipMemcpy(out, c->dscalar, sizeof(int), hipMemcpyDeviceToHost));
+	(void)hipFree(buf);
+	return MCS_OK;
+}
+
+int mcs_descriptor_distance(mcs_ctx* c, const uint8_t* a, const uint8_t* b, int dim, int* out) { return single_distance(c, a, b, nullptr, nullptr, dim, out); }
+int mcs_descriptor_distance_masked(mcs_ctx* c, const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out) {
+	if (!ma || !mb) return fail(MCS_ERR_INVALID, "null masks");
+	return single_distance(c, a, b, ma, mb, dim, out);
+}
+
+}  // extern "C"

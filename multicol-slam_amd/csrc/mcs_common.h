@@ -1,0 +1,112 @@
+// mcs_common.h — shared definitions of the gfx950 feature front end (device tables, launch prototypes).
+// Written for CDNA4 only (wave64, 160 KiB LDS/CU, 8 XCDs); no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mcs_c.h"
+
+namespace mcs {
+
+constexpr int kEdge = 25;          // EDGE_THRESHOLD   (reference src/mdBRIEFextractorOct.cpp:86)
+constexpr int kHalfPatch = 16;     // HALF_PATCH_SIZE  (:85)
+constexpr int kPatchSize = 32;     // PATCH_SIZE       (:84)
+constexpr int kMinBorder = kEdge - 3;  // 22 (:876)
+constexpr int kCellW = 30;         // W (:868)
+constexpr int kMaxRoots = 32;
+constexpr int kMaxNodes = 2560;    // oct-tree node capacity per (image, level): nfeatures_level + 3 must fit
+constexpr int kNumXCD = 8;
+
+// One pyramid level of one image (identical for every image of the batch).
+struct LevelInfo {
+	int w, h, stride;       // size and row pitch in bytes (pitch is a multiple of 64)
+	int off;                // byte offset inside the per-image pyramid block (level 0 of the UNBLURRED pyramid may alias the input)
+	// FAST cell grid (reference :884-890)
+	int nCols, nRows, wCell, hCell;
+	int cellBase;           // first cell of this level in the per-image cell list
+	int capc;               // candidate slots per cell  = ceil(wCell/2)*ceil(hCell/2)  (strict local maxima cannot be 8-adjacent)
+	int slotBase;           // first candidate slot of this level in the per-image slot array
+	int denseBase, denseCap;// dense (compacted, ordered) candidate list of this level
+	int nfeat;              // mnFeaturesPerLevel[level]
+	int selBase, selCap;    // selected-keypoint region (nfeat + 3 slots)
+	int nIni;               // oct-tree roots = cvRound(width/height)
+	int rootX[kMaxRoots + 1];
+	double hX;
+	int tabX, tabY;         // offsets of this level's resize tables (from level-1), in entries
+	int mapX, mapY;         // offsets of this level's composed nearest-neighbour maps to level-0 mask coordinates
+	float scale;            // (float)mvScaleFactor[level]
+	float kpSize;           // (float)(int)(PATCH_SIZE*mvScaleFactor[level])
+};
+
+struct PyrDesc {
+	int nlevels;
+	int width, height;
+	int pyrBytes;           // per-image pyramid block size
+	int cellsPerImage, slotsPerImage, densePerImage, selPerImage;
+	int kpCap;              // output rows per image
+	int fastThreshold;
+	int descSize, npoints;
+	int mode;               // 0 ORB, 1 dBRIEF, 2 mdBRIEF
+	int undistort;          // do_dBrief (reference gates undistortion on it only, Appendix B.1)
+	LevelInfo lv[MCS_MAX_LEVELS];
+};
+
+struct CellInfo { short level; short x0, y0; short cw, ch; short pad; int slot; };  // processed region [x0,x0+cw) x [y0,y0+ch) in level ROI coords
+
+// bilinear resize tables (Appendix A.1), one entry per destination column / row of a level
+struct ResizeTap { short ofs; short a0; short a1; short pad; };
+
+// device-side camera model (double precision, Scaramuzza)
+struct OcamDev {
+	double c, d, e, u0, v0, invAffine;
+	double p[MCS_MAX_POLY];
+	double invP[MCS_MAX_POLY];
+	int p_deg, invP_deg;
+};
+
+struct ExtractBuffers {
+	const PyrDesc* desc;          // device copy
+	const CellInfo* cells;        // [cellsPerImage]
+	const ResizeTap* taps;        // x and y tables, all levels
+	const short* maskMap;         // composed NN maps, all levels
+	const uint8_t* img0; size_t img0Pitch; int img0Stride;       // level 0 (input images, device)
+	const uint8_t* mask0; size_t mask0Pitch; int mask0Stride;    // level-0 masks or nullptr
+	uint8_t* pyr;                 // [B][pyrBytes] unblurred levels 1.. (level 0 region unused when aliasing the input)
+	uint8_t* blur;                // [B][pyrBytes] blurred levels 0..
+	uint32_t* slots;              // [B][slotsPerImage] per-cell candidate slots  (x | y<<12 | score<<24, border-relative coords)
+	int* cellCount;               // [B][cellsPerImage]
+	uint32_t* dense;              // [B][densePerImage] ordered candidates per level
+	unsigned short* knode;        // [B][densePerImage] oct-tree scratch: list position of the node holding the key
+	int* denseCount;              // [B][nlevels]
+	uint32_t* sel;                // [B][selPerImage] selected keys in final list order
+	int* selCount;                // [B][nlevels]
+	const OcamDev* cams;          // [B] or nullptr
+	int* status;                  // device error word (capacity overflows)
+	// outputs
+	int* nkp; mcs_keypoint* kps; uint8_t* out_desc; uint8_t* out_mask; double* rays;
+};
+
+__host__ __device__ inline const uint8_t* level_ptr(const ExtractBuffers& b, const PyrDesc& d, int img, int level, int* stride) {
+	if (level == 0) { *stride = b.img0Stride; return b.img0 + (size_t)img * b.img0Pitch; }
+	*stride = d.lv[level].stride;
+	return b.pyr + (size_t)img * d.pyrBytes + d.lv[level].off;
+}
+
+// kernel launchers (each enqueues on `s`)
+void launch_pyramid(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
+void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
+void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
+void launch_blur(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
+void launch_describe(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
+
+struct MatchArgs {
+	const uint8_t* qd; const uint8_t* qm; const uint8_t* qvalid; const int* qgroup; int nq; int qstride; size_t qpitch;
+	const uint8_t* td; const uint8_t* tm; const uint8_t* tvalid; const int* tgroup; int nt; int tstride; size_t tpitch;
+	int nsets; int dim; int K; int countThresh;
+	int splits;                // train-range splits per (set, query tile)
+	uint32_t* partial;         // [nsets][splits][nq][K] packed (dist<<20 | idx), ascending
+	int* partialCount;         // [nsets][splits][nq]
+	int* outDist; int* outIdx; int* outCount;
+};
+void launch_match(const MatchArgs& a, hipStream_t s);
+
+}  // namespace mcs

@@ -1,0 +1,280 @@
+// mcs_describe.hip — E5 + E7a/b/c + E8 + the per-keypoint part of E9: one wave64 per selected keypoint.
+// Reference: IC_Angle src/mdBRIEFextractorOct.cpp:221-248; rotatePattern :285-301; rotateAndDistortPattern :250-283;
+// compute_ORB :303-354; compute_dBRIEF :356-408; compute_mdBRIEF :410-554; operator() glue :1286-1336;
+// omni model src/cam_model_omni.cpp:49-67,146-161, include/cam_model_omni.h:127-145, include/misc.h:115-122;
+// rays src/cMultiFrame.cpp:146-152.  cv::fastAtan2 per SURVEY Appendix A.5.
+//
+//   orientation   845-pixel disc of the UNBLURRED level, lanes stride over the disc, int32 moments reduced with
+//                 cross-lane shuffles (exact, order-free), then the float polynomial of cv::fastAtan2.
+//   descriptor    lane l owns pattern pairs l, l+64, l+128, ... ; one __ballot per 64 pairs yields 8 descriptor bytes
+//                 (bit k -> byte k/8, LSB first, exactly the reference's packing).
+//   dBRIEF        every pattern point goes through the Scaramuzza model in FP64 (sqrt, atan, degree-11 Horner);
+//                 the mean of the 2*8*descSize distorted points is accumulated SEQUENTIALLY (lane 0: x, lane 1: y)
+//                 from LDS in the reference's order, because FP64 addition order decides cvRound ties.
+//   mdBRIEF       three patterns (angle, +20deg, -20deg); mask bit = both rotated tests agree with the main test.
+// Samples inside the level come from the blurred pyramid, samples in the 25-px frame from the unblurred level with
+// reflect-101 indices (the reference's frame is filled before the in-place blur), beyond the frame: clamped.
+// Compiled with -ffp-contract=off: no FMA contraction anywhere, like the oracle.
+#include "mcs_common.h"
+
+namespace mcs {
+
+__constant__ signed char c_pattern[2048];
+__constant__ signed char c_disc[845 * 2];
+
+void upload_describe_tables(const signed char* pattern, const signed char* disc) {
+	if (pattern) (void)hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), pattern, 2048);
+	if (disc) (void)hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc, 845 * 2);
+}
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+	const float K = (float)(180 / 3.1415926535897932384626433832795);
+	const float p1 = 0.9997878412794807f * K, p3 = -0.3258083974640975f * K, p5 = 0.1555786518463281f * K,
+	            p7 = -0.04432655554792128f * K;
+	const float eps = (float)2.2204460492503131e-16;
+	float ax = fabsf(x), ay = fabsf(y);
+	float a, c, c2;
+	if (ax >= ay) {
+		c = ay / (ax + eps);
+		c2 = c * c;
+		a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+	} else {
+		c = ax / (ay + eps);
+		c2 = c * c;
+		a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+	}
+	if (x < 0) a = 180.f - a;
+	if (y < 0) a = 360.f - a;
+	return a;
+}
+
+__device__ __forceinline__ double horner_d(const double* coeffs, int s, double x) {
+	double res = 0.0;
+	for (int i = s - 1; i >= 0; i--) res = res * x + coeffs[i];
+	return res;
+}
+
+__device__ __forceinline__ void world2img(const OcamDev& cam, double x, double y, double z, double& u, double& v) {
+	double norm = sqrt(x * x + y * y);
+	if (norm == 0.0) norm = 1e-14;
+	const double theta = atan(-z / norm);
+	const double rho = horner_d(cam.invP, cam.invP_deg, theta);
+	const double uu = x / norm * rho;
+	const double vv = y / norm * rho;
+	u = uu * cam.c + vv * cam.d + cam.u0;
+	v = uu * cam.e + vv + cam.v0;
+}
+
+__device__ __forceinline__ void img2world(const OcamDev& cam, double u, double v, double& xo, double& yo, double& zo) {
+	const double u_t = u - cam.u0;
+	const double v_t = v - cam.v0;
+	double x = (u_t - cam.d * v_t) / cam.invAffine;
+	double y = (-cam.e * u_t + cam.c * v_t) / cam.invAffine;
+	const double X2 = x * x;
+	const double Y2 = y * y;
+	double z = -horner_d(cam.p, cam.p_deg, sqrt(X2 + Y2));
+	double norm = sqrt(X2 + Y2 + z * z);
+	xo = x / norm;
+	yo = y / norm;
+	zo = z / norm;
+}
+
+struct Sampler {
+	const uint8_t* blur; int bstride;
+	const uint8_t* raw; int rstride;
+	int w, h;
+	__device__ __forceinline__ int at(int r, int c) const {
+		if ((unsigned)r < (unsigned)h && (unsigned)c < (unsigned)w) return blur[(size_t)r * bstride + c];
+		r = r < -kEdge ? -kEdge : (r > h + kEdge - 1 ? h + kEdge - 1 : r);   // clamp to the bordered buffer
+		c = c < -kEdge ? -kEdge : (c > w + kEdge - 1 ? w + kEdge - 1 : c);
+		r = r < 0 ? -r : (r >= h ? 2 * (h - 1) - r : r);                   // BORDER_REFLECT_101
+		c = c < 0 ? -c : (c >= w ? 2 * (w - 1) - c : c);
+		return raw[(size_t)r * rstride + c];
+	}
+};
+
+constexpr int kMaxBallots = 8;   // descSize 64 -> 512 pairs -> 8 ballots
+
+template <int MODE>   // 0 ORB, 1 dBRIEF, 2 mdBRIEF
+__global__ __launch_bounds__(256) void k_describe(ExtractBuffers b, int wavesPerImage) {
+	extern __shared__ __attribute__((aligned(16))) double lds[];   // [4 waves][2][npoints] distorted coordinates (MODE > 0)
+	__shared__ double meanv[4][2];
+	const PyrDesc& d = *b.desc;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int gw = blockIdx.x * 4 + wave;
+	const int img = gw / wavesPerImage;
+	const int s = gw - img * wavesPerImage;
+	const int* selCount = b.selCount + (size_t)img * d.nlevels;
+
+	int total = 0, before = 0, level = -1, pos = 0;
+	for (int l = 0; l < d.nlevels; ++l) {
+		const int c = selCount[l];
+		if (s >= d.lv[l].selBase && s < d.lv[l].selBase + d.lv[l].selCap) { level = l; pos = s - d.lv[l].selBase; before = total; }
+		total += c;
+	}
+	if (s == 0 && lane == 0) b.nkp[img] = total < d.kpCap ? total : d.kpCap;
+	bool active = level >= 0 && s < d.selPerImage && pos < selCount[level >= 0 ? level : 0];
+	const int out = before + pos;
+	if (active && out >= d.kpCap) { if (lane == 0) atomicExch(b.status, MCS_ERR_CAPACITY); active = false; }
+	if (MODE == 0 && !active) return;   // no barriers in ORB mode
+
+	const int np = d.npoints, nballots = d.descSize / 8;
+	float angle = 0.f, pxf = 0.f, pyf = 0.f;
+	int row = 0, col = 0;
+	Sampler sm = {};
+	if (active) {
+		const LevelInfo& L = d.lv[level];
+		const uint32_t rec = b.sel[(size_t)img * d.selPerImage + L.selBase + pos];
+		col = (int)(rec & 0xFFF) + kMinBorder;
+		row = (int)((rec >> 12) & 0xFFF) + kMinBorder;
+		const float resp = (float)(rec >> 24);
+		int rstride;
+		const uint8_t* raw = level_ptr(b, d, img, level, &rstride);
+		sm.blur = b.blur + (size_t)img * d.pyrBytes + L.off; sm.bstride = L.stride;
+		sm.raw = raw; sm.rstride = rstride; sm.w = L.w; sm.h = L.h;
+		// ---- IC_Angle
+		int m10 = 0, m01 = 0;
+		const uint8_t* center = raw + (size_t)row * rstride + col;
+		for (int i = lane; i < 845; i += 64) {
+			const int du = c_disc[2 * i], dv = c_disc[2 * i + 1];
+			const int val = center[dv * rstride + du];
+			m10 += du * val;
+			m01 += dv * val;
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+		angle = fast_atan2_deg((float)m01, (float)m10);
+		// ---- keypoint record (E8): level coordinates -> image coordinates with the FLOAT scale (:1305,1331)
+		pxf = (float)col; pyf = (float)row;
+		if (level != 0) { pxf = pxf * L.scale; pyf = pyf * L.scale; }
+		if (lane == 0) {
+			mcs_keypoint kp;
+			kp.x = pxf; kp.y = pyf; kp.size = L.kpSize; kp.angle = angle; kp.response = resp; kp.octave = level; kp.class_id = -1;
+			b.kps[(size_t)img * d.kpCap + out] = kp;
+			if (b.rays && b.cams) {
+				double rx, ry, rz;
+				img2world(b.cams[img], (double)pxf, (double)pyf, rx, ry, rz);
+				double* rp = b.rays + ((size_t)img * d.kpCap + out) * 3;
+				rp[0] = rx; rp[1] = ry; rp[2] = rz;
+			}
+		}
+	}
+	uint8_t* dout = b.out_desc + ((size_t)img * d.kpCap + out) * d.descSize;
+	uint8_t* mout = b.out_mask + ((size_t)img * d.kpCap + out) * d.descSize;
+
+	if (MODE == 0) {
+		const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
+		const double ang = (double)(angle * DEG2RADf);
+		const double ax = cos(ang), ay = sin(ang);
+		for (int j = 0; j < nballots; ++j) {
+			const int k = j * 64 + lane;
+			const double x0 = c_pattern[4 * k], y0 = c_pattern[4 * k + 1], x1 = c_pattern[4 * k + 2], y1 = c_pattern[4 * k + 3];
+			const int ix0 = __double2int_rn(x0 * ax - y0 * ay), iy0 = __double2int_rn(x0 * ay + y0 * ax);
+			const int ix1 = __double2int_rn(x1 * ax - y1 * ay), iy1 = __double2int_rn(x1 * ay + y1 * ax);
+			const int t0 = sm.at(row + iy0, col + ix0), t1 = sm.at(row + iy1, col + ix1);
+			const unsigned long long bits = __ballot(t0 < t1);
+			if (lane == 0) {
+				*reinterpret_cast<unsigned long long*>(dout + 8 * j) = bits;
+				*reinterpret_cast<unsigned long long*>(mout + 8 * j) = 0ull;   // descriptorMasks = zeros (:1216)
+			}
+		}
+		return;
+	}
+
+	// ---------------------------------------------------------------- dBRIEF / mdBRIEF
+	double* xs = lds + (size_t)wave * 2 * np;
+	double* ys = xs + np;
+	double ukx = 0.0, uky = 0.0, zc = 0.0;
+	double angles[3] = {0.0, 0.0, 0.0};
+	if (active) {
+		const OcamDev& cam = b.cams[img];
+		zc = -cam.p[0];   // distortPointsOcam: WorldToImg(x, y, -p1)
+		if (d.undistort) {   // undistortPointsOcam(pt*scale, scaleF = p[0]) (:1306-1317)
+			double x, y, z;
+			img2world(cam, (double)pxf, (double)pyf, x, y, z);
+			ukx = -x / z * cam.p[0];
+			uky = -y / z * cam.p[0];
+		}
+		if (MODE == 1) {
+			const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
+			angles[0] = (double)(angle * DEG2RADf);
+		} else {
+			const float RHOf = 180.0f / 3.1415926535897932384626f;
+			const double RHOd = 180.0 / 3.1415926535897932384626433832795028841971693993;
+			const double rot = 20.0 / RHOd;
+			const double a = (double)(angle / RHOf);
+			angles[0] = a; angles[1] = a + rot; angles[2] = a - rot;
+		}
+	}
+	unsigned long long bitsMain[kMaxBallots], agree[kMaxBallots];
+#pragma unroll
+	for (int j = 0; j < kMaxBallots; ++j) { bitsMain[j] = 0ull; agree[j] = ~0ull; }
+	const int npat = MODE == 2 ? 3 : 1;
+	for (int pat = 0; pat < npat; ++pat) {
+		double xd[2 * kMaxBallots], yd[2 * kMaxBallots];
+		if (active) {
+			const OcamDev& cam = b.cams[img];
+			const double ax = cos(angles[pat]), ay = sin(angles[pat]);
+#pragma unroll
+			for (int j = 0; j < kMaxBallots; ++j) {
+				if (j < nballots) {
+					const int k = j * 64 + lane;
+#pragma unroll
+					for (int e = 0; e < 2; ++e) {
+						const double px = c_pattern[4 * k + 2 * e], py = c_pattern[4 * k + 2 * e + 1];
+						const double xr = px * ax - py * ay + ukx;
+						const double yr = px * ay + py * ax + uky;
+						double u, v;
+						world2img(cam, xr, yr, zc, u, v);
+						xd[2 * j + e] = u; yd[2 * j + e] = v;
+						xs[2 * k + e] = u; ys[2 * k + e] = v;
+					}
+				}
+			}
+		}
+		__syncthreads();
+		if (active && lane < 2) {   // sumX += xcoords[p] for p = 0..npoints-1, in order (:264-276)
+			const double* arr = lane == 0 ? xs : ys;
+			double sum = 0.0;
+			for (int p = 0; p < np; p += 8) {
+				const double a0 = arr[p], a1 = arr[p + 1], a2 = arr[p + 2], a3 = arr[p + 3], a4 = arr[p + 4], a5 = arr[p + 5],
+				             a6 = arr[p + 6], a7 = arr[p + 7];
+				sum += a0; sum += a1; sum += a2; sum += a3; sum += a4; sum += a5; sum += a6; sum += a7;
+			}
+			meanv[wave][lane] = sum / (double)np;
+		}
+		__syncthreads();
+		if (active) {
+			const double meanX = meanv[wave][0], meanY = meanv[wave][1];
+#pragma unroll
+			for (int j = 0; j < kMaxBallots; ++j) {
+				if (j < nballots) {
+					const int ix0 = __double2int_rn(xd[2 * j] - meanX), iy0 = __double2int_rn(yd[2 * j] - meanY);
+					const int ix1 = __double2int_rn(xd[2 * j + 1] - meanX), iy1 = __double2int_rn(yd[2 * j + 1] - meanY);
+					const int t0 = sm.at(row + iy0, col + ix0), t1 = sm.at(row + iy1, col + ix1);
+					const unsigned long long bits = __ballot(t0 < t1);
+					if (pat == 0) bitsMain[j] = bits;
+					else agree[j] &= ~(bits ^ bitsMain[j]);
+				}
+			}
+		}
+		__syncthreads();   // xs/ys are rewritten by the next pattern
+	}
+	if (active && lane == 0) {
+		for (int j = 0; j < nballots; ++j) {
+			*reinterpret_cast<unsigned long long*>(dout + 8 * j) = bitsMain[j];
+			*reinterpret_cast<unsigned long long*>(mout + 8 * j) = MODE == 2 ? agree[j] : 0ull;
+		}
+	}
+}
+
+void launch_describe(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
+	const int wavesPerImage = (hd.selPerImage + 3) / 4 * 4;
+	const int blocks = nimg * wavesPerImage / 4;
+	const size_t ldsBytes = (size_t)4 * 2 * hd.npoints * sizeof(double);
+	if (hd.mode == 0) hipLaunchKernelGGL(k_describe<0>, dim3(blocks), dim3(256), 0, s, b, wavesPerImage);
+	else if (hd.mode == 1) hipLaunchKernelGGL(k_describe<1>, dim3(blocks), dim3(256), ldsBytes, s, b, wavesPerImage);
+	else hipLaunchKernelGGL(k_describe<2>, dim3(blocks), dim3(256), ldsBytes, s, b, wavesPerImage);
+}
+
+}  // namespace mcs

@@ -1,0 +1,151 @@
+// mcs_fast.hip — E2: grid-cell FAST-9/16 + non-max suppression + mirror-mask filter.
+// Reference: src/mdBRIEFextractorOct.cpp:863-949 (one cv::FastFeatureDetector(th, nonmax=true, TYPE_9_16)->detect()
+// per ~30x30 cell view with its mask view); FAST arithmetic per SURVEY Appendix A.3.
+//
+// One 256-thread workgroup per (image, cell): the cell's processed region plus its 3-px ring is staged in LDS once,
+// every pixel's corner score is computed from LDS, NMS runs on an LDS score tile whose 1-px frame is zero — which is
+// exactly the reference's behaviour: every cell is its own FAST() call, so a neighbour outside the cell's processed
+// region counts as score 0 and corners are never suppressed across a cell seam.
+// Score (closed form of cv::cornerScore<16>, proven equal by tests/test_oracle_kat.py):
+//     d[k] = v - I[k];  A = max over the 16 arcs of 9 contiguous k of min d;  B = max over arcs of min(-d)
+//     corner <=> max(A,B) > t;   score = max(A,B) - 1  (stored as u8, 0 = no corner)
+// Survivors are emitted in the reference's order (row-major inside the cell) with wave64 ballots + prefix counts into
+// the cell's private slot range, so the later compaction is a pure prefix sum over cells (cell row-major order).
+// Candidate record: x | y<<12 | score<<24 with x,y relative to minBorder (22), like vToDistributeKeys.
+#include "mcs_common.h"
+
+namespace mcs {
+
+constexpr int kTilePitch = 68;   // >= wCell_max(60) + 6, multiple of 4
+constexpr int kTileRows = 66;
+constexpr int kScPitch = 64;     // >= wCell_max + 2
+constexpr int kScRows = 62;
+
+__device__ __forceinline__ int fast_score(const uint8_t* c /* centre in LDS tile */, int t) {
+	const int v = c[0];
+	int d[16];
+	d[0] = v - c[3 * kTilePitch];
+	d[8] = v - c[-3 * kTilePitch];
+	d[4] = v - c[3];
+	d[12] = v - c[-3];
+	// necessary condition (same pairs as cv::FAST's high-speed test): every 9-arc contains k or k+8 for each k
+	{
+		const bool o0 = (d[0] > t) | (d[0] < -t) | (d[8] > t) | (d[8] < -t);
+		const bool o4 = (d[4] > t) | (d[4] < -t) | (d[12] > t) | (d[12] < -t);
+		if (!(o0 & o4)) return 0;
+	}
+	d[1] = v - c[3 * kTilePitch + 1];
+	d[2] = v - c[2 * kTilePitch + 2];
+	d[3] = v - c[1 * kTilePitch + 3];
+	d[5] = v - c[-1 * kTilePitch + 3];
+	d[6] = v - c[-2 * kTilePitch + 2];
+	d[7] = v - c[-3 * kTilePitch + 1];
+	d[9] = v - c[-3 * kTilePitch - 1];
+	d[10] = v - c[-2 * kTilePitch - 2];
+	d[11] = v - c[-1 * kTilePitch - 3];
+	d[13] = v - c[1 * kTilePitch - 3];
+	d[14] = v - c[2 * kTilePitch - 2];
+	d[15] = v - c[3 * kTilePitch - 1];
+	int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+	for (int k = 0; k < 16; ++k) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+	for (int k = 0; k < 16; ++k) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+	int A = -256, Bn = 256;
+#pragma unroll
+	for (int k = 0; k < 16; ++k) {
+		int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);   // min d[k..k+8]
+		int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);   // max d[k..k+8]
+		A = max(A, lo9);
+		Bn = min(Bn, hi9);
+	}
+	const int best = max(A, -Bn);
+	return best > t ? best - 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd) {
+	__shared__ __attribute__((aligned(16))) uint8_t tile[kTileRows * kTilePitch];
+	__shared__ uint8_t sc[kScRows * kScPitch];
+	__shared__ int waveCnt[4];
+	__shared__ int runBase;
+
+	// XCD-aware mapping: hardware places block i on XCD i%8; give every XCD a contiguous run of cells so that the
+	// overlapping cell rings / shared cache lines of neighbouring cells hit the same L2.
+	const int logical = (blockIdx.x % kNumXCD) * perXcd + blockIdx.x / kNumXCD;
+	if (logical >= nblocks) return;
+	const PyrDesc& d = *b.desc;
+	const int img = logical / d.cellsPerImage;
+	const int ci = logical - img * d.cellsPerImage;
+	const CellInfo cell = b.cells[ci];
+	const LevelInfo& L = d.lv[cell.level];
+	const int tid = threadIdx.x;
+	const int cw = cell.cw, ch = cell.ch;
+	int* countOut = b.cellCount + (size_t)img * d.cellsPerImage + ci;
+	if (cw <= 0 || ch <= 0) { if (tid == 0) *countOut = 0; return; }
+
+	int stride;
+	const uint8_t* src = level_ptr(b, d, img, cell.level, &stride);
+	src += (size_t)(cell.y0 - 3) * stride + (cell.x0 - 3);
+	const int tw = cw + 6, th = ch + 6;
+	for (int i = tid; i < tw * th; i += 256) {
+		int ty = i / tw, tx = i - ty * tw;
+		tile[ty * kTilePitch + tx] = src[(size_t)ty * stride + tx];
+	}
+	const int sw = cw + 2, sh = ch + 2;
+	for (int i = tid; i < sh * kScPitch; i += 256) sc[i] = 0;
+	if (tid == 0) runBase = 0;
+	__syncthreads();
+
+	const int t = d.fastThreshold;
+	const int npx = cw * ch;
+	for (int p = tid; p < npx; p += 256) {
+		int py = p / cw, px = p - py * cw;
+		int s = fast_score(&tile[(py + 3) * kTilePitch + px + 3], t);
+		sc[(py + 1) * kScPitch + px + 1] = (uint8_t)s;
+	}
+	__syncthreads();
+
+	uint32_t* slots = b.slots + (size_t)img * d.slotsPerImage + cell.slot;
+	const int lane = tid & 63, wave = tid >> 6;
+	const short* mapX = b.maskMap + L.mapX;
+	const short* mapY = b.maskMap + L.mapY;
+	const uint8_t* mask = b.mask0 ? b.mask0 + (size_t)img * b.mask0Pitch : nullptr;
+	for (int base = 0; base < npx; base += 256) {
+		const int p = base + tid;
+		bool keep = false;
+		int py = 0, px = 0, s = 0;
+		if (p < npx) {
+			py = p / cw; px = p - py * cw;
+			const uint8_t* q = &sc[(py + 1) * kScPitch + px + 1];
+			s = q[0];
+			keep = s > q[-1] && s > q[1] && s > q[-kScPitch - 1] && s > q[-kScPitch] && s > q[-kScPitch + 1] &&
+			       s > q[kScPitch - 1] && s > q[kScPitch] && s > q[kScPitch + 1];
+			if (keep && mask) {   // KeyPointsFilter::runByPixelsMask on the (nearest-neighbour) mask pyramid
+				int mx = mapX[cell.x0 + px], my = mapY[cell.y0 + py];
+				keep = mask[(size_t)my * b.mask0Stride + mx] != 0;
+			}
+		}
+		const unsigned long long bal = __ballot(keep);
+		if (lane == 0) waveCnt[wave] = __popcll(bal);
+		__syncthreads();
+		int off = runBase;
+		for (int w = 0; w < wave; ++w) off += waveCnt[w];
+		if (keep) {
+			off += __popcll(bal & ((1ull << lane) - 1ull));
+			slots[off] = (uint32_t)(cell.x0 + px - kMinBorder) | ((uint32_t)(cell.y0 + py - kMinBorder) << 12) | ((uint32_t)s << 24);
+		}
+		__syncthreads();
+		if (tid == 0) runBase += waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
+		__syncthreads();
+	}
+	if (tid == 0) *countOut = runBase;
+	(void)sw;
+}
+
+void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
+	const int nblocks = nimg * hd.cellsPerImage;
+	const int perXcd = (nblocks + kNumXCD - 1) / kNumXCD;
+	hipLaunchKernelGGL(k_fast_cells, dim3(perXcd * kNumXCD), dim3(256), 0, s, b, nimg, nblocks, perXcd);
+}
+
+}  // namespace mcs

@@ -1,0 +1,178 @@
+// mcs_match.hip — M1/M2 + the brute-force inner loops of M4/M4'/M5: K nearest train descriptors per query by
+// (distance, train index), eligibility = valid flag and (optionally) equal camera group.
+// Reference: DescriptorDistance64 / DescriptorDistance64Masked src/cORBmatcher.cpp:2438-2474 (xor + popcount, the masked
+// form sums popcnt((a^b)&ma) + popcnt((a^b)&mb) over all words and halves the TOTAL once); loops :907-948 (SearchByBoW
+// KF,KF), :231-262 (SearchByBoW KF,F), :1037-1066 (SearchForTriangulationRaw).  The strict-'<' best/second tracking of
+// the reference means "ties -> lowest train index", which is the (distance<<20 | index) ordering used here.
+//
+// Integer VALU-bound (descriptors are re-used nt times): one query per lane held in registers, 256 train rows (+masks,
+// +eligibility) staged per step in LDS and read back as wave-uniform broadcasts (v_xor + v_and + v_bcnt accumulate).
+// The train range is split over blockIdx.y so that a single 3000x3000 pair still fills 256 CUs; a second tiny kernel
+// merges the per-split sorted lists.  Sets (keyframes) are blockIdx.z: one launch sweeps a whole keyframe database.
+#include "mcs_common.h"
+
+namespace mcs {
+
+constexpr int MT = 256;   // train rows per LDS step
+
+template <int DW, bool MASKED>
+__device__ __forceinline__ int hamming(const uint32_t* q, const uint32_t* qm, const uint32_t* t, const uint32_t* tm) {
+	int acc = 0;
+#pragma unroll
+	for (int w = 0; w < DW; ++w) {
+		const uint32_t x = q[w] ^ t[w];
+		if (MASKED) { acc += __popc(x & qm[w]); acc += __popc(x & tm[w]); }
+		else acc += __popc(x);
+	}
+	return MASKED ? acc >> 1 : acc;   // static_cast<int>(dist / 2): ONE division of the total
+}
+
+template <int K, int DW, bool MASKED>
+__global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
+	__shared__ __attribute__((aligned(16))) uint32_t td[MT * DW];
+	__shared__ __attribute__((aligned(16))) uint32_t tm[MASKED ? MT * DW : 4];
+	__shared__ int tflag[MT];   // camera group of the train row, or -1 if not eligible at all
+	const int tid = threadIdx.x;
+	const int set = blockIdx.z, split = blockIdx.y;
+	const int qi = blockIdx.x * 256 + tid;
+	const size_t qrow0 = (size_t)set * a.qpitch, trow0 = (size_t)set * a.tpitch;
+	bool qok = qi < a.nq;
+	if (qok && a.qvalid) qok = a.qvalid[qrow0 + qi] != 0;
+	uint32_t q[DW], qm[DW];
+	int qg = 0;
+	if (qok) {
+		const uint32_t* qp = reinterpret_cast<const uint32_t*>(a.qd + (qrow0 + qi) * a.qstride);
+#pragma unroll
+		for (int w = 0; w < DW; ++w) q[w] = qp[w];
+		if (MASKED) {
+			const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.qm + (qrow0 + qi) * a.qstride);
+#pragma unroll
+			for (int w = 0; w < DW; ++w) qm[w] = mp[w];
+		}
+		if (a.qgroup) qg = a.qgroup[qrow0 + qi];
+	} else {
+#pragma unroll
+		for (int w = 0; w < DW; ++w) { q[w] = 0; qm[w] = 0; }
+	}
+	uint32_t best[K];
+#pragma unroll
+	for (int p = 0; p < K; ++p) best[p] = 0xFFFFFFFFu;
+	int countLe = 0;
+	const bool useGroup = a.qgroup != nullptr && a.tgroup != nullptr;
+
+	const int per = ((a.nt + a.splits - 1) / a.splits + MT - 1) / MT * MT;
+	const int t0 = split * per, t1 = min(a.nt, t0 + per);
+	for (int base = t0; base < t1; base += MT) {
+		const int j = base + tid;
+		int flag = -1;
+		if (j < t1) {
+			const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.td + (trow0 + j) * a.tstride);
+#pragma unroll
+			for (int w = 0; w < DW; ++w) td[tid * DW + w] = tp[w];
+			if (MASKED) {
+				const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.tm + (trow0 + j) * a.tstride);
+#pragma unroll
+				for (int w = 0; w < DW; ++w) tm[tid * DW + w] = mp[w];
+			}
+			const bool ok = a.tvalid ? a.tvalid[trow0 + j] != 0 : true;
+			flag = ok ? (a.tgroup ? a.tgroup[trow0 + j] : 0) : -1;
+		}
+		tflag[tid] = flag;
+		__syncthreads();
+		if (qok) {
+			const int cnt = min(MT, t1 - base);
+			for (int r = 0; r < cnt; ++r) {
+				const int g = tflag[r];
+				if (g < 0 || (useGroup && g != qg)) continue;
+				const int dist = hamming<DW, MASKED>(q, qm, &td[r * DW], &tm[MASKED ? r * DW : 0]);
+				countLe += dist <= a.countThresh ? 1 : 0;
+				uint32_t key = ((uint32_t)dist << 20) | (uint32_t)(base + r);
+				if (key < best[K - 1]) {
+#pragma unroll
+					for (int p = 0; p < K; ++p) { const uint32_t lo = min(best[p], key), hi = max(best[p], key); best[p] = lo; key = hi; }
+				}
+			}
+		}
+		__syncthreads();
+	}
+	if (qi < a.nq) {
+		const size_t o = ((size_t)set * a.splits + split) * a.nq + qi;
+#pragma unroll
+		for (int p = 0; p < K; ++p) a.partial[o * K + p] = best[p];
+		a.partialCount[o] = countLe;
+	}
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_match_merge(MatchArgs a) {
+	const int qi = blockIdx.x * 256 + threadIdx.x;
+	const int set = blockIdx.z;
+	if (qi >= a.nq) return;
+	uint32_t best[K];
+#pragma unroll
+	for (int p = 0; p < K; ++p) best[p] = 0xFFFFFFFFu;
+	int countLe = 0;
+	for (int s = 0; s < a.splits; ++s) {
+		const size_t o = ((size_t)set * a.splits + s) * a.nq + qi;
+		countLe += a.partialCount[o];
+		for (int e = 0; e < K; ++e) {
+			uint32_t key = a.partial[o * K + e];
+			if (key >= best[K - 1]) break;   // lists are ascending
+#pragma unroll
+			for (int p = 0; p < K; ++p) { const uint32_t lo = min(best[p], key), hi = max(best[p], key); best[p] = lo; key = hi; }
+		}
+	}
+	const size_t o = (size_t)set * a.nq + qi;
+#pragma unroll
+	for (int p = 0; p < K; ++p) {
+		const bool none = best[p] == 0xFFFFFFFFu;
+		a.outDist[o * K + p] = none ? 0x7FFFFFFF : (int)(best[p] >> 20);
+		a.outIdx[o * K + p] = none ? -1 : (int)(best[p] & 0xFFFFFu);
+	}
+	a.outCount[o] = countLe;
+}
+
+template <int K, int DW>
+static void launch_kd(const MatchArgs& a, hipStream_t s) {
+	dim3 grid((a.nq + 255) / 256, a.splits, a.nsets);
+	if (a.qm && a.tm) hipLaunchKernelGGL((k_match_partial<K, DW, true>), grid, dim3(256), 0, s, a);
+	else hipLaunchKernelGGL((k_match_partial<K, DW, false>), grid, dim3(256), 0, s, a);
+	hipLaunchKernelGGL((k_match_merge<K>), dim3((a.nq + 255) / 256, 1, a.nsets), dim3(256), 0, s, a);
+}
+
+template <int K>
+static void launch_k(const MatchArgs& a, hipStream_t s) {
+	if (a.dim == 16) launch_kd<K, 4>(a, s);
+	else if (a.dim == 32) launch_kd<K, 8>(a, s);
+	else launch_kd<K, 16>(a, s);
+}
+
+void launch_match(const MatchArgs& a, hipStream_t s) {
+	switch (a.K) {
+		case 1: launch_k<1>(a, s); break;
+		case 2: launch_k<2>(a, s); break;
+		case 4: launch_k<4>(a, s); break;
+		case 8: launch_k<8>(a, s); break;
+		case 16: launch_k<16>(a, s); break;
+		default: launch_k<32>(a, s); break;
+	}
+}
+
+__global__ void k_single_distance(const uint32_t* x, const uint32_t* y, const uint32_t* mx, const uint32_t* my, int dw, int* out) {
+	if (threadIdx.x == 0) {
+		int acc = 0;
+		for (int w = 0; w < dw; ++w) {
+			const uint32_t v = x[w] ^ y[w];
+			if (mx) { acc += __popc(v & mx[w]); acc += __popc(v & my[w]); }
+			else acc += __popc(v);
+		}
+		*out = mx ? acc >> 1 : acc;
+	}
+}
+
+void launch_single_distance(const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out, hipStream_t s) {
+	hipLaunchKernelGGL(k_single_distance, dim3(1), dim3(64), 0, s, (const uint32_t*)a, (const uint32_t*)b, (const uint32_t*)ma,
+	                   (const uint32_t*)mb, dim / 4, out);
+}
+
+}  // namespace mcs

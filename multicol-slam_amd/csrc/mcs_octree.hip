@@ -1,0 +1,292 @@
+// mcs_octree.hip — E3/E4: DistributeOctTree on the GPU, one 256-thread workgroup per (image, pyramid level).
+// Reference: src/mdBRIEFextractorOct.cpp:569-629 (DivideNode), 631-861 (DistributeOctTree) — a sequential std::list
+// walk that push_front()s children.  Here the node list is REBUILT once per pass from prefix sums and keys never move:
+// a key only stores the list position of its node (they keep their original order inside a node, exactly like the
+// reference's vKeys).  tests/octree_array_model.py is the executable specification of this formulation and
+// tests/test_octree_model.py proves it equal to the literal list-based oracle.  Pure integer arithmetic (FAST
+// coordinates are integers), so the result is bit-exact by construction.
+//
+//   pass, phase A (:698-763):  every node with >1 key is split, in list order.
+//   pass, phase B (:774-835):  nodes created by the previous pass with >1 key, largest first (ties: later created
+//                              first — the documented stand-in for the reference's heap-address tie-break), stop as
+//                              soon as the list holds >= N nodes.
+//   new list = children of the LAST processed node first (each node: n4,n3,n2,n1), then the untouched nodes in order.
+//   finally one key per node: max response, first wins ties (:840-858); output order = list order.
+//
+// Prologue: the per-cell candidate slots written by the FAST kernel are compacted into the level's dense list in the
+// reference's order (cell row-major, then row-major inside the cell) with a prefix sum over the cell counts.
+#include "mcs_common.h"
+
+namespace mcs {
+
+constexpr int MAXN = 1024;   // node capacity; host guarantees nfeat+3 <= MAXN and 4*nIni <= MAXN
+
+struct NodeBuf {
+	short x0[MAXN], x1[MAXN], y0[MAXN], y1[MAXN];
+	int cnt[MAXN];
+	short cre[MAXN];   // creation index inside the pass that made the node if cnt > 1, else -1
+};
+
+// exclusive scan of a[0..n) (n <= MAXN) by the whole 256-thread block; returns the total.  Caller must have synced.
+__device__ int block_exscan(int* a, int n, int* wsum) {
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int base = tid * 4;
+	int v0 = base < n ? a[base] : 0, v1 = base + 1 < n ? a[base + 1] : 0, v2 = base + 2 < n ? a[base + 2] : 0,
+	    v3 = base + 3 < n ? a[base + 3] : 0;
+	const int s = v0 + v1 + v2 + v3;
+	int x = s;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		int y = __shfl_up(x, o);
+		if (lane >= o) x += y;
+	}
+	if (lane == 63) wsum[wave] = x;
+	__syncthreads();
+	int woff = 0;
+	for (int w = 0; w < wave; ++w) woff += wsum[w];
+	const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+	int ex = woff + x - s;
+	if (base < n) a[base] = ex;
+	if (base + 1 < n) a[base + 1] = ex + v0;
+	if (base + 2 < n) a[base + 2] = ex + v0 + v1;
+	if (base + 3 < n) a[base + 3] = ex + v0 + v1 + v2;
+	__syncthreads();
+	return total;
+}
+
+__global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg) {
+	__shared__ NodeBuf nb[2];
+	__shared__ int cc[MAXN * 4];
+	__shared__ short mapq[MAXN * 4];
+	__shared__ int scanA[MAXN];
+	__shared__ int scanB[MAXN];
+	__shared__ short crank[MAXN];
+	__shared__ short byRank[MAXN];
+	__shared__ int wsum[4];
+	__shared__ int shR;
+
+	const PyrDesc& d = *b.desc;
+	const int img = blockIdx.x / d.nlevels;
+	const int level = blockIdx.x - img * d.nlevels;
+	const LevelInfo& Lv = d.lv[level];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int N = Lv.nfeat;
+
+	uint32_t* dense = b.dense + (size_t)img * d.densePerImage + Lv.denseBase;
+	unsigned short* knode = b.knode + (size_t)img * d.densePerImage + Lv.denseBase;
+	uint32_t* sel = b.sel + (size_t)img * d.selPerImage + Lv.selBase;
+	int* selCount = b.selCount + (size_t)img * d.nlevels + level;
+	int* denseCount = b.denseCount + (size_t)img * d.nlevels + level;
+
+	// ---------------------------------------------------------------- compaction of the cell slots (ordered)
+	const int ncell = Lv.nCols * Lv.nRows;
+	const int* cellCount = b.cellCount + (size_t)img * d.cellsPerImage + Lv.cellBase;
+	const uint32_t* slots = b.slots + (size_t)img * d.slotsPerImage + Lv.slotBase;
+	int n = 0;
+	for (int c0 = 0; c0 < ncell; c0 += MAXN) {
+		const int m = min(MAXN, ncell - c0);
+		__syncthreads();
+		for (int i = tid; i < m; i += 256) scanA[i] = cellCount[c0 + i];
+		__syncthreads();
+		const int tot = block_exscan(scanA, m, wsum);
+		for (int c = wave; c < m; c += 4) {
+			const int cnt = cellCount[c0 + c];
+			const int off = n + scanA[c];
+			const uint32_t* sp = slots + (size_t)(c0 + c) * Lv.capc;
+			for (int j = lane; j < cnt; j += 64) dense[off + j] = sp[j];
+		}
+		n += tot;
+	}
+	__syncthreads();
+	if (tid == 0) *denseCount = n;
+	if (n == 0) { if (tid == 0) *selCount = 0; return; }
+
+	// ---------------------------------------------------------------- roots (:641-683)
+	const int nIni = Lv.nIni;
+	const double hX = Lv.hX;
+	const int H = Lv.h - 2 * kMinBorder;   // maxY - minY
+	for (int i = tid; i < kMaxRoots; i += 256) scanA[i] = 0;
+	__syncthreads();
+	for (int k = tid; k < n; k += 256) {
+		const int x = dense[k] & 0xFFF;
+		int r = (int)((double)x / hX);    // vpIniNodes[kp.pt.x / hX]
+		r = r < nIni - 1 ? r : nIni - 1;
+		knode[k] = (unsigned short)r;
+		atomicAdd(&scanA[r], 1);
+	}
+	__syncthreads();
+	if (tid == 0) {
+		int L0 = 0;
+		for (int i = 0; i < nIni; ++i) {
+			if (scanA[i] > 0) {
+				nb[0].x0[L0] = (short)Lv.rootX[i]; nb[0].x1[L0] = (short)Lv.rootX[i + 1];
+				nb[0].y0[L0] = 0; nb[0].y1[L0] = (short)H;
+				nb[0].cnt[L0] = scanA[i]; nb[0].cre[L0] = -1;
+				scanB[i] = L0++;
+			}
+		}
+		shR = L0;
+	}
+	__syncthreads();
+	int L = shR;
+	for (int k = tid; k < n; k += 256) knode[k] = (unsigned short)scanB[knode[k]];
+	__syncthreads();
+
+	// ---------------------------------------------------------------- passes
+	int cur = 0;
+	bool phaseB = false;
+	for (int pass = 0; pass < 64; ++pass) {
+		NodeBuf& A = nb[cur];
+		NodeBuf& Bn = nb[cur ^ 1];
+		const int prevL = L;
+		// (1) candidate ranks
+		int M;
+		if (!phaseB) {
+			for (int i = tid; i < L; i += 256) scanA[i] = A.cnt[i] > 1 ? 1 : 0;
+			__syncthreads();
+			M = block_exscan(scanA, L, wsum);
+			for (int i = tid; i < L; i += 256) crank[i] = A.cnt[i] > 1 ? (short)scanA[i] : (short)-1;
+		} else {
+			for (int i = tid; i < L; i += 256) scanA[i] = A.cre[i] >= 0 ? 1 : 0;
+			__syncthreads();
+			M = block_exscan(scanA, L, wsum);
+			for (int i = tid; i < L; i += 256) {   // rank = number of candidates with a larger (cnt, cre) key
+				short r = -1;
+				if (A.cre[i] >= 0) {
+					const unsigned long long key = ((unsigned long long)A.cnt[i] << 16) | (unsigned)(unsigned short)A.cre[i];
+					int g = 0;
+					for (int j = 0; j < L; ++j) {
+						const int cj = A.cre[j];
+						const unsigned long long kj = ((unsigned long long)A.cnt[j] << 16) | (unsigned)(unsigned short)cj;
+						g += (cj >= 0 && kj > key) ? 1 : 0;
+					}
+					r = (short)g;
+				}
+				crank[i] = r;
+			}
+		}
+		for (int i = tid; i < L * 4; i += 256) cc[i] = 0;
+		__syncthreads();
+		if (M == 0) break;   // nothing can be split: lNodes.size() == prevSize (:767,832)
+		// (2) child key counts of every candidate
+		for (int k = tid; k < n; k += 256) {
+			const int i = knode[k];
+			if (crank[i] >= 0) {
+				const uint32_t rec = dense[k];
+				const int x = rec & 0xFFF, y = (rec >> 12) & 0xFFF;
+				const int mx = A.x0[i] + ((A.x1[i] - A.x0[i] + 1) >> 1);
+				const int my = A.y0[i] + ((A.y1[i] - A.y0[i] + 1) >> 1);
+				const int q = (x < mx ? 0 : 1) + (y < my ? 0 : 2);
+				atomicAdd(&cc[i * 4 + q], 1);
+			}
+		}
+		for (int i = tid; i < L; i += 256)
+			if (crank[i] >= 0) byRank[crank[i]] = (short)i;
+		__syncthreads();
+		// (3) how many candidates are processed: all (phase A) or up to the node that lifts the list to >= N (phase B, :828)
+		int P = M;
+		if (phaseB) {
+			for (int r = tid; r < M; r += 256) {
+				const int i = byRank[r];
+				scanB[r] = (cc[i * 4] > 0) + (cc[i * 4 + 1] > 0) + (cc[i * 4 + 2] > 0) + (cc[i * 4 + 3] > 0) - 1;
+			}
+			if (tid == 0) shR = M - 1;
+			__syncthreads();
+			block_exscan(scanB, M, wsum);
+			for (int r = tid; r < M; r += 256) {
+				const int i = byRank[r];
+				const int nch = (cc[i * 4] > 0) + (cc[i * 4 + 1] > 0) + (cc[i * 4 + 2] > 0) + (cc[i * 4 + 3] > 0);
+				const int sizeAfter = L + scanB[r] + nch - 1;
+				if (sizeAfter >= N) atomicMin(&shR, r);
+			}
+			__syncthreads();
+			P = shR + 1;
+			__syncthreads();
+		}
+		// (4) prefix sums in processing order: children (list placement) and big children (creation index)
+		for (int r = tid; r < P; r += 256) {
+			const int i = byRank[r];
+			scanA[r] = (cc[i * 4] > 0) + (cc[i * 4 + 1] > 0) + (cc[i * 4 + 2] > 0) + (cc[i * 4 + 3] > 0);
+			scanB[r] = (cc[i * 4] > 1) + (cc[i * 4 + 1] > 1) + (cc[i * 4 + 2] > 1) + (cc[i * 4 + 3] > 1);
+		}
+		__syncthreads();
+		const int T = block_exscan(scanA, P, wsum);
+		const int nToExpand = block_exscan(scanB, P, wsum);
+		const int newL = T + L - P;
+		if (newL > MAXN) { if (tid == 0) atomicExch(b.status, MCS_ERR_CAPACITY); L = 0; break; }
+		// children of processed nodes
+		for (int r = tid; r < P; r += 256) {
+			const int i = byRank[r];
+			const int c0 = cc[i * 4], c1 = cc[i * 4 + 1], c2 = cc[i * 4 + 2], c3 = cc[i * 4 + 3];
+			const int nch = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+			int pos = T - scanA[r] - nch;        // children of later-processed nodes sit in front
+			int cre = scanB[r];
+			const short x0 = A.x0[i], x1 = A.x1[i], y0 = A.y0[i], y1 = A.y1[i];
+			const short mx = (short)(x0 + ((x1 - x0 + 1) >> 1)), my = (short)(y0 + ((y1 - y0 + 1) >> 1));
+			short p0 = -1, p1 = -1, p2 = -1, p3 = -1;
+			if (c3 > 0) p3 = (short)pos++;       // list order inside the node: n4, n3, n2, n1
+			if (c2 > 0) p2 = (short)pos++;
+			if (c1 > 0) p1 = (short)pos++;
+			if (c0 > 0) p0 = (short)pos++;
+			if (c0 > 0) { Bn.x0[p0] = x0; Bn.x1[p0] = mx; Bn.y0[p0] = y0; Bn.y1[p0] = my; Bn.cnt[p0] = c0; Bn.cre[p0] = c0 > 1 ? (short)cre++ : (short)-1; }
+			if (c1 > 0) { Bn.x0[p1] = mx; Bn.x1[p1] = x1; Bn.y0[p1] = y0; Bn.y1[p1] = my; Bn.cnt[p1] = c1; Bn.cre[p1] = c1 > 1 ? (short)cre++ : (short)-1; }
+			if (c2 > 0) { Bn.x0[p2] = x0; Bn.x1[p2] = mx; Bn.y0[p2] = my; Bn.y1[p2] = y1; Bn.cnt[p2] = c2; Bn.cre[p2] = c2 > 1 ? (short)cre++ : (short)-1; }
+			if (c3 > 0) { Bn.x0[p3] = mx; Bn.x1[p3] = x1; Bn.y0[p3] = my; Bn.y1[p3] = y1; Bn.cnt[p3] = c3; Bn.cre[p3] = c3 > 1 ? (short)cre++ : (short)-1; }
+			mapq[i * 4] = p0; mapq[i * 4 + 1] = p1; mapq[i * 4 + 2] = p2; mapq[i * 4 + 3] = p3;
+		}
+		__syncthreads();
+		// untouched nodes keep their relative order behind the new children
+		for (int i = tid; i < L; i += 256) scanA[i] = (crank[i] >= 0 && crank[i] < P) ? 0 : 1;
+		__syncthreads();
+		block_exscan(scanA, L, wsum);
+		for (int i = tid; i < L; i += 256) {
+			if (!(crank[i] >= 0 && crank[i] < P)) {
+				const int p = T + scanA[i];
+				Bn.x0[p] = A.x0[i]; Bn.x1[p] = A.x1[i]; Bn.y0[p] = A.y0[i]; Bn.y1[p] = A.y1[i];
+				Bn.cnt[p] = A.cnt[i]; Bn.cre[p] = -1;
+				mapq[i * 4] = (short)p;
+				crank[i] = -1;
+			}
+		}
+		__syncthreads();
+		// (6) keys follow their node
+		for (int k = tid; k < n; k += 256) {
+			const int i = knode[k];
+			int q = 0;
+			if (crank[i] >= 0) {
+				const uint32_t rec = dense[k];
+				const int x = rec & 0xFFF, y = (rec >> 12) & 0xFFF;
+				const int mx = A.x0[i] + ((A.x1[i] - A.x0[i] + 1) >> 1);
+				const int my = A.y0[i] + ((A.y1[i] - A.y0[i] + 1) >> 1);
+				q = (x < mx ? 0 : 1) + (y < my ? 0 : 2);
+			}
+			knode[k] = (unsigned short)mapq[i * 4 + q];
+		}
+		__syncthreads();
+		cur ^= 1;
+		L = newL;
+		// (7) termination (:767-771, :832)
+		if (L >= N || L == prevL) break;
+		if (!phaseB && L + 3 * nToExpand > N) phaseB = true;
+	}
+	__syncthreads();
+
+	// ---------------------------------------------------------------- best key per node (:840-858)
+	unsigned* best = reinterpret_cast<unsigned*>(scanA);
+	for (int i = tid; i < L; i += 256) best[i] = 0;
+	__syncthreads();
+	for (int k = tid; k < n; k += 256) {
+		const unsigned v = (dense[k] & 0xFF000000u) | (0xFFFFFFu - (unsigned)k);   // max response, lowest index wins ties
+		atomicMax(&best[knode[k]], v);
+	}
+	__syncthreads();
+	if (L > Lv.selCap) { if (tid == 0) { atomicExch(b.status, MCS_ERR_CAPACITY); *selCount = 0; } return; }
+	for (int i = tid; i < L; i += 256) sel[i] = dense[0xFFFFFFu - (best[i] & 0xFFFFFFu)];
+	if (tid == 0) *selCount = L;
+}
+
+void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
+	hipLaunchKernelGGL(k_octree, dim3(nimg * hd.nlevels), dim3(256), 0, s, b, nimg);
+}
+
+}  // namespace mcs
