@@ -115,6 +115,31 @@ int mcs_match_topk_batched(mcs_ctx*, int nsets, const mcs_desc_set* q, size_t q_
                            size_t t_set_pitch_rows, int dim, int K, int count_thresh, mcs_mem_kind kind, int32_t* out_dist,
                            int32_t* out_idx, int32_t* out_count_le);
 
+/* ------------------------------------------------------------------ cORBmatcher's three brute-force searches, complete
+ * (top-K lists + the greedy, order-dependent resolution, both on the device; exact for any K — K only trades list size
+ * against per-query rescans, reported in fallbacks[set]).  nsets independent (set 1, set 2) pairs per call, laid out
+ * like mcs_match_topk_batched.  Thresholds follow cORBmatcher::cORBmatcher (src/cORBmatcher.cpp:46-65):
+ * masks given -> TH_LOW = dim, else 2*dim.  mbCheckOrientation is false at every reference call site and not implemented.
+ *
+ * mcs_search_kf_kf         int cORBmatcher::SearchByBoW(cMultiKeyFrame*, cMultiKeyFrame*, vector<cMapPoint*>&)  (:885-966)
+ *     valid = "has a good map point" on both sides;  match12[set*n1 + i] = index in set 2 or -1
+ * mcs_search_kf_f          int cORBmatcher::SearchByBoW(cMultiKeyFrame*, cMultiFrame&, vector<cMapPoint*>&)     (:179-323)
+ *     with the vocabulary-node restriction removed (BASELINE config 3): kf.valid = "has a good map point";
+ *     matchF[set*nF + j] = keyframe feature index matched to FRAME feature j, or -1
+ * mcs_search_triangulation int cORBmatcher::SearchForTriangulationRaw(...)                                      (:968-1155)
+ *     valid = "has NO map point yet", group = camera index (required), rays = 3 doubles per row (same set pitch as the
+ *     descriptors), E = nrCams*nrCams essential matrices (3x3 row-major, E[c1*nrCams+c2]);  match12 as above          */
+int mcs_search_kf_kf(mcs_ctx*, int nsets, const mcs_desc_set* kf1, size_t pitch1_rows, const mcs_desc_set* kf2, size_t pitch2_rows, int dim,
+                     double nnratio, int K, mcs_mem_kind kind, int32_t* match12, int32_t* nmatches, int32_t* fallbacks /* optional */);
+int mcs_search_kf_f(mcs_ctx*, int nsets, const mcs_desc_set* kf, size_t pitchKF_rows, const mcs_desc_set* frame, size_t pitchF_rows, int dim,
+                    double nnratio, int K, mcs_mem_kind kind, int32_t* matchF, int32_t* nmatches, int32_t* fallbacks);
+int mcs_search_triangulation(mcs_ctx*, int nsets, const mcs_desc_set* kf1, size_t pitch1_rows, const mcs_desc_set* kf2, size_t pitch2_rows,
+                             const double* rays1, const double* rays2, const double* E, int nrCams, int dim, int K, mcs_mem_kind kind,
+                             int32_t* match12, int32_t* nmatches, int32_t* fallbacks);
+
+/* device helper: valid[i*cap + k] = (k < nkp[i]) for the row layout produced by mcs_extract_batch (all pointers on the GPU) */
+int mcs_rows_valid(mcs_ctx*, const int32_t* nkp_dev, int nimg, int cap, uint8_t* valid_dev);
+
 /* single-pair distances on the device (known-answer / spot checks) */
 int mcs_descriptor_distance(mcs_ctx*, const uint8_t* a, const uint8_t* b, int dim, int* out);
 int mcs_descriptor_distance_masked(mcs_ctx*, const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out);

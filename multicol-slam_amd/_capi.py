@@ -67,7 +67,7 @@ EXPORTS = [
     "mcs_extractor_destroy", "mcs_extractor_kp_capacity", "mcs_extractor_levels", "mcs_extract_batch", "mcs_extractor_status",
     "mcs_extractor_tap_level", "mcs_extractor_tap_candidates", "mcs_extractor_tap_selected", "mcs_match_topk",
     "mcs_match_topk_batched", "mcs_descriptor_distance", "mcs_descriptor_distance_masked", "mcs_ctx_enable_timing",
-    "mcs_ctx_kernel_ms",
+    "mcs_ctx_kernel_ms", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_rows_valid",
 ]
 
 _lib = None
@@ -102,6 +102,12 @@ def lib():
     L.mcs_match_topk.argtypes = [vp, C.POINTER(DescSet), C.POINTER(DescSet), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.mcs_match_topk_batched.argtypes = [vp, C.c_int, C.POINTER(DescSet), C.c_size_t, C.POINTER(DescSet), C.c_size_t, C.c_int,
                                          C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    srch = [vp, C.c_int, C.POINTER(DescSet), C.c_size_t, C.POINTER(DescSet), C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_int, vp, vp, vp]
+    L.mcs_search_kf_kf.argtypes = srch
+    L.mcs_search_kf_f.argtypes = srch
+    L.mcs_search_triangulation.argtypes = [vp, C.c_int, C.POINTER(DescSet), C.c_size_t, C.POINTER(DescSet), C.c_size_t, vp, vp, vp, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.mcs_rows_valid.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     L.mcs_descriptor_distance.argtypes = [vp, vp, vp, C.c_int, i32p]
     L.mcs_descriptor_distance_masked.argtypes = [vp, vp, vp, vp, vp, C.c_int, i32p]
     _lib = L

@@ -21,46 +21,9 @@ static const signed char kPattern[2048] = {
 
 using namespace mcs;
 
-static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) { g_err = msg; return code; }
-#define HIPCHK(expr)                                                                                       \
-	do {                                                                                                   \
-		hipError_t _e = (expr);                                                                            \
-		if (_e != hipSuccess) return fail(MCS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-	} while (0)
+std::string& mcs_err() { static thread_local std::string e; return e; }
 
-static inline int cvRound_(double v) { return (int)lrint(v); }
-static inline int cvRoundf_(float v) { return (int)lrintf(v); }
-static inline int cvFloor_(double v) { int i = (int)v; return i - (i > v); }
-static inline short sat_short(float v) { int iv = cvRoundf_(v); return (short)(iv < -32768 ? -32768 : iv > 32767 ? 32767 : iv); }
-
-struct Timer { hipEvent_t a = nullptr, b = nullptr; bool used = false; };
-
-struct mcs_ctx {
-	int device = 0;
-	hipStream_t stream = nullptr;
-	bool ownStream = false;
-	bool timing = false;
-	std::map<std::string, Timer> timers;
-	// matcher scratch
-	uint32_t* partial = nullptr; size_t partialCap = 0;
-	int* partialCount = nullptr; size_t partialCountCap = 0;
-	uint8_t* stage = nullptr; size_t stageCap = 0;   // host-kind staging for the matcher
-	int* dscalar = nullptr;
-
-	void tic(const char* name) {
-		if (!timing) return;
-		Timer& t = timers[name];
-		if (!t.a) { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
-		(void)hipEventRecord(t.a, stream);
-	}
-	void toc(const char* name) {
-		if (!timing) return;
-		Timer& t = timers[name];
-		(void)hipEventRecord(t.b, stream);
-		t.used = true;
-	}
-};
+#include "mcs_host.h"
 
 struct mcs_extractor {
 	mcs_ctx* ctx = nullptr;
@@ -86,7 +49,7 @@ struct mcs_extractor {
 
 extern "C" {
 
-const char* mcs_last_error(void) { return g_err.c_str(); }
+const char* mcs_last_error(void) { return mcs_err().c_str(); }
 
 int mcs_device_count(int* n) {
 	if (!n) return fail(MCS_ERR_INVALID, "null");
@@ -115,6 +78,7 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 	(void)hipStreamSynchronize(c->stream);
 	for (auto& kv : c->timers) { if (kv.second.a) { (void)hipEventDestroy(kv.second.a); (void)hipEventDestroy(kv.second.b); } }
 	(void)hipFree(c->partial); (void)hipFree(c->partialCount); (void)hipFree(c->stage); (void)hipFree(c->dscalar);
+	(void)hipFree(c->topDist); (void)hipFree(c->topIdx); (void)hipFree(c->topCnt); (void)hipFree(c->stageOut);
 	if (c->ownStream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return MCS_OK;
@@ -478,112 +442,6 @@ int mcs_extractor_tap_candidates(mcs_extractor* e, int img, int level, uint32_t*
 int mcs_extractor_tap_selected(mcs_extractor* e, int img, int level, uint32_t* out, int cap, int* n) {
 	if (!e || !out || !n || img < 0 || img >= e->lastN || level < 0 || level >= e->hd.nlevels) return fail(MCS_ERR_INVALID, "bad tap");
 	return tap_list(e, img, level, e->d_sel, e->d_selCount, e->hd.selPerImage, e->hd.lv[level].selBase, out, cap, n);
-}
-
-// ------------------------------------------------------------------------------------------------ matcher
-static int ensure(void** p, size_t* cap, size_t need) {
-	if (*cap >= need) return MCS_OK;
-	if (*p) (void)hipFree(*p);
-	*p = nullptr; *cap = 0;
-	size_t want = need + need / 2;
-	HIPCHK(hipMalloc(p, want));
-	*cap = want;
-	return MCS_OK;
-}
-
-int mcs_match_topk_batched(mcs_ctx* c, int nsets, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, int dim, int K,
-                           int count_thresh, mcs_mem_kind kind, int32_t* out_dist, int32_t* out_idx, int32_t* out_count_le) {
-	if (!c || !q || !t || !out_dist || !out_idx || !out_count_le) return fail(MCS_ERR_INVALID, "null argument");
-	if (dim != 16 && dim != 32 && dim != 64) return fail(MCS_ERR_INVALID, "dim must be 16, 32 or 64");
-	if (K != 1 && K != 2 && K != 4 && K != 8 && K != 16 && K != 32) return fail(MCS_ERR_INVALID, "K must be 1,2,4,8,16 or 32");
-	if (nsets < 1 || q->n < 0 || t->n < 0 || t->n >= (1 << 20)) return fail(MCS_ERR_INVALID, "bad set size (train rows must be < 2^20)");
-	if (q->stride < dim || t->stride < dim || (q->stride & 3) || (t->stride & 3)) return fail(MCS_ERR_INVALID, "descriptor stride must be >= dim and a multiple of 4");
-	if ((q->mask == nullptr) != (t->mask == nullptr)) return fail(MCS_ERR_INVALID, "masks must be given for both sets or neither");
-	if (!q->desc || !t->desc) return fail(MCS_ERR_INVALID, "null descriptors");
-	HIPCHK(hipSetDevice(c->device));
-	hipStream_t s = c->stream;
-	MatchArgs a{};
-	a.nq = q->n; a.nt = t->n; a.qstride = q->stride; a.tstride = t->stride; a.qpitch = qpitch; a.tpitch = tpitch;
-	a.nsets = nsets; a.dim = dim; a.K = K; a.countThresh = count_thresh;
-	const size_t outRows = (size_t)nsets * q->n;
-	if (q->n == 0) return MCS_OK;
-	const int qTiles = (q->n + 255) / 256;
-	int splits = (2048 + qTiles * nsets - 1) / (qTiles * nsets);
-	splits = std::max(1, std::min(splits, (t->n + 255) / 256));
-	a.splits = splits;
-	if (int r = ensure((void**)&c->partial, &c->partialCap, outRows * splits * K * sizeof(uint32_t))) return r;
-	if (int r = ensure((void**)&c->partialCount, &c->partialCountCap, outRows * splits * sizeof(int))) return r;
-	a.partial = c->partial; a.partialCount = c->partialCount;
-
-	if (kind == MCS_MEM_DEVICE) {
-		a.qd = q->desc; a.qm = q->mask; a.qvalid = q->valid; a.qgroup = q->group;
-		a.td = t->desc; a.tm = t->mask; a.tvalid = t->valid; a.tgroup = t->group;
-		a.outDist = out_dist; a.outIdx = out_idx; a.outCount = out_count_le;
-		c->tic("match"); launch_match(a, s); c->toc("match");
-		HIPCHK(hipGetLastError());
-		return MCS_OK;
-	}
-	// host pointers: stage everything
-	const size_t qRows = qpitch * (nsets - 1) + q->n, tRows = tpitch * (nsets - 1) + t->n;
-	auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-	size_t need = 0;
-	const size_t oQd = need; need += al(qRows * q->stride);
-	const size_t oQm = need; need += q->mask ? al(qRows * q->stride) : 0;
-	const size_t oQv = need; need += q->valid ? al(qRows) : 0;
-	const size_t oQg = need; need += q->group ? al(qRows * 4) : 0;
-	const size_t oTd = need; need += al(tRows * t->stride);
-	const size_t oTm = need; need += t->mask ? al(tRows * t->stride) : 0;
-	const size_t oTv = need; need += t->valid ? al(tRows) : 0;
-	const size_t oTg = need; need += t->group ? al(tRows * 4) : 0;
-	const size_t oOd = need; need += al(outRows * K * 4);
-	const size_t oOi = need; need += al(outRows * K * 4);
-	const size_t oOc = need; need += al(outRows * 4);
-	if (int r = ensure((void**)&c->stage, &c->stageCap, need)) return r;
-	uint8_t* st = c->stage;
-	HIPCHK(hipMemcpyAsync(st + oQd, q->desc, qRows * q->stride, hipMemcpyHostToDevice, s));
-	if (q->mask) HIPCHK(hipMemcpyAsync(st + oQm, q->mask, qRows * q->stride, hipMemcpyHostToDevice, s));
-	if (q->valid) HIPCHK(hipMemcpyAsync(st + oQv, q->valid, qRows, hipMemcpyHostToDevice, s));
-	if (q->group) HIPCHK(hipMemcpyAsync(st + oQg, q->group, qRows * 4, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(st + oTd, t->desc, tRows * t->stride, hipMemcpyHostToDevice, s));
-	if (t->mask) HIPCHK(hipMemcpyAsync(st + oTm, t->mask, tRows * t->stride, hipMemcpyHostToDevice, s));
-	if (t->valid) HIPCHK(hipMemcpyAsync(st + oTv, t->valid, tRows, hipMemcpyHostToDevice, s));
-	if (t->group) HIPCHK(hipMemcpyAsync(st + oTg, t->group, tRows * 4, hipMemcpyHostToDevice, s));
-	a.qd = st + oQd; a.qm = q->mask ? st + oQm : nullptr; a.qvalid = q->valid ? st + oQv : nullptr; a.qgroup = q->group ? (const int*)(st + oQg) : nullptr;
-	a.td = st + oTd; a.tm = t->mask ? st + oTm : nullptr; a.tvalid = t->valid ? st + oTv : nullptr; a.tgroup = t->group ? (const int*)(st + oTg) : nullptr;
-	a.outDist = (int*)(st + oOd); a.outIdx = (int*)(st + oOi); a.outCount = (int*)(st + oOc);
-	c->tic("match"); launch_match(a, s); c->toc("match");
-	HIPCHK(hipGetLastError());
-	HIPCHK(hipMemcpyAsync(out_dist, st + oOd, outRows * K * 4, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipMemcpyAsync(out_idx, st + oOi, outRows * K * 4, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipMemcpyAsync(out_count_le, st + oOc, outRows * 4, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
-	return MCS_OK;
-}
-
-int mcs_match_topk(mcs_ctx* c, const mcs_desc_set* q, const mcs_desc_set* t, int dim, int K, int count_thresh, mcs_mem_kind kind,
-                   int32_t* out_dist, int32_t* out_idx, int32_t* out_count_le) {
-	return mcs_match_topk_batched(c, 1, q, 0, t, 0, dim, K, count_thresh, kind, out_dist, out_idx, out_count_le);
-}
-
-static int single_distance(mcs_ctx* c, const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out) {
-	if (!c || !a || !b || !out || (dim != 16 && dim != 32 && dim != 64)) return fail(MCS_ERR_INVALID, "bad argument");
-	HIPCHK(hipSetDevice(c->device));
-	uint8_t* buf = nullptr;
-	HIPCHK(hipMalloc((void**)&buf, 4 * 64));
-	HIPCHK(hipMemcpy(buf, a, dim, hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(buf + 64, b, dim, hipMemcpyHostToDevice));
-	if (ma) { HIPCHK(hipMemcpy(buf + 128, ma, dim, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(buf + 192, mb, dim, hipMemcpyHostToDevice)); }
-	launch_single_distance(buf, buf + 64, ma ? buf + 128 : nullptr, ma ? buf + 192 : nullptr, dim, c->dscalar, c->stream);
-	HIPCHK(hipStreamSynchronize(c->stream));
-	HIPCHK(hipMemcpy(out, c->dscalar, sizeof(int), hipMemcpyDeviceToHost));
-	(void)hipFree(buf);
-	return MCS_OK;
-}
-
-int mcs_descriptor_distance(mcs_ctx* c, const uint8_t* a, const uint8_t* b, int dim, int* out) { return single_distance(c, a, b, nullptr, nullptr, dim, out); }
-int mcs_descriptor_distance_masked(mcs_ctx* c, const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out) {
-	if (!ma || !mb) return fail(MCS_ERR_INVALID, "null masks");
-	return single_distance(c, a, b, ma, mb, dim, out);
 }
 
 }  // extern "C"

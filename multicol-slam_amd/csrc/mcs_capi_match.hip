@@ -1,0 +1,225 @@
+// mcs_capi_match.hip — matcher half of the C ABI: top-K Hamming lists and the three brute-force searches of cORBmatcher.
+#include "mcs_host.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace mcs {
+void launch_single_distance(const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out, hipStream_t s);
+void launch_rows_valid(const int* nkp, int nimg, int cap, uint8_t* valid, hipStream_t s);
+}
+using namespace mcs;
+
+static int ensure(void** p, size_t* cap, size_t need) {
+	if (*cap >= need && *p) return MCS_OK;
+	if (*p) (void)hipFree(*p);
+	*p = nullptr; *cap = 0;
+	size_t want = need + need / 2 + 256;
+	HIPCHK(hipMalloc(p, want));
+	*cap = want;
+	return MCS_OK;
+}
+
+struct DevSets {   // device views of a (query sets, train sets) pair
+	const uint8_t *qd, *qm, *qvalid; const int* qgroup;
+	const uint8_t *td, *tm, *tvalid; const int* tgroup;
+};
+
+static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+static int validate_sets(mcs_ctx* c, int nsets, const mcs_desc_set* q, const mcs_desc_set* t, int dim, int K) {
+	if (!c || !q || !t) return fail(MCS_ERR_INVALID, "null argument");
+	if (dim != 16 && dim != 32 && dim != 64) return fail(MCS_ERR_INVALID, "dim must be 16, 32 or 64");
+	if (K != 1 && K != 2 && K != 4 && K != 8 && K != 16 && K != 32) return fail(MCS_ERR_INVALID, "K must be 1,2,4,8,16 or 32");
+	if (nsets < 1 || q->n < 0 || t->n < 0 || t->n >= (1 << 20)) return fail(MCS_ERR_INVALID, "bad set size (train rows must be < 2^20)");
+	if (q->stride < dim || t->stride < dim || (q->stride & 3) || (t->stride & 3)) return fail(MCS_ERR_INVALID, "descriptor stride must be >= dim and a multiple of 4");
+	if ((q->mask == nullptr) != (t->mask == nullptr)) return fail(MCS_ERR_INVALID, "masks must be given for both sets or neither");
+	if ((q->n > 0 && !q->desc) || (t->n > 0 && !t->desc)) return fail(MCS_ERR_INVALID, "null descriptors");
+	return MCS_OK;
+}
+
+// host pointers -> staged device copies (on the context's stream); device pointers pass through
+static int stage_sets(mcs_ctx* c, int nsets, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, mcs_mem_kind kind,
+                      DevSets* out, const double** rays1, const double** rays2, const double** E, int nE) {
+	if (kind == MCS_MEM_DEVICE) {
+		out->qd = q->desc; out->qm = q->mask; out->qvalid = q->valid; out->qgroup = q->group;
+		out->td = t->desc; out->tm = t->mask; out->tvalid = t->valid; out->tgroup = t->group;
+		return MCS_OK;
+	}
+	hipStream_t s = c->stream;
+	const size_t qRows = qpitch * (nsets - 1) + q->n, tRows = tpitch * (nsets - 1) + t->n;
+	size_t need = 0;
+	const size_t oQd = need; need += al256(qRows * q->stride);
+	const size_t oQm = need; need += q->mask ? al256(qRows * q->stride) : 0;
+	const size_t oQv = need; need += q->valid ? al256(qRows) : 0;
+	const size_t oQg = need; need += q->group ? al256(qRows * 4) : 0;
+	const size_t oTd = need; need += al256(tRows * t->stride);
+	const size_t oTm = need; need += t->mask ? al256(tRows * t->stride) : 0;
+	const size_t oTv = need; need += t->valid ? al256(tRows) : 0;
+	const size_t oTg = need; need += t->group ? al256(tRows * 4) : 0;
+	const size_t oR1 = need; need += (rays1 && *rays1) ? al256(qRows * 24) : 0;
+	const size_t oR2 = need; need += (rays2 && *rays2) ? al256(tRows * 24) : 0;
+	const size_t oE = need; need += (E && *E) ? al256((size_t)nE * 8) : 0;
+	HIPCHK(hipStreamSynchronize(s));   // staging buffer may still be in use by an earlier call
+	if (int r = ensure((void**)&c->stage, &c->stageCap, need)) return r;
+	uint8_t* st = c->stage;
+	if (qRows) HIPCHK(hipMemcpyAsync(st + oQd, q->desc, qRows * q->stride, hipMemcpyHostToDevice, s));
+	if (q->mask && qRows) HIPCHK(hipMemcpyAsync(st + oQm, q->mask, qRows * q->stride, hipMemcpyHostToDevice, s));
+	if (q->valid && qRows) HIPCHK(hipMemcpyAsync(st + oQv, q->valid, qRows, hipMemcpyHostToDevice, s));
+	if (q->group && qRows) HIPCHK(hipMemcpyAsync(st + oQg, q->group, qRows * 4, hipMemcpyHostToDevice, s));
+	if (tRows) HIPCHK(hipMemcpyAsync(st + oTd, t->desc, tRows * t->stride, hipMemcpyHostToDevice, s));
+	if (t->mask && tRows) HIPCHK(hipMemcpyAsync(st + oTm, t->mask, tRows * t->stride, hipMemcpyHostToDevice, s));
+	if (t->valid && tRows) HIPCHK(hipMemcpyAsync(st + oTv, t->valid, tRows, hipMemcpyHostToDevice, s));
+	if (t->group && tRows) HIPCHK(hipMemcpyAsync(st + oTg, t->group, tRows * 4, hipMemcpyHostToDevice, s));
+	out->qd = st + oQd; out->qm = q->mask ? st + oQm : nullptr; out->qvalid = q->valid ? st + oQv : nullptr;
+	out->qgroup = q->group ? (const int*)(st + oQg) : nullptr;
+	out->td = st + oTd; out->tm = t->mask ? st + oTm : nullptr; out->tvalid = t->valid ? st + oTv : nullptr;
+	out->tgroup = t->group ? (const int*)(st + oTg) : nullptr;
+	if (rays1 && *rays1) { if (qRows) HIPCHK(hipMemcpyAsync(st + oR1, *rays1, qRows * 24, hipMemcpyHostToDevice, s)); *rays1 = (const double*)(st + oR1); }
+	if (rays2 && *rays2) { if (tRows) HIPCHK(hipMemcpyAsync(st + oR2, *rays2, tRows * 24, hipMemcpyHostToDevice, s)); *rays2 = (const double*)(st + oR2); }
+	if (E && *E) { HIPCHK(hipMemcpyAsync(st + oE, *E, (size_t)nE * 8, hipMemcpyHostToDevice, s)); *E = (const double*)(st + oE); }
+	return MCS_OK;
+}
+
+static int run_topk(mcs_ctx* c, const DevSets& d, int nsets, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, int dim,
+                    int K, int count_thresh, int* outDist, int* outIdx, int* outCount) {
+	MatchArgs a{};
+	a.qd = d.qd; a.qm = d.qm; a.qvalid = d.qvalid; a.qgroup = d.qgroup; a.td = d.td; a.tm = d.tm; a.tvalid = d.tvalid; a.tgroup = d.tgroup;
+	a.nq = q->n; a.nt = t->n; a.qstride = q->stride; a.tstride = t->stride; a.qpitch = qpitch; a.tpitch = tpitch;
+	a.nsets = nsets; a.dim = dim; a.K = K; a.countThresh = count_thresh;
+	const size_t outRows = (size_t)nsets * q->n;
+	const int qTiles = (q->n + 255) / 256;
+	int splits = (2048 + qTiles * nsets - 1) / (qTiles * nsets);
+	splits = std::max(1, std::min(splits, (t->n + 255) / 256));
+	a.splits = splits;
+	if (int r = ensure((void**)&c->partial, &c->partialCap, outRows * splits * K * sizeof(uint32_t))) return r;
+	if (int r = ensure((void**)&c->partialCount, &c->partialCountCap, outRows * splits * sizeof(int))) return r;
+	a.partial = c->partial; a.partialCount = c->partialCount;
+	a.outDist = outDist; a.outIdx = outIdx; a.outCount = outCount;
+	c->tic("match"); launch_match(a, c->stream); c->toc("match");
+	HIPCHK(hipGetLastError());
+	return MCS_OK;
+}
+
+extern "C" {
+
+int mcs_match_topk_batched(mcs_ctx* c, int nsets, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, int dim, int K,
+                           int count_thresh, mcs_mem_kind kind, int32_t* out_dist, int32_t* out_idx, int32_t* out_count_le) {
+	if (int r = validate_sets(c, nsets, q, t, dim, K)) return r;
+	if (!out_dist || !out_idx || !out_count_le) return fail(MCS_ERR_INVALID, "null output");
+	if (q->n == 0) return MCS_OK;
+	HIPCHK(hipSetDevice(c->device));
+	DevSets d{};
+	if (int r = stage_sets(c, nsets, q, qpitch, t, tpitch, kind, &d, nullptr, nullptr, nullptr, 0)) return r;
+	const size_t outRows = (size_t)nsets * q->n;
+	if (kind == MCS_MEM_DEVICE) return run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, count_thresh, out_dist, out_idx, out_count_le);
+	const size_t oD = 0, oI = al256(outRows * K * 4), oC = oI + al256(outRows * K * 4);
+	if (int r = ensure((void**)&c->stageOut, &c->stageOutCap, oC + al256(outRows * 4))) return r;
+	uint8_t* so = c->stageOut;
+	if (int r = run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, count_thresh, (int*)(so + oD), (int*)(so + oI), (int*)(so + oC))) return r;
+	HIPCHK(hipMemcpyAsync(out_dist, so + oD, outRows * K * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(out_idx, so + oI, outRows * K * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(out_count_le, so + oC, outRows * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return MCS_OK;
+}
+
+int mcs_match_topk(mcs_ctx* c, const mcs_desc_set* q, const mcs_desc_set* t, int dim, int K, int count_thresh, mcs_mem_kind kind,
+                   int32_t* out_dist, int32_t* out_idx, int32_t* out_count_le) {
+	return mcs_match_topk_batched(c, 1, q, 0, t, 0, dim, K, count_thresh, kind, out_dist, out_idx, out_count_le);
+}
+
+// mode 0: SearchByBoW(KF,KF)   1: SearchByBoW(KF,F)   2: SearchForTriangulationRaw
+static int search_common(mcs_ctx* c, int mode, int nsets, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, int dim,
+                         double nnratio, int K, mcs_mem_kind kind, const double* rays1, const double* rays2, const double* E, int nrCams,
+                         int32_t* out_match, int32_t* out_nmatches, int32_t* out_fallbacks) {
+	if (int r = validate_sets(c, nsets, q, t, dim, K)) return r;
+	if (!out_match || !out_nmatches) return fail(MCS_ERR_INVALID, "null output");
+	if (t->n > 131072) return fail(MCS_ERR_UNSUPPORTED, "more than 131072 train rows per set");
+	if (mode == 2 && (!rays1 || !rays2 || !E || nrCams < 1)) return fail(MCS_ERR_INVALID, "triangulation search needs rays and essential matrices");
+	HIPCHK(hipSetDevice(c->device));
+	hipStream_t s = c->stream;
+	const bool havingMasks = q->mask != nullptr;
+	// thresholds of cORBmatcher::cORBmatcher (src/cORBmatcher.cpp:46-65); only TH_LOW_ is used by these three searches
+	const int thLow = havingMasks ? (int)floor((double)dim) : 2 * dim;
+	DevSets d{};
+	if (int r = stage_sets(c, nsets, q, qpitch, t, tpitch, kind, &d, mode == 2 ? &rays1 : nullptr, mode == 2 ? &rays2 : nullptr,
+	                       mode == 2 ? &E : nullptr, nrCams * nrCams * 9)) return r;
+	const size_t rows = (size_t)nsets * q->n;
+	if (int r = ensure((void**)&c->topDist, &c->topDistCap, std::max<size_t>(rows, 1) * K * 4)) return r;
+	if (int r = ensure((void**)&c->topIdx, &c->topIdxCap, std::max<size_t>(rows, 1) * K * 4)) return r;
+	if (int r = ensure((void**)&c->topCnt, &c->topCntCap, std::max<size_t>(rows, 1) * 4)) return r;
+	if (q->n > 0)
+		if (int r = run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, thLow, c->topDist, c->topIdx, c->topCnt)) return r;
+	GreedyArgs g{};
+	g.qd = d.qd; g.qm = d.qm; g.qvalid = d.qvalid; g.qgroup = d.qgroup; g.td = d.td; g.tm = d.tm; g.tvalid = d.tvalid; g.tgroup = d.tgroup;
+	g.nq = q->n; g.nt = t->n; g.qstride = q->stride; g.tstride = t->stride; g.qpitch = qpitch; g.tpitch = tpitch;
+	g.nsets = nsets; g.dim = dim; g.K = K; g.topDist = c->topDist; g.topIdx = c->topIdx;
+	g.thLow = thLow; g.thInclusive = mode == 1 ? 1 : 0; g.ratio = nnratio; g.mode = mode;
+	g.rays1 = rays1; g.rays2 = rays2; g.E = E; g.nrCams = nrCams;
+	const size_t outN = (size_t)nsets * (mode == 1 ? t->n : q->n);
+	if (kind == MCS_MEM_DEVICE) {
+		g.outMatch = out_match; g.outCount = out_nmatches; g.outFallbacks = out_fallbacks;
+		c->tic("greedy"); launch_greedy(g, s); c->toc("greedy");
+		HIPCHK(hipGetLastError());
+		return MCS_OK;
+	}
+	const size_t oM = 0, oN = al256(std::max<size_t>(outN, 1) * 4), oF = oN + al256((size_t)nsets * 4);
+	if (int r = ensure((void**)&c->stageOut, &c->stageOutCap, oF + al256((size_t)nsets * 4))) return r;
+	uint8_t* so = c->stageOut;
+	g.outMatch = (int*)(so + oM); g.outCount = (int*)(so + oN); g.outFallbacks = (int*)(so + oF);
+	c->tic("greedy"); launch_greedy(g, s); c->toc("greedy");
+	HIPCHK(hipGetLastError());
+	if (outN) HIPCHK(hipMemcpyAsync(out_match, so + oM, outN * 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(out_nmatches, so + oN, (size_t)nsets * 4, hipMemcpyDeviceToHost, s));
+	if (out_fallbacks) HIPCHK(hipMemcpyAsync(out_fallbacks, so + oF, (size_t)nsets * 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	return MCS_OK;
+}
+
+int mcs_search_kf_kf(mcs_ctx* c, int nsets, const mcs_desc_set* kf1, size_t pitch1, const mcs_desc_set* kf2, size_t pitch2, int dim, double nnratio,
+                     int K, mcs_mem_kind kind, int32_t* match12, int32_t* nmatches, int32_t* fallbacks) {
+	return search_common(c, 0, nsets, kf1, pitch1, kf2, pitch2, dim, nnratio, K, kind, nullptr, nullptr, nullptr, 0, match12, nmatches, fallbacks);
+}
+
+int mcs_search_kf_f(mcs_ctx* c, int nsets, const mcs_desc_set* kf, size_t pitchKF, const mcs_desc_set* f, size_t pitchF, int dim, double nnratio, int K,
+                    mcs_mem_kind kind, int32_t* matchF, int32_t* nmatches, int32_t* fallbacks) {
+	return search_common(c, 1, nsets, kf, pitchKF, f, pitchF, dim, nnratio, K, kind, nullptr, nullptr, nullptr, 0, matchF, nmatches, fallbacks);
+}
+
+int mcs_search_triangulation(mcs_ctx* c, int nsets, const mcs_desc_set* kf1, size_t pitch1, const mcs_desc_set* kf2, size_t pitch2, const double* rays1,
+                             const double* rays2, const double* E, int nrCams, int dim, int K, mcs_mem_kind kind, int32_t* match12,
+                             int32_t* nmatches, int32_t* fallbacks) {
+	return search_common(c, 2, nsets, kf1, pitch1, kf2, pitch2, dim, 0.0, K, kind, rays1, rays2, E, nrCams, match12, nmatches, fallbacks);
+}
+
+int mcs_rows_valid(mcs_ctx* c, const int32_t* nkp_dev, int nimg, int cap, uint8_t* valid_dev) {
+	if (!c || !nkp_dev || !valid_dev || nimg < 1 || cap < 1) return fail(MCS_ERR_INVALID, "bad argument");
+	HIPCHK(hipSetDevice(c->device));
+	launch_rows_valid(nkp_dev, nimg, cap, valid_dev, c->stream);
+	HIPCHK(hipGetLastError());
+	return MCS_OK;
+}
+
+static int single_distance(mcs_ctx* c, const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out) {
+	if (!c || !a || !b || !out || (dim != 16 && dim != 32 && dim != 64)) return fail(MCS_ERR_INVALID, "bad argument");
+	HIPCHK(hipSetDevice(c->device));
+	uint8_t* buf = nullptr;
+	HIPCHK(hipMalloc((void**)&buf, 4 * 64));
+	HIPCHK(hipMemcpy(buf, a, dim, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(buf + 64, b, dim, hipMemcpyHostToDevice));
+	if (ma) { HIPCHK(hipMemcpy(buf + 128, ma, dim, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(buf + 192, mb, dim, hipMemcpyHostToDevice)); }
+	launch_single_distance(buf, buf + 64, ma ? buf + 128 : nullptr, ma ? buf + 192 : nullptr, dim, c->dscalar, c->stream);
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipMemcpy(out, c->dscalar, sizeof(int), hipMemcpyDeviceToHost));
+	(void)hipFree(buf);
+	return MCS_OK;
+}
+
+int mcs_descriptor_distance(mcs_ctx* c, const uint8_t* a, const uint8_t* b, int dim, int* out) { return single_distance(c, a, b, nullptr, nullptr, dim, out); }
+int mcs_descriptor_distance_masked(mcs_ctx* c, const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out) {
+	if (!ma || !mb) return fail(MCS_ERR_INVALID, "null masks");
+	return single_distance(c, a, b, ma, mb, dim, out);
+}
+
+}  // extern "C"

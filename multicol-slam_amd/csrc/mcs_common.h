@@ -109,4 +109,17 @@ struct MatchArgs {
 };
 void launch_match(const MatchArgs& a, hipStream_t s);
 
+// greedy, order-dependent resolution of the reference's brute-force searches on top of the top-K lists
+struct GreedyArgs {
+	const uint8_t* qd; const uint8_t* qm; const uint8_t* qvalid; const int* qgroup; int nq; int qstride; size_t qpitch;
+	const uint8_t* td; const uint8_t* tm; const uint8_t* tvalid; const int* tgroup; int nt; int tstride; size_t tpitch;
+	int nsets; int dim; int K;
+	const int* topDist; const int* topIdx;   // [nsets][nq][K], ascending (dist, idx)
+	int thLow; int thInclusive; double ratio;
+	int mode;                                // 0 SearchByBoW(KF,KF)  1 SearchByBoW(KF,F)  2 SearchForTriangulationRaw
+	const double* rays1; const double* rays2; const double* E; int nrCams;
+	int* outMatch; int* outCount; int* outFallbacks;
+};
+void launch_greedy(const GreedyArgs& g, hipStream_t s);
+
 }  // namespace mcs

@@ -1,0 +1,210 @@
+// mcs_greedy.hip — M4 / M4' / M5: the greedy, order-dependent part of cORBmatcher's brute-force searches, on the device.
+// Reference: SearchByBoW(KF,KF) src/cORBmatcher.cpp:885-966 (accept best < TH_LOW_ and best < ratio*second, mark the train
+// matched), SearchByBoW(KF,F) :179-323 without the BoW-node restriction (accept best <= TH_LOW_, output indexed by the frame
+// feature), SearchForTriangulationRaw :968-1155 (candidates dist <= TH_LOW_ sorted by (dist, idx), DistTh = 2*best, first one
+// passing CheckDistEpipolarLine src/misc.cpp:53-69 wins).  Queries are processed strictly in index order because every
+// accepted match removes a train row from all later queries (vbMatched2 / vpMapPointMatches).
+//
+// One wave64 per (query set, train set) pair: the "matched" bitmap lives in LDS, lane e holds entry e of the query's
+// top-K list (sorted by (distance, index) by mcs_match.hip), a __ballot over "entry still free" yields best and second.
+// When the K entries cannot decide (too many of them already taken), the wave rescans the whole train set for that one
+// query — exact for any K, K only trades list size against rescans.  Integer + a few FP64 mul/div: bit-exact.
+#include "mcs_common.h"
+
+namespace mcs {
+
+constexpr int kBitmapWords = 4096;   // nt <= 131072 train rows per set
+
+template <int DW, bool MASKED>
+__device__ __forceinline__ int hamming_g(const uint32_t* q, const uint32_t* qm, const uint32_t* t, const uint32_t* tm) {
+	int acc = 0;
+#pragma unroll
+	for (int w = 0; w < DW; ++w) {
+		const uint32_t x = q[w] ^ t[w];
+		if (MASKED) { acc += __popc(x & qm[w]); acc += __popc(x & tm[w]); }
+		else acc += __popc(x);
+	}
+	return MASKED ? acc >> 1 : acc;
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { const uint32_t y = __shfl_xor(v, o); v = y < v ? y : v; }
+	return v;
+}
+
+__device__ __forceinline__ bool check_epipolar(const double* ray1, const double* ray2, const double* E, double thresh) {
+	double t[3];
+	for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += ray2[k] * E[3 * k + j]; t[j] = s; }
+	double nom = 0;
+	for (int k = 0; k < 3; ++k) nom += t[k] * ray1[k];
+	double Ex1[3], Etx2[3];
+	for (int i = 0; i < 3; ++i) { double s = 0; for (int k = 0; k < 3; ++k) s += E[3 * i + k] * ray1[k]; Ex1[i] = s; }
+	for (int i = 0; i < 3; ++i) { double s = 0; for (int k = 0; k < 3; ++k) s += E[3 * k + i] * ray2[k]; Etx2[i] = s; }
+	const double den = Ex1[0] * Ex1[0] + Ex1[1] * Ex1[1] + Ex1[2] * Ex1[2] + Etx2[0] * Etx2[0] + Etx2[1] * Etx2[1] + Etx2[2] * Etx2[2];
+	if (den == 0.0) return false;
+	const double dsqr = (nom * nom) / den;
+	return dsqr < thresh;
+}
+
+template <int DW, bool MASKED>
+__global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
+	__shared__ uint32_t matched[kBitmapWords];
+	const int set = blockIdx.x, lane = threadIdx.x;
+	const size_t q0 = (size_t)set * g.qpitch, t0 = (size_t)set * g.tpitch;
+	const int K = g.K;
+	for (int i = lane; i < (g.nt + 31) / 32; i += 64) matched[i] = 0;
+	int* outM = g.outMatch + (size_t)set * (g.mode == 1 ? g.nt : g.nq);
+	if (g.mode == 1) for (int j = lane; j < g.nt; j += 64) outM[j] = -1;
+	__syncthreads();
+	const bool useGroup = g.qgroup != nullptr && g.tgroup != nullptr;
+	int nmatches = 0, nfallback = 0;
+
+	for (int i = 0; i < g.nq; ++i) {
+		const bool qok = g.qvalid ? g.qvalid[q0 + i] != 0 : true;   // uniform
+		if (!qok) { if (g.mode != 1 && lane == 0) outM[i] = -1; continue; }
+		int d = 0x7FFFFFFF, idx = -1;
+		if (lane < K) { const size_t o = ((size_t)set * g.nq + i) * K + lane; d = g.topDist[o]; idx = g.topIdx[o]; }
+		const bool freeE = idx >= 0 && !((matched[idx >> 5] >> (idx & 31)) & 1u);
+		const unsigned long long bal = __ballot(freeE);
+		const int lastIdx = __shfl(idx, K - 1), dK = __shfl(d, K - 1);
+		const bool full = lastIdx >= 0;
+		const int qg = useGroup ? g.qgroup[q0 + i] : 0;
+
+		// lazily loaded query row for rescans
+		uint32_t q[DW], qm[DW];
+		bool qLoaded = false;
+		auto load_q = [&]() {
+			if (qLoaded) return;
+			const uint32_t* qp = reinterpret_cast<const uint32_t*>(g.qd + (q0 + i) * g.qstride);
+#pragma unroll
+			for (int w = 0; w < DW; ++w) q[w] = qp[w];
+			if (MASKED) {
+				const uint32_t* mp = reinterpret_cast<const uint32_t*>(g.qm + (q0 + i) * g.qstride);
+#pragma unroll
+				for (int w = 0; w < DW; ++w) qm[w] = mp[w];
+			}
+			qLoaded = true;
+		};
+		// smallest key > after with distance <= bound among free, eligible train rows (0xFFFFFFFF if none); also second smallest
+		auto rescan = [&](uint32_t after, int bound, uint32_t& k1, uint32_t& k2) {
+			load_q();
+			uint32_t a = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
+			for (int j = lane; j < g.nt; j += 64) {
+				if ((matched[j >> 5] >> (j & 31)) & 1u) continue;
+				if (g.tvalid && g.tvalid[t0 + j] == 0) continue;
+				if (useGroup && g.tgroup[t0 + j] != qg) continue;
+				const uint32_t* tp = reinterpret_cast<const uint32_t*>(g.td + (t0 + j) * g.tstride);
+				const uint32_t* mp = MASKED ? reinterpret_cast<const uint32_t*>(g.tm + (t0 + j) * g.tstride) : tp;
+				const int dist = hamming_g<DW, MASKED>(q, qm, tp, mp);
+				if (dist > bound) continue;
+				const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)j;
+				if (key <= after && after != 0xFFFFFFFFu) continue;
+				if (key < a) { b2 = a; a = key; } else if (key < b2) b2 = key;
+			}
+			const uint32_t m1 = wave_min_u32(a);
+			const uint32_t m2 = wave_min_u32(a == m1 ? b2 : a);   // keys are unique (index bits), so exactly one lane owns m1
+			k1 = m1; k2 = m2;
+		};
+
+		if (g.mode != 2) {
+			const int n = __popcll(bal);
+			int best = 0x7FFFFFFF, bestIdx = -1, second = 0x7FFFFFFF;
+			bool needScan = false, reject = false;
+			if (n >= 1) { const int e0 = __ffsll((long long)bal) - 1; best = __shfl(d, e0); bestIdx = __shfl(idx, e0); }
+			if (n >= 2) { const int e1 = __ffsll((long long)(bal & (bal - 1))) - 1; second = __shfl(d, e1); }
+			if (n < 2 && full) {   // the list may continue beyond K entries, every hidden entry has distance >= dK
+				if (n == 1) {
+					const bool pass = g.thInclusive ? best <= g.thLow : best < g.thLow;
+					if (!pass) reject = true;
+					else if (static_cast<double>(best) < g.ratio * static_cast<double>(dK)) second = dK;   // accepted for any second >= dK
+					else needScan = true;
+				} else {
+					const bool pass = g.thInclusive ? dK <= g.thLow : dK < g.thLow;
+					if (!pass) reject = true; else needScan = true;
+				}
+			}
+			if (needScan) {
+				uint32_t k1, k2;
+				rescan(0xFFFFFFFFu, 0x7FF, k1, k2);
+				++nfallback;
+				best = k1 == 0xFFFFFFFFu ? 0x7FFFFFFF : (int)(k1 >> 20);
+				bestIdx = k1 == 0xFFFFFFFFu ? -1 : (int)(k1 & 0xFFFFFu);
+				second = k2 == 0xFFFFFFFFu ? 0x7FFFFFFF : (int)(k2 >> 20);
+			}
+			bool accept = false;
+			if (!reject && bestIdx >= 0) {
+				const bool pass = g.thInclusive ? best <= g.thLow : best < g.thLow;
+				accept = pass && (static_cast<double>(best) < g.ratio * static_cast<double>(second));
+			}
+			if (accept) {
+				if (lane == 0) {
+					matched[bestIdx >> 5] |= 1u << (bestIdx & 31);
+					if (g.mode == 0) outM[i] = bestIdx; else outM[bestIdx] = i;
+				}
+				++nmatches;
+			} else if (g.mode == 0 && lane == 0) outM[i] = -1;
+			__syncthreads();   // single wave: orders the LDS bitmap update before the next query's reads
+		} else {
+			// ---- SearchForTriangulationRaw
+			int bestDist = -1, distTh = 0x7FFFFFFF, found = -1;
+			uint32_t lastKey = 0xFFFFFFFFu;
+			bool exhausted = true;   // ran off a full list without a stop condition
+			const double* ray1 = g.rays1 + (q0 + i) * 3;
+			const double* Em = g.E + (size_t)9 * ((size_t)qg * g.nrCams + qg);   // same-camera rule: camIdx2 == camIdx1
+			for (int e = 0; e < K; ++e) {
+				const int de = __shfl(d, e), ie = __shfl(idx, e);
+				if (ie < 0 || de > g.thLow) { exhausted = false; break; }
+				lastKey = ((uint32_t)de << 20) | (uint32_t)ie;
+				if ((matched[ie >> 5] >> (ie & 31)) & 1u) continue;
+				if (bestDist < 0) { bestDist = de; distTh = 2 * de; }
+				if (de > distTh) { exhausted = false; break; }
+				if (check_epipolar(ray1, g.rays2 + (t0 + ie) * 3, Em, 1e-2)) { found = ie; exhausted = false; break; }
+			}
+			if (exhausted && full) {
+				for (int guard = 0; guard < g.nt; ++guard) {
+					uint32_t k1, k2;
+					const int bound = bestDist < 0 ? g.thLow : (distTh < g.thLow ? distTh : g.thLow);
+					rescan(lastKey, bound, k1, k2);
+					++nfallback;
+					if (k1 == 0xFFFFFFFFu) break;
+					const int de = (int)(k1 >> 20), ie = (int)(k1 & 0xFFFFFu);
+					if (bestDist < 0) { bestDist = de; distTh = 2 * de; }
+					if (de > distTh) break;
+					if (check_epipolar(ray1, g.rays2 + (t0 + ie) * 3, Em, 1e-2)) { found = ie; break; }
+					lastKey = k1;
+				}
+			}
+			if (found >= 0) { if (lane == 0) matched[found >> 5] |= 1u << (found & 31); ++nmatches; }
+			if (lane == 0) outM[i] = found;
+			__syncthreads();
+		}
+	}
+	if (lane == 0) {
+		g.outCount[set] = nmatches;
+		if (g.outFallbacks) g.outFallbacks[set] = nfallback;
+	}
+}
+
+template <int DW>
+static void launch_dw(const GreedyArgs& g, hipStream_t s) {
+	if (g.qm && g.tm) hipLaunchKernelGGL((k_greedy<DW, true>), dim3(g.nsets), dim3(64), 0, s, g);
+	else hipLaunchKernelGGL((k_greedy<DW, false>), dim3(g.nsets), dim3(64), 0, s, g);
+}
+
+void launch_greedy(const GreedyArgs& g, hipStream_t s) {
+	if (g.dim == 16) launch_dw<4>(g, s);
+	else if (g.dim == 32) launch_dw<8>(g, s);
+	else launch_dw<16>(g, s);
+}
+
+__global__ void k_rows_valid(const int* nkp, int nimg, int cap, uint8_t* valid) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nimg * cap) valid[i] = (i % cap) < nkp[i / cap] ? 1 : 0;
+}
+
+void launch_rows_valid(const int* nkp, int nimg, int cap, uint8_t* valid, hipStream_t s) {
+	hipLaunchKernelGGL(k_rows_valid, dim3((nimg * cap + 255) / 256), dim3(256), 0, s, nkp, nimg, cap, valid);
+}
+
+}  // namespace mcs

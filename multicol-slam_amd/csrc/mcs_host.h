@@ -1,0 +1,49 @@
+// mcs_host.h — host-side internals shared by the C-ABI translation units (context, error plumbing).
+#pragma once
+#include "mcs_common.h"
+#include <cmath>
+#include <map>
+#include <string>
+
+std::string& mcs_err();
+inline int fail(int code, const std::string& msg) { mcs_err() = msg; return code; }
+#define HIPCHK(expr)                                                                                       \
+	do {                                                                                                   \
+		hipError_t _e = (expr);                                                                            \
+		if (_e != hipSuccess) return fail(MCS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+	} while (0)
+
+static inline int cvRound_(double v) { return (int)lrint(v); }
+static inline int cvRoundf_(float v) { return (int)lrintf(v); }
+static inline int cvFloor_(double v) { int i = (int)v; return i - (i > v); }
+static inline short sat_short(float v) { int iv = cvRoundf_(v); return (short)(iv < -32768 ? -32768 : iv > 32767 ? 32767 : iv); }
+
+struct Timer { hipEvent_t a = nullptr, b = nullptr; bool used = false; };
+
+struct mcs_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool ownStream = false;
+	bool timing = false;
+	std::map<std::string, Timer> timers;
+	// matcher scratch
+	uint32_t* partial = nullptr; size_t partialCap = 0;
+	int* partialCount = nullptr; size_t partialCountCap = 0;
+	uint8_t* stage = nullptr; size_t stageCap = 0;   // host-kind staging for the matcher
+	int* dscalar = nullptr;
+	int *topDist = nullptr, *topIdx = nullptr, *topCnt = nullptr; size_t topDistCap = 0, topIdxCap = 0, topCntCap = 0;   // top-K lists feeding the greedy kernels
+	uint8_t* stageOut = nullptr; size_t stageOutCap = 0;
+
+	void tic(const char* name) {
+		if (!timing) return;
+		Timer& t = timers[name];
+		if (!t.a) { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
+		(void)hipEventRecord(t.a, stream);
+	}
+	void toc(const char* name) {
+		if (!timing) return;
+		Timer& t = timers[name];
+		(void)hipEventRecord(t.b, stream);
+		t.used = true;
+	}
+};

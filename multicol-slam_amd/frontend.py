@@ -1,0 +1,295 @@
+"""Host-side mirror of the reference's class surface for the hot path (same names, argument meaning and outputs):
+
+  mdBRIEFextractorOct / ORBextractor   include/mdBRIEFextractorOct.h:335-421, include/cORBextractor.h:61-63
+  cMultiFrame (extraction part)        include/cMultiFrame.h:62-162, src/cMultiFrame.cpp:92-216,342-353
+  cORBmatcher (brute-force searches)   include/cORBmatcher.h:43-133, src/cORBmatcher.cpp:46-65,179-323,885-1155
+  DescriptorDistance64[_Masked]        src/cORBmatcher.cpp:2438-2474
+
+Everything numeric runs in libmcs_hip.so on the GPU; this file only shapes inputs/outputs (numpy stands in for cv::Mat).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import Context, Extractor
+from ._capi import KP_DTYPE, MEM_HOST, DescSet, check, lib, make_ocam, np_ptr
+
+FRAME_GRID_ROWS, FRAME_GRID_COLS = 48, 64   # include/cMultiFrame.h
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class cCamModelGeneral_:
+    """Scaramuzza omni camera (include/cam_model_omni.h); holds the calibration and the level-0 mirror mask."""
+
+    def __init__(self, cdeu0v0, p, invP, Iw, Ih, mirror_mask=None):
+        c, d, e, u0, v0 = cdeu0v0
+        self.calib = dict(c=c, d=d, e=e, u0=u0, v0=v0, p=list(p), invP=list(invP), width=int(Iw), height=int(Ih))
+        self.ocam = make_ocam(self.calib)
+        self._mask = mirror_mask
+
+    @classmethod
+    def from_dict(cls, cam, mirror_mask=None):
+        return cls((cam["c"], cam["d"], cam["e"], cam["u0"], cam["v0"]), cam["p"], cam["invP"], cam["width"], cam["height"], mirror_mask)
+
+    def GetWidth(self):
+        return self.calib["width"]
+
+    def GetHeight(self):
+        return self.calib["height"]
+
+    def GetMirrorMask(self, level=0):
+        assert level == 0, "only level 0 is used by the extractor (src/cMultiFrame.cpp:138)"
+        return self._mask
+
+
+class cMultiCamSys_:
+    def __init__(self, cam_models):
+        self.cams = list(cam_models)
+
+    def GetNrCams(self):
+        return len(self.cams)
+
+    def GetCamModelObj(self, c):
+        return self.cams[c]
+
+
+class mdBRIEFextractorOct:
+    """Same 13 constructor arguments as the reference (include/mdBRIEFextractorOct.h:339-351)."""
+
+    HARRIS_SCORE, FAST_SCORE = 0, 1
+
+    def __init__(self, _nfeatures=1000, _scaleFactor=1.2, _nlevels=8, _edgeThreshold=25, _firstLevel=0, _scoreType=0, _patchSize=32,
+                 _fastThreshold=20, _useAgast=False, _fastAgastType=2, _do_dBrief=False, _learnMasks=False, _descSize=32, ctx=None):
+        self.kw = dict(nfeatures=_nfeatures, scaleFactor=_scaleFactor, nlevels=_nlevels, edgeThreshold=_edgeThreshold, firstLevel=_firstLevel,
+                       scoreType=_scoreType, patchSize=_patchSize, fastThreshold=_fastThreshold, useAgast=int(_useAgast),
+                       fastAgastType=_fastAgastType, do_dBrief=int(_do_dBrief), learnMasks=int(_learnMasks), descSize=_descSize)
+        self.ctx = ctx or default_context()
+        self._ex = {}
+
+    def _extractor(self, w, h, batch):
+        key = (w, h)
+        ex = self._ex.get(key)
+        if ex is None or ex.max_batch < batch:
+            if ex is not None:
+                ex.close()
+            ex = Extractor(self.ctx, w, h, max_batch=max(batch, 1), **self.kw)
+            self._ex[key] = ex
+        return ex
+
+    def __call__(self, image, mask, camModel):
+        """operator()(image, mask, keypoints, camModel, descriptors, descriptorMasks) -> (keypoints, descriptors, descriptorMasks)."""
+        if image is None or image.size == 0:
+            return np.zeros(0, KP_DTYPE), None, None     # empty image -> silent return (:1252-1253)
+        assert image.dtype == np.uint8 and image.ndim == 2   # assert(image.type() == CV_8UC1) (:1256)
+        h, w = image.shape
+        ex = self._extractor(w, h, 1)
+        cams = None if camModel is None else [camModel.ocam]
+        kps, d, dm, _ = ex.extract_host([image], None if mask is None else [mask], cams, want_rays=False)[0]
+        if len(kps) == 0:
+            return kps, None, None                        # _descriptors.release() (:1270-1274)
+        return kps, d, dm
+
+    def extract_rig(self, images, masks, cam_models):
+        """All cameras of a multi-frame in ONE device batch (the GPU analogue of the reference's omp loop over cameras)."""
+        h, w = images[0].shape
+        ex = self._extractor(w, h, len(images))
+        return ex.extract_host(images, masks, [c.ocam for c in cam_models], want_rays=True)
+
+    def GetLevels(self):
+        return self.kw["nlevels"]
+
+    def GetScaleFactor(self):
+        return float(np.float32(self.kw["scaleFactor"]))   # the member is the double of the FLOAT ctor argument
+
+    def GetMasksLearned(self):
+        return bool(self.kw["learnMasks"])
+
+    def GetDescriptorSize(self):
+        return self.kw["descSize"]
+
+
+class ORBextractor(mdBRIEFextractorOct):
+    """include/cORBextractor.h (declared but never built in the reference): the extractor in ORB mode."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, scoreType=1, fastTh=20, ctx=None):
+        super().__init__(nfeatures, scaleFactor, nlevels, 25, 0, scoreType, 32, fastTh, False, 2, False, False, 32, ctx=ctx)
+
+    def __call__(self, image, mask):
+        kps, d, _ = super().__call__(image, mask, None)
+        return kps, d
+
+
+class cMultiFrame:
+    """Extraction part of cMultiFrame::cMultiFrame (src/cMultiFrame.cpp:92-216): public fields the matcher/tracker read."""
+
+    nNextId = 0
+
+    def __init__(self, images, timeStamp, extractor, voc, camSystem, imgCnt=0):
+        nrCams = camSystem.GetNrCams()
+        self.images, self.mTimeStamp, self.camSystem, self.imgCnt = images, timeStamp, camSystem, imgCnt
+        ex0 = extractor[0] if isinstance(extractor, (list, tuple)) else extractor
+        cams = [camSystem.GetCamModelObj(c) for c in range(nrCams)]
+        masks = [cm.GetMirrorMask(0) for cm in cams]
+        res = ex0.extract_rig(list(images), None if any(m is None for m in masks) else masks, cams)
+        self.mDescriptors = [r[1] for r in res]
+        self.mDescriptorMasks = [r[2] for r in res]
+        self.N = [len(r[0]) for r in res]
+        self.totalN = int(sum(self.N))
+        self.mvKeys = np.concatenate([r[0] for r in res]) if self.totalN else np.zeros(0, KP_DTYPE)
+        self.mvKeysRays = np.concatenate([r[3] for r in res]) if self.totalN else np.zeros((0, 3))
+        self.keypoint_to_cam = np.concatenate([np.full(n, c, np.int32) for c, n in enumerate(self.N)]) if self.totalN else np.zeros(0, np.int32)
+        self.cont_idx_to_local_cam_idx = np.concatenate([np.arange(n, dtype=np.int32) for n in self.N]) if self.totalN else np.zeros(0, np.int32)
+        self.mnMinX, self.mnMinY = [0] * nrCams, [0] * nrCams
+        self.mnMaxX = [cm.GetWidth() for cm in cams]
+        self.mnMaxY = [cm.GetHeight() for cm in cams]
+        self.mfGridElementWidthInv = [FRAME_GRID_COLS / float(self.mnMaxX[c] - self.mnMinX[c]) for c in range(nrCams)]
+        self.mfGridElementHeightInv = [FRAME_GRID_ROWS / float(self.mnMaxY[c] - self.mnMinY[c]) for c in range(nrCams)]
+        self.mGrids = [[[[] for _ in range(FRAME_GRID_ROWS)] for _ in range(FRAME_GRID_COLS)] for _ in range(nrCams)]
+        for i in range(self.totalN):   # serial flatten + grid fill (:167-184)
+            c = int(self.keypoint_to_cam[i])
+            ok, gx, gy = self.PosInGrid(c, self.mvKeys[i])
+            if ok:
+                self.mGrids[c][gx][gy].append(i)
+        self.mvbOutlier = [False] * self.totalN
+        self.mvpMapPoints = [None] * self.totalN
+        self.mnId = cMultiFrame.nNextId
+        cMultiFrame.nNextId += 1
+        self.mnScaleLevels = ex0.GetLevels()
+        self.mfScaleFactor = ex0.GetScaleFactor()
+        self.mvScaleFactors, self.mvLevelSigma2 = [1.0], [1.0]
+        for i in range(1, self.mnScaleLevels):
+            self.mvScaleFactors.append(self.mvScaleFactors[i - 1] * self.mfScaleFactor)
+            self.mvLevelSigma2.append(self.mvScaleFactors[i] * self.mvScaleFactors[i])
+        self.mvInvLevelSigma2 = [1 / s for s in self.mvLevelSigma2]
+        self.masksLearned = ex0.GetMasksLearned()
+        self.descDimension = ex0.GetDescriptorSize()
+
+    def PosInGrid(self, cam, kp):   # src/cMultiFrame.cpp:342-353 (cvRound, not floor; bins 64 / 48 are dropped)
+        posX = int(np.rint((float(kp["x"]) - self.mnMinX[cam]) * self.mfGridElementWidthInv[cam]))
+        posY = int(np.rint((float(kp["y"]) - self.mnMinY[cam]) * self.mfGridElementHeightInv[cam]))
+        if posX < 0 or posX >= FRAME_GRID_COLS or posY < 0 or posY >= FRAME_GRID_ROWS:
+            return False, posX, posY
+        return True, posX, posY
+
+    # flat (all cameras concatenated) descriptor views, the row order of mvKeys
+    def all_descriptors(self):
+        return np.concatenate(self.mDescriptors) if self.totalN else np.zeros((0, self.descDimension), np.uint8)
+
+    def all_masks(self):
+        return np.concatenate(self.mDescriptorMasks) if self.totalN else np.zeros((0, self.descDimension), np.uint8)
+
+
+class cMultiKeyFrame:
+    """Thin keyframe view: the accessors the brute-force searches use (src/cMultiKeyFrame.cpp:54,77,356-364)."""
+
+    def __init__(self, F):
+        self.camSystem = F.camSystem
+        self.mDescriptors, self.mDescriptorMasks = F.mDescriptors, F.mDescriptorMasks   # shallow copies like cv::Mat
+        self.mvKeys, self.mvKeysRays = F.mvKeys, F.mvKeysRays
+        self.keypoint_to_cam, self.cont_idx_to_local_cam_idx = F.keypoint_to_cam, F.cont_idx_to_local_cam_idx
+        self.mvpMapPoints = list(F.mvpMapPoints)
+        self._d, self._m = F.all_descriptors(), F.all_masks()
+
+    def GetMapPointMatches(self):
+        return self.mvpMapPoints
+
+    def GetKeyPoints(self):
+        return self.mvKeys
+
+    def GetKeyPointsRays(self):
+        return self.mvKeysRays
+
+
+def _good(mp):
+    return mp is not None and not (hasattr(mp, "isBad") and mp.isBad())
+
+
+class cORBmatcher:
+    """cORBmatcher(nnratio, checkOri, featDim, havingMasks) (src/cORBmatcher.cpp:46-65); brute-force searches only."""
+
+    HISTO_LENGTH = 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, featDim=32, havingMasks_=False, ctx=None, K=8):
+        self.mfNNratio, self.mbCheckOrientation, self.mbFeatDim, self.havingMasks = nnratio, checkOri, featDim, havingMasks_
+        if havingMasks_:
+            self.TH_HIGH_, self.TH_LOW_ = int(np.floor(1.5 * featDim)), int(np.floor(featDim))
+        else:
+            self.TH_HIGH_, self.TH_LOW_ = 3 * featDim, 2 * featDim
+        if checkOri:
+            raise NotImplementedError("mbCheckOrientation is false at every reference call site (include/cORBmatcher.h:40)")
+        self.ctx = ctx or default_context()
+        self.K = K
+        self.last_fallbacks = 0
+
+    def _sets(self, d1, m1, v1, g1, d2, m2, v2, g2):
+        keep = [np.ascontiguousarray(d1, np.uint8), np.ascontiguousarray(d2, np.uint8)]
+        mm = [None, None]
+        if self.havingMasks:
+            mm = [np.ascontiguousarray(m1, np.uint8), np.ascontiguousarray(m2, np.uint8)]
+        q = DescSet(np_ptr(keep[0]), np_ptr(mm[0]), np_ptr(v1), np_ptr(g1), keep[0].shape[0], self.mbFeatDim)
+        t = DescSet(np_ptr(keep[1]), np_ptr(mm[1]), np_ptr(v2), np_ptr(g2), keep[1].shape[0], self.mbFeatDim)
+        return q, t, (keep, mm, v1, v2, g1, g2)
+
+    def SearchByBoW(self, pKF1, other):
+        """(KF,KF) -> (nmatches, vpMatches12) with vpMatches12[idx1] = map point of KF2 (src/cORBmatcher.cpp:885-966);
+        (KF,F)  -> (nmatches, vpMapPointMatches) indexed by frame feature (:179-323, vocabulary restriction removed)."""
+        mp1 = pKF1.GetMapPointMatches()
+        v1 = np.array([_good(m) for m in mp1], np.uint8)
+        fb = np.zeros(1, np.int32)
+        nm = np.zeros(1, np.int32)
+        if isinstance(other, cMultiKeyFrame):
+            mp2 = other.GetMapPointMatches()
+            v2 = np.array([_good(m) for m in mp2], np.uint8)
+            q, t, keep = self._sets(pKF1._d, pKF1._m, v1, None, other._d, other._m, v2, None)
+            m12 = np.full(max(len(mp1), 1), -1, np.int32)
+            check(lib().mcs_search_kf_kf(self.ctx.h, 1, C.byref(q), 0, C.byref(t), 0, self.mbFeatDim, self.mfNNratio, self.K, MEM_HOST,
+                                         np_ptr(m12), np_ptr(nm), np_ptr(fb)))
+            self.last_fallbacks = int(fb[0])
+            return int(nm[0]), [mp2[j] if j >= 0 else None for j in m12[:len(mp1)]]
+        F = other
+        q, t, keep = self._sets(pKF1._d, pKF1._m, v1, None, F.all_descriptors(), F.all_masks(), None, None)
+        mF = np.full(max(F.totalN, 1), -1, np.int32)
+        check(lib().mcs_search_kf_f(self.ctx.h, 1, C.byref(q), 0, C.byref(t), 0, self.mbFeatDim, self.mfNNratio, self.K, MEM_HOST, np_ptr(mF),
+                                    np_ptr(nm), np_ptr(fb)))
+        self.last_fallbacks = int(fb[0])
+        return int(nm[0]), [mp1[i] if i >= 0 else None for i in mF[:F.totalN]]
+
+    def SearchForTriangulationRaw(self, pKF1, pKF2, Es):
+        """-> (nmatches, vMatchedKeys1, vMatchedKeysRays1, vMatchedKeys2, vMatchedKeysRays2, vMatchedPairs) (:968-1155).
+        Es: [nrCams][nrCams] 3x3 essential matrices (the reference precomputes them from the rig poses, :990-1003)."""
+        nr = pKF1.camSystem.GetNrCams()
+        E = np.ascontiguousarray(np.asarray(Es, np.float64).reshape(nr * nr, 9))
+        v1 = np.array([m is None for m in pKF1.GetMapPointMatches()], np.uint8)    # "if (pMP1) continue"
+        v2 = np.array([m is None for m in pKF2.GetMapPointMatches()], np.uint8)
+        g1 = np.ascontiguousarray(pKF1.keypoint_to_cam, np.int32)
+        g2 = np.ascontiguousarray(pKF2.keypoint_to_cam, np.int32)
+        q, t, keep = self._sets(pKF1._d, pKF1._m, v1, g1, pKF2._d, pKF2._m, v2, g2)
+        r1 = np.ascontiguousarray(pKF1.mvKeysRays, np.float64)
+        r2 = np.ascontiguousarray(pKF2.mvKeysRays, np.float64)
+        m12 = np.full(max(len(v1), 1), -1, np.int32)
+        nm = np.zeros(1, np.int32)
+        fb = np.zeros(1, np.int32)
+        check(lib().mcs_search_triangulation(self.ctx.h, 1, C.byref(q), 0, C.byref(t), 0, np_ptr(r1), np_ptr(r2), np_ptr(E), nr, self.mbFeatDim,
+                                             max(self.K, 16), MEM_HOST, np_ptr(m12), np_ptr(nm), np_ptr(fb)))
+        self.last_fallbacks = int(fb[0])
+        pairs = [(i, int(j)) for i, j in enumerate(m12[:len(v1)]) if j >= 0]
+        i1 = [p[0] for p in pairs]
+        i2 = [p[1] for p in pairs]
+        return int(nm[0]), pKF1.mvKeys[i1], pKF1.mvKeysRays[i1], pKF2.mvKeys[i2], pKF2.mvKeysRays[i2], pairs
+
+
+def DescriptorDistance64(descr_i, descr_j, dim=32, ctx=None):
+    return (ctx or default_context()).descriptor_distance(np.frombuffer(descr_i, np.uint8)[:dim], np.frombuffer(descr_j, np.uint8)[:dim])
+
+
+def DescriptorDistance64Masked(descr_i, descr_j, mask_i, mask_j, dim=32, ctx=None):
+    f = lambda a: np.frombuffer(a, np.uint8)[:dim]
+    return (ctx or default_context()).descriptor_distance(f(descr_i), f(descr_j), f(mask_i), f(mask_j))

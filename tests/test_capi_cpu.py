@@ -1,0 +1,77 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/mcs_c.h declares, fails
+loudly without a GPU, and the product never touches the oracle."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as ge
+    ge.build()
+    return importlib.import_module("multicol-slam_amd")
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "mcs_c.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcs_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    names = _declared()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(L, n), "libmcs_hip.so does not export %s" % n
+    assert sorted(pkg._capi.EXPORTS) == names
+
+
+def test_fails_loudly_without_gpu(pkg):
+    n = C.c_int32(-1)
+    rc = pkg.lib().mcs_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.McsError):
+        pkg.Context(0)
+
+
+def test_struct_layouts(pkg):
+    assert C.sizeof(pkg._capi.KeyPoint) == 28 and pkg.KP_DTYPE.itemsize == 28       # cv::KeyPoint
+    assert C.sizeof(pkg._capi.ExtractorParams) == 13 * 4
+    assert C.sizeof(pkg._capi.Ocam) == 5 * 8 + 16 * 8 + 8 + 16 * 8 + 8 + 8
+    assert C.sizeof(pkg._capi.DescSet) == 4 * 8 + 8
+
+
+def test_product_never_touches_the_oracle():
+    bad = []
+    for d, _, files in os.walk(os.path.join(ROOT, "multicol-slam_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
+                txt = open(os.path.join(d, f), errors="replace").read()
+                if re.search(r"oracle_lib|mcs_oracle|libmcs_oracle|orc_[a-z]", txt):
+                    bad.append(os.path.join(d, f))
+    for d, _, files in os.walk(os.path.join(ROOT, "include")):
+        for f in files:
+            if re.search(r"mcs_oracle|orc_[a-z]", open(os.path.join(d, f), errors="replace").read()):
+                bad.append(os.path.join(d, f))
+    assert not bad, bad
+
+
+def test_synthetic_inputs_are_deterministic_and_rich(synth):
+    cams = synth.lafida_cameras()
+    a = synth.synth_image(3, 1, cams[1])
+    b = synth.synth_image(3, 1, cams[1])
+    assert (a == b).all() and a.shape == (480, 754) and a.dtype.name == "uint8"
+    m = synth.mirror_mask(cams[1])
+    assert (a[m == 0] == 0).all() and a[m != 0].std() > 20
+    c = synth.synth_image(4, 1, cams[1])   # next frame = same scene shifted by (3,1)
+    inner = (slice(100, 380), slice(200, 550))
+    assert abs(a[inner].astype(int) - c[101:381, 203:553].astype(int)).mean() < 4.0
+    big = synth.scaled_camera(cams[0], 1280, 800)
+    assert big["width"] == 1280 and abs(big["u0"] - cams[0]["u0"] * 1280 / 754) < 1e-9
