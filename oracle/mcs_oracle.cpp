@@ -1066,4 +1066,47 @@ long orc_extract_many(const orc_params* p, int nimg, const uint8_t* const* imgs,
 	return total;
 }
 
+long orc_extract_match_many(const orc_params* p, int nframes, int ncam, const uint8_t* const* imgs, int w, int h, int stride,
+                            const uint8_t* const* masks, const orc_ocam* cams, int threads, double nnratio, int* nmatch, double* seconds) {
+	const int nimg = nframes * ncam, cap = p->nfeatures + 4 * p->nlevels, ds = p->descSize;
+	std::vector<orc_keypoint> kps((size_t)nimg * cap);
+	std::vector<int> nkp(nimg, 0);
+	std::vector<uint8_t> desc((size_t)nimg * cap * ds), dmask((size_t)nimg * cap * ds);
+#ifdef _OPENMP
+	double t0 = omp_get_wtime();
+#else
+	double t0 = 0;
+#endif
+	long total = orc_extract_many(p, nimg, imgs, w, h, stride, masks, cams, threads, kps.data(), cap, nkp.data(), desc.data(), dmask.data());
+#ifdef _OPENMP
+	double t1 = omp_get_wtime();
+#else
+	double t1 = 0;
+#endif
+	// flatten every multi-frame (cameras concatenated, like cMultiFrame's mvKeys order)
+	std::vector<std::vector<uint8_t> > fd(nframes), fm(nframes);
+	for (int f = 0; f < nframes; ++f)
+		for (int c = 0; c < ncam; ++c) {
+			const int i = f * ncam + c;
+			fd[f].insert(fd[f].end(), desc.begin() + (size_t)i * cap * ds, desc.begin() + ((size_t)i * cap + nkp[i]) * ds);
+			fm[f].insert(fm[f].end(), dmask.begin() + (size_t)i * cap * ds, dmask.begin() + ((size_t)i * cap + nkp[i]) * ds);
+		}
+	nmatch[0] = 0;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+	for (int f = 1; f < nframes; ++f) {
+		const int n1 = (int)(fd[f].size() / ds), n2 = (int)(fd[f - 1].size() / ds);
+		std::vector<uint8_t> v1(n1, 1), v2(n2, 1);
+		std::vector<int> m12(n1 > 0 ? n1 : 1);
+		nmatch[f] = orc_search_kf_kf(fd[f].data(), fm[f].data(), v1.data(), n1, fd[f - 1].data(), fm[f - 1].data(), v2.data(), n2, ds, p->learnMasks,
+		                             nnratio, m12.data());
+	}
+#ifdef _OPENMP
+	double t2 = omp_get_wtime();
+#else
+	double t2 = 0;
+#endif
+	if (seconds) { seconds[0] = t1 - t0; seconds[1] = t2 - t1; }
+	return total;
+}
+
 }  // extern "C"

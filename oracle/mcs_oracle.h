@@ -101,6 +101,11 @@ long orc_extract_many(const orc_params* p, int nimg, const uint8_t* const* imgs,
                       const uint8_t* const* masks, const orc_ocam* cams, int threads,
                       orc_keypoint* kps, int cap, int* nkp, uint8_t* desc, uint8_t* dmask);
 int orc_num_threads(void);
+/* extract nframes multi-frames of ncam cameras (image f*ncam+c), then SearchByBoW(KF,KF) of every multi-frame f >= 1
+ * against multi-frame f-1 (all features "have map points"); OpenMP over images / frames.  Returns total keypoints;
+ * nmatch[f] = matches of frame f (nmatch[0] = 0); seconds[0] = extraction wall time, seconds[1] = matching wall time. */
+long orc_extract_match_many(const orc_params* p, int nframes, int ncam, const uint8_t* const* imgs, int w, int h, int stride,
+                            const uint8_t* const* masks, const orc_ocam* cams, int threads, double nnratio, int* nmatch, double* seconds);
 
 #ifdef __cplusplus
 }
