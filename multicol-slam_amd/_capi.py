@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcs_hip.so")
+LIB_PATH = os.environ.get("MCS_HIP_LIB", os.path.join(_HERE, "libmcs_hip.so"))   # override only for A/B kernel experiments
 
 MCS_OK, MCS_ERR_INVALID, MCS_ERR_HIP, MCS_ERR_CAPACITY, MCS_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 MEM_HOST, MEM_DEVICE = 0, 1

@@ -93,15 +93,17 @@ struct Sampler {
 	}
 };
 
+#ifndef MCS_ABLATE
+#define MCS_ABLATE 0   // A/B experiments only: 1 skip the sequential mean, 2 skip the omni model, 4 skip sampling
+#endif
 constexpr int kMaxBallots = 8;   // descSize 64 -> 512 pairs -> 8 ballots
 
-template <int MODE>   // 0 ORB, 1 dBRIEF, 2 mdBRIEF
-__global__ __launch_bounds__(256) void k_describe(ExtractBuffers b, int wavesPerImage) {
-	extern __shared__ __attribute__((aligned(16))) double lds[];   // [4 waves][2][npoints] distorted coordinates (MODE > 0)
-	__shared__ double meanv[4][2];
+template <int MODE, int NB>   // MODE 0 ORB, 1 dBRIEF, 2 mdBRIEF; NB = descSize/8 ballots
+__global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffers b, int wavesPerImage) {
+	extern __shared__ __attribute__((aligned(16))) double lds[];   // MODE > 0: [waves][2 buffers][x|y][npoints]
 	const PyrDesc& d = *b.desc;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int gw = blockIdx.x * 4 + wave;
+	const int gw = blockIdx.x * (MODE == 0 ? 4 : 1) + wave;
 	const int img = gw / wavesPerImage;
 	const int s = gw - img * wavesPerImage;
 	const int* selCount = b.selCount + (size_t)img * d.nlevels;
@@ -116,9 +118,9 @@ __global__ __launch_bounds__(256) void k_describe(ExtractBuffers b, int wavesPer
 	bool active = level >= 0 && s < d.selPerImage && pos < selCount[level >= 0 ? level : 0];
 	const int out = before + pos;
 	if (active && out >= d.kpCap) { if (lane == 0) atomicExch(b.status, MCS_ERR_CAPACITY); active = false; }
-	if (MODE == 0 && !active) return;   // no barriers in ORB mode
+	if (!active) return;   // waves are independent (no block barriers anywhere in this kernel)
 
-	const int np = d.npoints, nballots = d.descSize / 8;
+	constexpr int nballots = NB;
 	float angle = 0.f, pxf = 0.f, pyf = 0.f;
 	int row = 0, col = 0;
 	Sampler sm = {};
@@ -182,99 +184,105 @@ __global__ __launch_bounds__(256) void k_describe(ExtractBuffers b, int wavesPer
 	}
 
 	// ---------------------------------------------------------------- dBRIEF / mdBRIEF
-	double* xs = lds + (size_t)wave * 2 * np;
-	double* ys = xs + np;
-	double ukx = 0.0, uky = 0.0, zc = 0.0;
-	double angles[3] = {0.0, 0.0, 0.0};
-	if (active) {
-		const OcamDev& cam = b.cams[img];
-		zc = -cam.p[0];   // distortPointsOcam: WorldToImg(x, y, -p1)
-		if (d.undistort) {   // undistortPointsOcam(pt*scale, scaleF = p[0]) (:1306-1317)
-			double x, y, z;
-			img2world(cam, (double)pxf, (double)pyf, x, y, z);
-			ukx = -x / z * cam.p[0];
-			uky = -y / z * cam.p[0];
-		}
-		if (MODE == 1) {
-			const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
-			angles[0] = (double)(angle * DEG2RADf);
-		} else {
-			const float RHOf = 180.0f / 3.1415926535897932384626f;
-			const double RHOd = 180.0 / 3.1415926535897932384626433832795028841971693993;
-			const double rot = 20.0 / RHOd;
-			const double a = (double)(angle / RHOf);
-			angles[0] = a; angles[1] = a + rot; angles[2] = a - rot;
-		}
+	// Waves are independent here (one keypoint per wave, private LDS slice, no block barrier).
+	if (!active) return;
+	constexpr int NP = 128 * NB;              // pattern points = 2*8*descSize
+	constexpr int CH = NP / (2 * NB);         // chain elements folded into one point iteration (= 64)
+	double* buf = lds + (size_t)wave * 2 * NP;   // [x | y][NP] distorted coordinates of the current pattern
+	const OcamDev& cam = b.cams[img];
+	const double zc = -cam.p[0];              // distortPointsOcam: WorldToImg(x, y, -p1)
+	double ukx = 0.0, uky = 0.0;
+	if (d.undistort) {                        // undistortPointsOcam(pt*scale, scaleF = p[0]) (:1306-1317)
+		double x, y, z;
+		img2world(cam, (double)pxf, (double)pyf, x, y, z);
+		ukx = -x / z * cam.p[0];
+		uky = -y / z * cam.p[0];
 	}
-	unsigned long long bitsMain[kMaxBallots], agree[kMaxBallots];
+	double ang0, ang1 = 0.0, ang2 = 0.0;
+	if (MODE == 1) {
+		const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
+		ang0 = (double)(angle * DEG2RADf);
+	} else {
+		const float RHOf = 180.0f / 3.1415926535897932384626f;
+		const double RHOd = 180.0 / 3.1415926535897932384626433832795028841971693993;
+		const double rot = 20.0 / RHOd;
+		ang0 = (double)(angle / RHOf);
+		ang1 = ang0 + rot; ang2 = ang0 - rot;
+	}
+	// One pass = (optionally) the omni model of pattern `nxt` written to buffer wb, interleaved in the same straight-line
+	// code with (optionally) the SEQUENTIAL coordinate sum of the pattern in buffer rb: even lanes accumulate sum(x),
+	// odd lanes sum(y), p = 0..NP-1 in the reference's order (:264-276).  The sum is a 512-long dependent FP64 add chain;
+	// folding 64 of its steps into each of the 2*NB point evaluations lets the scheduler hide its latency under the math.
+	auto pass = [&](bool doMath, double ang, double* wb, bool doChain, const double* rb, double& sum) {
+		double ax = 0.0, ay = 0.0;
+		if (doMath) { ax = cos(ang); ay = sin(ang); }
+		const double* arr = rb + (lane & 1) * NP;
+#pragma unroll 1
+		for (int t = 0; t < 2 * NB; ++t) {
+			if (doMath) {
+				const int k = (t >> 1) * 64 + lane, e = t & 1;
+				const double px = c_pattern[4 * k + 2 * e], py = c_pattern[4 * k + 2 * e + 1];
+				const double xr = px * ax - py * ay + ukx;
+				const double yr = px * ay + py * ax + uky;
+				double u, v;
+				if (MCS_ABLATE & 2) { u = xr; v = yr; } else world2img(cam, xr, yr, zc, u, v);
+				wb[2 * k + e] = u; wb[NP + 2 * k + e] = v;
+			}
+			if (doChain && !(MCS_ABLATE & 1)) {
+#pragma unroll 16
+				for (int p = 0; p < CH; ++p) sum += arr[t * CH + p];
+			}
+		}
+	};
+	unsigned long long bitsMain[NB], agree[NB];
 #pragma unroll
-	for (int j = 0; j < kMaxBallots; ++j) { bitsMain[j] = 0ull; agree[j] = ~0ull; }
-	const int npat = MODE == 2 ? 3 : 1;
+	for (int j = 0; j < NB; ++j) { bitsMain[j] = 0ull; agree[j] = ~0ull; }
+	constexpr int npat = MODE == 2 ? 3 : 1;
+#pragma unroll
 	for (int pat = 0; pat < npat; ++pat) {
-		double xd[2 * kMaxBallots], yd[2 * kMaxBallots];
-		if (active) {
-			const OcamDev& cam = b.cams[img];
-			const double ax = cos(angles[pat]), ay = sin(angles[pat]);
+		double* cur = buf;
+		double sum = 0.0;
+		pass(true, pat == 0 ? ang0 : (pat == 1 ? ang1 : ang2), cur, false, cur, sum);
+		pass(false, 0.0, cur, true, cur, sum);
+		const double mean = sum / (double)NP;
+		const double meanX = __shfl(mean, 0), meanY = __shfl(mean, 1);
 #pragma unroll
-			for (int j = 0; j < kMaxBallots; ++j) {
-				if (j < nballots) {
-					const int k = j * 64 + lane;
-#pragma unroll
-					for (int e = 0; e < 2; ++e) {
-						const double px = c_pattern[4 * k + 2 * e], py = c_pattern[4 * k + 2 * e + 1];
-						const double xr = px * ax - py * ay + ukx;
-						const double yr = px * ay + py * ax + uky;
-						double u, v;
-						world2img(cam, xr, yr, zc, u, v);
-						xd[2 * j + e] = u; yd[2 * j + e] = v;
-						xs[2 * k + e] = u; ys[2 * k + e] = v;
-					}
-				}
-			}
+		for (int j = 0; j < NB; ++j) {
+			const int k = j * 64 + lane;
+			const int ix0 = __double2int_rn(cur[2 * k] - meanX), iy0 = __double2int_rn(cur[NP + 2 * k] - meanY);
+			const int ix1 = __double2int_rn(cur[2 * k + 1] - meanX), iy1 = __double2int_rn(cur[NP + 2 * k + 1] - meanY);
+			const int t0 = (MCS_ABLATE & 4) ? ix0 : sm.at(row + iy0, col + ix0), t1 = (MCS_ABLATE & 4) ? iy1 : sm.at(row + iy1, col + ix1);
+			const unsigned long long bits = __ballot(t0 < t1);
+			if (pat == 0) bitsMain[j] = bits;
+			else agree[j] &= ~(bits ^ bitsMain[j]);
 		}
-		__syncthreads();
-		if (active && lane < 2) {   // sumX += xcoords[p] for p = 0..npoints-1, in order (:264-276)
-			const double* arr = lane == 0 ? xs : ys;
-			double sum = 0.0;
-			for (int p = 0; p < np; p += 8) {
-				const double a0 = arr[p], a1 = arr[p + 1], a2 = arr[p + 2], a3 = arr[p + 3], a4 = arr[p + 4], a5 = arr[p + 5],
-				             a6 = arr[p + 6], a7 = arr[p + 7];
-				sum += a0; sum += a1; sum += a2; sum += a3; sum += a4; sum += a5; sum += a6; sum += a7;
-			}
-			meanv[wave][lane] = sum / (double)np;
-		}
-		__syncthreads();
-		if (active) {
-			const double meanX = meanv[wave][0], meanY = meanv[wave][1];
-#pragma unroll
-			for (int j = 0; j < kMaxBallots; ++j) {
-				if (j < nballots) {
-					const int ix0 = __double2int_rn(xd[2 * j] - meanX), iy0 = __double2int_rn(yd[2 * j] - meanY);
-					const int ix1 = __double2int_rn(xd[2 * j + 1] - meanX), iy1 = __double2int_rn(yd[2 * j + 1] - meanY);
-					const int t0 = sm.at(row + iy0, col + ix0), t1 = sm.at(row + iy1, col + ix1);
-					const unsigned long long bits = __ballot(t0 < t1);
-					if (pat == 0) bitsMain[j] = bits;
-					else agree[j] &= ~(bits ^ bitsMain[j]);
-				}
-			}
-		}
-		__syncthreads();   // xs/ys are rewritten by the next pattern
 	}
-	if (active && lane == 0) {
-		for (int j = 0; j < nballots; ++j) {
+	if (lane == 0) {
+#pragma unroll
+		for (int j = 0; j < NB; ++j) {
 			*reinterpret_cast<unsigned long long*>(dout + 8 * j) = bitsMain[j];
 			*reinterpret_cast<unsigned long long*>(mout + 8 * j) = MODE == 2 ? agree[j] : 0ull;
 		}
 	}
 }
 
+template <int MODE>
+static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
+	// ORB: 4 keypoints (waves) per 256-thread block.  dBRIEF/mdBRIEF: one wave per block with a private 2*NB KiB LDS slice.
+	const int wpb = MODE == 0 ? 4 : 1;
+	const int wavesPerImage = (hd.selPerImage + wpb - 1) / wpb * wpb;
+	const int blocks = nimg * wavesPerImage / wpb;
+	const size_t ldsBytes = MODE == 0 ? 0 : (size_t)wpb * 2 * hd.npoints * sizeof(double);
+	const int nb = hd.descSize / 8;
+	if (nb == 2) hipLaunchKernelGGL((k_describe<MODE, 2>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
+	else if (nb == 4) hipLaunchKernelGGL((k_describe<MODE, 4>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
+	else hipLaunchKernelGGL((k_describe<MODE, 8>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
+}
+
 void launch_describe(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
-	const int wavesPerImage = (hd.selPerImage + 3) / 4 * 4;
-	const int blocks = nimg * wavesPerImage / 4;
-	const size_t ldsBytes = (size_t)4 * 2 * hd.npoints * sizeof(double);
-	if (hd.mode == 0) hipLaunchKernelGGL(k_describe<0>, dim3(blocks), dim3(256), 0, s, b, wavesPerImage);
-	else if (hd.mode == 1) hipLaunchKernelGGL(k_describe<1>, dim3(blocks), dim3(256), ldsBytes, s, b, wavesPerImage);
-	else hipLaunchKernelGGL(k_describe<2>, dim3(blocks), dim3(256), ldsBytes, s, b, wavesPerImage);
+	if (hd.mode == 0) launch_mode<0>(b, hd, nimg, s);
+	else if (hd.mode == 1) launch_mode<1>(b, hd, nimg, s);
+	else launch_mode<2>(b, hd, nimg, s);
 }
 
 }  // namespace mcs

@@ -186,8 +186,173 @@ __global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Speculative wave-parallel form of the same greedy for SearchByBoW (modes 0 and 1).  64 consecutive queries are handled
+// at once, one per lane, each lane holding its own top-K list in registers:
+//   round:  every unresolved lane derives its decision (first two FREE entries of its list -> best / second -> threshold
+//           and ratio tests) against the current "matched" bitmap;  accepting lanes publish their target with an LDS
+//           atomicMin of the lane id;  a lane's decision is FINAL if no LOWER lane of this round claimed its best or its
+//           second entry (those two rows are the only free rows the decision looked at);  all lanes below the first
+//           non-final lane commit in one step, the others retry against the updated bitmap.
+// The lowest unresolved lane is always final, so every round commits at least one query; the result is identical to the
+// reference's strictly sequential loop (proof sketch: a committed lane saw exactly the bitmap the sequential loop would
+// have had, because every lower lane either committed earlier or commits in the same step without touching its rows).
+// A lane whose list cannot decide (its K entries are used up) is rescanned cooperatively by the wave when it becomes the
+// lowest unresolved lane, and blocks the lanes above it until then.
+constexpr int kClaimRows = 16384;   // train rows per set supported by the speculative kernel (LDS claim table)
+
+template <int K, int DW, bool MASKED>
+__global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
+	__shared__ uint32_t matched[kClaimRows / 32];
+	__shared__ uint32_t claim[kClaimRows];
+	const int set = blockIdx.x, lane = threadIdx.x;
+	const size_t q0 = (size_t)set * g.qpitch, t0 = (size_t)set * g.tpitch;
+	for (int i = lane; i < (g.nt + 31) / 32; i += 64) matched[i] = 0;
+	for (int i = lane; i < g.nt; i += 64) claim[i] = 0xFFFFFFFFu;
+	int* outM = g.outMatch + (size_t)set * (g.mode == 1 ? g.nt : g.nq);
+	if (g.mode == 1) for (int j = lane; j < g.nt; j += 64) outM[j] = -1;
+	__syncthreads();
+	int nmatches = 0, nfallback = 0;
+	constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+
+	for (int i0 = 0; i0 < g.nq; i0 += 64) {
+		const int i = i0 + lane;
+		const bool inRange = i < g.nq;
+		bool qok = inRange;
+		if (qok && g.qvalid) qok = g.qvalid[q0 + i] != 0;
+		uint32_t key[K];
+#pragma unroll
+		for (int e = 0; e < K; ++e) key[e] = EMPTY;
+		if (qok) {
+			const size_t o = ((size_t)set * g.nq + i) * K;
+#pragma unroll
+			for (int e = 0; e < K; ++e) {
+				const int ie = g.topIdx[o + e];
+				key[e] = ie < 0 ? EMPTY : (((uint32_t)g.topDist[o + e] << 20) | (uint32_t)ie);
+			}
+		}
+		bool resolved = !qok;
+		if (inRange && !qok && g.mode == 0) outM[i] = -1;
+		const bool full = key[K - 1] != EMPTY;
+		const int dK = full ? (int)(key[K - 1] >> 20) : 0x7FFFFFFF;
+
+		for (int round = 0; round < 130; ++round) {
+			const unsigned long long pend = __ballot(!resolved);
+			if (pend == 0ull) break;
+			const int low = __ffsll((long long)pend) - 1;
+			// ---- tentative decision of every unresolved lane
+			int state = 0;            // 0 reject, 1 accept, 2 needs rescan
+			int best = 0x7FFFFFFF, bestIdx = -1, second = 0x7FFFFFFF, secondIdx = -1;
+			if (!resolved) {
+				int n = 0;
+#pragma unroll
+				for (int e = 0; e < K; ++e) {
+					const uint32_t k = key[e];
+					if (k != EMPTY && n < 2) {
+						const int idx = (int)(k & 0xFFFFFu);
+						if (!((matched[idx >> 5] >> (idx & 31)) & 1u)) {
+							if (n == 0) { best = (int)(k >> 20); bestIdx = idx; } else { second = (int)(k >> 20); secondIdx = idx; }
+							++n;
+						}
+					}
+				}
+				if (n >= 2 || !full) {
+					const bool pass = bestIdx >= 0 && (g.thInclusive ? best <= g.thLow : best < g.thLow);
+					state = (pass && static_cast<double>(best) < g.ratio * static_cast<double>(second)) ? 1 : 0;
+				} else if (n == 1) {   // hidden rows beyond the list all have distance >= dK
+					const bool pass = g.thInclusive ? best <= g.thLow : best < g.thLow;
+					if (!pass) state = 0;
+					else if (static_cast<double>(best) < g.ratio * static_cast<double>(dK)) state = 1;
+					else state = 2;
+				} else {
+					const bool pass = g.thInclusive ? dK <= g.thLow : dK < g.thLow;
+					state = pass ? 2 : 0;
+				}
+			}
+			// ---- the lowest unresolved lane may need an exact rescan of the whole train set (wave-cooperative)
+			if (__shfl(state, low) == 2) {
+				const int qi = i0 + low;
+				uint32_t q[DW], qm[DW];
+				const uint32_t* qp = reinterpret_cast<const uint32_t*>(g.qd + (q0 + qi) * g.qstride);
+#pragma unroll
+				for (int w = 0; w < DW; ++w) q[w] = qp[w];
+				if (MASKED) {
+					const uint32_t* mp = reinterpret_cast<const uint32_t*>(g.qm + (q0 + qi) * g.qstride);
+#pragma unroll
+					for (int w = 0; w < DW; ++w) qm[w] = mp[w];
+				}
+				uint32_t a = EMPTY, b2 = EMPTY;
+				for (int j = lane; j < g.nt; j += 64) {
+					if ((matched[j >> 5] >> (j & 31)) & 1u) continue;
+					if (g.tvalid && g.tvalid[t0 + j] == 0) continue;
+					const uint32_t* tp = reinterpret_cast<const uint32_t*>(g.td + (t0 + j) * g.tstride);
+					const uint32_t* mp = MASKED ? reinterpret_cast<const uint32_t*>(g.tm + (t0 + j) * g.tstride) : tp;
+					const uint32_t k = ((uint32_t)hamming_g<DW, MASKED>(q, qm, tp, mp) << 20) | (uint32_t)j;
+					if (k < a) { b2 = a; a = k; } else if (k < b2) b2 = k;
+				}
+				const uint32_t m1 = wave_min_u32(a);
+				const uint32_t m2 = wave_min_u32(a == m1 ? b2 : a);
+				++nfallback;
+				if (lane == low) {
+					best = m1 == EMPTY ? 0x7FFFFFFF : (int)(m1 >> 20);
+					bestIdx = m1 == EMPTY ? -1 : (int)(m1 & 0xFFFFFu);
+					second = m2 == EMPTY ? 0x7FFFFFFF : (int)(m2 >> 20);
+					secondIdx = -1;   // exact: depends on nothing a lower lane can still change (there is no lower pending lane)
+					const bool pass = bestIdx >= 0 && (g.thInclusive ? best <= g.thLow : best < g.thLow);
+					state = (pass && static_cast<double>(best) < g.ratio * static_cast<double>(second)) ? 1 : 0;
+				}
+			}
+			// ---- claims and finality
+			if (!resolved && state == 1) atomicMin(&claim[bestIdx], (uint32_t)lane);
+			__syncthreads();
+			bool blocked = false;
+			if (!resolved) {
+				if (state == 2) blocked = true;
+				else {
+					if (bestIdx >= 0 && claim[bestIdx] < (uint32_t)lane) blocked = true;
+					if (secondIdx >= 0 && claim[secondIdx] < (uint32_t)lane) blocked = true;
+				}
+			}
+			const unsigned long long blk = __ballot(blocked);
+			const int firstBlocked = blk ? __ffsll((long long)blk) - 1 : 64;
+			__syncthreads();
+			if (!resolved && state == 1) claim[bestIdx] = 0xFFFFFFFFu;   // reset own claim (all claims of this round)
+			const bool commit = !resolved && lane < firstBlocked;
+			if (commit) {
+				if (state == 1) {
+					atomicOr(&matched[bestIdx >> 5], 1u << (bestIdx & 31));
+					if (g.mode == 0) outM[i] = bestIdx; else outM[bestIdx] = i;
+				} else if (g.mode == 0) outM[i] = -1;
+				resolved = true;
+			}
+			nmatches += __popcll(__ballot(commit && state == 1));
+			__syncthreads();
+		}
+	}
+	if (lane == 0) {
+		g.outCount[set] = nmatches;
+		if (g.outFallbacks) g.outFallbacks[set] = nfallback;
+	}
+}
+
+template <int K, int DW>
+static void launch_spec_kd(const GreedyArgs& g, hipStream_t s) {
+	if (g.qm && g.tm) hipLaunchKernelGGL((k_greedy_spec<K, DW, true>), dim3(g.nsets), dim3(64), 0, s, g);
+	else hipLaunchKernelGGL((k_greedy_spec<K, DW, false>), dim3(g.nsets), dim3(64), 0, s, g);
+}
+
 template <int DW>
 static void launch_dw(const GreedyArgs& g, hipStream_t s) {
+	if (g.mode != 2 && g.nt <= kClaimRows) {
+		switch (g.K) {
+			case 1: launch_spec_kd<1, DW>(g, s); return;
+			case 2: launch_spec_kd<2, DW>(g, s); return;
+			case 4: launch_spec_kd<4, DW>(g, s); return;
+			case 8: launch_spec_kd<8, DW>(g, s); return;
+			case 16: launch_spec_kd<16, DW>(g, s); return;
+			default: launch_spec_kd<32, DW>(g, s); return;
+		}
+	}
 	if (g.qm && g.tm) hipLaunchKernelGGL((k_greedy<DW, true>), dim3(g.nsets), dim3(64), 0, s, g);
 	else hipLaunchKernelGGL((k_greedy<DW, false>), dim3(g.nsets), dim3(64), 0, s, g);
 }
