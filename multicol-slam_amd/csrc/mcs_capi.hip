@@ -78,7 +78,7 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 	(void)hipStreamSynchronize(c->stream);
 	for (auto& kv : c->timers) { if (kv.second.a) { (void)hipEventDestroy(kv.second.a); (void)hipEventDestroy(kv.second.b); } }
 	(void)hipFree(c->partial); (void)hipFree(c->partialCount); (void)hipFree(c->stage); (void)hipFree(c->dscalar);
-	(void)hipFree(c->topDist); (void)hipFree(c->topIdx); (void)hipFree(c->topCnt); (void)hipFree(c->stageOut);
+	(void)hipFree(c->topKeys); (void)hipFree(c->topCnt); (void)hipFree(c->stageOut);
 	if (c->ownStream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return MCS_OK;

@@ -2,6 +2,7 @@
 #include "mcs_host.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace mcs {
@@ -82,14 +83,18 @@ static int stage_sets(mcs_ctx* c, int nsets, const mcs_desc_set* q, size_t qpitc
 }
 
 static int run_topk(mcs_ctx* c, const DevSets& d, int nsets, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, int dim,
-                    int K, int count_thresh, int* outDist, int* outIdx, int* outCount) {
+                    int K, int count_thresh, int max_dist, int* outDist, int* outIdx, int* outCount) {
 	MatchArgs a{};
+	a.maxDist = max_dist;
+	if (int r = ensure((void**)&c->topKeys, &c->topKeysCap, std::max<size_t>((size_t)nsets * q->n, 1) * K * sizeof(uint32_t))) return r;
+	a.keys = c->topKeys;
 	a.qd = d.qd; a.qm = d.qm; a.qvalid = d.qvalid; a.qgroup = d.qgroup; a.td = d.td; a.tm = d.tm; a.tvalid = d.tvalid; a.tgroup = d.tgroup;
 	a.nq = q->n; a.nt = t->n; a.qstride = q->stride; a.tstride = t->stride; a.qpitch = qpitch; a.tpitch = tpitch;
 	a.nsets = nsets; a.dim = dim; a.K = K; a.countThresh = count_thresh;
 	const size_t outRows = (size_t)nsets * q->n;
 	const int qTiles = (q->n + 255) / 256;
-	int splits = (2048 + qTiles * nsets - 1) / (qTiles * nsets);
+	static const int kTargetBlocks = getenv("MCS_MATCH_BLOCKS") ? atoi(getenv("MCS_MATCH_BLOCKS")) : 1024;
+	int splits = (kTargetBlocks + qTiles * nsets - 1) / (qTiles * nsets);
 	splits = std::max(1, std::min(splits, (t->n + 255) / 256));
 	a.splits = splits;
 	if (int r = ensure((void**)&c->partial, &c->partialCap, outRows * splits * K * sizeof(uint32_t))) return r;
@@ -112,11 +117,11 @@ int mcs_match_topk_batched(mcs_ctx* c, int nsets, const mcs_desc_set* q, size_t 
 	DevSets d{};
 	if (int r = stage_sets(c, nsets, q, qpitch, t, tpitch, kind, &d, nullptr, nullptr, nullptr, 0)) return r;
 	const size_t outRows = (size_t)nsets * q->n;
-	if (kind == MCS_MEM_DEVICE) return run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, count_thresh, out_dist, out_idx, out_count_le);
+	if (kind == MCS_MEM_DEVICE) return run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, count_thresh, 0x7FFFFFFF, out_dist, out_idx, out_count_le);
 	const size_t oD = 0, oI = al256(outRows * K * 4), oC = oI + al256(outRows * K * 4);
 	if (int r = ensure((void**)&c->stageOut, &c->stageOutCap, oC + al256(outRows * 4))) return r;
 	uint8_t* so = c->stageOut;
-	if (int r = run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, count_thresh, (int*)(so + oD), (int*)(so + oI), (int*)(so + oC))) return r;
+	if (int r = run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, count_thresh, 0x7FFFFFFF, (int*)(so + oD), (int*)(so + oI), (int*)(so + oC))) return r;
 	HIPCHK(hipMemcpyAsync(out_dist, so + oD, outRows * K * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(out_idx, so + oI, outRows * K * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(out_count_le, so + oC, outRows * 4, hipMemcpyDeviceToHost, c->stream));
@@ -146,15 +151,20 @@ static int search_common(mcs_ctx* c, int mode, int nsets, const mcs_desc_set* q,
 	if (int r = stage_sets(c, nsets, q, qpitch, t, tpitch, kind, &d, mode == 2 ? &rays1 : nullptr, mode == 2 ? &rays2 : nullptr,
 	                       mode == 2 ? &E : nullptr, nrCams * nrCams * 9)) return r;
 	const size_t rows = (size_t)nsets * q->n;
-	if (int r = ensure((void**)&c->topDist, &c->topDistCap, std::max<size_t>(rows, 1) * K * 4)) return r;
-	if (int r = ensure((void**)&c->topIdx, &c->topIdxCap, std::max<size_t>(rows, 1) * K * 4)) return r;
 	if (int r = ensure((void**)&c->topCnt, &c->topCntCap, std::max<size_t>(rows, 1) * 4)) return r;
-	if (q->n > 0)
-		if (int r = run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, thLow, c->topDist, c->topIdx, c->topCnt)) return r;
+	{
+		// Rows that can never influence a decision stay out of the lists: SearchByBoW needs best <= TH_LOW and, for the ratio
+		// test, seconds up to the largest d with nnratio*d <= TH_LOW (any farther second passes best < nnratio*second for every
+		// admissible best); SearchForTriangulationRaw only collects dist <= TH_LOW (:1062).
+		int maxDist = thLow;
+		if (mode != 2) while (maxDist < 8 * dim && nnratio * static_cast<double>(maxDist + 1) <= static_cast<double>(thLow)) ++maxDist;
+		if (q->n > 0)
+			if (int r = run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, thLow, maxDist, nullptr, nullptr, c->topCnt)) return r;
+	}
 	GreedyArgs g{};
 	g.qd = d.qd; g.qm = d.qm; g.qvalid = d.qvalid; g.qgroup = d.qgroup; g.td = d.td; g.tm = d.tm; g.tvalid = d.tvalid; g.tgroup = d.tgroup;
 	g.nq = q->n; g.nt = t->n; g.qstride = q->stride; g.tstride = t->stride; g.qpitch = qpitch; g.tpitch = tpitch;
-	g.nsets = nsets; g.dim = dim; g.K = K; g.topDist = c->topDist; g.topIdx = c->topIdx;
+	g.nsets = nsets; g.dim = dim; g.K = K; g.keys = c->topKeys;
 	g.thLow = thLow; g.thInclusive = mode == 1 ? 1 : 0; g.ratio = nnratio; g.mode = mode;
 	g.rays1 = rays1; g.rays2 = rays2; g.E = E; g.nrCams = nrCams;
 	const size_t outN = (size_t)nsets * (mode == 1 ? t->n : q->n);

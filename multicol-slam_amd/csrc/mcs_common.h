@@ -102,10 +102,13 @@ struct MatchArgs {
 	const uint8_t* qd; const uint8_t* qm; const uint8_t* qvalid; const int* qgroup; int nq; int qstride; size_t qpitch;
 	const uint8_t* td; const uint8_t* tm; const uint8_t* tvalid; const int* tgroup; int nt; int tstride; size_t tpitch;
 	int nsets; int dim; int K; int countThresh;
+	int maxDist;               // rows farther than this never enter a list (INT_MAX for plain top-K)
 	int splits;                // train-range splits per (set, query tile)
-	uint32_t* partial;         // [nsets][splits][nq][K] packed (dist<<20 | idx), ascending
+	uint32_t* partial;         // [nsets][splits][K][nq] packed (dist<<20 | idx), ascending in K
 	int* partialCount;         // [nsets][splits][nq]
-	int* outDist; int* outIdx; int* outCount;
+	uint32_t* keys;            // [nsets][K][nq] final packed lists (0xFFFFFFFF = empty)
+	int* outDist; int* outIdx; // optional public [nsets][nq][K] form
+	int* outCount;
 };
 void launch_match(const MatchArgs& a, hipStream_t s);
 
@@ -114,7 +117,7 @@ struct GreedyArgs {
 	const uint8_t* qd; const uint8_t* qm; const uint8_t* qvalid; const int* qgroup; int nq; int qstride; size_t qpitch;
 	const uint8_t* td; const uint8_t* tm; const uint8_t* tvalid; const int* tgroup; int nt; int tstride; size_t tpitch;
 	int nsets; int dim; int K;
-	const int* topDist; const int* topIdx;   // [nsets][nq][K], ascending (dist, idx)
+	const uint32_t* keys;                    // [nsets][K][nq] packed (dist<<20 | idx) ascending in K, 0xFFFFFFFF = empty
 	int thLow; int thInclusive; double ratio;
 	int mode;                                // 0 SearchByBoW(KF,KF)  1 SearchByBoW(KF,F)  2 SearchForTriangulationRaw
 	const double* rays1; const double* rays2; const double* E; int nrCams;

@@ -64,7 +64,10 @@ __global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
 		const bool qok = g.qvalid ? g.qvalid[q0 + i] != 0 : true;   // uniform
 		if (!qok) { if (g.mode != 1 && lane == 0) outM[i] = -1; continue; }
 		int d = 0x7FFFFFFF, idx = -1;
-		if (lane < K) { const size_t o = ((size_t)set * g.nq + i) * K + lane; d = g.topDist[o]; idx = g.topIdx[o]; }
+		if (lane < K) {
+			const uint32_t k = g.keys[((size_t)set * K + lane) * g.nq + i];
+			if (k != 0xFFFFFFFFu) { d = (int)(k >> 20); idx = (int)(k & 0xFFFFFu); }
+		}
 		const bool freeE = idx >= 0 && !((matched[idx >> 5] >> (idx & 31)) & 1u);
 		const unsigned long long bal = __ballot(freeE);
 		const int lastIdx = __shfl(idx, K - 1), dK = __shfl(d, K - 1);
@@ -224,12 +227,9 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 #pragma unroll
 		for (int e = 0; e < K; ++e) key[e] = EMPTY;
 		if (qok) {
-			const size_t o = ((size_t)set * g.nq + i) * K;
+			const uint32_t* src = g.keys + (size_t)set * K * g.nq + i;   // [K][nq]: coalesced across lanes
 #pragma unroll
-			for (int e = 0; e < K; ++e) {
-				const int ie = g.topIdx[o + e];
-				key[e] = ie < 0 ? EMPTY : (((uint32_t)g.topDist[o + e] << 20) | (uint32_t)ie);
-			}
+			for (int e = 0; e < K; ++e) key[e] = src[(size_t)e * g.nq];
 		}
 		bool resolved = !qok;
 		if (inRange && !qok && g.mode == 0) outM[i] = -1;
@@ -282,13 +282,21 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 					for (int w = 0; w < DW; ++w) qm[w] = mp[w];
 				}
 				uint32_t a = EMPTY, b2 = EMPTY;
-				for (int j = lane; j < g.nt; j += 64) {
-					if ((matched[j >> 5] >> (j & 31)) & 1u) continue;
-					if (g.tvalid && g.tvalid[t0 + j] == 0) continue;
-					const uint32_t* tp = reinterpret_cast<const uint32_t*>(g.td + (t0 + j) * g.tstride);
-					const uint32_t* mp = MASKED ? reinterpret_cast<const uint32_t*>(g.tm + (t0 + j) * g.tstride) : tp;
-					const uint32_t k = ((uint32_t)hamming_g<DW, MASKED>(q, qm, tp, mp) << 20) | (uint32_t)j;
-					if (k < a) { b2 = a; a = k; } else if (k < b2) b2 = k;
+				// branch-free body, 4 rows per lane and trip: all global loads of a trip are issued before the first use
+				for (int j0 = lane; j0 < g.nt; j0 += 256) {
+					uint32_t kk[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const int j = j0 + 64 * u;
+						const int jc = j < g.nt ? j : g.nt - 1;
+						const uint32_t* tp = reinterpret_cast<const uint32_t*>(g.td + (t0 + jc) * g.tstride);
+						const uint32_t* mp = MASKED ? reinterpret_cast<const uint32_t*>(g.tm + (t0 + jc) * g.tstride) : tp;
+						const bool ok = j < g.nt && !((matched[jc >> 5] >> (jc & 31)) & 1u) && (g.tvalid ? g.tvalid[t0 + jc] != 0 : true);
+						const uint32_t k = ((uint32_t)hamming_g<DW, MASKED>(q, qm, tp, mp) << 20) | (uint32_t)jc;
+						kk[u] = ok ? k : EMPTY;
+					}
+#pragma unroll
+					for (int u = 0; u < 4; ++u) { const uint32_t k = kk[u]; if (k < a) { b2 = a; a = k; } else if (k < b2) b2 = k; }
 				}
 				const uint32_t m1 = wave_min_u32(a);
 				const uint32_t m2 = wave_min_u32(a == m1 ? b2 : a);

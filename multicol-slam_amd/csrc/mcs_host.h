@@ -31,7 +31,8 @@ struct mcs_ctx {
 	int* partialCount = nullptr; size_t partialCountCap = 0;
 	uint8_t* stage = nullptr; size_t stageCap = 0;   // host-kind staging for the matcher
 	int* dscalar = nullptr;
-	int *topDist = nullptr, *topIdx = nullptr, *topCnt = nullptr; size_t topDistCap = 0, topIdxCap = 0, topCntCap = 0;   // top-K lists feeding the greedy kernels
+	uint32_t* topKeys = nullptr; size_t topKeysCap = 0;   // packed [set][K][nq] top-K lists feeding the greedy kernels
+	int* topCnt = nullptr; size_t topCntCap = 0;
 	uint8_t* stageOut = nullptr; size_t stageOutCap = 0;
 
 	void tic(const char* name) {

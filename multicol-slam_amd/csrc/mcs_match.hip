@@ -9,6 +9,7 @@
 // +eligibility) staged per step in LDS and read back as wave-uniform broadcasts (v_xor + v_and + v_bcnt accumulate).
 // The train range is split over blockIdx.y so that a single 3000x3000 pair still fills 256 CUs; a second tiny kernel
 // merges the per-split sorted lists.  Sets (keyframes) are blockIdx.z: one launch sweeps a whole keyframe database.
+// Lists are kept as packed keys in a [set][K][query] layout: lane = query, so every list store/load is coalesced.
 #include "mcs_common.h"
 
 namespace mcs {
@@ -32,6 +33,8 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	__shared__ __attribute__((aligned(16))) uint32_t td[MT * DW];
 	__shared__ __attribute__((aligned(16))) uint32_t tm[MASKED ? MT * DW : 4];
 	__shared__ int tflag[MT];   // camera group of the train row, or -1 if not eligible at all
+	constexpr int CB = 32;      // candidate column depth per lane
+	__shared__ uint32_t cand[CB * 256];
 	const int tid = threadIdx.x;
 	const int set = blockIdx.z, split = blockIdx.y;
 	const int qi = blockIdx.x * 256 + tid;
@@ -59,6 +62,23 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	for (int p = 0; p < K; ++p) best[p] = 0xFFFFFFFFu;
 	int countLe = 0;
 	const bool useGroup = a.qgroup != nullptr && a.tgroup != nullptr;
+	// Candidate keys are first appended to a private LDS column (one ds_write per hit) and merged into the sorted
+	// register list only when some lane's column is full or at the end: a sorted insert costs 2K VALU ops for the WHOLE
+	// wave whenever ANY lane hits, which at K = 32 was more than the distance arithmetic itself.
+	int cnt = 0;
+	auto flush = [&]() {
+		int m = cnt;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+		for (int e = 0; e < m; ++e) {
+			uint32_t key = e < cnt ? cand[e * 256 + tid] : 0xFFFFFFFFu;
+			if (__any(key < best[K - 1])) {
+#pragma unroll
+				for (int p = 0; p < K; ++p) { const uint32_t lo = min(best[p], key), hi = max(best[p], key); best[p] = lo; key = hi; }
+			}
+		}
+		cnt = 0;
+	};
 
 	const int per = ((a.nt + a.splits - 1) / a.splits + MT - 1) / MT * MT;
 	const int t0 = split * per, t1 = min(a.nt, t0 + per);
@@ -80,26 +100,27 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 		tflag[tid] = flag;
 		__syncthreads();
 		if (qok) {
-			const int cnt = min(MT, t1 - base);
-			for (int r = 0; r < cnt; ++r) {
+			const int rows = min(MT, t1 - base);
+			for (int r = 0; r < rows; ++r) {
 				const int g = tflag[r];
 				if (g < 0 || (useGroup && g != qg)) continue;
 				const int dist = hamming<DW, MASKED>(q, qm, &td[r * DW], &tm[MASKED ? r * DW : 0]);
 				countLe += dist <= a.countThresh ? 1 : 0;
-				uint32_t key = ((uint32_t)dist << 20) | (uint32_t)(base + r);
-				if (key < best[K - 1]) {
-#pragma unroll
-					for (int p = 0; p < K; ++p) { const uint32_t lo = min(best[p], key), hi = max(best[p], key); best[p] = lo; key = hi; }
-				}
+				const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)(base + r);
+				if (dist <= a.maxDist && key < best[K - 1]) { cand[cnt * 256 + tid] = key; ++cnt; }
+				if (__any(cnt == CB)) flush();
 			}
 		}
 		__syncthreads();
 	}
+	flush();
 	if (qi < a.nq) {
-		const size_t o = ((size_t)set * a.splits + split) * a.nq + qi;
+		// splits == 1: these are the final lists; otherwise a partial list per split
+		uint32_t* dst = a.splits == 1 ? a.keys + (size_t)set * K * a.nq : a.partial + ((size_t)set * a.splits + split) * K * a.nq;
 #pragma unroll
-		for (int p = 0; p < K; ++p) a.partial[o * K + p] = best[p];
-		a.partialCount[o] = countLe;
+		for (int p = 0; p < K; ++p) dst[(size_t)p * a.nq + qi] = best[p];
+		if (a.splits == 1) a.outCount[(size_t)set * a.nq + qi] = countLe;
+		else a.partialCount[((size_t)set * a.splits + split) * a.nq + qi] = countLe;
 	}
 }
 
@@ -113,23 +134,35 @@ __global__ __launch_bounds__(256) void k_match_merge(MatchArgs a) {
 	for (int p = 0; p < K; ++p) best[p] = 0xFFFFFFFFu;
 	int countLe = 0;
 	for (int s = 0; s < a.splits; ++s) {
-		const size_t o = ((size_t)set * a.splits + s) * a.nq + qi;
-		countLe += a.partialCount[o];
+		const size_t o = (size_t)set * a.splits + s;
+		countLe += a.partialCount[o * a.nq + qi];
+		const uint32_t* src = a.partial + o * K * a.nq;
 		for (int e = 0; e < K; ++e) {
-			uint32_t key = a.partial[o * K + e];
+			uint32_t key = src[(size_t)e * a.nq + qi];
 			if (key >= best[K - 1]) break;   // lists are ascending
 #pragma unroll
 			for (int p = 0; p < K; ++p) { const uint32_t lo = min(best[p], key), hi = max(best[p], key); best[p] = lo; key = hi; }
 		}
 	}
-	const size_t o = (size_t)set * a.nq + qi;
+	uint32_t* dst = a.keys + (size_t)set * K * a.nq;
 #pragma unroll
-	for (int p = 0; p < K; ++p) {
-		const bool none = best[p] == 0xFFFFFFFFu;
-		a.outDist[o * K + p] = none ? 0x7FFFFFFF : (int)(best[p] >> 20);
-		a.outIdx[o * K + p] = none ? -1 : (int)(best[p] & 0xFFFFFu);
+	for (int p = 0; p < K; ++p) dst[(size_t)p * a.nq + qi] = best[p];
+	a.outCount[(size_t)set * a.nq + qi] = countLe;
+}
+
+// packed [set][K][nq] keys -> the public [set][nq][K] (dist, idx) arrays of mcs_match_topk
+__global__ __launch_bounds__(256) void k_match_unpack(MatchArgs a) {
+	const int qi = blockIdx.x * 256 + threadIdx.x;
+	const int set = blockIdx.z;
+	if (qi >= a.nq) return;
+	const uint32_t* src = a.keys + (size_t)set * a.K * a.nq;
+	const size_t o = ((size_t)set * a.nq + qi) * a.K;
+	for (int p = 0; p < a.K; ++p) {
+		const uint32_t k = src[(size_t)p * a.nq + qi];
+		const bool none = k == 0xFFFFFFFFu;
+		a.outDist[o + p] = none ? 0x7FFFFFFF : (int)(k >> 20);
+		a.outIdx[o + p] = none ? -1 : (int)(k & 0xFFFFFu);
 	}
-	a.outCount[o] = countLe;
 }
 
 template <int K, int DW>
@@ -137,7 +170,8 @@ static void launch_kd(const MatchArgs& a, hipStream_t s) {
 	dim3 grid((a.nq + 255) / 256, a.splits, a.nsets);
 	if (a.qm && a.tm) hipLaunchKernelGGL((k_match_partial<K, DW, true>), grid, dim3(256), 0, s, a);
 	else hipLaunchKernelGGL((k_match_partial<K, DW, false>), grid, dim3(256), 0, s, a);
-	hipLaunchKernelGGL((k_match_merge<K>), dim3((a.nq + 255) / 256, 1, a.nsets), dim3(256), 0, s, a);
+	if (a.splits > 1) hipLaunchKernelGGL((k_match_merge<K>), dim3((a.nq + 255) / 256, 1, a.nsets), dim3(256), 0, s, a);
+	if (a.outDist && a.outIdx) hipLaunchKernelGGL(k_match_unpack, dim3((a.nq + 255) / 256, 1, a.nsets), dim3(256), 0, s, a);
 }
 
 template <int K>
