@@ -1,0 +1,205 @@
+// mcs_facade.hpp — header-only C++ host facade over the C ABI (include/mcs_c.h) with the reference's class names, so
+// that cTracking / cLocalMapping / cLoopClosing compile against it unchanged in spirit:
+//
+//   MultiColSLAM::mdBRIEFextractorOct   include/mdBRIEFextractorOct.h:335-421 (13-argument ctor, operator(), getters)
+//   MultiColSLAM::cORBmatcher           include/cORBmatcher.h:43-133 (the three brute-force searches on flat views)
+//   MultiColSLAM::DescriptorDistance64[_Masked]   src/cORBmatcher.cpp:2438-2474
+//
+// OpenCV is not a dependency: minimal layout-compatible PODs stand in for cv::KeyPoint / cv::Mat / cv::Vec3d.  With
+// -DMCS_WITH_OPENCV the adapters at the bottom accept the real types (cv::KeyPoint is 28 bytes, same layout).
+// Link with -lmcs_hip.  No CPU fallback: every call needs a HIP device and throws std::runtime_error otherwise.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../mcs_c.h"
+
+namespace MultiColSLAM {
+
+struct KeyPoint { float ptx, pty, size, angle, response; int32_t octave, class_id; };   // == cv::KeyPoint, 28 B
+static_assert(sizeof(KeyPoint) == 28 && sizeof(mcs_keypoint) == 28, "cv::KeyPoint layout");
+struct Vec3d { double v[3]; };
+
+struct Mat8u {   // CV_8UC1 matrix view / owner (rows x cols, step bytes per row)
+	int rows = 0, cols = 0, step = 0;
+	std::vector<uint8_t> store;
+	uint8_t* data = nullptr;
+	void create(int r, int c) { rows = r; cols = c; step = c; store.assign((size_t)r * c, 0); data = store.data(); }
+	void release() { rows = cols = step = 0; store.clear(); data = nullptr; }
+	bool empty() const { return rows == 0 || cols == 0; }
+	const uint64_t* ptr64(int r) const { return reinterpret_cast<const uint64_t*>(data + (size_t)r * step); }
+};
+
+inline void mcs_throw(int rc) { if (rc != MCS_OK) throw std::runtime_error(std::string("libmcs_hip: ") + mcs_last_error()); }
+
+class Context {
+public:
+	explicit Context(int device = 0, void* hipStream = nullptr) { mcs_throw(mcs_ctx_create(device, hipStream, &h)); }
+	~Context() { mcs_ctx_destroy(h); }
+	Context(const Context&) = delete;
+	Context& operator=(const Context&) = delete;
+	mcs_ctx* h = nullptr;
+};
+
+// cCamModelGeneral_ (include/cam_model_omni.h): calibration + level-0 mirror mask
+struct cCamModelGeneral_ {
+	mcs_ocam ocam{};
+	Mat8u mirrorMask0;
+	double GetWidth() const { return ocam.width; }
+	double GetHeight() const { return ocam.height; }
+	const Mat8u& GetMirrorMask(int) const { return mirrorMask0; }
+};
+
+class mdBRIEFextractorOct {
+public:
+	enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+	mdBRIEFextractorOct(Context& ctx, int _nfeatures = 1000, float _scaleFactor = 1.2f, int _nlevels = 8, int _edgeThreshold = 25,
+	                    int _firstLevel = 0, int _scoreType = HARRIS_SCORE, int _patchSize = 32, int _fastThreshold = 20, bool _useAgast = false,
+	                    int _fastAgastType = 2, bool _do_dBrief = false, bool _learnMasks = false, int _descSize = 32)
+	    : ctx_(ctx), p_{_nfeatures, _scaleFactor, _nlevels, _edgeThreshold, _firstLevel, _scoreType, _patchSize, _fastThreshold, _useAgast ? 1 : 0,
+	                    _fastAgastType, _do_dBrief ? 1 : 0, _learnMasks ? 1 : 0, _descSize} {}
+	~mdBRIEFextractorOct() { if (ex_) mcs_extractor_destroy(ex_); }
+
+	// operator()(image, mask, keypoints, camModel, descriptors, descriptorMasks)  (src/mdBRIEFextractorOct.cpp:1244-1337)
+	void operator()(const Mat8u& image, const Mat8u& mask, std::vector<KeyPoint>& keypoints, cCamModelGeneral_& camModel, Mat8u& descriptors,
+	                Mat8u& descriptorMasks) {
+		if (image.empty()) return;   // :1252-1253
+		ensure(image.cols, image.rows, 1);
+		std::vector<mcs_keypoint> kps(cap_);
+		std::vector<uint8_t> d((size_t)cap_ * p_.descSize), m((size_t)cap_ * p_.descSize);
+		int32_t n = 0;
+		mcs_throw(mcs_extract_batch(ex_, 1, image.data, 0, image.step, mask.empty() ? nullptr : mask.data, 0, mask.step, &camModel.ocam,
+		                            MCS_MEM_HOST, &n, kps.data(), d.data(), m.data(), nullptr));
+		keypoints.resize(n);
+		if (n) std::memcpy(keypoints.data(), kps.data(), (size_t)n * sizeof(KeyPoint));
+		if (n == 0) { descriptors.release(); descriptorMasks.release(); return; }   // :1270-1274
+		descriptors.create(n, p_.descSize);
+		descriptorMasks.create(n, p_.descSize);
+		std::memcpy(descriptors.data, d.data(), (size_t)n * p_.descSize);
+		std::memcpy(descriptorMasks.data, m.data(), (size_t)n * p_.descSize);
+	}
+
+	// All cameras of a rig in one device batch (the GPU analogue of `#pragma omp parallel for num_threads(nrCams)`,
+	// src/cMultiFrame.cpp:128); also returns the rays of src/cMultiFrame.cpp:146-152.
+	void extractRig(const std::vector<const uint8_t*>& images, int width, int height, int stride, const std::vector<const uint8_t*>& masks,
+	                const std::vector<mcs_ocam>& cams, std::vector<std::vector<KeyPoint>>& keys, std::vector<Mat8u>& desc, std::vector<Mat8u>& dmask,
+	                std::vector<std::vector<Vec3d>>& rays) {
+		const int n = (int)images.size();
+		ensure(width, height, n);
+		std::vector<uint8_t> img((size_t)n * stride * height), msk;
+		for (int i = 0; i < n; ++i) std::memcpy(img.data() + (size_t)i * stride * height, images[i], (size_t)stride * height);
+		if (!masks.empty()) {
+			msk.resize(img.size());
+			for (int i = 0; i < n; ++i) std::memcpy(msk.data() + (size_t)i * stride * height, masks[i], (size_t)stride * height);
+		}
+		std::vector<int32_t> nkp(n);
+		std::vector<mcs_keypoint> kps((size_t)n * cap_);
+		std::vector<uint8_t> d((size_t)n * cap_ * p_.descSize), m(d.size());
+		std::vector<double> r((size_t)n * cap_ * 3);
+		mcs_throw(mcs_extract_batch(ex_, n, img.data(), (size_t)stride * height, stride, msk.empty() ? nullptr : msk.data(), (size_t)stride * height,
+		                            stride, cams.data(), MCS_MEM_HOST, nkp.data(), kps.data(), d.data(), m.data(), r.data()));
+		keys.assign(n, {}); desc.assign(n, {}); dmask.assign(n, {}); rays.assign(n, {});
+		for (int i = 0; i < n; ++i) {
+			const int k = nkp[i];
+			keys[i].resize(k); rays[i].resize(k);
+			if (!k) continue;
+			std::memcpy(keys[i].data(), kps.data() + (size_t)i * cap_, (size_t)k * sizeof(KeyPoint));
+			std::memcpy(rays[i].data(), r.data() + (size_t)i * cap_ * 3, (size_t)k * sizeof(Vec3d));
+			desc[i].create(k, p_.descSize); dmask[i].create(k, p_.descSize);
+			std::memcpy(desc[i].data, d.data() + (size_t)i * cap_ * p_.descSize, (size_t)k * p_.descSize);
+			std::memcpy(dmask[i].data, m.data() + (size_t)i * cap_ * p_.descSize, (size_t)k * p_.descSize);
+		}
+	}
+
+	int GetLevels() { return p_.nlevels; }
+	double GetScaleFactor() { return (double)p_.scaleFactor; }   // member is the double of the FLOAT ctor argument
+	bool GetMasksLearned() { return p_.learnMasks != 0; }
+	int GetDescriptorSize() { return p_.descSize; }
+
+private:
+	void ensure(int w, int h, int batch) {
+		if (ex_ && w == w_ && h == h_ && batch <= batch_) return;
+		if (ex_) mcs_extractor_destroy(ex_);
+		ex_ = nullptr;
+		mcs_throw(mcs_extractor_create(ctx_.h, &p_, w, h, batch, &ex_));
+		mcs_throw(mcs_extractor_kp_capacity(ex_, &cap_));
+		w_ = w; h_ = h; batch_ = batch;
+	}
+	Context& ctx_;
+	mcs_extractor_params p_;
+	mcs_extractor* ex_ = nullptr;
+	int w_ = 0, h_ = 0, batch_ = 0, cap_ = 0;
+};
+
+// flat view of a (multi-)keyframe / frame as the brute-force searches see it: all cameras concatenated in mvKeys order
+struct FeatureSetView {
+	const uint8_t* descriptors = nullptr;   // n x dim
+	const uint8_t* masks = nullptr;         // n x dim or nullptr
+	std::vector<uint8_t> flag;              // meaning depends on the search (see cORBmatcher)
+	std::vector<int32_t> cam;               // keypoint_to_cam
+	const double* rays = nullptr;           // n x 3
+	int n = 0;
+};
+
+class cORBmatcher {
+public:
+	cORBmatcher(Context& ctx, double nnratio = 0.6, bool checkOri = true, int featDim = 32, bool havingMasks_ = false, int K = 32)
+	    : ctx_(ctx), mfNNratio(nnratio), mbFeatDim(featDim), havingMasks(havingMasks_), K_(K) {
+		if (checkOri) throw std::invalid_argument("mbCheckOrientation is false at every reference call site (include/cORBmatcher.h:40)");
+	}
+	// SearchByBoW(pKF1, pKF2, vpMatches12): flag = "has a good map point".  match12[i] = index in kf2 or -1.  (:885-966)
+	int SearchByBoW(const FeatureSetView& kf1, const FeatureSetView& kf2, std::vector<int>& match12) {
+		return run(0, kf1, kf2, nullptr, 0, match12, kf1.n);
+	}
+	// SearchByBoW(pKF, F, vpMapPointMatches) without the vocabulary restriction: matchF[j] = keyframe feature or -1.  (:179-323)
+	int SearchByBoWFrame(const FeatureSetView& kf, const FeatureSetView& frame, std::vector<int>& matchF) {
+		return run(1, kf, frame, nullptr, 0, matchF, frame.n);
+	}
+	// SearchForTriangulationRaw: flag = "has NO map point", cam + rays required, E = nrCams*nrCams 3x3 row-major.  (:968-1155)
+	int SearchForTriangulationRaw(const FeatureSetView& kf1, const FeatureSetView& kf2, const double* E, int nrCams,
+	                              std::vector<std::pair<size_t, size_t>>& vMatchedPairs) {
+		std::vector<int> m12;
+		const int n = run(2, kf1, kf2, E, nrCams, m12, kf1.n);
+		vMatchedPairs.clear();
+		for (size_t i = 0; i < m12.size(); ++i) if (m12[i] >= 0) vMatchedPairs.emplace_back(i, (size_t)m12[i]);
+		return n;
+	}
+
+private:
+	int run(int mode, const FeatureSetView& a, const FeatureSetView& b, const double* E, int nrCams, std::vector<int>& out, int outN) {
+		mcs_desc_set q{a.descriptors, havingMasks ? a.masks : nullptr, a.flag.empty() ? nullptr : a.flag.data(), mode == 2 ? a.cam.data() : nullptr, a.n, mbFeatDim};
+		mcs_desc_set t{b.descriptors, havingMasks ? b.masks : nullptr, (mode == 1 || b.flag.empty()) ? nullptr : b.flag.data(), mode == 2 ? b.cam.data() : nullptr, b.n, mbFeatDim};
+		out.assign(outN > 0 ? outN : 1, -1);
+		int32_t nm = 0, fb = 0;
+		int rc;
+		if (mode == 0) rc = mcs_search_kf_kf(ctx_.h, 1, &q, 0, &t, 0, mbFeatDim, mfNNratio, K_, MCS_MEM_HOST, out.data(), &nm, &fb);
+		else if (mode == 1) rc = mcs_search_kf_f(ctx_.h, 1, &q, 0, &t, 0, mbFeatDim, mfNNratio, K_, MCS_MEM_HOST, out.data(), &nm, &fb);
+		else rc = mcs_search_triangulation(ctx_.h, 1, &q, 0, &t, 0, a.rays, b.rays, E, nrCams, mbFeatDim, K_, MCS_MEM_HOST, out.data(), &nm, &fb);
+		mcs_throw(rc);
+		out.resize(outN);
+		return nm;
+	}
+	Context& ctx_;
+	double mfNNratio;
+	int mbFeatDim;
+	bool havingMasks;
+	int K_;
+};
+
+inline int DescriptorDistance64(Context& c, const uint64_t* descr_i, const uint64_t* descr_j, const int& dim) {
+	int out = 0;
+	mcs_throw(mcs_descriptor_distance(c.h, (const uint8_t*)descr_i, (const uint8_t*)descr_j, dim, &out));
+	return out;
+}
+inline int DescriptorDistance64Masked(Context& c, const uint64_t* descr_i, const uint64_t* descr_j, const uint64_t* mask_i, const uint64_t* mask_j,
+                                      const int& dim) {
+	int out = 0;
+	mcs_throw(mcs_descriptor_distance_masked(c.h, (const uint8_t*)descr_i, (const uint8_t*)descr_j, (const uint8_t*)mask_i, (const uint8_t*)mask_j, dim, &out));
+	return out;
+}
+
+}  // namespace MultiColSLAM
