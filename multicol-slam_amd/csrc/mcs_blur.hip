@@ -3,15 +3,17 @@
 // window pixels outside the ROI taken from the reflect-101 frame of the UNBLURRED level (= reflected indices here).
 // The blurred pyramid is a separate buffer, so FAST / orientation keep reading the unblurred one.
 //
-// HBM-bound: reads S, writes S bytes per image.  64x16-pixel output tile per 256-thread workgroup, the 68x20 input tile
-// is staged in LDS, horizontal 5-sums are formed once per input row (u16 in LDS), each thread then emits 4 adjacent
-// pixels as one dword store.  All levels of all images go out in ONE launch (tile list per level is prefix-indexed).
+// HBM-bound: reads S, writes S bytes per image.  128x32-pixel output tile per 256-thread workgroup (enough bytes in
+// flight per workgroup to cover HBM latency), the 132x36 input tile is staged in LDS with coalesced dword loads,
+// horizontal 5-sums are formed once per input row (u16 in LDS), each thread then emits 4 adjacent pixels per row as one
+// dword store.  All levels of all images go out in ONE launch (tile list per level is prefix-indexed).
 #include "mcs_common.h"
 
 namespace mcs {
 
-constexpr int BT_W = 64, BT_H = 16;
+constexpr int BT_W = 128, BT_H = 32;
 constexpr int BI_W = BT_W + 4, BI_H = BT_H + 4;
+constexpr int BI_PITCH = BI_W + 4;   // 136: multiple of 4
 
 __device__ __forceinline__ int reflect101(int p, int len) {
 	// single reflection is enough for |overshoot| < len; callers guarantee len >= 3 and overshoot <= 25 < len
@@ -20,8 +22,8 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 }
 
 __global__ __launch_bounds__(256) void k_blur(ExtractBuffers b, int tilesPerImage) {
-	__shared__ uint8_t in[BI_H][BI_W + 4];
-	__shared__ unsigned short hs[BI_H][BT_W];
+	__shared__ __attribute__((aligned(16))) uint8_t in[BI_H][BI_PITCH];
+	__shared__ __attribute__((aligned(16))) unsigned short hs[BI_H][BT_W];
 	const PyrDesc& d = *b.desc;
 	const int img = blockIdx.x / tilesPerImage;
 	int t = blockIdx.x - img * tilesPerImage;
@@ -37,27 +39,46 @@ __global__ __launch_bounds__(256) void k_blur(ExtractBuffers b, int tilesPerImag
 	int stride;
 	const uint8_t* src = level_ptr(b, d, img, level, &stride);
 	const int tid = threadIdx.x;
-	for (int i = tid; i < BI_H * BI_W; i += 256) {
-		const int r = i / BI_W, c = i - r * BI_W;
-		const int y = reflect101(min(ty0 + r - 2, L.h + 1), L.h), x = reflect101(min(tx0 + c - 2, L.w + 1), L.w);
-		in[r][c] = src[(size_t)y * stride + x];
+	const bool interior = tx0 >= 2 && ty0 >= 2 && tx0 + BT_W + 2 <= L.w && ty0 + BT_H + 2 <= L.h;
+	if (interior) {   // 33 dwords per input row, coalesced (global addresses may be unaligned; LDS rows are 4-byte aligned)
+		for (int i = tid; i < BI_H * (BI_W / 4); i += 256) {
+			const int r = i / (BI_W / 4), k = i - r * (BI_W / 4);
+			uint32_t v;
+			__builtin_memcpy(&v, src + (size_t)(ty0 + r - 2) * stride + (tx0 - 2) + 4 * k, 4);
+			*reinterpret_cast<uint32_t*>(&in[r][4 * k]) = v;
+		}
+	} else {
+		for (int i = tid; i < BI_H * BI_W; i += 256) {
+			const int r = i / BI_W, c = i - r * BI_W;
+			const int y = reflect101(min(ty0 + r - 2, L.h + 1), L.h), x = reflect101(min(tx0 + c - 2, L.w + 1), L.w);
+			in[r][c] = src[(size_t)y * stride + x];
+		}
 	}
 	__syncthreads();
-	for (int i = tid; i < BI_H * BT_W; i += 256) {
-		const int r = i / BT_W, c = i - r * BT_W;
-		hs[r][c] = (unsigned short)(in[r][c] + in[r][c + 1] + in[r][c + 2] + in[r][c + 3] + in[r][c + 4]);
+	// horizontal 5-sums, 4 adjacent columns per thread from two aligned dword reads
+	for (int i = tid; i < BI_H * (BT_W / 4); i += 256) {
+		const int r = i / (BT_W / 4), c = (i - r * (BT_W / 4)) * 4;
+		const uint32_t a = *reinterpret_cast<const uint32_t*>(&in[r][c]), bq = *reinterpret_cast<const uint32_t*>(&in[r][c + 4]);
+		const int p0 = a & 0xff, p1 = (a >> 8) & 0xff, p2 = (a >> 16) & 0xff, p3 = a >> 24;
+		const int p4 = bq & 0xff, p5 = (bq >> 8) & 0xff, p6 = (bq >> 16) & 0xff, p7 = bq >> 24;
+		const int s0 = p0 + p1 + p2 + p3 + p4;
+		const int s1 = s0 - p0 + p5, s2 = s1 - p1 + p6, s3 = s2 - p2 + p7;
+		*reinterpret_cast<uint2*>(&hs[r][c]) = make_uint2((uint32_t)s0 | ((uint32_t)s1 << 16), (uint32_t)s2 | ((uint32_t)s3 << 16));
 	}
 	__syncthreads();
-	const int oy = tid / 16, ox = (tid % 16) * 4;
-	const int y = ty0 + oy, x = tx0 + ox;
-	if (y < L.h && x < L.w) {
+	const int ox = (tid & 31) * 4;
+	const int x = tx0 + ox;
+	if (x >= L.w) return;
+	uint8_t* dst = b.blur + (size_t)img * d.pyrBytes + L.off;
+	for (int oy = tid >> 5; oy < BT_H; oy += 8) {
+		const int y = ty0 + oy;
+		if (y >= L.h) break;
 		uint32_t packed = 0;
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
 			const int s = hs[oy][ox + i] + hs[oy + 1][ox + i] + hs[oy + 2][ox + i] + hs[oy + 3][ox + i] + hs[oy + 4][ox + i];
 			packed |= (uint32_t)((s + 12) / 25) << (8 * i);
 		}
-		uint8_t* dst = b.blur + (size_t)img * d.pyrBytes + L.off;
 		*reinterpret_cast<uint32_t*>(dst + (size_t)y * L.stride + x) = packed;   // pitch is a multiple of 64: tail bytes stay in-pitch
 	}
 }

@@ -87,9 +87,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 	const uint8_t* src = level_ptr(b, d, img, cell.level, &stride);
 	src += (size_t)(cell.y0 - 3) * stride + (cell.x0 - 3);
 	const int tw = cw + 6, th = ch + 6;
-	for (int i = tid; i < tw * th; i += 256) {
-		int ty = i / tw, tx = i - ty * tw;
-		tile[ty * kTilePitch + tx] = src[(size_t)ty * stride + tx];
+	const int ndw = (tw + 3) >> 2;   // unaligned dword loads; the <= 3 bytes of over-read per row stay inside the image row
+	for (int i = tid; i < ndw * th; i += 256) {
+		const int ty = i / ndw, kx = i - ty * ndw;
+		uint32_t v;
+		__builtin_memcpy(&v, src + (size_t)ty * stride + 4 * kx, 4);
+		*reinterpret_cast<uint32_t*>(&tile[ty * kTilePitch + 4 * kx]) = v;
 	}
 	const int sw = cw + 2, sh = ch + 2;
 	for (int i = tid; i < sh * kScPitch; i += 256) sc[i] = 0;
