@@ -12,7 +12,7 @@
 #include <vector>
 
 namespace mcs {
-void upload_describe_tables(const signed char* pattern, const signed char* disc);
+void upload_describe_tables(const signed char* pattern, const signed char* disc, const int* umax);
 void launch_single_distance(const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out, hipStream_t s);
 static const signed char kPattern[2048] = {
 #include "learned_pattern_64_orb.inc"
@@ -78,7 +78,7 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 	(void)hipStreamSynchronize(c->stream);
 	for (auto& kv : c->timers) { if (kv.second.a) { (void)hipEventDestroy(kv.second.a); (void)hipEventDestroy(kv.second.b); } }
 	(void)hipFree(c->partial); (void)hipFree(c->partialCount); (void)hipFree(c->stage); (void)hipFree(c->dscalar);
-	(void)hipFree(c->topKeys); (void)hipFree(c->topCnt); (void)hipFree(c->stageOut);
+	(void)hipFree(c->topKeys); (void)hipFree(c->topCnt); (void)hipFree(c->stageOut); (void)hipFree(c->tflag);
 	if (c->ownStream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return MCS_OK;
@@ -260,7 +260,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	for (int v = -kHalfPatch; v <= kHalfPatch; ++v)
 		for (int u = -umax[std::abs(v)]; u <= umax[std::abs(v)]; ++u) { disc.push_back((signed char)u); disc.push_back((signed char)v); }
 	if (disc.size() != 845 * 2) { delete e; return fail(MCS_ERR_INVALID, "internal: disc size"); }
-	upload_describe_tables(kPattern, disc.data());
+	upload_describe_tables(kPattern, disc.data(), umax);
 
 	const size_t B = max_batch;
 #define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) { mcs_extractor_destroy(e); return fail(MCS_ERR_HIP, std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(_e)); } } while (0)

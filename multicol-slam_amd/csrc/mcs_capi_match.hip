@@ -8,6 +8,9 @@
 namespace mcs {
 void launch_single_distance(const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out, hipStream_t s);
 void launch_rows_valid(const int* nkp, int nimg, int cap, uint8_t* valid, hipStream_t s);
+void launch_build_tflag(const uint8_t* tvalid, const int* tgroup, size_t rows, int* out, hipStream_t s);
+void launch_match_stream(const MatchArgs& a, const int* tflag32, hipStream_t s);
+void launch_match_tail(const MatchArgs& a, hipStream_t s);
 }
 using namespace mcs;
 
@@ -93,7 +96,8 @@ static int run_topk(mcs_ctx* c, const DevSets& d, int nsets, const mcs_desc_set*
 	a.nsets = nsets; a.dim = dim; a.K = K; a.countThresh = count_thresh;
 	const size_t outRows = (size_t)nsets * q->n;
 	const int qTiles = (q->n + 255) / 256;
-	static const int kTargetBlocks = getenv("MCS_MATCH_BLOCKS") ? atoi(getenv("MCS_MATCH_BLOCKS")) : 1024;
+	static const int kTargetBlocks = getenv("MCS_MATCH_BLOCKS") ? atoi(getenv("MCS_MATCH_BLOCKS")) : 2048;
+	static const bool kStream = getenv("MCS_MATCH_LDS") == nullptr;   // default: scalar-streamed first stage; MCS_MATCH_LDS=1 selects the LDS-tiled one (A/B)
 	int splits = (kTargetBlocks + qTiles * nsets - 1) / (qTiles * nsets);
 	splits = std::max(1, std::min(splits, (t->n + 255) / 256));
 	a.splits = splits;
@@ -101,7 +105,19 @@ static int run_topk(mcs_ctx* c, const DevSets& d, int nsets, const mcs_desc_set*
 	if (int r = ensure((void**)&c->partialCount, &c->partialCountCap, outRows * splits * sizeof(int))) return r;
 	a.partial = c->partial; a.partialCount = c->partialCount;
 	a.outDist = outDist; a.outIdx = outIdx; a.outCount = outCount;
-	c->tic("match"); launch_match(a, c->stream); c->toc("match");
+	c->tic("match");
+	if (kStream) {
+		const int* tflag32 = nullptr;
+		if (d.tvalid || d.tgroup) {
+			const size_t tRows = tpitch * (nsets - 1) + t->n;
+			if (int r = ensure((void**)&c->tflag, &c->tflagCap, tRows * sizeof(int))) return r;
+			launch_build_tflag(d.tvalid, d.tgroup, tRows, c->tflag, c->stream);
+			tflag32 = c->tflag;
+		}
+		launch_match_stream(a, tflag32, c->stream);
+		launch_match_tail(a, c->stream);
+	} else launch_match(a, c->stream);
+	c->toc("match");
 	HIPCHK(hipGetLastError());
 	return MCS_OK;
 }

@@ -20,9 +20,11 @@
 namespace mcs {
 
 __constant__ signed char c_pattern[2048];
-__constant__ signed char c_disc[845 * 2];
+__constant__ signed char c_disc[845 * 2];   // (u, v) offsets of the orientation disc, row-major in v (kept for reference / taps)
+__constant__ int c_umax[kHalfPatch + 1];      // half-width of disc row |v|
 
-void upload_describe_tables(const signed char* pattern, const signed char* disc) {
+void upload_describe_tables(const signed char* pattern, const signed char* disc, const int* umax) {
+	if (umax) (void)hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax, sizeof(int) * (kHalfPatch + 1));
 	if (pattern) (void)hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), pattern, 2048);
 	if (disc) (void)hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc, 845 * 2);
 }
@@ -79,11 +81,20 @@ __device__ __forceinline__ void img2world(const OcamDev& cam, double u, double v
 	zo = z / norm;
 }
 
+// Blurred neighbourhood of the keypoint staged in LDS: rows row-24..row+24, 52 bytes (13 dwords) from col-24.  A keypoint
+// sits >= 25 px inside the level, so the patch is always inside the ROI; undistorted ORB offsets (|.| <= 22) and almost
+// all distorted ones land in it — a scattered 64-lane byte gather from global memory per sample was address-unit-bound.
+constexpr int kPatchR = 24, kPatchRows = 2 * kPatchR + 1, kPatchPitch = 52;
+constexpr int kPatchBytes = kPatchRows * kPatchPitch;   // 2548
+
 struct Sampler {
 	const uint8_t* blur; int bstride;
 	const uint8_t* raw; int rstride;
 	int w, h;
+	const uint8_t* patch; int prow, pcol;   // LDS patch and the level coordinates of its origin
 	__device__ __forceinline__ int at(int r, int c) const {
+		const unsigned pr = (unsigned)(r - prow), pc = (unsigned)(c - pcol);
+		if (pr < (unsigned)kPatchRows && pc < (unsigned)kPatchRows) return patch[pr * kPatchPitch + pc];
 		if ((unsigned)r < (unsigned)h && (unsigned)c < (unsigned)w) return blur[(size_t)r * bstride + c];
 		r = r < -kEdge ? -kEdge : (r > h + kEdge - 1 ? h + kEdge - 1 : r);   // clamp to the bordered buffer
 		c = c < -kEdge ? -kEdge : (c > w + kEdge - 1 ? w + kEdge - 1 : c);
@@ -134,14 +145,38 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 		const uint8_t* raw = level_ptr(b, d, img, level, &rstride);
 		sm.blur = b.blur + (size_t)img * d.pyrBytes + L.off; sm.bstride = L.stride;
 		sm.raw = raw; sm.rstride = rstride; sm.w = L.w; sm.h = L.h;
-		// ---- IC_Angle
+		{   // stage the blurred 49x52 neighbourhood (13 unaligned dwords per row, rows are in-pitch even at the right edge)
+			constexpr int kWaveLds = (MODE == 0 ? 0 : 2 * 128 * NB * 8) + 2560;
+			uint8_t* patch = reinterpret_cast<uint8_t*>(lds) + (size_t)wave * kWaveLds + (MODE == 0 ? 0 : 2 * 128 * NB * 8);
+			const uint8_t* bp = sm.blur + (size_t)(row - kPatchR) * sm.bstride + (col - kPatchR);
+			for (int i = lane; i < kPatchRows * 13; i += 64) {
+				const int r = i / 13, k = i - r * 13;
+				uint32_t v;
+				__builtin_memcpy(&v, bp + (size_t)r * sm.bstride + 4 * k, 4);
+				*reinterpret_cast<uint32_t*>(&patch[r * kPatchPitch + 4 * k]) = v;
+			}
+			sm.patch = patch; sm.prow = row - kPatchR; sm.pcol = col - kPatchR;
+		}
+		// ---- IC_Angle: lane l < 33 owns disc row v = l - 16 (9 independent unaligned dword loads), int32 moments
 		int m10 = 0, m01 = 0;
-		const uint8_t* center = raw + (size_t)row * rstride + col;
-		for (int i = lane; i < 845; i += 64) {
-			const int du = c_disc[2 * i], dv = c_disc[2 * i + 1];
-			const int val = center[dv * rstride + du];
-			m10 += du * val;
-			m01 += dv * val;
+		if (lane <= 2 * kHalfPatch) {
+			const int v = lane - kHalfPatch;
+			const int um = c_umax[v < 0 ? -v : v];
+			const uint8_t* rp = raw + (size_t)(row + v) * rstride + (col - kHalfPatch);
+			uint32_t w[9];
+#pragma unroll
+			for (int k = 0; k < 9; ++k) __builtin_memcpy(&w[k], rp + 4 * k, 4);
+			int rowSum = 0, rowMom = 0;
+#pragma unroll
+			for (int j = 0; j <= 2 * kHalfPatch; ++j) {
+				const int u = j - kHalfPatch;
+				int val = (int)((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+				val = (u >= -um && u <= um) ? val : 0;
+				rowSum += val;
+				rowMom += u * val;
+			}
+			m10 = rowMom;
+			m01 = v * rowSum;
 		}
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
@@ -188,7 +223,7 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 	if (!active) return;
 	constexpr int NP = 128 * NB;              // pattern points = 2*8*descSize
 	constexpr int CH = NP / (2 * NB);         // chain elements folded into one point iteration (= 64)
-	double* buf = lds + (size_t)wave * 2 * NP;   // [x | y][NP] distorted coordinates of the current pattern
+	double* buf = reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(lds) + (size_t)wave * (2 * NP * 8 + 2560));   // [x | y][NP] distorted coordinates
 	const OcamDev& cam = b.cams[img];
 	const double zc = -cam.p[0];              // distortPointsOcam: WorldToImg(x, y, -p1)
 	double ukx = 0.0, uky = 0.0;
@@ -272,7 +307,7 @@ static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hi
 	const int wpb = MODE == 0 ? 4 : 1;
 	const int wavesPerImage = (hd.selPerImage + wpb - 1) / wpb * wpb;
 	const int blocks = nimg * wavesPerImage / wpb;
-	const size_t ldsBytes = MODE == 0 ? 0 : (size_t)wpb * 2 * hd.npoints * sizeof(double);
+	const size_t ldsBytes = (size_t)wpb * ((MODE == 0 ? 0 : 2 * hd.npoints * sizeof(double)) + 2560);   // coordinates + blurred patch per wave
 	const int nb = hd.descSize / 8;
 	if (nb == 2) hipLaunchKernelGGL((k_describe<MODE, 2>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 	else if (nb == 4) hipLaunchKernelGGL((k_describe<MODE, 4>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);

@@ -33,6 +33,7 @@ struct mcs_ctx {
 	int* dscalar = nullptr;
 	uint32_t* topKeys = nullptr; size_t topKeysCap = 0;   // packed [set][K][nq] top-K lists feeding the greedy kernels
 	int* topCnt = nullptr; size_t topCntCap = 0;
+	int* tflag = nullptr; size_t tflagCap = 0;            // per-train-row eligibility (camera group or -1) for the streamed matcher
 	uint8_t* stageOut = nullptr; size_t stageOutCap = 0;
 
 	void tic(const char* name) {

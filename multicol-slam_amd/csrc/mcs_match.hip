@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	__shared__ __attribute__((aligned(16))) uint32_t td[MT * DW];
 	__shared__ __attribute__((aligned(16))) uint32_t tm[MASKED ? MT * DW : 4];
 	__shared__ int tflag[MT];   // camera group of the train row, or -1 if not eligible at all
-	constexpr int CB = 32;      // candidate column depth per lane
+	constexpr int CB = 16;      // candidate column depth per lane
 	__shared__ uint32_t cand[CB * 256];
 	const int tid = threadIdx.x;
 	const int set = blockIdx.z, split = blockIdx.y;
@@ -101,14 +101,22 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 		__syncthreads();
 		if (qok) {
 			const int rows = min(MT, t1 - base);
-			for (int r = 0; r < rows; ++r) {
-				const int g = tflag[r];
-				if (g < 0 || (useGroup && g != qg)) continue;
-				const int dist = hamming<DW, MASKED>(q, qm, &td[r * DW], &tm[MASKED ? r * DW : 0]);
-				countLe += dist <= a.countThresh ? 1 : 0;
-				const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)(base + r);
-				if (dist <= a.maxDist && key < best[K - 1]) { cand[cnt * 256 + tid] = key; ++cnt; }
-				if (__any(cnt == CB)) flush();
+			// 4 train rows per trip, branch-free: all LDS broadcasts of a trip are issued before the first use (ILP), rows past
+			// the end of the range carry flag -1 and turn into empty keys
+			for (int r = 0; r < rows; r += 4) {
+				uint32_t key[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const int g = tflag[r + u];
+					const int dist = hamming<DW, MASKED>(q, qm, &td[(r + u) * DW], &tm[MASKED ? (r + u) * DW : 0]);
+					const bool ok = g >= 0 && (!useGroup || g == qg);
+					countLe += (ok && dist <= a.countThresh) ? 1 : 0;
+					key[u] = (ok && dist <= a.maxDist) ? (((uint32_t)dist << 20) | (uint32_t)(base + r + u)) : 0xFFFFFFFFu;
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+					if (key[u] < best[K - 1]) { cand[cnt * 256 + tid] = key[u]; ++cnt; }
+				if (__any(cnt > CB - 4)) flush();
 			}
 		}
 		__syncthreads();
@@ -179,6 +187,22 @@ static void launch_k(const MatchArgs& a, hipStream_t s) {
 	if (a.dim == 16) launch_kd<K, 4>(a, s);
 	else if (a.dim == 32) launch_kd<K, 8>(a, s);
 	else launch_kd<K, 16>(a, s);
+}
+
+// merge + unpack stages only (used after the scalar-streamed first stage of mcs_match_stream.hip)
+void launch_match_tail(const MatchArgs& a, hipStream_t s) {
+	const dim3 grid((a.nq + 255) / 256, 1, a.nsets);
+	if (a.splits > 1) {
+		switch (a.K) {
+			case 1: hipLaunchKernelGGL((k_match_merge<1>), grid, dim3(256), 0, s, a); break;
+			case 2: hipLaunchKernelGGL((k_match_merge<2>), grid, dim3(256), 0, s, a); break;
+			case 4: hipLaunchKernelGGL((k_match_merge<4>), grid, dim3(256), 0, s, a); break;
+			case 8: hipLaunchKernelGGL((k_match_merge<8>), grid, dim3(256), 0, s, a); break;
+			case 16: hipLaunchKernelGGL((k_match_merge<16>), grid, dim3(256), 0, s, a); break;
+			default: hipLaunchKernelGGL((k_match_merge<32>), grid, dim3(256), 0, s, a); break;
+		}
+	}
+	if (a.outDist && a.outIdx) hipLaunchKernelGGL(k_match_unpack, grid, dim3(256), 0, s, a);
 }
 
 void launch_match(const MatchArgs& a, hipStream_t s) {
