@@ -97,7 +97,7 @@ static int run_topk(mcs_ctx* c, const DevSets& d, int nsets, const mcs_desc_set*
 	const size_t outRows = (size_t)nsets * q->n;
 	const int qTiles = (q->n + 255) / 256;
 	static const int kTargetBlocks = getenv("MCS_MATCH_BLOCKS") ? atoi(getenv("MCS_MATCH_BLOCKS")) : 2048;
-	static const bool kStream = getenv("MCS_MATCH_LDS") == nullptr;   // default: scalar-streamed first stage; MCS_MATCH_LDS=1 selects the LDS-tiled one (A/B)
+	static const bool kStream = getenv("MCS_MATCH_STREAM") != nullptr;   // default: LDS-tiled first stage; MCS_MATCH_STREAM=1 selects the scalar-streamed one (A/B: equal speed, both int-VALU-bound)
 	int splits = (kTargetBlocks + qTiles * nsets - 1) / (qTiles * nsets);
 	splits = std::max(1, std::min(splits, (t->n + 255) / 256));
 	a.splits = splits;
@@ -175,7 +175,7 @@ static int search_common(mcs_ctx* c, int mode, int nsets, const mcs_desc_set* q,
 		int maxDist = thLow;
 		if (mode != 2) while (maxDist < 8 * dim && nnratio * static_cast<double>(maxDist + 1) <= static_cast<double>(thLow)) ++maxDist;
 		if (q->n > 0)
-			if (int r = run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, thLow, maxDist, nullptr, nullptr, c->topCnt)) return r;
+			if (int r = run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, -1, maxDist, nullptr, nullptr, c->topCnt)) return r;
 	}
 	GreedyArgs g{};
 	g.qd = d.qd; g.qm = d.qm; g.qvalid = d.qvalid; g.qgroup = d.qgroup; g.td = d.td; g.tm = d.tm; g.tvalid = d.tvalid; g.tgroup = d.tgroup;

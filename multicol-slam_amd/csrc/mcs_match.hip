@@ -28,7 +28,7 @@ __device__ __forceinline__ int hamming(const uint32_t* q, const uint32_t* qm, co
 	return MASKED ? acc >> 1 : acc;   // static_cast<int>(dist / 2): ONE division of the total
 }
 
-template <int K, int DW, bool MASKED>
+template <int K, int DW, bool MASKED, bool COUNT>
 __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	__shared__ __attribute__((aligned(16))) uint32_t td[MT * DW];
 	__shared__ __attribute__((aligned(16))) uint32_t tm[MASKED ? MT * DW : 4];
@@ -110,13 +110,16 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 					const int g = tflag[r + u];
 					const int dist = hamming<DW, MASKED>(q, qm, &td[(r + u) * DW], &tm[MASKED ? (r + u) * DW : 0]);
 					const bool ok = g >= 0 && (!useGroup || g == qg);
-					countLe += (ok && dist <= a.countThresh) ? 1 : 0;
+					if (COUNT) countLe += (ok && dist <= a.countThresh) ? 1 : 0;
 					key[u] = (ok && dist <= a.maxDist) ? (((uint32_t)dist << 20) | (uint32_t)(base + r + u)) : 0xFFFFFFFFu;
 				}
+				const uint32_t mk = min(min(key[0], key[1]), min(key[2], key[3]));
+				if (__any(mk < best[K - 1])) {   // rare: some lane has a candidate among these 4 rows
 #pragma unroll
-				for (int u = 0; u < 4; ++u)
-					if (key[u] < best[K - 1]) { cand[cnt * 256 + tid] = key[u]; ++cnt; }
-				if (__any(cnt > CB - 4)) flush();
+					for (int u = 0; u < 4; ++u)
+						if (key[u] < best[K - 1]) { cand[cnt * 256 + tid] = key[u]; ++cnt; }
+					if (__any(cnt > CB - 4)) flush();
+				}
 			}
 		}
 		__syncthreads();
@@ -176,8 +179,11 @@ __global__ __launch_bounds__(256) void k_match_unpack(MatchArgs a) {
 template <int K, int DW>
 static void launch_kd(const MatchArgs& a, hipStream_t s) {
 	dim3 grid((a.nq + 255) / 256, a.splits, a.nsets);
-	if (a.qm && a.tm) hipLaunchKernelGGL((k_match_partial<K, DW, true>), grid, dim3(256), 0, s, a);
-	else hipLaunchKernelGGL((k_match_partial<K, DW, false>), grid, dim3(256), 0, s, a);
+	const bool masked = a.qm && a.tm, count = a.countThresh >= 0;   // the searches do not need count_le: skip its 3 VALU ops per pair
+	if (masked && count) hipLaunchKernelGGL((k_match_partial<K, DW, true, true>), grid, dim3(256), 0, s, a);
+	else if (masked) hipLaunchKernelGGL((k_match_partial<K, DW, true, false>), grid, dim3(256), 0, s, a);
+	else if (count) hipLaunchKernelGGL((k_match_partial<K, DW, false, true>), grid, dim3(256), 0, s, a);
+	else hipLaunchKernelGGL((k_match_partial<K, DW, false, false>), grid, dim3(256), 0, s, a);
 	if (a.splits > 1) hipLaunchKernelGGL((k_match_merge<K>), dim3((a.nq + 255) / 256, 1, a.nsets), dim3(256), 0, s, a);
 	if (a.outDist && a.outIdx) hipLaunchKernelGGL(k_match_unpack, dim3((a.nq + 255) / 256, 1, a.nsets), dim3(256), 0, s, a);
 }
