@@ -21,6 +21,17 @@ constexpr int kTileRows = 66;
 constexpr int kScPitch = 64;     // >= wCell_max + 2
 constexpr int kScRows = 62;
 
+// Necessary condition for a 9-of-16 arc: it covers at least two ADJACENT compass points (k = 0, 4, 8, 12), so two
+// adjacent compass pixels must both be darker (d > t) or both be brighter (d < -t) than the centre.  Stricter than
+// cv::FAST's opposite-pair test and never rejects a corner.
+__device__ __forceinline__ bool fast_quick(const uint8_t* c, int t) {
+	const int v = c[0];
+	const int d0 = v - c[3 * kTilePitch], d8 = v - c[-3 * kTilePitch], d4 = v - c[3], d12 = v - c[-3];
+	const bool h0 = d0 > t, h4 = d4 > t, h8 = d8 > t, h12 = d12 > t;
+	const bool l0 = d0 < -t, l4 = d4 < -t, l8 = d8 < -t, l12 = d12 < -t;
+	return (h0 & h4) | (h4 & h8) | (h8 & h12) | (h12 & h0) | (l0 & l4) | (l4 & l8) | (l8 & l12) | (l12 & l0);
+}
+
 __device__ __forceinline__ int fast_score(const uint8_t* c /* centre in LDS tile */, int t) {
 	const int v = c[0];
 	int d[16];
@@ -28,12 +39,6 @@ __device__ __forceinline__ int fast_score(const uint8_t* c /* centre in LDS tile
 	d[8] = v - c[-3 * kTilePitch];
 	d[4] = v - c[3];
 	d[12] = v - c[-3];
-	// necessary condition (same pairs as cv::FAST's high-speed test): every 9-arc contains k or k+8 for each k
-	{
-		const bool o0 = (d[0] > t) | (d[0] < -t) | (d[8] > t) | (d[8] < -t);
-		const bool o4 = (d[4] > t) | (d[4] < -t) | (d[12] > t) | (d[12] < -t);
-		if (!(o0 & o4)) return 0;
-	}
 	d[1] = v - c[3 * kTilePitch + 1];
 	d[2] = v - c[2 * kTilePitch + 2];
 	d[3] = v - c[1 * kTilePitch + 3];
@@ -68,6 +73,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 	__shared__ uint8_t sc[kScRows * kScPitch];
 	__shared__ int waveCnt[4];
 	__shared__ int runBase;
+	__shared__ int nSurv;
+	__shared__ unsigned short surv[60 * 60];   // pixel indices that pass the compass test (cell processed region <= 60x60)
 
 	// XCD-aware mapping: hardware places block i on XCD i%8; give every XCD a contiguous run of cells so that the
 	// overlapping cell rings / shared cache lines of neighbouring cells hit the same L2.
@@ -96,20 +103,37 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 	}
 	const int sw = cw + 2, sh = ch + 2;
 	for (int i = tid; i < sh * kScPitch; i += 256) sc[i] = 0;
-	if (tid == 0) runBase = 0;
+	if (tid == 0) { runBase = 0; nSurv = 0; }
 	__syncthreads();
 
 	const int t = d.fastThreshold;
 	const int npx = cw * ch;
-	for (int p = tid; p < npx; p += 256) {
-		int py = p / cw, px = p - py * cw;
-		int s = fast_score(&tile[(py + 3) * kTilePitch + px + 3], t);
-		sc[(py + 1) * kScPitch + px + 1] = (uint8_t)s;
+	const int lane = tid & 63, wave = tid >> 6;
+	// pass 1: cheap compass test on every pixel; survivors are compacted into an LDS list (order is irrelevant here) so that
+	// pass 2 — the full 16-pixel arc score, ~10x the work — runs with all lanes busy instead of diverging inside each wave
+	for (int base = 0; base < npx; base += 256) {
+		const int p = base + tid;
+		bool pass = false;
+		if (p < npx) {
+			const int py = p / cw, px = p - py * cw;
+			pass = fast_quick(&tile[(py + 3) * kTilePitch + px + 3], t);
+		}
+		const unsigned long long bal = __ballot(pass);
+		int wbase = 0;
+		if (lane == 0 && bal) wbase = atomicAdd(&nSurv, __popcll(bal));
+		wbase = __shfl(wbase, 0);
+		if (pass) surv[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)p;
+	}
+	__syncthreads();
+	const int ns = nSurv;
+	for (int i = tid; i < ns; i += 256) {
+		const int p = surv[i];
+		const int py = p / cw, px = p - py * cw;
+		sc[(py + 1) * kScPitch + px + 1] = (uint8_t)fast_score(&tile[(py + 3) * kTilePitch + px + 3], t);
 	}
 	__syncthreads();
 
 	uint32_t* slots = b.slots + (size_t)img * d.slotsPerImage + cell.slot;
-	const int lane = tid & 63, wave = tid >> 6;
 	const short* mapX = b.maskMap + L.mapX;
 	const short* mapY = b.maskMap + L.mapY;
 	const uint8_t* mask = b.mask0 ? b.mask0 + (size_t)img * b.mask0Pitch : nullptr;
