@@ -155,32 +155,44 @@ def run_stream(args, e):
     d_imgs, d_masks = torch.from_numpy(imgs_np).to(dev), torch.from_numpy(masks_np).to(dev)
     camarr = (mcs.Ocam * nimg)(*[mcs.make_ocam(cams[i % NCAM]) for i in range(nimg)])
     rows_f = NCAM * cap
-    # descriptor-side buffers carry one extra multi-frame slot: slot 0 = last multi-frame of the previous step (the stored keyframe)
-    d_nkp = torch.zeros((F + 1) * NCAM, dtype=torch.int32, device=dev)
-    d_kps = torch.zeros(((F + 1) * rows_f, 7), dtype=torch.float32, device=dev)
-    d_desc = torch.zeros(((F + 1) * rows_f, ds), dtype=torch.uint8, device=dev)
-    d_dmask = torch.zeros(((F + 1) * rows_f, ds), dtype=torch.uint8, device=dev)
-    d_rays = torch.zeros(((F + 1) * rows_f, 3), dtype=torch.float64, device=dev)
-    d_valid = torch.zeros((F + 1) * rows_f, dtype=torch.uint8, device=dev)
-    d_match = torch.full((F * rows_f,), -1, dtype=torch.int32, device=dev)
-    d_nmatch = torch.zeros(F, dtype=torch.int32, device=dev)
-    d_fb = torch.zeros(F, dtype=torch.int32, device=dev)
-    q = mcs.DescSet(ptr(d_desc, rows_f), ptr(d_dmask, rows_f) if masks_on else None, ptr(d_valid, rows_f), None, rows_f, ds)
-    t = mcs.DescSet(ptr(d_desc, 0), ptr(d_dmask, 0) if masks_on else None, ptr(d_valid, 0), None, rows_f, ds)
+    # Descriptor-side buffers carry one extra multi-frame slot: slot 0 = last multi-frame of the previous step (the stored keyframe).
+    # Two such buffer sets alternate between steps (ping-pong): the greedy match resolution of step n runs on the library's side
+    # stream while step n+1 already extracts into the other set.
+    def make_set():
+        b = Env()
+        b.nkp = torch.zeros((F + 1) * NCAM, dtype=torch.int32, device=dev)
+        b.kps = torch.zeros(((F + 1) * rows_f, 7), dtype=torch.float32, device=dev)
+        b.desc = torch.zeros(((F + 1) * rows_f, ds), dtype=torch.uint8, device=dev)
+        b.dmask = torch.zeros(((F + 1) * rows_f, ds), dtype=torch.uint8, device=dev)
+        b.rays = torch.zeros(((F + 1) * rows_f, 3), dtype=torch.float64, device=dev)
+        b.valid = torch.zeros((F + 1) * rows_f, dtype=torch.uint8, device=dev)
+        b.match = torch.full((F * rows_f,), -1, dtype=torch.int32, device=dev)
+        b.nmatch = torch.zeros(F, dtype=torch.int32, device=dev)
+        b.fb = torch.zeros(F, dtype=torch.int32, device=dev)
+        b.q = mcs.DescSet(ptr(b.desc, rows_f), ptr(b.dmask, rows_f) if masks_on else None, ptr(b.valid, rows_f), None, rows_f, ds)
+        b.t = mcs.DescSet(ptr(b.desc, 0), ptr(b.dmask, 0) if masks_on else None, ptr(b.valid, 0), None, rows_f, ds)
+        return b
+
+    sets = [make_set(), make_set()]
+    state = {"cur": 0}
 
     def step():
-        ex.extract_device(nimg, d_imgs.data_ptr(), W * H, W, d_masks.data_ptr(), W * H, W, camarr, ptr(d_nkp, NCAM), ptr(d_kps, rows_f), ptr(d_desc, rows_f),
-                          ptr(d_dmask, rows_f), ptr(d_rays, rows_f))
-        mcs.check(lib.mcs_rows_valid(ctx.h, C.c_void_p(ptr(d_nkp, 0)), (F + 1) * NCAM, cap, C.c_void_p(ptr(d_valid, 0))))
-        mcs.check(lib.mcs_search_kf_kf(ctx.h, F, C.byref(q), rows_f, C.byref(t), rows_f, ds, 0.9, args.topk, mcs.MEM_DEVICE, C.c_void_p(d_match.data_ptr()),
-                                       C.c_void_p(d_nmatch.data_ptr()), C.c_void_p(d_fb.data_ptr())))
-        d_nkp[:NCAM].copy_(d_nkp[F * NCAM:], non_blocking=True)       # slot F -> slot 0: next step's stored keyframe
-        d_desc[:rows_f].copy_(d_desc[F * rows_f:], non_blocking=True)
-        d_dmask[:rows_f].copy_(d_dmask[F * rows_f:], non_blocking=True)
+        b, o = sets[state["cur"]], sets[state["cur"] ^ 1]
+        state["cur"] ^= 1
+        b.nkp[:NCAM].copy_(o.nkp[F * NCAM:], non_blocking=True)       # previous step's last multi-frame -> slot 0 (stored keyframe)
+        b.desc[:rows_f].copy_(o.desc[F * rows_f:], non_blocking=True)
+        b.dmask[:rows_f].copy_(o.dmask[F * rows_f:], non_blocking=True)
+        ex.extract_device(nimg, d_imgs.data_ptr(), W * H, W, d_masks.data_ptr(), W * H, W, camarr, ptr(b.nkp, NCAM), ptr(b.kps, rows_f), ptr(b.desc, rows_f),
+                          ptr(b.dmask, rows_f), ptr(b.rays, rows_f))
+        mcs.check(lib.mcs_rows_valid(ctx.h, C.c_void_p(ptr(b.nkp, 0)), (F + 1) * NCAM, cap, C.c_void_p(ptr(b.valid, 0))))
+        mcs.check(lib.mcs_search_kf_kf(ctx.h, F, C.byref(b.q), rows_f, C.byref(b.t), rows_f, ds, 0.9, args.topk, mcs.MEM_DEVICE, C.c_void_p(b.match.data_ptr()),
+                                       C.c_void_p(b.nmatch.data_ptr()), C.c_void_p(b.fb.data_ptr())))
 
     elapsed = timed(e, step, args.warmup, args.steps, ex.status)
+    last = sets[state["cur"] ^ 1]                                       # the set written by the last step
+    d_nkp, d_desc, d_dmask = last.nkp, last.desc, last.dmask
     feats_step = int(d_nkp[NCAM:].sum().item())
-    matches_step, fallbacks = int(d_nmatch.sum().item()), int(d_fb.sum().item())
+    matches_step, fallbacks = int(last.nmatch.sum().item()), int(last.fb.sum().item())
     elapsed_max, feats_all = e.rig.reduce_timing(elapsed, feats_step, dev, e.world)
 
     roof = check = cpu = None

@@ -64,6 +64,12 @@ int mcs_device_count(int* n);
 int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out);
 int mcs_ctx_destroy(mcs_ctx*);
 int mcs_ctx_synchronize(mcs_ctx*);
+/* DEVICE-kind calls only enqueue work.  Internally the library forks independent / latency-bound kernels (the blur, the
+ * greedy match resolution) onto a second stream so they overlap the VALU-bound ones.  Everything an extraction produces is
+ * ordered on the context's stream again before mcs_extract_batch returns; the outputs of mcs_search_* (match arrays, counts)
+ * are complete for later work on the context's stream only after mcs_ctx_join (a stream-side wait, no host block), after
+ * the next mcs_search_* / mcs_match_* call, or after mcs_ctx_synchronize.  MCS_NO_OVERLAP=1 in the environment disables the fork. */
+int mcs_ctx_join(mcs_ctx*);
 
 /* ------------------------------------------------------------------ extractor
  * An extractor is built for one image size and a maximum batch (images per launch).  It owns the device pyramid,

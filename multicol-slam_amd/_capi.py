@@ -67,7 +67,7 @@ EXPORTS = [
     "mcs_extractor_destroy", "mcs_extractor_kp_capacity", "mcs_extractor_levels", "mcs_extract_batch", "mcs_extractor_status",
     "mcs_extractor_tap_level", "mcs_extractor_tap_candidates", "mcs_extractor_tap_selected", "mcs_match_topk",
     "mcs_match_topk_batched", "mcs_descriptor_distance", "mcs_descriptor_distance_masked", "mcs_ctx_enable_timing",
-    "mcs_ctx_kernel_ms", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_rows_valid",
+    "mcs_ctx_kernel_ms", "mcs_ctx_join", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_rows_valid",
 ]
 
 _lib = None
@@ -88,6 +88,7 @@ def lib():
     L.mcs_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     L.mcs_ctx_destroy.argtypes = [vp]
     L.mcs_ctx_synchronize.argtypes = [vp]
+    L.mcs_ctx_join.argtypes = [vp]
     L.mcs_ctx_enable_timing.argtypes = [vp, C.c_int]
     L.mcs_ctx_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float)]
     L.mcs_extractor_create.argtypes = [vp, C.POINTER(ExtractorParams), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -68,7 +69,21 @@ int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
 	if (hip_stream) c->stream = (hipStream_t)hip_stream;
 	else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownStream = true; }
 	HIPCHK(hipMalloc(&c->dscalar, 64));
+	if (getenv("MCS_NO_OVERLAP") == nullptr) {
+		HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+		HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&c->evBlur, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&c->evMatch, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&c->evGreedy, hipEventDisableTiming));
+	}
 	*out = c;
+	return MCS_OK;
+}
+
+// make the context's main stream wait for everything queued on the side stream (outputs of the searches are written there)
+int mcs_ctx_join(mcs_ctx* c) {
+	if (!c) return fail(MCS_ERR_INVALID, "null ctx");
+	if (c->side && c->greedyPending) { HIPCHK(hipStreamWaitEvent(c->stream, c->evGreedy, 0)); c->greedyPending = false; }
 	return MCS_OK;
 }
 
@@ -79,6 +94,11 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 	for (auto& kv : c->timers) { if (kv.second.a) { (void)hipEventDestroy(kv.second.a); (void)hipEventDestroy(kv.second.b); } }
 	(void)hipFree(c->partial); (void)hipFree(c->partialCount); (void)hipFree(c->stage); (void)hipFree(c->dscalar);
 	(void)hipFree(c->topKeys); (void)hipFree(c->topCnt); (void)hipFree(c->stageOut); (void)hipFree(c->tflag);
+	if (c->side) {
+		(void)hipStreamSynchronize(c->side);
+		(void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evBlur); (void)hipEventDestroy(c->evMatch); (void)hipEventDestroy(c->evGreedy);
+		(void)hipStreamDestroy(c->side);
+	}
 	if (c->ownStream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return MCS_OK;
@@ -87,6 +107,7 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 int mcs_ctx_synchronize(mcs_ctx* c) {
 	if (!c) return fail(MCS_ERR_INVALID, "null ctx");
 	HIPCHK(hipStreamSynchronize(c->stream));
+	if (c->side) { HIPCHK(hipStreamSynchronize(c->side)); c->greedyPending = false; }
 	return MCS_OK;
 }
 
@@ -382,9 +403,19 @@ int mcs_extract_batch(mcs_extractor* e, int nimg, const uint8_t* images, size_t 
 		b.cams = e->d_cams;
 	}
 	c->tic("pyramid"); launch_pyramid(b, hd, nimg, s); c->toc("pyramid");
-	c->tic("fast"); launch_fast(b, hd, nimg, s); c->toc("fast");
-	c->tic("octree"); launch_octree(b, hd, nimg, s); c->toc("octree");
-	c->tic("blur"); launch_blur(b, hd, nimg, s); c->toc("blur");
+	if (c->overlap()) {   // blur only needs the pyramid: run it beside FAST + oct-tree (the oct-tree leaves most CUs idle)
+		HIPCHK(hipEventRecord(c->evFork, s));
+		HIPCHK(hipStreamWaitEvent(c->side, c->evFork, 0));
+		launch_blur(b, hd, nimg, c->side);
+		HIPCHK(hipEventRecord(c->evBlur, c->side));
+		launch_fast(b, hd, nimg, s);
+		launch_octree(b, hd, nimg, s);
+		HIPCHK(hipStreamWaitEvent(s, c->evBlur, 0));
+	} else {
+		c->tic("fast"); launch_fast(b, hd, nimg, s); c->toc("fast");
+		c->tic("octree"); launch_octree(b, hd, nimg, s); c->toc("octree");
+		c->tic("blur"); launch_blur(b, hd, nimg, s); c->toc("blur");
+	}
 	c->tic("describe"); launch_describe(b, hd, nimg, s); c->toc("describe");
 	HIPCHK(hipGetLastError());
 	e->last = b; e->lastN = nimg;

@@ -89,6 +89,7 @@ static int run_topk(mcs_ctx* c, const DevSets& d, int nsets, const mcs_desc_set*
                     int K, int count_thresh, int max_dist, int* outDist, int* outIdx, int* outCount) {
 	MatchArgs a{};
 	a.maxDist = max_dist;
+	if (c->side && c->greedyPending) { HIPCHK(hipStreamWaitEvent(c->stream, c->evGreedy, 0)); c->greedyPending = false; }
 	if (int r = ensure((void**)&c->topKeys, &c->topKeysCap, std::max<size_t>((size_t)nsets * q->n, 1) * K * sizeof(uint32_t))) return r;
 	a.keys = c->topKeys;
 	a.qd = d.qd; a.qm = d.qm; a.qvalid = d.qvalid; a.qgroup = d.qgroup; a.td = d.td; a.tm = d.tm; a.tvalid = d.tvalid; a.tgroup = d.tgroup;
@@ -160,6 +161,10 @@ static int search_common(mcs_ctx* c, int mode, int nsets, const mcs_desc_set* q,
 	if (mode == 2 && (!rays1 || !rays2 || !E || nrCams < 1)) return fail(MCS_ERR_INVALID, "triangulation search needs rays and essential matrices");
 	HIPCHK(hipSetDevice(c->device));
 	hipStream_t s = c->stream;
+	if (c->side && c->greedyPending) {   // the previous search's greedy pass (side stream) still reads the shared list buffers
+		HIPCHK(hipStreamWaitEvent(s, c->evGreedy, 0));
+		c->greedyPending = false;
+	}
 	const bool havingMasks = q->mask != nullptr;
 	// thresholds of cORBmatcher::cORBmatcher (src/cORBmatcher.cpp:46-65); only TH_LOW_ is used by these three searches
 	const int thLow = havingMasks ? (int)floor((double)dim) : 2 * dim;
@@ -186,7 +191,16 @@ static int search_common(mcs_ctx* c, int mode, int nsets, const mcs_desc_set* q,
 	const size_t outN = (size_t)nsets * (mode == 1 ? t->n : q->n);
 	if (kind == MCS_MEM_DEVICE) {
 		g.outMatch = out_match; g.outCount = out_nmatches; g.outFallbacks = out_fallbacks;
-		c->tic("greedy"); launch_greedy(g, s); c->toc("greedy");
+		if (c->overlap()) {
+			// the greedy resolution is one wave per set pair (latency-bound): run it on the side stream so that whatever the caller
+			// enqueues next on the main stream (the next batch's extraction) fills the idle CUs.  mcs_ctx_join / the next search /
+			// mcs_ctx_synchronize order later work behind it.
+			HIPCHK(hipEventRecord(c->evMatch, s));
+			HIPCHK(hipStreamWaitEvent(c->side, c->evMatch, 0));
+			launch_greedy(g, c->side);
+			HIPCHK(hipEventRecord(c->evGreedy, c->side));
+			c->greedyPending = true;
+		} else { c->tic("greedy"); launch_greedy(g, s); c->toc("greedy"); }
 		HIPCHK(hipGetLastError());
 		return MCS_OK;
 	}

@@ -35,6 +35,12 @@ struct mcs_ctx {
 	int* topCnt = nullptr; size_t topCntCap = 0;
 	int* tflag = nullptr; size_t tflagCap = 0;            // per-train-row eligibility (camera group or -1) for the streamed matcher
 	uint8_t* stageOut = nullptr; size_t stageOutCap = 0;
+	// Second HIP stream for the latency-bound / independent kernels (blur next to FAST+oct-tree, the greedy resolution next to the
+	// following batch's extraction): they leave most CUs idle, so overlapping them with the VALU-bound kernels is free throughput.
+	hipStream_t side = nullptr;
+	hipEvent_t evFork = nullptr, evBlur = nullptr, evMatch = nullptr, evGreedy = nullptr;
+	bool greedyPending = false;
+	bool overlap() const { return side != nullptr && !timing; }   // per-kernel timing runs everything in order on the main stream
 
 	void tic(const char* name) {
 		if (!timing) return;
