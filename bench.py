@@ -75,11 +75,16 @@ def setup():
     e.rank = int(os.environ.get("RANK", "0"))
     e.world = int(os.environ.get("WORLD_SIZE", "1"))
     e.local = int(os.environ.get("LOCAL_RANK", "0"))
+    # MCS_BENCH_SHARE_GPU=1: functional test of the N>1 code path on a 1-GPU box (all ranks on cuda:0, gloo for the collectives)
+    share = os.environ.get("MCS_BENCH_SHARE_GPU") == "1"
+    if share:
+        e.local = 0
     if e.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=e.rank, world_size=e.world)
+        dist.init_process_group("gloo" if share else "nccl", rank=e.rank, world_size=e.world)
     torch.cuda.set_device(e.local)
     e.dev = torch.device("cuda", e.local)
+    e.red_dev = torch.device("cpu") if share else e.dev
     e.mcs = importlib.import_module("multicol-slam_amd")
     e.synth = importlib.import_module("multicol-slam_amd.synth")
     e.rig = importlib.import_module("multicol-slam_amd.rig")
@@ -193,7 +198,7 @@ def run_stream(args, e):
     d_nkp, d_desc, d_dmask = last.nkp, last.desc, last.dmask
     feats_step = int(d_nkp[NCAM:].sum().item())
     matches_step, fallbacks = int(last.nmatch.sum().item()), int(last.fb.sum().item())
-    elapsed_max, feats_all = e.rig.reduce_timing(elapsed, feats_step, dev, e.world)
+    elapsed_max, feats_all = e.rig.reduce_timing(elapsed, feats_step, e.red_dev, e.world)
 
     roof = check = cpu = None
     if e.rank == 0:
@@ -335,8 +340,8 @@ def run_rig(args, e):
     feats_step = int(state["an"].sum().item())        # identical on every rank (gathered): counted once
     nq = int(db_valid.sum().item()) if kfs else 0                     # keyframe features of this rank's shard (queries)
     pairs_local = float(nq) * float(state["an"].sum().item())         # x frame features of the F multi-frames of a step
-    elapsed_max, pairs_all = rig.reduce_timing(elapsed, pairs_local, dev, e.world)
-    kern = kernel_times(e, step) if e.rank == 0 else {}
+    elapsed_max, pairs_all = rig.reduce_timing(elapsed, pairs_local, e.red_dev, e.world)
+    kern = kernel_times(e, step)   # every rank: step() contains the all-gather (a collective), so all ranks must keep calling it
     if e.rank == 0:
         value = feats_step * args.steps / elapsed_max / 1e6
         out = {"metric": "Mfeatures/s extract+match, 6-cam 1280x800 rig vs keyframe database", "value": round(value, 3), "unit": "Mfeatures/s", "n_gpus": e.world,

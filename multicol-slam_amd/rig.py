@@ -47,10 +47,14 @@ def allgather_rig(desc, dmask, nkp, ncam, rank, world, group=None):
         return out
 
     send_d, send_m, send_n = pad(desc), pad(dmask), pad(nkp)
+    host_bounce = send_d.is_cuda and dist.get_backend(group) == "gloo"   # functional tests of the N>1 path on one GPU
+
     def gather(send):   # concatenated-along-dim-0 output form (accepted by both nccl/RCCL and gloo), viewed as [world, ...]
-        out = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=dev)
+        if host_bounce:
+            send = send.cpu()
+        out = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         dist.all_gather_into_tensor(out, send, group=group)
-        return out.view((world,) + tuple(send.shape))
+        return out.view((world,) + tuple(send.shape)).to(dev)
 
     out_d, out_m, out_n = gather(send_d), gather(send_m), gather(send_n)
     # rank r, slot j  ->  camera r + j*world   (camera_shard order)
