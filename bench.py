@@ -89,7 +89,11 @@ def setup():
     e.synth = importlib.import_module("multicol-slam_amd.synth")
     e.rig = importlib.import_module("multicol-slam_amd.rig")
     e.lib = e.mcs.lib()
-    e.ctx = e.mcs.Context(e.local, torch.cuda.current_stream(e.dev).cuda_stream)
+    # one explicit (non-default) stream shared by torch's copies and the library's kernels, so their order is the enqueue order
+    e.stream = torch.cuda.Stream(device=e.dev)
+    torch.cuda.set_stream(e.stream)
+    assert e.stream.cuda_stream != 0
+    e.ctx = e.mcs.Context(e.local, e.stream.cuda_stream)
     return e
 
 

@@ -111,3 +111,55 @@ def test_batch_equals_single(G):
     assert G.first_diff(a[0][1], b[0][1]) is None and G.first_diff(a[3][1], b[0][1]) is None
     assert G.first_diff(a[0][2], a[3][2]) is None
     ex3.close()
+
+
+@pytest.mark.parametrize("desc_size,mode", [(16, "mdbrief"), (64, "mdbrief"), (64, "orb"), (16, "dbrief")])
+def test_descriptor_sizes(G, desc_size, mode):
+    """extractor.descSize 16 / 64 (reference: 'Extractor: 32 -> ORB , (16/32/64) -> dBRIEF and mdBRIEF')."""
+    cam = G.cams3()[1]
+    img, mask = G.synth.synth_image(7, 1, cam), G.synth.mirror_mask(cam)
+    kw = dict(MODES[mode], descSize=desc_size, nfeatures=600)
+    ex = G.mcs.Extractor(G.ctx(), 754, 480, max_batch=1, **kw)
+    gk, gd, gm, gr = ex.extract_host([img], [mask], [G.mcs.make_ocam(cam)])[0]
+    _, kps, d, dm, rays = G.oracle_extract(img, mask, cam, **kw)
+    assert gd.shape[1] == desc_size and G.first_diff(gk, kps) is None
+    assert G.first_diff(gd, d) is None and G.first_diff(gm, dm) is None
+    ex.close()
+
+
+def test_big_rig_sizes_config4(G):
+    """BASELINE configs[3]/[4] geometry: 1280x800, 2000 features per camera, scaled Lafida calibration."""
+    cam = G.synth.scaled_camera(G.cams3()[0], 1280, 800)
+    img, mask = G.synth.synth_image(1, 0, cam), G.synth.mirror_mask(cam)
+    kw = dict(MODES["mdbrief"], nfeatures=2000)
+    ex = G.mcs.Extractor(G.ctx(), 1280, 800, max_batch=2, **kw)
+    res = ex.extract_host([img, img[::-1].copy()], [mask, mask[::-1].copy()], [G.mcs.make_ocam(cam)] * 2)
+    for im, mk, r in [(img, mask, res[0]), (img[::-1].copy(), mask[::-1].copy(), res[1])]:
+        _, kps, d, dm, rays = G.oracle_extract(im, mk, cam, **kw)
+        assert len(kps) > 1900
+        assert G.first_diff(r[0], kps) is None and G.first_diff(r[1], d) is None and G.first_diff(r[2], dm) is None
+        assert G.first_diff(r[3].view(np.uint64), rays.view(np.uint64)) is None
+    ex.close()
+
+
+def test_other_pyramid_parameters(G):
+    """scaleFactor 1.1 / 12 levels / FAST threshold 5 / 2N features (the init extractor of src/cTracking.cpp:152-158 uses th 5, 2N)."""
+    cam = G.cams3()[2]
+    img, mask = G.synth.synth_image(9, 2, cam), G.synth.mirror_mask(cam)
+    for kw in (dict(nfeatures=2000, fastThreshold=5), dict(nfeatures=800, scaleFactor=1.1, nlevels=12), dict(nfeatures=300, scaleFactor=1.44, nlevels=4)):
+        ex = G.mcs.Extractor(G.ctx(), 754, 480, max_batch=1, **kw)
+        gk, gd, gm, gr = ex.extract_host([img], [mask], [G.mcs.make_ocam(cam)])[0]
+        _, kps, d, dm, rays = G.oracle_extract(img, mask, cam, **kw)
+        assert G.first_diff(gk, kps) is None and G.first_diff(gd, d) is None, kw
+        ex.close()
+
+
+def test_unsupported_parameters_fail_loudly(G):
+    with pytest.raises(G.mcs.McsError):
+        G.mcs.Extractor(G.ctx(), 754, 480, useAgast=1)
+    with pytest.raises(G.mcs.McsError):
+        G.mcs.Extractor(G.ctx(), 754, 480, fastAgastType=1)
+    with pytest.raises(G.mcs.McsError):
+        G.mcs.Extractor(G.ctx(), 754, 480, descSize=24)
+    with pytest.raises(G.mcs.McsError):
+        G.mcs.Extractor(G.ctx(), 120, 90)            # too small: a level has no 30-px FAST cell
