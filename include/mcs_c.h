@@ -143,6 +143,25 @@ int mcs_search_triangulation(mcs_ctx*, int nsets, const mcs_desc_set* kf1, size_
                              const double* rays1, const double* rays2, const double* E, int nrCams, int dim, int K, mcs_mem_kind kind,
                              int32_t* match12, int32_t* nmatches, int32_t* fallbacks);
 
+/* ------------------------------------------------------------------ window matcher (SURVEY §8f "next" row 1)
+ * int cORBmatcher::SearchByProjection(cMultiFrame& F, const vector<cMapPoint*>& vpMapPoints, const double th)  (src/cORBmatcher.cpp:67-166)
+ * including cMultiFrame::GetFeaturesInArea (src/cMultiFrame.cpp:272-340), PosInGrid (:342-353) and RadiusByViewingCos (:169-175).
+ * A "projection" is one (map point, camera) pair that isInFrustum() marked mbTrackInView, listed in the reference's visiting
+ * order (map point index, then camera): proj_x/y = mTrackProjX/Y, view_cos = mTrackViewCos, level = mnTrackScaleLevel, desc/mask =
+ * the map point's descriptor.  The frame is given flat in mvKeys order (cameras concatenated): keys, desc, mask, keypoint_to_cam,
+ * assigned[i] = (F.mvpMapPoints[i] != NULL) on entry (updated in place like the reference), image size per camera, mvScaleFactors.
+ * match[p] = frame feature index matched to projection p or -1.  Thresholds per cORBmatcher's constructor (TH_HIGH).          */
+typedef struct {
+	const double* proj_x; const double* proj_y; const double* view_cos; const int32_t* level; const int32_t* cam;
+	const uint8_t* desc; const uint8_t* mask; int32_t n; int32_t stride;
+} mcs_projection_set;
+typedef struct {
+	const mcs_keypoint* keys; const uint8_t* desc; const uint8_t* mask; const int32_t* cam; uint8_t* assigned; int32_t n; int32_t stride;
+	int32_t nr_cams; const int32_t* width; const int32_t* height; const double* scale_factors; int32_t nlevels;
+} mcs_frame_view;
+int mcs_search_by_projection(mcs_ctx*, const mcs_projection_set* mp, const mcs_frame_view* frame, double th, double nnratio, int dim,
+                             mcs_mem_kind kind, int32_t* match, int32_t* nmatches);
+
 /* device helper: valid[i*cap + k] = (k < nkp[i]) for the row layout produced by mcs_extract_batch (all pointers on the GPU) */
 int mcs_rows_valid(mcs_ctx*, const int32_t* nkp_dev, int nimg, int cap, uint8_t* valid_dev);
 

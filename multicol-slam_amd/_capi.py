@@ -68,7 +68,19 @@ EXPORTS = [
     "mcs_extractor_tap_level", "mcs_extractor_tap_candidates", "mcs_extractor_tap_selected", "mcs_match_topk",
     "mcs_match_topk_batched", "mcs_descriptor_distance", "mcs_descriptor_distance_masked", "mcs_ctx_enable_timing",
     "mcs_ctx_kernel_ms", "mcs_ctx_join", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_rows_valid",
+    "mcs_search_by_projection",
 ]
+
+
+class ProjectionSet(C.Structure):
+    _fields_ = [("proj_x", C.c_void_p), ("proj_y", C.c_void_p), ("view_cos", C.c_void_p), ("level", C.c_void_p), ("cam", C.c_void_p),
+                ("desc", C.c_void_p), ("mask", C.c_void_p), ("n", C.c_int32), ("stride", C.c_int32)]
+
+
+class FrameView(C.Structure):
+    _fields_ = [("keys", C.c_void_p), ("desc", C.c_void_p), ("mask", C.c_void_p), ("cam", C.c_void_p), ("assigned", C.c_void_p),
+                ("n", C.c_int32), ("stride", C.c_int32), ("nr_cams", C.c_int32), ("width", C.c_void_p), ("height", C.c_void_p),
+                ("scale_factors", C.c_void_p), ("nlevels", C.c_int32)]
 
 _lib = None
 
@@ -109,6 +121,7 @@ def lib():
     L.mcs_search_triangulation.argtypes = [vp, C.c_int, C.POINTER(DescSet), C.c_size_t, C.POINTER(DescSet), C.c_size_t, vp, vp, vp, C.c_int,
                                            C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.mcs_rows_valid.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.mcs_search_by_projection.argtypes = [vp, C.POINTER(ProjectionSet), C.POINTER(FrameView), C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]
     L.mcs_descriptor_distance.argtypes = [vp, vp, vp, C.c_int, i32p]
     L.mcs_descriptor_distance_masked.argtypes = [vp, vp, vp, vp, vp, C.c_int, i32p]
     _lib = L

@@ -233,6 +233,73 @@ int mcs_search_triangulation(mcs_ctx* c, int nsets, const mcs_desc_set* kf1, siz
 	return search_common(c, 2, nsets, kf1, pitch1, kf2, pitch2, dim, 0.0, K, kind, rays1, rays2, E, nrCams, match12, nmatches, fallbacks);
 }
 
+int mcs_search_by_projection(mcs_ctx* c, const mcs_projection_set* mp, const mcs_frame_view* f, double th, double nnratio, int dim, mcs_mem_kind kind,
+                             int32_t* match, int32_t* nmatches) {
+	if (!c || !mp || !f || !match || !nmatches) return fail(MCS_ERR_INVALID, "null argument");
+	if (dim != 16 && dim != 32 && dim != 64) return fail(MCS_ERR_INVALID, "dim must be 16, 32 or 64");
+	if (mp->n < 0 || f->n < 0 || f->n > 65536 || f->nr_cams < 1 || f->nlevels < 1) return fail(MCS_ERR_INVALID, "bad sizes (frame features must be <= 65536)");
+	if ((mp->mask == nullptr) != (f->mask == nullptr)) return fail(MCS_ERR_INVALID, "masks must be given for both sides or neither");
+	if (mp->stride < dim || f->stride < dim || (mp->stride & 3) || (f->stride & 3)) return fail(MCS_ERR_INVALID, "descriptor stride must be >= dim and a multiple of 4");
+	HIPCHK(hipSetDevice(c->device));
+	hipStream_t s = c->stream;
+	if (c->side && c->greedyPending) { HIPCHK(hipStreamWaitEvent(s, c->evGreedy, 0)); c->greedyPending = false; }
+	const bool havingMasks = mp->mask != nullptr;
+	ProjArgs a{};
+	a.nproj = mp->n; a.pstride = mp->stride; a.nfeat = f->n; a.fstride = f->stride; a.nrCams = f->nr_cams;
+	a.th = th; a.ratio = nnratio; a.dim = dim;
+	a.thHigh = havingMasks ? (int)floor(1.5 * dim) : 3 * dim;   // TH_HIGH_ (src/cORBmatcher.cpp:46-65)
+	const size_t np = std::max(mp->n, 1), nf = std::max(f->n, 1);
+	// scratch: lists + counts (+ staged inputs / outputs for host pointers), one allocation per call (this row is not a bench path)
+	size_t need = al256(np * kProjListCap * 8) + al256(np * 4);
+	const size_t oLists = 0, oCounts = al256(np * kProjListCap * 8);
+	size_t o = need;
+	auto reserve = [&](size_t bytes) { const size_t at = o; o += al256(bytes); return at; };
+	size_t oPx = 0, oPy = 0, oVc = 0, oLv = 0, oPc = 0, oPd = 0, oPm = 0, oKeys = 0, oFd = 0, oFm = 0, oFc = 0, oAs = 0, oW = 0, oH = 0, oSc = 0, oMatch = 0, oNm = 0;
+	const bool host = kind == MCS_MEM_HOST;
+	if (host) {
+		oPx = reserve(np * 8); oPy = reserve(np * 8); oVc = reserve(np * 8); oLv = reserve(np * 4); oPc = reserve(np * 4);
+		oPd = reserve(np * mp->stride); oPm = reserve(np * mp->stride); oKeys = reserve(nf * sizeof(mcs_keypoint));
+		oFd = reserve(nf * f->stride); oFm = reserve(nf * f->stride); oFc = reserve(nf * 4); oAs = reserve(nf);
+		oW = reserve((size_t)f->nr_cams * 4); oH = reserve((size_t)f->nr_cams * 4); oSc = reserve((size_t)f->nlevels * 8);
+		oMatch = reserve(np * 4); oNm = reserve(4);
+	}
+	uint8_t* buf = nullptr;
+	HIPCHK(hipMalloc((void**)&buf, o));
+	auto done = [&](int rc) { (void)hipStreamSynchronize(s); (void)hipFree(buf); return rc; };
+	a.lists = (unsigned long long*)(buf + oLists); a.counts = (int*)(buf + oCounts);
+	if (host) {
+#define UP(off, src, bytes) do { if ((bytes) && hipMemcpyAsync(buf + (off), (src), (bytes), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "H2D copy failed")); } while (0)
+		UP(oPx, mp->proj_x, (size_t)mp->n * 8); UP(oPy, mp->proj_y, (size_t)mp->n * 8); UP(oVc, mp->view_cos, (size_t)mp->n * 8);
+		UP(oLv, mp->level, (size_t)mp->n * 4); UP(oPc, mp->cam, (size_t)mp->n * 4); UP(oPd, mp->desc, (size_t)mp->n * mp->stride);
+		if (havingMasks) { UP(oPm, mp->mask, (size_t)mp->n * mp->stride); UP(oFm, f->mask, (size_t)f->n * f->stride); }
+		UP(oKeys, f->keys, (size_t)f->n * sizeof(mcs_keypoint)); UP(oFd, f->desc, (size_t)f->n * f->stride); UP(oFc, f->cam, (size_t)f->n * 4);
+		UP(oAs, f->assigned, (size_t)f->n); UP(oW, f->width, (size_t)f->nr_cams * 4); UP(oH, f->height, (size_t)f->nr_cams * 4);
+		UP(oSc, f->scale_factors, (size_t)f->nlevels * 8);
+#undef UP
+		a.px = (const double*)(buf + oPx); a.py = (const double*)(buf + oPy); a.vcos = (const double*)(buf + oVc); a.level = (const int*)(buf + oLv);
+		a.pcam = (const int*)(buf + oPc); a.pdesc = buf + oPd; a.pmask = havingMasks ? buf + oPm : nullptr;
+		a.keys = (const mcs_keypoint*)(buf + oKeys); a.fdesc = buf + oFd; a.fmask = havingMasks ? buf + oFm : nullptr; a.fcam = (const int*)(buf + oFc);
+		a.assigned = buf + oAs; a.width = (const int*)(buf + oW); a.height = (const int*)(buf + oH); a.scales = (const double*)(buf + oSc);
+		a.match = (int*)(buf + oMatch); a.nmatches = (int*)(buf + oNm);
+	} else {
+		a.px = mp->proj_x; a.py = mp->proj_y; a.vcos = mp->view_cos; a.level = mp->level; a.pcam = mp->cam; a.pdesc = mp->desc; a.pmask = mp->mask;
+		a.keys = f->keys; a.fdesc = f->desc; a.fmask = f->mask; a.fcam = f->cam; a.assigned = f->assigned; a.width = f->width; a.height = f->height;
+		a.scales = f->scale_factors; a.match = match; a.nmatches = nmatches;
+	}
+	if (mp->n > 0) launch_projection(a, s);
+	else if (!host) { HIPCHK(hipMemsetAsync(nmatches, 0, 4, s)); }
+	if (hipGetLastError() != hipSuccess) return done(fail(MCS_ERR_HIP, "projection kernels failed to launch"));
+	if (host) {
+		*nmatches = 0;
+		if (mp->n > 0) {
+			if (hipMemcpyAsync(match, buf + oMatch, (size_t)mp->n * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
+			if (hipMemcpyAsync(nmatches, buf + oNm, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
+			if (hipMemcpyAsync(f->assigned, buf + oAs, (size_t)f->n, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
+		}
+	}
+	return done(MCS_OK);   // synchronises: the scratch is freed here (DEVICE kind therefore blocks too; this row is not on the bench path)
+}
+
 int mcs_rows_valid(mcs_ctx* c, const int32_t* nkp_dev, int nimg, int cap, uint8_t* valid_dev) {
 	if (!c || !nkp_dev || !valid_dev || nimg < 1 || cap < 1) return fail(MCS_ERR_INVALID, "bad argument");
 	HIPCHK(hipSetDevice(c->device));

@@ -125,4 +125,18 @@ struct GreedyArgs {
 };
 void launch_greedy(const GreedyArgs& g, hipStream_t s);
 
+// window matcher (SearchByProjection), mcs_project.hip
+constexpr int kProjListCap = 64;
+struct ProjArgs {
+	const double* px; const double* py; const double* vcos; const int* level; const int* pcam;
+	const uint8_t* pdesc; const uint8_t* pmask; int nproj; int pstride;
+	const mcs_keypoint* keys; const uint8_t* fdesc; const uint8_t* fmask; const int* fcam; uint8_t* assigned; int nfeat; int fstride;
+	const int* width; const int* height; const double* scales; int nrCams;
+	double th; double ratio; int dim; int thHigh;
+	unsigned long long* lists; int* counts;   // [nproj][kProjCap], [nproj] (count may exceed kProjCap = overflow)
+	int* match; int* nmatches;
+};
+
+void launch_projection(const ProjArgs& a, hipStream_t s);
+
 }  // namespace mcs

@@ -1,0 +1,191 @@
+// mcs_project.hip — window matcher, SURVEY §8f "next" row 1:
+//   cORBmatcher::SearchByProjection(cMultiFrame&, const vector<cMapPoint*>&, th)   src/cORBmatcher.cpp:67-166
+//   cMultiFrame::GetFeaturesInArea                                                src/cMultiFrame.cpp:272-340
+//   cMultiFrame::PosInGrid (cvRound binning, bins 64 / 48 dropped)                :342-353
+//   cORBmatcher::RadiusByViewingCos                                               src/cORBmatcher.cpp:169-175
+// The reference visits the 64x48 grid cells of the window column by column (ix outer, iy inner) and the features of a cell
+// in insertion (= mvKeys index) order; with strict '<' updates the winner is the candidate with the smallest
+// (distance, cell, index) and the runner-up the next one.  So every (map point, camera) projection gets the list of its window
+// members keyed by  dist<<42 | cell<<20 | index  (k_proj_candidates, one wave per projection, fully parallel), and the greedy
+// part — a feature taken by an earlier projection is skipped by all later ones — runs as the same speculative wave-parallel
+// commit as the brute-force searches (k_proj_greedy).  Pure integer + IEEE double arithmetic: bit-exact.
+#include "mcs_common.h"
+
+namespace mcs {
+
+constexpr int kGridCols = 64, kGridRows = 48;   // FRAME_GRID_COLS / ROWS (include/cMultiFrame.h)
+constexpr int kProjCap = 64;                    // list entries per projection; longer windows are rescanned exactly
+
+struct Window { int minCX, maxCX, minCY, maxCY, minLevel, maxLevel; double x, y, rr, wInv, hInv; bool empty; };
+
+__device__ __forceinline__ Window make_window(const ProjArgs& a, int p) {
+	Window w;
+	const int cam = a.pcam[p], lvl = a.level[p];
+	double r = a.vcos[p] > 0.998 ? 2.5 : 4.0;
+	if (a.th != 1.0) r *= a.th;
+	w.x = a.px[p]; w.y = a.py[p]; w.rr = r * a.scales[lvl];
+	w.minLevel = lvl - 1; w.maxLevel = lvl;
+	w.wInv = static_cast<double>(kGridCols) / static_cast<double>(a.width[cam] - 0);
+	w.hInv = static_cast<double>(kGridRows) / static_cast<double>(a.height[cam] - 0);
+	w.empty = false;
+	int v = (int)floor((w.x - 0 - w.rr) * w.wInv); v = max(0, v); if (v >= kGridCols) w.empty = true; w.minCX = v;
+	v = (int)ceil((w.x - 0 + w.rr) * w.wInv); v = min(kGridCols - 1, v); if (v < 0) w.empty = true; w.maxCX = v;
+	v = (int)floor((w.y - 0 - w.rr) * w.hInv); v = max(0, v); if (v >= kGridRows) w.empty = true; w.minCY = v;
+	v = (int)ceil((w.y - 0 + w.rr) * w.hInv); v = min(kGridRows - 1, v); if (v < 0) w.empty = true; w.maxCY = v;
+	return w;
+}
+
+// visiting-order part of the key (cell<<20 | index) if feature i is returned by GetFeaturesInArea for this window, else ~0
+__device__ __forceinline__ unsigned long long member_key(const ProjArgs& a, const Window& w, int cam, int i) {
+	if (a.fcam[i] != cam) return ~0ull;
+	const mcs_keypoint kp = a.keys[i];
+	const int gx = __double2int_rn((kp.x - 0) * w.wInv), gy = __double2int_rn((kp.y - 0) * w.hInv);   // PosInGrid: cvRound
+	if (gx < 0 || gx >= kGridCols || gy < 0 || gy >= kGridRows) return ~0ull;                            // never entered a cell
+	if (gx < w.minCX || gx > w.maxCX || gy < w.minCY || gy > w.maxCY) return ~0ull;
+	const bool checkLevels = !(w.minLevel == -1 && w.maxLevel == -1), same = w.minLevel == w.maxLevel;
+	if (checkLevels && !same) { if (kp.octave < w.minLevel || kp.octave > w.maxLevel) return ~0ull; }
+	else if (same) { if (kp.octave != w.minLevel) return ~0ull; }
+	if (fabs(kp.x - w.x) > w.rr || fabs(kp.y - w.y) > w.rr) return ~0ull;
+	return ((unsigned long long)(gx * kGridRows + gy) << 20) | (unsigned long long)i;
+}
+
+__device__ __forceinline__ int proj_distance(const ProjArgs& a, int p, int i) {
+	const uint32_t* q = reinterpret_cast<const uint32_t*>(a.pdesc + (size_t)p * a.pstride);
+	const uint32_t* t = reinterpret_cast<const uint32_t*>(a.fdesc + (size_t)i * a.fstride);
+	int acc = 0;
+	if (a.pmask) {
+		const uint32_t* qm = reinterpret_cast<const uint32_t*>(a.pmask + (size_t)p * a.pstride);
+		const uint32_t* tm = reinterpret_cast<const uint32_t*>(a.fmask + (size_t)i * a.fstride);
+		for (int w = 0; w < a.dim / 4; ++w) { const uint32_t x = q[w] ^ t[w]; acc += __popc(x & qm[w]); acc += __popc(x & tm[w]); }
+		return acc >> 1;
+	}
+	for (int w = 0; w < a.dim / 4; ++w) acc += __popc(q[w] ^ t[w]);
+	return acc;
+}
+
+__global__ __launch_bounds__(64) void k_proj_candidates(ProjArgs a) {
+	__shared__ int cnt;
+	const int p = blockIdx.x, lane = threadIdx.x;
+	if (lane == 0) cnt = 0;
+	__syncthreads();
+	const Window w = make_window(a, p);
+	const int cam = a.pcam[p];
+	if (!w.empty) {
+		for (int i0 = 0; i0 < a.nfeat; i0 += 64) {
+			const int i = i0 + lane;
+			unsigned long long key = ~0ull;
+			if (i < a.nfeat) {
+				const unsigned long long mk = member_key(a, w, cam, i);
+				if (mk != ~0ull) key = ((unsigned long long)proj_distance(a, p, i) << 42) | mk;
+			}
+			if (key != ~0ull) {
+				const int slot = atomicAdd(&cnt, 1);
+				if (slot < kProjCap) a.lists[(size_t)p * kProjCap + slot] = key;
+			}
+		}
+	}
+	__syncthreads();
+	if (lane == 0) a.counts[p] = cnt;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+		const unsigned long long y = ((unsigned long long)hi << 32) | lo;
+		v = y < v ? y : v;
+	}
+	return v;
+}
+
+__global__ __launch_bounds__(64) void k_proj_greedy(ProjArgs a) {
+	__shared__ uint32_t taken[65536 / 32];   // frame features <= 65536
+	const int lane = threadIdx.x;
+	for (int i = lane; i < (a.nfeat + 31) / 32; i += 64) taken[i] = 0;
+	__syncthreads();
+	for (int i = lane; i < a.nfeat; i += 64) if (a.assigned[i]) atomicOr(&taken[i >> 5], 1u << (i & 31));
+	__syncthreads();
+	int nmatches = 0;
+	const unsigned long long NONE = ~0ull;
+	for (int p0 = 0; p0 < a.nproj; p0 += 64) {
+		const int p = p0 + lane;
+		bool resolved = p >= a.nproj;
+		const int cnt = resolved ? 0 : a.counts[p];
+		if (!resolved) a.match[p] = -1;
+		if (!resolved && cnt == 0) resolved = true;
+		for (int round = 0; round < 130; ++round) {
+			const unsigned long long pend = __ballot(!resolved);
+			if (pend == 0ull) break;
+			const int low = __ffsll((long long)pend) - 1;
+			// tentative best / second among the free members of my window
+			unsigned long long k1 = NONE, k2 = NONE;
+			const bool overflow = !resolved && cnt > kProjCap;
+			if (!resolved && !overflow) {
+				for (int e = 0; e < cnt; ++e) {
+					const unsigned long long k = a.lists[(size_t)p * kProjCap + e];
+					const int idx = (int)(k & 0xFFFFFu);
+					if ((taken[idx >> 5] >> (idx & 31)) & 1u) continue;
+					if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+				}
+			}
+			// the lowest pending projection is rescanned exactly by the whole wave if its list overflowed
+			if (__shfl((int)overflow, low)) {
+				const int pp = p0 + low;
+				const Window w = make_window(a, pp);
+				const int cam = a.pcam[pp];
+				unsigned long long b1 = NONE, b2 = NONE;
+				for (int i = lane; i < a.nfeat; i += 64) {
+					if ((taken[i >> 5] >> (i & 31)) & 1u) continue;
+					const unsigned long long mk = member_key(a, w, cam, i);
+					if (mk == NONE) continue;
+					const unsigned long long k = ((unsigned long long)proj_distance(a, pp, i) << 42) | mk;
+					if (k < b1) { b2 = b1; b1 = k; } else if (k < b2) b2 = k;
+				}
+				const unsigned long long m1 = wave_min_u64(b1);
+				const unsigned long long m2 = wave_min_u64(b1 == m1 ? b2 : b1);
+				if (lane == low) { k1 = m1; k2 = m2; }
+			}
+			// decision (:153-163)
+			int state = 0, bestIdx = -1, secondIdx = -1;   // 0 no match, 1 match, 2 waiting for its rescan
+			if (!resolved) {
+				if (overflow && lane != low) state = 2;
+				else if (k1 != NONE) {
+					const int best = (int)(k1 >> 42);
+					bestIdx = (int)(k1 & 0xFFFFFu);
+					int second = 0x7FFFFFFF, lvl2 = -1;
+					if (k2 != NONE) { second = (int)(k2 >> 42); secondIdx = (int)(k2 & 0xFFFFFu); lvl2 = a.keys[secondIdx].octave; }
+					const int lvl1 = a.keys[bestIdx].octave;
+					if (best <= a.thHigh && !(lvl1 == lvl2 && static_cast<double>(best) > a.ratio * static_cast<double>(second))) state = 1;
+				}
+			}
+			// finality: no lower pending lane of this round may take my best or my second feature (accepting lanes broadcast their
+			// target one after the other; at most 64 shuffles per round)
+			bool blocked = !resolved && state == 2;
+			const unsigned long long acc = __ballot(!resolved && state == 1);
+			unsigned long long rest = acc;
+			while (rest) {
+				const int l = __ffsll((long long)rest) - 1;
+				rest &= rest - 1;
+				const int tgt = __shfl(bestIdx, l);
+				if (!resolved && lane > l && (tgt == bestIdx || tgt == secondIdx)) blocked = true;
+			}
+			const unsigned long long blk = __ballot(blocked);
+			const int firstBlocked = blk ? __ffsll((long long)blk) - 1 : 64;
+			const bool commit = !resolved && lane < firstBlocked;
+			if (commit) {
+				if (state == 1) { atomicOr(&taken[bestIdx >> 5], 1u << (bestIdx & 31)); a.assigned[bestIdx] = 1; a.match[p] = bestIdx; }
+				resolved = true;
+			}
+			nmatches += __popcll(__ballot(commit && state == 1));
+			__syncthreads();
+		}
+	}
+	if (lane == 0) *a.nmatches = nmatches;
+}
+
+void launch_projection(const ProjArgs& a, hipStream_t s) {
+	hipLaunchKernelGGL(k_proj_candidates, dim3(a.nproj), dim3(64), 0, s, a);
+	hipLaunchKernelGGL(k_proj_greedy, dim3(1), dim3(64), 0, s, a);
+}
+
+}  // namespace mcs

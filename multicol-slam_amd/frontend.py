@@ -262,6 +262,49 @@ class cORBmatcher:
         self.last_fallbacks = int(fb[0])
         return int(nm[0]), [mp1[i] if i >= 0 else None for i in mF[:F.totalN]]
 
+    def SearchByProjection(self, F, vpMapPoints, th):
+        """int SearchByProjection(cMultiFrame &F, const vector<cMapPoint*> &vpMapPoints, const double th) (src/cORBmatcher.cpp:67-166).
+        Map points carry what isInFrustum() left on them (src/cMultiFrame.cpp:218-270): mbTrackInView[cam], mTrackProjX/Y[cam],
+        mnTrackScaleLevel[cam], mTrackViewCos[cam], plus GetDescriptor()/GetDescriptorMask() (numpy rows).  Fills F.mvpMapPoints."""
+        from ._capi import FrameView, ProjectionSet
+        nr = F.camSystem.GetNrCams()
+        owner, px, py, vc, lv, pc, dd, mm = [], [], [], [], [], [], [], []
+        for pMP in vpMapPoints:                       # the reference's visiting order: map point, then camera
+            if pMP.isBad():
+                continue
+            for cam in range(nr):
+                if not pMP.mbTrackInView[cam]:
+                    continue
+                owner.append(pMP); px.append(pMP.mTrackProjX[cam]); py.append(pMP.mTrackProjY[cam]); vc.append(pMP.mTrackViewCos[cam])
+                lv.append(pMP.mnTrackScaleLevel[cam]); pc.append(cam); dd.append(pMP.GetDescriptor())
+                if self.havingMasks:
+                    mm.append(pMP.GetDescriptorMask())
+        n = len(owner)
+        if n == 0:
+            return 0
+        px, py, vc = (np.ascontiguousarray(v, np.float64) for v in (px, py, vc))
+        lv, pc = np.ascontiguousarray(lv, np.int32), np.ascontiguousarray(pc, np.int32)
+        dd = np.ascontiguousarray(np.stack(dd), np.uint8)
+        mm = np.ascontiguousarray(np.stack(mm), np.uint8) if self.havingMasks else None
+        keys = np.ascontiguousarray(F.mvKeys)
+        fd = np.ascontiguousarray(F.all_descriptors(), np.uint8)
+        fm = np.ascontiguousarray(F.all_masks(), np.uint8) if self.havingMasks else None
+        fc = np.ascontiguousarray(F.keypoint_to_cam, np.int32)
+        assigned = np.array([m is not None for m in F.mvpMapPoints], np.uint8)
+        w, h = np.ascontiguousarray(F.mnMaxX, np.int32), np.ascontiguousarray(F.mnMaxY, np.int32)
+        sc = np.ascontiguousarray(F.mvScaleFactors, np.float64)
+        mp = ProjectionSet(np_ptr(px), np_ptr(py), np_ptr(vc), np_ptr(lv), np_ptr(pc), np_ptr(dd), np_ptr(mm), n, self.mbFeatDim)
+        fv = FrameView(np_ptr(keys), np_ptr(fd), np_ptr(fm), np_ptr(fc), np_ptr(assigned), F.totalN, self.mbFeatDim, nr, np_ptr(w), np_ptr(h), np_ptr(sc),
+                       len(sc))
+        match = np.full(n, -1, np.int32)
+        nm = np.zeros(1, np.int32)
+        check(lib().mcs_search_by_projection(self.ctx.h, C.byref(mp), C.byref(fv), float(th), self.mfNNratio, self.mbFeatDim, MEM_HOST, np_ptr(match),
+                                             np_ptr(nm)))
+        for p, j in enumerate(match):
+            if j >= 0:
+                F.mvpMapPoints[int(j)] = owner[p]
+        return int(nm[0])
+
     def SearchForTriangulationRaw(self, pKF1, pKF2, Es):
         """-> (nmatches, vMatchedKeys1, vMatchedKeysRays1, vMatchedKeys2, vMatchedKeysRays2, vMatchedPairs) (:968-1155).
         Es: [nrCams][nrCams] 3x3 essential matrices (the reference precomputes them from the rig poses, :990-1003)."""

@@ -1038,6 +1038,89 @@ int orc_search_triangulation(const uint8_t* d1, const uint8_t* m1, const uint8_t
 	return nmatches;
 }
 
+// ---------------------------------------------------------------- "next" row: SearchByProjection(F, mapPoints, th)
+int orc_search_by_projection(const double* projx, const double* projy, const double* viewcos, const int* level, const int* pcam,
+                             const uint8_t* pdesc, const uint8_t* pmask, int nproj, const orc_keypoint* keys, const uint8_t* fdesc,
+                             const uint8_t* fmask, const int* fcam, uint8_t* assigned, int nfeat, const int* width, const int* height, int nrCams,
+                             const double* scaleFactors, int nlevels, double th, double nnratio, int dim, int havingMasks, int* match) {
+	const int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64;
+	int TH_HIGH, TH_LOW;
+	orc_thresholds(dim, havingMasks, &TH_HIGH, &TH_LOW);
+	// mGrids[cam][x][y]: filled in mvKeys order (src/cMultiFrame.cpp:167-184) with PosInGrid (:342-353)
+	std::vector<std::vector<std::vector<std::vector<size_t> > > > grids(nrCams);
+	std::vector<double> wInv(nrCams), hInv(nrCams);
+	for (int c = 0; c < nrCams; ++c) {
+		grids[c].assign(FRAME_GRID_COLS, std::vector<std::vector<size_t> >(FRAME_GRID_ROWS));
+		wInv[c] = static_cast<double>(FRAME_GRID_COLS) / static_cast<double>(width[c] - 0);
+		hInv[c] = static_cast<double>(FRAME_GRID_ROWS) / static_cast<double>(height[c] - 0);
+	}
+	for (int i = 0; i < nfeat; ++i) {
+		const int c = fcam[i];
+		const int posX = cvRound_((keys[i].x - 0) * wInv[c]);
+		const int posY = cvRound_((keys[i].y - 0) * hInv[c]);
+		if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) continue;
+		grids[c][posX][posY].push_back(i);
+	}
+	int nmatches = 0;
+	const bool bFactor = th != 1.0;
+	for (int p = 0; p < nproj; ++p) {
+		match[p] = -1;
+		const int cam = pcam[p];
+		const int nPredictedLevel = level[p];
+		double r = viewcos[p] > 0.998 ? 2.5 : 4.0;   // RadiusByViewingCos (:169-175)
+		if (bFactor) r *= th;
+		// GetFeaturesInArea(cam, x, y, r*mvScaleFactors[level], level-1, level)
+		const double x = projx[p], y = projy[p], rr = r * scaleFactors[nPredictedLevel];
+		const int minLevel = nPredictedLevel - 1, maxLevel = nPredictedLevel;
+		std::vector<size_t> vIndices;
+		do {
+			int nMinCellX = (int)floor((x - 0 - rr) * wInv[cam]);
+			nMinCellX = std::max(0, nMinCellX);
+			if (nMinCellX >= FRAME_GRID_COLS) break;
+			int nMaxCellX = (int)ceil((x - 0 + rr) * wInv[cam]);
+			nMaxCellX = std::min(FRAME_GRID_COLS - 1, nMaxCellX);
+			if (nMaxCellX < 0) break;
+			int nMinCellY = (int)floor((y - 0 - rr) * hInv[cam]);
+			nMinCellY = std::max(0, nMinCellY);
+			if (nMinCellY >= FRAME_GRID_ROWS) break;
+			int nMaxCellY = (int)ceil((y - 0 + rr) * hInv[cam]);
+			nMaxCellY = std::min(FRAME_GRID_ROWS - 1, nMaxCellY);
+			if (nMaxCellY < 0) break;
+			bool bCheckLevels = true, bSameLevel = false;
+			if (minLevel == -1 && maxLevel == -1) bCheckLevels = false;
+			else if (minLevel == maxLevel) bSameLevel = true;
+			for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
+				for (int iy = nMinCellY; iy <= nMaxCellY; ++iy) {
+					const std::vector<size_t>& vCell = grids[cam][ix][iy];
+					for (size_t j = 0; j < vCell.size(); ++j) {
+						const orc_keypoint& kpUn = keys[vCell[j]];
+						if (bCheckLevels && !bSameLevel) { if (kpUn.octave < minLevel || kpUn.octave > maxLevel) continue; }
+						else if (bSameLevel) { if (kpUn.octave != minLevel) continue; }
+						if (std::abs(kpUn.x - x) > rr || std::abs(kpUn.y - y) > rr) continue;
+						vIndices.push_back(vCell[j]);
+					}
+				}
+		} while (0);
+		(void)nlevels;
+		if (vIndices.empty()) continue;
+		int bestDist = INT_MAX, bestLevel = -1, bestDist2 = INT_MAX, bestLevel2 = -1, bestIdx = -1;
+		for (size_t k = 0; k < vIndices.size(); ++k) {
+			const size_t idx = vIndices[k];
+			if (assigned[idx]) continue;
+			const int dist = dist_any(pdesc, pmask, p, fdesc, fmask, (int)idx, dim, havingMasks);
+			if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = keys[idx].octave; bestIdx = (int)idx; }
+			else if (dist < bestDist2) { bestLevel2 = keys[idx].octave; bestDist2 = dist; }
+		}
+		if (bestDist <= TH_HIGH) {
+			if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+			assigned[bestIdx] = 1;
+			match[p] = bestIdx;
+			++nmatches;
+		}
+	}
+	return nmatches;
+}
+
 // ---------------------------------------------------------------- CPU baseline helper
 int orc_num_threads(void) {
 #ifdef _OPENMP

@@ -95,6 +95,15 @@ int orc_search_triangulation(const uint8_t* d1, const uint8_t* m1, const uint8_t
                              const uint8_t* d2, const uint8_t* m2, const uint8_t* hasMP2, const int* cam2, const double* rays2, int n2,
                              const double* E, int nrCams, int dim, int havingMasks, int* match12);
 int orc_check_epipolar(const double* ray1, const double* ray2, const double* E12, double thresh);
+/* "next" row: cORBmatcher::SearchByProjection(cMultiFrame&, const vector<cMapPoint*>&, th) src/cORBmatcher.cpp:67-166
+ * with cMultiFrame::GetFeaturesInArea src/cMultiFrame.cpp:272-340 and PosInGrid :342-353.  One "projection" = one (map point, camera)
+ * pair with mbTrackInView, in the reference's visiting order.  assigned[] = F.mvpMapPoints[idx] != NULL (updated in place).
+ * match[p] = frame feature index or -1.  returns nmatches. */
+int orc_search_by_projection(const double* projx, const double* projy, const double* viewcos, const int* level, const int* pcam,
+                             const uint8_t* pdesc, const uint8_t* pmask, int nproj,
+                             const orc_keypoint* keys, const uint8_t* fdesc, const uint8_t* fmask, const int* fcam, uint8_t* assigned, int nfeat,
+                             const int* width, const int* height, int nrCams, const double* scaleFactors, int nlevels,
+                             double th, double nnratio, int dim, int havingMasks, int* match);
 
 /* ---- timed CPU baseline helper: extract nimg images (OpenMP over images), returns total keypoints ---- */
 long orc_extract_many(const orc_params* p, int nimg, const uint8_t* const* imgs, int w, int h, int stride,

@@ -195,3 +195,14 @@ def search_triangulation(d1, m1, mp1, cam1, rays1, d2, m2, mp2, cam2, rays2, E, 
     n = lib().orc_search_triangulation(ptr(d1), ptr(m1), ptr(mp1), ptr(cam1), ptr(rays1), n1, ptr(d2), ptr(m2), ptr(mp2), ptr(cam2),
                                        ptr(rays2), d2.shape[0], ptr(E), nr_cams, dim, int(masks), ptr(out))
     return n, out
+
+
+def search_by_projection(px, py, vc, lv, pc, pd, pm, keys, fd, fm, fc, assigned, width, height, scales, th, ratio, masks):
+    L = lib()
+    L.orc_search_by_projection.argtypes = [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                                                              C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p]
+    match = np.full(len(px), -1, np.int32)
+    n = L.orc_search_by_projection(ptr(px), ptr(py), ptr(vc), ptr(lv), ptr(pc), ptr(pd), ptr(pm), len(px), ptr(keys), ptr(fd), ptr(fm), ptr(fc),
+                                   ptr(assigned), len(keys), ptr(width), ptr(height), len(width), ptr(scales), len(scales), th, ratio, pd.shape[1],
+                                   int(masks), ptr(match))
+    return n, match

@@ -166,3 +166,72 @@ def test_extractor_facade_modes(G, FE):
     assert G.first_diff(kps, ek) is None and G.first_diff(d, ed) is None and G.first_diff(dm, edm) is None
     k0, d0, m0 = odd(np.zeros((0, 0), np.uint8), None, model)
     assert len(k0) == 0 and d0 is None
+
+
+class TrackedMP(MP):
+    """cMapPoint stand-in carrying what cMultiFrame::isInFrustum leaves on it (src/cMultiFrame.cpp:218-270)."""
+
+    def __init__(self, i, desc, mask, nr_cams):
+        super().__init__(i)
+        self.desc, self.mask = desc, mask
+        self.mbTrackInView = [False] * nr_cams
+        self.mTrackProjX, self.mTrackProjY = [0.0] * nr_cams, [0.0] * nr_cams
+        self.mnTrackScaleLevel, self.mTrackViewCos = [0] * nr_cams, [1.0] * nr_cams
+
+    def GetDescriptor(self):
+        return self.desc
+
+    def GetDescriptorMask(self):
+        return self.mask
+
+
+@pytest.mark.parametrize("th,masks", [(1.0, True), (3.0, True), (15.0, False)])
+def test_search_by_projection_window_matcher(G, FE, frames, th, masks):
+    """SearchByProjection(F, mapPoints, th) incl. GetFeaturesInArea / PosInGrid, vs the oracle."""
+    _, rig, fr = frames
+    Fa, Fb = fr[0][1], fr[1][1]
+    rng = np.random.default_rng(int(th * 10) + masks)
+    # map points = features of frame a (descriptor + where the motion model would project them in frame b: shifted by (3,1) + noise)
+    mps = []
+    da, ma = Fa.all_descriptors(), Fa.all_masks()
+    for i in rng.permutation(Fa.totalN)[:1500]:
+        kp = Fa.mvKeys[i]
+        cam = int(Fa.keypoint_to_cam[i])
+        mp = TrackedMP(int(i), da[i], ma[i], 3)
+        mp.bad = rng.random() < 0.03
+        for c in ([cam] if rng.random() < 0.9 else [cam, (cam + 1) % 3]):   # a few points are "in view" of two cameras
+            mp.mbTrackInView[c] = True
+            mp.mTrackProjX[c] = float(kp["x"]) + 3.0 + rng.normal(0, 1.5)
+            mp.mTrackProjY[c] = float(kp["y"]) + 1.0 + rng.normal(0, 1.5)
+            mp.mnTrackScaleLevel[c] = int(np.clip(kp["octave"] + rng.integers(-1, 2), 0, 7))
+            mp.mTrackViewCos[c] = float(rng.choice([0.9995, 0.99, 0.5]))
+        mps.append(mp)
+    # a few projections far outside the image / at the borders (empty windows, clamped cell ranges)
+    for k, (x, y) in enumerate([(-500.0, 10.0), (2000.0, 100.0), (5.0, 5.0), (750.0, 478.0), (377.0, -90.0)]):
+        mp = TrackedMP(10000 + k, da[k], ma[k], 3)
+        mp.mbTrackInView[0] = True
+        mp.mTrackProjX[0], mp.mTrackProjY[0], mp.mnTrackScaleLevel[0], mp.mTrackViewCos[0] = x, y, k % 8, 0.999
+        mps.append(mp)
+    Fb.mvpMapPoints = [MP(-1) if rng.random() < 0.1 else None for _ in range(Fb.totalN)]   # some features already have a point
+    pre = [m is not None for m in Fb.mvpMapPoints]
+    m = FE.cORBmatcher(0.8, False, 32, masks, ctx=G.ctx())
+    # oracle on the same flat inputs (built in the reference's visiting order)
+    px, py, vc, lv, pc, pd, pm, owner = [], [], [], [], [], [], [], []
+    for mp in mps:
+        if mp.isBad():
+            continue
+        for c in range(3):
+            if mp.mbTrackInView[c]:
+                px.append(mp.mTrackProjX[c]); py.append(mp.mTrackProjY[c]); vc.append(mp.mTrackViewCos[c]); lv.append(mp.mnTrackScaleLevel[c])
+                pc.append(c); pd.append(mp.desc); pm.append(mp.mask); owner.append(mp.i)
+    arr = lambda v, t: np.ascontiguousarray(v, t)
+    assigned = np.array(pre, np.uint8)
+    en, ematch = G.O.search_by_projection(arr(px, np.float64), arr(py, np.float64), arr(vc, np.float64), arr(lv, np.int32), arr(pc, np.int32),
+                                          arr(np.stack(pd), np.uint8), arr(np.stack(pm), np.uint8), arr(Fb.mvKeys, Fb.mvKeys.dtype),
+                                          arr(Fb.all_descriptors(), np.uint8), arr(Fb.all_masks(), np.uint8), arr(Fb.keypoint_to_cam, np.int32), assigned,
+                                          arr(Fb.mnMaxX, np.int32), arr(Fb.mnMaxY, np.int32), arr(Fb.mvScaleFactors, np.float64), th, 0.8, masks)
+    n = m.SearchByProjection(Fb, mps, th)
+    exp = {int(j): owner[p] for p, j in enumerate(ematch) if j >= 0}
+    got = {j: mp.i for j, mp in enumerate(Fb.mvpMapPoints) if mp is not None and not pre[j]}
+    assert n == en and got == exp, (th, masks, n, en)
+    assert n > (300 if th <= 3 else 100)
