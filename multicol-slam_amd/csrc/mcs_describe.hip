@@ -50,6 +50,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 	return a;
 }
 
+// wave-uniform double load: both halves go through v_readfirstlane so the value lives in SGPRs
+__device__ __forceinline__ double uniform_f64(const double* p) {
+	const unsigned lo = __builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(p)[0]);
+	const unsigned hi = __builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(p)[1]);
+	return __hiloint2double((int)hi, (int)lo);
+}
+
 __device__ __forceinline__ double horner_d(const double* coeffs, int s, double x) {
 	double res = 0.0;
 	for (int i = s - 1; i >= 0; i--) res = res * x + coeffs[i];
@@ -225,6 +232,40 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 	constexpr int CH = NP / (2 * NB);         // chain elements folded into one point iteration (= 64)
 	double* buf = reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(lds) + (size_t)wave * (2 * NP * 8 + 2560));   // [x | y][NP] distorted coordinates
 	const OcamDev& cam = b.cams[img];
+	// The camera is the same for the whole wave: pull the backward polynomial and the affine terms into SGPRs ONCE.  (The
+	// first version re-loaded every Horner coefficient through a vector global load inside a 12-trip loop per pattern point —
+	// a ~200-cycle dependent load 36 864 times per keypoint; the kernel was latency-bound on it.)  Coefficients above the
+	// model's degree are zero: res = 0*x + 0 stays +0 until the first real coefficient, so the padded fixed-length Horner
+	// below is bit-identical to the reference's loop (include/misc.h:115-122).
+	double cP[MCS_MAX_POLY];
+#pragma unroll
+	for (int i = 0; i < MCS_MAX_POLY; ++i) cP[i] = uniform_f64(&cam.invP[i]);
+	const int cDeg = __builtin_amdgcn_readfirstlane(cam.invP_deg);
+	const double cC = uniform_f64(&cam.c), cD = uniform_f64(&cam.d), cE = uniform_f64(&cam.e), cU0 = uniform_f64(&cam.u0), cV0 = uniform_f64(&cam.v0);
+	auto w2i = [&](double x, double y, double z, double& u, double& v) {   // cCamModelGeneral_::WorldToImg (src/cam_model_omni.cpp:146-161)
+		double norm = sqrt(x * x + y * y);
+		if (norm == 0.0) norm = 1e-14;
+		const double theta = atan(-z / norm);
+		double rho = 0.0;
+		if (cDeg == 12) {
+#pragma unroll
+			for (int i = 11; i >= 0; --i) rho = rho * theta + cP[i];
+		} else {
+#pragma unroll
+			for (int i = MCS_MAX_POLY - 1; i >= 0; --i) rho = rho * theta + cP[i];
+		}
+		const double uu = x / norm * rho;
+		const double vv = y / norm * rho;
+		u = uu * cC + vv * cD + cU0;
+		v = uu * cE + vv + cV0;
+	};
+	// this lane's 2*NB pattern points (x, y as small integers), loaded once for all patterns
+	double ppx[2 * NB], ppy[2 * NB];
+#pragma unroll
+	for (int t = 0; t < 2 * NB; ++t) {
+		const int k = (t >> 1) * 64 + lane, e = t & 1;
+		ppx[t] = c_pattern[4 * k + 2 * e]; ppy[t] = c_pattern[4 * k + 2 * e + 1];
+	}
 	const double zc = -cam.p[0];              // distortPointsOcam: WorldToImg(x, y, -p1)
 	double ukx = 0.0, uky = 0.0;
 	if (d.undistort) {                        // undistortPointsOcam(pt*scale, scaleF = p[0]) (:1306-1317)
@@ -249,25 +290,24 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 	// odd lanes sum(y), p = 0..NP-1 in the reference's order (:264-276).  The sum is a 512-long dependent FP64 add chain;
 	// folding 64 of its steps into each of the 2*NB point evaluations lets the scheduler hide its latency under the math.
 	auto pass = [&](bool doMath, double ang, double* wb, bool doChain, const double* rb, double& sum) {
-		double ax = 0.0, ay = 0.0;
-		if (doMath) { ax = cos(ang); ay = sin(ang); }
-		const double* arr = rb + (lane & 1) * NP;
-#pragma unroll 1
-		for (int t = 0; t < 2 * NB; ++t) {
-			if (doMath) {
+		if (doMath) {
+			const double ax = cos(ang), ay = sin(ang);
+#pragma unroll
+			for (int t = 0; t < 2 * NB; ++t) {
 				const int k = (t >> 1) * 64 + lane, e = t & 1;
-				const double px = c_pattern[4 * k + 2 * e], py = c_pattern[4 * k + 2 * e + 1];
-				const double xr = px * ax - py * ay + ukx;
-				const double yr = px * ay + py * ax + uky;
+				const double xr = ppx[t] * ax - ppy[t] * ay + ukx;
+				const double yr = ppx[t] * ay + ppy[t] * ax + uky;
 				double u, v;
-				if (MCS_ABLATE & 2) { u = xr; v = yr; } else world2img(cam, xr, yr, zc, u, v);
+				if (MCS_ABLATE & 2) { u = xr; v = yr; } else w2i(xr, yr, zc, u, v);
 				wb[2 * k + e] = u; wb[NP + 2 * k + e] = v;
 			}
-			if (doChain && !(MCS_ABLATE & 1)) {
-#pragma unroll 16
-				for (int p = 0; p < CH; ++p) sum += arr[t * CH + p];
-			}
 		}
+		if (doChain && !(MCS_ABLATE & 1)) {
+			const double* arr = rb + (lane & 1) * NP;
+#pragma unroll 16
+			for (int p = 0; p < NP; ++p) sum += arr[p];
+		}
+		(void)CH;
 	};
 	unsigned long long bitsMain[NB], agree[NB];
 #pragma unroll
