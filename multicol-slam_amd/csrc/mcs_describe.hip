@@ -19,7 +19,7 @@
 
 namespace mcs {
 
-__constant__ signed char c_pattern[2048];
+__constant__ __attribute__((aligned(16))) signed char c_pattern[2048];
 __constant__ signed char c_disc[845 * 2];   // (u, v) offsets of the orientation disc, row-major in v (kept for reference / taps)
 __constant__ int c_umax[kHalfPatch + 1];      // half-width of disc row |v|
 
@@ -57,9 +57,17 @@ __device__ __forceinline__ double uniform_f64(const double* p) {
 	return __hiloint2double((int)hi, (int)lo);
 }
 
+// include/misc.h:115-122.  The coefficient arrays of OcamDev are MCS_MAX_POLY long and zero above the model's degree, and
+// 0*x + 0 = +0 for finite x, so the fixed-length form is bit-identical to the reference's loop while all coefficient
+// loads are independent (one memory round trip instead of one per term).
 __device__ __forceinline__ double horner_d(const double* coeffs, int s, double x) {
+	double c[MCS_MAX_POLY];
+#pragma unroll
+	for (int i = 0; i < MCS_MAX_POLY; ++i) c[i] = coeffs[i];
 	double res = 0.0;
-	for (int i = s - 1; i >= 0; i--) res = res * x + coeffs[i];
+#pragma unroll
+	for (int i = MCS_MAX_POLY - 1; i >= 0; i--) res = res * x + c[i];
+	(void)s;
 	return res;
 }
 
@@ -140,6 +148,7 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 
 	constexpr int nballots = NB;
 	float angle = 0.f, pxf = 0.f, pyf = 0.f;
+	double rayx = 0.0, rayy = 0.0, rayz = 0.0;
 	int row = 0, col = 0;
 	Sampler sm = {};
 	if (active) {
@@ -191,15 +200,15 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 		// ---- keypoint record (E8): level coordinates -> image coordinates with the FLOAT scale (:1305,1331)
 		pxf = (float)col; pyf = (float)row;
 		if (level != 0) { pxf = pxf * L.scale; pyf = pyf * L.scale; }
+		// ImgToWorld of the keypoint: the ray of src/cMultiFrame.cpp:146-152 AND the input of undistortPointsOcam (:1306-1317)
+		if (b.cams && (b.rays || MODE != 0)) img2world(b.cams[img], (double)pxf, (double)pyf, rayx, rayy, rayz);
 		if (lane == 0) {
 			mcs_keypoint kp;
 			kp.x = pxf; kp.y = pyf; kp.size = L.kpSize; kp.angle = angle; kp.response = resp; kp.octave = level; kp.class_id = -1;
 			b.kps[(size_t)img * d.kpCap + out] = kp;
 			if (b.rays && b.cams) {
-				double rx, ry, rz;
-				img2world(b.cams[img], (double)pxf, (double)pyf, rx, ry, rz);
 				double* rp = b.rays + ((size_t)img * d.kpCap + out) * 3;
-				rp[0] = rx; rp[1] = ry; rp[2] = rz;
+				rp[0] = rayx; rp[1] = rayy; rp[2] = rayz;
 			}
 		}
 	}
@@ -260,19 +269,16 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 		v = uu * cE + vv + cV0;
 	};
 	// this lane's 2*NB pattern points (x, y as small integers), loaded once for all patterns
-	double ppx[2 * NB], ppy[2 * NB];
+	// (kept packed — one dword per pair: x0,y0,x1,y1 as int8 — and widened at the point of use, to save 28 VGPRs)
+	uint32_t ppk[NB];
 #pragma unroll
-	for (int t = 0; t < 2 * NB; ++t) {
-		const int k = (t >> 1) * 64 + lane, e = t & 1;
-		ppx[t] = c_pattern[4 * k + 2 * e]; ppy[t] = c_pattern[4 * k + 2 * e + 1];
-	}
+	for (int j = 0; j < NB; ++j) ppk[j] = reinterpret_cast<const uint32_t*>(c_pattern)[j * 64 + lane];
 	const double zc = -cam.p[0];              // distortPointsOcam: WorldToImg(x, y, -p1)
 	double ukx = 0.0, uky = 0.0;
 	if (d.undistort) {                        // undistortPointsOcam(pt*scale, scaleF = p[0]) (:1306-1317)
-		double x, y, z;
-		img2world(cam, (double)pxf, (double)pyf, x, y, z);
-		ukx = -x / z * cam.p[0];
-		uky = -y / z * cam.p[0];
+		const double p0 = uniform_f64(&cam.p[0]);
+		ukx = -rayx / rayz * p0;
+		uky = -rayy / rayz * p0;
 	}
 	double ang0, ang1 = 0.0, ang2 = 0.0;
 	if (MODE == 1) {
@@ -295,8 +301,9 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 #pragma unroll
 			for (int t = 0; t < 2 * NB; ++t) {
 				const int k = (t >> 1) * 64 + lane, e = t & 1;
-				const double xr = ppx[t] * ax - ppy[t] * ay + ukx;
-				const double yr = ppx[t] * ay + ppy[t] * ax + uky;
+				const double ptx = (double)(int)(signed char)(ppk[t >> 1] >> (16 * e)), pty = (double)(int)(signed char)(ppk[t >> 1] >> (16 * e + 8));
+				const double xr = ptx * ax - pty * ay + ukx;
+				const double yr = ptx * ay + pty * ax + uky;
 				double u, v;
 				if (MCS_ABLATE & 2) { u = xr; v = yr; } else w2i(xr, yr, zc, u, v);
 				wb[2 * k + e] = u; wb[NP + 2 * k + e] = v;
