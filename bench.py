@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--mode", default="mdbrief", choices=list(MODES))
     ap.add_argument("--nfeatures", type=int, default=0, help="features per camera (default 1000 stream / 2000 rig)")
     ap.add_argument("--topk", type=int, default=32)
+    ap.add_argument("--substreams", type=int, default=1, help="independent sub-streams (HIP streams) per GPU; measured: 1 is best (2 equal, 3-4 slower), kept for A/B")
     ap.add_argument("--keyframes", type=int, default=32, help="rig workload: stored keyframes in the database (sharded over ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="multi-frames in the bounded CPU-baseline sample (default: cores/2, >= 48)")
@@ -159,54 +160,99 @@ def run_stream(args, e):
     pool = [synth.synth_multiframe(e.rank * 1000 + f, cams) for f in range(POOL)]   # this rank's shard of the stream (untimed)
     imgs_np = np.stack([pool[f % POOL][c] for f in range(F) for c in range(NCAM)])
     masks_np = np.stack([synth.mirror_mask(cams[c]) for _ in range(F) for c in range(NCAM)])
-    ex = mcs.Extractor(ctx, W, H, max_batch=nimg, nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)
-    cap, ds = ex.cap, 32
-    d_imgs, d_masks = torch.from_numpy(imgs_np).to(dev), torch.from_numpy(masks_np).to(dev)
-    camarr = (mcs.Ocam * nimg)(*[mcs.make_ocam(cams[i % NCAM]) for i in range(nimg)])
-    rows_f = NCAM * cap
-    # Descriptor-side buffers carry one extra multi-frame slot: slot 0 = last multi-frame of the previous step (the stored keyframe).
-    # Two such buffer sets alternate between steps (ping-pong): the greedy match resolution of step n runs on the library's side
-    # stream while step n+1 already extracts into the other set.
-    def make_set():
-        b = Env()
-        b.nkp = torch.zeros((F + 1) * NCAM, dtype=torch.int32, device=dev)
-        b.kps = torch.zeros(((F + 1) * rows_f, 7), dtype=torch.float32, device=dev)
-        b.desc = torch.zeros(((F + 1) * rows_f, ds), dtype=torch.uint8, device=dev)
-        b.dmask = torch.zeros(((F + 1) * rows_f, ds), dtype=torch.uint8, device=dev)
-        b.rays = torch.zeros(((F + 1) * rows_f, 3), dtype=torch.float64, device=dev)
-        b.valid = torch.zeros((F + 1) * rows_f, dtype=torch.uint8, device=dev)
-        b.match = torch.full((F * rows_f,), -1, dtype=torch.int32, device=dev)
-        b.nmatch = torch.zeros(F, dtype=torch.int32, device=dev)
-        b.fb = torch.zeros(F, dtype=torch.int32, device=dev)
-        b.q = mcs.DescSet(ptr(b.desc, rows_f), ptr(b.dmask, rows_f) if masks_on else None, ptr(b.valid, rows_f), None, rows_f, ds)
-        b.t = mcs.DescSet(ptr(b.desc, 0), ptr(b.dmask, 0) if masks_on else None, ptr(b.valid, 0), None, rows_f, ds)
-        return b
+    ds = 32
 
-    sets = [make_set(), make_set()]
-    state = {"cur": 0}
+    class Sub:
+        """One independent sub-stream of multi-frames on its own HIP stream / library context (frames [f0, f0+Fs) of every step).
+        Several sub-streams per GPU interleave on the hardware: the latency-bound phases of one (oct-tree, kernel tails, launch
+        gaps) are filled by the VALU-bound kernels of the other.  Each sub-stream matches against ITS previous multi-frame."""
+
+        def __init__(self, f0, Fs, ctx_, stream_):
+            self.ctx, self.stream, self.Fs, self.f0 = ctx_, stream_, Fs, f0
+            self.n = Fs * NCAM
+            self.ex = mcs.Extractor(ctx_, W, H, max_batch=self.n, nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)
+            self.cap = self.ex.cap
+            self.rows_f = NCAM * self.cap
+            self.imgs = torch.from_numpy(imgs_np[f0 * NCAM:(f0 + Fs) * NCAM]).to(dev)
+            self.masks = torch.from_numpy(masks_np[f0 * NCAM:(f0 + Fs) * NCAM]).to(dev)
+            self.camarr = (mcs.Ocam * self.n)(*[mcs.make_ocam(cams[i % NCAM]) for i in range(self.n)])
+            # Descriptor-side buffers carry one extra multi-frame slot: slot 0 = last multi-frame of the previous step (the stored
+            # keyframe).  Two buffer sets alternate between steps (ping-pong): the greedy match resolution of step n runs on the
+            # library's side stream while step n+1 already extracts into the other set.
+            self.sets = [self.make_set(), self.make_set()]
+            self.cur = 0
+
+        def make_set(self):
+            Fs, rows_f = self.Fs, self.rows_f
+            b = Env()
+            b.nkp = torch.zeros((Fs + 1) * NCAM, dtype=torch.int32, device=dev)
+            b.kps = torch.zeros(((Fs + 1) * rows_f, 7), dtype=torch.float32, device=dev)
+            b.desc = torch.zeros(((Fs + 1) * rows_f, ds), dtype=torch.uint8, device=dev)
+            b.dmask = torch.zeros(((Fs + 1) * rows_f, ds), dtype=torch.uint8, device=dev)
+            b.rays = torch.zeros(((Fs + 1) * rows_f, 3), dtype=torch.float64, device=dev)
+            b.valid = torch.zeros((Fs + 1) * rows_f, dtype=torch.uint8, device=dev)
+            b.match = torch.full((Fs * rows_f,), -1, dtype=torch.int32, device=dev)
+            b.nmatch = torch.zeros(Fs, dtype=torch.int32, device=dev)
+            b.fb = torch.zeros(Fs, dtype=torch.int32, device=dev)
+            b.q = mcs.DescSet(ptr(b.desc, rows_f), ptr(b.dmask, rows_f) if masks_on else None, ptr(b.valid, rows_f), None, rows_f, ds)
+            b.t = mcs.DescSet(ptr(b.desc, 0), ptr(b.dmask, 0) if masks_on else None, ptr(b.valid, 0), None, rows_f, ds)
+            return b
+
+        def step(self):
+            Fs, rows_f, cap = self.Fs, self.rows_f, self.cap
+            b, o = self.sets[self.cur], self.sets[self.cur ^ 1]
+            self.cur ^= 1
+            with torch.cuda.stream(self.stream):
+                b.nkp[:NCAM].copy_(o.nkp[Fs * NCAM:], non_blocking=True)       # previous step's last multi-frame -> slot 0 (stored keyframe)
+                b.desc[:rows_f].copy_(o.desc[Fs * rows_f:], non_blocking=True)
+                b.dmask[:rows_f].copy_(o.dmask[Fs * rows_f:], non_blocking=True)
+                self.ex.extract_device(self.n, self.imgs.data_ptr(), W * H, W, self.masks.data_ptr(), W * H, W, self.camarr, ptr(b.nkp, NCAM),
+                                       ptr(b.kps, rows_f), ptr(b.desc, rows_f), ptr(b.dmask, rows_f), ptr(b.rays, rows_f))
+                mcs.check(lib.mcs_rows_valid(self.ctx.h, C.c_void_p(ptr(b.nkp, 0)), (Fs + 1) * NCAM, cap, C.c_void_p(ptr(b.valid, 0))))
+                mcs.check(lib.mcs_search_kf_kf(self.ctx.h, Fs, C.byref(b.q), rows_f, C.byref(b.t), rows_f, ds, 0.9, args.topk, mcs.MEM_DEVICE,
+                                               C.c_void_p(b.match.data_ptr()), C.c_void_p(b.nmatch.data_ptr()), C.c_void_p(b.fb.data_ptr())))
+
+        def last(self):
+            return self.sets[self.cur ^ 1]
+
+    S = max(1, min(args.substreams, F))
+    bounds = [round(i * F / S) for i in range(S + 1)]
+    subs = []
+    for i in range(S):
+        if i == 0:
+            st, cx = e.stream, ctx
+        else:
+            st = torch.cuda.Stream(device=dev)
+            cx = mcs.Context(e.local, st.cuda_stream)
+        subs.append(Sub(bounds[i], bounds[i + 1] - bounds[i], cx, st))
+    cap = subs[0].cap
 
     def step():
-        b, o = sets[state["cur"]], sets[state["cur"] ^ 1]
-        state["cur"] ^= 1
-        b.nkp[:NCAM].copy_(o.nkp[F * NCAM:], non_blocking=True)       # previous step's last multi-frame -> slot 0 (stored keyframe)
-        b.desc[:rows_f].copy_(o.desc[F * rows_f:], non_blocking=True)
-        b.dmask[:rows_f].copy_(o.dmask[F * rows_f:], non_blocking=True)
-        ex.extract_device(nimg, d_imgs.data_ptr(), W * H, W, d_masks.data_ptr(), W * H, W, camarr, ptr(b.nkp, NCAM), ptr(b.kps, rows_f), ptr(b.desc, rows_f),
-                          ptr(b.dmask, rows_f), ptr(b.rays, rows_f))
-        mcs.check(lib.mcs_rows_valid(ctx.h, C.c_void_p(ptr(b.nkp, 0)), (F + 1) * NCAM, cap, C.c_void_p(ptr(b.valid, 0))))
-        mcs.check(lib.mcs_search_kf_kf(ctx.h, F, C.byref(b.q), rows_f, C.byref(b.t), rows_f, ds, 0.9, args.topk, mcs.MEM_DEVICE, C.c_void_p(b.match.data_ptr()),
-                                       C.c_void_p(b.nmatch.data_ptr()), C.c_void_p(b.fb.data_ptr())))
+        for sb in subs:
+            sb.step()
 
-    elapsed = timed(e, step, args.warmup, args.steps, ex.status)
-    last = sets[state["cur"] ^ 1]                                       # the set written by the last step
-    d_nkp, d_desc, d_dmask = last.nkp, last.desc, last.dmask
-    feats_step = int(d_nkp[NCAM:].sum().item())
-    matches_step, fallbacks = int(last.nmatch.sum().item()), int(last.fb.sum().item())
+    def status():
+        for sb in subs:
+            sb.ex.status()
+
+    elapsed = timed(e, step, args.warmup, args.steps, status)
+    feats_step = sum(int(sb.last().nkp[NCAM:].sum().item()) for sb in subs)
+    matches_step = sum(int(sb.last().nmatch.sum().item()) for sb in subs)
+    fallbacks = sum(int(sb.last().fb.sum().item()) for sb in subs)
     elapsed_max, feats_all = e.rig.reduce_timing(elapsed, feats_step, e.red_dev, e.world)
+    d_nkp, d_desc, d_dmask = subs[0].last().nkp, subs[0].last().desc, subs[0].last().dmask
+    ex = subs[0].ex
+    # per-kernel times for the roofline block are measured on ONE stream over the whole batch (so kernels are timed alone)
+    if S == 1:
+        full = subs[0]
+    elif e.rank == 0:
+        full = Sub(0, F, ctx, e.stream)
+        full.step()
+    kstep = (lambda: full.step()) if (S == 1 or e.rank == 0) else None
 
     roof = check = cpu = None
     if e.rank == 0:
-        roof = roofline(kernel_times(e, step), args.mode, nimg, feats_step, ex.level_sizes)
+        roof = roofline(kernel_times(e, kstep), args.mode, nimg, feats_step, ex.level_sizes)
     if args.check and e.rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
@@ -227,7 +273,7 @@ def run_stream(args, e):
                "config": {"workload": "BASELINE configs[1]: 3-camera 754x480 multi-frames, %s extract (N=%d, 8 levels, FAST 20) + cORBmatcher BF-Hamming "
                                       "SearchByBoW(KF,KF) vs the previous multi-frame, %d multi-frames (%d images) per step per GPU, inputs resident in HBM"
                                       % (args.mode, nfeat, F, nimg), "multi_frames_per_step_per_gpu": F, "features_per_step": int(feats_all),
-                          "matches_per_step_rank0": matches_step, "greedy_rescans_rank0": fallbacks, "topk": args.topk,
+                          "matches_per_step_rank0": matches_step, "greedy_rescans_rank0": fallbacks, "topk": args.topk, "substreams_per_gpu": S,
                           "parallelism": "stream-shard x%d" % e.world},
                "roofline": roof, "cpu_baseline": cpu}
         if check is not None:
