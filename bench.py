@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="stream", choices=["stream", "rig"])
-    ap.add_argument("--frames", type=int, default=0, help="multi-frames per step and GPU (default 32 stream / 4 rig)")
+    ap.add_argument("--frames", type=int, default=0, help="multi-frames per step and GPU (default 64 stream / 4 rig)")
     ap.add_argument("--mode", default="mdbrief", choices=list(MODES))
     ap.add_argument("--nfeatures", type=int, default=0, help="features per camera (default 1000 stream / 2000 rig)")
     ap.add_argument("--topk", type=int, default=32)
@@ -151,7 +151,7 @@ def roofline(kern, mode, nimg, nkp_total, sizes):
 def run_stream(args, e):
     torch, mcs, synth, lib, ctx, dev = e.torch, e.mcs, e.synth, e.lib, e.ctx, e.dev
     W, H, NCAM = 754, 480, 3
-    F = args.frames or 32
+    F = args.frames or 64
     nfeat = args.nfeatures or 1000
     nimg = F * NCAM
     do_db, masks_on = MODES[args.mode]

@@ -19,8 +19,9 @@
 
 namespace mcs {
 
-constexpr int MAXN = 1024;   // node capacity; host guarantees nfeat+3 <= MAXN and 4*nIni <= MAXN
+// MAXN = node capacity (host guarantees nfeat+3 <= MAXN and 4*nIni <= MAXN); KCACHE = keys kept in LDS (larger levels use HBM)
 
+template <int MAXN>
 struct NodeBuf {
 	short x0[MAXN], x1[MAXN], y0[MAXN], y1[MAXN];
 	int cnt[MAXN];
@@ -54,8 +55,11 @@ __device__ int block_exscan(int* a, int n, int* wsum) {
 	return total;
 }
 
+template <int MAXN, int KCACHE>
 __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg) {
-	__shared__ NodeBuf nb[2];
+	__shared__ NodeBuf<MAXN> nb[2];
+	__shared__ uint32_t kd[KCACHE];          // LDS copy of the level's candidate records ...
+	__shared__ unsigned short kn[KCACHE];    // ... and of the node position of every key, when the level fits
 	__shared__ int cc[MAXN * 4];
 	__shared__ short mapq[MAXN * 4];
 	__shared__ int scanA[MAXN];
@@ -72,8 +76,8 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg) {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int N = Lv.nfeat;
 
-	uint32_t* dense = b.dense + (size_t)img * d.densePerImage + Lv.denseBase;
-	unsigned short* knode = b.knode + (size_t)img * d.densePerImage + Lv.denseBase;
+	uint32_t* denseG = b.dense + (size_t)img * d.densePerImage + Lv.denseBase;
+	unsigned short* knodeG = b.knode + (size_t)img * d.densePerImage + Lv.denseBase;
 	uint32_t* sel = b.sel + (size_t)img * d.selPerImage + Lv.selBase;
 	int* selCount = b.selCount + (size_t)img * d.nlevels + level;
 	int* denseCount = b.denseCount + (size_t)img * d.nlevels + level;
@@ -93,13 +97,19 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg) {
 			const int cnt = cellCount[c0 + c];
 			const int off = n + scanA[c];
 			const uint32_t* sp = slots + (size_t)(c0 + c) * Lv.capc;
-			for (int j = lane; j < cnt; j += 64) dense[off + j] = sp[j];
+			for (int j = lane; j < cnt; j += 64) denseG[off + j] = sp[j];
 		}
 		n += tot;
 	}
 	__syncthreads();
 	if (tid == 0) *denseCount = n;
 	if (n == 0) { if (tid == 0) *selCount = 0; return; }
+	// keys of small levels live in LDS for the passes below (each pass walks all keys twice; from HBM that is the kernel's latency)
+	const bool inLds = n <= KCACHE;
+	if (inLds) for (int k = tid; k < n; k += 256) kd[k] = denseG[k];
+	const uint32_t* dense = inLds ? kd : denseG;
+	unsigned short* knode = inLds ? kn : knodeG;
+	__syncthreads();
 
 	// ---------------------------------------------------------------- roots (:641-683)
 	const int nIni = Lv.nIni;
@@ -136,8 +146,8 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg) {
 	int cur = 0;
 	bool phaseB = false;
 	for (int pass = 0; pass < 64; ++pass) {
-		NodeBuf& A = nb[cur];
-		NodeBuf& Bn = nb[cur ^ 1];
+		NodeBuf<MAXN>& A = nb[cur];
+		NodeBuf<MAXN>& Bn = nb[cur ^ 1];
 		const int prevL = L;
 		// (1) candidate ranks
 		int M;
@@ -286,7 +296,10 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg) {
 }
 
 void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
-	hipLaunchKernelGGL(k_octree, dim3(nimg * hd.nlevels), dim3(256), 0, s, b, nimg);
+	int need = 0;
+	for (int l = 0; l < hd.nlevels; ++l) need = need > hd.lv[l].nfeat + 3 ? need : hd.lv[l].nfeat + 3, need = need > 4 * hd.lv[l].nIni ? need : 4 * hd.lv[l].nIni;
+	if (need <= 512) hipLaunchKernelGGL((k_octree<512, 3072>), dim3(nimg * hd.nlevels), dim3(256), 0, s, b, nimg);   // 50 KB LDS: 3 workgroups per CU
+	else hipLaunchKernelGGL((k_octree<1024, 2048>), dim3(nimg * hd.nlevels), dim3(256), 0, s, b, nimg);
 }
 
 }  // namespace mcs
