@@ -32,7 +32,9 @@ template <int K, int DW, bool MASKED, bool COUNT>
 __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	__shared__ __attribute__((aligned(16))) uint32_t td[MT * DW];
 	__shared__ __attribute__((aligned(16))) uint32_t tm[MASKED ? MT * DW : 4];
-	__shared__ int tflag[MT];   // camera group of the train row, or -1 if not eligible at all
+	__shared__ __attribute__((aligned(16))) int tflag[MT + 4];        // camera group of the staged (eligible) rows
+	__shared__ __attribute__((aligned(16))) uint32_t tidx[MT + 4];    // their original train index; 0xFFFFFFFF = padding
+	__shared__ int wcnt[4];
 	constexpr int CB = 16;      // candidate column depth per lane
 	__shared__ uint32_t cand[CB * 256];
 	const int tid = threadIdx.x;
@@ -80,38 +82,53 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 		cnt = 0;
 	};
 
-	const int per = ((a.nt + a.splits - 1) / a.splits + MT - 1) / MT * MT;
+	const int per = ((a.nt + a.splits - 1) / a.splits + 63) / 64 * 64;
 	const int t0 = split * per, t1 = min(a.nt, t0 + per);
+	const int lane = tid & 63, wv = tid >> 6;
 	for (int base = t0; base < t1; base += MT) {
+		// Stage only the ELIGIBLE rows of this step, compacted in order (ballot prefix), with their original index next to them;
+		// the tail up to a multiple of 4 gets index 0xFFFFFFFF, which ORs every key to "empty".  The inner loop then needs no
+		// per-row eligibility test at all (that test used to serialise every row behind a wave-uniform LDS read + branch).
 		const int j = base + tid;
 		int flag = -1;
 		if (j < t1) {
-			const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.td + (trow0 + j) * a.tstride);
-#pragma unroll
-			for (int w = 0; w < DW; ++w) td[tid * DW + w] = tp[w];
-			if (MASKED) {
-				const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.tm + (trow0 + j) * a.tstride);
-#pragma unroll
-				for (int w = 0; w < DW; ++w) tm[tid * DW + w] = mp[w];
-			}
 			const bool ok = a.tvalid ? a.tvalid[trow0 + j] != 0 : true;
 			flag = ok ? (a.tgroup ? a.tgroup[trow0 + j] : 0) : -1;
 		}
-		tflag[tid] = flag;
+		const unsigned long long bal = __ballot(flag >= 0);
+		if (lane == 0) wcnt[wv] = __popcll(bal);
+		__syncthreads();
+		int pos = __popcll(bal & ((1ull << lane) - 1ull));
+		for (int w = 0; w < wv; ++w) pos += wcnt[w];
+		const int rows = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+		if (flag >= 0) {
+			const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.td + (trow0 + j) * a.tstride);
+#pragma unroll
+			for (int w = 0; w < DW; ++w) td[pos * DW + w] = tp[w];
+			if (MASKED) {
+				const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.tm + (trow0 + j) * a.tstride);
+#pragma unroll
+				for (int w = 0; w < DW; ++w) tm[pos * DW + w] = mp[w];
+			}
+			tidx[pos] = (uint32_t)j;
+			tflag[pos] = flag;
+		}
+		if (tid < 4) { tidx[rows + tid] = 0xFFFFFFFFu; tflag[rows + tid] = -1; }   // padding rows of the last trip
 		__syncthreads();
 		if (qok) {
-			const int rows = min(MT, t1 - base);
-			// 4 train rows per trip, branch-free: all LDS broadcasts of a trip are issued before the first use (ILP), rows past
-			// the end of the range carry flag -1 and turn into empty keys
+			// 4 train rows per trip, no branches: all LDS broadcasts of a trip are issued before the first use (ILP)
 			for (int r = 0; r < rows; r += 4) {
 				uint32_t key[4];
+				const uint4 ti = *reinterpret_cast<const uint4*>(&tidx[r]);
+				const uint32_t tiu[4] = {ti.x, ti.y, ti.z, ti.w};
+				int tgu[4] = {0, 0, 0, 0};
+				if (useGroup) { const int4 tg = *reinterpret_cast<const int4*>(&tflag[r]); tgu[0] = tg.x; tgu[1] = tg.y; tgu[2] = tg.z; tgu[3] = tg.w; }
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
-					const int g = tflag[r + u];
 					const int dist = hamming<DW, MASKED>(q, qm, &td[(r + u) * DW], &tm[MASKED ? (r + u) * DW : 0]);
-					const bool ok = g >= 0 && (!useGroup || g == qg);
-					if (COUNT) countLe += (ok && dist <= a.countThresh) ? 1 : 0;
-					key[u] = (ok && dist <= a.maxDist) ? (((uint32_t)dist << 20) | (uint32_t)(base + r + u)) : 0xFFFFFFFFu;
+					const bool ok = !useGroup || tgu[u] == qg;
+					if (COUNT) countLe += (ok && tiu[u] != 0xFFFFFFFFu && dist <= a.countThresh) ? 1 : 0;
+					key[u] = (ok && dist <= a.maxDist) ? (((uint32_t)dist << 20) | tiu[u]) : 0xFFFFFFFFu;
 				}
 				const uint32_t mk = min(min(key[0], key[1]), min(key[2], key[3]));
 				if (__any(mk < best[K - 1])) {   // rare: some lane has a candidate among these 4 rows
