@@ -134,17 +134,31 @@ def kernel_times(e, step, reps=5):
     return {k: v / reps for k, v in acc.items()}
 
 
-def roofline(kern, mode, nimg, nkp_total, sizes):
+def measured_traffic(dom, mode, frames, nfeat):
+    """HBM bytes per launch of kernel `dom` from the committed PMC passes (profiles/pmc_traffic.json), if they were taken on this workload."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        w = t["workload"]
+        if (w["frames"], w["mode"], w["nfeatures"]) != (frames, mode, nfeat):
+            return None
+        k = t["kernels"][dom]
+        return int((k["fetch_kib"] + k["write_kib"]) * 1024)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def roofline(kern, mode, nimg, nkp_total, sizes, nfeat=1000):
     # algorithmic bytes per launch (SURVEY.md §8d / DESIGN.md §4)
     per_kp = 845 + 512 * (3 if mode == "mdbrief" else 1) + 28 + 32 + (32 if mode == "mdbrief" else 0)
     S = [w * h for w, h in sizes]
     alg = {"describe": per_kp * nkp_total, "pyramid": nimg * (sum(S) - S[-1] + sum(S) - S[0]), "fast": nimg * sum(S), "blur": nimg * 2 * sum(S)}
     dom = max(alg, key=lambda k: kern[k])
     ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
-    return {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": None,
+    return {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": measured_traffic(dom, mode, nimg // 3, nfeat),
             "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kern[dom], 4), "per_kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "per_kernel_alg_GBps": {k: round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) for k in alg},
-            "note": "k_describe is FP64-VALU-bound in dBRIEF/mdBRIEF mode (1536 omni-model evaluations per keypoint), see DESIGN.md §6"}
+            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
+            "note": "every kernel of this path is VALU-issue-bound, not HBM-bound (k_describe: FP64 at 16 lanes/clk; matcher: v_bitop3/v_bcnt at 16 lanes/clk), see DESIGN.md §6"}
 
 
 # ------------------------------------------------------------------------------------------------ stream workload
@@ -252,7 +266,7 @@ def run_stream(args, e):
 
     roof = check = cpu = None
     if e.rank == 0:
-        roof = roofline(kernel_times(e, kstep), args.mode, nimg, feats_step, ex.level_sizes)
+        roof = roofline(kernel_times(e, kstep), args.mode, nimg, feats_step, ex.level_sizes, nfeat)
     if args.check and e.rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
