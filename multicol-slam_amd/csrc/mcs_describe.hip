@@ -4,13 +4,16 @@
 // omni model src/cam_model_omni.cpp:49-67,146-161, include/cam_model_omni.h:127-145, include/misc.h:115-122;
 // rays src/cMultiFrame.cpp:146-152.  cv::fastAtan2 per SURVEY Appendix A.5.
 //
-//   orientation   845-pixel disc of the UNBLURRED level, lanes stride over the disc, int32 moments reduced with
-//                 cross-lane shuffles (exact, order-free), then the float polynomial of cv::fastAtan2.
+//   orientation   845-pixel disc of the UNBLURRED level: lane r owns disc row r-15 (half-width c_umax[|v|]), int32 moments
+//                 reduced with cross-lane shuffles (exact, order-free), then the float polynomial of cv::fastAtan2.
+//   patch         the 49x49 blurred neighbourhood every sample can touch is staged once in LDS (row stride 52).
 //   descriptor    lane l owns pattern pairs l, l+64, l+128, ... ; one __ballot per 64 pairs yields 8 descriptor bytes
 //                 (bit k -> byte k/8, LSB first, exactly the reference's packing).
-//   dBRIEF        every pattern point goes through the Scaramuzza model in FP64 (sqrt, atan, degree-11 Horner);
-//                 the mean of the 2*8*descSize distorted points is accumulated SEQUENTIALLY (lane 0: x, lane 1: y)
-//                 from LDS in the reference's order, because FP64 addition order decides cvRound ties.
+//   dBRIEF        every pattern point goes through the Scaramuzza model in FP64 (sqrt, atan, Horner); the camera's
+//                 coefficients sit in SGPRs (readfirstlane) and the Horner chains have the fixed zero-padded length.
+//                 The mean of the 2*8*descSize distorted points is accumulated SEQUENTIALLY from LDS in the reference's
+//                 order (even lanes: x, odd lanes: y, all lanes redundantly so no divergence), because FP64 addition
+//                 order decides cvRound ties.  Math pass and chain pass are separate loops (registers).
 //   mdBRIEF       three patterns (angle, +20deg, -20deg); mask bit = both rotated tests agree with the main test.
 // Samples inside the level come from the blurred pyramid, samples in the 25-px frame from the unblurred level with
 // reflect-101 indices (the reference's frame is filled before the in-place blur), beyond the frame: clamped.
