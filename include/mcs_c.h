@@ -162,6 +162,37 @@ typedef struct {
 int mcs_search_by_projection(mcs_ctx*, const mcs_projection_set* mp, const mcs_frame_view* frame, double th, double nnratio, int dim,
                              mcs_mem_kind kind, int32_t* match, int32_t* nmatches);
 
+/* ------------------------------------------------------------------ the other grid-window matchers of cTracking
+ * One device routine serves them; a "probe" is one window the reference opens with cMultiFrame::GetFeaturesInArea(cam, x, y, radius,
+ * min_level, max_level) (src/cMultiFrame.cpp:272-340; min_level = max_level = -1: no level check) together with the descriptor (+mask)
+ * compared against the window's features, listed in the reference's visiting order.  Rules:
+ *   MCS_WINDOW_RATIO      int cORBmatcher::WindowSearch(F1, F2, windowSize, vpMapPointMatches2, minScaleLevel, maxScaleLevel)   (:326-473)
+ *                         int cORBmatcher::SearchByProjection(F1, F2, windowSize, vpMapPointMatches2)                            (:476-577)
+ *                         features already taken are skipped; accept if best <= second*nnratio && best <= TH_HIGH
+ *   MCS_WINDOW_BEST       int cORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th)                                       (:1990-2118)
+ *                         features already taken are skipped; accept if best <= TH_HIGH
+ *   MCS_WINDOW_INITIALIZE int cORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)               (:579-726)
+ *                         a feature matched at distance d is skipped by later probes whose distance is >= d and stolen by closer ones;
+ *                         accept if best <= TH_LOW && best < second*nnratio
+ * frame->assigned[i] = "feature i is taken" on entry (updated in place; ignored by MCS_WINDOW_INITIALIZE).  match[p] = frame feature
+ * index matched to probe p, or -1 (for MCS_WINDOW_INITIALIZE after all steals).  mbCheckOrientation is false at every reference call
+ * site (include/cORBmatcher.h:40) and is not offered.  frame->scale_factors / nlevels are not read by these rules.               */
+typedef struct {
+	const double* x; const double* y; const double* radius; const int32_t* min_level; const int32_t* max_level; const int32_t* cam;
+	const uint8_t* desc; const uint8_t* mask; int32_t n; int32_t stride;
+} mcs_window_probes;
+typedef enum { MCS_WINDOW_RATIO = 1, MCS_WINDOW_BEST = 2, MCS_WINDOW_INITIALIZE = 3 } mcs_window_rule;
+int mcs_window_match(mcs_ctx*, const mcs_window_probes* probes, const mcs_frame_view* frame, mcs_window_rule rule, double nnratio, int dim,
+                     mcs_mem_kind kind, int32_t* match, int32_t* nmatches);
+
+/* void cMultiCamSys_::WorldToCamHom_fast(int c, cv::Vec3d& pt3, cv::Vec2d& pt2) (src/cam_system_omni.cpp:114-133, the flagMcMt branch:
+ * ptRot = MtMc_inv[c] * (pt3, 1), then cCamModelGeneral_::WorldToImg) for n points, point i into camera cam[i], followed by
+ * cCamModelGeneral_::isPointInMirrorMask(u, v, 0) (src/cam_model_omni.cpp:163-178).  MtMc_inv: nr_cams 4x4 row-major matrices;
+ * mirror_masks: nr_cams pointers to the level-0 masks (rows of cams[c].width bytes) or NULL (bounds test only).
+ * uv = 2 doubles per point; flags bit0 = inside the mirror mask, bit1 = ptRot.z <= 0 (the bool the Vec4d overload returns, :92-112). */
+int mcs_world_to_cam(mcs_ctx*, const double* MtMc_inv, const mcs_ocam* cams, int nr_cams, const uint8_t* const* mirror_masks,
+                     const double* pts3, const int32_t* cam, int n, mcs_mem_kind kind, double* uv, uint8_t* flags);
+
 /* device helper: valid[i*cap + k] = (k < nkp[i]) for the row layout produced by mcs_extract_batch (all pointers on the GPU) */
 int mcs_rows_valid(mcs_ctx*, const int32_t* nkp_dev, int nimg, int cap, uint8_t* valid_dev);
 

@@ -246,7 +246,7 @@ int mcs_search_by_projection(mcs_ctx* c, const mcs_projection_set* mp, const mcs
 	const bool havingMasks = mp->mask != nullptr;
 	ProjArgs a{};
 	a.nproj = mp->n; a.pstride = mp->stride; a.nfeat = f->n; a.fstride = f->stride; a.nrCams = f->nr_cams;
-	a.th = th; a.ratio = nnratio; a.dim = dim;
+	a.th = th; a.ratio = nnratio; a.dim = dim; a.rule = 0; a.cap = kProjListCap;
 	a.thHigh = havingMasks ? (int)floor(1.5 * dim) : 3 * dim;   // TH_HIGH_ (src/cORBmatcher.cpp:46-65)
 	const size_t np = std::max(mp->n, 1), nf = std::max(f->n, 1);
 	// scratch: lists + counts (+ staged inputs / outputs for host pointers), one allocation per call (this row is not a bench path)

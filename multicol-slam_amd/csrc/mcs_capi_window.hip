@@ -1,0 +1,149 @@
+// mcs_capi_window.hip — C ABI of the grid-window matchers other than SearchByProjection(F, mapPoints) and of the projection they
+// consume (include/mcs_c.h: mcs_window_match, mcs_world_to_cam).  Kernels: mcs_project.hip.
+#include "mcs_host.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+using namespace mcs;
+
+namespace {
+inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+// one device allocation per call carved into aligned pieces; host-kind inputs are staged into it (these rows are not bench paths)
+struct Arena {
+	std::vector<size_t> sizes;
+	uint8_t* base = nullptr;
+	size_t add(size_t bytes) { sizes.push_back(al256(std::max<size_t>(bytes, 1))); return sizes.size() - 1; }
+	hipError_t alloc() { size_t t = 0; for (size_t v : sizes) t += v; return hipMalloc((void**)&base, t); }
+	uint8_t* at(size_t id) const { size_t o = 0; for (size_t i = 0; i < id; ++i) o += sizes[i]; return base + o; }
+	~Arena() { if (base) (void)hipFree(base); }
+};
+}  // namespace
+
+int mcs_window_match(mcs_ctx* c, const mcs_window_probes* pr, const mcs_frame_view* f, mcs_window_rule rule, double nnratio, int dim, mcs_mem_kind kind,
+                     int32_t* match, int32_t* nmatches) {
+	if (!c || !pr || !f || !match || !nmatches) return fail(MCS_ERR_INVALID, "null argument");
+	if (rule != MCS_WINDOW_RATIO && rule != MCS_WINDOW_BEST && rule != MCS_WINDOW_INITIALIZE) return fail(MCS_ERR_INVALID, "unknown window rule");
+	if (dim != 16 && dim != 32 && dim != 64) return fail(MCS_ERR_INVALID, "dim must be 16, 32 or 64");
+	if (pr->n < 0 || f->n < 0 || f->n > 65536 || f->nr_cams < 1) return fail(MCS_ERR_INVALID, "bad sizes (frame features must be <= 65536)");
+	if ((pr->mask == nullptr) != (f->mask == nullptr)) return fail(MCS_ERR_INVALID, "masks must be given for both sides or neither");
+	if (pr->stride < dim || f->stride < dim || (pr->stride & 3) || (f->stride & 3)) return fail(MCS_ERR_INVALID, "descriptor stride must be >= dim and a multiple of 4");
+	if (rule != MCS_WINDOW_INITIALIZE && !f->assigned) return fail(MCS_ERR_INVALID, "frame->assigned is required");
+	HIPCHK(hipSetDevice(c->device));
+	hipStream_t s = c->stream;
+	if (c->side && c->greedyPending) { HIPCHK(hipStreamWaitEvent(s, c->evGreedy, 0)); c->greedyPending = false; }
+	const bool havingMasks = pr->mask != nullptr, host = kind == MCS_MEM_HOST;
+	const size_t np = pr->n, nf = f->n;
+	ProjArgs a{};
+	a.rule = (int)rule; a.cap = kWindowListCap;
+	a.nproj = pr->n; a.pstride = pr->stride; a.nfeat = f->n; a.fstride = f->stride; a.nrCams = f->nr_cams;
+	a.ratio = nnratio; a.dim = dim; a.th = 1.0;
+	a.thHigh = havingMasks ? (int)floor(1.5 * dim) : 3 * dim;   // TH_HIGH_ / TH_LOW_ (src/cORBmatcher.cpp:46-65)
+	a.thLow = havingMasks ? (int)floor((double)dim) : 2 * dim;
+	Arena ar;
+	const size_t iLists = ar.add(np * kWindowListCap * 8), iCounts = ar.add(np * 4), iOwner = ar.add(nf * 4), iMdist = ar.add(nf * 4), iAsg = ar.add(nf);
+	size_t iX = 0, iY = 0, iR = 0, iLo = 0, iHi = 0, iPc = 0, iPd = 0, iPm = 0, iKeys = 0, iFd = 0, iFm = 0, iFc = 0, iW = 0, iH = 0, iMatch = 0, iNm = 0;
+	if (host) {
+		iX = ar.add(np * 8); iY = ar.add(np * 8); iR = ar.add(np * 8); iLo = ar.add(np * 4); iHi = ar.add(np * 4); iPc = ar.add(np * 4);
+		iPd = ar.add(np * pr->stride); iPm = ar.add(np * pr->stride); iKeys = ar.add(nf * sizeof(mcs_keypoint)); iFd = ar.add(nf * f->stride);
+		iFm = ar.add(nf * f->stride); iFc = ar.add(nf * 4); iW = ar.add((size_t)f->nr_cams * 4); iH = ar.add((size_t)f->nr_cams * 4);
+		iMatch = ar.add(np * 4); iNm = ar.add(4);
+	}
+	HIPCHK(ar.alloc());
+	auto done = [&](int rc) { (void)hipStreamSynchronize(s); return rc; };   // the arena is freed by its destructor after this sync
+	a.lists = (unsigned long long*)ar.at(iLists); a.counts = (int*)ar.at(iCounts); a.owner = (int*)ar.at(iOwner); a.mdist = (int*)ar.at(iMdist);
+	if (host) {
+#define UP(id, src, bytes) do { if ((bytes) && hipMemcpyAsync(ar.at(id), (src), (bytes), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "H2D copy failed")); } while (0)
+		UP(iX, pr->x, np * 8); UP(iY, pr->y, np * 8); UP(iR, pr->radius, np * 8); UP(iLo, pr->min_level, np * 4); UP(iHi, pr->max_level, np * 4);
+		UP(iPc, pr->cam, np * 4); UP(iPd, pr->desc, np * pr->stride);
+		if (havingMasks) { UP(iPm, pr->mask, np * pr->stride); UP(iFm, f->mask, nf * f->stride); }
+		UP(iKeys, f->keys, nf * sizeof(mcs_keypoint)); UP(iFd, f->desc, nf * f->stride); UP(iFc, f->cam, nf * 4);
+		UP(iW, f->width, (size_t)f->nr_cams * 4); UP(iH, f->height, (size_t)f->nr_cams * 4);
+		if (f->assigned) UP(iAsg, f->assigned, nf);
+#undef UP
+		a.px = (const double*)ar.at(iX); a.py = (const double*)ar.at(iY); a.rad = (const double*)ar.at(iR); a.minLvl = (const int*)ar.at(iLo);
+		a.maxLvl = (const int*)ar.at(iHi); a.pcam = (const int*)ar.at(iPc); a.pdesc = ar.at(iPd); a.pmask = havingMasks ? ar.at(iPm) : nullptr;
+		a.keys = (const mcs_keypoint*)ar.at(iKeys); a.fdesc = ar.at(iFd); a.fmask = havingMasks ? ar.at(iFm) : nullptr; a.fcam = (const int*)ar.at(iFc);
+		a.width = (const int*)ar.at(iW); a.height = (const int*)ar.at(iH); a.assigned = ar.at(iAsg);
+		a.match = (int*)ar.at(iMatch); a.nmatches = (int*)ar.at(iNm);
+	} else {
+		a.px = pr->x; a.py = pr->y; a.rad = pr->radius; a.minLvl = pr->min_level; a.maxLvl = pr->max_level; a.pcam = pr->cam; a.pdesc = pr->desc;
+		a.pmask = pr->mask; a.keys = f->keys; a.fdesc = f->desc; a.fmask = f->mask; a.fcam = f->cam; a.width = f->width; a.height = f->height;
+		a.assigned = f->assigned ? f->assigned : ar.at(iAsg); a.match = match; a.nmatches = nmatches;
+	}
+	if (!f->assigned) { if (hipMemsetAsync(ar.at(iAsg), 0, std::max<size_t>(nf, 1), s) != hipSuccess) return done(fail(MCS_ERR_HIP, "memset failed")); }
+	if (pr->n > 0) launch_projection(a, s);
+	else if (!host) { if (hipMemsetAsync(nmatches, 0, 4, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "memset failed")); }
+	if (hipGetLastError() != hipSuccess) return done(fail(MCS_ERR_HIP, "window kernels failed to launch"));
+	if (host) {
+		*nmatches = 0;
+		if (pr->n > 0) {
+			if (hipMemcpyAsync(match, ar.at(iMatch), np * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
+			if (hipMemcpyAsync(nmatches, ar.at(iNm), 4, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
+			if (f->assigned && nf && hipMemcpyAsync(f->assigned, ar.at(iAsg), nf, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
+		}
+	}
+	return done(MCS_OK);
+}
+
+int mcs_world_to_cam(mcs_ctx* c, const double* MtMc_inv, const mcs_ocam* cams, int nr_cams, const uint8_t* const* mirror_masks, const double* pts3,
+                     const int32_t* cam, int n, mcs_mem_kind kind, double* uv, uint8_t* flags) {
+	if (!c || !MtMc_inv || !cams || !pts3 || !cam || !uv || !flags) return fail(MCS_ERR_INVALID, "null argument");
+	if (nr_cams < 1 || n < 0) return fail(MCS_ERR_INVALID, "bad sizes");
+	HIPCHK(hipSetDevice(c->device));
+	hipStream_t s = c->stream;
+	const bool host = kind == MCS_MEM_HOST;
+	std::vector<OcamDev> hc(nr_cams);
+	std::vector<int> w(nr_cams), h(nr_cams);
+	size_t maskBytes = 0;
+	for (int i = 0; i < nr_cams; ++i) {
+		const mcs_ocam& m = cams[i];
+		if (m.p_deg < 1 || m.p_deg > MCS_MAX_POLY || m.invP_deg < 1 || m.invP_deg > MCS_MAX_POLY) return fail(MCS_ERR_INVALID, "bad polynomial degree");
+		if (m.width < 1 || m.height < 1) return fail(MCS_ERR_INVALID, "bad image size");
+		OcamDev& o = hc[i];
+		memset(&o, 0, sizeof(o));
+		o.c = m.c; o.d = m.d; o.e = m.e; o.u0 = m.u0; o.v0 = m.v0; o.invAffine = m.c - m.d * m.e;
+		for (int k = 0; k < m.p_deg; ++k) o.p[k] = m.p[k];
+		for (int k = 0; k < m.invP_deg; ++k) o.invP[k] = m.invP[k];
+		o.p_deg = m.p_deg; o.invP_deg = m.invP_deg;
+		w[i] = m.width; h[i] = m.height;
+		if (mirror_masks && mirror_masks[i]) maskBytes += al256((size_t)m.width * m.height);
+	}
+	Arena ar;
+	const size_t iM = ar.add((size_t)nr_cams * 128), iC = ar.add(sizeof(OcamDev) * nr_cams), iW = ar.add(4 * (size_t)nr_cams), iH = ar.add(4 * (size_t)nr_cams),
+	             iMp = ar.add(sizeof(void*) * nr_cams), iMk = ar.add(host ? maskBytes : 0);
+	size_t iP = 0, iPc = 0, iUv = 0, iFl = 0;
+	if (host) { iP = ar.add((size_t)n * 24); iPc = ar.add((size_t)n * 4); iUv = ar.add((size_t)n * 16); iFl = ar.add((size_t)n); }
+	HIPCHK(ar.alloc());
+	auto done = [&](int rc) { (void)hipStreamSynchronize(s); return rc; };
+#define UP(dst, src, bytes) do { if ((bytes) && hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "H2D copy failed")); } while (0)
+	// the matrices / calibrations are host values for either kind (they are the camera system's state, a few hundred bytes)
+	UP(ar.at(iM), MtMc_inv, (size_t)nr_cams * 128); UP(ar.at(iC), hc.data(), sizeof(OcamDev) * nr_cams); UP(ar.at(iW), w.data(), 4 * (size_t)nr_cams);
+	UP(ar.at(iH), h.data(), 4 * (size_t)nr_cams);
+	std::vector<const uint8_t*> mp(nr_cams, nullptr);
+	if (mirror_masks) {
+		size_t off = 0;
+		for (int i = 0; i < nr_cams; ++i) {
+			if (!mirror_masks[i]) continue;
+			if (host) { uint8_t* d = ar.at(iMk) + off; UP(d, mirror_masks[i], (size_t)w[i] * h[i]); mp[i] = d; off += al256((size_t)w[i] * h[i]); }
+			else mp[i] = mirror_masks[i];
+		}
+	}
+	UP(ar.at(iMp), mp.data(), sizeof(void*) * nr_cams);
+	WorldToCamArgs a{};
+	a.M = (const double*)ar.at(iM); a.cams = (const OcamDev*)ar.at(iC); a.width = (const int*)ar.at(iW); a.height = (const int*)ar.at(iH);
+	a.masks = mirror_masks ? (const uint8_t* const*)ar.at(iMp) : nullptr; a.n = n;
+	if (host) {
+		UP(ar.at(iP), pts3, (size_t)n * 24); UP(ar.at(iPc), cam, (size_t)n * 4);
+		a.pts = (const double*)ar.at(iP); a.pcam = (const int*)ar.at(iPc); a.uv = (double*)ar.at(iUv); a.flags = ar.at(iFl);
+	} else { a.pts = pts3; a.pcam = cam; a.uv = uv; a.flags = flags; }
+#undef UP
+	launch_world_to_cam(a, s);
+	if (hipGetLastError() != hipSuccess) return done(fail(MCS_ERR_HIP, "k_world_to_cam failed to launch"));
+	if (host && n > 0) {
+		if (hipMemcpyAsync(uv, ar.at(iUv), (size_t)n * 16, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
+		if (hipMemcpyAsync(flags, ar.at(iFl), (size_t)n, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
+	}
+	return done(MCS_OK);
+}

@@ -126,17 +126,36 @@ struct GreedyArgs {
 void launch_greedy(const GreedyArgs& g, hipStream_t s);
 
 // window matcher (SearchByProjection), mcs_project.hip
-constexpr int kProjListCap = 64;
+constexpr int kProjListCap = 64;     // rule 0 (radius 2.5-4 px x scale)
+constexpr int kWindowListCap = 128;  // rules 1-3 (windows of 40-60 px)
+// rule 0  SearchByProjection(F, mapPoints, th)   window from vcos / level / th, level-aware ratio test        (src/cORBmatcher.cpp:67-166)
+// rule 1  WindowSearch, SearchByProjection(F1,F2) explicit window, taken features skipped, best <= second*ratio && best <= TH_HIGH (:326-577)
+// rule 2  SearchByProjection(Cur, Last, th)       explicit window, taken features skipped, best <= TH_HIGH     (:1990-2118)
+// rule 3  SearchForInitialization                 explicit window, matched-distance stealing, best <= TH_LOW && best < second*ratio (:579-726)
 struct ProjArgs {
 	const double* px; const double* py; const double* vcos; const int* level; const int* pcam;
 	const uint8_t* pdesc; const uint8_t* pmask; int nproj; int pstride;
 	const mcs_keypoint* keys; const uint8_t* fdesc; const uint8_t* fmask; const int* fcam; uint8_t* assigned; int nfeat; int fstride;
 	const int* width; const int* height; const double* scales; int nrCams;
 	double th; double ratio; int dim; int thHigh;
-	unsigned long long* lists; int* counts;   // [nproj][kProjCap], [nproj] (count may exceed kProjCap = overflow)
+	unsigned long long* lists; int* counts;   // [nproj][cap], [nproj] (count may exceed cap = overflow)
 	int* match; int* nmatches;
+	// rules 1-3
+	int rule; int cap; int thLow;
+	const double* rad; const int* minLvl; const int* maxLvl;   // explicit window per probe
+	int* owner; int* mdist;                                    // rule 3: vnMatches21 / vMatchedDistance, [nfeat]
 };
 
 void launch_projection(const ProjArgs& a, hipStream_t s);
+
+struct WorldToCamArgs {   // cMultiCamSys_::WorldToCamHom_fast + isPointInMirrorMask (src/cam_system_omni.cpp:92-133, src/cam_model_omni.cpp:163-178)
+	const double* M;              // [nrCams][16] MtMc_inv, row-major
+	const OcamDev* cams;          // [nrCams]
+	const int* width; const int* height;
+	const uint8_t* const* masks;  // [nrCams] level-0 mirror masks (tight rows) or nullptr
+	const double* pts; const int* pcam; int n;
+	double* uv; uint8_t* flags;
+};
+void launch_world_to_cam(const WorldToCamArgs& a, hipStream_t s);
 
 }  // namespace mcs

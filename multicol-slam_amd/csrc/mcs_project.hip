@@ -1,5 +1,9 @@
-// mcs_project.hip — window matcher, SURVEY §8f "next" row 1:
-//   cORBmatcher::SearchByProjection(cMultiFrame&, const vector<cMapPoint*>&, th)   src/cORBmatcher.cpp:67-166
+// mcs_project.hip — grid-window matchers, SURVEY §8f "next" row 1:
+//   cORBmatcher::SearchByProjection(cMultiFrame&, const vector<cMapPoint*>&, th)   src/cORBmatcher.cpp:67-166      (rule 0)
+//   cORBmatcher::WindowSearch, SearchByProjection(F1, F2, windowSize, ...)          :326-577                        (rule 1)
+//   cORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th)                    :1990-2118                      (rule 2)
+//   cORBmatcher::SearchForInitialization                                            :579-726                        (rule 3)
+//   cMultiCamSys_::WorldToCamHom_fast + isPointInMirrorMask                         src/cam_system_omni.cpp:92-133, src/cam_model_omni.cpp:163-178
 //   cMultiFrame::GetFeaturesInArea                                                src/cMultiFrame.cpp:272-340
 //   cMultiFrame::PosInGrid (cvRound binning, bins 64 / 48 dropped)                :342-353
 //   cORBmatcher::RadiusByViewingCos                                               src/cORBmatcher.cpp:169-175
@@ -14,17 +18,22 @@
 namespace mcs {
 
 constexpr int kGridCols = 64, kGridRows = 48;   // FRAME_GRID_COLS / ROWS (include/cMultiFrame.h)
-constexpr int kProjCap = 64;                    // list entries per projection; longer windows are rescanned exactly
 
 struct Window { int minCX, maxCX, minCY, maxCY, minLevel, maxLevel; double x, y, rr, wInv, hInv; bool empty; };
 
 __device__ __forceinline__ Window make_window(const ProjArgs& a, int p) {
 	Window w;
-	const int cam = a.pcam[p], lvl = a.level[p];
-	double r = a.vcos[p] > 0.998 ? 2.5 : 4.0;
-	if (a.th != 1.0) r *= a.th;
-	w.x = a.px[p]; w.y = a.py[p]; w.rr = r * a.scales[lvl];
-	w.minLevel = lvl - 1; w.maxLevel = lvl;
+	const int cam = a.pcam[p];
+	w.x = a.px[p]; w.y = a.py[p];
+	if (a.rule == 0) {
+		const int lvl = a.level[p];
+		double r = a.vcos[p] > 0.998 ? 2.5 : 4.0;
+		if (a.th != 1.0) r *= a.th;
+		w.rr = r * a.scales[lvl];
+		w.minLevel = lvl - 1; w.maxLevel = lvl;
+	} else {
+		w.rr = a.rad[p]; w.minLevel = a.minLvl[p]; w.maxLevel = a.maxLvl[p];
+	}
 	w.wInv = static_cast<double>(kGridCols) / static_cast<double>(a.width[cam] - 0);
 	w.hInv = static_cast<double>(kGridRows) / static_cast<double>(a.height[cam] - 0);
 	w.empty = false;
@@ -42,7 +51,7 @@ __device__ __forceinline__ unsigned long long member_key(const ProjArgs& a, cons
 	const int gx = __double2int_rn((kp.x - 0) * w.wInv), gy = __double2int_rn((kp.y - 0) * w.hInv);   // PosInGrid: cvRound
 	if (gx < 0 || gx >= kGridCols || gy < 0 || gy >= kGridRows) return ~0ull;                            // never entered a cell
 	if (gx < w.minCX || gx > w.maxCX || gy < w.minCY || gy > w.maxCY) return ~0ull;
-	const bool checkLevels = !(w.minLevel == -1 && w.maxLevel == -1), same = w.minLevel == w.maxLevel;
+	const bool checkLevels = !(w.minLevel == -1 && w.maxLevel == -1), same = checkLevels && w.minLevel == w.maxLevel;
 	if (checkLevels && !same) { if (kp.octave < w.minLevel || kp.octave > w.maxLevel) return ~0ull; }
 	else if (same) { if (kp.octave != w.minLevel) return ~0ull; }
 	if (fabs(kp.x - w.x) > w.rr || fabs(kp.y - w.y) > w.rr) return ~0ull;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(64) void k_proj_candidates(ProjArgs a) {
 			}
 			if (key != ~0ull) {
 				const int slot = atomicAdd(&cnt, 1);
-				if (slot < kProjCap) a.lists[(size_t)p * kProjCap + slot] = key;
+				if (slot < a.cap) a.lists[(size_t)p * a.cap + slot] = key;
 			}
 		}
 	}
@@ -101,10 +110,21 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 __global__ __launch_bounds__(64) void k_proj_greedy(ProjArgs a) {
 	__shared__ uint32_t taken[65536 / 32];   // frame features <= 65536
 	const int lane = threadIdx.x;
-	for (int i = lane; i < (a.nfeat + 31) / 32; i += 64) taken[i] = 0;
+	const bool steal = a.rule == 3;
+	if (steal) {
+		for (int i = lane; i < a.nfeat; i += 64) { a.owner[i] = -1; a.mdist[i] = 0x7FFFFFFF; }
+		__threadfence_block();
+	} else {
+		for (int i = lane; i < (a.nfeat + 31) / 32; i += 64) taken[i] = 0;
+		__syncthreads();
+		for (int i = lane; i < a.nfeat; i += 64) if (a.assigned[i]) atomicOr(&taken[i >> 5], 1u << (i & 31));
+	}
 	__syncthreads();
-	for (int i = lane; i < a.nfeat; i += 64) if (a.assigned[i]) atomicOr(&taken[i >> 5], 1u << (i & 31));
-	__syncthreads();
+	// is frame feature idx (at distance dist from the probe) still a candidate?
+	auto free_for = [&](int idx, int dist) -> bool {
+		if (steal) return a.mdist[idx] > dist;                  // "if (vMatchedDistance[i2] <= dist) continue" (:652)
+		return !((taken[idx >> 5] >> (idx & 31)) & 1u);         // "if (vpMapPointMatches2[i2]) continue"
+	};
 	int nmatches = 0;
 	const unsigned long long NONE = ~0ull;
 	for (int p0 = 0; p0 < a.nproj; p0 += 64) {
@@ -119,43 +139,53 @@ __global__ __launch_bounds__(64) void k_proj_greedy(ProjArgs a) {
 			const int low = __ffsll((long long)pend) - 1;
 			// tentative best / second among the free members of my window
 			unsigned long long k1 = NONE, k2 = NONE;
-			const bool overflow = !resolved && cnt > kProjCap;
+			const bool overflow = !resolved && cnt > a.cap;
 			if (!resolved && !overflow) {
 				for (int e = 0; e < cnt; ++e) {
-					const unsigned long long k = a.lists[(size_t)p * kProjCap + e];
-					const int idx = (int)(k & 0xFFFFFu);
-					if ((taken[idx >> 5] >> (idx & 31)) & 1u) continue;
+					const unsigned long long k = a.lists[(size_t)p * a.cap + e];
+					if (!free_for((int)(k & 0xFFFFFu), (int)(k >> 42))) continue;
 					if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
 				}
 			}
-			// the lowest pending projection is rescanned exactly by the whole wave if its list overflowed
+			// the lowest pending probe is rescanned exactly by the whole wave if its list overflowed
 			if (__shfl((int)overflow, low)) {
 				const int pp = p0 + low;
 				const Window w = make_window(a, pp);
 				const int cam = a.pcam[pp];
 				unsigned long long b1 = NONE, b2 = NONE;
 				for (int i = lane; i < a.nfeat; i += 64) {
-					if ((taken[i >> 5] >> (i & 31)) & 1u) continue;
 					const unsigned long long mk = member_key(a, w, cam, i);
 					if (mk == NONE) continue;
-					const unsigned long long k = ((unsigned long long)proj_distance(a, pp, i) << 42) | mk;
+					const int dist = proj_distance(a, pp, i);
+					if (!free_for(i, dist)) continue;
+					const unsigned long long k = ((unsigned long long)dist << 42) | mk;
 					if (k < b1) { b2 = b1; b1 = k; } else if (k < b2) b2 = k;
 				}
 				const unsigned long long m1 = wave_min_u64(b1);
 				const unsigned long long m2 = wave_min_u64(b1 == m1 ? b2 : b1);
 				if (lane == low) { k1 = m1; k2 = m2; }
 			}
-			// decision (:153-163)
-			int state = 0, bestIdx = -1, secondIdx = -1;   // 0 no match, 1 match, 2 waiting for its rescan
+			// decision
+			int state = 0, bestIdx = -1, secondIdx = -1, best = 0;   // 0 no match, 1 match, 2 waiting for its rescan
 			if (!resolved) {
 				if (overflow && lane != low) state = 2;
 				else if (k1 != NONE) {
-					const int best = (int)(k1 >> 42);
+					best = (int)(k1 >> 42);
 					bestIdx = (int)(k1 & 0xFFFFFu);
-					int second = 0x7FFFFFFF, lvl2 = -1;
-					if (k2 != NONE) { second = (int)(k2 >> 42); secondIdx = (int)(k2 & 0xFFFFFu); lvl2 = a.keys[secondIdx].octave; }
-					const int lvl1 = a.keys[bestIdx].octave;
-					if (best <= a.thHigh && !(lvl1 == lvl2 && static_cast<double>(best) > a.ratio * static_cast<double>(second))) state = 1;
+					int second = 0x7FFFFFFF;
+					if (k2 != NONE) { second = (int)(k2 >> 42); secondIdx = (int)(k2 & 0xFFFFFu); }
+					if (a.rule == 0) {          // :153-163
+						const int lvl2 = k2 != NONE ? a.keys[secondIdx].octave : -1;
+						const int lvl1 = a.keys[bestIdx].octave;
+						if (best <= a.thHigh && !(lvl1 == lvl2 && static_cast<double>(best) > a.ratio * static_cast<double>(second))) state = 1;
+					} else if (a.rule == 1) {   // :416, :558-560
+						if (static_cast<double>(best) <= static_cast<double>(second) * a.ratio && best <= a.thHigh) state = 1;
+					} else if (a.rule == 2) {   // :2072 (no runner-up)
+						secondIdx = -1;
+						if (best <= a.thHigh) state = 1;
+					} else {                    // :670-672
+						if (best <= a.thLow && static_cast<double>(best) < static_cast<double>(second) * a.ratio) state = 1;
+					}
 				}
 			}
 			// finality: no lower pending lane of this round may take my best or my second feature (accepting lanes broadcast their
@@ -172,15 +202,75 @@ __global__ __launch_bounds__(64) void k_proj_greedy(ProjArgs a) {
 			const unsigned long long blk = __ballot(blocked);
 			const int firstBlocked = blk ? __ffsll((long long)blk) - 1 : 64;
 			const bool commit = !resolved && lane < firstBlocked;
+			bool stole = false;
 			if (commit) {
-				if (state == 1) { atomicOr(&taken[bestIdx >> 5], 1u << (bestIdx & 31)); a.assigned[bestIdx] = 1; a.match[p] = bestIdx; }
+				if (state == 1) {
+					if (steal) {            // :674-681
+						const int prev = a.owner[bestIdx];
+						if (prev >= 0) { a.match[prev] = -1; stole = true; }
+						a.owner[bestIdx] = p; a.mdist[bestIdx] = best;
+					} else {
+						atomicOr(&taken[bestIdx >> 5], 1u << (bestIdx & 31));
+						a.assigned[bestIdx] = 1;
+					}
+					a.match[p] = bestIdx;
+				}
 				resolved = true;
 			}
-			nmatches += __popcll(__ballot(commit && state == 1));
+			nmatches += __popcll(__ballot(commit && state == 1)) - __popcll(__ballot(stole));
+			__threadfence_block();
 			__syncthreads();
 		}
 	}
 	if (lane == 0) *a.nmatches = nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------- WorldToCamHom_fast
+// include/misc.h:115-122 (zero-padded fixed-length form, see mcs_describe.hip)
+__device__ __forceinline__ double horner_fixed(const double* coeffs, double x) {
+	double res = 0.0;
+#pragma unroll
+	for (int i = MCS_MAX_POLY - 1; i >= 0; i--) res = res * x + coeffs[i];
+	return res;
+}
+
+__global__ __launch_bounds__(64) void k_world_to_cam(WorldToCamArgs a) {
+	const int i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= a.n) return;
+	const int c = a.pcam[i];
+	const double* M = a.M + 16 * (size_t)c;
+	const double pt4[4] = {a.pts[3 * (size_t)i], a.pts[3 * (size_t)i + 1], a.pts[3 * (size_t)i + 2], 1.0};
+	double r[4];
+#pragma unroll
+	for (int row = 0; row < 4; ++row) {   // cv::Matx product: s = 0; s += a(i,k) * b(k)
+		double s = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) s += M[4 * row + k] * pt4[k];
+		r[row] = s;
+	}
+	const OcamDev& cam = a.cams[c];
+	double norm = sqrt(r[0] * r[0] + r[1] * r[1]);   // cCamModelGeneral_::WorldToImg (src/cam_model_omni.cpp:146-161)
+	if (norm == 0.0) norm = 1e-14;
+	const double theta = atan(-r[2] / norm);
+	const double rho = horner_fixed(cam.invP, theta);
+	const double uu = r[0] / norm * rho;
+	const double vv = r[1] / norm * rho;
+	const double u = uu * cam.c + vv * cam.d + cam.u0;
+	const double v = uu * cam.e + vv + cam.v0;
+	a.uv[2 * (size_t)i] = u; a.uv[2 * (size_t)i + 1] = v;
+	const int ur = __double2int_rn(u), vr = __double2int_rn(v);
+	unsigned fl = 0;
+	const int W = a.width[c], H = a.height[c];
+	if (!(ur >= W || ur <= 0 || vr >= H || vr <= 0)) {
+		const uint8_t* m = a.masks ? a.masks[c] : nullptr;
+		if (!m || m[(size_t)vr * W + ur] > 0) fl |= 1u;
+	}
+	if (r[2] <= 0.0) fl |= 2u;
+	a.flags[i] = (uint8_t)fl;
+}
+
+void launch_world_to_cam(const WorldToCamArgs& a, hipStream_t s) {
+	if (a.n > 0) hipLaunchKernelGGL(k_world_to_cam, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 }
 
 void launch_projection(const ProjArgs& a, hipStream_t s) {

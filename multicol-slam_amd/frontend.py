@@ -3,6 +3,8 @@
   mdBRIEFextractorOct / ORBextractor   include/mdBRIEFextractorOct.h:335-421, include/cORBextractor.h:61-63
   cMultiFrame (extraction part)        include/cMultiFrame.h:62-162, src/cMultiFrame.cpp:92-216,342-353
   cORBmatcher (brute-force searches)   include/cORBmatcher.h:43-133, src/cORBmatcher.cpp:46-65,179-323,885-1155
+  cORBmatcher (grid-window searches)   src/cORBmatcher.cpp:67-166,326-726,1990-2118
+  cMultiCamSys_ (pose, projection)     src/cam_system_omni.cpp:92-133,168-198
   DescriptorDistance64[_Masked]        src/cORBmatcher.cpp:2438-2474
 
 Everything numeric runs in libmcs_hip.so on the GPU; this file only shapes inputs/outputs (numpy stands in for cv::Mat).
@@ -50,9 +52,67 @@ class cCamModelGeneral_:
         return self._mask
 
 
+def _matx_mul(A, B):
+    """cv::Matx product (s = 0; s += a(i,k) * b(k,j) in k order), so MtMc is rounded like the reference's."""
+    A, B = np.asarray(A, np.float64), np.asarray(B, np.float64)
+    out = np.zeros((A.shape[0], B.shape[1]))
+    for i in range(A.shape[0]):
+        for j in range(B.shape[1]):
+            acc = np.float64(0.0)
+            for k in range(A.shape[1]):
+                acc = acc + A[i, k] * B[k, j]
+            out[i, j] = acc
+    return out
+
+
+def _inv_mat(M):
+    """cConverter::invMat (src/cConverter.cpp:31-44): rigid inverse, t = -(R^T) * t."""
+    M = np.asarray(M, np.float64)
+    Rt = M[:3, :3].T.copy()
+    t = _matx_mul(-Rt, M[:3, 3:4])[:, 0]
+    out = np.eye(4)
+    out[:3, :3] = Rt
+    out[:3, 3] = t
+    return out
+
+
 class cMultiCamSys_:
-    def __init__(self, cam_models):
+    """Calibrations + poses of the rig (include/cam_system_omni.h): M_t = rig pose, M_c[c] = camera c in the rig frame."""
+
+    def __init__(self, cam_models, M_c=None, M_t=None):
         self.cams = list(cam_models)
+        self.M_c = [np.asarray(m, np.float64) for m in M_c] if M_c is not None else [np.eye(4) for _ in self.cams]
+        self.Set_M_t(np.eye(4) if M_t is None else M_t)
+
+    def Set_M_t(self, M_t_):   # src/cam_system_omni.cpp:184-198
+        self.M_t = np.asarray(M_t_, np.float64).copy()
+        self.M_t_inv = _inv_mat(self.M_t)
+        self.MtMc = [_matx_mul(self.M_t, mc) for mc in self.M_c]
+        self.MtMc_inv = [_inv_mat(m) for m in self.MtMc]
+
+    def world_to_cam(self, pts3, cam_idx, ctx=None):
+        """Batched WorldToCamHom_fast + isPointInMirrorMask(u, v, 0) on the GPU -> (uv [n,2] float64, flags [n] uint8; bit0 = in mask,
+        bit1 = behind the camera)."""
+        pts3 = np.ascontiguousarray(pts3, np.float64).reshape(-1, 3)
+        cam_idx = np.ascontiguousarray(cam_idx, np.int32)
+        n = len(pts3)
+        uv, flags = np.zeros((max(n, 1), 2)), np.zeros(max(n, 1), np.uint8)
+        if n == 0:
+            return uv[:0], flags[:0]
+        nr = len(self.cams)
+        M = np.ascontiguousarray(np.stack(self.MtMc_inv).reshape(nr, 16))
+        ocs = (type(self.cams[0].ocam) * nr)(*[cm.ocam for cm in self.cams])
+        masks = [cm.GetMirrorMask(0) for cm in self.cams]
+        keep = [None if m is None else np.ascontiguousarray(m, np.uint8) for m in masks]
+        mp = (C.c_void_p * nr)(*[None if m is None else m.ctypes.data for m in keep])
+        ctx = ctx or default_context()
+        check(lib().mcs_world_to_cam(ctx.h, np_ptr(M), ocs, nr, mp if any(m is not None for m in keep) else None, np_ptr(pts3), np_ptr(cam_idx), n,
+                                     MEM_HOST, np_ptr(uv), np_ptr(flags)))
+        return uv[:n], flags[:n]
+
+    def WorldToCamHom_fast(self, c, pt3):   # src/cam_system_omni.cpp:114-133
+        uv, _ = self.world_to_cam(np.asarray(pt3, np.float64)[:3].reshape(1, 3), [c])
+        return uv[0]
 
     def GetNrCams(self):
         return len(self.cams)
@@ -262,10 +322,16 @@ class cORBmatcher:
         self.last_fallbacks = int(fb[0])
         return int(nm[0]), [mp1[i] if i >= 0 else None for i in mF[:F.totalN]]
 
-    def SearchByProjection(self, F, vpMapPoints, th):
+    def SearchByProjection(self, F, vpMapPoints, th, *rest):
         """int SearchByProjection(cMultiFrame &F, const vector<cMapPoint*> &vpMapPoints, const double th) (src/cORBmatcher.cpp:67-166).
         Map points carry what isInFrustum() left on them (src/cMultiFrame.cpp:218-270): mbTrackInView[cam], mTrackProjX/Y[cam],
-        mnTrackScaleLevel[cam], mTrackViewCos[cam], plus GetDescriptor()/GetDescriptorMask() (numpy rows).  Fills F.mvpMapPoints."""
+        mnTrackScaleLevel[cam], mTrackViewCos[cam], plus GetDescriptor()/GetDescriptorMask() (numpy rows).  Fills F.mvpMapPoints.
+        The reference's other overloads dispatch on the argument types like C++ would: (CurrentFrame, LastFrame, th) -> SearchByProjectionLast,
+        (F1, F2, windowSize, vpMapPointMatches2) -> SearchByProjectionFrames."""
+        if isinstance(vpMapPoints, cMultiFrame):
+            if rest:
+                return self.SearchByProjectionFrames(F, vpMapPoints, th, rest[0])
+            return self.SearchByProjectionLast(F, vpMapPoints, th)
         from ._capi import FrameView, ProjectionSet
         nr = F.camSystem.GetNrCams()
         owner, px, py, vc, lv, pc, dd, mm = [], [], [], [], [], [], [], []
@@ -304,6 +370,116 @@ class cORBmatcher:
             if j >= 0:
                 F.mvpMapPoints[int(j)] = owner[p]
         return int(nm[0])
+
+    # ------------------------------------------------------------------ grid-window searches other than (F, mapPoints)
+    def _frame_view(self, F, assigned):
+        from ._capi import FrameView
+        keys = np.ascontiguousarray(F.mvKeys)
+        fd = np.ascontiguousarray(F.all_descriptors(), np.uint8)
+        fm = np.ascontiguousarray(F.all_masks(), np.uint8) if self.havingMasks else None
+        fc = np.ascontiguousarray(F.keypoint_to_cam, np.int32)
+        w, h = np.ascontiguousarray(F.mnMaxX, np.int32), np.ascontiguousarray(F.mnMaxY, np.int32)
+        sc = np.ascontiguousarray(F.mvScaleFactors, np.float64)
+        fv = FrameView(np_ptr(keys), np_ptr(fd), np_ptr(fm), np_ptr(fc), np_ptr(assigned), F.totalN, self.mbFeatDim, F.camSystem.GetNrCams(), np_ptr(w),
+                       np_ptr(h), np_ptr(sc), len(sc))
+        return fv, (keys, fd, fm, fc, w, h, sc, assigned)
+
+    def _window_match(self, rule, x, y, r, lo, hi, cam, rows, F1, F2, assigned):
+        """probes (window centre / radius / level range / camera / descriptor row of F1) against frame F2 -> (match per probe, nmatches)"""
+        from ._capi import WindowProbes
+        n = len(rows)
+        if n == 0:
+            return np.zeros(0, np.int32), 0
+        x, y, r = (np.ascontiguousarray(v, np.float64) for v in (x, y, r))
+        lo, hi, cam = (np.ascontiguousarray(v, np.int32) for v in (lo, hi, cam))
+        rows = np.asarray(rows, np.int64)
+        dd = np.ascontiguousarray(F1.all_descriptors()[rows], np.uint8)
+        mm = np.ascontiguousarray(F1.all_masks()[rows], np.uint8) if self.havingMasks else None
+        pr = WindowProbes(np_ptr(x), np_ptr(y), np_ptr(r), np_ptr(lo), np_ptr(hi), np_ptr(cam), np_ptr(dd), np_ptr(mm), n, self.mbFeatDim)
+        fv, keep = self._frame_view(F2, assigned)
+        match = np.full(n, -1, np.int32)
+        nm = np.zeros(1, np.int32)
+        check(lib().mcs_window_match(self.ctx.h, C.byref(pr), C.byref(fv), rule, self.mfNNratio, self.mbFeatDim, MEM_HOST, np_ptr(match), np_ptr(nm)))
+        return match, int(nm[0])
+
+    def WindowSearch(self, F1, F2, windowSize, minScaleLevel=0, maxScaleLevel=2**31 - 1):
+        """-> (nmatches, vpMapPointMatches2) (src/cORBmatcher.cpp:326-473)."""
+        from ._capi import WINDOW_RATIO
+        rows = [i for i, mp in enumerate(F1.mvpMapPoints) if _good(mp) and not (minScaleLevel > 0 and F1.mvKeys[i]["octave"] < minScaleLevel)
+                and not (maxScaleLevel < 2**31 - 1 and F1.mvKeys[i]["octave"] > maxScaleLevel)]
+        k = F1.mvKeys[rows]
+        n = len(rows)
+        assigned = np.zeros(max(F2.totalN, 1), np.uint8)
+        match, nm = self._window_match(WINDOW_RATIO, k["x"].astype(np.float64), k["y"].astype(np.float64), np.full(n, float(windowSize)), np.full(n, -1),
+                                       np.full(n, -1), F1.keypoint_to_cam[rows], rows, F1, F2, assigned)
+        out = [None] * F2.totalN
+        self.last_matches21 = np.full(F2.totalN, -1, np.int32)
+        for p, j in enumerate(match):
+            if j >= 0:
+                out[int(j)] = F1.mvpMapPoints[rows[p]]
+                self.last_matches21[int(j)] = rows[p]
+        return nm, out
+
+    def SearchByProjectionFrames(self, F1, F2, windowSize, vpMapPointMatches2):
+        """int SearchByProjection(F1, F2, windowSize, vpMapPointMatches2) (src/cORBmatcher.cpp:476-577); the list is filled in place."""
+        from ._capi import WINDOW_RATIO
+        vpMapPointMatches2[:] = list(F2.mvpMapPoints)
+        found = set(id(m) for m in vpMapPointMatches2 if m is not None)
+        nr = F1.camSystem.GetNrCams()
+        seen, sel = set(), []
+        for i1, mp in enumerate(F1.mvpMapPoints):
+            if mp is None or (hasattr(mp, "isBad") and mp.isBad()) or id(mp) in found or id(mp) in seen:
+                continue
+            seen.add(id(mp))
+            sel.append(i1)
+        if not sel:
+            return 0
+        pts = np.repeat(np.stack([np.asarray(F1.mvpMapPoints[i].GetWorldPos(), np.float64)[:3] for i in sel]), nr, axis=0)
+        cams = np.tile(np.arange(nr, dtype=np.int32), len(sel))
+        uv, fl = F2.camSystem.world_to_cam(pts, cams, self.ctx)
+        ok = (fl & 1) != 0
+        rows = np.repeat(np.asarray(sel), nr)[ok]
+        lv = F1.mvKeys["octave"][rows]
+        n = len(rows)
+        assigned = np.array([m is not None for m in vpMapPointMatches2] + [0] * (F2.totalN == 0), np.uint8)
+        match, nm = self._window_match(WINDOW_RATIO, uv[ok, 0], uv[ok, 1], np.full(n, float(windowSize)), lv, lv, cams[ok], rows, F1, F2, assigned)
+        for p, j in enumerate(match):
+            if j >= 0:
+                vpMapPointMatches2[int(j)] = F1.mvpMapPoints[int(rows[p])]
+        return nm
+
+    def SearchByProjectionLast(self, CurrentFrame, LastFrame, th):
+        """int SearchByProjection(CurrentFrame, LastFrame, th) (src/cORBmatcher.cpp:1990-2118); fills CurrentFrame.mvpMapPoints."""
+        from ._capi import WINDOW_BEST
+        sel = [i for i, mp in enumerate(LastFrame.mvpMapPoints) if _good(mp) and not LastFrame.mvbOutlier[i]]
+        if not sel:
+            return 0
+        pts = np.stack([np.asarray(LastFrame.mvpMapPoints[i].GetWorldPos(), np.float64)[:3] for i in sel])
+        cams = np.ascontiguousarray(LastFrame.keypoint_to_cam[sel], np.int32)
+        uv, fl = CurrentFrame.camSystem.world_to_cam(pts, cams, self.ctx)
+        ok = (fl & 1) != 0
+        rows = np.asarray(sel)[ok]
+        octv = LastFrame.mvKeys["octave"][rows]
+        radius = float(th) * np.asarray(CurrentFrame.mvScaleFactors, np.float64)[octv]
+        assigned = np.array([m is not None for m in CurrentFrame.mvpMapPoints] + [0] * (CurrentFrame.totalN == 0), np.uint8)
+        match, nm = self._window_match(WINDOW_BEST, uv[ok, 0], uv[ok, 1], radius, octv - 1, octv + 1, cams[ok], rows, LastFrame, CurrentFrame, assigned)
+        for p, j in enumerate(match):
+            if j >= 0:
+                CurrentFrame.mvpMapPoints[int(j)] = LastFrame.mvpMapPoints[int(rows[p])]
+        return nm
+
+    def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize=10):
+        """-> (nmatches, vnMatches12); vbPrevMatched ([n1,2] float64) is updated in place (src/cORBmatcher.cpp:579-726)."""
+        from ._capi import WINDOW_INITIALIZE
+        n = F1.totalN
+        rows = np.arange(n)
+        lv = F1.mvKeys["octave"].astype(np.int32)
+        match, nm = self._window_match(WINDOW_INITIALIZE, vbPrevMatched[:, 0], vbPrevMatched[:, 1], np.full(n, float(windowSize)), lv, lv,
+                                       F1.keypoint_to_cam, rows, F1, F2, None)
+        for i1, j in enumerate(match):
+            if j >= 0:
+                vbPrevMatched[i1, 0], vbPrevMatched[i1, 1] = float(F2.mvKeys[int(j)]["x"]), float(F2.mvKeys[int(j)]["y"])
+        return nm, match
 
     def SearchForTriangulationRaw(self, pKF1, pKF2, Es):
         """-> (nmatches, vMatchedKeys1, vMatchedKeysRays1, vMatchedKeys2, vMatchedKeysRays2, vMatchedPairs) (:968-1155).

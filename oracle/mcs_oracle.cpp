@@ -27,6 +27,7 @@
 #include <cstring>
 #include <malloc.h>
 #include <list>
+#include <set>
 #include <utility>
 #include <vector>
 #ifdef _OPENMP
@@ -1117,6 +1118,301 @@ int orc_search_by_projection(const double* projx, const double* projy, const dou
 			match[p] = bestIdx;
 			++nmatches;
 		}
+	}
+	return nmatches;
+}
+
+// ---------------------------------------------------------------- "next" row: the other grid-window matchers of cTracking
+namespace {
+const int FRAME_GRID_ROWS_ = 48, FRAME_GRID_COLS_ = 64, HISTO_LENGTH_ = 30;
+
+struct FrameGrid {   // mGrids + GetFeaturesInArea of one cMultiFrame (src/cMultiFrame.cpp:167-184, 272-340, 342-353)
+	const orc_frame_view* f;
+	std::vector<std::vector<std::vector<std::vector<size_t> > > > grids;
+	std::vector<double> wInv, hInv;
+	explicit FrameGrid(const orc_frame_view* fv) : f(fv), grids(fv->nrCams), wInv(fv->nrCams), hInv(fv->nrCams) {
+		for (int c = 0; c < f->nrCams; ++c) {
+			grids[c].assign(FRAME_GRID_COLS_, std::vector<std::vector<size_t> >(FRAME_GRID_ROWS_));
+			wInv[c] = static_cast<double>(FRAME_GRID_COLS_) / static_cast<double>(f->width[c] - 0);
+			hInv[c] = static_cast<double>(FRAME_GRID_ROWS_) / static_cast<double>(f->height[c] - 0);
+		}
+		for (int i = 0; i < f->n; ++i) {
+			const int c = f->cam[i];
+			const int posX = cvRound_((f->keys[i].x - 0) * wInv[c]);
+			const int posY = cvRound_((f->keys[i].y - 0) * hInv[c]);
+			if (posX < 0 || posX >= FRAME_GRID_COLS_ || posY < 0 || posY >= FRAME_GRID_ROWS_) continue;
+			grids[c][posX][posY].push_back(i);
+		}
+	}
+	std::vector<size_t> GetFeaturesInArea(int cam, double x, double y, double r, int minLevel = -1, int maxLevel = -1) const {
+		std::vector<size_t> vIndices;
+		int nMinCellX = (int)floor((x - 0 - r) * wInv[cam]);
+		nMinCellX = std::max(0, nMinCellX);
+		if (nMinCellX >= FRAME_GRID_COLS_) return vIndices;
+		int nMaxCellX = (int)ceil((x - 0 + r) * wInv[cam]);
+		nMaxCellX = std::min(FRAME_GRID_COLS_ - 1, nMaxCellX);
+		if (nMaxCellX < 0) return vIndices;
+		int nMinCellY = (int)floor((y - 0 - r) * hInv[cam]);
+		nMinCellY = std::max(0, nMinCellY);
+		if (nMinCellY >= FRAME_GRID_ROWS_) return vIndices;
+		int nMaxCellY = (int)ceil((y - 0 + r) * hInv[cam]);
+		nMaxCellY = std::min(FRAME_GRID_ROWS_ - 1, nMaxCellY);
+		if (nMaxCellY < 0) return vIndices;
+		bool bCheckLevels = true, bSameLevel = false;
+		if (minLevel == -1 && maxLevel == -1) bCheckLevels = false;
+		else if (minLevel == maxLevel) bSameLevel = true;
+		for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
+			for (int iy = nMinCellY; iy <= nMaxCellY; ++iy) {
+				const std::vector<size_t>& vCell = grids[cam][ix][iy];
+				for (size_t j = 0; j < vCell.size(); ++j) {
+					const orc_keypoint& kpUn = f->keys[vCell[j]];
+					if (bCheckLevels && !bSameLevel) { if (kpUn.octave < minLevel || kpUn.octave > maxLevel) continue; }
+					else if (bSameLevel) { if (kpUn.octave != minLevel) continue; }
+					if (std::abs(kpUn.x - x) > r || std::abs(kpUn.y - y) > r) continue;
+					vIndices.push_back(vCell[j]);
+				}
+			}
+		return vIndices;
+	}
+};
+
+void ComputeThreeMaxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {  // src/cORBmatcher.cpp:2394-2436
+	int max1 = 0, max2 = 0, max3 = 0;
+	for (int i = 0; i < L; i++) {
+		const int s = (int)histo[i].size();
+		if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+		else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+		else if (s > max3) { max3 = s; ind3 = i; }
+	}
+	if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+	else if (max3 < 0.1f * (float)max1) ind3 = -1;
+}
+}  // namespace
+
+// cMultiCamSys_::WorldToCamHom_fast (src/cam_system_omni.cpp:92-133, flagMcMt branch: ptRot = MtMc_inv[c] * pt4) followed by
+// cCamModelGeneral_::isPointInMirrorMask(u, v, 0) (src/cam_model_omni.cpp:163-178).  cv::Matx product: s = 0; s += a(i,k)*b(k).
+// flags bit0 = inside the mirror mask (1 if no mask image is given and the rounded pixel is inside the bounds test), bit1 = z <= 0.
+void orc_world_to_cam(const double* MtMc_inv /* nrCams x 16 row-major */, const orc_ocam* cams, const uint8_t* const* mirrorMasks /* level 0, tight, or NULL */,
+                      const double* pts3 /* n x 3 */, const int* pcam, int n, double* uv /* n x 2 */, uint8_t* flags) {
+	for (int i = 0; i < n; ++i) {
+		const int c = pcam[i];
+		const double* M = MtMc_inv + 16 * (size_t)c;
+		const double pt4[4] = {pts3[3 * i], pts3[3 * i + 1], pts3[3 * i + 2], 1.0};
+		double ptRot[4];
+		for (int r = 0; r < 4; ++r) { double s = 0; for (int k = 0; k < 4; ++k) s += M[4 * r + k] * pt4[k]; ptRot[r] = s; }
+		double u = 0.0, v = 0.0;
+		orc_world2img(&cams[c], ptRot[0], ptRot[1], ptRot[2], &u, &v);
+		uv[2 * i] = u; uv[2 * i + 1] = v;
+		const int ur = cvRound_(u), vr = cvRound_(v);
+		uint8_t fl = 0;
+		if (!(ur >= cams[c].width || ur <= 0 || vr >= cams[c].height || vr <= 0)) {
+			if (!mirrorMasks || !mirrorMasks[c] || mirrorMasks[c][(size_t)vr * cams[c].width + ur] > 0) fl |= 1;
+		}
+		if (ptRot[2] <= 0.0) fl |= 2;
+		flags[i] = fl;
+	}
+}
+
+// cORBmatcher::WindowSearch (src/cORBmatcher.cpp:326-473).  hasMP1[i1] = F1.mvpMapPoints[i1] && !isBad().  maxScaleLevel < 0 means INT_MAX.
+// match21[i2] = i1 (vnMatches21 / the owner of vpMapPointMatches2[i2]) or -1.
+int orc_window_search(const orc_frame_view* F1, const uint8_t* hasMP1, const orc_frame_view* F2, int windowSize, int minScaleLevel, int maxScaleLevel,
+                      double nnratio, int dim, int havingMasks, int checkOri, int* match21) {
+	int TH_HIGH, TH_LOW;
+	orc_thresholds(dim, havingMasks, &TH_HIGH, &TH_LOW);
+	FrameGrid G2(F2);
+	int nmatches = 0;
+	for (int i = 0; i < F2->n; ++i) match21[i] = -1;
+	std::vector<int> rotHist[HISTO_LENGTH_];
+	const double factor = 1.0f / HISTO_LENGTH_;
+	const bool bMinLevel = minScaleLevel > 0;
+	const bool bMaxLevel = maxScaleLevel >= 0 && maxScaleLevel < INT_MAX;
+	for (int i1 = 0; i1 < F1->n; ++i1) {
+		if (!hasMP1[i1]) continue;
+		const orc_keypoint& kp1 = F1->keys[i1];
+		const int level1 = kp1.octave;
+		if (bMinLevel && level1 < minScaleLevel) continue;
+		if (bMaxLevel && level1 > maxScaleLevel) continue;
+		const int camIdx1 = F1->cam[i1];
+		std::vector<size_t> vIndices2 = G2.GetFeaturesInArea(camIdx1, kp1.x, kp1.y, windowSize);
+		if (vIndices2.empty()) continue;
+		int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+		for (size_t k = 0; k < vIndices2.size(); ++k) {
+			const size_t i2 = vIndices2[k];
+			if (match21[i2] >= 0) continue;
+			const int dist = dist_any(F1->desc, F1->mask, i1, F2->desc, F2->mask, (int)i2, dim, havingMasks);
+			if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+			else if (dist < bestDist2) bestDist2 = dist;
+		}
+		if (bestDist <= bestDist2 * nnratio && bestDist <= TH_HIGH) {
+			match21[bestIdx2] = i1;
+			nmatches++;
+			float rot = F1->keys[i1].angle - F2->keys[bestIdx2].angle;
+			if (rot < 0.0) rot += 360.0f;
+			int bin = cvRound_(rot * factor);
+			if (bin == HISTO_LENGTH_) bin = 0;
+			rotHist[bin].push_back(bestIdx2);
+		}
+	}
+	if (checkOri) {
+		int ind1 = -1, ind2 = -1, ind3 = -1;
+		ComputeThreeMaxima(rotHist, HISTO_LENGTH_, ind1, ind2, ind3);
+		for (int i = 0; i < HISTO_LENGTH_; ++i)
+			if (i != ind1 && i != ind2 && i != ind3)
+				for (size_t j = 0; j < rotHist[i].size(); ++j) { match21[rotHist[i][j]] = -1; --nmatches; }
+	}
+	return nmatches;
+}
+
+// cORBmatcher::SearchByProjection(F1, F2, windowSize, vpMapPointMatches2) (src/cORBmatcher.cpp:476-577).
+// mp1[i1] / mp2[i2]: map point id (>= 0) or -1 for NULL; bad1[i1] = isBad().  uv / inMask: [n1][nrCams] projections of F1's map points
+// into F2's cameras (WorldToCamHom_fast + isPointInMirrorMask, see orc_world_to_cam).  match21[i2] = i1 for the NEW matches, else -1.
+int orc_search_by_projection_frames(const orc_frame_view* F1, const int* mp1, const uint8_t* bad1, const orc_frame_view* F2, const int* mp2,
+                                    const double* uv, const uint8_t* inMask, int windowSize, double nnratio, int dim, int havingMasks, int* match21) {
+	int TH_HIGH, TH_LOW;
+	orc_thresholds(dim, havingMasks, &TH_HIGH, &TH_LOW);
+	FrameGrid G2(F2);
+	std::vector<char> taken(F2->n, 0);   // vpMapPointMatches2[i2] != NULL
+	std::set<int> spMapPointsAlreadyFound;
+	for (int i = 0; i < F2->n; ++i) { match21[i] = -1; taken[i] = mp2[i] >= 0; if (mp2[i] >= 0) spMapPointsAlreadyFound.insert(mp2[i]); }
+	int nmatches = 0;
+	std::set<int> mapPt_2_obs_idx;
+	const int nrCams = F1->nrCams;
+	for (int i1 = 0; i1 < F1->n; ++i1) {
+		const int pMP1 = mp1[i1];
+		if (pMP1 < 0) continue;
+		if (bad1[i1] || spMapPointsAlreadyFound.count(pMP1)) continue;
+		if (mapPt_2_obs_idx.count(pMP1) > 0) continue;
+		mapPt_2_obs_idx.insert(pMP1);
+		const int level1 = F1->keys[i1].octave;
+		for (int c = 0; c < nrCams; ++c) {
+			if (!inMask[(size_t)i1 * nrCams + c]) continue;
+			const double u = uv[2 * ((size_t)i1 * nrCams + c)], v = uv[2 * ((size_t)i1 * nrCams + c) + 1];
+			std::vector<size_t> vIndices2 = G2.GetFeaturesInArea(c, u, v, windowSize, level1, level1);
+			if (vIndices2.empty()) continue;
+			int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+			for (size_t k = 0; k < vIndices2.size(); ++k) {
+				const size_t i2 = vIndices2[k];
+				if (taken[i2]) continue;
+				const int dist = dist_any(F1->desc, F1->mask, i1, F2->desc, F2->mask, (int)i2, dim, havingMasks);
+				if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+				else if (dist < bestDist2) bestDist2 = dist;
+			}
+			if (static_cast<double>(bestDist) <= static_cast<double>(bestDist2) * nnratio && bestDist <= TH_HIGH) {
+				taken[bestIdx2] = 1;
+				match21[bestIdx2] = i1;
+				++nmatches;
+			}
+		}
+	}
+	return nmatches;
+}
+
+// cORBmatcher::SearchForInitialization (src/cORBmatcher.cpp:579-726).  prevMatched: [n1][2] in/out (vbPrevMatched).  match12[i1] = i2 or -1.
+int orc_search_for_initialization(const orc_frame_view* F1, const orc_frame_view* F2, double* prevMatched, int windowSize, double nnratio, int dim,
+                                  int havingMasks, int checkOri, int* match12) {
+	int TH_HIGH, TH_LOW;
+	orc_thresholds(dim, havingMasks, &TH_HIGH, &TH_LOW);
+	FrameGrid G2(F2);
+	int nmatches = 0;
+	for (int i = 0; i < F1->n; ++i) match12[i] = -1;
+	std::vector<int> rotHist[HISTO_LENGTH_];
+	const double factor = 1.0 / HISTO_LENGTH_;
+	std::vector<int> vMatchedDistance(F2->n, INT_MAX), vnMatches21(F2->n, -1);
+	for (int i1 = 0; i1 < F1->n; ++i1) {
+		const orc_keypoint kp1 = F1->keys[i1];
+		const int level1 = kp1.octave;
+		const int camIdx1 = F1->cam[i1];
+		std::vector<size_t> vIndices2 = G2.GetFeaturesInArea(camIdx1, prevMatched[2 * i1], prevMatched[2 * i1 + 1], windowSize, level1, level1);
+		if (vIndices2.empty()) continue;
+		int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+		for (size_t k = 0; k < vIndices2.size(); ++k) {
+			const size_t i2 = vIndices2[k];
+			const int dist = dist_any(F1->desc, F1->mask, i1, F2->desc, F2->mask, (int)i2, dim, havingMasks);
+			if (vMatchedDistance[i2] <= dist) continue;
+			if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+			else if (dist < bestDist2) bestDist2 = dist;
+		}
+		if (bestDist <= TH_LOW) {
+			if (bestDist < (double)bestDist2 * nnratio) {
+				if (vnMatches21[bestIdx2] >= 0) { match12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+				match12[i1] = bestIdx2;
+				vnMatches21[bestIdx2] = i1;
+				vMatchedDistance[bestIdx2] = bestDist;
+				nmatches++;
+				if (checkOri) {
+					float rot = F1->keys[i1].angle - F2->keys[bestIdx2].angle;
+					if (rot < 0.0) rot += 360.0f;
+					int bin = (int)round(rot * factor);
+					if (bin == HISTO_LENGTH_) bin = 0;
+					rotHist[bin].push_back(i1);
+				}
+			}
+		}
+	}
+	if (checkOri) {
+		int ind1 = -1, ind2 = -1, ind3 = -1;
+		ComputeThreeMaxima(rotHist, HISTO_LENGTH_, ind1, ind2, ind3);
+		for (int i = 0; i < HISTO_LENGTH_; i++) {
+			if (i == ind1 || i == ind2 || i == ind3) continue;
+			for (size_t j = 0; j < rotHist[i].size(); j++) {
+				const int idx1 = rotHist[i][j];
+				if (match12[idx1] >= 0) { match12[idx1] = -1; --nmatches; }
+			}
+		}
+	}
+	for (int i1 = 0; i1 < F1->n; ++i1)
+		if (match12[i1] >= 0) { prevMatched[2 * i1] = F2->keys[match12[i1]].x; prevMatched[2 * i1 + 1] = F2->keys[match12[i1]].y; }
+	return nmatches;
+}
+
+// cORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th) (src/cORBmatcher.cpp:1990-2118).  lastMP[i] = map point non-NULL && !isBad();
+// lastOutlier[i] = LastFrame.mvbOutlier[i]; uv / inMask: [nLast] projection of the map point into camera cam(i) of the CURRENT frame;
+// curAssigned[i2] = CurrentFrame.mvpMapPoints[i2] != NULL (updated in place); matchCur[i2] = index in Last of the NEW match, else -1.
+int orc_search_by_projection_last(const orc_frame_view* Cur, uint8_t* curAssigned, const orc_frame_view* Last, const uint8_t* lastMP, const uint8_t* lastOutlier,
+                                  const double* uv, const uint8_t* inMask, const double* scaleFactors, double th, int dim, int havingMasks, int checkOri,
+                                  int* matchCur) {
+	int TH_HIGH, TH_LOW;
+	orc_thresholds(dim, havingMasks, &TH_HIGH, &TH_LOW);
+	FrameGrid G(Cur);
+	int nmatches = 0;
+	for (int i = 0; i < Cur->n; ++i) matchCur[i] = -1;
+	std::vector<int> rotHist[HISTO_LENGTH_];
+	const float factor = 1.0f / HISTO_LENGTH_;
+	for (int i = 0; i < Last->n; ++i) {
+		if (!lastMP[i]) continue;
+		const int cam = Last->cam[i];
+		if (lastOutlier[i]) continue;
+		if (!inMask[i]) continue;
+		const int nPredictedOctave = Last->keys[i].octave;
+		const double radius = th * scaleFactors[nPredictedOctave];
+		std::vector<size_t> vIndices2 = G.GetFeaturesInArea(cam, uv[2 * i], uv[2 * i + 1], radius, nPredictedOctave - 1, nPredictedOctave + 1);
+		if (vIndices2.empty()) continue;
+		int bestDist = INT_MAX, bestIdx2 = -1;
+		for (size_t k = 0; k < vIndices2.size(); ++k) {
+			const size_t i2 = vIndices2[k];
+			if (curAssigned[i2]) continue;
+			const int dist = dist_any(Last->desc, Last->mask, i, Cur->desc, Cur->mask, (int)i2, dim, havingMasks);
+			if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+		}
+		if (bestDist <= TH_HIGH) {
+			curAssigned[bestIdx2] = 1;
+			matchCur[bestIdx2] = i;
+			++nmatches;
+			if (checkOri) {
+				float rot = Last->keys[i].angle - Cur->keys[bestIdx2].angle;
+				if (rot < 0.0) rot += 360.0f;
+				int bin = cvRoundf_(rot * factor);
+				if (bin == HISTO_LENGTH_) bin = 0;
+				rotHist[bin].push_back(bestIdx2);
+			}
+		}
+	}
+	if (checkOri) {
+		int ind1 = -1, ind2 = -1, ind3 = -1;
+		ComputeThreeMaxima(rotHist, HISTO_LENGTH_, ind1, ind2, ind3);
+		for (int i = 0; i < HISTO_LENGTH_; i++)
+			if (i != ind1 && i != ind2 && i != ind3)
+				for (size_t j = 0; j < rotHist[i].size(); j++) { curAssigned[rotHist[i][j]] = 0; matchCur[rotHist[i][j]] = -1; --nmatches; }
 	}
 	return nmatches;
 }

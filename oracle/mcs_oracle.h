@@ -105,6 +105,24 @@ int orc_search_by_projection(const double* projx, const double* projy, const dou
                              const int* width, const int* height, int nrCams, const double* scaleFactors, int nlevels,
                              double th, double nnratio, int dim, int havingMasks, int* match);
 
+/* "next" row, the remaining grid-window matchers (src/cORBmatcher.cpp:326-726, 1990-2118) + the projection they consume
+ * (src/cam_system_omni.cpp:92-133, src/cam_model_omni.cpp:163-178).  A frame view = the flat (all cameras) per-feature arrays. */
+typedef struct orc_frame_view {
+	const orc_keypoint* keys; const uint8_t* desc; const uint8_t* mask; const int32_t* cam; int32_t n; int32_t nrCams;
+	const int32_t* width; const int32_t* height;
+} orc_frame_view;
+void orc_world_to_cam(const double* MtMc_inv, const orc_ocam* cams, const uint8_t* const* mirrorMasks, const double* pts3, const int* pcam, int n,
+                      double* uv, uint8_t* flags);
+int orc_window_search(const orc_frame_view* F1, const uint8_t* hasMP1, const orc_frame_view* F2, int windowSize, int minScaleLevel, int maxScaleLevel,
+                      double nnratio, int dim, int havingMasks, int checkOri, int* match21);
+int orc_search_by_projection_frames(const orc_frame_view* F1, const int* mp1, const uint8_t* bad1, const orc_frame_view* F2, const int* mp2,
+                                    const double* uv, const uint8_t* inMask, int windowSize, double nnratio, int dim, int havingMasks, int* match21);
+int orc_search_for_initialization(const orc_frame_view* F1, const orc_frame_view* F2, double* prevMatched, int windowSize, double nnratio, int dim,
+                                  int havingMasks, int checkOri, int* match12);
+int orc_search_by_projection_last(const orc_frame_view* Cur, uint8_t* curAssigned, const orc_frame_view* Last, const uint8_t* lastMP,
+                                  const uint8_t* lastOutlier, const double* uv, const uint8_t* inMask, const double* scaleFactors, double th, int dim,
+                                  int havingMasks, int checkOri, int* matchCur);
+
 /* ---- timed CPU baseline helper: extract nimg images (OpenMP over images), returns total keypoints ---- */
 long orc_extract_many(const orc_params* p, int nimg, const uint8_t* const* imgs, int w, int h, int stride,
                       const uint8_t* const* masks, const orc_ocam* cams, int threads,

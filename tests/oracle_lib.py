@@ -206,3 +206,80 @@ def search_by_projection(px, py, vc, lv, pc, pd, pm, keys, fd, fm, fc, assigned,
                                    ptr(assigned), len(keys), ptr(width), ptr(height), len(width), ptr(scales), len(scales), th, ratio, pd.shape[1],
                                    int(masks), ptr(match))
     return n, match
+
+
+# ---- "next" row: grid-window matchers + projection (oracle/mcs_oracle.h: orc_frame_view ...)
+class FrameViewO(C.Structure):
+    _fields_ = [("keys", C.c_void_p), ("desc", C.c_void_p), ("mask", C.c_void_p), ("cam", C.c_void_p), ("n", C.c_int32), ("nrCams", C.c_int32),
+                ("width", C.c_void_p), ("height", C.c_void_p)]
+
+
+def frame_view(keys, desc, mask, cam, width, height):
+    """-> (FrameViewO, keepalive).  keys: KP_DTYPE array; desc/mask: [n, dim] uint8 (mask may be None); cam: int32 [n]."""
+    keep = [np.ascontiguousarray(keys), np.ascontiguousarray(desc, np.uint8), None if mask is None else np.ascontiguousarray(mask, np.uint8),
+            np.ascontiguousarray(cam, np.int32), np.ascontiguousarray(width, np.int32), np.ascontiguousarray(height, np.int32)]
+    fv = FrameViewO(ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), len(keep[0]), len(keep[4]), ptr(keep[4]), ptr(keep[5]))
+    return fv, keep
+
+
+def world_to_cam(MtMc_inv, cams, masks, pts3, pcam):
+    L = lib()
+    L.orc_world_to_cam.restype = None
+    L.orc_world_to_cam.argtypes = [C.c_void_p, C.POINTER(Ocam), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    nr = len(cams)
+    M = np.ascontiguousarray(np.asarray(MtMc_inv, np.float64).reshape(nr, 16))
+    ocs = (Ocam * nr)(*[make_ocam(c) for c in cams])
+    keep = [None if m is None else np.ascontiguousarray(m, np.uint8) for m in (masks or [None] * nr)]
+    mp = (C.c_void_p * nr)(*[None if m is None else m.ctypes.data for m in keep])
+    pts3 = np.ascontiguousarray(pts3, np.float64).reshape(-1, 3)
+    pcam = np.ascontiguousarray(pcam, np.int32)
+    n = len(pts3)
+    uv, fl = np.zeros((max(n, 1), 2)), np.zeros(max(n, 1), np.uint8)
+    L.orc_world_to_cam(ptr(M), ocs, mp if masks else None, ptr(pts3), ptr(pcam), n, ptr(uv), ptr(fl))
+    return uv[:n], fl[:n]
+
+
+def window_search(F1, hasMP1, F2, windowSize, minLevel, maxLevel, ratio, dim, masks, checkOri=0):
+    L = lib()
+    L.orc_window_search.argtypes = [C.POINTER(FrameViewO), C.c_void_p, C.POINTER(FrameViewO), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p]
+    hasMP1 = np.ascontiguousarray(hasMP1, np.uint8)
+    m21 = np.full(max(F2.n, 1), -1, np.int32)
+    n = L.orc_window_search(C.byref(F1), ptr(hasMP1), C.byref(F2), windowSize, minLevel, maxLevel, ratio, dim, int(masks), checkOri, ptr(m21))
+    return n, m21[:F2.n]
+
+
+def search_by_projection_frames(F1, mp1, bad1, F2, mp2, uv, inMask, windowSize, ratio, dim, masks):
+    L = lib()
+    L.orc_search_by_projection_frames.argtypes = [C.POINTER(FrameViewO), C.c_void_p, C.c_void_p, C.POINTER(FrameViewO), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p]
+    mp1, mp2 = np.ascontiguousarray(mp1, np.int32), np.ascontiguousarray(mp2, np.int32)
+    bad1, inMask = np.ascontiguousarray(bad1, np.uint8), np.ascontiguousarray(inMask, np.uint8)
+    uv = np.ascontiguousarray(uv, np.float64)
+    m21 = np.full(max(F2.n, 1), -1, np.int32)
+    n = L.orc_search_by_projection_frames(C.byref(F1), ptr(mp1), ptr(bad1), C.byref(F2), ptr(mp2), ptr(uv), ptr(inMask), windowSize, ratio, dim, int(masks),
+                                          ptr(m21))
+    return n, m21[:F2.n]
+
+
+def search_for_initialization(F1, F2, prevMatched, windowSize, ratio, dim, masks, checkOri=0):
+    L = lib()
+    L.orc_search_for_initialization.argtypes = [C.POINTER(FrameViewO), C.POINTER(FrameViewO), C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                                C.c_void_p]
+    pm = np.ascontiguousarray(prevMatched, np.float64).copy()
+    m12 = np.full(max(F1.n, 1), -1, np.int32)
+    n = L.orc_search_for_initialization(C.byref(F1), C.byref(F2), ptr(pm), windowSize, ratio, dim, int(masks), checkOri, ptr(m12))
+    return n, m12[:F1.n], pm
+
+
+def search_by_projection_last(Cur, curAssigned, Last, lastMP, lastOutlier, uv, inMask, scales, th, dim, masks, checkOri=0):
+    L = lib()
+    L.orc_search_by_projection_last.argtypes = [C.POINTER(FrameViewO), C.c_void_p, C.POINTER(FrameViewO), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    ca = np.ascontiguousarray(curAssigned, np.uint8).copy()
+    lastMP, lastOutlier, inMask = (np.ascontiguousarray(v, np.uint8) for v in (lastMP, lastOutlier, inMask))
+    uv, scales = np.ascontiguousarray(uv, np.float64), np.ascontiguousarray(scales, np.float64)
+    mc = np.full(max(Cur.n, 1), -1, np.int32)
+    n = L.orc_search_by_projection_last(C.byref(Cur), ptr(ca), C.byref(Last), ptr(lastMP), ptr(lastOutlier), ptr(uv), ptr(inMask), ptr(scales), th, dim,
+                                        int(masks), checkOri, ptr(mc))
+    return n, mc[:Cur.n], ca
