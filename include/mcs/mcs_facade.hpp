@@ -169,7 +169,84 @@ public:
 		return n;
 	}
 
+	// ---- grid-window searches (src/cORBmatcher.cpp:326-726, 1990-2118).  A FrameGridView is the flat cMultiFrame the windows are opened in.
+	struct FrameGridView {
+		const KeyPoint* mvKeys = nullptr; const uint8_t* descriptors = nullptr; const uint8_t* masks = nullptr;
+		std::vector<int32_t> keypoint_to_cam; std::vector<uint8_t> hasMapPoint;   // hasMapPoint[i] = mvpMapPoints[i] != NULL (updated by the searches)
+		std::vector<int32_t> width, height; std::vector<double> mvScaleFactors; int n = 0;
+	};
+	// WindowSearch(F1, F2, windowSize, vpMapPointMatches2, minScaleLevel, maxScaleLevel): good1[i1] = map point non-NULL && !isBad();
+	// vnMatches21[i2] = i1 or -1.  (:326-473)
+	int WindowSearch(const FrameGridView& F1, const std::vector<uint8_t>& good1, FrameGridView& F2, int windowSize, std::vector<int>& vnMatches21,
+	                 int minScaleLevel = 0, int maxScaleLevel = INT32_MAX) {
+		Probes p;
+		for (int i1 = 0; i1 < F1.n; ++i1) {
+			const int lvl = F1.mvKeys[i1].octave;
+			if (!good1[i1] || (minScaleLevel > 0 && lvl < minScaleLevel) || (maxScaleLevel < INT32_MAX && lvl > maxScaleLevel)) continue;
+			p.add(F1.mvKeys[i1].ptx, F1.mvKeys[i1].pty, windowSize, -1, -1, F1.keypoint_to_cam[i1], i1);
+		}
+		std::vector<uint8_t> none(F2.n > 0 ? F2.n : 1, 0);   // vpMapPointMatches2 starts all-NULL
+		std::swap(none, F2.hasMapPoint);
+		std::vector<int> m;
+		const int nm = window(MCS_WINDOW_RATIO, p, F1, F2, m);
+		std::swap(none, F2.hasMapPoint);
+		vnMatches21.assign(F2.n, -1);
+		for (size_t k = 0; k < m.size(); ++k) if (m[k] >= 0) vnMatches21[m[k]] = p.src[k];
+		return nm;
+	}
+	// SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize): vbPrevMatched = 2 doubles per F1 feature, updated.  (:579-726)
+	int SearchForInitialization(const FrameGridView& F1, FrameGridView& F2, std::vector<double>& vbPrevMatched, std::vector<int>& vnMatches12,
+	                            int windowSize = 10) {
+		Probes p;
+		for (int i1 = 0; i1 < F1.n; ++i1)
+			p.add(vbPrevMatched[2 * i1], vbPrevMatched[2 * i1 + 1], windowSize, F1.mvKeys[i1].octave, F1.mvKeys[i1].octave, F1.keypoint_to_cam[i1], i1);
+		const int nm = window(MCS_WINDOW_INITIALIZE, p, F1, F2, vnMatches12);
+		vnMatches12.resize(F1.n);
+		for (int i1 = 0; i1 < F1.n; ++i1)
+			if (vnMatches12[i1] >= 0) { vbPrevMatched[2 * i1] = F2.mvKeys[vnMatches12[i1]].ptx; vbPrevMatched[2 * i1 + 1] = F2.mvKeys[vnMatches12[i1]].pty; }
+		return nm;
+	}
+	// SearchByProjection(CurrentFrame, LastFrame, th): search1[i] = map point good && !mvbOutlier[i] && projection inside the mirror mask;
+	// uv = the projections (mcs_world_to_cam).  matchCur[i2] = index in LastFrame or -1; CurrentFrame.hasMapPoint is updated.  (:1990-2118)
+	int SearchByProjection(FrameGridView& CurrentFrame, const FrameGridView& LastFrame, const std::vector<uint8_t>& search1, const double* uv, double th,
+	                       std::vector<int>& matchCur) {
+		Probes p;
+		for (int i = 0; i < LastFrame.n; ++i) {
+			if (!search1[i]) continue;
+			const int o = LastFrame.mvKeys[i].octave;
+			p.add(uv[2 * i], uv[2 * i + 1], th * CurrentFrame.mvScaleFactors[o], o - 1, o + 1, LastFrame.keypoint_to_cam[i], i);
+		}
+		std::vector<int> m;
+		const int nm = window(MCS_WINDOW_BEST, p, LastFrame, CurrentFrame, m);
+		matchCur.assign(CurrentFrame.n, -1);
+		for (size_t k = 0; k < m.size(); ++k) if (m[k] >= 0) matchCur[m[k]] = p.src[k];
+		return nm;
+	}
+
 private:
+	struct Probes {
+		std::vector<double> x, y, r; std::vector<int32_t> lo, hi, cam, src;
+		void add(double x_, double y_, double r_, int lo_, int hi_, int cam_, int src_) {
+			x.push_back(x_); y.push_back(y_); r.push_back(r_); lo.push_back(lo_); hi.push_back(hi_); cam.push_back(cam_); src.push_back(src_);
+		}
+	};
+	int window(mcs_window_rule rule, const Probes& p, const FrameGridView& from, FrameGridView& in, std::vector<int>& match) {
+		const int n = (int)p.x.size();
+		std::vector<uint8_t> d((size_t)(n > 0 ? n : 1) * mbFeatDim), m(havingMasks ? d.size() : 0);
+		for (int k = 0; k < n; ++k) {
+			std::memcpy(&d[(size_t)k * mbFeatDim], from.descriptors + (size_t)p.src[k] * mbFeatDim, mbFeatDim);
+			if (havingMasks) std::memcpy(&m[(size_t)k * mbFeatDim], from.masks + (size_t)p.src[k] * mbFeatDim, mbFeatDim);
+		}
+		mcs_window_probes pr{p.x.data(), p.y.data(), p.r.data(), p.lo.data(), p.hi.data(), p.cam.data(), d.data(), havingMasks ? m.data() : nullptr, n, mbFeatDim};
+		mcs_frame_view fv{reinterpret_cast<const mcs_keypoint*>(in.mvKeys), in.descriptors, havingMasks ? in.masks : nullptr, in.keypoint_to_cam.data(),
+		                  rule == MCS_WINDOW_INITIALIZE ? nullptr : in.hasMapPoint.data(), in.n, mbFeatDim, (int32_t)in.width.size(), in.width.data(),
+		                  in.height.data(), in.mvScaleFactors.data(), (int32_t)in.mvScaleFactors.size()};
+		match.assign(n > 0 ? n : 1, -1);
+		int32_t nm = 0;
+		mcs_throw(mcs_window_match(ctx_.h, &pr, &fv, rule, mfNNratio, mbFeatDim, MCS_MEM_HOST, match.data(), &nm));
+		match.resize(n);
+		return nm;
+	}
 	int run(int mode, const FeatureSetView& a, const FeatureSetView& b, const double* E, int nrCams, std::vector<int>& out, int outN) {
 		mcs_desc_set q{a.descriptors, havingMasks ? a.masks : nullptr, a.flag.empty() ? nullptr : a.flag.data(), mode == 2 ? a.cam.data() : nullptr, a.n, mbFeatDim};
 		mcs_desc_set t{b.descriptors, havingMasks ? b.masks : nullptr, (mode == 1 || b.flag.empty()) ? nullptr : b.flag.data(), mode == 2 ? b.cam.data() : nullptr, b.n, mbFeatDim};
