@@ -193,6 +193,14 @@ int mcs_window_match(mcs_ctx*, const mcs_window_probes* probes, const mcs_frame_
 int mcs_world_to_cam(mcs_ctx*, const double* MtMc_inv, const mcs_ocam* cams, int nr_cams, const uint8_t* const* mirror_masks,
                      const double* pts3, const int32_t* cam, int n, mcs_mem_kind kind, double* uv, uint8_t* flags);
 
+/* void cMapPoint::ComputeDistinctiveDescriptors(bool havingMasks) (src/cMapPoint.cpp:294-382) for a batch of map points.
+ * desc / mask: the observed descriptors (+ masks, or NULL) of all map points, row-major, `stride` bytes per row; map point k owns rows
+ * offsets[k] .. offsets[k+1]-1 in the order the reference's loop collects them (keyframe, then observation).  best_idx[k] = the row
+ * (relative to offsets[k]) whose descriptor becomes mDescriptor: least median distance to the later rows, first one on ties,
+ * 0 for N <= 2, -1 for N = 0 (the reference returns early and keeps the old descriptor).  Rows per map point <= 65535. */
+int mcs_distinctive_descriptors(mcs_ctx*, const uint8_t* desc, const uint8_t* mask, int stride, int dim, const int32_t* offsets, int npoints,
+                                mcs_mem_kind kind, int32_t* best_idx);
+
 /* device helper: valid[i*cap + k] = (k < nkp[i]) for the row layout produced by mcs_extract_batch (all pointers on the GPU) */
 int mcs_rows_valid(mcs_ctx*, const int32_t* nkp_dev, int nimg, int cap, uint8_t* valid_dev);
 

@@ -147,3 +147,40 @@ int mcs_world_to_cam(mcs_ctx* c, const double* MtMc_inv, const mcs_ocam* cams, i
 	}
 	return done(MCS_OK);
 }
+
+int mcs_distinctive_descriptors(mcs_ctx* c, const uint8_t* desc, const uint8_t* mask, int stride, int dim, const int32_t* offsets, int npoints,
+                                mcs_mem_kind kind, int32_t* best_idx) {
+	if (!c || !desc || !offsets || !best_idx) return fail(MCS_ERR_INVALID, "null argument");
+	if (dim != 16 && dim != 32 && dim != 64) return fail(MCS_ERR_INVALID, "dim must be 16, 32 or 64");
+	if (stride < dim || (stride & 3) || npoints < 0) return fail(MCS_ERR_INVALID, "bad stride / count");
+	if (npoints == 0) return MCS_OK;
+	HIPCHK(hipSetDevice(c->device));
+	hipStream_t s = c->stream;
+	const bool host = kind == MCS_MEM_HOST;
+	DistinctArgs a{};
+	a.stride = stride; a.dim = dim; a.npoints = npoints;
+	if (!host) {   // offsets are validated by the caller in this mode
+		a.desc = desc; a.mask = mask; a.offsets = offsets; a.bestIdx = best_idx;
+		launch_distinct(a, s);
+		HIPCHK(hipGetLastError());
+		return MCS_OK;
+	}
+	if (offsets[0] != 0) return fail(MCS_ERR_INVALID, "offsets[0] must be 0");
+	for (int k = 0; k < npoints; ++k)
+		if (offsets[k + 1] < offsets[k] || offsets[k + 1] - offsets[k] > 65535) return fail(MCS_ERR_INVALID, "offsets must be non-decreasing, <= 65535 rows per map point");
+	const size_t rows = (size_t)offsets[npoints];
+	Arena ar;
+	const size_t iD = ar.add(rows * stride), iM = ar.add(mask ? rows * stride : 0), iO = ar.add(((size_t)npoints + 1) * 4), iB = ar.add((size_t)npoints * 4);
+	HIPCHK(ar.alloc());
+	auto done = [&](int rc) { (void)hipStreamSynchronize(s); return rc; };
+#define UP(id, src, bytes) do { if ((bytes) && hipMemcpyAsync(ar.at(id), (src), (bytes), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "H2D copy failed")); } while (0)
+	UP(iD, desc, rows * stride);
+	if (mask) UP(iM, mask, rows * stride);
+	UP(iO, offsets, ((size_t)npoints + 1) * 4);
+#undef UP
+	a.desc = ar.at(iD); a.mask = mask ? ar.at(iM) : nullptr; a.offsets = (const int*)ar.at(iO); a.bestIdx = (int*)ar.at(iB);
+	launch_distinct(a, s);
+	if (hipGetLastError() != hipSuccess) return done(fail(MCS_ERR_HIP, "k_distinct failed to launch"));
+	if (hipMemcpyAsync(best_idx, ar.at(iB), (size_t)npoints * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
+	return done(MCS_OK);
+}

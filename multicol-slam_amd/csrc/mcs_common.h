@@ -158,4 +158,11 @@ struct WorldToCamArgs {   // cMultiCamSys_::WorldToCamHom_fast + isPointInMirror
 };
 void launch_world_to_cam(const WorldToCamArgs& a, hipStream_t s);
 
+struct DistinctArgs {   // cMapPoint::ComputeDistinctiveDescriptors for a batch of map points (mcs_distinct.hip)
+	const uint8_t* desc; const uint8_t* mask; int stride; int dim;
+	const int* offsets;   // [npoints + 1] CSR row offsets of the observations of each map point
+	int npoints; int* bestIdx;
+};
+void launch_distinct(const DistinctArgs& a, hipStream_t s);
+
 }  // namespace mcs

@@ -512,3 +512,81 @@ def DescriptorDistance64(descr_i, descr_j, dim=32, ctx=None):
 def DescriptorDistance64Masked(descr_i, descr_j, mask_i, mask_j, dim=32, ctx=None):
     f = lambda a: np.frombuffer(a, np.uint8)[:dim]
     return (ctx or default_context()).descriptor_distance(f(descr_i), f(descr_j), f(mask_i), f(mask_j))
+
+
+def ComputeDistinctiveDescriptorsBatch(observed, dim=32, ctx=None):
+    """cMapPoint::ComputeDistinctiveDescriptors (src/cMapPoint.cpp:294-382) for many map points in one device call.
+    observed: one (descriptors [N_k, dim] uint8, masks [N_k, dim] uint8 or None) pair per map point, rows in the order the reference's loop
+    collects them.  -> int32 array, the chosen row per map point (-1 where N_k == 0: the reference keeps the old descriptor)."""
+    n = len(observed)
+    if n == 0:
+        return np.zeros(0, np.int32)
+    having = observed[0][1] is not None
+    counts = [len(d) for d, _ in observed]
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum(counts)
+    rows = int(off[-1])
+    dd = np.zeros((max(rows, 1), dim), np.uint8)
+    mm = np.zeros((max(rows, 1), dim), np.uint8) if having else None
+    for k, (d, m) in enumerate(observed):
+        if counts[k]:
+            dd[off[k]:off[k + 1]] = d
+            if having:
+                mm[off[k]:off[k + 1]] = m
+    best = np.full(n, -1, np.int32)
+    ctx = ctx or default_context()
+    check(lib().mcs_distinctive_descriptors(ctx.h, np_ptr(dd), np_ptr(mm), dim, dim, np_ptr(off), n, MEM_HOST, np_ptr(best)))
+    return best
+
+
+class cMapPoint:
+    """The descriptor side of cMapPoint (include/cMapPoint.h): observations -> representative descriptor (+ mask)."""
+
+    def __init__(self, Pos=None, ctx=None):
+        self.mWorldPos = None if Pos is None else np.asarray(Pos, np.float64)
+        self.mObservations = []          # [(keyframe, [feature indices])] in insertion order (the reference's std::map orders by POINTER)
+        self.mDescriptor = self.mDescriptorMask = None
+        self.mbBad = False
+        self.ctx = ctx
+
+    def isBad(self):
+        return self.mbBad
+
+    def GetWorldPos(self):
+        return self.mWorldPos
+
+    def AddObservation(self, pKF, idx):
+        for kf, lst in self.mObservations:
+            if kf is pKF:
+                lst.append(int(idx))
+                return
+        self.mObservations.append((pKF, [int(idx)]))
+
+    def _observed(self, havingMasks):
+        d, m = [], []
+        for kf, lst in self.mObservations:
+            if hasattr(kf, "isBad") and kf.isBad():
+                continue
+            for l in lst:
+                d.append(kf._d[l])
+                if havingMasks:
+                    m.append(kf._m[l])
+        dim = d[0].shape[0] if d else 32
+        return (np.stack(d) if d else np.zeros((0, dim), np.uint8)), ((np.stack(m) if m else np.zeros((0, dim), np.uint8)) if havingMasks else None)
+
+    def ComputeDistinctiveDescriptors(self, havingMasks):
+        if self.mbBad or not self.mObservations:
+            return
+        d, m = self._observed(havingMasks)
+        if len(d) == 0:
+            return
+        b = int(ComputeDistinctiveDescriptorsBatch([(d, m)], d.shape[1], self.ctx)[0])
+        self.mDescriptor = d[b].copy()
+        if havingMasks:
+            self.mDescriptorMask = m[b].copy()
+
+    def GetDescriptor(self):
+        return self.mDescriptor
+
+    def GetDescriptorMask(self):
+        return self.mDescriptorMask

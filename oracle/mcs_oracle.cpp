@@ -1417,6 +1417,32 @@ int orc_search_by_projection_last(const orc_frame_view* Cur, uint8_t* curAssigne
 	return nmatches;
 }
 
+// ---------------------------------------------------------------- "next" row 3: cMapPoint::ComputeDistinctiveDescriptors
+// src/cMapPoint.cpp:294-382 with median() of include/misc.h:95-104 (nth_element at size/2).  desc/mask: the N observed descriptors
+// in the order the reference's loop pushed them (its std::map is keyed by keyframe POINTER, so that order is the caller's to define).
+// Quirks kept: the median of row i only covers j > i, the last row is never a candidate, N <= 2 -> index 0.  Returns BestIdx.
+int orc_distinctive_descriptor(const uint8_t* desc, const uint8_t* mask, int N, int dim, int havingMasks) {
+	if (N <= 0) return -1;
+	std::vector<int> Distances((size_t)N * N, 0);
+	for (int i = 0; i < N; ++i)
+		for (int j = i + 1; j < N; ++j) {
+			const int distij = dist_any(desc, mask, i, desc, mask, j, dim, havingMasks);
+			Distances[(size_t)i * N + j] = distij;
+			Distances[(size_t)j * N + i] = distij;
+		}
+	int BestMedian = INT_MAX, BestIdx = 0;
+	if (N > 2) {
+		for (int i = 0; i < N - 1; ++i) {
+			std::vector<int> vDists;
+			for (int j = i + 1; j < N; ++j) vDists.push_back(Distances[(size_t)i * N + j]);
+			std::nth_element(vDists.begin(), vDists.begin() + vDists.size() / 2, vDists.end());
+			const int medianV = vDists[vDists.size() / 2];
+			if (medianV < BestMedian) { BestMedian = medianV; BestIdx = i; }
+		}
+	} else BestIdx = 0;
+	return BestIdx;
+}
+
 // ---------------------------------------------------------------- CPU baseline helper
 int orc_num_threads(void) {
 #ifdef _OPENMP

@@ -123,6 +123,9 @@ int orc_search_by_projection_last(const orc_frame_view* Cur, uint8_t* curAssigne
                                   const uint8_t* lastOutlier, const double* uv, const uint8_t* inMask, const double* scaleFactors, double th, int dim,
                                   int havingMasks, int checkOri, int* matchCur);
 
+/* "next" row 3: cMapPoint::ComputeDistinctiveDescriptors (src/cMapPoint.cpp:294-382): index of the chosen observation */
+int orc_distinctive_descriptor(const uint8_t* desc, const uint8_t* mask, int N, int dim, int havingMasks);
+
 /* ---- timed CPU baseline helper: extract nimg images (OpenMP over images), returns total keypoints ---- */
 long orc_extract_many(const orc_params* p, int nimg, const uint8_t* const* imgs, int w, int h, int stride,
                       const uint8_t* const* masks, const orc_ocam* cams, int threads,

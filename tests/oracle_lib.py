@@ -283,3 +283,14 @@ def search_by_projection_last(Cur, curAssigned, Last, lastMP, lastOutlier, uv, i
     n = L.orc_search_by_projection_last(C.byref(Cur), ptr(ca), C.byref(Last), ptr(lastMP), ptr(lastOutlier), ptr(uv), ptr(inMask), ptr(scales), th, dim,
                                         int(masks), checkOri, ptr(mc))
     return n, mc[:Cur.n], ca
+
+
+def distinctive_descriptor(desc, mask):
+    """oracle cMapPoint::ComputeDistinctiveDescriptors: index of the chosen row (-1 for no rows)"""
+    L = lib()
+    L.orc_distinctive_descriptor.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    desc = np.ascontiguousarray(desc, np.uint8)
+    mask = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    if len(desc) == 0:
+        return -1
+    return L.orc_distinctive_descriptor(ptr(desc), ptr(mask), len(desc), desc.shape[1], int(mask is not None))
