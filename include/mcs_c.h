@@ -185,6 +185,18 @@ typedef enum { MCS_WINDOW_RATIO = 1, MCS_WINDOW_BEST = 2, MCS_WINDOW_INITIALIZE 
 int mcs_window_match(mcs_ctx*, const mcs_window_probes* probes, const mcs_frame_view* frame, mcs_window_rule rule, double nnratio, int dim,
                      mcs_mem_kind kind, int32_t* match, int32_t* nmatches);
 
+/* Best feature per probe with a caller-given distance threshold — the search loops of the mapping / loop-closing matchers, whose
+ * surrounding map-point surgery stays on the host:
+ *   skip_taken = 0  every probe independently: cORBmatcher::Fuse (three overloads, :1265-1719; accept <= TH_LOW), SearchBySim3 (:1721-1988,
+ *                   both directions, <= TH_HIGH), SearchForTriangulationBetweenCameras (:1158-1263, <= 100), SearchByProjection(pKF, Scw, ...)
+ *                   (:2265-2392).  Their "kpLevel < nPredictedLevel-1 || kpLevel > nPredictedLevel" filter is the probe's level range.
+ *   skip_taken = 1  in probe order, features with frame->assigned set are skipped and an accepted feature becomes assigned:
+ *                   SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:2120-2263, accept <= ORBdist).
+ * match[p] = feature index with the smallest distance (first in GetFeaturesInArea order on ties) if that distance <= max_dist, else -1;
+ * dist[p] (optional) = that smallest distance (INT_MAX if the window is empty; with skip_taken only for accepted probes). */
+int mcs_window_best(mcs_ctx*, const mcs_window_probes* probes, const mcs_frame_view* frame, int max_dist, int skip_taken, int dim, mcs_mem_kind kind,
+                    int32_t* match, int32_t* dist /* optional */, int32_t* nmatches);
+
 /* void cMultiCamSys_::WorldToCamHom_fast(int c, cv::Vec3d& pt3, cv::Vec2d& pt2) (src/cam_system_omni.cpp:114-133, the flagMcMt branch:
  * ptRot = MtMc_inv[c] * (pt3, 1), then cCamModelGeneral_::WorldToImg) for n points, point i into camera cam[i], followed by
  * cCamModelGeneral_::isPointInMirrorMask(u, v, 0) (src/cam_model_omni.cpp:163-178).  MtMc_inv: nr_cams 4x4 row-major matrices;

@@ -21,15 +21,19 @@ struct Arena {
 };
 }  // namespace
 
-int mcs_window_match(mcs_ctx* c, const mcs_window_probes* pr, const mcs_frame_view* f, mcs_window_rule rule, double nnratio, int dim, mcs_mem_kind kind,
-                     int32_t* match, int32_t* nmatches) {
+namespace mcs { void launch_window_best(const ProjArgs& a, bool skipTaken, int* outDist, hipStream_t s); }
+
+// bestMode 0: mcs_window_match (rule decides); 1: independent best-in-window; 2: best-in-window skipping taken features.  maxDist replaces TH_HIGH
+// for bestMode != 0; dist (optional) receives the best distance per probe.
+static int window_common(mcs_ctx* c, const mcs_window_probes* pr, const mcs_frame_view* f, mcs_window_rule rule, double nnratio, int dim, mcs_mem_kind kind,
+                         int32_t* match, int32_t* nmatches, int bestMode, int maxDist, int32_t* dist) {
 	if (!c || !pr || !f || !match || !nmatches) return fail(MCS_ERR_INVALID, "null argument");
 	if (rule != MCS_WINDOW_RATIO && rule != MCS_WINDOW_BEST && rule != MCS_WINDOW_INITIALIZE) return fail(MCS_ERR_INVALID, "unknown window rule");
 	if (dim != 16 && dim != 32 && dim != 64) return fail(MCS_ERR_INVALID, "dim must be 16, 32 or 64");
 	if (pr->n < 0 || f->n < 0 || f->n > 65536 || f->nr_cams < 1) return fail(MCS_ERR_INVALID, "bad sizes (frame features must be <= 65536)");
 	if ((pr->mask == nullptr) != (f->mask == nullptr)) return fail(MCS_ERR_INVALID, "masks must be given for both sides or neither");
 	if (pr->stride < dim || f->stride < dim || (pr->stride & 3) || (f->stride & 3)) return fail(MCS_ERR_INVALID, "descriptor stride must be >= dim and a multiple of 4");
-	if (rule != MCS_WINDOW_INITIALIZE && !f->assigned) return fail(MCS_ERR_INVALID, "frame->assigned is required");
+	if (rule != MCS_WINDOW_INITIALIZE && bestMode != 1 && !f->assigned) return fail(MCS_ERR_INVALID, "frame->assigned is required");
 	HIPCHK(hipSetDevice(c->device));
 	hipStream_t s = c->stream;
 	if (c->side && c->greedyPending) { HIPCHK(hipStreamWaitEvent(s, c->evGreedy, 0)); c->greedyPending = false; }
@@ -41,6 +45,7 @@ int mcs_window_match(mcs_ctx* c, const mcs_window_probes* pr, const mcs_frame_vi
 	a.ratio = nnratio; a.dim = dim; a.th = 1.0;
 	a.thHigh = havingMasks ? (int)floor(1.5 * dim) : 3 * dim;   // TH_HIGH_ / TH_LOW_ (src/cORBmatcher.cpp:46-65)
 	a.thLow = havingMasks ? (int)floor((double)dim) : 2 * dim;
+	if (bestMode) a.thHigh = maxDist;
 	Arena ar;
 	const size_t iLists = ar.add(np * kWindowListCap * 8), iCounts = ar.add(np * 4), iOwner = ar.add(nf * 4), iMdist = ar.add(nf * 4), iAsg = ar.add(nf);
 	size_t iX = 0, iY = 0, iR = 0, iLo = 0, iHi = 0, iPc = 0, iPd = 0, iPm = 0, iKeys = 0, iFd = 0, iFm = 0, iFc = 0, iW = 0, iH = 0, iMatch = 0, iNm = 0;
@@ -50,6 +55,7 @@ int mcs_window_match(mcs_ctx* c, const mcs_window_probes* pr, const mcs_frame_vi
 		iFm = ar.add(nf * f->stride); iFc = ar.add(nf * 4); iW = ar.add((size_t)f->nr_cams * 4); iH = ar.add((size_t)f->nr_cams * 4);
 		iMatch = ar.add(np * 4); iNm = ar.add(4);
 	}
+	const size_t iDist = ar.add(host && dist ? np * 4 : 0);
 	HIPCHK(ar.alloc());
 	auto done = [&](int rc) { (void)hipStreamSynchronize(s); return rc; };   // the arena is freed by its destructor after this sync
 	a.lists = (unsigned long long*)ar.at(iLists); a.counts = (int*)ar.at(iCounts); a.owner = (int*)ar.at(iOwner); a.mdist = (int*)ar.at(iMdist);
@@ -73,9 +79,11 @@ int mcs_window_match(mcs_ctx* c, const mcs_window_probes* pr, const mcs_frame_vi
 		a.assigned = f->assigned ? f->assigned : ar.at(iAsg); a.match = match; a.nmatches = nmatches;
 	}
 	if (!f->assigned) { if (hipMemsetAsync(ar.at(iAsg), 0, std::max<size_t>(nf, 1), s) != hipSuccess) return done(fail(MCS_ERR_HIP, "memset failed")); }
-	if (pr->n > 0) launch_projection(a, s);
+	int* ddist = dist ? (host ? (int*)ar.at(iDist) : dist) : nullptr;
+	if (pr->n > 0) { if (bestMode) launch_window_best(a, bestMode == 2, ddist, s); else launch_projection(a, s); }
 	else if (!host) { if (hipMemsetAsync(nmatches, 0, 4, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "memset failed")); }
 	if (hipGetLastError() != hipSuccess) return done(fail(MCS_ERR_HIP, "window kernels failed to launch"));
+	if (host && dist && pr->n > 0 && hipMemcpyAsync(dist, ddist, np * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
 	if (host) {
 		*nmatches = 0;
 		if (pr->n > 0) {
@@ -85,6 +93,17 @@ int mcs_window_match(mcs_ctx* c, const mcs_window_probes* pr, const mcs_frame_vi
 		}
 	}
 	return done(MCS_OK);
+}
+
+int mcs_window_match(mcs_ctx* c, const mcs_window_probes* pr, const mcs_frame_view* f, mcs_window_rule rule, double nnratio, int dim, mcs_mem_kind kind,
+                     int32_t* match, int32_t* nmatches) {
+	return window_common(c, pr, f, rule, nnratio, dim, kind, match, nmatches, 0, 0, nullptr);
+}
+
+int mcs_window_best(mcs_ctx* c, const mcs_window_probes* pr, const mcs_frame_view* f, int max_dist, int skip_taken, int dim, mcs_mem_kind kind,
+                    int32_t* match, int32_t* dist, int32_t* nmatches) {
+	if (max_dist < 0) return fail(MCS_ERR_INVALID, "max_dist must be >= 0");
+	return window_common(c, pr, f, MCS_WINDOW_BEST, 1.0, dim, kind, match, nmatches, skip_taken ? 2 : 1, max_dist, dist);
 }
 
 int mcs_world_to_cam(mcs_ctx* c, const double* MtMc_inv, const mcs_ocam* cams, int nr_cams, const uint8_t* const* mirror_masks, const double* pts3,

@@ -273,9 +273,54 @@ void launch_world_to_cam(const WorldToCamArgs& a, hipStream_t s) {
 	if (a.n > 0) hipLaunchKernelGGL(k_world_to_cam, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 }
 
+// Independent best-in-window (no feature is ever "taken"): the search loops of Fuse (:1265-1719), SearchBySim3 (:1721-1988),
+// SearchForTriangulationBetweenCameras (:1158-1263) and SearchByProjection(pKF, Scw, ...) (:2265-2392).  One wave per probe, the
+// smallest (dist, cell, index) key is the reference's strict-'<' winner; accepted if dist <= thHigh.
+__global__ __launch_bounds__(64) void k_proj_best(ProjArgs a, int* outDist) {
+	const int p = blockIdx.x, lane = threadIdx.x;
+	const Window w = make_window(a, p);
+	const int cam = a.pcam[p];
+	unsigned long long best = ~0ull;
+	if (!w.empty) {
+		for (int i = lane; i < a.nfeat; i += 64) {
+			const unsigned long long mk = member_key(a, w, cam, i);
+			if (mk == ~0ull) continue;
+			const unsigned long long k = ((unsigned long long)proj_distance(a, p, i) << 42) | mk;
+			best = k < best ? k : best;
+		}
+	}
+	best = wave_min_u64(best);
+	if (lane == 0) {
+		const bool found = best != ~0ull;
+		const int d = found ? (int)(best >> 42) : 0x7FFFFFFF;
+		const bool ok = found && d <= a.thHigh;
+		a.match[p] = ok ? (int)(best & 0xFFFFFu) : -1;
+		if (outDist) outDist[p] = d;
+		if (ok) atomicAdd(a.nmatches, 1);
+	}
+}
+
+// distances of the accepted matches of a greedy pass (mcs_window_best with skip_taken)
+__global__ __launch_bounds__(64) void k_proj_fill_dist(ProjArgs a, int* outDist) {
+	const int p = blockIdx.x * 64 + threadIdx.x;
+	if (p >= a.nproj) return;
+	const int j = a.match[p];
+	outDist[p] = j >= 0 ? proj_distance(a, p, j) : 0x7FFFFFFF;
+}
+
 void launch_projection(const ProjArgs& a, hipStream_t s) {
 	hipLaunchKernelGGL(k_proj_candidates, dim3(a.nproj), dim3(64), 0, s, a);
 	hipLaunchKernelGGL(k_proj_greedy, dim3(1), dim3(64), 0, s, a);
+}
+
+void launch_window_best(const ProjArgs& a, bool skipTaken, int* outDist, hipStream_t s) {
+	if (skipTaken) {
+		launch_projection(a, s);   // rule 2 with thHigh = the caller's threshold
+		if (outDist) hipLaunchKernelGGL(k_proj_fill_dist, dim3((a.nproj + 63) / 64), dim3(64), 0, s, a, outDist);
+	} else {
+		(void)hipMemsetAsync(a.nmatches, 0, sizeof(int), s);
+		hipLaunchKernelGGL(k_proj_best, dim3(a.nproj), dim3(64), 0, s, a, outDist);
+	}
 }
 
 }  // namespace mcs

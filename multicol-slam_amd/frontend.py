@@ -402,6 +402,28 @@ class cORBmatcher:
         check(lib().mcs_window_match(self.ctx.h, C.byref(pr), C.byref(fv), rule, self.mfNNratio, self.mbFeatDim, MEM_HOST, np_ptr(match), np_ptr(nm)))
         return match, int(nm[0])
 
+    def BestInWindows(self, x, y, r, lo, hi, cam, desc, mask, F, max_dist, skip_taken=False, assigned=None):
+        """The search loop of Fuse (src/cORBmatcher.cpp:1265-1719), SearchBySim3 (:1721-1988), SearchForTriangulationBetweenCameras (:1158-1263),
+        SearchByProjection(pKF, Scw, ...) (:2265-2392) [skip_taken False] and of the relocalisation SearchByProjection(CurrentFrame, pKF,
+        sAlreadyFound, th, ORBdist) (:2120-2263) [skip_taken True, `assigned` updated in place]: per probe (window centre x/y, radius r, level
+        range lo..hi, camera, descriptor row) the closest feature of frame F inside the window -> (match [-1 if > max_dist], dist, nmatches)."""
+        from ._capi import WindowProbes
+        n = len(x)
+        if n == 0:
+            return np.zeros(0, np.int32), np.zeros(0, np.int32), 0
+        x, y, r = (np.ascontiguousarray(v, np.float64) for v in (x, y, r))
+        lo, hi, cam = (np.ascontiguousarray(v, np.int32) for v in (lo, hi, cam))
+        dd = np.ascontiguousarray(desc, np.uint8)
+        mm = np.ascontiguousarray(mask, np.uint8) if self.havingMasks else None
+        pr = WindowProbes(np_ptr(x), np_ptr(y), np_ptr(r), np_ptr(lo), np_ptr(hi), np_ptr(cam), np_ptr(dd), np_ptr(mm), n, self.mbFeatDim)
+        if skip_taken and assigned is None:
+            assigned = np.array([m is not None for m in F.mvpMapPoints] + [0] * (F.totalN == 0), np.uint8)
+        fv, keep = self._frame_view(F, assigned if skip_taken else None)
+        match, dist, nm = np.full(n, -1, np.int32), np.zeros(n, np.int32), np.zeros(1, np.int32)
+        check(lib().mcs_window_best(self.ctx.h, C.byref(pr), C.byref(fv), int(max_dist), int(bool(skip_taken)), self.mbFeatDim, MEM_HOST, np_ptr(match),
+                                    np_ptr(dist), np_ptr(nm)))
+        return match, dist, int(nm[0])
+
     def WindowSearch(self, F1, F2, windowSize, minScaleLevel=0, maxScaleLevel=2**31 - 1):
         """-> (nmatches, vpMapPointMatches2) (src/cORBmatcher.cpp:326-473)."""
         from ._capi import WINDOW_RATIO

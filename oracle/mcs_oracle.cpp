@@ -1417,6 +1417,37 @@ int orc_search_by_projection_last(const orc_frame_view* Cur, uint8_t* curAssigne
 	return nmatches;
 }
 
+// The search loop shared by cORBmatcher::Fuse (src/cORBmatcher.cpp:1265-1719), SearchBySim3 (:1721-1988), SearchForTriangulationBetweenCameras
+// (:1158-1263), SearchByProjection(pKF, Scw, ...) (:2265-2392) [skipTaken = 0] and SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th,
+// ORBdist) (:2120-2263) [skipTaken = 1]: GetFeaturesInArea, level range, strict-'<' best, accept if bestDist <= maxDist.
+// pdesc / pmask: one descriptor row per probe.  match[p] = feature or -1, dist[p] = best distance (INT_MAX for an empty window).
+int orc_window_best(const double* x, const double* y, const double* radius, const int* minLevel, const int* maxLevel, const int* pcam, const uint8_t* pdesc,
+                    const uint8_t* pmask, int nprobes, const orc_frame_view* F, uint8_t* assigned, int maxDist, int skipTaken, int dim, int havingMasks,
+                    int* match, int* dist) {
+	FrameGrid G(F);
+	int nmatches = 0;
+	for (int p = 0; p < nprobes; ++p) {
+		match[p] = -1; dist[p] = INT_MAX;
+		std::vector<size_t> vIndices = G.GetFeaturesInArea(pcam[p], x[p], y[p], radius[p], minLevel[p], maxLevel[p]);
+		if (vIndices.empty()) continue;
+		int bestDist = INT_MAX, bestIdx = -1;
+		for (size_t k = 0; k < vIndices.size(); ++k) {
+			const size_t idx = vIndices[k];
+			if (skipTaken && assigned[idx]) continue;
+			const int d = dist_any(pdesc, pmask, p, F->desc, F->mask, (int)idx, dim, havingMasks);
+			if (d < bestDist) { bestDist = d; bestIdx = (int)idx; }
+		}
+		if (bestIdx < 0) continue;
+		if (!skipTaken) dist[p] = bestDist;
+		if (bestDist <= maxDist) {
+			match[p] = bestIdx;
+			if (skipTaken) { assigned[bestIdx] = 1; dist[p] = bestDist; }
+			++nmatches;
+		}
+	}
+	return nmatches;
+}
+
 // ---------------------------------------------------------------- "next" row 3: cMapPoint::ComputeDistinctiveDescriptors
 // src/cMapPoint.cpp:294-382 with median() of include/misc.h:95-104 (nth_element at size/2).  desc/mask: the N observed descriptors
 // in the order the reference's loop pushed them (its std::map is keyed by keyframe POINTER, so that order is the caller's to define).

@@ -123,6 +123,10 @@ int orc_search_by_projection_last(const orc_frame_view* Cur, uint8_t* curAssigne
                                   const uint8_t* lastOutlier, const double* uv, const uint8_t* inMask, const double* scaleFactors, double th, int dim,
                                   int havingMasks, int checkOri, int* matchCur);
 
+/* best-in-window search loop of Fuse / SearchBySim3 / SearchForTriangulationBetweenCameras / the relocalisation SearchByProjection */
+int orc_window_best(const double* x, const double* y, const double* radius, const int* minLevel, const int* maxLevel, const int* pcam, const uint8_t* pdesc,
+                    const uint8_t* pmask, int nprobes, const orc_frame_view* F, uint8_t* assigned, int maxDist, int skipTaken, int dim, int havingMasks,
+                    int* match, int* dist);
 /* "next" row 3: cMapPoint::ComputeDistinctiveDescriptors (src/cMapPoint.cpp:294-382): index of the chosen observation */
 int orc_distinctive_descriptor(const uint8_t* desc, const uint8_t* mask, int N, int dim, int havingMasks);
 

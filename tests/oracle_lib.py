@@ -294,3 +294,18 @@ def distinctive_descriptor(desc, mask):
     if len(desc) == 0:
         return -1
     return L.orc_distinctive_descriptor(ptr(desc), ptr(mask), len(desc), desc.shape[1], int(mask is not None))
+
+
+def window_best(x, y, r, lo, hi, cam, pdesc, pmask, F, assigned, max_dist, skip_taken, dim, masks):
+    L = lib()
+    L.orc_window_best.argtypes = [C.c_void_p] * 8 + [C.c_int, C.POINTER(FrameViewO), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    x, y, r = (np.ascontiguousarray(v, np.float64) for v in (x, y, r))
+    lo, hi, cam = (np.ascontiguousarray(v, np.int32) for v in (lo, hi, cam))
+    pdesc = np.ascontiguousarray(pdesc, np.uint8)
+    pmask = None if pmask is None else np.ascontiguousarray(pmask, np.uint8)
+    asg = np.ascontiguousarray(assigned if assigned is not None else np.zeros(max(F.n, 1)), np.uint8).copy()
+    n = len(x)
+    match, dist = np.full(max(n, 1), -1, np.int32), np.zeros(max(n, 1), np.int32)
+    nm = L.orc_window_best(ptr(x), ptr(y), ptr(r), ptr(lo), ptr(hi), ptr(cam), ptr(pdesc), ptr(pmask), n, C.byref(F), ptr(asg), max_dist, int(skip_taken), dim,
+                           int(masks), ptr(match), ptr(dist))
+    return nm, match[:n], dist[:n], asg
