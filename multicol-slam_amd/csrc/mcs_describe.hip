@@ -126,6 +126,13 @@ struct Sampler {
 #define MCS_ABLATE 0   // A/B experiments only: 1 skip the sequential mean, 2 skip the omni model, 4 skip sampling
 #endif
 constexpr int kMaxBallots = 8;   // descSize 64 -> 512 pairs -> 8 ballots
+#ifndef MCS_MERGE_CHAINS
+#define MCS_MERGE_CHAINS 0   // A/B only.  1 = mdBRIEF keeps all three distorted patterns in LDS and runs their six coordinate sums as ONE
+                             // chain (lanes 0..5): 1024 fewer dependent adds per keypoint, but 26.5 KB LDS per wave (6 waves/CU instead
+                             // of 12) and 186 VGPRs; measured 3.00 ms vs 2.93 ms per 192 images, so the separate chains stay.
+#endif
+// coordinate buffers per wave: [pattern][x | y][npoints] doubles
+__host__ __device__ constexpr int coord_bytes(int mode, int npoints) { return mode == 0 ? 0 : (mode == 2 && MCS_MERGE_CHAINS ? 3 : 1) * 2 * npoints * 8; }
 
 template <int MODE, int NB>   // MODE 0 ORB, 1 dBRIEF, 2 mdBRIEF; NB = descSize/8 ballots
 __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffers b, int wavesPerImage) {
@@ -165,8 +172,8 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 		sm.blur = b.blur + (size_t)img * d.pyrBytes + L.off; sm.bstride = L.stride;
 		sm.raw = raw; sm.rstride = rstride; sm.w = L.w; sm.h = L.h;
 		{   // stage the blurred 49x52 neighbourhood (13 unaligned dwords per row, rows are in-pitch even at the right edge)
-			constexpr int kWaveLds = (MODE == 0 ? 0 : 2 * 128 * NB * 8) + 2560;
-			uint8_t* patch = reinterpret_cast<uint8_t*>(lds) + (size_t)wave * kWaveLds + (MODE == 0 ? 0 : 2 * 128 * NB * 8);
+			constexpr int kWaveLds = coord_bytes(MODE, 128 * NB) + 2560;
+			uint8_t* patch = reinterpret_cast<uint8_t*>(lds) + (size_t)wave * kWaveLds + coord_bytes(MODE, 128 * NB);
 			const uint8_t* bp = sm.blur + (size_t)(row - kPatchR) * sm.bstride + (col - kPatchR);
 			for (int i = lane; i < kPatchRows * 13; i += 64) {
 				const int r = i / 13, k = i - r * 13;
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 	if (!active) return;
 	constexpr int NP = 128 * NB;              // pattern points = 2*8*descSize
 	constexpr int CH = NP / (2 * NB);         // chain elements folded into one point iteration (= 64)
-	double* buf = reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(lds) + (size_t)wave * (2 * NP * 8 + 2560));   // [x | y][NP] distorted coordinates
+	double* buf = reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(lds) + (size_t)wave * (coord_bytes(MODE, NP) + 2560));   // [pattern][x | y][NP] distorted coordinates
 	const OcamDev& cam = b.cams[img];
 	// The camera is the same for the whole wave: pull the backward polynomial and the affine terms into SGPRs ONCE.  (The
 	// first version re-loaded every Horner coefficient through a vector global load inside a 12-trip loop per pattern point —
@@ -323,14 +330,30 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 #pragma unroll
 	for (int j = 0; j < NB; ++j) { bitsMain[j] = 0ull; agree[j] = ~0ull; }
 	constexpr int npat = MODE == 2 ? 3 : 1;
+	constexpr bool merged = MODE == 2 && MCS_MERGE_CHAINS;
+	double sumAll = 0.0;
+	if (merged) {
+		// all three patterns first, then ONE dependent add chain: lane 2*pat + c accumulates coordinate c of pattern pat (each of the
+		// six sums still runs p = 0..NP-1 in the reference's order; the other lanes repeat lane 0's work)
+#pragma unroll
+		for (int pat = 0; pat < npat; ++pat) pass(true, pat == 0 ? ang0 : (pat == 1 ? ang1 : ang2), buf + pat * 2 * NP, false, buf, sumAll);
+		if (!(MCS_ABLATE & 1)) {
+			const int cl = lane < 2 * npat ? lane : 0;
+			const double* arr = buf + (cl >> 1) * 2 * NP + (cl & 1) * NP;
+#pragma unroll 16
+			for (int p = 0; p < NP; ++p) sumAll += arr[p];
+		}
+	}
 #pragma unroll
 	for (int pat = 0; pat < npat; ++pat) {
-		double* cur = buf;
-		double sum = 0.0;
-		pass(true, pat == 0 ? ang0 : (pat == 1 ? ang1 : ang2), cur, false, cur, sum);
-		pass(false, 0.0, cur, true, cur, sum);
+		double* cur = merged ? buf + pat * 2 * NP : buf;
+		double sum = sumAll;
+		if (!merged) {
+			pass(true, pat == 0 ? ang0 : (pat == 1 ? ang1 : ang2), cur, false, cur, sum);
+			pass(false, 0.0, cur, true, cur, sum);
+		}
 		const double mean = sum / (double)NP;
-		const double meanX = __shfl(mean, 0), meanY = __shfl(mean, 1);
+		const double meanX = __shfl(mean, merged ? 2 * pat : 0), meanY = __shfl(mean, merged ? 2 * pat + 1 : 1);
 #pragma unroll
 		for (int j = 0; j < NB; ++j) {
 			const int k = j * 64 + lane;
@@ -357,7 +380,7 @@ static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hi
 	const int wpb = MODE == 0 ? 4 : 1;
 	const int wavesPerImage = (hd.selPerImage + wpb - 1) / wpb * wpb;
 	const int blocks = nimg * wavesPerImage / wpb;
-	const size_t ldsBytes = (size_t)wpb * ((MODE == 0 ? 0 : 2 * hd.npoints * sizeof(double)) + 2560);   // coordinates + blurred patch per wave
+	const size_t ldsBytes = (size_t)wpb * (coord_bytes(MODE, hd.npoints) + 2560);   // coordinates + blurred patch per wave
 	const int nb = hd.descSize / 8;
 	if (nb == 2) hipLaunchKernelGGL((k_describe<MODE, 2>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 	else if (nb == 4) hipLaunchKernelGGL((k_describe<MODE, 4>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
