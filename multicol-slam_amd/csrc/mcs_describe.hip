@@ -132,7 +132,10 @@ constexpr int kMaxBallots = 8;   // descSize 64 -> 512 pairs -> 8 ballots
                              // of 12) and 186 VGPRs; measured 3.00 ms vs 2.93 ms per 192 images, so the separate chains stay.
 #endif
 // coordinate buffers per wave: [pattern][x | y][npoints] doubles
-__host__ __device__ constexpr int coord_bytes(int mode, int npoints) { return mode == 0 ? 0 : (mode == 2 && MCS_MERGE_CHAINS ? 3 : 1) * 2 * npoints * 8; }
+// The y array starts 2 doubles after the end of the x array: x[p] and y[p] are read in the same ds_read (even / odd lanes) and must not
+// share LDS banks (an offset of exactly npoints doubles = a multiple of 256 B made every read of the sum chain a 2-way bank conflict).
+__host__ __device__ constexpr int pat_doubles(int npoints) { return 2 * npoints + 2; }
+__host__ __device__ constexpr int coord_bytes(int mode, int npoints) { return mode == 0 ? 0 : (mode == 2 && MCS_MERGE_CHAINS ? 3 : 1) * pat_doubles(npoints) * 8; }
 
 template <int MODE, int NB>   // MODE 0 ORB, 1 dBRIEF, 2 mdBRIEF; NB = descSize/8 ballots
 __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffers b, int wavesPerImage) {
@@ -249,6 +252,8 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 	if (!active) return;
 	constexpr int NP = 128 * NB;              // pattern points = 2*8*descSize
 	constexpr int CH = NP / (2 * NB);         // chain elements folded into one point iteration (= 64)
+	constexpr int YO = NP + 2;                // offset of the y array inside a pattern buffer (bank shift, see pat_doubles)
+	constexpr int PD = pat_doubles(NP);
 	double* buf = reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(lds) + (size_t)wave * (coord_bytes(MODE, NP) + 2560));   // [pattern][x | y][NP] distorted coordinates
 	const OcamDev& cam = b.cams[img];
 	// The camera is the same for the whole wave: pull the backward polynomial and the affine terms into SGPRs ONCE.  (The
@@ -316,11 +321,11 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 				const double yr = ptx * ay + pty * ax + uky;
 				double u, v;
 				if (MCS_ABLATE & 2) { u = xr; v = yr; } else w2i(xr, yr, zc, u, v);
-				wb[2 * k + e] = u; wb[NP + 2 * k + e] = v;
+				wb[2 * k + e] = u; wb[YO + 2 * k + e] = v;
 			}
 		}
 		if (doChain && !(MCS_ABLATE & 1)) {
-			const double* arr = rb + (lane & 1) * NP;
+			const double* arr = rb + (lane & 1) * YO;
 #pragma unroll 16
 			for (int p = 0; p < NP; ++p) sum += arr[p];
 		}
@@ -336,17 +341,17 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 		// all three patterns first, then ONE dependent add chain: lane 2*pat + c accumulates coordinate c of pattern pat (each of the
 		// six sums still runs p = 0..NP-1 in the reference's order; the other lanes repeat lane 0's work)
 #pragma unroll
-		for (int pat = 0; pat < npat; ++pat) pass(true, pat == 0 ? ang0 : (pat == 1 ? ang1 : ang2), buf + pat * 2 * NP, false, buf, sumAll);
+		for (int pat = 0; pat < npat; ++pat) pass(true, pat == 0 ? ang0 : (pat == 1 ? ang1 : ang2), buf + pat * PD, false, buf, sumAll);
 		if (!(MCS_ABLATE & 1)) {
 			const int cl = lane < 2 * npat ? lane : 0;
-			const double* arr = buf + (cl >> 1) * 2 * NP + (cl & 1) * NP;
+			const double* arr = buf + (cl >> 1) * PD + (cl & 1) * YO;
 #pragma unroll 16
 			for (int p = 0; p < NP; ++p) sumAll += arr[p];
 		}
 	}
 #pragma unroll
 	for (int pat = 0; pat < npat; ++pat) {
-		double* cur = merged ? buf + pat * 2 * NP : buf;
+		double* cur = merged ? buf + pat * PD : buf;
 		double sum = sumAll;
 		if (!merged) {
 			pass(true, pat == 0 ? ang0 : (pat == 1 ? ang1 : ang2), cur, false, cur, sum);
@@ -357,8 +362,8 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 #pragma unroll
 		for (int j = 0; j < NB; ++j) {
 			const int k = j * 64 + lane;
-			const int ix0 = __double2int_rn(cur[2 * k] - meanX), iy0 = __double2int_rn(cur[NP + 2 * k] - meanY);
-			const int ix1 = __double2int_rn(cur[2 * k + 1] - meanX), iy1 = __double2int_rn(cur[NP + 2 * k + 1] - meanY);
+			const int ix0 = __double2int_rn(cur[2 * k] - meanX), iy0 = __double2int_rn(cur[YO + 2 * k] - meanY);
+			const int ix1 = __double2int_rn(cur[2 * k + 1] - meanX), iy1 = __double2int_rn(cur[YO + 2 * k + 1] - meanY);
 			const int t0 = (MCS_ABLATE & 4) ? ix0 : sm.at(row + iy0, col + ix0), t1 = (MCS_ABLATE & 4) ? iy1 : sm.at(row + iy1, col + ix1);
 			const unsigned long long bits = __ballot(t0 < t1);
 			if (pat == 0) bitsMain[j] = bits;

@@ -16,16 +16,41 @@ namespace mcs {
 
 constexpr int MT = 256;   // train rows per LDS step
 
+// Raw popcount total of one (query, train row) pair: sum_w popc((q^t)&qm) + popc((q^t)&tm) (masked; the reference halves this total
+// ONCE, src/cORBmatcher.cpp:2452-2474) or sum_w popc(q^t).  v_bcnt_u32_b32 d, a, b = popcount(a) + b, so the running total rides on
+// the popcounts: the chain is written as asm because the compiler otherwise emits bcnt(x, 0) plus a tree of v_add3, and is seeded
+// with the literal 0 (no v_mov).  t / tm point into LDS at 16-byte aligned rows and are read as ds_read_b128 broadcasts.
+template <int DW, bool MASKED>
+__device__ __forceinline__ uint32_t pair_total(const uint32_t* q, const uint32_t* qm, const uint4* t, const uint4* tm) {
+	uint32_t acc = 0;
+#pragma unroll
+	for (int w4 = 0; w4 < DW / 4; ++w4) {
+		const uint4 tv = t[w4];
+		const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w};
+		uint32_t mw[4] = {0, 0, 0, 0};
+		if (MASKED) { const uint4 mv = tm[w4]; mw[0] = mv.x; mw[1] = mv.y; mw[2] = mv.z; mw[3] = mv.w; }
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int w = 4 * w4 + k;
+			const uint32_t x = q[w] ^ tw[k];
+			if (MASKED) {
+				const uint32_t xa = x & qm[w], xb = x & mw[k];
+				if (w == 0) asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(acc) : "v"(xa));
+				else asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(xa));
+				asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(xb));
+			} else {
+				if (w == 0) asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(acc) : "v"(x));
+				else asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x));
+			}
+		}
+	}
+	return acc;
+}
+
 template <int DW, bool MASKED>
 __device__ __forceinline__ int hamming(const uint32_t* q, const uint32_t* qm, const uint32_t* t, const uint32_t* tm) {
-	int acc = 0;
-#pragma unroll
-	for (int w = 0; w < DW; ++w) {
-		const uint32_t x = q[w] ^ t[w];
-		if (MASKED) { acc += __popc(x & qm[w]); acc += __popc(x & tm[w]); }
-		else acc += __popc(x);
-	}
-	return MASKED ? acc >> 1 : acc;   // static_cast<int>(dist / 2): ONE division of the total
+	const uint32_t acc = pair_total<DW, MASKED>(q, qm, reinterpret_cast<const uint4*>(t), reinterpret_cast<const uint4*>(tm));
+	return MASKED ? (int)(acc >> 1) : (int)acc;   // static_cast<int>(dist / 2): ONE division of the total
 }
 
 template <int K, int DW, bool MASKED, bool COUNT>
@@ -36,7 +61,7 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	__shared__ __attribute__((aligned(16))) uint32_t tidx[MT + 4];    // their original train index; 0xFFFFFFFF = padding
 	__shared__ int wcnt[4];
 	constexpr int CB = 16;      // candidate column depth per lane
-	__shared__ uint32_t cand[CB * 256];
+	__shared__ uint32_t cand[(CB + 1) * 256];   // + one dump row
 	const int tid = threadIdx.x;
 	const int set = blockIdx.z, split = blockIdx.y;
 	const int qi = blockIdx.x * 256 + tid;
@@ -116,27 +141,37 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 		if (tid < 4) { tidx[rows + tid] = 0xFFFFFFFFu; tflag[rows + tid] = -1; }   // padding rows of the last trip
 		__syncthreads();
 		if (qok) {
-			// 4 train rows per trip, no branches: all LDS broadcasts of a trip are issued before the first use (ILP)
+			// 4 train rows per trip.  Per pair beyond the 2 x DW (masked) bitop3 / bcnt: and + shift-or (key), compare, select (slot),
+			// add (count) — the distance threshold, the padding rows (index 0xFFFFFFFF) and "list is full" are ONE unsigned compare of
+			// the key against lim = min(K-th best key, (maxDist+1) << 20).
+			const uint32_t distCap = a.maxDist >= 4095 ? 0xFFFFFFFFu : ((uint32_t)(a.maxDist + 1) << 20);
 			for (int r = 0; r < rows; r += 4) {
-				uint32_t key[4];
 				const uint4 ti = *reinterpret_cast<const uint4*>(&tidx[r]);
 				const uint32_t tiu[4] = {ti.x, ti.y, ti.z, ti.w};
 				int tgu[4] = {0, 0, 0, 0};
 				if (useGroup) { const int4 tg = *reinterpret_cast<const int4*>(&tflag[r]); tgu[0] = tg.x; tgu[1] = tg.y; tgu[2] = tg.z; tgu[3] = tg.w; }
+				const uint4* trow = reinterpret_cast<const uint4*>(&td[r * DW]);
+				const uint4* mrow = reinterpret_cast<const uint4*>(&tm[MASKED ? r * DW : 0]);
+				const uint32_t lim = min(best[K - 1], distCap);
+				uint32_t key[4];
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
-					const int dist = hamming<DW, MASKED>(q, qm, &td[(r + u) * DW], &tm[MASKED ? (r + u) * DW : 0]);
-					const bool ok = !useGroup || tgu[u] == qg;
-					if (COUNT) countLe += (ok && tiu[u] != 0xFFFFFFFFu && dist <= a.countThresh) ? 1 : 0;
-					key[u] = (ok && dist <= a.maxDist) ? (((uint32_t)dist << 20) | tiu[u]) : 0xFFFFFFFFu;
+					const uint32_t acc = pair_total<DW, MASKED>(q, qm, trow + u * (DW / 4), mrow + (MASKED ? u * (DW / 4) : 0));
+					// (acc >> 1) << 20 | idx  ==  (acc & ~1) << 19 | idx
+					key[u] = MASKED ? (((acc & ~1u) << 19) | tiu[u]) : ((acc << 20) | tiu[u]);
+					if (useGroup) key[u] = tgu[u] == qg ? key[u] : 0xFFFFFFFFu;
+					if (COUNT) countLe += (tiu[u] != 0xFFFFFFFFu && key[u] != 0xFFFFFFFFu && (int)(MASKED ? acc >> 1 : acc) <= a.countThresh) ? 1 : 0;
 				}
-				const uint32_t mk = min(min(key[0], key[1]), min(key[2], key[3]));
-				if (__any(mk < best[K - 1])) {   // rare: some lane has a candidate among these 4 rows
+				// Branch-free append: a key that cannot enter the list goes to the lane's dump slot (row CB).  On repetitive imagery
+				// ~16 % of all pairs are within maxDist, so "some lane of the wave has a candidate in these 4 rows" holds on
+				// practically every trip and a wave vote + predicated blocks only added instructions.
 #pragma unroll
-					for (int u = 0; u < 4; ++u)
-						if (key[u] < best[K - 1]) { cand[cnt * 256 + tid] = key[u]; ++cnt; }
-					if (__any(cnt > CB - 4)) flush();
+				for (int u = 0; u < 4; ++u) {
+					const bool in = key[u] < lim;
+					cand[(in ? cnt : CB) * 256 + tid] = key[u];
+					cnt += in ? 1 : 0;
 				}
+				if (__any(cnt > CB - 4)) flush();
 			}
 		}
 		__syncthreads();
