@@ -53,7 +53,7 @@ __device__ __forceinline__ int hamming(const uint32_t* q, const uint32_t* qm, co
 	return MASKED ? (int)(acc >> 1) : (int)acc;   // static_cast<int>(dist / 2): ONE division of the total
 }
 
-template <int K, int DW, bool MASKED, bool COUNT>
+template <int K, int DW, bool MASKED, bool COUNT, bool GROUP>
 __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	__shared__ __attribute__((aligned(16))) uint32_t td[MT * DW];
 	__shared__ __attribute__((aligned(16))) uint32_t tm[MASKED ? MT * DW : 4];
@@ -88,12 +88,16 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 #pragma unroll
 	for (int p = 0; p < K; ++p) best[p] = 0xFFFFFFFFu;
 	int countLe = 0;
-	const bool useGroup = a.qgroup != nullptr && a.tgroup != nullptr;
+	constexpr bool useGroup = GROUP;   // = both sides carry camera groups (chosen by the launcher)
 	// Candidate keys are first appended to a private LDS column (one ds_write per hit) and merged into the sorted
 	// register list only when some lane's column is full or at the end: a sorted insert costs 2K VALU ops for the WHOLE
 	// wave whenever ANY lane hits, which at K = 32 was more than the distance arithmetic itself.
-	int cnt = 0;
+	// `next` = index of the lane's next free slot in its column (tid, tid + 256, ...), kept as an index so that an append is
+	// compare, select (slot or dump row), store, select + add (advance)
+	const uint32_t col0 = tid, dump = CB * 256 + tid;
+	uint32_t next = col0;
 	auto flush = [&]() {
+		const int cnt = (int)((next - col0) >> 8);
 		int m = cnt;
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 				for (int p = 0; p < K; ++p) { const uint32_t lo = min(best[p], key), hi = max(best[p], key); best[p] = lo; key = hi; }
 			}
 		}
-		cnt = 0;
+		next = col0;
 	};
 
 	const int per = ((a.nt + a.splits - 1) / a.splits + 63) / 64 * 64;
@@ -168,10 +172,10 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
 					const bool in = key[u] < lim;
-					cand[(in ? cnt : CB) * 256 + tid] = key[u];
-					cnt += in ? 1 : 0;
+					cand[in ? next : dump] = key[u];
+					next += in ? 256u : 0u;
 				}
-				if (__any(cnt > CB - 4)) flush();
+				if (__any(next > col0 + (CB - 4) * 256)) flush();
 			}
 		}
 		__syncthreads();
@@ -231,11 +235,14 @@ __global__ __launch_bounds__(256) void k_match_unpack(MatchArgs a) {
 template <int K, int DW>
 static void launch_kd(const MatchArgs& a, hipStream_t s) {
 	dim3 grid((a.nq + 255) / 256, a.splits, a.nsets);
-	const bool masked = a.qm && a.tm, count = a.countThresh >= 0;   // the searches do not need count_le: skip its 3 VALU ops per pair
-	if (masked && count) hipLaunchKernelGGL((k_match_partial<K, DW, true, true>), grid, dim3(256), 0, s, a);
-	else if (masked) hipLaunchKernelGGL((k_match_partial<K, DW, true, false>), grid, dim3(256), 0, s, a);
-	else if (count) hipLaunchKernelGGL((k_match_partial<K, DW, false, true>), grid, dim3(256), 0, s, a);
-	else hipLaunchKernelGGL((k_match_partial<K, DW, false, false>), grid, dim3(256), 0, s, a);
+	const bool masked = a.qm && a.tm, count = a.countThresh >= 0;   // the searches do not need count_le: skip its VALU ops per pair
+	const bool group = a.qgroup != nullptr && a.tgroup != nullptr;
+#define MCS_LAUNCH_PARTIAL(M, C, G) hipLaunchKernelGGL((k_match_partial<K, DW, M, C, G>), grid, dim3(256), 0, s, a)
+	if (masked) { if (count) { if (group) MCS_LAUNCH_PARTIAL(true, true, true); else MCS_LAUNCH_PARTIAL(true, true, false); }
+	              else { if (group) MCS_LAUNCH_PARTIAL(true, false, true); else MCS_LAUNCH_PARTIAL(true, false, false); } }
+	else { if (count) { if (group) MCS_LAUNCH_PARTIAL(false, true, true); else MCS_LAUNCH_PARTIAL(false, true, false); }
+	       else { if (group) MCS_LAUNCH_PARTIAL(false, false, true); else MCS_LAUNCH_PARTIAL(false, false, false); } }
+#undef MCS_LAUNCH_PARTIAL
 	if (a.splits > 1) hipLaunchKernelGGL((k_match_merge<K>), dim3((a.nq + 255) / 256, 1, a.nsets), dim3(256), 0, s, a);
 	if (a.outDist && a.outIdx) hipLaunchKernelGGL(k_match_unpack, dim3((a.nq + 255) / 256, 1, a.nsets), dim3(256), 0, s, a);
 }
