@@ -108,6 +108,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 
 	const int t = d.fastThreshold;
 	const int npx = cw * ch;
+	// p / cw by multiplication: cw <= 60 and p < 3600, so with M = ceil(2^18 / cw) the error term p * (M*cw - 2^18) < 3600 * 60 < 2^18
+	// and (p * M) >> 18 is exact (a variable integer division is ~20 VALU instructions, and there were three per pixel).
+	const unsigned divM = (262144u + (unsigned)cw - 1u) / (unsigned)cw;
 	const int lane = tid & 63, wave = tid >> 6;
 	// pass 1: cheap compass test on every pixel; survivors are compacted into an LDS list (order is irrelevant here) so that
 	// pass 2 — the full 16-pixel arc score, ~10x the work — runs with all lanes busy instead of diverging inside each wave
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 		const int p = base + tid;
 		bool pass = false;
 		if (p < npx) {
-			const int py = p / cw, px = p - py * cw;
+			const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
 			pass = fast_quick(&tile[(py + 3) * kTilePitch + px + 3], t);
 		}
 		const unsigned long long bal = __ballot(pass);
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 	const int ns = nSurv;
 	for (int i = tid; i < ns; i += 256) {
 		const int p = surv[i];
-		const int py = p / cw, px = p - py * cw;
+		const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
 		sc[(py + 1) * kScPitch + px + 1] = (uint8_t)fast_score(&tile[(py + 3) * kTilePitch + px + 3], t);
 	}
 	__syncthreads();
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 		bool keep = false;
 		int py = 0, px = 0, s = 0;
 		if (p < npx) {
-			py = p / cw; px = p - py * cw;
+			py = (int)(((unsigned)p * divM) >> 18); px = p - py * cw;
 			const uint8_t* q = &sc[(py + 1) * kScPitch + px + 1];
 			s = q[0];
 			keep = s > q[-1] && s > q[1] && s > q[-kScPitch - 1] && s > q[-kScPitch] && s > q[-kScPitch + 1] &&
