@@ -312,7 +312,8 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 	// folding 64 of its steps into each of the 2*NB point evaluations lets the scheduler hide its latency under the math.
 	auto pass = [&](bool doMath, double ang, double* wb, bool doChain, const double* rb, double& sum) {
 		if (doMath) {
-			const double ax = cos(ang), ay = sin(ang);
+			double ax, ay;
+			sincos(ang, &ay, &ax);   // one argument reduction for both (same ocml kernels as cos() / sin())
 #pragma unroll
 			for (int t = 0; t < 2 * NB; ++t) {
 				const int k = (t >> 1) * 64 + lane, e = t & 1;
