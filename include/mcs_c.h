@@ -213,6 +213,11 @@ int mcs_world_to_cam(mcs_ctx*, const double* MtMc_inv, const mcs_ocam* cams, int
 int mcs_distinctive_descriptors(mcs_ctx*, const uint8_t* desc, const uint8_t* mask, int stride, int dim, const int32_t* offsets, int npoints,
                                 mcs_mem_kind kind, int32_t* best_idx);
 
+/* self-test of an arithmetic shortcut of the descriptor kernel: the omni model's three divisions by the same norm (src/cam_model_omni.cpp:
+ * 146-161) share one refined reciprocal; this runs n pseudo-random (numerator, denominator) pairs of the magnitudes the kernel sees through
+ * both forms on the device and returns the number of results that are not bit-identical to a / d (must be 0). */
+int mcs_selftest_shared_reciprocal(mcs_ctx*, uint64_t seed, int n, int32_t* mismatches);
+
 /* device helper: valid[i*cap + k] = (k < nkp[i]) for the row layout produced by mcs_extract_batch (all pointers on the GPU) */
 int mcs_rows_valid(mcs_ctx*, const int32_t* nkp_dev, int nimg, int cap, uint8_t* valid_dev);
 

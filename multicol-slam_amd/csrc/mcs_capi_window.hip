@@ -203,3 +203,20 @@ int mcs_distinctive_descriptors(mcs_ctx* c, const uint8_t* desc, const uint8_t* 
 	if (hipMemcpyAsync(best_idx, ar.at(iB), (size_t)npoints * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
 	return done(MCS_OK);
 }
+
+namespace mcs { void launch_selftest_recip(unsigned long long seed, int n, int* mismatches, hipStream_t s); }
+
+int mcs_selftest_shared_reciprocal(mcs_ctx* c, uint64_t seed, int n, int32_t* mismatches) {
+	if (!c || !mismatches || n < 1) return fail(MCS_ERR_INVALID, "bad argument");
+	HIPCHK(hipSetDevice(c->device));
+	int* d = nullptr;
+	HIPCHK(hipMalloc((void**)&d, 4));
+	(void)hipMemsetAsync(d, 0, 4, c->stream);
+	launch_selftest_recip(seed, n, d, c->stream);
+	const hipError_t e1 = hipGetLastError();
+	const hipError_t e2 = hipMemcpyAsync(mismatches, d, 4, hipMemcpyDeviceToHost, c->stream);
+	const hipError_t e3 = hipStreamSynchronize(c->stream);
+	(void)hipFree(d);
+	if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(MCS_ERR_HIP, "selftest kernel failed");
+	return MCS_OK;
+}

@@ -53,6 +53,45 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 	return a;
 }
 
+// Division by a shared denominator: the compiler's own f64 division expansion (rcp, two Newton steps, q0 = n*r,
+// e = fma(-d, q0, n), q = fma(e, r, q0)) with its denominator-only part computed once.  v_div_scale / v_div_fixup of the full
+// expansion only act on operands near the exponent limits, so for ordinary magnitudes div_shared(a, d, recip_refined(d)) is
+// bit-identical to a / d (checked on the device by mcs_selftest_shared_reciprocal, tests/test_gpu_match.py).  The one difference is
+// the sign of a ZERO quotient (-0 / d gives +0 here, v_div_fixup would restore -0); the omni model adds the principal point to
+// every product of these quotients, so a zero's sign never reaches u or v.
+__device__ __forceinline__ double recip_refined(double d) {
+	const double r0 = __builtin_amdgcn_rcp(d);
+	const double r1 = __builtin_fma(r0, __builtin_fma(-d, r0, 1.0), r0);
+	return __builtin_fma(r1, __builtin_fma(-d, r1, 1.0), r1);
+}
+__device__ __forceinline__ double div_shared(double a, double d, double r) {
+	const double q0 = a * r;
+	return __builtin_fma(__builtin_fma(-d, q0, a), r, q0);
+}
+
+// a / d vs div_shared on pseudo-random operands of the magnitudes k_describe sees (d in [1e-14, 1e5], |a| <= 1e4, zeros and tiny
+// numerators included); counts the bit mismatches
+__global__ void k_selftest_recip(unsigned long long seed, int n, int* mismatches) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	unsigned long long st = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+	auto next = [&]() { st ^= st >> 12; st ^= st << 25; st ^= st >> 27; return st * 0x2545F4914F6CDD1Dull; };
+	auto unit = [&]() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); };
+	const double ed = -14.0 + 19.0 * unit();
+	const double d = exp10(ed) * (1.0 + unit());
+	double a = (unit() * 2.0 - 1.0) * exp10(-18.0 + 22.0 * unit());
+	if ((i & 127) == 0) a = 0.0;
+	if ((i & 127) == 1) a = -d;
+	if ((i & 127) == 2) a = d;
+	const double r = recip_refined(d);
+	const double q1 = div_shared(a, d, r), q2 = a / d;
+	if (__double_as_longlong(q1) != __double_as_longlong(q2)) atomicAdd(mismatches, 1);
+}
+
+void launch_selftest_recip(unsigned long long seed, int n, int* mismatches, hipStream_t s) {
+	hipLaunchKernelGGL(k_selftest_recip, dim3((n + 255) / 256), dim3(256), 0, s, seed, n, mismatches);
+}
+
 // wave-uniform double load: both halves go through v_readfirstlane so the value lives in SGPRs
 __device__ __forceinline__ double uniform_f64(const double* p) {
 	const unsigned lo = __builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(p)[0]);
@@ -269,7 +308,12 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 	auto w2i = [&](double x, double y, double z, double& u, double& v) {   // cCamModelGeneral_::WorldToImg (src/cam_model_omni.cpp:146-161)
 		double norm = sqrt(x * x + y * y);
 		if (norm == 0.0) norm = 1e-14;
-		const double theta = atan(-z / norm);
+		// The three IEEE divisions by `norm` share ONE refined reciprocal (recip_refined / div_shared above): norm is in
+		// [1e-14, 1e4] and the numerators are pattern coordinates, so every quotient is bit-identical to `a / norm` — and the
+		// point costs 19 FP64 instructions less.
+		const double rn = recip_refined(norm);
+		auto over_norm = [&](double a) { return div_shared(a, norm, rn); };
+		const double theta = atan(over_norm(-z));
 		double rho = 0.0;
 		if (cDeg == 12) {
 #pragma unroll
@@ -278,8 +322,8 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 #pragma unroll
 			for (int i = MCS_MAX_POLY - 1; i >= 0; --i) rho = rho * theta + cP[i];
 		}
-		const double uu = x / norm * rho;
-		const double vv = y / norm * rho;
+		const double uu = over_norm(x) * rho;
+		const double vv = over_norm(y) * rho;
 		u = uu * cC + vv * cD + cU0;
 		v = uu * cE + vv + cV0;
 	};

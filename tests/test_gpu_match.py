@@ -90,3 +90,14 @@ def test_empty_sets(G):
     assert d.shape == (0, 4)
     d, i, c = G.ctx().match_topk(np.zeros((3, 32), np.uint8), np.zeros((0, 32), np.uint8), 4, 10)
     assert (i == -1).all() and (d == 0x7FFFFFFF).all() and (c == 0).all()
+
+
+def test_shared_reciprocal_division_is_bit_identical():
+    """k_describe divides x, y and -z by the same norm through one refined reciprocal; the library's self-test runs that form and the
+    plain a / d on 8 M pseudo-random operand pairs on the device: no result may differ in any bit."""
+    import ctypes as C
+    import gpu_common as G
+    for seed in (1, 2, 3, 4):
+        bad = C.c_int32(-1)
+        G.mcs.check(G.mcs.lib().mcs_selftest_shared_reciprocal(G.ctx().h, seed, 2_000_000, C.byref(bad)))
+        assert bad.value == 0
