@@ -70,7 +70,7 @@ __device__ __forceinline__ int fast_score(const uint8_t* c /* centre in LDS tile
 
 __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd) {
 	__shared__ __attribute__((aligned(16))) uint8_t tile[kTileRows * kTilePitch];
-	__shared__ uint8_t sc[kScRows * kScPitch];
+	__shared__ __attribute__((aligned(16))) uint8_t sc[kScRows * kScPitch];
 	__shared__ int waveCnt[4];
 	__shared__ int runBase;
 	__shared__ int nSurv;
@@ -95,14 +95,17 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 	src += (size_t)(cell.y0 - 3) * stride + (cell.x0 - 3);
 	const int tw = cw + 6, th = ch + 6;
 	const int ndw = (tw + 3) >> 2;   // unaligned dword loads; the <= 3 bytes of over-read per row stay inside the image row
+	// i / ndw by multiplication: ndw <= 17 and i < 17 * 66, so with M = ceil(2^16 / ndw) the error term i * (M*ndw - 2^16) < 2^16 and
+	// (i * M) >> 16 is exact; 32-bit offsets keep the address arithmetic out of 64-bit multiplies.
+	const unsigned rowM = (65536u + (unsigned)ndw - 1u) / (unsigned)ndw;
 	for (int i = tid; i < ndw * th; i += 256) {
-		const int ty = i / ndw, kx = i - ty * ndw;
+		const unsigned ty = ((unsigned)i * rowM) >> 16, kx = (unsigned)i - ty * (unsigned)ndw;
 		uint32_t v;
-		__builtin_memcpy(&v, src + (size_t)ty * stride + 4 * kx, 4);
+		__builtin_memcpy(&v, src + (ty * (unsigned)stride + 4u * kx), 4);
 		*reinterpret_cast<uint32_t*>(&tile[ty * kTilePitch + 4 * kx]) = v;
 	}
 	const int sw = cw + 2, sh = ch + 2;
-	for (int i = tid; i < sh * kScPitch; i += 256) sc[i] = 0;
+	for (int i = tid; i < sh * (kScPitch / 4); i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;   // score tile cleared as dwords
 	if (tid == 0) { runBase = 0; nSurv = 0; }
 	__syncthreads();
 
