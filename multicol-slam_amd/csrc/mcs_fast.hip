@@ -71,7 +71,8 @@ __device__ __forceinline__ int fast_score(const uint8_t* c /* centre in LDS tile
 __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd) {
 	__shared__ __attribute__((aligned(16))) uint8_t tile[kTileRows * kTilePitch];
 	__shared__ __attribute__((aligned(16))) uint8_t sc[kScRows * kScPitch];
-	__shared__ int waveCnt[4];
+	__shared__ uint32_t keepBits[128];   // NMS + mask verdict per pixel of the cell (row-major bit index), 60*60 <= 4096 bits
+	__shared__ int groupOff[64];         // exclusive prefix of the kept-pixel counts per 64-pixel group
 	__shared__ int runBase;
 	__shared__ int nSurv;
 	__shared__ unsigned short surv[60 * 60];   // pixel indices that pass the compass test (cell processed region <= 60x60)
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 	}
 	const int sw = cw + 2, sh = ch + 2;
 	for (int i = tid; i < sh * (kScPitch / 4); i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;   // score tile cleared as dwords
+	if (tid < 128) keepBits[tid] = 0;
 	if (tid == 0) { runBase = 0; nSurv = 0; }
 	__syncthreads();
 
@@ -143,34 +145,47 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 	const short* mapX = b.maskMap + L.mapX;
 	const short* mapY = b.maskMap + L.mapY;
 	const uint8_t* mask = b.mask0 ? b.mask0 + (size_t)img * b.mask0Pitch : nullptr;
-	for (int base = 0; base < npx; base += 256) {
-		const int p = base + tid;
-		bool keep = false;
-		int py = 0, px = 0, s = 0;
-		if (p < npx) {
-			py = (int)(((unsigned)p * divM) >> 18); px = p - py * cw;
-			const uint8_t* q = &sc[(py + 1) * kScPitch + px + 1];
-			s = q[0];
-			keep = s > q[-1] && s > q[1] && s > q[-kScPitch - 1] && s > q[-kScPitch] && s > q[-kScPitch + 1] &&
-			       s > q[kScPitch - 1] && s > q[kScPitch] && s > q[kScPitch + 1];
-			if (keep && mask) {   // KeyPointsFilter::runByPixelsMask on the (nearest-neighbour) mask pyramid
-				int mx = mapX[cell.x0 + px], my = mapY[cell.y0 + py];
-				keep = mask[(size_t)my * b.mask0Stride + mx] != 0;
-			}
+	// pass 3a: non-max suppression + mirror mask, only for the pixels that have a score at all (the compass survivors); the verdicts go
+	// into a bitmap indexed by the pixel's row-major number inside the cell
+	for (int i = tid; i < ns; i += 256) {
+		const int p = surv[i];
+		const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
+		const uint8_t* q = &sc[(py + 1) * kScPitch + px + 1];
+		const int s0 = q[0];
+		const int nb = max(max(max((int)q[-1], (int)q[1]), max((int)q[-kScPitch - 1], (int)q[-kScPitch])),
+		                   max(max((int)q[-kScPitch + 1], (int)q[kScPitch - 1]), max((int)q[kScPitch], (int)q[kScPitch + 1])));
+		bool keep = s0 > nb;   // strictly greater than all 8 neighbours (a score of 0 never is)
+		if (keep && mask) {   // KeyPointsFilter::runByPixelsMask on the (nearest-neighbour) mask pyramid
+			const int mx = mapX[cell.x0 + px], my = mapY[cell.y0 + py];
+			keep = mask[(size_t)my * b.mask0Stride + mx] != 0;
 		}
-		const unsigned long long bal = __ballot(keep);
-		if (lane == 0) waveCnt[wave] = __popcll(bal);
-		__syncthreads();
-		int off = runBase;
-		for (int w = 0; w < wave; ++w) off += waveCnt[w];
-		if (keep) {
-			off += __popcll(bal & ((1ull << lane) - 1ull));
-			slots[off] = (uint32_t)(cell.x0 + px - kMinBorder) | ((uint32_t)(cell.y0 + py - kMinBorder) << 12) | ((uint32_t)s << 24);
-		}
-		__syncthreads();
-		if (tid == 0) runBase += waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
-		__syncthreads();
+		if (keep) atomicOr(&keepBits[p >> 5], 1u << (p & 31));
 	}
+	__syncthreads();
+	// 64 consecutive pixels = one wave's ballot = two bitmap words: the emission order (row-major inside the cell, the reference's) is an
+	// exclusive prefix sum over <= 57 group counts (one wave), then every kept pixel writes its record — two barriers for the whole cell
+	// instead of three per 256-pixel slab.
+	const int ngroups = (npx + 63) >> 6;
+	if (wave == 0) {
+		const int v = lane < ngroups ? __popc(keepBits[2 * lane]) + __popc(keepBits[2 * lane + 1]) : 0;
+		int incl = v;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+		groupOff[lane] = incl - v;
+		if (lane == 63) runBase = incl;
+	}
+	__syncthreads();
+	for (int g = wave; g < ngroups; g += 4) {
+		const unsigned long long bal = (unsigned long long)keepBits[2 * g] | ((unsigned long long)keepBits[2 * g + 1] << 32);
+		if ((bal >> lane) & 1ull) {
+			const int p = g * 64 + lane;
+			const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
+			const int s0 = sc[(py + 1) * kScPitch + px + 1];
+			const int off = groupOff[g] + __popcll(bal & ((1ull << lane) - 1ull));
+			slots[off] = (uint32_t)(cell.x0 + px - kMinBorder) | ((uint32_t)(cell.y0 + py - kMinBorder) << 12) | ((uint32_t)s0 << 24);
+		}
+	}
+	__syncthreads();
 	if (tid == 0) *countOut = runBase;
 	(void)sw;
 }
