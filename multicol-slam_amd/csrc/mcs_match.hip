@@ -96,16 +96,49 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	// compare, select (slot or dump row), store, select + add (advance)
 	const uint32_t col0 = tid, dump = CB * 256 + tid;
 	uint32_t next = col0;
+	// Merge of the lane's candidate column into its sorted list.  K >= 16: the (<= CB = 16) candidates are loaded into registers
+	// (empty slots = 0xFFFFFFFF), sorted by a 16-input bitonic network, folded against the upper half of the list
+	// (m[i] = min(best[i], c[K-1-i]) holds the K smallest of both and is bitonic) and re-sorted by one bitonic MERGE — a fixed
+	// ~340 VALU ops per flush, where inserting one candidate at a time through the sorted list cost 2K ops per candidate of the
+	// fullest lane (~900 per flush at K = 32).  Smaller K keep the insertion loop.
 	auto flush = [&]() {
 		const int cnt = (int)((next - col0) >> 8);
-		int m = cnt;
+		if (K >= CB) {
+			uint32_t c[CB];
 #pragma unroll
-		for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-		for (int e = 0; e < m; ++e) {
-			uint32_t key = e < cnt ? cand[e * 256 + tid] : 0xFFFFFFFFu;
-			if (__any(key < best[K - 1])) {
+			for (int e = 0; e < CB; ++e) c[e] = e < cnt ? cand[e * 256 + tid] : 0xFFFFFFFFu;
 #pragma unroll
-				for (int p = 0; p < K; ++p) { const uint32_t lo = min(best[p], key), hi = max(best[p], key); best[p] = lo; key = hi; }
+			for (int k = 2; k <= CB; k <<= 1)
+#pragma unroll
+				for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+					for (int i = 0; i < CB; ++i) {
+						const int l = i ^ j;
+						if (l > i) {
+							const uint32_t lo = min(c[i], c[l]), hi = max(c[i], c[l]);
+							const bool up = (i & k) == 0;
+							c[i] = up ? lo : hi; c[l] = up ? hi : lo;
+						}
+					}
+#pragma unroll
+			for (int i = 0; i < CB; ++i) best[K - 1 - i] = min(best[K - 1 - i], c[i]);   // fold: ascending c against the descending tail
+#pragma unroll
+			for (int j = K >> 1; j > 0; j >>= 1)
+#pragma unroll
+				for (int i = 0; i < K; ++i) {
+					const int l = i ^ j;
+					if (l > i) { const uint32_t lo = min(best[i], best[l]), hi = max(best[i], best[l]); best[i] = lo; best[l] = hi; }
+				}
+		} else {
+			int m = cnt;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+			for (int e = 0; e < m; ++e) {
+				uint32_t key = e < cnt ? cand[e * 256 + tid] : 0xFFFFFFFFu;
+				if (__any(key < best[K - 1])) {
+#pragma unroll
+					for (int p = 0; p < K; ++p) { const uint32_t lo = min(best[p], key), hi = max(best[p], key); best[p] = lo; key = hi; }
+				}
 			}
 		}
 		next = col0;
