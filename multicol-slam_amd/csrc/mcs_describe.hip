@@ -159,6 +159,20 @@ struct Sampler {
 		c = c < 0 ? -c : (c >= w ? 2 * (w - 1) - c : c);
 		return raw[(size_t)r * rstride + c];
 	}
+	// Both samples of a test pair given as offsets from the keypoint (the patch centre).  Fast path, taken when every lane of the
+	// wave has both samples inside the LDS patch (practically always): two ds_read_u8 with 32-bit LDS addresses.  The general
+	// `at()` (generic pointer to LDS / blurred level / bordered raw level, three-way address select) stays for the rest.
+	__device__ __forceinline__ void pair(int row, int col, int dy0, int dx0, int dy1, int dx1, int& t0, int& t1) const {
+		const unsigned r0 = (unsigned)(dy0 + kPatchR), c0 = (unsigned)(dx0 + kPatchR), r1 = (unsigned)(dy1 + kPatchR), c1 = (unsigned)(dx1 + kPatchR);
+		const bool inside = max(max(r0, c0), max(r1, c1)) < (unsigned)kPatchRows;
+		if (!__any(!inside)) {
+			t0 = patch[r0 * kPatchPitch + c0];
+			t1 = patch[r1 * kPatchPitch + c1];
+		} else {
+			t0 = at(row + dy0, col + dx0);
+			t1 = at(row + dy1, col + dx1);
+		}
+	}
 };
 
 #ifndef MCS_ABLATE
@@ -276,7 +290,8 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 			const double x0 = c_pattern[4 * k], y0 = c_pattern[4 * k + 1], x1 = c_pattern[4 * k + 2], y1 = c_pattern[4 * k + 3];
 			const int ix0 = __double2int_rn(x0 * ax - y0 * ay), iy0 = __double2int_rn(x0 * ay + y0 * ax);
 			const int ix1 = __double2int_rn(x1 * ax - y1 * ay), iy1 = __double2int_rn(x1 * ay + y1 * ax);
-			const int t0 = sm.at(row + iy0, col + ix0), t1 = sm.at(row + iy1, col + ix1);
+			int t0, t1;
+			sm.pair(row, col, iy0, ix0, iy1, ix1, t0, t1);
 			const unsigned long long bits = __ballot(t0 < t1);
 			if (lane == 0) {
 				*reinterpret_cast<unsigned long long*>(dout + 8 * j) = bits;
@@ -409,7 +424,8 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 			const int k = j * 64 + lane;
 			const int ix0 = __double2int_rn(cur[2 * k] - meanX), iy0 = __double2int_rn(cur[YO + 2 * k] - meanY);
 			const int ix1 = __double2int_rn(cur[2 * k + 1] - meanX), iy1 = __double2int_rn(cur[YO + 2 * k + 1] - meanY);
-			const int t0 = (MCS_ABLATE & 4) ? ix0 : sm.at(row + iy0, col + ix0), t1 = (MCS_ABLATE & 4) ? iy1 : sm.at(row + iy1, col + ix1);
+			int t0 = ix0, t1 = iy1;
+			if (!(MCS_ABLATE & 4)) sm.pair(row, col, iy0, ix0, iy1, ix1, t0, t1);
 			const unsigned long long bits = __ballot(t0 < t1);
 			if (pat == 0) bitsMain[j] = bits;
 			else agree[j] &= ~(bits ^ bitsMain[j]);
