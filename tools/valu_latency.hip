@@ -1,0 +1,79 @@
+// Micro-benchmark: cycles per wave-instruction on gfx950 for dependent chains vs independent streams, at 1..4 waves per SIMD.
+// hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/valu_latency.hip -o tools/valu_latency && tools/valu_latency
+// One 256-thread block = 4 waves = one wave per SIMD of a CU; 256*W blocks -> W waves per SIMD (the dispatcher spreads blocks evenly).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(double* out, int iters) {
+	double f[8];
+	uint32_t u[8];
+	for (int i = 0; i < 8; ++i) { f[i] = 1.0 + threadIdx.x * 1e-9 + i; u[i] = threadIdx.x * 2654435761u + i; }
+	const double c = 1.0000001;
+	for (int it = 0; it < iters; ++it) {
+#pragma unroll
+		for (int r = 0; r < 16; ++r) {
+			if (MODE == 0) { asm volatile("v_add_f64 %0, %0, %1" : "+v"(f[0]) : "v"(c)); }                                   // dependent FP64 add
+			if (MODE == 1) { asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(f[0]) : "v"(c)); }                               // dependent FP64 fma
+			if (MODE == 2) {                                                                                                  // 8 independent FP64 adds
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_add_f64 %0, %0, %1" : "+v"(f[j]) : "v"(c));
+			}
+			if (MODE == 3) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[0]) : "v"(u[1])); }                                 // dependent int add
+			if (MODE == 4) {                                                                                                  // 8 independent int adds
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 5) {                                                                                                  // 8 independent v_mov
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 6) {                                                                                                  // 8 independent bcnt
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 7) { asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(u[0]) : "v"(u[1])); }                            // dependent bcnt
+			if (MODE == 8) {                                                                                                  // 8 independent FP64 mul
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(f[j]) : "v"(c));
+			}
+		}
+	}
+	double s = 0;
+	for (int i = 0; i < 8; ++i) s += f[i] + u[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int MODE>
+static void run(const char* name, int per, double* d) {
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	const int iters = 2000;
+	for (int W = 1; W <= 4; ++W) {
+		float best = 1e9f;
+		for (int rep = 0; rep < 3; ++rep) {
+			hipEventRecord(e0);
+			hipLaunchKernelGGL(k<MODE>, dim3(256 * W), dim3(256), 0, 0, d, iters);
+			hipEventRecord(e1); hipEventSynchronize(e1);
+			float ms; hipEventElapsedTime(&ms, e0, e1);
+			best = ms < best ? ms : best;
+		}
+		const double instr = (double)iters * 16 * per;               // wave-instructions per wave
+		const double cyc = best * 1e-3 * 2.4e9;                      // at 2.4 GHz
+		printf("%-28s W=%d  %.3f ms  %.2f cycles per wave-instruction per wave, %.2f per SIMD issue slot\n", name, W, best, cyc / instr, cyc / instr / W);
+	}
+}
+
+int main() {
+	double* d; hipMalloc(&d, 1024 * 256 * 8);
+	run<0>("dependent v_add_f64", 1, d);
+	run<1>("dependent v_fma_f64", 1, d);
+	run<2>("8 independent v_add_f64", 8, d);
+	run<8>("8 independent v_mul_f64", 8, d);
+	run<3>("dependent v_add_u32", 1, d);
+	run<4>("8 independent v_add_u32", 8, d);
+	run<5>("8 independent v_mov_b32", 8, d);
+	run<7>("dependent v_bcnt_u32_b32", 1, d);
+	run<6>("8 independent v_bcnt_u32_b32", 8, d);
+	return 0;
+}
