@@ -213,6 +213,20 @@ int mcs_world_to_cam(mcs_ctx*, const double* MtMc_inv, const mcs_ocam* cams, int
 int mcs_distinctive_descriptors(mcs_ctx*, const uint8_t* desc, const uint8_t* mask, int stride, int dim, const int32_t* offsets, int npoints,
                                 mcs_mem_kind kind, int32_t* best_idx);
 
+/* ------------------------------------------------------------------ cMultiFrame::ComputeBoW (src/cMultiFrame.cpp:356-363), SURVEY §8f row 4
+ * mpORBvocabulary->transform(descriptors, mBowVec, mFeatVec, levelsup) = one DBoW2 tree descent per descriptor
+ * (ThirdParty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259, FORB::distance over 32 bytes).  The vocabulary is passed flat: node 0 is the
+ * root, node_desc holds 32 bytes per node, the children of node i are child_idx[child_off[i] .. child_off[i+1]) in the order
+ * TemplatedVocabulary::load (:1573-1622) appended them (file order), L = depth levels.  Per feature the call returns the leaf node reached
+ * (its word id and weight are look-ups in the caller's node table) and the node of the path at level L - levelsup (0 if that level is
+ * <= 0), i.e. the FeatureVector key.  Building the BowVector / FeatureVector maps from these (weights, L1 normalisation) stays on the host.
+ * With node ids as `group` on both sides, mcs_search_kf_f is the vocabulary-restricted SearchByBoW(KF, F) of the reference
+ * (keyframe rows ordered by (node, index), src/cORBmatcher.cpp:179-323). */
+typedef struct mcs_vocabulary mcs_vocabulary;
+int mcs_vocabulary_create(mcs_ctx*, int n_nodes, const uint8_t* node_desc, const int32_t* child_off, const int32_t* child_idx, int L, mcs_vocabulary** out);
+void mcs_vocabulary_destroy(mcs_vocabulary*);
+int mcs_bow_transform(mcs_vocabulary*, const uint8_t* desc, int n, int stride, int levelsup, mcs_mem_kind kind, int32_t* leaf_node, int32_t* node_at_level);
+
 /* self-test of an arithmetic shortcut of the descriptor kernel: the omni model's three divisions by the same norm (src/cam_model_omni.cpp:
  * 146-161) share one refined reciprocal; this runs n pseudo-random (numerator, denominator) pairs of the magnitudes the kernel sees through
  * both forms on the device and returns the number of results that are not bit-identical to a / d (must be 0). */

@@ -68,7 +68,7 @@ EXPORTS = [
     "mcs_extractor_tap_level", "mcs_extractor_tap_candidates", "mcs_extractor_tap_selected", "mcs_match_topk",
     "mcs_match_topk_batched", "mcs_descriptor_distance", "mcs_descriptor_distance_masked", "mcs_ctx_enable_timing",
     "mcs_ctx_kernel_ms", "mcs_ctx_join", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_rows_valid",
-    "mcs_search_by_projection", "mcs_window_match", "mcs_window_best", "mcs_world_to_cam", "mcs_distinctive_descriptors", "mcs_selftest_shared_reciprocal",
+    "mcs_search_by_projection", "mcs_window_match", "mcs_window_best", "mcs_world_to_cam", "mcs_distinctive_descriptors", "mcs_selftest_shared_reciprocal", "mcs_vocabulary_create", "mcs_vocabulary_destroy", "mcs_bow_transform",
 ]
 
 WINDOW_RATIO, WINDOW_BEST, WINDOW_INITIALIZE = 1, 2, 3
@@ -134,6 +134,10 @@ def lib():
     L.mcs_world_to_cam.argtypes = [vp, vp, C.POINTER(Ocam), C.c_int, C.POINTER(vp), vp, vp, C.c_int, C.c_int, vp, vp]
     L.mcs_distinctive_descriptors.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
     L.mcs_selftest_shared_reciprocal.argtypes = [vp, C.c_uint64, C.c_int, i32p]
+    L.mcs_vocabulary_create.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(vp)]
+    L.mcs_vocabulary_destroy.argtypes = [vp]
+    L.mcs_vocabulary_destroy.restype = None
+    L.mcs_bow_transform.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.mcs_descriptor_distance.argtypes = [vp, vp, vp, C.c_int, i32p]
     L.mcs_descriptor_distance_masked.argtypes = [vp, vp, vp, vp, vp, C.c_int, i32p]
     _lib = L

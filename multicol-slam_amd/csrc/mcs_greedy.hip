@@ -281,6 +281,8 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 #pragma unroll
 					for (int w = 0; w < DW; ++w) qm[w] = mp[w];
 				}
+				const bool grouped = g.qgroup != nullptr && g.tgroup != nullptr;
+				const int qgLow = grouped ? g.qgroup[q0 + qi] : 0;
 				uint32_t a = EMPTY, b2 = EMPTY;
 				// branch-free body, 4 rows per lane and trip: all global loads of a trip are issued before the first use
 				for (int j0 = lane; j0 < g.nt; j0 += 256) {
@@ -291,7 +293,8 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 						const int jc = j < g.nt ? j : g.nt - 1;
 						const uint32_t* tp = reinterpret_cast<const uint32_t*>(g.td + (t0 + jc) * g.tstride);
 						const uint32_t* mp = MASKED ? reinterpret_cast<const uint32_t*>(g.tm + (t0 + jc) * g.tstride) : tp;
-						const bool ok = j < g.nt && !((matched[jc >> 5] >> (jc & 31)) & 1u) && (g.tvalid ? g.tvalid[t0 + jc] != 0 : true);
+						const bool ok = j < g.nt && !((matched[jc >> 5] >> (jc & 31)) & 1u) && (g.tvalid ? g.tvalid[t0 + jc] != 0 : true) &&
+						                (!grouped || g.tgroup[t0 + jc] == qgLow);   // same camera / FeatureVector node only
 						const uint32_t k = ((uint32_t)hamming_g<DW, MASKED>(q, qm, tp, mp) << 20) | (uint32_t)jc;
 						kk[u] = ok ? k : EMPTY;
 					}

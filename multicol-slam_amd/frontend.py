@@ -195,6 +195,7 @@ class cMultiFrame:
     def __init__(self, images, timeStamp, extractor, voc, camSystem, imgCnt=0):
         nrCams = camSystem.GetNrCams()
         self.images, self.mTimeStamp, self.camSystem, self.imgCnt = images, timeStamp, camSystem, imgCnt
+        self.mpORBvocabulary, self.mBowVec, self.mFeatVec = voc, None, None
         ex0 = extractor[0] if isinstance(extractor, (list, tuple)) else extractor
         cams = [camSystem.GetCamModelObj(c) for c in range(nrCams)]
         masks = [cm.GetMirrorMask(0) for cm in cams]
@@ -239,6 +240,10 @@ class cMultiFrame:
             return False, posX, posY
         return True, posX, posY
 
+    def ComputeBoW(self):   # src/cMultiFrame.cpp:356-363 (voc = the cORBVocabulary given to the constructor)
+        if not getattr(self, "mBowVec", None):
+            self.mBowVec, self.mFeatVec = self.mpORBvocabulary.transform(self.all_descriptors(), 4)
+
     # flat (all cameras concatenated) descriptor views, the row order of mvKeys
     def all_descriptors(self):
         return np.concatenate(self.mDescriptors) if self.totalN else np.zeros((0, self.descDimension), np.uint8)
@@ -257,9 +262,13 @@ class cMultiKeyFrame:
         self.keypoint_to_cam, self.cont_idx_to_local_cam_idx = F.keypoint_to_cam, F.cont_idx_to_local_cam_idx
         self.mvpMapPoints = list(F.mvpMapPoints)
         self._d, self._m = F.all_descriptors(), F.all_masks()
+        self.mBowVec, self.mFeatVec = getattr(F, "mBowVec", None), getattr(F, "mFeatVec", None)
 
     def GetMapPointMatches(self):
         return self.mvpMapPoints
+
+    def GetFeatureVector(self):
+        return self.mFeatVec
 
     def GetKeyPoints(self):
         return self.mvKeys
@@ -315,6 +324,22 @@ class cORBmatcher:
             self.last_fallbacks = int(fb[0])
             return int(nm[0]), [mp2[j] if j >= 0 else None for j in m12[:len(mp1)]]
         F = other
+        kfv, ffv = getattr(pKF1, "mFeatVec", None), getattr(F, "mFeatVec", None)
+        if kfv and ffv:
+            # the reference's vocabulary-restricted search: a keyframe feature only meets frame features of the same FeatureVector node;
+            # nodes ascending, the features of a node in index order = keyframe rows permuted to (node, index) order, node id as `group`
+            order = np.array([i for _, lst in kfv.items() for i in lst], np.int64)
+            gk = np.array([nd for nd, lst in kfv.items() for _ in lst], np.int32)
+            gf = np.full(F.totalN, -1, np.int32)
+            for nd, lst in ffv.items():
+                gf[lst] = nd
+            vf = (gf >= 0).astype(np.uint8)
+            q, t, keep = self._sets(pKF1._d[order], pKF1._m[order], np.ascontiguousarray(v1[order]), gk, F.all_descriptors(), F.all_masks(), vf, gf)
+            mF = np.full(max(F.totalN, 1), -1, np.int32)
+            check(lib().mcs_search_kf_f(self.ctx.h, 1, C.byref(q), 0, C.byref(t), 0, self.mbFeatDim, self.mfNNratio, self.K, MEM_HOST, np_ptr(mF),
+                                        np_ptr(nm), np_ptr(fb)))
+            self.last_fallbacks = int(fb[0])
+            return int(nm[0]), [mp1[int(order[i])] if i >= 0 else None for i in mF[:F.totalN]]
         q, t, keep = self._sets(pKF1._d, pKF1._m, v1, None, F.all_descriptors(), F.all_masks(), None, None)
         mF = np.full(max(F.totalN, 1), -1, np.int32)
         check(lib().mcs_search_kf_f(self.ctx.h, 1, C.byref(q), 0, C.byref(t), 0, self.mbFeatDim, self.mfNNratio, self.K, MEM_HOST, np_ptr(mF),
@@ -612,3 +637,59 @@ class cMapPoint:
 
     def GetDescriptorMask(self):
         return self.mDescriptorMask
+
+
+class cORBVocabulary:
+    """ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (include/cORBVocabulary.h) as far as the front end uses it:
+    transform(features, levelsup) -> (BowVector, FeatureVector) (ThirdParty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1205).  The tree descent of
+    every descriptor runs on the GPU (mcs_bow_transform); the two std::map's are rebuilt here with the reference's arithmetic order."""
+
+    def __init__(self, voc, ctx=None):
+        """voc: the dict of multicol-slam_amd.io.load_vocabulary (or a path to the vocabulary YAML)."""
+        if isinstance(voc, str):
+            from . import io as _io
+            voc = _io.load_vocabulary(voc)
+        self.voc = voc
+        self.ctx = ctx or default_context()
+        self.m_k, self.m_L = voc["k"], voc["L"]
+        if voc["scoringType"] != 0 or voc["weightingType"] != 0:
+            raise NotImplementedError("only TF_IDF weighting with L1 scoring (the shipped small_orb_omni_voc_9_6.yml) is mirrored")
+        self.h = C.c_void_p()
+        nd = np.ascontiguousarray(voc["node_desc"], np.uint8)
+        co, ci = np.ascontiguousarray(voc["child_off"], np.int32), np.ascontiguousarray(voc["child_idx"], np.int32)
+        check(lib().mcs_vocabulary_create(self.ctx.h, len(nd), np_ptr(nd), np_ptr(co), np_ptr(ci), self.m_L, C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().mcs_vocabulary_destroy(self.h)
+        except Exception:
+            pass
+
+    def descend(self, descriptors, levelsup):
+        """-> (leaf node, node at level L - levelsup) per descriptor row"""
+        d = np.ascontiguousarray(descriptors, np.uint8)
+        n = len(d)
+        leaf, nid = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        if n:
+            check(lib().mcs_bow_transform(self.h, np_ptr(d), n, d.shape[1], int(levelsup), MEM_HOST, np_ptr(leaf), np_ptr(nid)))
+        return leaf[:n], nid[:n]
+
+    def transform(self, descriptors, levelsup=4):
+        """-> (BowVector {word id: value}, FeatureVector {node id: [feature indices]}), both in ascending key order like std::map."""
+        leaf, nid = self.descend(descriptors, levelsup)
+        words, weights = self.voc["word_id"][leaf], self.voc["weight"][leaf]
+        bow, fv = {}, {}
+        for i in range(len(leaf)):            # TF_IDF branch: addWeight accumulates in feature order (:1147-1163)
+            w = float(weights[i])
+            if w > 0:
+                wid = int(words[i])
+                bow[wid] = bow.get(wid, 0.0) + w
+                fv.setdefault(int(nid[i]), []).append(i)
+        bow = dict(sorted(bow.items()))
+        norm = 0.0                            # L1 scoring: mustNormalize -> BowVector::normalize(L1) in key order (BowVector.cpp)
+        for v in bow.values():
+            norm += abs(v)
+        if norm > 0.0:
+            bow = {k: v / norm for k, v in bow.items()}
+        return bow, dict(sorted(fv.items()))

@@ -143,3 +143,40 @@ def read_pgm(path):
         raise ValueError("only 8-bit binary PGM (P5) is supported")
     w, h = int(tok[1]), int(tok[2])
     return np.frombuffer(data, np.uint8, w * h, pos + 1).reshape(h, w).copy()
+
+
+def load_vocabulary(path):
+    """DBoW2 vocabulary in OpenCV-YAML form (TemplatedVocabulary::load, ThirdParty/DBoW2/DBoW2/TemplatedVocabulary.h:1573-1622) -> the flat
+    arrays mcs_vocabulary_create takes plus the per-node word id / weight tables:
+      k, L, scoringType, weightingType, node_desc [N+1, 32] u8 (row 0 = root, zeros), parent [N+1], child_off [N+2], child_idx [N] (children in
+      file order), word_id [N+1] (-1 for inner nodes), weight [N+1] float64, n_words."""
+    import re
+    txt = open(path, "r", encoding="latin-1").read()
+    head = txt[:txt.index("nodes:")]
+    hdr = {k: int(re.search(r"\b%s:\s*(-?\d+)" % k, head).group(1)) for k in ("k", "L", "scoringType", "weightingType")}
+    nodes = re.findall(r"nodeId:\s*(\d+),\s*parentId:\s*(\d+),\s*weight:\s*([^,\s]+),\s*descriptor:\s*\"([^\"]*)\"", txt)
+    words = re.findall(r"wordId:\s*(\d+),\s*nodeId:\s*(\d+)", txt)
+    n = len(nodes)
+    if n == 0:
+        raise ValueError("no nodes in %s" % path)
+    node_desc = np.zeros((n + 1, 32), np.uint8)
+    parent = np.zeros(n + 1, np.int32)
+    weight = np.zeros(n + 1, np.float64)
+    children = [[] for _ in range(n + 1)]
+    for nid, pid, w, d in nodes:
+        nid, pid = int(nid), int(pid)
+        vals = d.split()
+        if len(vals) != 32:
+            raise ValueError("FORB descriptors are 32 bytes (node %d has %d)" % (nid, len(vals)))
+        node_desc[nid] = np.array(vals, np.int64).astype(np.uint8)
+        parent[nid], weight[nid] = pid, float(w)
+        children[pid].append(nid)
+    child_off = np.zeros(n + 2, np.int32)
+    child_off[1:] = np.cumsum([len(c) for c in children])
+    child_idx = np.array([c for lst in children for c in lst], np.int32)
+    word_id = np.full(n + 1, -1, np.int32)
+    for wid, nid in words:
+        word_id[int(nid)] = int(wid)
+    out = dict(hdr)
+    out.update(node_desc=node_desc, parent=parent, child_off=child_off, child_idx=child_idx, word_id=word_id, weight=weight, n_words=len(words))
+    return out

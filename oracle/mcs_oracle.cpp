@@ -27,6 +27,7 @@
 #include <cstring>
 #include <malloc.h>
 #include <list>
+#include <map>
 #include <set>
 #include <utility>
 #include <vector>
@@ -1472,6 +1473,89 @@ int orc_distinctive_descriptor(const uint8_t* desc, const uint8_t* mask, int N, 
 		}
 	} else BestIdx = 0;
 	return BestIdx;
+}
+
+// ---------------------------------------------------------------- "next" row 4: cMultiFrame::ComputeBoW -> DBoW2 transform
+// ThirdParty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259 (one feature down the tree; first strict minimum among a node's children in
+// file order), FORB::distance ThirdParty/DBoW2/DBoW2/FORB.cpp:85-105 (32 bytes, the bit-trick popcount).  The vocabulary is given flat:
+// node 0 = root, node_desc = 32 bytes per node, children of node i = child_idx[child_off[i] .. child_off[i+1]) in the order
+// TemplatedVocabulary::load (:1573-1622) pushed them.  leaf[f] = the leaf node reached (word / weight are table look-ups on it),
+// nid[f] = the node on the path at level L - levelsup (0 = root if that level is <= 0).
+static inline int forb_distance(const uint8_t* a, const uint8_t* b) {
+	const int32_t* pa = reinterpret_cast<const int32_t*>(a);
+	const int32_t* pb = reinterpret_cast<const int32_t*>(b);
+	int dist = 0;
+	for (int i = 0; i < 8; i++, pa++, pb++) {
+		unsigned int v = *pa ^ *pb;
+		v = v - ((v >> 1) & 0x55555555);
+		v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+		dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+	}
+	return dist;
+}
+
+void orc_bow_transform(const uint8_t* node_desc, const int32_t* child_off, const int32_t* child_idx, int L, const uint8_t* desc, int n, int stride,
+                       int levelsup, int32_t* leaf, int32_t* nid) {
+	for (int f = 0; f < n; ++f) {
+		const uint8_t* feature = desc + (size_t)f * stride;
+		const int nid_level = L - levelsup;
+		int nidv = 0;   // "if (nid_level <= 0 && nid != NULL) *nid = 0; // root"
+		int final_id = 0, current_level = 0;
+		do {
+			++current_level;
+			const int32_t* nodes = child_idx + child_off[final_id];
+			const int cnt = child_off[final_id + 1] - child_off[final_id];
+			final_id = nodes[0];
+			double best_d = forb_distance(feature, node_desc + 32 * (size_t)final_id);
+			for (int c = 1; c < cnt; ++c) {
+				const int id = nodes[c];
+				const double d = forb_distance(feature, node_desc + 32 * (size_t)id);
+				if (d < best_d) { best_d = d; final_id = id; }
+			}
+			if (current_level == nid_level) nidv = final_id;
+		} while (child_off[final_id + 1] - child_off[final_id] > 0);   // !isLeaf()
+		leaf[f] = final_id;
+		nid[f] = nidv;
+	}
+}
+
+// cORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) WITH the vocabulary restriction (src/cORBmatcher.cpp:179-323): only features that
+// share a FeatureVector node are compared; nodes ascending, keyframe features of a node in index order.  nodeKF / nodeF: node id per
+// feature or -1 (stopped word: not in the FeatureVector).  matchF[j] = keyframe feature or -1.
+int orc_search_kf_f_bow(const uint8_t* dKF, const uint8_t* mKF, const uint8_t* validKF, const int* nodeKF, int nKF, const uint8_t* dF, const uint8_t* mF,
+                        const int* nodeF, int nF, int dim, int havingMasks, double nnratio, int* matchF) {
+	int TH_HIGH, TH_LOW;
+	orc_thresholds(dim, havingMasks, &TH_HIGH, &TH_LOW);
+	std::map<int, std::vector<unsigned int> > vFeatVecKF, FeatVecF;   // DBoW2::FeatureVector (addFeature keeps index order)
+	for (int i = 0; i < nKF; ++i) if (nodeKF[i] >= 0) vFeatVecKF[nodeKF[i]].push_back(i);
+	for (int j = 0; j < nF; ++j) if (nodeF[j] >= 0) FeatVecF[nodeF[j]].push_back(j);
+	for (int j = 0; j < nF; ++j) matchF[j] = -1;
+	int nmatches = 0;
+	std::map<int, std::vector<unsigned int> >::iterator KFit = vFeatVecKF.begin(), Fit = FeatVecF.begin();
+	while (KFit != vFeatVecKF.end() && Fit != FeatVecF.end()) {
+		if (KFit->first == Fit->first) {
+			const std::vector<unsigned int>& vIndicesKF = KFit->second;
+			const std::vector<unsigned int>& vIndicesF = Fit->second;
+			for (size_t iKF = 0; iKF < vIndicesKF.size(); ++iKF) {
+				const unsigned int realIdxKF = vIndicesKF[iKF];
+				if (!validKF[realIdxKF]) continue;
+				int bestDist1 = INT_MAX, bestIdxF = -1, bestDist2 = INT_MAX;
+				for (size_t iF = 0; iF < vIndicesF.size(); ++iF) {
+					const unsigned int realIdxF = vIndicesF[iF];
+					if (matchF[realIdxF] >= 0) continue;
+					const int dist = dist_any(dKF, mKF, (int)realIdxKF, dF, mF, (int)realIdxF, dim, havingMasks);
+					if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
+					else if (dist < bestDist2) bestDist2 = dist;
+				}
+				if (bestDist1 <= TH_LOW) {
+					if (static_cast<double>(bestDist1) < nnratio * static_cast<double>(bestDist2)) { matchF[bestIdxF] = (int)realIdxKF; ++nmatches; }
+				}
+			}
+			++KFit; ++Fit;
+		} else if (KFit->first < Fit->first) KFit = vFeatVecKF.lower_bound(Fit->first);
+		else Fit = FeatVecF.lower_bound(KFit->first);
+	}
+	return nmatches;
 }
 
 // ---------------------------------------------------------------- CPU baseline helper

@@ -130,6 +130,12 @@ int orc_window_best(const double* x, const double* y, const double* radius, cons
 /* "next" row 3: cMapPoint::ComputeDistinctiveDescriptors (src/cMapPoint.cpp:294-382): index of the chosen observation */
 int orc_distinctive_descriptor(const uint8_t* desc, const uint8_t* mask, int N, int dim, int havingMasks);
 
+/* "next" row 4: DBoW2 vocabulary descent of cMultiFrame::ComputeBoW and the vocabulary-restricted SearchByBoW(KF,F) */
+void orc_bow_transform(const uint8_t* node_desc, const int32_t* child_off, const int32_t* child_idx, int L, const uint8_t* desc, int n, int stride,
+                       int levelsup, int32_t* leaf, int32_t* nid);
+int orc_search_kf_f_bow(const uint8_t* dKF, const uint8_t* mKF, const uint8_t* validKF, const int* nodeKF, int nKF, const uint8_t* dF, const uint8_t* mF,
+                        const int* nodeF, int nF, int dim, int havingMasks, double nnratio, int* matchF);
+
 /* ---- timed CPU baseline helper: extract nimg images (OpenMP over images), returns total keypoints ---- */
 long orc_extract_many(const orc_params* p, int nimg, const uint8_t* const* imgs, int w, int h, int stride,
                       const uint8_t* const* masks, const orc_ocam* cams, int threads,

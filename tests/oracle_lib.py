@@ -309,3 +309,30 @@ def window_best(x, y, r, lo, hi, cam, pdesc, pmask, F, assigned, max_dist, skip_
     nm = L.orc_window_best(ptr(x), ptr(y), ptr(r), ptr(lo), ptr(hi), ptr(cam), ptr(pdesc), ptr(pmask), n, C.byref(F), ptr(asg), max_dist, int(skip_taken), dim,
                            int(masks), ptr(match), ptr(dist))
     return nm, match[:n], dist[:n], asg
+
+
+def bow_transform(voc, desc, levelsup):
+    """oracle DBoW2 descent: voc = dict of multicol-slam_amd.io.load_vocabulary -> (leaf node, node at level L - levelsup) per row"""
+    L = lib()
+    L.orc_bow_transform.restype = None
+    L.orc_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    nd = np.ascontiguousarray(voc["node_desc"], np.uint8)
+    co, ci = np.ascontiguousarray(voc["child_off"], np.int32), np.ascontiguousarray(voc["child_idx"], np.int32)
+    d = np.ascontiguousarray(desc, np.uint8)
+    n = len(d)
+    leaf, nid = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    L.orc_bow_transform(ptr(nd), ptr(co), ptr(ci), voc["L"], ptr(d), n, d.shape[1], levelsup, ptr(leaf), ptr(nid))
+    return leaf[:n], nid[:n]
+
+
+def search_kf_f_bow(dk, mk, vk, nodek, df, mf, nodef, masks, ratio):
+    L = lib()
+    L.orc_search_kf_f_bow.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    dk, df = np.ascontiguousarray(dk, np.uint8), np.ascontiguousarray(df, np.uint8)
+    mk = None if mk is None else np.ascontiguousarray(mk, np.uint8)
+    mf = None if mf is None else np.ascontiguousarray(mf, np.uint8)
+    vk = np.ascontiguousarray(vk, np.uint8)
+    nodek, nodef = np.ascontiguousarray(nodek, np.int32), np.ascontiguousarray(nodef, np.int32)
+    out = np.full(max(len(df), 1), -1, np.int32)
+    n = L.orc_search_kf_f_bow(ptr(dk), ptr(mk), ptr(vk), ptr(nodek), len(dk), ptr(df), ptr(mf), ptr(nodef), len(df), dk.shape[1], int(masks), ratio, ptr(out))
+    return n, out[:len(df)]
