@@ -2,15 +2,23 @@
 // that cTracking / cLocalMapping / cLoopClosing compile against it unchanged in spirit:
 //
 //   MultiColSLAM::mdBRIEFextractorOct   include/mdBRIEFextractorOct.h:335-421 (13-argument ctor, operator(), getters)
-//   MultiColSLAM::cORBmatcher           include/cORBmatcher.h:43-133 (the three brute-force searches on flat views)
+//   MultiColSLAM::cORBmatcher           include/cORBmatcher.h:43-133 (brute-force and grid-window searches on flat views)
+//   MultiColSLAM::cMultiCamSys_ / LoadMCS / cORBVocabulary / ComputeDistinctiveDescriptors   the callers either side of the path
 //   MultiColSLAM::DescriptorDistance64[_Masked]   src/cORBmatcher.cpp:2438-2474
 //
 // OpenCV is not a dependency: minimal layout-compatible PODs stand in for cv::KeyPoint / cv::Mat / cv::Vec3d.  With
 // -DMCS_WITH_OPENCV the adapters at the bottom accept the real types (cv::KeyPoint is 28 bytes, same layout).
 // Link with -lmcs_hip.  No CPU fallback: every call needs a HIP device and throws std::runtime_error otherwise.
 #pragma once
+#include <array>
+#include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -135,6 +143,202 @@ private:
 	int w_ = 0, h_ = 0, batch_ = 0, cap_ = 0;
 };
 
+// ---------------------------------------------------------------------------------------------- settings / calibration files
+// The flat `key: value` subset of OpenCV FileStorage YAML the reference's Examples use (`%YAML:1.0` header, `#` comments).
+inline std::map<std::string, std::string> ReadSettings(const std::string& path) {
+	std::ifstream f(path);
+	if (!f) throw std::runtime_error("cannot open " + path);
+	std::map<std::string, std::string> out;
+	std::string line;
+	while (std::getline(f, line)) {
+		const size_t h = line.find('#');
+		if (h != std::string::npos) line.erase(h);
+		const size_t c = line.find(':');
+		if (line.empty() || line[0] == '%' || c == std::string::npos) continue;
+		auto trim = [](std::string v) { const size_t a = v.find_first_not_of(" \t\r\""), b = v.find_last_not_of(" \t\r\""); return a == std::string::npos ? std::string() : v.substr(a, b - a + 1); };
+		const std::string k = trim(line.substr(0, c)), v = trim(line.substr(c + 1));
+		if (!k.empty() && !v.empty()) out[k] = v;
+	}
+	return out;
+}
+inline double SettingD(const std::map<std::string, std::string>& s, const std::string& k) {
+	auto it = s.find(k);
+	if (it == s.end()) throw std::runtime_error("missing setting " + k);
+	return std::strtod(it->second.c_str(), nullptr);
+}
+inline int SettingI(const std::map<std::string, std::string>& s, const std::string& k) { return (int)SettingD(s, k); }
+
+// CreateMirrorMask (src/cam_model_omni.cpp:181-220), level 0: float arithmetic, the principal-point names swapped like the reference
+inline void CreateMirrorMask0(const mcs_ocam& cam, Mat8u& mask) {
+	const int w = cam.width, h = cam.height;
+	const float u0 = (float)cam.v0, v0 = (float)cam.u0;
+	mask.create(h, w);
+	for (int i = 0; i < h; ++i)
+		for (int j = 0; j < w; ++j) {
+			const float ans = std::sqrt((float)std::pow((double)(i - u0), 2) + (float)std::pow((double)(j - v0), 2));
+			mask.data[(size_t)i * w + j] = ans < (u0 + 22.0f) ? 255 : 0;
+		}
+}
+
+using Matx44d = std::array<double, 16>;   // row-major
+inline Matx44d MatMul(const Matx44d& A, const Matx44d& B) {   // cv::Matx product: s = 0; s += a(i,k) * b(k,j)
+	Matx44d C{};
+	for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double s = 0; for (int k = 0; k < 4; ++k) s += A[4 * i + k] * B[4 * k + j]; C[4 * i + j] = s; }
+	return C;
+}
+inline Matx44d InvMat(const Matx44d& M) {   // cConverter::invMat (src/cConverter.cpp:31-44): rigid inverse, t = -(R^T) t
+	Matx44d o{};
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o[4 * i + j] = M[4 * j + i];
+	for (int i = 0; i < 3; ++i) { double s = 0; for (int k = 0; k < 3; ++k) s += -o[4 * i + k] * M[4 * k + 3]; o[4 * i + 3] = s; }
+	o[15] = 1.0;
+	return o;
+}
+inline Matx44d Cayley2Hom(const double c[6]) {   // include/misc.h:132-160, 211-224
+	const double c1 = c[0], c2 = c[1], c3 = c[2], a = c1 * c1, b = c2 * c2, g = c3 * c3, sc = 1.0 / (1.0 + a + b + g);
+	const double R[9] = {1 + a - b - g, 2 * (c1 * c2 - c3), 2 * (c1 * c3 + c2), 2 * (c1 * c2 + c3), 1 - a + b - g, 2 * (c2 * c3 - c1),
+	                     2 * (c1 * c3 - c2), 2 * (c2 * c3 + c1), 1 - a - b + g};
+	Matx44d M{};
+	for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[4 * i + j] = sc * R[3 * i + j]; M[4 * i + 3] = c[3 + i]; }
+	M[15] = 1.0;
+	return M;
+}
+
+// cMultiCamSys_ (include/cam_system_omni.h): calibrations + poses; the projection of many points runs on the GPU in one call
+class cMultiCamSys_ {
+public:
+	std::vector<cCamModelGeneral_> camModels;
+	std::vector<Matx44d> M_c, MtMc, MtMc_inv;
+	Matx44d M_t{};
+	int GetNrCams() const { return (int)camModels.size(); }
+	cCamModelGeneral_& GetCamModelObj(int c) { return camModels[c]; }
+	void Set_M_t(const Matx44d& M) {   // src/cam_system_omni.cpp:184-198
+		M_t = M;
+		MtMc.resize(M_c.size()); MtMc_inv.resize(M_c.size());
+		for (size_t c = 0; c < M_c.size(); ++c) { MtMc[c] = MatMul(M_t, M_c[c]); MtMc_inv[c] = InvMat(MtMc[c]); }
+	}
+	// WorldToCamHom_fast + isPointInMirrorMask(u, v, 0) for n points (point i into camera cam[i]): uv = 2 doubles per point,
+	// flags bit0 = inside the mirror mask, bit1 = behind the camera (src/cam_system_omni.cpp:92-133, src/cam_model_omni.cpp:163-178)
+	void WorldToCamHom_fast(Context& ctx, const double* pts3, const int32_t* cam, int n, double* uv, uint8_t* flags) {
+		std::vector<mcs_ocam> oc;
+		std::vector<const uint8_t*> masks;
+		bool any = false;
+		for (auto& m : camModels) { oc.push_back(m.ocam); masks.push_back(m.mirrorMask0.empty() ? nullptr : m.mirrorMask0.data); any = any || !m.mirrorMask0.empty(); }
+		std::vector<double> M((size_t)GetNrCams() * 16);
+		for (int c = 0; c < GetNrCams(); ++c) std::memcpy(&M[16 * (size_t)c], MtMc_inv[c].data(), 128);
+		mcs_throw(mcs_world_to_cam(ctx.h, M.data(), oc.data(), GetNrCams(), any ? masks.data() : nullptr, pts3, cam, n, MCS_MEM_HOST, uv, flags));
+	}
+};
+
+// cSystem::LoadMCS (src/cSystem.cpp:125-180): MultiCamSys_Calibration.yaml + InteriorOrientationFisheye<c>.yaml, M_t = identity
+inline void LoadMCS(const std::string& path2calibrations, cMultiCamSys_& camSystem) {
+	const auto mcs = ReadSettings(path2calibrations + "/MultiCamSys_Calibration.yaml");
+	const int nrCams = SettingI(mcs, "CameraSystem.nrCams");
+	camSystem.camModels.assign(nrCams, {});
+	camSystem.M_c.assign(nrCams, {});
+	for (int c = 0; c < nrCams; ++c) {
+		double cay[6];
+		for (int p = 1; p < 7; ++p) cay[p - 1] = SettingD(mcs, "CameraSystem.cam" + std::to_string(c + 1) + "_" + std::to_string(p));
+		camSystem.M_c[c] = Cayley2Hom(cay);
+		const auto fs = ReadSettings(path2calibrations + "/InteriorOrientationFisheye" + std::to_string(c) + ".yaml");
+		mcs_ocam& o = camSystem.camModels[c].ocam;
+		std::memset(&o, 0, sizeof(o));
+		const int nrpol = SettingI(fs, "Camera.nrpol"), nrinvpol = SettingI(fs, "Camera.nrinvpol");
+		if (nrpol > MCS_MAX_POLY || nrinvpol > MCS_MAX_POLY) throw std::runtime_error("polynomial degree above MCS_MAX_POLY");
+		for (int i = 0; i < nrpol; ++i) o.p[i] = SettingD(fs, "Camera.a" + std::to_string(i));
+		for (int i = 0; i < nrinvpol; ++i) o.invP[i] = SettingD(fs, "Camera.pol" + std::to_string(i));
+		o.p_deg = nrpol > 5 ? nrpol : 5; o.invP_deg = nrinvpol > 12 ? nrinvpol : 12;   // cv::Mat::zeros(5,1) / zeros(12,1) in the reference
+		o.width = SettingI(fs, "Camera.Iw"); o.height = SettingI(fs, "Camera.Ih");
+		o.c = SettingD(fs, "Camera.c"); o.d = SettingD(fs, "Camera.d"); o.e = SettingD(fs, "Camera.e"); o.u0 = SettingD(fs, "Camera.u0"); o.v0 = SettingD(fs, "Camera.v0");
+		if (SettingI(fs, "Camera.mirrorMask") == 1) CreateMirrorMask0(o, camSystem.camModels[c].mirrorMask0);
+		else { camSystem.camModels[c].mirrorMask0.create(o.height, o.width); std::memset(camSystem.camModels[c].mirrorMask0.data, 1, (size_t)o.width * o.height); }
+	}
+	Matx44d I{}; I[0] = I[5] = I[10] = I[15] = 1.0;
+	camSystem.Set_M_t(I);
+}
+
+// ORBVocabulary (include/cORBVocabulary.h = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) as far as cMultiFrame::ComputeBoW uses it
+class cORBVocabulary {
+public:
+	using BowVector = std::map<unsigned, double>;                       // DBoW2::BowVector
+	using FeatureVector = std::map<unsigned, std::vector<unsigned>>;    // DBoW2::FeatureVector
+	cORBVocabulary(Context& ctx) : ctx_(ctx) {}
+	~cORBVocabulary() { if (h_) mcs_vocabulary_destroy(h_); }
+	cORBVocabulary(const cORBVocabulary&) = delete;
+	cORBVocabulary& operator=(const cORBVocabulary&) = delete;
+	// TemplatedVocabulary::load from the OpenCV-YAML vocabulary file (ThirdParty/DBoW2/DBoW2/TemplatedVocabulary.h:1573-1622)
+	void load(const std::string& path) {
+		std::ifstream f(path);
+		if (!f) throw std::runtime_error("cannot open " + path);
+		std::stringstream ss; ss << f.rdbuf();
+		const std::string t = ss.str();
+		auto intAfter = [&](const std::string& key, size_t from, size_t& pos) { pos = t.find(key, from); return pos == std::string::npos ? -1L : std::strtol(t.c_str() + pos + key.size(), nullptr, 10); };
+		size_t p;
+		m_k = (int)intAfter(" k:", 0, p); m_L = (int)intAfter(" L:", 0, p);   // (" L:" — the header line "%YAML:1.0" also contains "L:")
+		if (intAfter("scoringType:", 0, p) != 0 || intAfter("weightingType:", 0, p) != 0) throw std::runtime_error("only TF_IDF / L1 vocabularies are mirrored");
+		struct N { int id, parent; double w; uint8_t d[32]; };
+		std::vector<N> nodes;
+		size_t pos = t.find("nodes:");
+		const size_t wordsAt = t.find("words:");
+		while (true) {
+			size_t q;
+			N n{};
+			n.id = (int)intAfter("nodeId:", pos, q);
+			if (q == std::string::npos || q > wordsAt) break;
+			n.parent = (int)intAfter("parentId:", q, p);
+			size_t wq = t.find("weight:", q);
+			n.w = std::strtod(t.c_str() + wq + 7, nullptr);
+			size_t dq = t.find('"', wq) + 1;
+			const char* c = t.c_str() + dq;
+			for (int i = 0; i < 32; ++i) { char* e; n.d[i] = (uint8_t)std::strtol(c, &e, 10); c = e; }
+			nodes.push_back(n);
+			pos = t.find('}', dq);
+		}
+		const int nn = (int)nodes.size() + 1;
+		nodeDesc.assign((size_t)nn * 32, 0); weight.assign(nn, 0.0); wordId.assign(nn, -1);
+		std::vector<std::vector<int>> ch(nn);
+		for (auto& n : nodes) { std::memcpy(&nodeDesc[(size_t)n.id * 32], n.d, 32); weight[n.id] = n.w; ch[n.parent].push_back(n.id); }
+		childOff.assign(nn + 1, 0); childIdx.clear();
+		for (int i = 0; i < nn; ++i) { childOff[i + 1] = childOff[i] + (int)ch[i].size(); childIdx.insert(childIdx.end(), ch[i].begin(), ch[i].end()); }
+		pos = wordsAt;
+		while (true) {
+			size_t q;
+			const long wid = intAfter("wordId:", pos, q);
+			if (q == std::string::npos) break;
+			wordId[intAfter("nodeId:", q, p)] = (int)wid;
+			pos = q + 7;
+		}
+		if (h_) { mcs_vocabulary_destroy(h_); h_ = nullptr; }
+		mcs_throw(mcs_vocabulary_create(ctx_.h, nn, nodeDesc.data(), childOff.data(), childIdx.data(), m_L, &h_));
+	}
+	// transform(features, v, fv, levelsup) (:1127-1205, TF_IDF weighting, L1 scoring): descriptors = n rows of `stride` >= 32 bytes
+	void transform(const uint8_t* descriptors, int n, int stride, BowVector& v, FeatureVector& fv, int levelsup) {
+		v.clear(); fv.clear();
+		if (!h_ || n <= 0) return;
+		std::vector<int32_t> leaf(n), nid(n);
+		mcs_throw(mcs_bow_transform(h_, descriptors, n, stride, levelsup, MCS_MEM_HOST, leaf.data(), nid.data()));
+		for (int i = 0; i < n; ++i) {
+			const double w = weight[leaf[i]];
+			if (w > 0) { v[(unsigned)wordId[leaf[i]]] += w; fv[(unsigned)nid[i]].push_back((unsigned)i); }
+		}
+		double norm = 0.0;
+		for (auto& e : v) norm += std::fabs(e.second);
+		if (norm > 0.0) for (auto& e : v) e.second /= norm;
+	}
+	int m_k = 0, m_L = 0;
+	std::vector<uint8_t> nodeDesc; std::vector<int32_t> childOff, childIdx, wordId; std::vector<double> weight;
+private:
+	Context& ctx_;
+	mcs_vocabulary* h_ = nullptr;
+};
+
+// cMapPoint::ComputeDistinctiveDescriptors (src/cMapPoint.cpp:294-382) for a batch: offsets = CSR rows of the observed descriptors
+inline void ComputeDistinctiveDescriptors(Context& ctx, const uint8_t* desc, const uint8_t* mask, int stride, int dim, const std::vector<int32_t>& offsets,
+                                          std::vector<int32_t>& bestIdx) {
+	const int np = (int)offsets.size() - 1;
+	bestIdx.assign(np > 0 ? np : 0, -1);
+	if (np > 0) mcs_throw(mcs_distinctive_descriptors(ctx.h, desc, mask, stride, dim, offsets.data(), np, MCS_MEM_HOST, bestIdx.data()));
+}
+
 // flat view of a (multi-)keyframe / frame as the brute-force searches see it: all cameras concatenated in mvKeys order
 struct FeatureSetView {
 	const uint8_t* descriptors = nullptr;   // n x dim
@@ -220,6 +424,48 @@ public:
 		const int nm = window(MCS_WINDOW_BEST, p, LastFrame, CurrentFrame, m);
 		matchCur.assign(CurrentFrame.n, -1);
 		for (size_t k = 0; k < m.size(); ++k) if (m[k] >= 0) matchCur[m[k]] = p.src[k];
+		return nm;
+	}
+
+	// SearchByProjection(F, vpMapPoints, th) (:67-166): one projection per (map point, camera) with mbTrackInView, in the reference's order;
+	// match[p] = frame feature or -1; F.hasMapPoint is updated.
+	struct Projections { std::vector<double> x, y, viewCos; std::vector<int32_t> level, cam; const uint8_t* desc = nullptr; const uint8_t* mask = nullptr; };
+	int SearchByProjection(FrameGridView& F, const Projections& mp, double th, std::vector<int>& match) {
+		const int n = (int)mp.x.size();
+		mcs_projection_set ps{mp.x.data(), mp.y.data(), mp.viewCos.data(), mp.level.data(), mp.cam.data(), mp.desc, havingMasks ? mp.mask : nullptr, n, mbFeatDim};
+		mcs_frame_view fv{reinterpret_cast<const mcs_keypoint*>(F.mvKeys), F.descriptors, havingMasks ? F.masks : nullptr, F.keypoint_to_cam.data(),
+		                  F.hasMapPoint.data(), F.n, mbFeatDim, (int32_t)F.width.size(), F.width.data(), F.height.data(), F.mvScaleFactors.data(),
+		                  (int32_t)F.mvScaleFactors.size()};
+		match.assign(n > 0 ? n : 1, -1);
+		int32_t nm = 0;
+		mcs_throw(mcs_search_by_projection(ctx_.h, &ps, &fv, th, mfNNratio, mbFeatDim, MCS_MEM_HOST, match.data(), &nm));
+		match.resize(n);
+		return nm;
+	}
+	// The search loop of Fuse / SearchBySim3 / SearchForTriangulationBetweenCameras (skipTaken = false) and of the relocalisation
+	// SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (skipTaken = true): closest feature per window, accepted if <= maxDist.
+	struct Windows { std::vector<double> x, y, r; std::vector<int32_t> lo, hi, cam; const uint8_t* desc = nullptr; const uint8_t* mask = nullptr; };
+	int BestInWindows(FrameGridView& F, const Windows& w, int maxDist, bool skipTaken, std::vector<int>& match, std::vector<int>& dist) {
+		const int n = (int)w.x.size();
+		mcs_window_probes pr{w.x.data(), w.y.data(), w.r.data(), w.lo.data(), w.hi.data(), w.cam.data(), w.desc, havingMasks ? w.mask : nullptr, n, mbFeatDim};
+		mcs_frame_view fv{reinterpret_cast<const mcs_keypoint*>(F.mvKeys), F.descriptors, havingMasks ? F.masks : nullptr, F.keypoint_to_cam.data(),
+		                  skipTaken ? F.hasMapPoint.data() : nullptr, F.n, mbFeatDim, (int32_t)F.width.size(), F.width.data(), F.height.data(),
+		                  F.mvScaleFactors.data(), (int32_t)F.mvScaleFactors.size()};
+		match.assign(n > 0 ? n : 1, -1); dist.assign(n > 0 ? n : 1, 0);
+		int32_t nm = 0;
+		mcs_throw(mcs_window_best(ctx_.h, &pr, &fv, maxDist, skipTaken ? 1 : 0, mbFeatDim, MCS_MEM_HOST, match.data(), dist.data(), &nm));
+		match.resize(n); dist.resize(n);
+		return nm;
+	}
+	// SearchByBoW(pKF, F, ...) WITH the vocabulary (:179-323): kf rows must be given in FeatureVector order (node ascending, index ascending),
+	// `cam` of both views carries the FeatureVector node id (frame features of stopped words: flag 0).  matchF[j] = kf row or -1.
+	int SearchByBoWFrameVocabulary(const FeatureSetView& kfInNodeOrder, const FeatureSetView& frame, std::vector<int>& matchF) {
+		mcs_desc_set q{kfInNodeOrder.descriptors, havingMasks ? kfInNodeOrder.masks : nullptr, kfInNodeOrder.flag.data(), kfInNodeOrder.cam.data(), kfInNodeOrder.n, mbFeatDim};
+		mcs_desc_set t{frame.descriptors, havingMasks ? frame.masks : nullptr, frame.flag.empty() ? nullptr : frame.flag.data(), frame.cam.data(), frame.n, mbFeatDim};
+		matchF.assign(frame.n > 0 ? frame.n : 1, -1);
+		int32_t nm = 0, fb = 0;
+		mcs_throw(mcs_search_kf_f(ctx_.h, 1, &q, 0, &t, 0, mbFeatDim, mfNNratio, K_, MCS_MEM_HOST, matchF.data(), &nm, &fb));
+		matchF.resize(frame.n);
 		return nm;
 	}
 

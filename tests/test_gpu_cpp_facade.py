@@ -76,3 +76,118 @@ def test_cpp_facade_end_to_end(tmp_path):
     en, e12, ep = O.search_for_initialization(v[0][0], v[1][0], p0, 50, 0.9, 32, True)
     assert ni == en and np.array_equal(i12, e12) and np.array_equal(prev, ep) and ni > 100
     assert off[0] == len(buf)
+
+
+def test_cpp_facade_callers_and_mapping_side(tmp_path):
+    """facade_driver2.cpp: LoadMCS from the reference's YAML layout, ComputeBoW, WorldToCamHom_fast, SearchByProjection(F, mapPoints), the
+    Fuse / SearchBySim3 window loop, ComputeDistinctiveDescriptors and the vocabulary-restricted SearchByBoW — all through the C++ classes."""
+    import importlib
+    import gpu_common as G
+    import test_io_formats as T
+    import vocab_synth
+    O = G.O
+    io = importlib.import_module("multicol-slam_amd.io")
+    cams = G.cams3()
+    ncam, w, h = 3, 754, 480
+    d = str(tmp_path)
+    T.write_lafida_dir(d, cams, T.CAYLEY)
+    vocab_synth.write_vocabulary(d + "/voc.yml", k=9, L=5, seed=3)
+    imgs = [G.synth.synth_multiframe(f, cams) for f in range(2)]
+    with open(d + "/frames.bin", "wb") as f:
+        for fr in imgs:
+            for im in fr:
+                f.write(np.ascontiguousarray(im, np.uint8).tobytes())
+    exe = tmp_path / "facade_driver2"
+    lib_dir = os.path.join(ROOT, "multicol-slam_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "facade_driver2.cpp"),
+                           "-o", str(exe), "-L" + lib_dir, "-lmcs_hip", "-Wl,-rpath," + lib_dir])
+    subprocess.check_call([str(exe), d, d + "/out.bin"])
+    buf = open(d + "/out.bin", "rb").read()
+    off = [0]
+
+    def take(dtype, n):
+        a = np.frombuffer(buf, dtype, n, off[0]).copy()
+        off[0] += a.nbytes
+        return a
+
+    def takev(dtype):
+        return take(dtype, int(take(np.int32, 1)[0]))
+
+    # --- LoadMCS
+    rig = io.LoadMCS(d)
+    masks = [G.synth.mirror_mask(c) for c in cams]
+    for c in range(ncam):
+        oc = take(np.uint8, 320)
+        assert oc.tobytes() == bytes(G.mcs.make_ocam(rig.GetCamModelObj(c).calib))
+        assert np.array_equal(take(np.float64, 16).reshape(4, 4), rig.M_c[c])
+        assert int(take(np.int64, 1)[0]) == int(masks[c].astype(np.int64).sum())
+    Mt = np.eye(4)
+    Mt[0, 3], Mt[1, 3], Mt[2, 3], Mt[0, 1], Mt[1, 0] = 0.02, -0.01, 0.03, 1e-3, -1e-3
+    rig.Set_M_t(Mt)
+    for c in range(ncam):
+        assert np.array_equal(take(np.float64, 16).reshape(4, 4), rig.MtMc_inv[c])
+    # --- extraction (600 features, mdBRIEF)
+    fr = []
+    for f in range(2):
+        cam = takev(np.int32)
+        n = len(cam)
+        keys, dd, mm = take(O.KP_DTYPE, n), take(np.uint8, n * 32).reshape(n, 32), take(np.uint8, n * 32).reshape(n, 32)
+        s, rays = 0, []
+        for c in range(ncam):
+            _, ek, ed, em, er = G.oracle_extract(imgs[f][c], masks[c], cams[c], nfeatures=600, do_dBrief=1, learnMasks=1)
+            k = int((cam == c).sum())
+            assert k == len(ek) and G.first_diff(keys[s:s + k], ek) is None and G.first_diff(dd[s:s + k], ed) is None and G.first_diff(mm[s:s + k], em) is None
+            rays.append(er)
+            s += k
+        fr.append((cam, keys, dd, mm, np.concatenate(rays)))
+    n0, n1 = len(fr[0][1]), len(fr[1][1])
+    # --- ComputeBoW
+    vd = io.load_vocabulary(d + "/voc.yml")
+    node = []
+    for f in range(2):
+        nd, ids, vals = takev(np.int32), takev(np.int32), takev(np.float64)
+        leaf, nid = O.bow_transform(vd, fr[f][2], 4)
+        wts = vd["weight"][leaf]
+        assert np.array_equal(nd, np.where(wts > 0, nid, -1))
+        bow = {}
+        for lf, wv in zip(leaf, wts):
+            if wv > 0:
+                bow[int(vd["word_id"][lf])] = bow.get(int(vd["word_id"][lf]), 0.0) + float(wv)
+        norm = 0.0
+        for k in sorted(bow):
+            norm += abs(bow[k])
+        assert list(ids) == sorted(bow) and np.array_equal(vals, np.array([bow[k] / norm for k in sorted(bow)]))
+        node.append(nd)
+    # --- WorldToCamHom_fast
+    pts, uv, fl = take(np.float64, 3 * n0).reshape(n0, 3), take(np.float64, 2 * n0).reshape(n0, 2), take(np.uint8, n0)
+    epts = np.stack([(rig.MtMc[int(c)] @ np.append(r * 2.5, 1.0))[:3] for c, r in zip(fr[0][0], fr[0][4])])
+    assert np.allclose(pts, epts, rtol=0, atol=1e-12)
+    euv, efl = O.world_to_cam(np.stack(rig.MtMc_inv), cams, masks, pts, fr[0][0])
+    assert np.allclose(uv, euv, rtol=0, atol=1e-9) and np.array_equal(fl, efl) and (fl & 1).mean() > 0.9
+    # --- SearchByProjection(F, mapPoints, 3.0)
+    v1, _k = O.frame_view(fr[1][1], fr[1][2], fr[1][3], fr[1][0], [w] * ncam, [h] * ncam)
+    sc = np.float64(np.float32(1.2)) ** 0 * np.cumprod([1.0] + [float(np.float32(1.2))] * 7)
+    nm, m = int(take(np.int32, 1)[0]), takev(np.int32)
+    pre, post = take(np.uint8, n1), take(np.uint8, n1)
+    px, py = fr[0][1]["x"].astype(np.float64) + 3.0, fr[0][1]["y"].astype(np.float64) + 1.0
+    vc = np.where(np.arange(n0) % 3 != 0, 0.9995, 0.9)
+    asg = pre.copy()
+    en, em = O.search_by_projection(px, py, vc, fr[0][1]["octave"].astype(np.int32), fr[0][0], fr[0][2], fr[0][3], np.ascontiguousarray(fr[1][1]), fr[1][2], fr[1][3],
+                                    fr[1][0], asg, np.array([w] * ncam, np.int32), np.array([h] * ncam, np.int32), sc, 3.0, 0.8, True)
+    assert nm == en and np.array_equal(m, em) and np.array_equal(post, asg) and nm > 100
+    # --- best-in-window loop
+    nm, bm, bd = int(take(np.int32, 1)[0]), takev(np.int32), takev(np.int32)
+    o = fr[0][1]["octave"].astype(np.int32)
+    en, em, ed, _ = O.window_best(px, py, 8.0 * sc[o], o - 1, o, fr[0][0], fr[0][2], fr[0][3], v1, None, 32, False, 32, True)
+    assert nm == en and np.array_equal(bm, em) and np.array_equal(bd, ed) and nm > 100
+    # --- ComputeDistinctiveDescriptors
+    offs, best = takev(np.int32), takev(np.int32)
+    assert offs[-1] == n0 and len(best) == len(offs) - 1
+    exp = [O.distinctive_descriptor(fr[0][2][a:b], fr[0][3][a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    assert list(best) == exp
+    # --- vocabulary-restricted SearchByBoW
+    nm, mF = int(take(np.int32, 1)[0]), takev(np.int32)
+    valid = (np.arange(n0) % 5 != 0).astype(np.uint8)
+    en, em = O.search_kf_f_bow(fr[0][2], fr[0][3], valid, node[0], fr[1][2], fr[1][3], node[1], True, 0.8)
+    assert nm == en and np.array_equal(mF, em) and nm > 30
+    assert off[0] == len(buf)
