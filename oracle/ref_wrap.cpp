@@ -1,0 +1,81 @@
+// ref_wrap.cpp — TEST INFRASTRUCTURE: C entry point around the REFERENCE's own mdBRIEFextractorOct (compiled from /root/reference/src, unmodified,
+// against oracle/cvshim).  Used by tests/test_oracle_vs_ref.py and tools/gen_golden_ref.py to pin the oracle's restatement.
+#include "mdBRIEFextractorOct.h"
+#include "cam_model_omni.h"
+
+using namespace MultiColSLAM;
+
+// The reference's DistributeOctTree breaks ties between equally full nodes by comparing the HEAP ADDRESSES of its std::list nodes
+// (sort of pair<int, ExtractorNode*>, src/mdBRIEFextractorOct.cpp:745-760), so its output depends on the allocator.  Inside this library every
+// allocation made during a ref_extract call comes from a bump arena (monotonically increasing addresses, nothing reused), which makes "pointer
+// order" = "creation order" — the order the oracle (and the GPU oct-tree) use for the same tie.  Linked with -Bsymbolic: only this .so is affected.
+#include <cstdlib>
+#include <new>
+namespace {
+char* g_arena = nullptr; size_t g_cap = 0, g_used = 0; bool g_on = false;
+void* bump(size_t n) {
+	n = (n + 15) & ~size_t(15);
+	if (!g_on || g_used + n > g_cap) return std::malloc(n);
+	void* p = g_arena + g_used; g_used += n; return p;
+}
+bool in_arena(void* p) { return (char*)p >= g_arena && (char*)p < g_arena + g_cap; }
+struct ArenaScope {
+	ArenaScope() { if (!g_arena) { g_cap = size_t(1) << 30; g_arena = (char*)std::malloc(g_cap); } g_used = 0; g_on = true; }
+	~ArenaScope() { g_on = false; }
+};
+}  // namespace
+void* operator new(size_t n) { void* p = bump(n); if (!p) throw std::bad_alloc(); return p; }
+void* operator new[](size_t n) { void* p = bump(n); if (!p) throw std::bad_alloc(); return p; }
+void operator delete(void* p) noexcept { if (p && !in_arena(p)) std::free(p); }
+void operator delete[](void* p) noexcept { if (p && !in_arena(p)) std::free(p); }
+void operator delete(void* p, size_t) noexcept { if (p && !in_arena(p)) std::free(p); }
+void operator delete[](void* p, size_t) noexcept { if (p && !in_arena(p)) std::free(p); }
+
+extern "C" int ref_extract(const orc_params* p, const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride, const orc_ocam* cam,
+                           orc_keypoint* kps, int cap, uint8_t* desc, uint8_t* dmask) {
+	try {
+		ArenaScope arena;   // everything below (and all its temporaries) dies before this scope ends
+		cv::Mat_<double> poly(cam->p_deg, 1), invpoly(cam->invP_deg, 1);
+		for (int i = 0; i < cam->p_deg; ++i) poly.at<double>(i, 0) = cam->p[i];
+		for (int i = 0; i < cam->invP_deg; ++i) invpoly.at<double>(i, 0) = cam->invP[i];
+		double cdeu0v0[5] = {cam->c, cam->d, cam->e, cam->u0, cam->v0};
+		cCamModelGeneral_ camModel(cdeu0v0, poly, invpoly, cam->width, cam->height);
+		mdBRIEFextractorOct ex(p->nfeatures, p->scaleFactor, p->nlevels, p->edgeThreshold, p->firstLevel, p->scoreType, p->patchSize, p->fastThreshold,
+		                       p->useAgast != 0, p->fastAgastType, p->do_dBrief != 0, p->learnMasks != 0, p->descSize);
+		cv::Mat image(h, w, CV_8UC1, (void*)img, (size_t)stride), m;
+		if (mask) m = cv::Mat(h, w, CV_8UC1, (void*)mask, (size_t)mstride);
+		std::vector<cv::KeyPoint> keys;
+		cv::Mat descriptors, descriptorMasks;
+		ex(image, m, keys, camModel, descriptors, descriptorMasks);
+		const int n = (int)keys.size();
+		if (n > cap) return -2;
+		for (int i = 0; i < n; ++i) {
+			kps[i].x = keys[i].pt.x; kps[i].y = keys[i].pt.y; kps[i].size = keys[i].size; kps[i].angle = keys[i].angle; kps[i].response = keys[i].response;
+			kps[i].octave = keys[i].octave; kps[i].class_id = keys[i].class_id;
+			std::memcpy(desc + (size_t)i * p->descSize, descriptors.ptr<uchar>(i), p->descSize);
+			std::memcpy(dmask + (size_t)i * p->descSize, descriptorMasks.ptr<uchar>(i), p->descSize);
+		}
+		return n;
+	} catch (const std::exception& e) {
+		std::cerr << "ref_extract: " << e.what() << std::endl;
+		return -1;
+	}
+}
+
+extern "C" void ref_world2img(const orc_ocam* cam, double x, double y, double z, double* u, double* v) {
+	cv::Mat_<double> poly(cam->p_deg, 1), invpoly(cam->invP_deg, 1);
+	for (int i = 0; i < cam->p_deg; ++i) poly.at<double>(i, 0) = cam->p[i];
+	for (int i = 0; i < cam->invP_deg; ++i) invpoly.at<double>(i, 0) = cam->invP[i];
+	double cdeu0v0[5] = {cam->c, cam->d, cam->e, cam->u0, cam->v0};
+	cCamModelGeneral_ camModel(cdeu0v0, poly, invpoly, cam->width, cam->height);
+	camModel.WorldToImg(x, y, z, *u, *v);
+}
+
+extern "C" void ref_img2world(const orc_ocam* cam, double u, double v, double* x, double* y, double* z) {
+	cv::Mat_<double> poly(cam->p_deg, 1), invpoly(cam->invP_deg, 1);
+	for (int i = 0; i < cam->p_deg; ++i) poly.at<double>(i, 0) = cam->p[i];
+	for (int i = 0; i < cam->invP_deg; ++i) invpoly.at<double>(i, 0) = cam->invP[i];
+	double cdeu0v0[5] = {cam->c, cam->d, cam->e, cam->u0, cam->v0};
+	cCamModelGeneral_ camModel(cdeu0v0, poly, invpoly, cam->width, cam->height);
+	camModel.ImgToWorld(*x, *y, *z, u, v);
+}
