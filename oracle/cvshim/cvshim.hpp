@@ -11,8 +11,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <fstream>
 #include <iostream>
+#include <map>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -23,6 +26,7 @@ typedef unsigned char uchar;
 typedef unsigned short ushort;
 
 #define CV_8U 0
+#define CV_32F 5
 #define CV_64F 6
 #define CV_8UC1 0
 #define CV_64FC1 6
@@ -128,7 +132,7 @@ public:
 	Mat(int r, int c, int type) { create(r, c, type); }
 	Mat(Size sz, int type) { create(sz.height, sz.width, type); }
 	Mat(int r, int c, int type, void* ext, size_t st = 0) : flags_type(type), rows(r), cols(c), step(st ? st : (size_t)c * esz(type)), data((uchar*)ext), wholeRows(r), wholeCols(c) {}
-	static size_t esz(int type) { return type == CV_64F ? 8 : 1; }
+	static size_t esz(int type) { return type == CV_64F ? 8 : (type == CV_32F ? 4 : 1); }
 	void create(int r, int c, int type) {
 		if (data && rows == r && cols == c && flags_type == type) return;   // cv::Mat::create keeps a matching allocation (copyMakeBorder relies on it)
 		flags_type = type; rows = r; cols = c; step = (size_t)c * esz(type);
@@ -282,6 +286,88 @@ inline void FAST(const Mat& image, std::vector<KeyPoint>& keypoints, int thresho
 struct KeyPointsFilter {
 	static void retainBest(std::vector<KeyPoint>& k, int n) {   // only reached from the reference's unused ComputeKeyPointsOld path
 		if (n >= 0 && (int)k.size() > n) { std::stable_sort(k.begin(), k.end(), [](const KeyPoint& a, const KeyPoint& b) { return a.response > b.response; }); k.resize(n); } }
+};
+
+// ---------------------------------------------------------------------------------------------- FileStorage (READ of the DBoW2 vocabulary layout)
+// Just enough for DBoW2::TemplatedVocabulary::load (ThirdParty/DBoW2/DBoW2/TemplatedVocabulary.h:1573-1622): a top-level map with scalar
+// entries and two sequences of one-line / two-line flow maps ("- { key:value, key:value, key:\"string\" }").  Writing is a no-op.
+class FileNode {
+public:
+	struct Data { std::string scalar; std::vector<std::pair<std::string, FileNode>> map; std::vector<FileNode> seq; };
+	std::shared_ptr<Data> d;
+	FileNode() : d(std::make_shared<Data>()) {}
+	FileNode operator[](const std::string& k) const { for (auto& e : d->map) if (e.first == k) return e.second; return FileNode(); }
+	FileNode operator[](const char* k) const { return (*this)[std::string(k)]; }
+	FileNode operator[](int i) const { return d->seq[i]; }
+	size_t size() const { return d->seq.size(); }
+	operator int() const { return (int)std::strtol(d->scalar.c_str(), nullptr, 10); }
+	operator float() const { return (float)std::strtod(d->scalar.c_str(), nullptr); }
+	operator double() const { return std::strtod(d->scalar.c_str(), nullptr); }
+	operator std::string() const { return d->scalar; }
+};
+class FileStorage {
+public:
+	enum { READ = 0, WRITE = 1 };
+	FileNode root; bool opened = false;
+	FileStorage() {}
+	FileStorage(const std::string& filename, int flags) { if (flags == READ) opened = parse(filename); }
+	bool isOpened() const { return opened; }
+	void release() {}
+	FileNode operator[](const std::string& k) const { return root[k]; }
+	FileNode operator[](const char* k) const { return root[std::string(k)]; }
+	template <class T> FileStorage& operator<<(const T&) { return *this; }
+private:
+	static std::string trim(const std::string& v) { const size_t a = v.find_first_not_of(" \t\r\n"), b = v.find_last_not_of(" \t\r\n"); return a == std::string::npos ? std::string() : v.substr(a, b - a + 1); }
+	static FileNode flow_map(const std::string& body) {   // key:value pairs separated by commas outside quotes
+		FileNode n;
+		size_t i = 0;
+		while (i < body.size()) {
+			const size_t c = body.find(':', i);
+			if (c == std::string::npos) break;
+			const std::string key = trim(body.substr(i, c - i));
+			size_t j = c + 1;
+			while (j < body.size() && (body[j] == ' ' || body[j] == '\n' || body[j] == '\r' || body[j] == '\t')) ++j;
+			std::string val;
+			if (j < body.size() && body[j] == '"') { const size_t e = body.find('"', j + 1); val = body.substr(j + 1, e - j - 1); j = body.find(',', e); }
+			else { const size_t e = body.find(',', j); val = trim(body.substr(j, (e == std::string::npos ? body.size() : e) - j)); j = e; }
+			FileNode s; s.d->scalar = val;
+			n.d->map.emplace_back(key, s);
+			if (j == std::string::npos) break;
+			i = j + 1;
+		}
+		return n;
+	}
+	bool parse(const std::string& filename) {
+		std::ifstream f(filename);
+		if (!f) return false;
+		std::stringstream ss; ss << f.rdbuf();
+		const std::string t = ss.str();
+		// top-level "name:" line, then "   key: value" scalars, then "   key:" sequences of "- { ... }"
+		size_t pos = t.find('\n');   // skip %YAML header
+		FileNode top, *cur = nullptr;
+		std::string topName;
+		std::vector<FileNode>* seq = nullptr;
+		while (pos != std::string::npos && pos < t.size()) {
+			size_t e = t.find('\n', pos + 1);
+			std::string line = t.substr(pos + 1, (e == std::string::npos ? t.size() : e) - pos - 1);
+			const std::string tl = trim(line);
+			if (tl.empty() || tl[0] == '#') { pos = e; continue; }
+			if (tl[0] == '-') {   // sequence element, may span lines until the closing brace
+				size_t ob = t.find('{', pos), cb = t.find('}', ob);
+				if (seq) seq->push_back(flow_map(t.substr(ob + 1, cb - ob - 1)));
+				pos = t.find('\n', cb);
+				continue;
+			}
+			const size_t c = tl.find(':');
+			const std::string key = trim(tl.substr(0, c)), val = trim(tl.substr(c + 1));
+			if (line[0] != ' ') { topName = key; cur = &top; seq = nullptr; }
+			else if (val.empty()) { FileNode s; cur->d->map.emplace_back(key, s); seq = &cur->d->map.back().second.d->seq; }
+			else { FileNode s; s.d->scalar = val; cur->d->map.emplace_back(key, s); seq = nullptr; }
+			pos = e;
+		}
+		root.d->map.emplace_back(topName, top);
+		return true;
+	}
 };
 
 }  // namespace cv

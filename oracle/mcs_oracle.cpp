@@ -17,6 +17,9 @@
  *       addresses (oracle/_ref runs it on such an arena and then agrees exactly).
  *   (2) descriptor samples that fall outside the 25-px bordered level buffer (out-of-bounds read in the
  *       reference) are clamped to the buffer.
+ *   (3) DBoW2 transform: a feature whose path reaches a leaf ABOVE the FeatureVector level leaves `nid` uninitialised in the reference
+ *       (TemplatedVocabulary.h:1147-1158, 1229-1251: in practice the previous feature's node) -> 0 (root) here.  Never happens with the
+ *       shipped vocabulary at levelsup = 4 (its shallowest leaf is at depth 3, the FeatureVector level is 2).
  * Build: g++ -O3 -march=native -ffp-contract=off -fopenmp (reference flags CMakeLists.txt:37-38 + no FMA contraction).
  */
 #include "mcs_oracle.h"

@@ -79,3 +79,26 @@ extern "C" void ref_img2world(const orc_ocam* cam, double u, double v, double* x
 	cCamModelGeneral_ camModel(cdeu0v0, poly, invpoly, cam->width, cam->height);
 	camModel.ImgToWorld(*x, *y, *z, u, v);
 }
+
+// ---------------------------------------------------------------- DBoW2 (ThirdParty/DBoW2, compiled unmodified): vocabulary load + transform
+#include "cORBVocabulary.h"
+
+// descriptors: n rows of 32 bytes.  Outputs: node id per feature (-1 if the feature is not in the FeatureVector), the BowVector as (ids, values)
+// up to cap entries (returns its size), vocabulary size in *nnodes_words[0..1].
+extern "C" int ref_bow_transform(const char* vocPath, const uint8_t* desc, int n, int levelsup, int* node, int* bowIds, double* bowVals, int cap, int* info) {
+	try {
+		ORBVocabulary voc;
+		voc.load(std::string(vocPath));
+		std::vector<cv::Mat> feats;
+		for (int i = 0; i < n; ++i) feats.push_back(cv::Mat(1, 32, CV_8U, (void*)(desc + 32 * (size_t)i)));
+		DBoW2::BowVector bv; DBoW2::FeatureVector fv;
+		voc.transform(feats, bv, fv, levelsup);
+		for (int i = 0; i < n; ++i) node[i] = -1;
+		for (auto& e : fv) for (unsigned i : e.second) node[i] = (int)e.first;
+		int k = 0;
+		for (auto& e : bv) { if (k < cap) { bowIds[k] = (int)e.first; bowVals[k] = e.second; } ++k; }
+		info[0] = (int)voc.size(); info[1] = voc.getBranchingFactor(); info[2] = voc.getDepthLevels();
+		return k;
+	} catch (const std::exception& e) { std::cerr << "ref_bow_transform: " << e.what() << std::endl; return -1; }
+	catch (const std::string& e) { std::cerr << "ref_bow_transform: " << e << std::endl; return -1; }
+}

@@ -79,3 +79,51 @@ def test_camera_model_equals_reference_code():
             ref.ref_img2world(C.byref(oc), u, v, *[C.byref(q) for q in r[:3]])
             L.orc_img2world(C.byref(oc), u, v, *[C.byref(q) for q in r[3:]])
             assert [q.value for q in r[:3]] == [q.value for q in r[3:]]
+
+
+def _expected_maps(vd, desc, levelsup):
+    """BowVector / FeatureVector from the ORACLE's descent with DBoW2's map arithmetic (TF_IDF + L1)"""
+    leaf, nid = O.bow_transform(vd, desc, levelsup)
+    bow, node = {}, np.full(len(desc), -1, np.int32)
+    for i, (lf, nd) in enumerate(zip(leaf, nid)):
+        w = float(vd["weight"][lf])
+        if w > 0:
+            wid = int(vd["word_id"][lf])
+            bow[wid] = bow.get(wid, 0.0) + w
+            node[i] = nd
+    norm = 0.0
+    for k in sorted(bow):
+        norm += abs(bow[k])
+    return node, [(k, bow[k] / norm) for k in sorted(bow)]
+
+
+@have_ref
+@pytest.mark.parametrize("which", ["synthetic", "shipped"])
+def test_bow_transform_equals_dbow2_code(which, tmp_path):
+    """DBoW2 (ThirdParty/DBoW2, compiled unmodified into oracle/_ref): TemplatedVocabulary::load + transform vs the vocabulary loader of
+    multicol-slam_amd.io + the oracle's descent + the host-side map arithmetic."""
+    import vocab_synth
+    io = importlib.import_module("multicol-slam_amd.io")
+    if which == "shipped":
+        path = "/root/reference/Examples/small_orb_omni_voc_9_6.yml"
+        if not os.path.exists(path):
+            pytest.skip("reference checkout not present")
+    else:
+        path = str(tmp_path / "voc.yml")
+        vocab_synth.write_vocabulary(path, k=9, L=5, seed=3)
+    vd = io.load_vocabulary(path)
+    rng = np.random.default_rng(4)
+    desc = rng.integers(0, 256, (3000, 32), dtype=np.uint8)
+    desc[:500] = vd["node_desc"][1:501]          # exact node descriptors (distance 0 / ties)
+    ref = C.CDLL(REF_SO)
+    ref.ref_bow_transform.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    # levels at or above the shallowest leaf only: below it the reference leaves `nid` UNINITIALISED when a feature's path ends early
+    # (NodeId nid; in the caller's loop, TemplatedVocabulary.h:1147-1158 -> the previous feature's value in practice); oracle and GPU return 0 there
+    for levelsup in (4, 3, 7):
+        node = np.zeros(len(desc), np.int32)
+        ids, vals, info = np.zeros(8000, np.int32), np.zeros(8000, np.float64), np.zeros(3, np.int32)
+        k = ref.ref_bow_transform(path.encode(), desc.ctypes.data, len(desc), levelsup, node.ctypes.data, ids.ctypes.data, vals.ctypes.data, 8000, info.ctypes.data)
+        assert k > 0 and list(info) == [vd["n_words"], vd["k"], vd["L"]]
+        enode, ebow = _expected_maps(vd, desc, levelsup)
+        assert np.array_equal(node, enode)
+        assert k == len(ebow) and list(ids[:k]) == [b[0] for b in ebow] and np.array_equal(vals[:k], np.array([b[1] for b in ebow]))
