@@ -20,6 +20,8 @@
 #include <string>
 #include <vector>
 
+#include <Eigen/Dense>
+
 #include "../mcs_oracle.h"
 
 typedef unsigned char uchar;
@@ -78,6 +80,24 @@ template <class T, int m, int n> struct Matx {
 	Matx(T a, T b, T c, T d, T e, T f, T g, T h, T i_) : Matx() { T v[9] = {a, b, c, d, e, f, g, h, i_}; for (int i = 0; i < 9; ++i) val[i] = v[i]; }
 	Matx(T a, T b, T c, T d, T e, T f, T g, T h, T i_, T j, T k, T l, T m_, T n_, T o, T p) : Matx() {
 		T v[16] = {a, b, c, d, e, f, g, h, i_, j, k, l, m_, n_, o, p}; for (int i = 0; i < 16; ++i) val[i] = v[i]; }
+	static Matx zeros() { return Matx(); }
+	static Matx all(T v) { Matx r; for (int i = 0; i < m * n; ++i) r.val[i] = v; return r; }
+	static Matx ones() { return all(T(1)); }
+	T dot(const Matx& o) const { T s = 0; for (int i = 0; i < m * n; ++i) s += val[i] * o.val[i]; return s; }
+	Matx inv() const {   // Gauss-Jordan with partial pivoting (square matrices; only small calibration algebra reaches this)
+		static_assert(m == n, "inv of a square matrix");
+		T a[m][2 * m];
+		for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) { a[i][j] = val[i * n + j]; a[i][m + j] = i == j ? T(1) : T(0); }
+		for (int c = 0; c < m; ++c) {
+			int p = c; for (int r = c + 1; r < m; ++r) if (std::fabs(a[r][c]) > std::fabs(a[p][c])) p = r;
+			for (int j = 0; j < 2 * m; ++j) std::swap(a[c][j], a[p][j]);
+			const T d = a[c][c];
+			for (int j = 0; j < 2 * m; ++j) a[c][j] /= d;
+			for (int r = 0; r < m; ++r) if (r != c) { const T f = a[r][c]; for (int j = 0; j < 2 * m; ++j) a[r][j] -= f * a[c][j]; }
+		}
+		Matx r; for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) r.val[i * n + j] = a[i][m + j];
+		return r;
+	}
 	static Matx eye() { Matx r; for (int i = 0; i < (m < n ? m : n); ++i) r.val[i * n + i] = T(1); return r; }
 	T& operator()(int i, int j) { return val[i * n + j]; }
 	const T& operator()(int i, int j) const { return val[i * n + j]; }
@@ -92,6 +112,7 @@ template <class T, int m, int n> Matx<T, m, n> operator*(T s, const Matx<T, m, n
 template <class T, int m, int n> Matx<T, m, n> operator+(const Matx<T, m, n>& a, const Matx<T, m, n>& b) { Matx<T, m, n> r; for (int i = 0; i < m * n; ++i) r.val[i] = a.val[i] + b.val[i]; return r; }
 template <class T, int m, int n> Matx<T, m, n> operator-(const Matx<T, m, n>& a, const Matx<T, m, n>& b) { Matx<T, m, n> r; for (int i = 0; i < m * n; ++i) r.val[i] = a.val[i] - b.val[i]; return r; }
 template <class T, int m, int n> Matx<T, m, n> operator-(const Matx<T, m, n>& a) { Matx<T, m, n> r; for (int i = 0; i < m * n; ++i) r.val[i] = -a.val[i]; return r; }
+typedef Matx<double, 2, 2> Matx22d; typedef Matx<double, 3, 4> Matx34d; typedef Matx<double, 2, 1> Matx21d; typedef Matx<double, 4, 1> Matx41d;
 typedef Matx<double, 3, 3> Matx33d; typedef Matx<double, 4, 4> Matx44d; typedef Matx<double, 3, 1> Matx31d; typedef Matx<double, 6, 1> Matx61d;
 
 template <class T, int cn> struct Vec : Matx<T, cn, 1> {
@@ -103,11 +124,19 @@ template <class T, int cn> struct Vec : Matx<T, cn, 1> {
 	T& operator[](int i) { return this->val[i]; }
 	const T& operator[](int i) const { return this->val[i]; }
 	Vec& operator/=(T s) { for (int i = 0; i < cn; ++i) this->val[i] /= s; return *this; }
+	Vec cross(const Vec& o) const { static_assert(cn == 3, "cross"); return Vec(this->val[1] * o.val[2] - this->val[2] * o.val[1], this->val[2] * o.val[0] - this->val[0] * o.val[2], this->val[0] * o.val[1] - this->val[1] * o.val[0]); }
 	Vec& operator=(T s) { for (int i = 0; i < cn; ++i) this->val[i] = s; return *this; }
 };
 template <class T> Point_<T>::Point_(const Vec<T, 2>& v) : x(v.val[0]), y(v.val[1]) {}
 typedef Vec<double, 2> Vec2d; typedef Vec<double, 3> Vec3d; typedef Vec<double, 4> Vec4d; typedef Vec<float, 2> Vec2f;
 template <class T, int cn> double norm(const Vec<T, cn>& v) { double s = 0; for (int i = 0; i < cn; ++i) s += (double)v.val[i] * v.val[i]; return std::sqrt(s); }
+template <class T, int cn> Vec<T, cn> operator*(const Vec<T, cn>& v, T s) { Vec<T, cn> r; for (int i = 0; i < cn; ++i) r.val[i] = v.val[i] * s; return r; }
+template <class T, int cn> Vec<T, cn> operator*(T s, const Vec<T, cn>& v) { return v * s; }
+template <class T, int cn> Vec<T, cn> operator+(const Vec<T, cn>& a, const Vec<T, cn>& b) { Vec<T, cn> r; for (int i = 0; i < cn; ++i) r.val[i] = a.val[i] + b.val[i]; return r; }
+template <class T, int cn> Vec<T, cn> operator-(const Vec<T, cn>& a, const Vec<T, cn>& b) { Vec<T, cn> r; for (int i = 0; i < cn; ++i) r.val[i] = a.val[i] - b.val[i]; return r; }
+template <class T, int cn> Vec<T, cn> operator-(const Vec<T, cn>& a) { Vec<T, cn> r; for (int i = 0; i < cn; ++i) r.val[i] = -a.val[i]; return r; }
+template <class T, int m, int n> Vec<T, m> operator*(const Matx<T, m, n>& a, const Vec<T, n>& b) { Vec<T, m> r; for (int i = 0; i < m; ++i) { T s = 0; for (int q = 0; q < n; ++q) s += a(i, q) * b.val[q]; r.val[i] = s; } return r; }
+template <class T, int m, int n> double norm(const Matx<T, m, n>& v) { double s = 0; for (int i = 0; i < m * n; ++i) s += (double)v.val[i] * v.val[i]; return std::sqrt(s); }
 template <class T, int cn> Vec<T, cn> operator/(const Vec<T, cn>& v, T s) { Vec<T, cn> r; for (int i = 0; i < cn; ++i) r.val[i] = v.val[i] / s; return r; }
 
 struct KeyPoint {
@@ -131,6 +160,7 @@ public:
 	Mat() {}
 	Mat(int r, int c, int type) { create(r, c, type); }
 	Mat(Size sz, int type) { create(sz.height, sz.width, type); }
+	template <class T, int m, int n> Mat(const Matx<T, m, n>& M) { create(m, n, CV_64F); for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) at<double>(i, j) = (double)M(i, j); }
 	Mat(int r, int c, int type, void* ext, size_t st = 0) : flags_type(type), rows(r), cols(c), step(st ? st : (size_t)c * esz(type)), data((uchar*)ext), wholeRows(r), wholeCols(c) {}
 	static size_t esz(int type) { return type == CV_64F ? 8 : (type == CV_32F ? 4 : 1); }
 	void create(int r, int c, int type) {
@@ -287,6 +317,13 @@ struct KeyPointsFilter {
 	static void retainBest(std::vector<KeyPoint>& k, int n) {   // only reached from the reference's unused ComputeKeyPointsOld path
 		if (n >= 0 && (int)k.size() > n) { std::stable_sort(k.begin(), k.end(), [](const KeyPoint& a, const KeyPoint& b) { return a.response > b.response; }); k.resize(n); } }
 };
+
+// Eigen <-> cv (opencv2/core/eigen.hpp): only dense double matrices
+template <class T, int R, int Cc, int Opt, int MR, int MC> void cv2eigen(const Mat& src, Eigen::Matrix<T, R, Cc, Opt, MR, MC>& dst) {
+	for (int i = 0; i < src.rows; ++i) for (int j = 0; j < src.cols; ++j) dst(i, j) = (T)src.at<double>(i, j); }
+template <class T, int m, int n, class E> void cv2eigen(const Matx<T, m, n>& src, E& dst) { for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) dst(i, j) = src(i, j); }
+template <class E, class T, int m, int n> void eigen2cv(const E& src, Matx<T, m, n>& dst) { for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) dst(i, j) = src(i, j); }
+template <class E> void eigen2cv(const E& src, Mat& dst) { dst.create((int)src.rows(), (int)src.cols(), CV_64F); for (int i = 0; i < dst.rows; ++i) for (int j = 0; j < dst.cols; ++j) dst.at<double>(i, j) = src(i, j); }
 
 // ---------------------------------------------------------------------------------------------- FileStorage (READ of the DBoW2 vocabulary layout)
 // Just enough for DBoW2::TemplatedVocabulary::load (ThirdParty/DBoW2/DBoW2/TemplatedVocabulary.h:1573-1622): a top-level map with scalar

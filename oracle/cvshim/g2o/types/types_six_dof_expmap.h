@@ -1,0 +1,1 @@
+#include "se3quat.h"

@@ -102,3 +102,63 @@ extern "C" int ref_bow_transform(const char* vocPath, const uint8_t* desc, int n
 	} catch (const std::exception& e) { std::cerr << "ref_bow_transform: " << e.what() << std::endl; return -1; }
 	catch (const std::string& e) { std::cerr << "ref_bow_transform: " << e << std::endl; return -1; }
 }
+
+// ---------------------------------------------------------------- camera system, converter, misc (src/cam_system_omni.cpp, cConverter.cpp, misc.cpp)
+#include "cam_system_omni.h"
+#include "cConverter.h"
+#include "misc.h"
+
+static cCamModelGeneral_ make_cam(const orc_ocam* cam, const uint8_t* mask) {
+	cv::Mat_<double> poly(cam->p_deg, 1), invpoly(cam->invP_deg, 1);
+	for (int i = 0; i < cam->p_deg; ++i) poly.at<double>(i, 0) = cam->p[i];
+	for (int i = 0; i < cam->invP_deg; ++i) invpoly.at<double>(i, 0) = cam->invP[i];
+	double cdeu0v0[5] = {cam->c, cam->d, cam->e, cam->u0, cam->v0};
+	cCamModelGeneral_ m(cdeu0v0, poly, invpoly, cam->width, cam->height);
+	std::vector<cv::Mat> masks;
+	if (mask) masks.push_back(cv::Mat(cam->height, cam->width, CV_8UC1, (void*)mask).clone());
+	else masks.push_back(cv::Mat::ones(cv::Size(cam->width, cam->height), CV_8UC1));
+	m.SetMirrorMasks(masks);
+	return m;
+}
+
+// cMultiCamSys_(M_t, M_c, camModels) -> for every point: WorldToCamHom_fast(cam, Vec4d) (returns z <= 0) + isPointInMirrorMask(u, v, 0);
+// also returns the MtMc_inv matrices the reference computed (invMat(M_t * M_c[c])).
+extern "C" int ref_world_to_cam(const double* M_t, const double* M_c, const orc_ocam* cams, const uint8_t* const* masks, int nrCams, const double* pts3,
+                                const int* pcam, int n, double* uv, uint8_t* flags, double* MtMc_inv_out) {
+	try {
+		cv::Matx44d Mt; std::memcpy(Mt.val, M_t, 128);
+		std::vector<cv::Matx44d> Mc(nrCams);
+		std::vector<cCamModelGeneral_> models;
+		for (int c = 0; c < nrCams; ++c) { std::memcpy(Mc[c].val, M_c + 16 * c, 128); models.push_back(make_cam(&cams[c], masks ? masks[c] : nullptr)); }
+		cMultiCamSys_ sys(Mt, Mc, models);
+		for (int c = 0; c < nrCams; ++c) { cv::Matx44d inv = sys.Get_MtMc_inv(c); std::memcpy(MtMc_inv_out + 16 * c, inv.val, 128); }
+		for (int i = 0; i < n; ++i) {
+			cv::Vec4d p4(pts3[3 * i], pts3[3 * i + 1], pts3[3 * i + 2], 1.0);
+			cv::Vec2d px(0.0, 0.0);
+			const bool behind = sys.WorldToCamHom_fast(pcam[i], p4, px);
+			cv::Vec3d p3(pts3[3 * i], pts3[3 * i + 1], pts3[3 * i + 2]);
+			cv::Vec2d px3(0.0, 0.0);
+			sys.WorldToCamHom_fast(pcam[i], p3, px3);   // the Vec3d overload must agree with the Vec4d one
+			if (px3(0) != px(0) && !(px3(0) != px3(0) && px(0) != px(0))) return -3;
+			uv[2 * i] = px(0); uv[2 * i + 1] = px(1);
+			uint8_t fl = behind ? 2 : 0;
+			if (sys.GetCamModelObj(pcam[i]).isPointInMirrorMask(px(0), px(1), 0)) fl |= 1;
+			flags[i] = fl;
+		}
+		return 0;
+	} catch (const std::exception& e) { std::cerr << "ref_world_to_cam: " << e.what() << std::endl; return -1; }
+}
+
+extern "C" int ref_check_epipolar(const double* ray1, const double* ray2, const double* E, double thresh) {
+	cv::Vec3d r1(ray1[0], ray1[1], ray1[2]), r2(ray2[0], ray2[1], ray2[2]);
+	cv::Matx33d E12; std::memcpy(E12.val, E, 72);
+	return CheckDistEpipolarLine(r1, r2, E12, thresh) ? 1 : 0;
+}
+
+extern "C" int ref_median_int(const int* v, int n) { std::vector<int> x(v, v + n); return median(x); }
+
+extern "C" void ref_cayley2hom(const double* c6, double* M) {
+	cv::Matx61d c; std::memcpy(c.val, c6, 48);
+	cv::Matx44d H = cayley2hom<double>(c);
+	std::memcpy(M, H.val, 128);
+}

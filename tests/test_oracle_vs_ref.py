@@ -127,3 +127,77 @@ def test_bow_transform_equals_dbow2_code(which, tmp_path):
         enode, ebow = _expected_maps(vd, desc, levelsup)
         assert np.array_equal(node, enode)
         assert k == len(ebow) and list(ids[:k]) == [b[0] for b in ebow] and np.array_equal(vals[:k], np.array([b[1] for b in ebow]))
+
+
+@have_ref
+def test_camera_system_pose_and_projection_equal_reference_code():
+    """src/cam_system_omni.cpp + cConverter.cpp compiled unmodified: cMultiCamSys_(M_t, M_c, camModels) -> MtMc_inv, WorldToCamHom_fast,
+    isPointInMirrorMask vs the host mirror (frontend._matx_mul / _inv_mat, io.cayley2hom) and the oracle's orc_world_to_cam."""
+    FE = importlib.import_module("multicol-slam_amd.frontend")
+    io = importlib.import_module("multicol-slam_amd.io")
+    import test_io_formats as T
+    ref = C.CDLL(REF_SO)
+    cams = synth.lafida_cameras()
+    masks = [np.ascontiguousarray(synth.mirror_mask(c)) for c in cams]
+    # Cayley -> homogeneous (include/misc.h) through the reference's template
+    ref.ref_cayley2hom.argtypes = [C.c_void_p, C.c_void_p]
+    M_c = []
+    for cay in T.CAYLEY:
+        c6, M = np.array(cay, np.float64), np.zeros((4, 4))
+        ref.ref_cayley2hom(c6.ctypes.data, M.ctypes.data)
+        assert np.array_equal(M, io.cayley2hom(cay))
+        M_c.append(M)
+    a = np.deg2rad(7.0)
+    M_t = np.eye(4)
+    M_t[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+    M_t[:3, 3] = [0.3, -0.2, 0.1]
+    rig = FE.cMultiCamSys_([FE.cCamModelGeneral_.from_dict(c, m) for c, m in zip(cams, masks)], M_c, M_t)
+    rng = np.random.default_rng(2)
+    n = 5000
+    pts = rng.normal(0, 3.0, (n, 3))
+    pc = rng.integers(0, 3, n).astype(np.int32)
+    uv, fl, inv = np.zeros((n, 2)), np.zeros(n, np.uint8), np.zeros((3, 4, 4))
+    oc = (O.Ocam * 3)(*[O.make_ocam(c) for c in cams])
+    mp = (C.c_void_p * 3)(*[m.ctypes.data for m in masks])
+    ref.ref_world_to_cam.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(O.Ocam), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+    rc = ref.ref_world_to_cam(np.ascontiguousarray(M_t).ctypes.data, np.ascontiguousarray(np.stack(M_c)).ctypes.data, oc, mp, 3, pts.ctypes.data, pc.ctypes.data,
+                              n, uv.ctypes.data, fl.ctypes.data, inv.ctypes.data)
+    assert rc == 0
+    for c in range(3):
+        assert np.array_equal(inv[c], rig.MtMc_inv[c])          # invMat(M_t * M_c[c]) with the Matx summation order
+    euv, efl = O.world_to_cam(np.stack(rig.MtMc_inv), cams, masks, pts, pc)
+    fin = np.isfinite(euv).all(axis=1)
+    assert np.array_equal(uv[fin], euv[fin]) and np.array_equal(fl[fin], efl[fin])
+    assert 0.05 < (fl & 1).mean() < 0.9 and 0.2 < (fl >> 1).mean() < 0.8
+
+
+@have_ref
+def test_epipolar_check_and_median_equal_reference_code():
+    """src/misc.cpp: CheckDistEpipolarLine (SearchForTriangulationRaw) and median() (ComputeDistinctiveDescriptors) vs the oracle"""
+    ref = C.CDLL(REF_SO)
+    ref.ref_check_epipolar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+    ref.ref_median_int.argtypes = [C.c_void_p, C.c_int]
+    L = O.lib()
+    L.orc_check_epipolar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+    rng = np.random.default_rng(9)
+    agree = 0
+    for i in range(20000):
+        r1, r2 = rng.normal(0, 1, 3), rng.normal(0, 1, 3)
+        r1 /= np.linalg.norm(r1); r2 /= np.linalg.norm(r2)
+        E = rng.normal(0, 1, (3, 3)) if i % 50 else np.zeros((3, 3))
+        th = float(rng.choice([1e-2, 1e-1, 0.5]))
+        a = ref.ref_check_epipolar(r1.ctypes.data, r2.ctypes.data, np.ascontiguousarray(E).ctypes.data, th)
+        b = L.orc_check_epipolar(r1.ctypes.data, r2.ctypes.data, np.ascontiguousarray(E).ctypes.data, th)
+        assert a == b
+        agree += a
+    assert 1000 < agree < 19000
+    for n in (1, 2, 3, 4, 7, 10, 33):
+        v = rng.integers(0, 50, n).astype(np.int32)
+        assert ref.ref_median_int(v.ctypes.data, n) == sorted(v.tolist())[n // 2]
+    # the distinctive-descriptor rule built on that median: rows j > i, position size/2 (oracle restatement vs a direct numpy evaluation)
+    for n in (3, 5, 8, 21):
+        d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        dist = np.unpackbits(d[:, None, :] ^ d[None, :, :], axis=2).sum(2)
+        med = [sorted(dist[i, i + 1:].tolist())[(n - 1 - i) // 2] for i in range(n - 1)]
+        assert O.distinctive_descriptor(d, None) == int(np.argmin(med))
