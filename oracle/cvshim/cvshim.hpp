@@ -28,6 +28,7 @@ typedef unsigned char uchar;
 typedef unsigned short ushort;
 
 #define CV_8U 0
+#define CV_32S 4
 #define CV_32F 5
 #define CV_64F 6
 #define CV_8UC1 0
@@ -45,6 +46,10 @@ namespace cv {
 
 template <class T> inline T sqrt(T v) { return std::sqrt(v); }   // a template, so that unqualified sqrt(double) under `using namespace cv, std` stays unambiguous
 enum { NORM_HAMMING = 6 };
+template <class T> struct DataType { enum { type = CV_8U }; };
+template <> struct DataType<int> { enum { type = CV_32S }; };
+template <> struct DataType<float> { enum { type = CV_32F }; };
+template <> struct DataType<double> { enum { type = CV_64F }; };
 template <class T> struct AutoBuffer { std::vector<T> v; explicit AutoBuffer(size_t n) : v(n) {} operator T*() { return v.data(); } };
 template <class T, int cn> struct Vec;
 inline float fastAtan2(float y, float x) { return orc_fastAtan2(y, x); }
@@ -137,6 +142,7 @@ template <class T, int cn> Vec<T, cn> operator-(const Vec<T, cn>& a, const Vec<T
 template <class T, int cn> Vec<T, cn> operator-(const Vec<T, cn>& a) { Vec<T, cn> r; for (int i = 0; i < cn; ++i) r.val[i] = -a.val[i]; return r; }
 template <class T, int m, int n> Vec<T, m> operator*(const Matx<T, m, n>& a, const Vec<T, n>& b) { Vec<T, m> r; for (int i = 0; i < m; ++i) { T s = 0; for (int q = 0; q < n; ++q) s += a(i, q) * b.val[q]; r.val[i] = s; } return r; }
 template <class T, int m, int n> double norm(const Matx<T, m, n>& v) { double s = 0; for (int i = 0; i < m * n; ++i) s += (double)v.val[i] * v.val[i]; return std::sqrt(s); }
+template <class T, int cn> Vec<T, cn> operator/(const Vec<T, cn>& v, int s) { Vec<T, cn> r; for (int i = 0; i < cn; ++i) r.val[i] = v.val[i] / s; return r; }
 template <class T, int cn> Vec<T, cn> operator/(const Vec<T, cn>& v, T s) { Vec<T, cn> r; for (int i = 0; i < cn; ++i) r.val[i] = v.val[i] / s; return r; }
 
 struct KeyPoint {
@@ -162,7 +168,7 @@ public:
 	Mat(Size sz, int type) { create(sz.height, sz.width, type); }
 	template <class T, int m, int n> Mat(const Matx<T, m, n>& M) { create(m, n, CV_64F); for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) at<double>(i, j) = (double)M(i, j); }
 	Mat(int r, int c, int type, void* ext, size_t st = 0) : flags_type(type), rows(r), cols(c), step(st ? st : (size_t)c * esz(type)), data((uchar*)ext), wholeRows(r), wholeCols(c) {}
-	static size_t esz(int type) { return type == CV_64F ? 8 : (type == CV_32F ? 4 : 1); }
+	static size_t esz(int type) { return type == CV_64F ? 8 : ((type == CV_32F || type == CV_32S) ? 4 : 1); }
 	void create(int r, int c, int type) {
 		if (data && rows == r && cols == c && flags_type == type) return;   // cv::Mat::create keeps a matching allocation (copyMakeBorder relies on it)
 		flags_type = type; rows = r; cols = c; step = (size_t)c * esz(type);

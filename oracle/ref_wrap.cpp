@@ -11,6 +11,7 @@ using namespace MultiColSLAM;
 // order" = "creation order" — the order the oracle (and the GPU oct-tree) use for the same tie.  Linked with -Bsymbolic: only this .so is affected.
 #include <cstdlib>
 #include <new>
+#include <sys/mman.h>
 namespace {
 char* g_arena = nullptr; size_t g_cap = 0, g_used = 0; bool g_on = false;
 void* bump(size_t n) {
@@ -19,8 +20,22 @@ void* bump(size_t n) {
 	void* p = g_arena + g_used; g_used += n; return p;
 }
 bool in_arena(void* p) { return (char*)p >= g_arena && (char*)p < g_arena + g_cap; }
+}  // namespace
+// The arena is never rewound: function-local statics of the reference / libstdc++ that were first touched while it was on must stay valid.
+// 64 GiB of address space are reserved (MAP_NORESERVE), only touched pages cost memory.
+static void arena_on() {
+	if (!g_arena) {
+		g_cap = size_t(64) << 30;
+		void* p = mmap(nullptr, g_cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+		if (p == MAP_FAILED) { g_cap = size_t(2) << 30; p = std::malloc(g_cap); }
+		g_arena = (char*)p;
+	}
+	g_on = true;
+}
+extern "C" void ref_arena(int on) { if (on) arena_on(); else g_on = false; }   // scenes of ref_wrap_match.cpp keep it on for their whole life
+namespace {
 struct ArenaScope {
-	ArenaScope() { if (!g_arena) { g_cap = size_t(1) << 30; g_arena = (char*)std::malloc(g_cap); } g_used = 0; g_on = true; }
+	ArenaScope() { arena_on(); }
 	~ArenaScope() { g_on = false; }
 };
 }  // namespace
