@@ -8,8 +8,9 @@
  *   src/cam_model_omni.cpp:49-67,146-161,163-220   include/cam_model_omni.h:127-145   include/misc.h:33-49,115-122
  *   src/cMultiFrame.cpp:146-152,342-353   src/cORBmatcher.cpp:46-65,179-323,885-1155,2438-2474   src/misc.cpp:53-69
  * plus the OpenCV 3.x generic-C++ primitives restated in SURVEY.md Appendix A (OpenCV is not vendored by the reference and not
- * installed here).  PINNING (see mcs_oracle.h): the extractor and the camera model are pinned bit for bit against the reference's
- * own sources compiled unmodified (oracle/_ref, tests/test_oracle_vs_ref.py); the OpenCV primitives and the matcher are UNPINNED.
+ * installed here).  PINNING (see mcs_oracle.h): extractor, camera model / system, cMultiFrame, the cORBmatcher searches, ComputeBoW and
+ * ComputeDistinctiveDescriptors are pinned bit for bit against the reference's own sources compiled unmodified (oracle/_ref,
+ * tests/test_oracle_vs_ref*.py); only the OpenCV primitives and orc_window_best are UNPINNED.
  *
  * Documented deviations where the reference has undefined / non-deterministic behaviour:
  *   (1) oct-tree sort ties (pair<int,Node*> compares heap addresses, :782) -> tie broken by node creation

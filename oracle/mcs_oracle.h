@@ -7,17 +7,23 @@
  * the timed CPU baseline.  The product (libmcs_hip.so and the host facade) never links or loads it.
  *
  * PINNING STATUS.  The reference ships no tests / golden vectors for this path and cannot be built as a whole here (OpenCV >= 3.0, Pangolin,
- * g2o ... are absent).
- *   PINNED: its extractor and camera model.  src/mdBRIEFextractorOct.cpp and src/cam_model_omni.cpp compile UNMODIFIED from /root/reference against
- *     oracle/cvshim (OpenCV's types re-implemented as far as those files use them; `make -C oracle ref` -> oracle/_ref/libmcs_ref.so).  On every tested
- *     image / mode / parameter set this oracle reproduces that library bit for bit — keypoints, descriptors, masks, WorldToImg, ImgToWorld
- *     (tests/test_oracle_vs_ref.py), and tests/golden/ref_extract.npz keeps vectors generated from it (tools/gen_golden_ref.py) for machines without the
- *     reference checkout.  That covers everything that is the REFERENCE's code: pyramid loop, cell grid, DistributeOctTree, IC_Angle, pattern rotation /
- *     distortion, the three descriptor variants, masks, operator() glue.
- *   UNPINNED: (a) the five OpenCV image primitives those files call (resize, copyMakeBorder, FAST, boxFilter, fastAtan2) and cvRound — un-vendored
- *     third-party code, restated from its published generic C++ algorithm; the shim forwards them to the restatements below,
- *     so _ref cannot check them (hand-derived known-answer tests do: tests/test_oracle_kat.py); (b) cORBmatcher / cMultiFrame / cMapPoint / DBoW2
- *     functions, whose sources need the whole SLAM object graph (g2o, OpenGV, Pangolin): restated here, checked by known-answer tests only.
+ * compiled g2o ... are absent).  But almost all of ITS OWN sources compile UNMODIFIED, from /root/reference, against oracle/cvshim (OpenCV's types
+ * re-implemented as far as they are used, type-only stubs for g2o's SE3Quat / Sim3): `make -C oracle ref` -> oracle/_ref/libmcs_ref.so =
+ * mdBRIEFextractorOct, cam_model_omni, cam_system_omni, cConverter, misc, cORBmatcher, cMultiFrame, cMultiKeyFrame, cMapPoint, cMap,
+ * cMultiKeyFrameDatabase + the vendored DBoW2.
+ *   PINNED, bit for bit against that library (tests/test_oracle_vs_ref.py, tests/test_oracle_vs_ref_match.py, golden vectors from it in
+ *     tests/golden/ref_extract.npz for machines without the checkout): the extractor in all three modes, the camera model and camera system
+ *     (poses, WorldToCamHom_fast, mirror-mask test), cMultiFrame's constructor fields and ComputeBoW (DBoW2 load + transform), SearchByBoW KF-KF and KF-F
+ *     (vocabulary-restricted and, through a one-leaf vocabulary, brute force), SearchForTriangulationRaw incl. ComputeE / CheckDistEpipolarLine,
+ *     WindowSearch, SearchForInitialization, the three SearchByProjection overloads, cMapPoint::ComputeDistinctiveDescriptors — driven through REAL
+ *     cMultiFrame / cMultiKeyFrame / cMapPoint / cORBmatcher objects (oracle/ref_wrap_match.cpp).
+ *   UNPINNED: (a) the OpenCV image primitives the sources call (resize, copyMakeBorder, FAST, boxFilter, fastAtan2, cvRound, Matx products) — un-vendored
+ *     third-party code restated from its published generic C++ algorithm; the shim forwards them to the restatements below, so
+ *     _ref cannot check them (hand-derived known-answer tests do: tests/test_oracle_kat.py); (b) orc_window_best, the common core of the Fuse /
+ *     SearchBySim3 / SearchForTriangulationBetweenCameras loops (those functions need map-point state the scene driver does not build).
+ *   The reference's DistributeOctTree orders equal nodes by heap address; _ref runs it on a bump arena (increasing addresses = creation order), the
+ *   order the oracle uses; with the system allocator the reference's own output varies from run to run.  _ref is built without -fopenmp (the
+ *   per-camera `#pragma omp parallel for` of cMultiFrame's constructor only changes timing).
  */
 #ifndef MCS_ORACLE_H
 #define MCS_ORACLE_H
