@@ -1481,6 +1481,51 @@ int orc_distinctive_descriptor(const uint8_t* desc, const uint8_t* mask, int N, 
 	return BestIdx;
 }
 
+// ---------------------------------------------------------------- mbCheckOrientation: the rotation-consistency filter of the searches
+// Every search keeps a 30-bin histogram of rot = angle_first - angle_second (+360 if negative) of its accepted matches and, when
+// mbCheckOrientation is set, drops the matches outside the three fullest bins (ComputeThreeMaxima, src/cORBmatcher.cpp:2394-2436).  The bin
+// arithmetic differs from function to function (and "factor" is 1/HISTO_LENGTH, not HISTO_LENGTH/360 — bins 0..12 only; kept):
+//   variant 0  SearchByBoW(KF,F) :191-194,272-282, SearchByProjection(Cur,Last) :1999,2084-2094, SearchByProjection(Cur,pKF,..) :2137,2222-2232
+//              float factor = 1.0f/30;  bin = cvRound(rot*factor)               (float product)
+//   variant 1  WindowSearch :339,428-438        double factor = 1.0f/30 (float division);  bin = cvRound(rot*factor)   (double product)
+//   variant 2  SearchForInitialization :596,686-694   double factor = 1.0/30;  bin = round(rot*factor)      (half away from zero)
+//   variant 3  SearchForTriangulationRaw :1011,1092-1101  double factor = 1.0/30; rot += 360.0 in DOUBLE;  bin = cvRound(rot*factor)
+// slot s is matched to partner match[s] (or -1).  swapped = 0: rot = angle_slot[s] - angle_partner[match[s]]; 1: partner minus slot.
+// accepted (optional): the partner at ACCEPTANCE time per slot, -1 if the slot never accepted — SearchForInitialization's histogram also counts
+// acceptances that were stolen later (:686-694 pushes before the steal, :706-719 only clears live matches).  Returns the number removed.
+static int rot_bin(int variant, float a_first, float a_second) {
+	float rot = a_first - a_second;
+	if (variant == 3) { if (rot < 0.0) rot += 360.0; }       // float = (double)rot + 360.0
+	else if (rot < 0.0) rot += 360.0f;
+	int bin;
+	if (variant == 0) { const float factor = 1.0f / 30; bin = cvRoundf_(rot * factor); }
+	else if (variant == 1) { const double factor = 1.0f / 30; bin = cvRound_(rot * factor); }
+	else if (variant == 2) { const double factor = 1.0 / 30; bin = (int)round(rot * factor); }
+	else { const double factor = 1.0 / 30; bin = cvRound_(rot * factor); }
+	if (bin == 30) bin = 0;
+	return bin;
+}
+int orc_rotation_consistency(int variant, const float* angle_slot, const float* angle_partner, const int* accepted, int* match, int n, int swapped) {
+	std::vector<int> rotHist[30];
+	for (int s = 0; s < n; ++s) {
+		const int p = accepted ? accepted[s] : match[s];
+		if (p < 0) continue;
+		const float a = angle_slot[s], b = angle_partner[p];
+		rotHist[rot_bin(variant, swapped ? b : a, swapped ? a : b)].push_back(s);
+	}
+	int ind1 = -1, ind2 = -1, ind3 = -1;
+	ComputeThreeMaxima(rotHist, 30, ind1, ind2, ind3);
+	int removed = 0;
+	for (int i = 0; i < 30; ++i) {
+		if (i == ind1 || i == ind2 || i == ind3) continue;
+		for (size_t j = 0; j < rotHist[i].size(); ++j) {
+			const int s = rotHist[i][j];
+			if (match[s] >= 0) { match[s] = -1; ++removed; }
+		}
+	}
+	return removed;
+}
+
 // ---------------------------------------------------------------- "next" row 4: cMultiFrame::ComputeBoW -> DBoW2 transform
 // ThirdParty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259 (one feature down the tree; first strict minimum among a node's children in
 // file order), FORB::distance ThirdParty/DBoW2/DBoW2/FORB.cpp:85-105 (32 bytes, the bit-trick popcount).  The vocabulary is given flat:

@@ -143,6 +143,9 @@ int orc_window_best(const double* x, const double* y, const double* radius, cons
 /* "next" row 3: cMapPoint::ComputeDistinctiveDescriptors (src/cMapPoint.cpp:294-382): index of the chosen observation */
 int orc_distinctive_descriptor(const uint8_t* desc, const uint8_t* mask, int N, int dim, int havingMasks);
 
+/* mbCheckOrientation: rotation-consistency filter shared by the searches (four bin-arithmetic variants, see mcs_oracle.cpp) */
+int orc_rotation_consistency(int variant, const float* angle_slot, const float* angle_partner, const int* accepted, int* match, int n, int swapped);
+
 /* "next" row 4: DBoW2 vocabulary descent of cMultiFrame::ComputeBoW and the vocabulary-restricted SearchByBoW(KF,F) */
 void orc_bow_transform(const uint8_t* node_desc, const int32_t* child_off, const int32_t* child_idx, int L, const uint8_t* desc, int n, int stride,
                        int levelsup, int32_t* leaf, int32_t* nid);

@@ -145,17 +145,17 @@ extern "C" int rs_bow_kf_kf(void* h, int k1, int k2, double nnratio, int* match1
 	for (size_t i = 0; i < v.size(); ++i) match12ids[i] = id_or_minus1(s, v[i]);
 	return n;
 }
-extern "C" int rs_bow_kf_f(void* h, int k, int f, double nnratio, int* matchFids) {
+extern "C" int rs_bow_kf_f(void* h, int k, int f, double nnratio, int checkOri, int* matchFids) {
 	Scene* s = (Scene*)h;
-	cORBmatcher m(nnratio, false, s->dim, s->masks);
+	cORBmatcher m(nnratio, checkOri != 0, s->dim, s->masks);
 	std::vector<cMapPoint*> v;
 	const int n = m.SearchByBoW(s->kfs[k], *s->frames[f], v);
 	for (size_t i = 0; i < v.size(); ++i) matchFids[i] = id_or_minus1(s, v[i]);
 	return n;
 }
-extern "C" int rs_triangulation(void* h, int k1, int k2, int* match12, double* E) {
+extern "C" int rs_triangulation(void* h, int k1, int k2, int checkOri, int* match12, double* E) {
 	Scene* s = (Scene*)h;
-	cORBmatcher m(0.6, false, s->dim, s->masks);
+	cORBmatcher m(0.6, checkOri != 0, s->dim, s->masks);
 	std::vector<cv::KeyPoint> a, b; std::vector<cv::Vec3d> ra, rb; std::vector<std::pair<size_t, size_t>> pairs;
 	const int n = m.SearchForTriangulationRaw(s->kfs[k1], s->kfs[k2], a, ra, b, rb, pairs);
 	const size_t n1 = s->kfs[k1]->GetKeyPoints().size();
@@ -168,17 +168,17 @@ extern "C" int rs_triangulation(void* h, int k1, int k2, int* match12, double* E
 	}
 	return n;
 }
-extern "C" int rs_window_search(void* h, int f1, int f2, int windowSize, int minLvl, int maxLvl, double nnratio, int* match2ids) {
+extern "C" int rs_window_search(void* h, int f1, int f2, int windowSize, int minLvl, int maxLvl, double nnratio, int checkOri, int* match2ids) {
 	Scene* s = (Scene*)h;
-	cORBmatcher m(nnratio, false, s->dim, s->masks);
+	cORBmatcher m(nnratio, checkOri != 0, s->dim, s->masks);
 	std::vector<cMapPoint*> v;
 	const int n = m.WindowSearch(*s->frames[f1], *s->frames[f2], windowSize, v, minLvl, maxLvl);
 	for (size_t i = 0; i < v.size(); ++i) match2ids[i] = id_or_minus1(s, v[i]);
 	return n;
 }
-extern "C" int rs_search_init(void* h, int f1, int f2, double* prevMatched, int windowSize, double nnratio, int* match12) {
+extern "C" int rs_search_init(void* h, int f1, int f2, double* prevMatched, int windowSize, double nnratio, int checkOri, int* match12) {
 	Scene* s = (Scene*)h;
-	cORBmatcher m(nnratio, false, s->dim, s->masks);
+	cORBmatcher m(nnratio, checkOri != 0, s->dim, s->masks);
 	cMultiFrame* F1 = s->frames[f1];
 	std::vector<cv::Vec2d> prev(F1->totalN);
 	for (size_t i = 0; i < F1->totalN; ++i) prev[i] = cv::Vec2d(prevMatched[2 * i], prevMatched[2 * i + 1]);
@@ -209,9 +209,9 @@ extern "C" int rs_proj_mappoints(void* h, int f, int k, const uint8_t* inView, c
 	for (size_t i = 0; i < F->totalN; ++i) matchFids[i] = id_or_minus1(s, F->mvpMapPoints[i]);
 	return n;
 }
-extern "C" int rs_proj_last(void* h, int cur, int last, double th, int* curIds) {
+extern "C" int rs_proj_last(void* h, int cur, int last, double th, int checkOri, int* curIds) {
 	Scene* s = (Scene*)h;
-	cORBmatcher m(0.8, false, s->dim, s->masks);
+	cORBmatcher m(0.8, checkOri != 0, s->dim, s->masks);
 	const int n = m.SearchByProjection(*s->frames[cur], *s->frames[last], th);
 	cMultiFrame* F = s->frames[cur];
 	for (size_t i = 0; i < F->totalN; ++i) curIds[i] = id_or_minus1(s, F->mvpMapPoints[i]);

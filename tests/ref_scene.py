@@ -31,12 +31,12 @@ class RefScene:
         L.rs_set_outliers.argtypes = [vp, C.c_int, vp]
         L.rs_frame_mappoint_ids.argtypes = [vp, C.c_int, vp]
         L.rs_bow_kf_kf.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp]
-        L.rs_bow_kf_f.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp]
-        L.rs_triangulation.argtypes = [vp, C.c_int, C.c_int, vp, vp]
-        L.rs_window_search.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp]
-        L.rs_search_init.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_double, vp]
+        L.rs_bow_kf_f.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, vp]
+        L.rs_triangulation.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+        L.rs_window_search.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
+        L.rs_search_init.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_double, C.c_int, vp]
         L.rs_proj_mappoints.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp]
-        L.rs_proj_last.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp]
+        L.rs_proj_last.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, vp]
         L.rs_proj_frames.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, vp]
         L.rs_distinctive.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
         L.rs_destroy.argtypes = [vp]

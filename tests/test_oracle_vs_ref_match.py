@@ -101,7 +101,7 @@ def test_search_by_bow_keyframes_and_frame(scene):
     en, e12 = O.search_kf_kf(fr[0]["desc"], fr[0]["mask"], f0, fr[1]["desc"], fr[1]["mask"], f1, having, 0.8)
     assert cnt == en and np.array_equal(ids, np.where(e12 >= 0, 100000 + e12, -1)) and cnt > 50
     # SearchByBoW(KF, F) :179-323 — vocabulary-restricted with the tree, brute force with the one-leaf vocabulary
-    cnt, ids = S._ids(S.L.rs_bow_kf_f, n1, k0, 1, 0.9)
+    cnt, ids = S._ids(S.L.rs_bow_kf_f, n1, k0, 1, 0.9, 0)
     if scene["tree"]:
         en, eF = O.search_kf_f_bow(fr[0]["desc"], fr[0]["mask"] if having else None, f0, fr[0]["node"], fr[1]["desc"], fr[1]["mask"] if having else None,
                                    fr[1]["node"], having, 0.9)
@@ -117,7 +117,7 @@ def test_search_for_triangulation_raw(scene):
     k0, k1, f0, f1 = scene["kfs"]
     n0 = fr[0]["n"]
     m12, E = np.zeros(n0, np.int32), np.zeros((NC * NC, 9))
-    cnt = S.L.rs_triangulation(S.h, k0, k1, m12.ctypes.data, E.ctypes.data)
+    cnt = S.L.rs_triangulation(S.h, k0, k1, 0, m12.ctypes.data, E.ctypes.data)
     # the essential matrices of :990-1003 from the host-side pose algebra (frontend._matx_mul / _inv_mat mirror cv::Matx)
     FE = importlib.import_module("multicol-slam_amd.frontend")
     r0 = FE.cMultiCamSys_([FE.cCamModelGeneral_.from_dict(c, None) for c in scene["cams"]], scene["M_c"], scene["poses"][0])
@@ -148,7 +148,7 @@ def test_window_search_and_initialization(scene):
     v0, _a = view(fr[0], having, cams)
     v1, _b = view(fr[1], having, cams)
     for window, lo, hi in ((60, 0, 2**31 - 1), (50, 3, 2**31 - 1), (40, 1, 5)):
-        cnt, ids = S._ids(S.L.rs_window_search, n1, 0, 1, window, lo, hi, 0.8)
+        cnt, ids = S._ids(S.L.rs_window_search, n1, 0, 1, window, lo, hi, 0.8, 0)
         en, e21 = O.window_search(v0, (flag == 1).astype(np.uint8), v1, window, lo, hi if hi < 2**31 - 1 else -1, 0.8, 32, having)
         assert cnt == en and np.array_equal(ids, np.where(e21 >= 0, 200000 + e21, -1)) and cnt > 20, (window, lo, hi)
     for window in (50, 100):
@@ -156,7 +156,7 @@ def test_window_search_and_initialization(scene):
         prev[:3] = [[-50, 10], [2000, 10], [377, 240]]
         p = prev.copy()
         m12 = np.zeros(n0, np.int32)
-        cnt = S.L.rs_search_init(S.h, 0, 1, p.ctypes.data, window, 0.9, m12.ctypes.data)
+        cnt = S.L.rs_search_init(S.h, 0, 1, p.ctypes.data, window, 0.9, 0, m12.ctypes.data)
         en, e12, ep = O.search_for_initialization(v0, v1, prev, window, 0.9, 32, having)
         assert cnt == en and np.array_equal(m12, e12) and np.array_equal(p, ep) and cnt > 20
 
@@ -204,7 +204,7 @@ def test_projection_searches(scene):
     S.set_outliers(0, outl)
     pre = (rng.random(n1) < 0.1).astype(np.uint8)
     S.set_mappoints(False, 1, pre, base=500000, ref_kf=k0)
-    cnt, ids = S._ids(S.L.rs_proj_last, n1, 1, 0, 15.0)
+    cnt, ids = S._ids(S.L.rs_proj_last, n1, 1, 0, 15.0, 0)
     euv, efl = O.world_to_cam(np.stack(rig1.MtMc_inv), cams, scene["masks"], pos, fr[0]["cam"])
     en, ecur, _ = O.search_by_projection_last(v1, pre, v0, (flag == 1).astype(np.uint8), outl, euv, efl & 1, sc, 15.0, 32, having)
     exp = np.where(pre == 1, 500000 + np.arange(n1), -1)
@@ -247,3 +247,71 @@ def test_compute_distinctive_descriptors(scene):
         assert np.array_equal(d, fr[0]["desc"][idx[b]])
         if having:
             assert np.array_equal(m, fr[0]["mask"][idx[b]])
+
+
+def rotation_filter(variant, angle_slot, angle_partner, match, swapped, accepted=None):
+    import ctypes as C
+    L = O.lib()
+    L.orc_rotation_consistency.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    a, b = np.ascontiguousarray(angle_slot, np.float32), np.ascontiguousarray(angle_partner, np.float32)
+    m = np.ascontiguousarray(match, np.int32).copy()
+    acc = None if accepted is None else np.ascontiguousarray(accepted, np.int32)
+    removed = L.orc_rotation_consistency(variant, O.ptr(a), O.ptr(b), O.ptr(acc), O.ptr(m), len(m), swapped)
+    return removed, m
+
+
+def test_rotation_consistency_with_check_orientation(scene):
+    """mbCheckOrientation = true (never used by the reference's callers, but a constructor argument): the reference's searches with the flag vs the
+    oracle — embedded histograms for the window searches, and the plain search + orc_rotation_consistency for the brute-force ones."""
+    S, fr, having, cams = scene["S"], scene["fr"], scene["having"], scene["cams"]
+    if "kfs" not in scene:
+        pytest.skip("needs the keyframes of an earlier test")
+    k0, k1, f0, f1 = scene["kfs"]
+    rng = np.random.default_rng(5)
+    n0, n1 = fr[0]["n"], fr[1]["n"]
+    a0, a1 = fr[0]["keys"]["angle"], fr[1]["keys"]["angle"]
+    v0, _a = view(fr[0], having, cams)
+    v1, _b = view(fr[1], having, cams)
+    # SearchByBoW(KF, F): matchF[j] = kf feature; rot = KF angle - frame angle (variant 0, partner minus slot)
+    cnt, ids = S._ids(S.L.rs_bow_kf_f, n1, k0, 1, 0.9, 1)
+    if scene["tree"]:
+        en, eF = O.search_kf_f_bow(fr[0]["desc"], fr[0]["mask"] if having else None, f0, fr[0]["node"], fr[1]["desc"], fr[1]["mask"] if having else None,
+                                   fr[1]["node"], having, 0.9)
+    else:
+        en, eF = O.search_kf_f(fr[0]["desc"], fr[0]["mask"], f0, fr[1]["desc"], fr[1]["mask"], having, 0.9)
+    rem, eF2 = rotation_filter(0, a1, a0, eF, 1)
+    assert cnt == en - rem and np.array_equal(ids, eF2) and rem > 0
+    # SearchForTriangulationRaw: match12[idx1] = idx2; rot = kp1 - kp2 (variant 3, slot minus partner)
+    m12, E = np.zeros(n0, np.int32), np.zeros((NC * NC, 9))
+    cnt = S.L.rs_triangulation(S.h, k0, k1, 1, m12.ctypes.data, E.ctypes.data)
+    en, e12 = O.search_triangulation(fr[0]["desc"], fr[0]["mask"], f0, fr[0]["cam"], fr[0]["rays"], fr[1]["desc"], fr[1]["mask"], f1, fr[1]["cam"], fr[1]["rays"],
+                                     E, NC, having)
+    rem, e12f = rotation_filter(3, a0, a1, e12, 0)
+    assert cnt == en - rem and np.array_equal(m12, e12f)
+    # WindowSearch / SearchForInitialization: the oracle's embedded histograms, and the generic filter on top of the unfiltered result
+    flag = rng.choice([0, 1], n0, p=[0.25, 0.75]).astype(np.uint8)
+    S.set_mappoints(False, 0, flag, base=800000, ref_kf=k0)
+    cnt, ids = S._ids(S.L.rs_window_search, n1, 0, 1, 60, 0, 2**31 - 1, 0.8, 1)
+    en, e21 = O.window_search(v0, flag, v1, 60, 0, -1, 0.8, 32, having, checkOri=1)
+    assert cnt == en and np.array_equal(ids, np.where(e21 >= 0, 800000 + e21, -1))
+    un, u21 = O.window_search(v0, flag, v1, 60, 0, -1, 0.8, 32, having, checkOri=0)
+    rem, g21 = rotation_filter(1, a1, a0, u21, 1)
+    assert np.array_equal(g21, e21) and un - rem == en and rem > 0
+    prev = np.stack([fr[0]["keys"]["x"], fr[0]["keys"]["y"]], axis=1).astype(np.float64)
+    p = prev.copy()
+    m12 = np.zeros(n0, np.int32)
+    cnt = S.L.rs_search_init(S.h, 0, 1, p.ctypes.data, 100, 0.9, 1, m12.ctypes.data)
+    en, e12, ep = O.search_for_initialization(v0, v1, prev, 100, 0.9, 32, having, checkOri=1)
+    assert cnt == en and np.array_equal(m12, e12) and np.array_equal(p, ep)
+    # SearchByProjection(Cur, Last): variant 0, rot = Last angle - Cur angle (partner minus slot)
+    FE = importlib.import_module("multicol-slam_amd.frontend")
+    rig0 = FE.cMultiCamSys_([FE.cCamModelGeneral_.from_dict(c, None) for c in cams], scene["M_c"], scene["poses"][0])
+    rig1 = FE.cMultiCamSys_([FE.cCamModelGeneral_.from_dict(c, None) for c in cams], scene["M_c"], scene["poses"][1])
+    pos = np.stack([(rig0.MtMc[int(c)] @ np.append(r * rng.uniform(1.5, 6.0), 1.0))[:3] for c, r in zip(fr[0]["cam"], fr[0]["rays"])])
+    sc = np.cumprod([1.0] + [float(np.float32(1.2))] * 7)
+    S.set_mappoints(False, 0, flag, pos=pos, base=900000, ref_kf=k0)
+    S.set_mappoints(False, 1, np.zeros(n1, np.uint8), base=0, ref_kf=k0)
+    cnt, ids = S._ids(S.L.rs_proj_last, n1, 1, 0, 15.0, 1)
+    euv, efl = O.world_to_cam(np.stack(rig1.MtMc_inv), cams, scene["masks"], pos, fr[0]["cam"])
+    en, ecur, _ = O.search_by_projection_last(v1, np.zeros(n1, np.uint8), v0, flag, np.zeros(n0, np.uint8), euv, efl & 1, sc, 15.0, 32, having, checkOri=1)
+    assert cnt == en and np.array_equal(ids, np.where(ecur >= 0, 900000 + ecur, -1))
