@@ -353,7 +353,17 @@ class cORBmatcher {
 public:
 	cORBmatcher(Context& ctx, double nnratio = 0.6, bool checkOri = true, int featDim = 32, bool havingMasks_ = false, int K = 32)
 	    : ctx_(ctx), mfNNratio(nnratio), mbFeatDim(featDim), havingMasks(havingMasks_), K_(K) {
-		if (checkOri) throw std::invalid_argument("mbCheckOrientation is false at every reference call site (include/cORBmatcher.h:40)");
+		mbCheckOrientation = checkOri;   // the searches below return unfiltered matches; RotationConsistency() is the separate pass of the reference's flag
+	}
+	// mbCheckOrientation pass (ComputeThreeMaxima, :2394-2436) on a match array (slot -> partner or -1); variant / swapped per search are listed at
+	// mcs_rotation_consistency in mcs_c.h.  Returns the number of matches removed; a no-op unless the matcher was built with checkOri = true.
+	int RotationConsistency(int variant, const KeyPoint* slotKeys, const KeyPoint* partnerKeys, int nPartner, std::vector<int>& match, bool swapped,
+	                        const std::vector<int>* accepted = nullptr) {
+		if (!mbCheckOrientation || match.empty() || nPartner <= 0) return 0;
+		int32_t removed = 0;
+		mcs_throw(mcs_rotation_consistency(ctx_.h, variant, &slotKeys[0].angle, (int)sizeof(KeyPoint), &partnerKeys[0].angle, (int)sizeof(KeyPoint),
+		                                   accepted ? accepted->data() : nullptr, match.data(), (int)match.size(), nPartner, swapped ? 1 : 0, MCS_MEM_HOST, &removed));
+		return removed;
 	}
 	// SearchByBoW(pKF1, pKF2, vpMatches12): flag = "has a good map point".  match12[i] = index in kf2 or -1.  (:885-966)
 	int SearchByBoW(const FeatureSetView& kf1, const FeatureSetView& kf2, std::vector<int>& match12) {
@@ -511,6 +521,7 @@ private:
 	int mbFeatDim;
 	bool havingMasks;
 	int K_;
+	bool mbCheckOrientation = false;
 };
 
 inline int DescriptorDistance64(Context& c, const uint64_t* descr_i, const uint64_t* descr_j, const int& dim) {

@@ -175,15 +175,33 @@ int mcs_search_by_projection(mcs_ctx*, const mcs_projection_set* mp, const mcs_f
  *                         a feature matched at distance d is skipped by later probes whose distance is >= d and stolen by closer ones;
  *                         accept if best <= TH_LOW && best < second*nnratio
  * frame->assigned[i] = "feature i is taken" on entry (updated in place; ignored by MCS_WINDOW_INITIALIZE).  match[p] = frame feature
- * index matched to probe p, or -1 (for MCS_WINDOW_INITIALIZE after all steals).  mbCheckOrientation is false at every reference call
- * site (include/cORBmatcher.h:40) and is not offered.  frame->scale_factors / nlevels are not read by these rules.               */
+ * index matched to probe p, or -1 (for MCS_WINDOW_INITIALIZE after all steals).  mbCheckOrientation (false at every reference call site,
+ * include/cORBmatcher.h:40) is a separate pass: mcs_rotation_consistency.  frame->scale_factors / nlevels are not read by these rules.  */
 typedef struct {
 	const double* x; const double* y; const double* radius; const int32_t* min_level; const int32_t* max_level; const int32_t* cam;
 	const uint8_t* desc; const uint8_t* mask; int32_t n; int32_t stride;
+	int32_t* accepted_out;   /* optional, MCS_WINDOW_INITIALIZE only: the feature a probe held when it was accepted, -1 if never (also kept when the match
+	                          * is stolen later) — the input of the rotation histogram, see mcs_rotation_consistency.  Same memory kind as `match`. */
 } mcs_window_probes;
 typedef enum { MCS_WINDOW_RATIO = 1, MCS_WINDOW_BEST = 2, MCS_WINDOW_INITIALIZE = 3 } mcs_window_rule;
 int mcs_window_match(mcs_ctx*, const mcs_window_probes* probes, const mcs_frame_view* frame, mcs_window_rule rule, double nnratio, int dim,
                      mcs_mem_kind kind, int32_t* match, int32_t* nmatches);
+
+/* mbCheckOrientation: the rotation-consistency filter every search applies when cORBmatcher was built with checkOri = true
+ * (ComputeThreeMaxima, src/cORBmatcher.cpp:2394-2436).  Slot s is matched to partner match[s] (or -1); a 30-bin histogram of
+ * rot = angle_first - angle_second (+360 if negative) is taken over the matches, those outside the three fullest bins are cleared in place.
+ * angle_slot / angle_partner point at the `angle` field of the first keypoint of each side, stride_* = bytes between keypoints
+ * (sizeof(mcs_keypoint) for keypoint arrays, 4 for plain float arrays).  swapped = 0: rot = slot angle - partner angle, 1: partner - slot.
+ * variant = the reference's bin arithmetic ("factor" is 1/HISTO_LENGTH there, so only bins 0..12 are ever hit; reproduced):
+ *   0  float factor, bin = cvRound(rot*factor) in float   SearchByBoW(KF,F) :191-282 [swapped 1], SearchByProjection(Cur,Last) :1999-2094 [1],
+ *                                                          SearchByProjection(Cur, pKF, ...) :2137-2232 [1]
+ *   1  double factor = (double)(1.0f/30), cvRound          WindowSearch :339-438 [1]
+ *   2  double factor = 1.0/30, round() half away from zero SearchForInitialization :596-694 [0]; pass probes->accepted_out as `accepted`: its
+ *                                                          histogram also counts acceptances that were stolen later
+ *   3  double factor, rot += 360.0 in double, cvRound      SearchForTriangulationRaw :1011-1101 [0]
+ * removed = number of matches cleared (the searches subtract it from their return value). */
+int mcs_rotation_consistency(mcs_ctx*, int variant, const float* angle_slot, int stride_slot, const float* angle_partner, int stride_partner,
+                             const int32_t* accepted /* optional */, int32_t* match, int n, int n_partner, int swapped, mcs_mem_kind kind, int32_t* removed);
 
 /* Best feature per probe with a caller-given distance threshold — the search loops of the mapping / loop-closing matchers, whose
  * surrounding map-point surgery stays on the host:

@@ -68,7 +68,7 @@ EXPORTS = [
     "mcs_extractor_tap_level", "mcs_extractor_tap_candidates", "mcs_extractor_tap_selected", "mcs_match_topk",
     "mcs_match_topk_batched", "mcs_descriptor_distance", "mcs_descriptor_distance_masked", "mcs_ctx_enable_timing",
     "mcs_ctx_kernel_ms", "mcs_ctx_join", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_rows_valid",
-    "mcs_search_by_projection", "mcs_window_match", "mcs_window_best", "mcs_world_to_cam", "mcs_distinctive_descriptors", "mcs_selftest_shared_reciprocal", "mcs_vocabulary_create", "mcs_vocabulary_destroy", "mcs_bow_transform",
+    "mcs_search_by_projection", "mcs_window_match", "mcs_window_best", "mcs_rotation_consistency", "mcs_world_to_cam", "mcs_distinctive_descriptors", "mcs_selftest_shared_reciprocal", "mcs_vocabulary_create", "mcs_vocabulary_destroy", "mcs_bow_transform",
 ]
 
 WINDOW_RATIO, WINDOW_BEST, WINDOW_INITIALIZE = 1, 2, 3
@@ -76,7 +76,7 @@ WINDOW_RATIO, WINDOW_BEST, WINDOW_INITIALIZE = 1, 2, 3
 
 class WindowProbes(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("radius", C.c_void_p), ("min_level", C.c_void_p), ("max_level", C.c_void_p),
-                ("cam", C.c_void_p), ("desc", C.c_void_p), ("mask", C.c_void_p), ("n", C.c_int32), ("stride", C.c_int32)]
+                ("cam", C.c_void_p), ("desc", C.c_void_p), ("mask", C.c_void_p), ("n", C.c_int32), ("stride", C.c_int32), ("accepted_out", C.c_void_p)]
 
 
 class ProjectionSet(C.Structure):
@@ -131,6 +131,7 @@ def lib():
     L.mcs_search_by_projection.argtypes = [vp, C.POINTER(ProjectionSet), C.POINTER(FrameView), C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]
     L.mcs_window_match.argtypes = [vp, C.POINTER(WindowProbes), C.POINTER(FrameView), C.c_int, C.c_double, C.c_int, C.c_int, vp, vp]
     L.mcs_window_best.argtypes = [vp, C.POINTER(WindowProbes), C.POINTER(FrameView), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.mcs_rotation_consistency.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.mcs_world_to_cam.argtypes = [vp, vp, C.POINTER(Ocam), C.c_int, C.POINTER(vp), vp, vp, C.c_int, C.c_int, vp, vp]
     L.mcs_distinctive_descriptors.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
     L.mcs_selftest_shared_reciprocal.argtypes = [vp, C.c_uint64, C.c_int, i32p]

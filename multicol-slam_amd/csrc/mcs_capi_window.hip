@@ -21,7 +21,11 @@ struct Arena {
 };
 }  // namespace
 
-namespace mcs { void launch_window_best(const ProjArgs& a, bool skipTaken, int* outDist, hipStream_t s); }
+namespace mcs {
+void launch_window_best(const ProjArgs& a, bool skipTaken, int* outDist, hipStream_t s);
+void launch_rotation_consistency(int variant, const float* angleSlot, int strideSlot, const float* anglePartner, int stridePartner, const int* accepted, int* match,
+                                 int n, int swapped, int* removedOut, hipStream_t s);
+}
 
 // bestMode 0: mcs_window_match (rule decides); 1: independent best-in-window; 2: best-in-window skipping taken features.  maxDist replaces TH_HIGH
 // for bestMode != 0; dist (optional) receives the best distance per probe.
@@ -56,6 +60,8 @@ static int window_common(mcs_ctx* c, const mcs_window_probes* pr, const mcs_fram
 		iMatch = ar.add(np * 4); iNm = ar.add(4);
 	}
 	const size_t iDist = ar.add(host && dist ? np * 4 : 0);
+	const bool wantAcc = rule == MCS_WINDOW_INITIALIZE && pr->accepted_out != nullptr && bestMode == 0;
+	const size_t iAcc = ar.add(host && wantAcc ? np * 4 : 0);
 	HIPCHK(ar.alloc());
 	auto done = [&](int rc) { (void)hipStreamSynchronize(s); return rc; };   // the arena is freed by its destructor after this sync
 	a.lists = (unsigned long long*)ar.at(iLists); a.counts = (int*)ar.at(iCounts); a.owner = (int*)ar.at(iOwner); a.mdist = (int*)ar.at(iMdist);
@@ -79,11 +85,13 @@ static int window_common(mcs_ctx* c, const mcs_window_probes* pr, const mcs_fram
 		a.assigned = f->assigned ? f->assigned : ar.at(iAsg); a.match = match; a.nmatches = nmatches;
 	}
 	if (!f->assigned) { if (hipMemsetAsync(ar.at(iAsg), 0, std::max<size_t>(nf, 1), s) != hipSuccess) return done(fail(MCS_ERR_HIP, "memset failed")); }
+	a.accepted = wantAcc ? (host ? (int*)ar.at(iAcc) : pr->accepted_out) : nullptr;
 	int* ddist = dist ? (host ? (int*)ar.at(iDist) : dist) : nullptr;
 	if (pr->n > 0) { if (bestMode) launch_window_best(a, bestMode == 2, ddist, s); else launch_projection(a, s); }
 	else if (!host) { if (hipMemsetAsync(nmatches, 0, 4, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "memset failed")); }
 	if (hipGetLastError() != hipSuccess) return done(fail(MCS_ERR_HIP, "window kernels failed to launch"));
 	if (host && dist && pr->n > 0 && hipMemcpyAsync(dist, ddist, np * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
+	if (host && wantAcc && pr->n > 0 && hipMemcpyAsync(pr->accepted_out, a.accepted, np * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
 	if (host) {
 		*nmatches = 0;
 		if (pr->n > 0) {
@@ -219,4 +227,36 @@ int mcs_selftest_shared_reciprocal(mcs_ctx* c, uint64_t seed, int n, int32_t* mi
 	(void)hipFree(d);
 	if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(MCS_ERR_HIP, "selftest kernel failed");
 	return MCS_OK;
+}
+
+int mcs_rotation_consistency(mcs_ctx* c, int variant, const float* angle_slot, int stride_slot, const float* angle_partner, int stride_partner,
+                             const int32_t* accepted, int32_t* match, int n, int n_partner, int swapped, mcs_mem_kind kind, int32_t* removed) {
+	if (!c || !angle_slot || !angle_partner || !match || !removed) return fail(MCS_ERR_INVALID, "null argument");
+	if (variant < 0 || variant > 3 || n < 0 || n_partner < 0 || stride_slot < 4 || stride_partner < 4 || (stride_slot & 3) || (stride_partner & 3))
+		return fail(MCS_ERR_INVALID, "bad variant / sizes / strides");
+	HIPCHK(hipSetDevice(c->device));
+	hipStream_t s = c->stream;
+	if (c->side && c->greedyPending) { HIPCHK(hipStreamWaitEvent(s, c->evGreedy, 0)); c->greedyPending = false; }   // `match` may come from a search whose greedy pass runs on the side stream
+	const bool host = kind == MCS_MEM_HOST;
+	if (!host) {
+		launch_rotation_consistency(variant, angle_slot, stride_slot, angle_partner, stride_partner, accepted, match, n, swapped, removed, s);
+		HIPCHK(hipGetLastError());
+		return MCS_OK;
+	}
+	const size_t bs = (size_t)n * stride_slot, bp = (size_t)n_partner * stride_partner;
+	Arena ar;
+	const size_t iS = ar.add(bs), iP = ar.add(bp), iA = ar.add(accepted ? (size_t)n * 4 : 0), iM = ar.add((size_t)n * 4), iR = ar.add(4);
+	HIPCHK(ar.alloc());
+	auto done = [&](int rc) { (void)hipStreamSynchronize(s); return rc; };
+#define UP(id, src, bytes) do { if ((bytes) && hipMemcpyAsync(ar.at(id), (src), (bytes), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "H2D copy failed")); } while (0)
+	UP(iS, angle_slot, bs > 0 ? bs - (stride_slot - 4) : 0); UP(iP, angle_partner, bp > 0 ? bp - (stride_partner - 4) : 0);   // the last keypoint's tail may not be readable
+	if (accepted) UP(iA, accepted, (size_t)n * 4);
+	UP(iM, match, (size_t)n * 4);
+#undef UP
+	launch_rotation_consistency(variant, (const float*)ar.at(iS), stride_slot, (const float*)ar.at(iP), stride_partner, accepted ? (const int*)ar.at(iA) : nullptr,
+	                            (int*)ar.at(iM), n, swapped, (int*)ar.at(iR), s);
+	if (hipGetLastError() != hipSuccess) return done(fail(MCS_ERR_HIP, "k_rotation_consistency failed to launch"));
+	if (n && hipMemcpyAsync(match, ar.at(iM), (size_t)n * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
+	if (hipMemcpyAsync(removed, ar.at(iR), 4, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
+	return done(MCS_OK);
 }

@@ -144,6 +144,7 @@ struct ProjArgs {
 	int rule; int cap; int thLow;
 	const double* rad; const int* minLvl; const int* maxLvl;   // explicit window per probe
 	int* owner; int* mdist;                                    // rule 3: vnMatches21 / vMatchedDistance, [nfeat]
+	int* accepted;                                             // rule 3, optional: partner at acceptance time per probe (rotation histogram)
 };
 
 void launch_projection(const ProjArgs& a, hipStream_t s);

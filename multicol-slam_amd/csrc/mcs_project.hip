@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void k_proj_greedy(ProjArgs a) {
 		const int p = p0 + lane;
 		bool resolved = p >= a.nproj;
 		const int cnt = resolved ? 0 : a.counts[p];
-		if (!resolved) a.match[p] = -1;
+		if (!resolved) { a.match[p] = -1; if (a.accepted) a.accepted[p] = -1; }
 		if (!resolved && cnt == 0) resolved = true;
 		for (int round = 0; round < 130; ++round) {
 			const unsigned long long pend = __ballot(!resolved);
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(64) void k_proj_greedy(ProjArgs a) {
 						const int prev = a.owner[bestIdx];
 						if (prev >= 0) { a.match[prev] = -1; stole = true; }
 						a.owner[bestIdx] = p; a.mdist[bestIdx] = best;
+						if (a.accepted) a.accepted[p] = bestIdx;   // also kept if the match is stolen later (rotation histogram, :686-694)
 					} else {
 						atomicOr(&taken[bestIdx >> 5], 1u << (bestIdx & 31));
 						a.assigned[bestIdx] = 1;
@@ -306,6 +307,68 @@ __global__ __launch_bounds__(64) void k_proj_fill_dist(ProjArgs a, int* outDist)
 	if (p >= a.nproj) return;
 	const int j = a.match[p];
 	outDist[p] = j >= 0 ? proj_distance(a, p, j) : 0x7FFFFFFF;
+}
+
+// ---------------------------------------------------------------------------------------------- mbCheckOrientation
+// Rotation-consistency filter of the searches (ComputeThreeMaxima, src/cORBmatcher.cpp:2394-2436): 30-bin histogram of
+// rot = angle_first - angle_second (+360 if negative) over the accepted matches, matches outside the three fullest bins are dropped.
+// The four bin-arithmetic variants of the reference are listed in include/mcs_c.h (mcs_rotation_consistency).  One workgroup.
+__device__ __forceinline__ int rot_bin(int variant, float aFirst, float aSecond) {
+	float rot = aFirst - aSecond;
+	if (variant == 3) { if (rot < 0.0f) rot = (float)((double)rot + 360.0); }
+	else if (rot < 0.0f) rot += 360.0f;
+	int bin;
+	if (variant == 0) { const float factor = 1.0f / 30; bin = __double2int_rn((double)(rot * factor)); }
+	else if (variant == 1) { const double factor = (double)(1.0f / 30); bin = __double2int_rn((double)rot * factor); }
+	else if (variant == 2) { const double factor = 1.0 / 30; bin = (int)round((double)rot * factor); }
+	else { const double factor = 1.0 / 30; bin = __double2int_rn((double)rot * factor); }
+	return bin == 30 ? 0 : bin;
+}
+
+__global__ __launch_bounds__(256) void k_rotation_consistency(int variant, const float* angleSlot, int strideSlot, const float* anglePartner, int stridePartner,
+                                                              const int* accepted, int* match, int n, int swapped, int* removedOut) {
+	__shared__ int hist[30];
+	__shared__ int keep[3];
+	__shared__ int removed;
+	const int tid = threadIdx.x;
+	if (tid < 30) hist[tid] = 0;
+	if (tid == 0) removed = 0;
+	__syncthreads();
+	auto angle = [](const float* base, int strideBytes, int i) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)i * strideBytes); };
+	for (int s = tid; s < n; s += 256) {
+		const int p = accepted ? accepted[s] : match[s];
+		if (p < 0) continue;
+		const float a = angle(angleSlot, strideSlot, s), b = angle(anglePartner, stridePartner, p);
+		atomicAdd(&hist[rot_bin(variant, swapped ? b : a, swapped ? a : b)], 1);
+	}
+	__syncthreads();
+	if (tid == 0) {   // ComputeThreeMaxima
+		int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+		for (int i = 0; i < 30; i++) {
+			const int sz = hist[i];
+			if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+			else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+			else if (sz > max3) { max3 = sz; ind3 = i; }
+		}
+		if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+		else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
+		keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
+	}
+	__syncthreads();
+	for (int s = tid; s < n; s += 256) {
+		const int p = accepted ? accepted[s] : match[s];
+		if (p < 0) continue;
+		const float a = angle(angleSlot, strideSlot, s), b = angle(anglePartner, stridePartner, p);
+		const int bin = rot_bin(variant, swapped ? b : a, swapped ? a : b);
+		if (bin != keep[0] && bin != keep[1] && bin != keep[2] && match[s] >= 0) { match[s] = -1; atomicAdd(&removed, 1); }
+	}
+	__syncthreads();
+	if (tid == 0) *removedOut = removed;
+}
+
+void launch_rotation_consistency(int variant, const float* angleSlot, int strideSlot, const float* anglePartner, int stridePartner, const int* accepted, int* match,
+                                 int n, int swapped, int* removedOut, hipStream_t s) {
+	hipLaunchKernelGGL(k_rotation_consistency, dim3(1), dim3(256), 0, s, variant, angleSlot, strideSlot, anglePartner, stridePartner, accepted, match, n, swapped, removedOut);
 }
 
 void launch_projection(const ProjArgs& a, hipStream_t s) {

@@ -292,11 +292,24 @@ class cORBmatcher:
             self.TH_HIGH_, self.TH_LOW_ = int(np.floor(1.5 * featDim)), int(np.floor(featDim))
         else:
             self.TH_HIGH_, self.TH_LOW_ = 3 * featDim, 2 * featDim
-        if checkOri:
-            raise NotImplementedError("mbCheckOrientation is false at every reference call site (include/cORBmatcher.h:40)")
         self.ctx = ctx or default_context()
         self.K = K
         self.last_fallbacks = 0
+
+    def _rot_filter(self, variant, keys_slot, keys_partner, match, swapped, accepted=None):
+        """mbCheckOrientation: rotation-consistency filter (mcs_rotation_consistency) on `match` (slot -> partner index or -1), in place.
+        -> number of matches removed (0 when the matcher was built with checkOri = False)."""
+        if not self.mbCheckOrientation or len(match) == 0:
+            return 0
+        ks, kp = np.ascontiguousarray(keys_slot), np.ascontiguousarray(keys_partner)
+        if len(kp) == 0:
+            return 0
+        off = KP_DTYPE.fields["angle"][1]
+        acc = None if accepted is None else np.ascontiguousarray(accepted, np.int32)
+        rem = np.zeros(1, np.int32)
+        check(lib().mcs_rotation_consistency(self.ctx.h, variant, C.c_void_p(ks.ctypes.data + off), KP_DTYPE.itemsize, C.c_void_p(kp.ctypes.data + off),
+                                             KP_DTYPE.itemsize, np_ptr(acc), np_ptr(match), len(match), len(kp), int(swapped), MEM_HOST, np_ptr(rem)))
+        return int(rem[0])
 
     def _sets(self, d1, m1, v1, g1, d2, m2, v2, g2):
         keep = [np.ascontiguousarray(d1, np.uint8), np.ascontiguousarray(d2, np.uint8)]
@@ -339,13 +352,17 @@ class cORBmatcher:
             check(lib().mcs_search_kf_f(self.ctx.h, 1, C.byref(q), 0, C.byref(t), 0, self.mbFeatDim, self.mfNNratio, self.K, MEM_HOST, np_ptr(mF),
                                         np_ptr(nm), np_ptr(fb)))
             self.last_fallbacks = int(fb[0])
-            return int(nm[0]), [mp1[int(order[i])] if i >= 0 else None for i in mF[:F.totalN]]
+            mF = np.where(mF[:F.totalN] >= 0, order[np.maximum(mF[:F.totalN], 0)], -1).astype(np.int32)   # back to keyframe feature indices
+            removed = self._rot_filter(0, F.mvKeys, pKF1.mvKeys, mF, True)
+            return int(nm[0]) - removed, [mp1[int(i)] if i >= 0 else None for i in mF]
         q, t, keep = self._sets(pKF1._d, pKF1._m, v1, None, F.all_descriptors(), F.all_masks(), None, None)
         mF = np.full(max(F.totalN, 1), -1, np.int32)
         check(lib().mcs_search_kf_f(self.ctx.h, 1, C.byref(q), 0, C.byref(t), 0, self.mbFeatDim, self.mfNNratio, self.K, MEM_HOST, np_ptr(mF),
                                     np_ptr(nm), np_ptr(fb)))
         self.last_fallbacks = int(fb[0])
-        return int(nm[0]), [mp1[i] if i >= 0 else None for i in mF[:F.totalN]]
+        mF = np.ascontiguousarray(mF[:F.totalN])
+        removed = self._rot_filter(0, F.mvKeys, pKF1.mvKeys, mF, True)
+        return int(nm[0]) - removed, [mp1[i] if i >= 0 else None for i in mF]
 
     def SearchByProjection(self, F, vpMapPoints, th, *rest):
         """int SearchByProjection(cMultiFrame &F, const vector<cMapPoint*> &vpMapPoints, const double th) (src/cORBmatcher.cpp:67-166).
@@ -420,7 +437,9 @@ class cORBmatcher:
         rows = np.asarray(rows, np.int64)
         dd = np.ascontiguousarray(F1.all_descriptors()[rows], np.uint8)
         mm = np.ascontiguousarray(F1.all_masks()[rows], np.uint8) if self.havingMasks else None
-        pr = WindowProbes(np_ptr(x), np_ptr(y), np_ptr(r), np_ptr(lo), np_ptr(hi), np_ptr(cam), np_ptr(dd), np_ptr(mm), n, self.mbFeatDim)
+        self.last_accepted = np.full(n, -1, np.int32)
+        pr = WindowProbes(np_ptr(x), np_ptr(y), np_ptr(r), np_ptr(lo), np_ptr(hi), np_ptr(cam), np_ptr(dd), np_ptr(mm), n, self.mbFeatDim,
+                          np_ptr(self.last_accepted) if rule == 3 else None)
         fv, keep = self._frame_view(F2, assigned)
         match = np.full(n, -1, np.int32)
         nm = np.zeros(1, np.int32)
@@ -459,12 +478,12 @@ class cORBmatcher:
         assigned = np.zeros(max(F2.totalN, 1), np.uint8)
         match, nm = self._window_match(WINDOW_RATIO, k["x"].astype(np.float64), k["y"].astype(np.float64), np.full(n, float(windowSize)), np.full(n, -1),
                                        np.full(n, -1), F1.keypoint_to_cam[rows], rows, F1, F2, assigned)
-        out = [None] * F2.totalN
         self.last_matches21 = np.full(F2.totalN, -1, np.int32)
         for p, j in enumerate(match):
             if j >= 0:
-                out[int(j)] = F1.mvpMapPoints[rows[p]]
                 self.last_matches21[int(j)] = rows[p]
+        nm -= self._rot_filter(1, F2.mvKeys, F1.mvKeys, self.last_matches21, True)
+        out = [F1.mvpMapPoints[int(i)] if i >= 0 else None for i in self.last_matches21]
         return nm, out
 
     def SearchByProjectionFrames(self, F1, F2, windowSize, vpMapPointMatches2):
@@ -510,9 +529,14 @@ class cORBmatcher:
         radius = float(th) * np.asarray(CurrentFrame.mvScaleFactors, np.float64)[octv]
         assigned = np.array([m is not None for m in CurrentFrame.mvpMapPoints] + [0] * (CurrentFrame.totalN == 0), np.uint8)
         match, nm = self._window_match(WINDOW_BEST, uv[ok, 0], uv[ok, 1], radius, octv - 1, octv + 1, cams[ok], rows, LastFrame, CurrentFrame, assigned)
+        mcur = np.full(CurrentFrame.totalN, -1, np.int32)
         for p, j in enumerate(match):
             if j >= 0:
-                CurrentFrame.mvpMapPoints[int(j)] = LastFrame.mvpMapPoints[int(rows[p])]
+                mcur[int(j)] = rows[p]
+        nm -= self._rot_filter(0, CurrentFrame.mvKeys, LastFrame.mvKeys, mcur, True)
+        for j, i in enumerate(mcur):
+            if i >= 0:
+                CurrentFrame.mvpMapPoints[j] = LastFrame.mvpMapPoints[int(i)]
         return nm
 
     def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize=10):
@@ -523,6 +547,7 @@ class cORBmatcher:
         lv = F1.mvKeys["octave"].astype(np.int32)
         match, nm = self._window_match(WINDOW_INITIALIZE, vbPrevMatched[:, 0], vbPrevMatched[:, 1], np.full(n, float(windowSize)), lv, lv,
                                        F1.keypoint_to_cam, rows, F1, F2, None)
+        nm -= self._rot_filter(2, F1.mvKeys, F2.mvKeys, match, False, self.last_accepted)
         for i1, j in enumerate(match):
             if j >= 0:
                 vbPrevMatched[i1, 0], vbPrevMatched[i1, 1] = float(F2.mvKeys[int(j)]["x"]), float(F2.mvKeys[int(j)]["y"])
@@ -546,7 +571,9 @@ class cORBmatcher:
         check(lib().mcs_search_triangulation(self.ctx.h, 1, C.byref(q), 0, C.byref(t), 0, np_ptr(r1), np_ptr(r2), np_ptr(E), nr, self.mbFeatDim,
                                              max(self.K, 16), MEM_HOST, np_ptr(m12), np_ptr(nm), np_ptr(fb)))
         self.last_fallbacks = int(fb[0])
-        pairs = [(i, int(j)) for i, j in enumerate(m12[:len(v1)]) if j >= 0]
+        m12 = np.ascontiguousarray(m12[:len(v1)])
+        nm[0] -= self._rot_filter(3, pKF1.mvKeys, pKF2.mvKeys, m12, False)
+        pairs = [(i, int(j)) for i, j in enumerate(m12) if j >= 0]
         i1 = [p[0] for p in pairs]
         i2 = [p[1] for p in pairs]
         return int(nm[0]), pKF1.mvKeys[i1], pKF1.mvKeysRays[i1], pKF2.mvKeys[i2], pKF2.mvKeysRays[i2], pairs

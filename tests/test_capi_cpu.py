@@ -82,7 +82,7 @@ def test_cpp_facade_compiles_and_links(pkg, tmp_path):
     import subprocess
     src = tmp_path / "facade.cpp"
     src.write_text('#include "mcs/mcs_facade.hpp"\n'
-                   'int main() { try { MultiColSLAM::Context c(0); MultiColSLAM::mdBRIEFextractorOct e(c); MultiColSLAM::cORBmatcher m(c, 0.9, false, 32, true); }\n'
+                   'int main() { try { MultiColSLAM::Context c(0); MultiColSLAM::mdBRIEFextractorOct e(c); MultiColSLAM::cORBmatcher m(c, 0.9, true, 32, true); }\n'
                    '  catch (const std::exception&) { return 3; } return 0; }\n')
     exe = tmp_path / "facade"
     lib_dir = os.path.join(ROOT, "multicol-slam_amd")

@@ -282,3 +282,102 @@ def test_window_match_device_pointers_and_errors(G, FE, frames):
         with pytest.raises(mcs.McsError):
             q = p or cap.WindowProbes(vp(dp["x"]), vp(dp["y"]), vp(dp["r"]), vp(dp["lo"]), vp(dp["hi"]), vp(dp["cam"]), vp(dp["d"]), vp(dp["m"]), n, 32)
             mcs.check(mcs.lib().mcs_window_match(G.ctx().h, C.byref(q), C.byref(fv), bad_rule, 0.8, 32, mcs.MEM_DEVICE, vp(dmatch), vp(dn)))
+
+
+def test_check_orientation_filters(G, FE, frames):
+    """cORBmatcher(checkOri = True): the rotation-consistency pass (mcs_rotation_consistency, four bin-arithmetic variants) on the GPU vs the oracle's
+    searches with the flag (embedded histograms) resp. search + orc_rotation_consistency."""
+    import ctypes as C
+    cams, fr = frames
+    Fa, Fb = fr
+    rng = np.random.default_rng(77)
+    L = G.O.lib()
+    L.orc_rotation_consistency.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+
+    def ofilter(variant, a_slot, a_partner, match, swapped):
+        a, b = np.ascontiguousarray(a_slot, np.float32), np.ascontiguousarray(a_partner, np.float32)
+        m = np.ascontiguousarray(match, np.int32).copy()
+        rem = L.orc_rotation_consistency(variant, G.O.ptr(a), G.O.ptr(b), None, G.O.ptr(m), len(m), swapped)
+        return rem, m
+
+    for masks in (True, False):
+        m = FE.cORBmatcher(0.9, True, 32, masks, ctx=G.ctx())
+        v1, _k1 = oview(G, Fa, masks)
+        v2, _k2 = oview(G, Fb, masks)
+        # WindowSearch (variant 1)
+        Fa.mvpMapPoints = [MP(i) if rng.random() < 0.8 else None for i in range(Fa.totalN)]
+        has = np.array([mp is not None for mp in Fa.mvpMapPoints], np.uint8)
+        n, out = m.WindowSearch(Fa, Fb, 60)
+        en, e21 = G.O.window_search(v1, has, v2, 60, 0, -1, 0.9, 32, masks, checkOri=1)
+        un, _u = G.O.window_search(v1, has, v2, 60, 0, -1, 0.9, 32, masks, checkOri=0)
+        assert n == en and np.array_equal(m.last_matches21, e21) and un > en
+        # SearchForInitialization (variant 2, histogram over every acceptance)
+        prev = np.stack([Fa.mvKeys["x"], Fa.mvKeys["y"]], axis=1).astype(np.float64)
+        p = prev.copy()
+        n, m12 = m.SearchForInitialization(Fa, Fb, p, 100)
+        en, e12, ep = G.O.search_for_initialization(v1, v2, prev, 100, 0.9, 32, masks, checkOri=1)
+        assert n == en and np.array_equal(m12, e12) and np.array_equal(p, ep)
+        # SearchByBoW(KF, F) brute force (variant 0) and SearchForTriangulationRaw (variant 3)
+        kf = FE.cMultiKeyFrame(Fa)
+        n, outF = m.SearchByBoW(kf, Fb)
+        en, eF = G.O.search_kf_f(Fa.all_descriptors(), Fa.all_masks(), has, Fb.all_descriptors(), Fb.all_masks(), masks, 0.9)
+        rem, eF2 = ofilter(0, Fb.mvKeys["angle"], Fa.mvKeys["angle"], eF, 1)
+        assert n == en - rem and [(-1 if o is None else o.i) for o in outF] == eF2.tolist() and rem > 0
+        Fa.mvpMapPoints = [None] * Fa.totalN
+    # SearchByProjection(Cur, Last) (variant 0)
+    Last, Cur = fr
+    idx = rng.permutation(Last.totalN)[:int(0.8 * Last.totalN)]
+    pts = world_points(Last, rng, idx)
+    Last.mvpMapPoints = [MP(i, pts[i]) if i in pts else None for i in range(Last.totalN)]
+    try:
+        m = FE.cORBmatcher(0.8, True, 32, True, ctx=G.ctx())
+        n = m.SearchByProjection(Cur, Last, 15.0)
+        P = np.zeros((Last.totalN, 3))
+        for i, pp in pts.items():
+            P[i] = pp
+        euv, efl = G.O.world_to_cam(np.stack(Cur.camSystem.MtMc_inv), cams, [G.synth.mirror_mask(c) for c in cams], P, Last.keypoint_to_cam)
+        lastMP = np.array([mp is not None for mp in Last.mvpMapPoints], np.uint8)
+        vc, _kc = oview(G, Cur, True)
+        vl, _kl = oview(G, Last, True)
+        en, ecur, _ = G.O.search_by_projection_last(vc, np.zeros(Cur.totalN, np.uint8), vl, lastMP, np.zeros(Last.totalN, np.uint8), euv, efl & 1, Cur.mvScaleFactors,
+                                                   15.0, 32, True, checkOri=1)
+        got = np.array([mp.i if mp is not None else -1 for mp in Cur.mvpMapPoints], np.int32)
+        assert n == en and np.array_equal(got, ecur)
+    finally:
+        Last.mvpMapPoints = [None] * Last.totalN
+        Cur.mvpMapPoints = [None] * Cur.totalN
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_rotation_consistency_kernel_random(G, variant):
+    """mcs_rotation_consistency on random matches / angles (all four bin arithmetics, both directions, with and without an acceptance record,
+    keypoint-strided and plain float angle arrays) vs orc_rotation_consistency"""
+    import ctypes as C
+    L = G.O.lib()
+    L.orc_rotation_consistency.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    rng = np.random.default_rng(variant)
+    for trial in range(6):
+        n, npart = int(rng.integers(1, 4000)), int(rng.integers(1, 4000))
+        peak = rng.uniform(0, 360)
+        a = np.where(rng.random(n) < 0.6, peak + rng.normal(0, 8, n), rng.uniform(0, 360, n)).astype(np.float32) % np.float32(360)
+        b = rng.uniform(0, 360, npart).astype(np.float32)
+        b[rng.integers(0, npart, npart // 3)] = np.float32(0.0)
+        match = np.where(rng.random(n) < 0.7, rng.integers(0, npart, n), -1).astype(np.int32)
+        accepted = None
+        if trial % 2:
+            accepted = match.copy()
+            stolen = rng.random(n) < 0.1
+            accepted[stolen & (match < 0)] = rng.integers(0, npart, int((stolen & (match < 0)).sum()))
+        for swapped in (0, 1):
+            em = match.copy()
+            erem = L.orc_rotation_consistency(variant, G.O.ptr(a), G.O.ptr(b), G.O.ptr(accepted), G.O.ptr(em), n, swapped)
+            gm, rem = match.copy(), np.zeros(1, np.int32)
+            if trial % 3 == 0:   # angles inside keypoint records
+                ka, kb = np.zeros(n, G.O.KP_DTYPE), np.zeros(npart, G.O.KP_DTYPE)
+                ka["angle"], kb["angle"] = a, b
+                pa, pb, st = C.c_void_p(ka.ctypes.data + 12), C.c_void_p(kb.ctypes.data + 12), 28
+            else:
+                pa, pb, st = C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), 4
+            G.mcs.check(G.mcs.lib().mcs_rotation_consistency(G.ctx().h, variant, pa, st, pb, st, G.O.ptr(accepted), G.O.ptr(gm), n, npart, swapped, G.mcs.MEM_HOST,
+                                                             G.O.ptr(rem)))
+            assert int(rem[0]) == erem and np.array_equal(gm, em), (variant, trial, swapped)
