@@ -331,7 +331,27 @@ def cpu_baseline(args, pool, POOL, cams, NCAM, W, H, nfeat, do_db, masks_on, syn
                 best = (wall, secs[0], secs[1], tot, threads)
     wall, se, sm, tot, threads = best
     per_frame = tot / nf
-    return {"value": round(per_frame * (nf - 1) / wall / 1e6, 4), "unit": "Mfeatures/s", "cores": threads, "kind": "port",
+    # the same extractor as the REFERENCE's own sources (oracle/_ref = src/mdBRIEFextractorOct.cpp compiled unmodified against oracle/cvshim, its image
+    # primitives are the oracle's), single thread, next to the oracle single thread: the port is not slower than the code it restates
+    side = None
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libmcs_ref.so")
+    if os.path.exists(ref_so):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import ref_compare as R
+            msk = [np.ascontiguousarray(m) for m in mk]
+            t0 = time.perf_counter()
+            for i in range(6):
+                R.run_ref(flat[i], msk[i % NCAM], cams[i % NCAM], nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)
+            t1 = time.perf_counter()
+            exo = [O.Extractor(nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on) for _ in range(NCAM)]
+            for i in range(6):
+                exo[i % NCAM](flat[i], msk[i % NCAM], O.make_ocam(cams[i % NCAM]))
+            t2 = time.perf_counter()
+            side = {"reference_sources_ms_per_image_1thread": round((t1 - t0) / 6 * 1e3, 1), "port_ms_per_image_1thread": round((t2 - t1) / 6 * 1e3, 1)}
+        except Exception as e:   # the side measurement is optional
+            side = {"error": str(e)[:120]}
+    return {"extract_1thread": side,"value": round(per_frame * (nf - 1) / wall / 1e6, 4), "unit": "Mfeatures/s", "cores": threads, "kind": "port",
             "sample": "%d multi-frames (%d images) of the same synthetic stream: oracle extract (%s) %.2fs + SearchByBoW(KF,KF) vs previous frame %.2fs wall, "
                       "OpenMP over images/frames on %d threads (cgroup CPU quota of this box: %d of %d hardware threads; best of quota and 2x quota, 2 passes each)"
                       % (nf, nf * NCAM, args.mode, se, sm, threads, quota, nproc),
