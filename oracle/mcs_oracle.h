@@ -15,12 +15,13 @@
  *     tests/golden/ref_extract.npz for machines without the checkout): the extractor in all three modes, the camera model and camera system
  *     (poses, WorldToCamHom_fast, mirror-mask test), cMultiFrame's constructor fields and ComputeBoW (DBoW2 load + transform), SearchByBoW KF-KF and KF-F
  *     (vocabulary-restricted and, through a one-leaf vocabulary, brute force), SearchForTriangulationRaw incl. ComputeE / CheckDistEpipolarLine,
- *     WindowSearch, SearchForInitialization, the three SearchByProjection overloads, cMapPoint::ComputeDistinctiveDescriptors — driven through REAL
+ *     WindowSearch, SearchForInitialization, the three SearchByProjection overloads, the rotation-consistency filter (mbCheckOrientation = true), the
+ *     search loop of Fuse, cMapPoint::ComputeDistinctiveDescriptors — driven through REAL
  *     cMultiFrame / cMultiKeyFrame / cMapPoint / cORBmatcher objects (oracle/ref_wrap_match.cpp).
- *   UNPINNED: (a) the OpenCV image primitives the sources call (resize, copyMakeBorder, FAST, boxFilter, fastAtan2, cvRound, Matx products) — un-vendored
+ *   UNPINNED: the OpenCV image primitives the sources call (resize, copyMakeBorder, FAST, boxFilter, fastAtan2, cvRound, Matx products) — un-vendored
  *     third-party code restated from its published generic C++ algorithm; the shim forwards them to the restatements below, so
- *     _ref cannot check them (hand-derived known-answer tests do: tests/test_oracle_kat.py); (b) orc_window_best, the common core of the Fuse /
- *     SearchBySim3 / SearchForTriangulationBetweenCameras loops (those functions need map-point state the scene driver does not build).
+ *     _ref cannot check them (hand-derived known-answer tests do: tests/test_oracle_kat.py).  (orc_window_best is pinned through Fuse; the other
+ *     users of that loop — SearchBySim3, SearchForTriangulationBetweenCameras — need Sim3 / relative-pose state the scene driver does not build.)
  *   The reference's DistributeOctTree orders equal nodes by heap address; _ref runs it on a bump arena (increasing addresses = creation order), the
  *   order the oracle uses; with the system allocator the reference's own output varies from run to run.  _ref is built without -fopenmp (the
  *   per-camera `#pragma omp parallel for` of cMultiFrame's constructor only changes timing).

@@ -237,3 +237,29 @@ extern "C" int rs_distinctive(void* h, int k, const int* idx, int n, uint8_t* de
 	if (s->masks) { cv::Mat mm = mp->GetDescriptorMask(); std::memcpy(mask, mm.ptr<uchar>(0), s->dim); }
 	return 0;
 }
+
+// cORBmatcher::Fuse(pKF, curKF, vpMapPoints, th) (src/cORBmatcher.cpp:1265-1418), one fresh map point at a time against a keyframe that holds no
+// map points: every accepted (point, camera) shows up as a new observation, which is recorded and removed again.  bestIdx: [n][nrCams], -1 = none.
+// minmax: GetMinDistanceInvariance / GetMaxDistanceInvariance of each point after UpdateNormalAndDepth.
+extern "C" int rs_fuse_probes(void* h, int kTarget, int kSource, const int* feat, const double* pos, int n, double th, int* bestIdx, double* minmax) {
+	Scene* s = (Scene*)h;
+	try {
+		cORBmatcher m(0.8, false, s->dim, s->masks);
+		cMultiKeyFrame* T = s->kfs[kTarget]; cMultiKeyFrame* S = s->kfs[kSource];
+		const int nc = s->rig.GetNrCams();
+		for (int i = 0; i < n; ++i) {
+			for (int c = 0; c < nc; ++c) bestIdx[i * nc + c] = -1;
+			cMapPoint* mp = new cMapPoint(cv::Vec3d(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]), S, s->map);
+			mp->AddObservation(S, (size_t)feat[i]);
+			mp->ComputeDistinctiveDescriptors(s->masks);
+			mp->UpdateNormalAndDepth();
+			minmax[2 * i] = mp->GetMinDistanceInvariance(); minmax[2 * i + 1] = mp->GetMaxDistanceInvariance();
+			std::vector<cMapPoint*> v(1, mp);
+			m.Fuse(T, S, v, th);
+			std::map<cMultiKeyFrame*, std::vector<size_t>> obs = mp->GetObservations();
+			if (obs.count(T))
+				for (size_t idx : obs[T]) { bestIdx[i * nc + T->keypoint_to_cam.find(idx)->second] = (int)idx; T->EraseMapPointMatch(idx); }
+		}
+		return 0;
+	} catch (const std::exception& e) { std::cerr << "rs_fuse_probes: " << e.what() << std::endl; return -1; }
+}
