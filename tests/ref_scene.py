@@ -17,8 +17,8 @@ def P(a):
 
 
 class RefScene:
-    def __init__(self, cams, masks, M_c, voc_path=None, **params):
-        self.L = C.CDLL(REF_SO)
+    def __init__(self, cams, masks, M_c, voc_path=None, so_path=None, **params):
+        self.L = C.CDLL(so_path or REF_SO)
         L = self.L
         L.rs_create.restype = vp
         L.rs_create.argtypes = [vp, C.POINTER(O.Ocam), C.POINTER(vp), C.c_int, C.POINTER(O.Params), C.c_char_p]
