@@ -263,3 +263,21 @@ extern "C" int rs_fuse_probes(void* h, int kTarget, int kSource, const int* feat
 		return 0;
 	} catch (const std::exception& e) { std::cerr << "rs_fuse_probes: " << e.what() << std::endl; return -1; }
 }
+
+// cORBmatcher::Fuse(pKF, curKF, vpMapPoints, th) the way cLocalMapping::SearchInNeighbors calls it (src/cLocalMapping.cpp:416-424): the whole map-point
+// list of the source keyframe in one call, against a target keyframe that holds map points of its own (the Replace / AddObservation surgery runs).
+// -> nFused; idsT / idsS = the map-point ids both keyframes hold afterwards, badS[i] = the point source feature i held BEFORE the call is bad now.
+extern "C" int rs_fuse(void* h, int kTarget, int kSource, double th, int* idsT, int* idsS, uint8_t* badS) {
+	Scene* s = (Scene*)h;
+	try {
+		cORBmatcher m(0.8, false, s->dim, s->masks);
+		cMultiKeyFrame* T = s->kfs[kTarget]; cMultiKeyFrame* S = s->kfs[kSource];
+		std::vector<cMapPoint*> v = S->GetMapPointMatches();
+		for (cMapPoint* p : v) if (p && !p->isBad()) p->UpdateNormalAndDepth();
+		const int n = m.Fuse(T, S, v, th);
+		std::vector<cMapPoint*> a = T->GetMapPointMatches(), b = S->GetMapPointMatches();
+		for (size_t i = 0; i < a.size(); ++i) idsT[i] = id_or_minus1(s, a[i]);
+		for (size_t i = 0; i < b.size(); ++i) { idsS[i] = id_or_minus1(s, b[i]); badS[i] = v[i] && v[i]->isBad(); }
+		return n;
+	} catch (const std::exception& e) { std::cerr << "rs_fuse: " << e.what() << std::endl; return -1; }
+}

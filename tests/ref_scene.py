@@ -40,6 +40,8 @@ class RefScene:
         L.rs_proj_frames.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, vp]
         L.rs_distinctive.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
         L.rs_fuse_probes.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_double, vp, vp]
+        if hasattr(L, "rs_fuse"):
+            L.rs_fuse.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp, vp, vp]
         L.rs_destroy.argtypes = [vp]
         self.nr = len(cams)
         self.prm = O.make_params(**params)
