@@ -4,12 +4,12 @@
 // cMultiFrame / cMultiKeyFrame / cMapPoint objects to libmcs_hip.so (include/mcs_c.h) and write the results back into the reference's own
 // containers.  What stays host code is exactly what the reference does between its distance loops: which features take part (map point present /
 // bad / already found / level gate), and the map-point surgery of Fuse.
-//   on the GPU      SearchByBoW (KF,KF) and (KF,F) incl. the vocabulary restriction, SearchForTriangulationRaw, WindowSearch, SearchForInitialization,
-//                   SearchByProjection (F, mapPoints) / (F1, F2, window) / (Current, Last), Fuse(pKF, curKF, mapPoints, th),
-//                   the mbCheckOrientation pass of each of them
-//   not replaced    the loop-closing / relocalisation variants (SearchBySim3, Fuse with Sim3 or neighbour lists, SearchByProjection with Scw /
-//                   sAlreadyFound, SearchForTriangulation / ...BetweenCameras): their search loop is mcs_window_best; a
-//                   maintainer keeps the reference's bodies for them.  Here they throw, so that nothing silently runs on the CPU.
+//   on the GPU      SearchByBoW (KF,KF) and (KF,F) incl. the vocabulary restriction, SearchForTriangulationRaw, SearchForTriangulationBetweenCameras,
+//                   WindowSearch, SearchForInitialization, SearchByProjection (F, mapPoints) / (F1, F2, window) / (Current, Last), SearchBySim3,
+//                   Fuse (pKF, curKF, points) / (pKF, points) / (pKF, Scw, points), and the mbCheckOrientation pass of each search that has one
+//   not replaced    SearchByProjection(CurrentFrame, pKF, sAlreadyFound, ...) and SearchByProjection(pKF, Scw, ...): the reference reads outside its
+//                   descriptor matrices there (see the end of this file), there is no defined result to reproduce.  They throw.
+//                   SearchForTriangulation and Fuse(curKF, neighKFs, map) are declared in the header but defined nowhere in the reference.
 // tests/test_gpu_dropin.py builds the reference's cMultiFrame.cpp, cMultiKeyFrame.cpp, cMapPoint.cpp ... around this file and
 // mdBRIEFextractorOct_mcs.cpp and compares every search with the all-reference build.
 #include <algorithm>
@@ -109,7 +109,8 @@ namespace
 		}
 	};
 	// WorldToCamHom_fast + isPointInMirrorMask for many (point, camera) pairs of one camera system
-	void project(cMultiCamSys_& cs, const std::vector<double>& pts, const std::vector<int32_t>& cam, std::vector<double>& uv, std::vector<uint8_t>& flags)
+	void project(cMultiCamSys_& cs, const std::vector<double>& pts, const std::vector<int32_t>& cam, std::vector<double>& uv, std::vector<uint8_t>& flags,
+		bool cameraCoordinates = false)   // true: the points are in camera coordinates already (cCamModelGeneral_::WorldToImg alone; identity * p is exact)
 	{
 		const int nr = cs.GetNrCams(), n = (int)cam.size();
 		std::vector<double> M((size_t)nr * 16);
@@ -118,7 +119,7 @@ namespace
 		std::vector<const uint8_t*> masks(nr);
 		for (int c = 0; c < nr; ++c)
 		{
-			cv::Matx44d inv = cs.Get_MtMc_inv(c);
+			cv::Matx44d inv = cameraCoordinates ? cv::Matx44d::eye() : cs.Get_MtMc_inv(c);
 			std::memcpy(&M[16 * (size_t)c], inv.val, 128);
 			cCamModelGeneral_ cm = cs.GetCamModelObj(c);
 			mcs_ocam& o = oc[c];
@@ -439,78 +440,248 @@ int cORBmatcher::SearchByProjection(cMultiFrame &CurrentFrame, const cMultiFrame
 }
 
 // ---- Fuse: the search on the GPU (one mcs_window_best for all (map point, camera) pairs), the map-point surgery as in the reference -------------
-int cORBmatcher::Fuse(cMultiKeyFrame *pKF, cMultiKeyFrame *curKF, vector<cMapPoint *> &vpMapPoints, double th)
+namespace
 {
-	cMultiCamSys_& camSys = pKF->camSystem;
-	const int nr = camSys.GetNrCams(), nMaxLevel = pKF->GetScaleLevels() - 1;
-	vector<double> vfScaleFactors = pKF->GetScaleFactors();
-	cv::Vec3d Ow = pKF->GetCameraCenter();
-	Flat b = flatten(pKF, mbFeatDim, havingMasks);
-	std::vector<double> pts; std::vector<int32_t> pc, owner;
-	for (size_t i = 0; i < vpMapPoints.size(); ++i)
+	struct FuseRule
 	{
-		cMapPoint* pMP = vpMapPoints[i];
-		if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
-		cv::Vec3d X = pMP->GetWorldPos();
-		for (int cam = 0; cam < nr; ++cam) { pts.push_back(X(0)); pts.push_back(X(1)); pts.push_back(X(2)); pc.push_back(cam); owner.push_back((int)i); }
-	}
-	if (owner.empty() || b.n == 0) return 0;
-	std::vector<double> uv; std::vector<uint8_t> fl;
-	project(camSys, pts, pc, uv, fl);
-	Probes p;
-
-	for (size_t k = 0; k < owner.size(); ++k)
+		bool floatDepth;          // dist3D rounded to float (:1305, :1463) or kept in double (:1621)
+		bool zeroDistance;        // Fuse(pKF, vpMapPoints, th) drops the value DescriptorDistance64 returns (:1513-1516): every distance is 0 there and the
+		                          // first feature of the window inside the level range wins.  Reproduced: all-zero descriptors on both sides.
+		bool inKeyFrameTest;      // skip test "isBad || IsInKeyFrame(pKF)" (re-evaluated per list entry) vs "isBad || in the snapshot set" (:1601)
+		cMultiKeyFrame* curKF;    // the epipolar test of :1384-1395, or NULL
+	};
+	int fuse_common(cMultiKeyFrame* pKF, cMultiCamSys_& camSys, const cv::Vec3d& Ow, const std::vector<cMapPoint*>& vpMapPoints, const std::set<cMapPoint*>& snapshot,
+		double th, const FuseRule& rule, int dim, bool havingMasks, int thLow)
 	{
-		if (!(fl[k] & 1)) continue;
-		cMapPoint* pMP = vpMapPoints[owner[k]];
-		const double maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
-		cv::Vec3d PO = pMP->GetWorldPos() - Ow;
-		const float dist3D = cv::norm(PO);
-		if (dist3D < minDistance || dist3D > maxDistance) continue;
-		const double ratio = dist3D / minDistance;
-		vector<double>::iterator it = std::lower_bound(vfScaleFactors.begin(), vfScaleFactors.end(), ratio);
-		const int nPredictedLevel = std::min(static_cast<int>(it - vfScaleFactors.begin()), nMaxLevel);
-		p.add(uv[2 * k], uv[2 * k + 1], th * vfScaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, pc[k], owner[k]);
-		const uchar* dp = (const uchar*)pMP->GetDescriptorPtr();
-		p.d.insert(p.d.end(), dp, dp + mbFeatDim);
-		if (havingMasks) { const uchar* mp = (const uchar*)pMP->GetDescriptorMaskPtr(); p.m.insert(p.m.end(), mp, mp + mbFeatDim); }
-
-	}
-	if (p.x.empty()) return 0;
-	mcs_window_probes pr = p.c(mbFeatDim, havingMasks);
-	mcs_frame_view fv = view(b, nullptr, mbFeatDim, havingMasks);
-	std::vector<int32_t> match(p.x.size(), -1), dist(p.x.size(), 0);
-	int32_t nfound = 0;
-	check(mcs_window_best(ctx(), &pr, &fv, TH_LOW_, 0, mbFeatDim, MCS_MEM_HOST, match.data(), dist.data(), &nfound), "mcs_window_best");
-	int nFused = 0;
-	int skipOwner = -1;
-	for (size_t k = 0; k < match.size(); ++k)   // probes are in (map point, camera) order: the surgery below sees them like the reference's loop
-	{
-		cMapPoint* pMP = vpMapPoints[p.src[k]];
-		// the reference tests isBad / IsInKeyFrame when it reaches list entry i, i.e. after the surgery of the entries before it (a map point listed
-		// twice, or replaced meanwhile, is skipped then); all cameras of one entry are searched before its own surgery starts
-		if (k == 0 || p.src[k] != p.src[k - 1]) skipOwner = (pMP->isBad() || pMP->IsInKeyFrame(pKF)) ? p.src[k] : -1;
-		if (p.src[k] == skipOwner || match[k] < 0) continue;
-		const int bestIdx = match[k];
-		cMapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
-		if (pMPinKF)
+		const int nr = camSys.GetNrCams(), nMaxLevel = pKF->GetScaleLevels() - 1;
+		vector<double> vfScaleFactors = pKF->GetScaleFactors();
+		const bool masks = havingMasks && !rule.zeroDistance;
+		Flat b = flatten(pKF, dim, masks);
+		if (rule.zeroDistance) std::fill(b.d.begin(), b.d.end(), 0);
+		std::vector<double> pts; std::vector<int32_t> pc, owner;
+		for (size_t i = 0; i < vpMapPoints.size(); ++i)
 		{
-			cv::Vec3d ray1 = curKF->GetKeyPointRay(p.src[k]);
-			cv::Vec3d ray2 = pKF->GetKeyPointRay(bestIdx);
-			const int camIdx1 = p.cam[k];
-			cv::Matx33d E12 = ComputeE(curKF->camSystem.Get_MtMc_inv(camIdx1) * pKF->camSystem.Get_MtMc(camIdx1));
-			if (!pMPinKF->isBad() && CheckDistEpipolarLine(ray1, ray2, E12, 1e-2)) { pMP->Replace(pMPinKF); ++nFused; }
+			cMapPoint* pMP = vpMapPoints[i];
+			if (!pMP || pMP->isBad() || (rule.inKeyFrameTest ? pMP->IsInKeyFrame(pKF) : snapshot.count(pMP) != 0)) continue;
+			cv::Vec3d X = pMP->GetWorldPos();
+			for (int cam = 0; cam < nr; ++cam) { pts.push_back(X(0)); pts.push_back(X(1)); pts.push_back(X(2)); pc.push_back(cam); owner.push_back((int)i); }
 		}
-		else { pMP->AddObservation(pKF, bestIdx); pKF->AddMapPoint(pMP, bestIdx); }
+		if (owner.empty() || b.n == 0) return 0;
+		std::vector<double> uv; std::vector<uint8_t> fl;
+		project(camSys, pts, pc, uv, fl);
+		Probes p;
+		for (size_t k = 0; k < owner.size(); ++k)
+		{
+			if (!(fl[k] & 1)) continue;
+			cMapPoint* pMP = vpMapPoints[owner[k]];
+			const double maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+			cv::Vec3d PO = pMP->GetWorldPos() - Ow;
+			double dist3D = cv::norm(PO);
+			if (rule.floatDepth) dist3D = (float)dist3D;
+			if (dist3D < minDistance || dist3D > maxDistance) continue;
+			const double ratio = dist3D / minDistance;
+			vector<double>::iterator it = std::lower_bound(vfScaleFactors.begin(), vfScaleFactors.end(), ratio);
+			const int nPredictedLevel = std::min(static_cast<int>(it - vfScaleFactors.begin()), nMaxLevel);
+			p.add(uv[2 * k], uv[2 * k + 1], th * vfScaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, pc[k], owner[k]);
+			if (rule.zeroDistance) { p.d.insert(p.d.end(), dim, 0); continue; }
+			const uchar* dp = (const uchar*)pMP->GetDescriptorPtr();
+			p.d.insert(p.d.end(), dp, dp + dim);
+			if (masks) { const uchar* mp = (const uchar*)pMP->GetDescriptorMaskPtr(); p.m.insert(p.m.end(), mp, mp + dim); }
+		}
+		if (p.x.empty()) return 0;
+		mcs_window_probes pr = p.c(dim, masks);
+		mcs_frame_view fv = view(b, nullptr, dim, masks);
+		std::vector<int32_t> match(p.x.size(), -1);
+		int32_t nfound = 0;
+		check(mcs_window_best(ctx(), &pr, &fv, thLow, 0, dim, MCS_MEM_HOST, match.data(), nullptr, &nfound), "mcs_window_best");
+		int nFused = 0, skipOwner = -1;
+		for (size_t k = 0; k < match.size(); ++k)   // probes are in (map point, camera) order: the surgery below sees them like the reference's loop
+		{
+			cMapPoint* pMP = vpMapPoints[p.src[k]];
+			// the reference evaluates its skip test when it reaches list entry i, i.e. after the surgery of the entries before it (a map point listed twice,
+			// or replaced meanwhile, is skipped then); all cameras of one entry are searched before its own surgery starts
+			if (k == 0 || p.src[k] != p.src[k - 1]) skipOwner = (pMP->isBad() || (rule.inKeyFrameTest && pMP->IsInKeyFrame(pKF))) ? p.src[k] : -1;
+			if (p.src[k] == skipOwner || match[k] < 0) continue;
+			const int bestIdx = match[k];
+			cMapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
+			if (!pMPinKF) { pMP->AddObservation(pKF, bestIdx); pKF->AddMapPoint(pMP, bestIdx); continue; }
+			bool ok = !pMPinKF->isBad();
+			if (rule.curKF)
+			{
+				cv::Vec3d ray1 = rule.curKF->GetKeyPointRay(p.src[k]), ray2 = pKF->GetKeyPointRay(bestIdx);
+				const int camIdx1 = p.cam[k];
+				cv::Matx33d E12 = ComputeE(rule.curKF->camSystem.Get_MtMc_inv(camIdx1) * pKF->camSystem.Get_MtMc(camIdx1));
+				ok = ok && CheckDistEpipolarLine(ray1, ray2, E12, 1e-2);
+			}
+			if (ok) { pMP->Replace(pMPinKF); ++nFused; }
+		}
+		return nFused;
 	}
-	return nFused;
+	// Scw -> the camera system posed at the de-scaled Scw, and its centre (:1576-1585, :2279-2290)
+	cv::Vec3d pose_from_sim3(cMultiCamSys_& camSys, const cv::Matx44d& Scw)
+	{
+		cv::Matx33d sRcw = cConverter::Hom2R(Scw);
+		cv::Vec3d row1(sRcw(0, 0), sRcw(0, 1), sRcw(0, 2));
+		const double inv_scw = 1.0 / cv::sqrt(row1.dot(row1));
+		cv::Matx33d Rcw = inv_scw * sRcw;
+		cv::Vec3d tcw = inv_scw * cConverter::Hom2T(Scw);
+		camSys.Set_M_t(cConverter::invMat(cConverter::Rt2Hom(Rcw, tcw)));
+		return cConverter::Hom2T(camSys.Get_M_t());
+	}
 }
 
-// ---- not replaced (see the header comment) -----------------------------------------------------------------------------------------
+int cORBmatcher::Fuse(cMultiKeyFrame *pKF, cMultiKeyFrame *curKF, vector<cMapPoint *> &vpMapPoints, double th)
+{
+	FuseRule rule = { true, false, true, curKF };
+	return fuse_common(pKF, pKF->camSystem, pKF->GetCameraCenter(), vpMapPoints, std::set<cMapPoint*>(), th, rule, mbFeatDim, havingMasks, TH_LOW_);
+}
+
+int cORBmatcher::Fuse(cMultiKeyFrame* pKF, std::vector<cMapPoint*> &vpMapPoints, double th)
+{
+	FuseRule rule = { true, true, true, nullptr };
+	return fuse_common(pKF, pKF->camSystem, pKF->GetCameraCenter(), vpMapPoints, std::set<cMapPoint*>(), th, rule, mbFeatDim, havingMasks, TH_LOW_);
+}
+
+int cORBmatcher::Fuse(cMultiKeyFrame *pKF, cv::Matx44d Scw, const vector<cMapPoint *> &vpPoints, double th)
+{
+	cMultiCamSys_ camSys = pKF->camSystem;
+	cv::Vec3d Ow = pose_from_sim3(camSys, Scw);
+	FuseRule rule = { false, false, false, nullptr };
+	return fuse_common(pKF, camSys, Ow, vpPoints, pKF->GetMapPoints(), th, rule, mbFeatDim, havingMasks, TH_LOW_);
+}
+
+// ---- SearchBySim3: both directions as one mcs_window_best each, the agreement test on the host --------------------------------------------------------
+int cORBmatcher::SearchBySim3(cMultiKeyFrame *pKF1, cMultiKeyFrame *pKF2, vector<cMapPoint*> &vpMatches12, const double &s12, const cv::Matx33d &R12,
+	const cv::Vec3d &t12, double th)
+{
+	cv::Matx44d T1 = pKF1->GetPoseInverse(), T2 = pKF2->GetPoseInverse();
+	cv::Matx33d R1w = cConverter::Hom2R(T1), R2w = cConverter::Hom2R(T2);
+	cv::Vec3d t1w = cConverter::Hom2T(T1), t2w = cConverter::Hom2T(T2);
+	cv::Matx33d sR12 = s12 * R12;
+	cv::Matx33d sR21 = (1.0 / s12) * R12.t();
+	cv::Vec3d t21 = -sR21 * t12;
+	vector<cMapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+	const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
+	vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+	for (int i = 0; i < N1; ++i)
+	{
+		cMapPoint* pMP = vpMatches12[i];
+		if (!pMP) continue;
+		vbAlreadyMatched1[i] = true;
+		int idx2 = pMP->GetIndexInKeyFrame(pKF2)[0];
+		if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+	}
+	// one direction: the points of `from` (already in the rig frame of `to` after Rw/tw and the similarity) into camera keypoint_to_cam[i] of `to`
+	struct Dir { cMultiKeyFrame* from; cMultiKeyFrame* to; const vector<cMapPoint*>* mps; const vector<bool>* done; cv::Matx33d Rw; cv::Vec3d tw; cv::Matx33d sR; cv::Vec3d t; };
+	Dir dirs[2] = { { pKF1, pKF2, &vpMapPoints1, &vbAlreadyMatched1, R1w, t1w, sR21, t21 }, { pKF2, pKF1, &vpMapPoints2, &vbAlreadyMatched2, R2w, t2w, sR12, t12 } };
+	std::vector<int> vnMatch[2] = { std::vector<int>(N1, -1), std::vector<int>(N2, -1) };
+	for (int dI = 0; dI < 2; ++dI)
+	{
+		Dir& D = dirs[dI];
+		const int nMaxLevel = D.to->GetScaleLevels() - 1;
+		vector<double> sf = D.to->GetScaleFactors();
+		std::vector<double> pts, d3; std::vector<int32_t> pc, owner;
+		for (int i = 0; i < (int)D.mps->size(); ++i)
+		{
+			cMapPoint* pMP = (*D.mps)[i];
+			if (!pMP || (*D.done)[i] || pMP->isBad()) continue;
+			const int camIdx = D.from->keypoint_to_cam.find(i)->second;
+			cv::Vec3d p3Dw = pMP->GetWorldPos();
+			cv::Vec3d pa = D.Rw * p3Dw + D.tw;
+			cv::Vec3d pb = D.sR * pa + D.t;
+			cv::Vec4d p4 = cConverter::invMat(D.to->camSystem.Get_M_c(camIdx)) * cConverter::toVec4d(pb);
+			if (pb(2) < 0.0) continue;
+			pts.push_back(p4(0)); pts.push_back(p4(1)); pts.push_back(p4(2)); pc.push_back(camIdx); owner.push_back(i);
+			d3.push_back(cv::norm(cv::Vec3d(p4(0), p4(1), p4(2))));
+		}
+		Flat b = flatten(D.to, mbFeatDim, havingMasks);
+		if (owner.empty() || b.n == 0) continue;
+		std::vector<double> uv; std::vector<uint8_t> fl;
+		project(pKF2->camSystem, pts, pc, uv, fl, true);   // both directions use pKF2's camera models (:1787, :1877); the points are in camera coordinates already
+		Probes p;
+		for (size_t k = 0; k < owner.size(); ++k)
+		{
+			if (!(fl[k] & 1)) continue;
+			cMapPoint* pMP = (*D.mps)[owner[k]];
+			const double maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+			if (d3[k] < minDistance || d3[k] > maxDistance) continue;
+			const double ratio = d3[k] / minDistance;
+			vector<double>::iterator it = std::lower_bound(sf.begin(), sf.end(), ratio);
+			const int lvl = std::min(static_cast<int>(it - sf.begin()), nMaxLevel);
+			p.add(uv[2 * k], uv[2 * k + 1], th * sf[lvl], lvl - 1, lvl, pc[k], owner[k]);
+			const uchar* dp = (const uchar*)pMP->GetDescriptorPtr();
+			p.d.insert(p.d.end(), dp, dp + mbFeatDim);
+			if (havingMasks) { const uchar* mp = (const uchar*)pMP->GetDescriptorMaskPtr(); p.m.insert(p.m.end(), mp, mp + mbFeatDim); }
+		}
+		if (p.x.empty()) continue;
+		mcs_window_probes pr = p.c(mbFeatDim, havingMasks);
+		mcs_frame_view fv = view(b, nullptr, mbFeatDim, havingMasks);
+		std::vector<int32_t> match(p.x.size(), -1);
+		int32_t nfound = 0;
+		check(mcs_window_best(ctx(), &pr, &fv, TH_HIGH_, 0, mbFeatDim, MCS_MEM_HOST, match.data(), nullptr, &nfound), "mcs_window_best");
+		for (size_t k = 0; k < match.size(); ++k) vnMatch[dI][p.src[k]] = match[k];
+	}
+	int nFound = 0;
+	for (int i1 = 0; i1 < N1; ++i1)
+	{
+		const int idx2 = vnMatch[0][i1];
+		if (idx2 >= 0 && vnMatch[1][idx2] == i1) { vpMatches12[i1] = vpMapPoints2[idx2]; ++nFound; }
+	}
+	return nFound;
+}
+
+// ---- SearchForTriangulationBetweenCameras: features of cam1 without a map point into cam2 of the same keyframe -----------------------------------------
+int cORBmatcher::SearchForTriangulationBetweenCameras(cMultiKeyFrame *pKF1, const int cam1, const int cam2, std::vector<cv::KeyPoint> &vMatchedKeys1,
+	std::vector<cv::Vec3d> &vMatchedKeysRays1, std::vector<cv::KeyPoint> &vMatchedKeys2, std::vector<cv::Vec3d> &vMatchedKeysRays2,
+	std::vector<std::pair<size_t, size_t> > &vMatchedPairs)
+{
+	cv::Matx44d RelOri = cConverter::invMat(pKF1->camSystem.Get_M_c(cam1)) * pKF1->camSystem.Get_M_c(cam2);
+	cv::Matx33d E12 = ComputeE(RelOri);
+	cv::Matx33d Rrel = cConverter::Hom2R(RelOri).t();
+	cv::Vec3d trel = -Rrel * cConverter::Hom2T(RelOri);
+	vector<cMapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+	vector<cv::KeyPoint> vKeys1 = pKF1->GetKeyPoints();
+	vector<cv::Vec3d> vKeysRays1 = pKF1->GetKeyPointsRays();
+	Flat a = flatten(pKF1, mbFeatDim, havingMasks);
+	std::vector<double> pts; std::vector<int32_t> pc, owner;
+	for (size_t idx1 = 0; idx1 < vpMapPoints1.size(); ++idx1)
+	{
+		if (vpMapPoints1[idx1] || a.cam[idx1] != cam1) continue;
+		cv::Vec3d rotPoint = Rrel * vKeysRays1[idx1] + trel;
+		rotPoint /= norm(rotPoint);
+		pts.push_back(rotPoint(0)); pts.push_back(rotPoint(1)); pts.push_back(rotPoint(2)); pc.push_back(cam2); owner.push_back((int)idx1);
+	}
+	if (owner.empty()) return 0;
+	std::vector<double> uv; std::vector<uint8_t> fl;
+	project(pKF1->camSystem, pts, pc, uv, fl, true);
+	Probes p;
+	for (size_t k = 0; k < owner.size(); ++k) if (fl[k] & 1) p.add(uv[2 * k], uv[2 * k + 1], 40, -1, -1, cam2, owner[k]);
+	if (p.x.empty()) return 0;
+	p.rows(a, mbFeatDim, havingMasks);
+	mcs_window_probes pr = p.c(mbFeatDim, havingMasks);
+	mcs_frame_view fv = view(a, nullptr, mbFeatDim, havingMasks);
+	std::vector<int32_t> match(p.x.size(), -1);
+	int32_t nfound = 0;
+	check(mcs_window_best(ctx(), &pr, &fv, 100, 0, mbFeatDim, MCS_MEM_HOST, match.data(), nullptr, &nfound), "mcs_window_best");
+	int nmatches = 0;
+	for (size_t k = 0; k < match.size(); ++k)
+	{
+		if (match[k] < 0) continue;
+		const int idx1 = p.src[k], bestIdx2 = match[k];
+		if (!CheckDistEpipolarLine(vKeysRays1[idx1], pKF1->GetKeyPointRay(bestIdx2), E12, 1e-2)) continue;
+		vMatchedKeys1.push_back(vKeys1[idx1]); vMatchedKeys2.push_back(vKeys1[bestIdx2]);
+		vMatchedKeysRays1.push_back(vKeysRays1[idx1]); vMatchedKeysRays2.push_back(vKeysRays1[bestIdx2]);
+		vMatchedPairs.push_back(make_pair((size_t)idx1, (size_t)bestIdx2));
+		++nmatches;
+	}
+	return nmatches;
+}
+
+// ---- not replaced: no defined behaviour to reproduce ----------------------------------------------------------------------------------------
+// SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:2120-2263, no caller in the reference) indexes the KEYFRAME's descriptor rows with the
+// current frame's feature indices (:2196-2197); SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (:2265-2392, cLoopClosing.cpp:401) takes the camera of
+// list position iMP from keypoint_to_cam (:2308) and reads descriptor row `idx` (the rig-wide index) of that camera's matrix (:2364) — past its end for every
+// camera but the first.  Both read outside their matrices in a multi-camera rig; their search loops are mcs_window_best (skip_taken = 1).
 int cORBmatcher::SearchByProjection(cMultiFrame&, cMultiKeyFrame*, const std::set<cMapPoint*>&, double, int) { not_replaced("SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)"); }
 int cORBmatcher::SearchByProjection(cMultiKeyFrame*, cv::Matx44d, const std::vector<cMapPoint*>&, std::vector<cMapPoint*>&, int) { not_replaced("SearchByProjection(pKF, Scw, ...)"); }
-int cORBmatcher::SearchForTriangulationBetweenCameras(cMultiKeyFrame*, const int, const int, std::vector<cv::KeyPoint>&, std::vector<cv::Vec3d>&, std::vector<cv::KeyPoint>&,
-	std::vector<cv::Vec3d>&, std::vector<std::pair<size_t, size_t> >&) { not_replaced("SearchForTriangulationBetweenCameras"); }
-int cORBmatcher::SearchBySim3(cMultiKeyFrame*, cMultiKeyFrame*, vector<cMapPoint*>&, const double&, const cv::Matx33d&, const cv::Vec3d&, double) { not_replaced("SearchBySim3"); }
-int cORBmatcher::Fuse(cMultiKeyFrame*, cv::Matx44d, const std::vector<cMapPoint*>&, double) { not_replaced("Fuse(pKF, Scw, ...)"); }
 }

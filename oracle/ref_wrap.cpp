@@ -9,15 +9,21 @@ using namespace MultiColSLAM;
 // (sort of pair<int, ExtractorNode*>, src/mdBRIEFextractorOct.cpp:745-760), so its output depends on the allocator.  Inside this library every
 // allocation made during a ref_extract call comes from a bump arena (monotonically increasing addresses, nothing reused), which makes "pointer
 // order" = "creation order" — the order the oracle (and the GPU oct-tree) use for the same tie.  Linked with -Bsymbolic: only this .so is affected.
+#include <atomic>
 #include <cstdlib>
 #include <new>
 #include <sys/mman.h>
 namespace {
-char* g_arena = nullptr; size_t g_cap = 0, g_used = 0; bool g_on = false;
+// The arena serves only the thread that switched it on (the test's calling thread).  When this library is loaded together with libmcs_hip.so (the
+// drop-in builds), the HIP / HSA runtime's own threads can resolve operator new to the definitions below; they must get plain malloc memory, and the
+// bump pointer must not race with them.
+char* g_arena = nullptr; size_t g_cap = 0; std::atomic<size_t> g_used{0}; thread_local bool g_on = false;
 void* bump(size_t n) {
 	n = (n + 15) & ~size_t(15);
-	if (!g_on || g_used + n > g_cap) return std::malloc(n);
-	void* p = g_arena + g_used; g_used += n; return p;
+	if (!g_on) return std::malloc(n);
+	const size_t at = g_used.fetch_add(n);
+	if (at + n > g_cap) return std::malloc(n);
+	return g_arena + at;
 }
 bool in_arena(void* p) { return (char*)p >= g_arena && (char*)p < g_arena + g_cap; }
 }  // namespace

@@ -12,6 +12,15 @@
 #include "misc.h"
 
 using namespace MultiColSLAM;
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void rs_crash(int sig) {   // test aid: where did a scene call die
+	void* fr[64]; const int n = backtrace(fr, 64);
+	const char msg[] = "rs_*: fatal signal, backtrace:\n"; (void)!write(2, msg, sizeof(msg) - 1);
+	backtrace_symbols_fd(fr, n, 2);
+	_exit(128 + sig);
+}
 
 extern "C" void ref_arena(int on);   // ref_wrap.cpp: bump allocation (monotone addresses) while a scene lives
 
@@ -43,6 +52,7 @@ int id_or_minus1(Scene* s, cMapPoint* p) { if (!p) return -1; auto it = s->idOf.
 
 extern "C" void* rs_create(const double* M_c, const orc_ocam* cams, const uint8_t* const* masks, int nrCams, const orc_params* p, const char* vocPath) {
 	try {
+		if (getenv("RS_BACKTRACE")) { signal(SIGSEGV, rs_crash); signal(SIGABRT, rs_crash); }
 		ref_arena(1);
 		Scene* s = new Scene();
 		std::vector<cv::Matx44d> Mc(nrCams);
@@ -264,20 +274,60 @@ extern "C" int rs_fuse_probes(void* h, int kTarget, int kSource, const int* feat
 	} catch (const std::exception& e) { std::cerr << "rs_fuse_probes: " << e.what() << std::endl; return -1; }
 }
 
-// cORBmatcher::Fuse(pKF, curKF, vpMapPoints, th) the way cLocalMapping::SearchInNeighbors calls it (src/cLocalMapping.cpp:416-424): the whole map-point
-// list of the source keyframe in one call, against a target keyframe that holds map points of its own (the Replace / AddObservation surgery runs).
+// The Fuse overloads the reference calls with whole lists (the Replace / AddObservation surgery runs against a target keyframe that holds map points):
+//   variant 0  Fuse(pKF, curKF, vpMapPoints, th)   cLocalMapping::SearchInNeighbors (src/cLocalMapping.cpp:416-424): the source keyframe's map-point list
+//   variant 1  Fuse(pKF, vpMapPoints, th)          (:450) the same list as fuse candidates
+//   variant 2  Fuse(pKF, Scw, vpPoints, th)        cLoopClosing::SearchAndFuse (src/cLoopClosing.cpp:608): the non-NULL points of the source keyframe
 // -> nFused; idsT / idsS = the map-point ids both keyframes hold afterwards, badS[i] = the point source feature i held BEFORE the call is bad now.
-extern "C" int rs_fuse(void* h, int kTarget, int kSource, double th, int* idsT, int* idsS, uint8_t* badS) {
+extern "C" int rs_fuse(void* h, int kTarget, int kSource, double th, int variant, const double* Scw, int* idsT, int* idsS, uint8_t* badS) {
 	Scene* s = (Scene*)h;
 	try {
 		cORBmatcher m(0.8, false, s->dim, s->masks);
 		cMultiKeyFrame* T = s->kfs[kTarget]; cMultiKeyFrame* S = s->kfs[kSource];
 		std::vector<cMapPoint*> v = S->GetMapPointMatches();
 		for (cMapPoint* p : v) if (p && !p->isBad()) p->UpdateNormalAndDepth();
-		const int n = m.Fuse(T, S, v, th);
+		int n = 0;
+		if (variant == 0) n = m.Fuse(T, S, v, th);
+		else if (variant == 1) n = m.Fuse(T, v, th);
+		else {
+			std::vector<cMapPoint*> pts;
+			for (cMapPoint* p : v) if (p) pts.push_back(p);
+			cv::Matx44d M; std::memcpy(M.val, Scw, 128);
+			n = m.Fuse(T, M, pts, th);
+		}
 		std::vector<cMapPoint*> a = T->GetMapPointMatches(), b = S->GetMapPointMatches();
 		for (size_t i = 0; i < a.size(); ++i) idsT[i] = id_or_minus1(s, a[i]);
 		for (size_t i = 0; i < b.size(); ++i) { idsS[i] = id_or_minus1(s, b[i]); badS[i] = v[i] && v[i]->isBad(); }
 		return n;
 	} catch (const std::exception& e) { std::cerr << "rs_fuse: " << e.what() << std::endl; return -1; }
+}
+// cLoopClosing::ComputeSim3's pair (src/cLoopClosing.cpp:281, :343): SearchByBoW(KF1, KF2) fills vpMatches12, SearchBySim3 adds to it.
+// ids12[i] = id of vpMatches12[i] afterwards; nBow = what SearchByBoW returned
+extern "C" int rs_sim3(void* h, int k1, int k2, double s12, const double* R12, const double* t12, double th, int* ids12, int* nBow) {
+	Scene* s = (Scene*)h;
+	try {
+		cORBmatcher m(0.75, false, s->dim, s->masks);
+		std::vector<cMapPoint*> v;
+		*nBow = m.SearchByBoW(s->kfs[k1], s->kfs[k2], v);
+		for (cMapPoint* p : s->kfs[k1]->GetMapPointMatches()) if (p && !p->isBad()) p->UpdateNormalAndDepth();
+		for (cMapPoint* p : s->kfs[k2]->GetMapPointMatches()) if (p && !p->isBad()) p->UpdateNormalAndDepth();
+		cv::Matx33d R; std::memcpy(R.val, R12, 72);
+		cv::Vec3d t(t12[0], t12[1], t12[2]);
+		const int n = m.SearchBySim3(s->kfs[k1], s->kfs[k2], v, s12, R, t, th);
+		for (size_t i = 0; i < v.size(); ++i) ids12[i] = id_or_minus1(s, v[i]);
+		return n;
+	} catch (const std::exception& e) { std::cerr << "rs_sim3: " << e.what() << std::endl; return -1; }
+}
+// SearchForTriangulationBetweenCameras(pKF, cam1, cam2, ...) (:1158-1263, no caller in the reference): match12[idx1] = idx2 or -1
+extern "C" int rs_tri_between(void* h, int k, int cam1, int cam2, int* match12) {
+	Scene* s = (Scene*)h;
+	try {
+		cORBmatcher m(0.8, false, s->dim, s->masks);
+		std::vector<cv::KeyPoint> k1, k2; std::vector<cv::Vec3d> r1, r2; std::vector<std::pair<size_t, size_t>> pairs;
+		const int n = m.SearchForTriangulationBetweenCameras(s->kfs[k], cam1, cam2, k1, r1, k2, r2, pairs);
+		const size_t N = s->kfs[k]->GetKeyPoints().size();
+		for (size_t i = 0; i < N; ++i) match12[i] = -1;
+		for (auto& p : pairs) match12[p.first] = (int)p.second;
+		return n;
+	} catch (const std::exception& e) { std::cerr << "rs_tri_between: " << e.what() << std::endl; return -1; }
 }

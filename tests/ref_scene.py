@@ -41,7 +41,9 @@ class RefScene:
         L.rs_distinctive.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
         L.rs_fuse_probes.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_double, vp, vp]
         if hasattr(L, "rs_fuse"):
-            L.rs_fuse.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp, vp, vp]
+            L.rs_fuse.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]
+            L.rs_sim3.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp, vp, C.c_double, vp, vp]
+            L.rs_tri_between.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
         L.rs_destroy.argtypes = [vp]
         self.nr = len(cams)
         self.prm = O.make_params(**params)

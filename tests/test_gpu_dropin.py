@@ -150,11 +150,24 @@ def _script(so, cams, masks, M_c, voc, params, imgs, poses):
     best, mm = np.zeros((len(feat), NC), np.int32), np.zeros((len(feat), 2))
     assert S.L.rs_fuse_probes(S.h, kT, k0, feat.ctypes.data, fpos.ctypes.data, len(feat), 10.0, best.ctypes.data, mm.ctypes.data) == 0
     R["fuse_probes"] = (int((best >= 0).sum()), best.reshape(-1))
-    for th in (2.5, 10.0):
+    # SearchBySim3 after SearchByBoW (cLoopClosing::ComputeSim3) with the true relative pose, slightly off in scale; SearchForTriangulationBetweenCameras
+    rel = np.linalg.inv(poses[0]) @ poses[1]
+    R12, t12 = np.ascontiguousarray(rel[:3, :3]), np.ascontiguousarray(rel[:3, 3])
+    for s12, th in ((1.0, 10.0), (1.02, 7.5)):
+        ids12, nbow = np.zeros(n0, np.int32), np.zeros(1, np.int32)
+        cnt = S.L.rs_sim3(S.h, k0, k1, s12, R12.ctypes.data, t12.ctypes.data, th, ids12.ctypes.data, nbow.ctypes.data)
+        R["sim3_%g" % s12] = (cnt, np.append(ids12, nbow[0]))
+    for c1, c2 in ((0, 1), (2, 0)):
+        m12 = np.zeros(n0, np.int32)
+        R["tri_between_%d%d" % (c1, c2)] = (S.L.rs_tri_between(S.h, k0, c1, c2, m12.ctypes.data), m12)
+    # the three Fuse overloads with whole lists: keyframe 0's map points into keyframe 1 (Replace / AddObservation surgery), each on the state the one before left
+    Scw = np.ascontiguousarray(np.linalg.inv(poses[1]) @ np.diag([1.0, 1.0, 1.0, 1 / 1.01]))
+    Scw[:3] *= 1.01
+    for variant, th in ((0, 2.5), (1, 2.5), (2, 4.0), (0, 10.0)):
         idsT, idsS, bad = np.zeros(n1, np.int32), np.zeros(n0, np.int32), np.zeros(n0, np.uint8)
-        nf = S.L.rs_fuse(S.h, k1, k0, th, idsT.ctypes.data, idsS.ctypes.data, bad.ctypes.data)
-        R["fuse_%g" % th] = (nf, np.concatenate([idsT, idsS, bad.astype(np.int32)]))
-        R["fuse_%g_new" % th] = (int((idsT >= 0).sum() - f1.sum()), idsT)
+        nf = S.L.rs_fuse(S.h, k1, k0, th, variant, Scw.ctypes.data, idsT.ctypes.data, idsS.ctypes.data, bad.ctypes.data)
+        R["fuse%d_%g" % (variant, th)] = (nf, np.concatenate([idsT, idsS, bad.astype(np.int32)]))
+        R["fuse%d_%g_held" % (variant, th)] = (int((idsT >= 0).sum()), idsT)
     S.close()
     return R
 
@@ -185,6 +198,7 @@ def test_reference_objects_over_the_gpu_matcher(mode, tmp_path):
         for key in ("keys", "desc", "mask", "cam", "rays", "node", "grid_inv", "cell"):
             assert np.array_equal(ref["frames"][f][key], gpu["frames"][f][key]), (f, key)
     floor = dict(kfkf=50, kff0=30, tri0=5, win_60_0_0=20, init_100_0=20, proj_mp=30, proj_last0=20, proj_frames=10, fuse_probes=15)
+    floor.update({"fuse0_2.5": 50, "fuse1_2.5": 5, "fuse2_4": 5, "sim3_1": 5, "tri_between_01": 3})
     for key in ref:
         if key == "frames":
             continue
