@@ -210,6 +210,8 @@ int mcs_rotation_consistency(mcs_ctx*, int variant, const float* angle_slot, int
  *                   (:2265-2392).  Their "kpLevel < nPredictedLevel-1 || kpLevel > nPredictedLevel" filter is the probe's level range.
  *   skip_taken = 1  in probe order, features with frame->assigned set are skipped and an accepted feature becomes assigned:
  *                   SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:2120-2263, accept <= ORBdist).
+ *   Fuse(pKF, vpMapPoints, th) (:1420-1568) never assigns the distance it computes (:1513-1516; `dist` stays 0), so the first feature of the window inside
+ *   the level range wins there: pass all-zero descriptors on both sides (no masks) to reproduce it — integration/cORBmatcher_mcs.cpp does.
  * match[p] = feature index with the smallest distance (first in GetFeaturesInArea order on ties) if that distance <= max_dist, else -1;
  * dist[p] (optional) = that smallest distance (INT_MAX if the window is empty; with skip_taken only for accepted probes). */
 int mcs_window_best(mcs_ctx*, const mcs_window_probes* probes, const mcs_frame_view* frame, int max_dist, int skip_taken, int dim, mcs_mem_kind kind,
