@@ -147,6 +147,23 @@ def measured_traffic(dom, mode, frames, nfeat):
         return None
 
 
+def valu_issue(dom, mode, frames, nfeat, launch_ms):
+    """The bound that actually applies: VALU wave instructions per launch (SQ_INSTS_VALU of the committed counter pass) over the live
+    launch time, against one wave instruction per 4 cycles and SIMD (1024 SIMDs x 2.4 GHz / 4) — the rate of the FP64 and bit-count instructions
+    these kernels consist of (32-bit ALU instructions issue faster, so the fraction is a lower bound on the issue-slot use)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        w = t["workload"]
+        if (w["frames"], w["mode"], w["nfeatures"]) != (frames, mode, nfeat):
+            return None
+        insts = t["kernels"][dom]["valu_insts"]
+    except (OSError, KeyError, ValueError):
+        return None
+    peak = 1024 * 2.4e9 / 4 / 1e9
+    ach = insts / (launch_ms * 1e-3) / 1e9
+    return {"wave_insts_per_launch": int(insts), "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s", "frac": round(ach / peak, 3)}
+
+
 def roofline(kern, mode, nimg, nkp_total, sizes, nfeat=1000):
     # algorithmic bytes per launch (SURVEY.md §8d / DESIGN.md §4)
     per_kp = 845 + 512 * (3 if mode == "mdbrief" else 1) + 28 + 32 + (32 if mode == "mdbrief" else 0)
@@ -158,6 +175,7 @@ def roofline(kern, mode, nimg, nkp_total, sizes, nfeat=1000):
             "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kern[dom], 4), "per_kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "per_kernel_alg_GBps": {k: round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) for k in alg},
             "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
+            "valu_issue": valu_issue(dom, mode, nimg // 3, nfeat, kern[dom]),
             "note": "every kernel of this path is VALU-issue-bound, not HBM-bound (k_describe: FP64 at 16 lanes/clk; matcher: v_bitop3/v_bcnt at 16 lanes/clk), see DESIGN.md §6"}
 
 
