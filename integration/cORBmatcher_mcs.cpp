@@ -31,11 +31,18 @@ const int cORBmatcher::HISTO_LENGTH = 30;
 
 namespace
 {
-	mcs_ctx* g_ctx = nullptr;
+	// The reference builds matchers on the stack of three threads (tracking, local mapping, loop closing) and runs them concurrently; an mcs_ctx owns one
+	// HIP stream and its staging buffers and serves one thread at a time, so every thread gets its own (released when the thread ends).
+	struct ThreadCtx
+	{
+		mcs_ctx* h = nullptr;
+		~ThreadCtx() { if (h) mcs_ctx_destroy(h); }
+	};
 	mcs_ctx* ctx()
 	{
-		if (!g_ctx && mcs_ctx_create(0, nullptr, &g_ctx) != MCS_OK) throw std::runtime_error(std::string("mcs_ctx_create: ") + mcs_last_error());
-		return g_ctx;
+		static thread_local ThreadCtx t;
+		if (!t.h && mcs_ctx_create(0, nullptr, &t.h) != MCS_OK) throw std::runtime_error(std::string("mcs_ctx_create: ") + mcs_last_error());
+		return t.h;
 	}
 	void check(int rc, const char* what) { if (rc != MCS_OK) throw std::runtime_error(std::string(what) + ": " + mcs_last_error()); }
 	[[noreturn]] void not_replaced(const char* name) { throw std::logic_error(std::string("cORBmatcher::") + name + " is not replaced by the GPU drop-in (keep the reference's body)"); }
