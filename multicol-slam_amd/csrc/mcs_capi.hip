@@ -36,12 +36,14 @@ struct mcs_extractor {
 	CellInfo* d_cells = nullptr;
 	ResizeTap* d_taps = nullptr;
 	short* d_maskMap = nullptr;
-	uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_mask0 = nullptr;
+	uint8_t *d_pyr = nullptr, *d_blur = nullptr;
 	uint32_t *d_slots = nullptr, *d_dense = nullptr, *d_sel = nullptr;
 	unsigned short* d_knode = nullptr;
 	int *d_cellCount = nullptr, *d_denseCount = nullptr, *d_selCount = nullptr, *d_status = nullptr;
 	OcamDev* d_cams = nullptr;
 	std::vector<OcamDev> h_cams;
+	// host-kind input staging: the caller's image / mask block as it lies in host memory (same pitch and stride), grown on demand
+	uint8_t *d_inImg = nullptr, *d_inMask = nullptr; size_t inImgCap = 0, inMaskCap = 0;
 	// host-kind output staging
 	int* d_nkp = nullptr; mcs_keypoint* d_kps = nullptr; uint8_t *d_odesc = nullptr, *d_omask = nullptr; double* d_rays = nullptr;
 	ExtractBuffers last{};
@@ -291,7 +293,6 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	ALLOC(e->d_maskMap, sizeof(short) * maps.size());
 	ALLOC(e->d_pyr, B * hd.pyrBytes);
 	ALLOC(e->d_blur, B * hd.pyrBytes);
-	ALLOC(e->d_mask0, B * (size_t)hd.lv[0].stride * hd.lv[0].h);
 	ALLOC(e->d_slots, B * hd.slotsPerImage * sizeof(uint32_t));
 	ALLOC(e->d_dense, B * hd.densePerImage * sizeof(uint32_t));
 	ALLOC(e->d_knode, B * hd.densePerImage * sizeof(unsigned short));
@@ -322,9 +323,9 @@ int mcs_extractor_destroy(mcs_extractor* e) {
 	if (!e) return MCS_OK;
 	(void)hipSetDevice(e->ctx->device);
 	(void)hipStreamSynchronize(e->ctx->stream);
-	void* ptrs[] = {e->d_desc, e->d_cells, e->d_taps, e->d_maskMap, e->d_pyr, e->d_blur, e->d_mask0, e->d_slots, e->d_dense, e->d_knode,
+	void* ptrs[] = {e->d_desc, e->d_cells, e->d_taps, e->d_maskMap, e->d_pyr, e->d_blur, e->d_slots, e->d_dense, e->d_knode,
 	                e->d_sel, e->d_cellCount, e->d_denseCount, e->d_selCount, e->d_status, e->d_cams, e->d_nkp, e->d_kps, e->d_odesc,
-	                e->d_omask, e->d_rays};
+	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask};
 	for (void* p : ptrs) (void)hipFree(p);
 	delete e;
 	return MCS_OK;
@@ -347,6 +348,15 @@ int mcs_extractor_levels(const mcs_extractor* e, int* nlevels, int* widths, int*
 	return MCS_OK;
 }
 
+static int grow(uint8_t** p, size_t* cap, size_t need) {   // device buffer of at least `need` bytes (host-kind calls end with a stream sync, so it is idle here)
+	if (*cap >= need) return MCS_OK;
+	if (*p) (void)hipFree(*p);
+	*p = nullptr; *cap = 0;
+	HIPCHK(hipMalloc((void**)p, need + need / 4));
+	*cap = need + need / 4;
+	return MCS_OK;
+}
+
 int mcs_extract_batch(mcs_extractor* e, int nimg, const uint8_t* images, size_t image_pitch, int image_stride, const uint8_t* masks,
                       size_t mask_pitch, int mask_stride, const mcs_ocam* cams, mcs_mem_kind kind, int32_t* nkp, mcs_keypoint* keypoints,
                       uint8_t* desc, uint8_t* descmask, double* rays) {
@@ -365,17 +375,17 @@ int mcs_extract_batch(mcs_extractor* e, int nimg, const uint8_t* images, size_t 
 	b.pyr = e->d_pyr; b.blur = e->d_blur; b.slots = e->d_slots; b.cellCount = e->d_cellCount; b.dense = e->d_dense; b.knode = e->d_knode;
 	b.denseCount = e->d_denseCount; b.sel = e->d_sel; b.selCount = e->d_selCount; b.status = e->d_status;
 	if (kind == MCS_MEM_HOST) {
-		const LevelInfo& L0 = hd.lv[0];
-		for (int i = 0; i < nimg; ++i)
-			HIPCHK(hipMemcpy2DAsync(e->d_pyr + (size_t)i * hd.pyrBytes + L0.off, L0.stride, images + (size_t)i * image_pitch, image_stride,
-			                        hd.width, hd.height, hipMemcpyHostToDevice, s));
-		b.img0 = e->d_pyr + L0.off; b.img0Pitch = hd.pyrBytes; b.img0Stride = L0.stride;
+		// ONE linear copy per block, in the caller's own layout; the kernels take any pitch / stride for level 0.  (A pitched hipMemcpy2D from pageable
+		// host memory is carried out row by row by the runtime: 2 x 480 small transfers per image, ~9 ms per image.)
+		const size_t imgSpan = (size_t)(nimg - 1) * image_pitch + (size_t)(hd.height - 1) * image_stride + hd.width;
+		if (int r = grow(&e->d_inImg, &e->inImgCap, imgSpan)) return r;
+		HIPCHK(hipMemcpyAsync(e->d_inImg, images, imgSpan, hipMemcpyHostToDevice, s));
+		b.img0 = e->d_inImg; b.img0Pitch = image_pitch; b.img0Stride = image_stride;
 		if (masks) {
-			const size_t mp = (size_t)L0.stride * L0.h;
-			for (int i = 0; i < nimg; ++i)
-				HIPCHK(hipMemcpy2DAsync(e->d_mask0 + (size_t)i * mp, L0.stride, masks + (size_t)i * mask_pitch, mask_stride, hd.width, hd.height,
-				                        hipMemcpyHostToDevice, s));
-			b.mask0 = e->d_mask0; b.mask0Pitch = mp; b.mask0Stride = L0.stride;
+			const size_t maskSpan = (size_t)(nimg - 1) * mask_pitch + (size_t)(hd.height - 1) * mask_stride + hd.width;
+			if (int r = grow(&e->d_inMask, &e->inMaskCap, maskSpan)) return r;
+			HIPCHK(hipMemcpyAsync(e->d_inMask, masks, maskSpan, hipMemcpyHostToDevice, s));
+			b.mask0 = e->d_inMask; b.mask0Pitch = mask_pitch; b.mask0Stride = mask_stride;
 		}
 		b.nkp = e->d_nkp; b.kps = e->d_kps; b.out_desc = e->d_odesc; b.out_mask = e->d_omask; b.rays = rays ? e->d_rays : nullptr;
 	} else {
