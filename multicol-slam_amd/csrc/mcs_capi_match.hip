@@ -246,12 +246,12 @@ int mcs_search_by_projection(mcs_ctx* c, const mcs_projection_set* mp, const mcs
 	const bool havingMasks = mp->mask != nullptr;
 	ProjArgs a{};
 	a.nproj = mp->n; a.pstride = mp->stride; a.nfeat = f->n; a.fstride = f->stride; a.nrCams = f->nr_cams;
-	a.th = th; a.ratio = nnratio; a.dim = dim; a.rule = 0; a.cap = kProjListCap;
+	a.th = th; a.ratio = nnratio; a.dim = dim; a.rule = 0; a.cap = kProjListK;
 	a.thHigh = havingMasks ? (int)floor(1.5 * dim) : 3 * dim;   // TH_HIGH_ (src/cORBmatcher.cpp:46-65)
 	const size_t np = std::max(mp->n, 1), nf = std::max(f->n, 1);
 	// scratch: lists + counts (+ staged inputs / outputs for host pointers), one allocation per call (this row is not a bench path)
-	size_t need = al256(np * kProjListCap * 8) + al256(np * 4);
-	const size_t oLists = 0, oCounts = al256(np * kProjListCap * 8);
+	size_t need = al256(np * kProjListK * 8) + al256(np * 4);
+	const size_t oLists = 0, oCounts = al256(np * kProjListK * 8);
 	size_t o = need;
 	auto reserve = [&](size_t bytes) { const size_t at = o; o += al256(bytes); return at; };
 	size_t oPx = 0, oPy = 0, oVc = 0, oLv = 0, oPc = 0, oPd = 0, oPm = 0, oKeys = 0, oFd = 0, oFm = 0, oFc = 0, oAs = 0, oW = 0, oH = 0, oSc = 0, oMatch = 0, oNm = 0;

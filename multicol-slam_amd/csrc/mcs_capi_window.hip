@@ -44,14 +44,14 @@ static int window_common(mcs_ctx* c, const mcs_window_probes* pr, const mcs_fram
 	const bool havingMasks = pr->mask != nullptr, host = kind == MCS_MEM_HOST;
 	const size_t np = pr->n, nf = f->n;
 	ProjArgs a{};
-	a.rule = (int)rule; a.cap = kWindowListCap;
+	a.rule = (int)rule; a.cap = kProjListK;
 	a.nproj = pr->n; a.pstride = pr->stride; a.nfeat = f->n; a.fstride = f->stride; a.nrCams = f->nr_cams;
 	a.ratio = nnratio; a.dim = dim; a.th = 1.0;
 	a.thHigh = havingMasks ? (int)floor(1.5 * dim) : 3 * dim;   // TH_HIGH_ / TH_LOW_ (src/cORBmatcher.cpp:46-65)
 	a.thLow = havingMasks ? (int)floor((double)dim) : 2 * dim;
 	if (bestMode) a.thHigh = maxDist;
 	Arena ar;
-	const size_t iLists = ar.add(np * kWindowListCap * 8), iCounts = ar.add(np * 4), iOwner = ar.add(nf * 4), iMdist = ar.add(nf * 4), iAsg = ar.add(nf);
+	const size_t iLists = ar.add(np * kProjListK * 8), iCounts = ar.add(np * 4), iOwner = ar.add(nf * 4), iMdist = ar.add(nf * 4), iAsg = ar.add(nf);
 	size_t iX = 0, iY = 0, iR = 0, iLo = 0, iHi = 0, iPc = 0, iPd = 0, iPm = 0, iKeys = 0, iFd = 0, iFm = 0, iFc = 0, iW = 0, iH = 0, iMatch = 0, iNm = 0;
 	if (host) {
 		iX = ar.add(np * 8); iY = ar.add(np * 8); iR = ar.add(np * 8); iLo = ar.add(np * 4); iHi = ar.add(np * 4); iPc = ar.add(np * 4);

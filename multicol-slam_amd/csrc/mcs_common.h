@@ -126,8 +126,7 @@ struct GreedyArgs {
 void launch_greedy(const GreedyArgs& g, hipStream_t s);
 
 // window matcher (SearchByProjection), mcs_project.hip
-constexpr int kProjListCap = 64;     // rule 0 (radius 2.5-4 px x scale)
-constexpr int kWindowListCap = 128;  // rules 1-3 (windows of 40-60 px)
+constexpr int kProjListK = 8;         // sorted candidate keys kept per probe (mcs_project.hip); longer windows fall back to exact rescans
 // rule 0  SearchByProjection(F, mapPoints, th)   window from vcos / level / th, level-aware ratio test        (src/cORBmatcher.cpp:67-166)
 // rule 1  WindowSearch, SearchByProjection(F1,F2) explicit window, taken features skipped, best <= second*ratio && best <= TH_HIGH (:326-577)
 // rule 2  SearchByProjection(Cur, Last, th)       explicit window, taken features skipped, best <= TH_HIGH     (:1990-2118)
@@ -138,7 +137,7 @@ struct ProjArgs {
 	const mcs_keypoint* keys; const uint8_t* fdesc; const uint8_t* fmask; const int* fcam; uint8_t* assigned; int nfeat; int fstride;
 	const int* width; const int* height; const double* scales; int nrCams;
 	double th; double ratio; int dim; int thHigh;
-	unsigned long long* lists; int* counts;   // [nproj][cap], [nproj] (count may exceed cap = overflow)
+	unsigned long long* lists; int* counts;   // [kProjListK][nproj] smallest keys ascending, [nproj] window members
 	int* match; int* nmatches;
 	// rules 1-3
 	int rule; int cap; int thLow;

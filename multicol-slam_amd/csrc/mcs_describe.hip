@@ -142,7 +142,6 @@ __device__ __forceinline__ void img2world(const OcamDev& cam, double u, double v
 // sits >= 25 px inside the level, so the patch is always inside the ROI; undistorted ORB offsets (|.| <= 22) and almost
 // all distorted ones land in it — a scattered 64-lane byte gather from global memory per sample was address-unit-bound.
 constexpr int kPatchR = 24, kPatchRows = 2 * kPatchR + 1, kPatchPitch = 52;
-constexpr int kPatchBytes = kPatchRows * kPatchPitch;   // 2548
 
 struct Sampler {
 	const uint8_t* blur; int bstride;
@@ -178,7 +177,6 @@ struct Sampler {
 #ifndef MCS_ABLATE
 #define MCS_ABLATE 0   // A/B experiments only: 1 skip the sequential mean, 2 skip the omni model, 4 skip sampling
 #endif
-constexpr int kMaxBallots = 8;   // descSize 64 -> 512 pairs -> 8 ballots
 #ifndef MCS_MERGE_CHAINS
 #define MCS_MERGE_CHAINS 0   // A/B only.  1 = mdBRIEF keeps all three distorted patterns in LDS and runs their six coordinate sums as ONE
                              // chain (lanes 0..5): 1024 fewer dependent adds per keypoint, but 26.5 KB LDS per wave (6 waves/CU instead

@@ -204,7 +204,12 @@ __global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
 // lowest unresolved lane, and blocks the lanes above it until then.
 constexpr int kClaimRows = 16384;   // train rows per set supported by the speculative kernel (LDS claim table)
 
-template <int K, int DW, bool MASKED>
+// SearchForTriangulationRaw (TRI) in the same scheme: a query's outcome needs two rows of its sorted candidate list — a = the first FREE candidate
+// (BestDist, DistTh = 2*BestDist) and b = the first free candidate that passes CheckDistEpipolarLine; b wins iff dist(b) <= DistTh.  The epipolar test
+// of an entry does not depend on the matched state, so every lane evaluates it once for its K entries (a K-bit mask); a round then only re-reads the
+// bitmap.  A decision is final if no lower lane of the round claimed a or b (rows between them can only turn from "free, fails the test" to "taken").
+// The exact rescan of the lowest lane finds a and b in ONE pass over the train rows (the epipolar test runs inside the pass).
+template <int K, int DW, bool MASKED, bool TRI>
 __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 	__shared__ uint32_t matched[kClaimRows / 32];
 	__shared__ uint32_t claim[kClaimRows];
@@ -232,9 +237,24 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 			for (int e = 0; e < K; ++e) key[e] = src[(size_t)e * g.nq];
 		}
 		bool resolved = !qok;
-		if (inRange && !qok && g.mode == 0) outM[i] = -1;
-		const bool full = key[K - 1] != EMPTY;
+		if (inRange && !qok && g.mode != 1) outM[i] = -1;
+		// TRI: a list that ends with an empty slot or an entry beyond TH_LOW holds every candidate; otherwise rows of distance >= dK may be hidden
+		const bool full = TRI ? (key[K - 1] != EMPTY && (int)(key[K - 1] >> 20) <= g.thLow) : key[K - 1] != EMPTY;
 		const int dK = full ? (int)(key[K - 1] >> 20) : 0x7FFFFFFF;
+		uint32_t epi = 0;           // TRI: bit e = entry e is a candidate (distance <= TH_LOW) that passes the epipolar test
+		double ray1[3] = {0.0, 0.0, 0.0};
+		const double* Em = g.E;
+		if (TRI && qok) {
+			const int qg = g.qgroup[q0 + i];
+			Em = g.E + (size_t)9 * ((size_t)qg * g.nrCams + qg);   // same-camera rule: camIdx2 == camIdx1 (the lists are built per camera)
+#pragma unroll
+			for (int c = 0; c < 3; ++c) ray1[c] = g.rays1[(q0 + i) * 3 + c];
+#pragma unroll
+			for (int e = 0; e < K; ++e) {
+				const uint32_t k = key[e];
+				if (k != EMPTY && (int)(k >> 20) <= g.thLow && check_epipolar(ray1, g.rays2 + (t0 + (k & 0xFFFFFu)) * 3, Em, 1e-2)) epi |= 1u << e;
+			}
+		}
 
 		for (int round = 0; round < 130; ++round) {
 			const unsigned long long pend = __ballot(!resolved);
@@ -243,7 +263,26 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 			// ---- tentative decision of every unresolved lane
 			int state = 0;            // 0 reject, 1 accept, 2 needs rescan
 			int best = 0x7FFFFFFF, bestIdx = -1, second = 0x7FFFFFFF, secondIdx = -1;
-			if (!resolved) {
+			// bestIdx = the row this lane takes if it accepts; bestIdx / secondIdx = the rows whose capture by a lower lane voids the decision
+			if (!resolved && TRI) {
+				int aIdx = -1, aDist = 0, bIdx = -1, bDist = 0;
+#pragma unroll
+				for (int e = 0; e < K; ++e) {
+					const uint32_t k = key[e];
+					if (k != EMPTY && (int)(k >> 20) <= g.thLow && bIdx < 0) {
+						const int idx = (int)(k & 0xFFFFFu);
+						if (!((matched[idx >> 5] >> (idx & 31)) & 1u)) {
+							if (aIdx < 0) { aIdx = idx; aDist = (int)(k >> 20); }
+							if ((epi >> e) & 1u) { bIdx = idx; bDist = (int)(k >> 20); }
+						}
+					}
+				}
+				secondIdx = aIdx;
+				if (bIdx >= 0) { state = bDist <= 2 * aDist ? 1 : 0; bestIdx = bIdx; }
+				else if (!full) state = 0;                             // every candidate is in the list and none qualifies
+				else if (aIdx >= 0 && dK > 2 * aDist) state = 0;       // hidden rows lie beyond DistTh (as long as a stays free)
+				else state = 2;
+			} else if (!resolved) {
 				int n = 0;
 #pragma unroll
 				for (int e = 0; e < K; ++e) {
@@ -284,6 +323,13 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 				const bool grouped = g.qgroup != nullptr && g.tgroup != nullptr;
 				const int qgLow = grouped ? g.qgroup[q0 + qi] : 0;
 				uint32_t a = EMPTY, b2 = EMPTY;
+				double r1[3] = {0.0, 0.0, 0.0};
+				const double* EmLow = g.E;
+				if (TRI) {
+#pragma unroll
+					for (int c = 0; c < 3; ++c) r1[c] = g.rays1[(q0 + qi) * 3 + c];
+					EmLow = g.E + (size_t)9 * ((size_t)qgLow * g.nrCams + qgLow);
+				}
 				// branch-free body, 4 rows per lane and trip: all global loads of a trip are issued before the first use
 				for (int j0 = lane; j0 < g.nt; j0 += 256) {
 					uint32_t kk[4];
@@ -295,22 +341,39 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 						const uint32_t* mp = MASKED ? reinterpret_cast<const uint32_t*>(g.tm + (t0 + jc) * g.tstride) : tp;
 						const bool ok = j < g.nt && !((matched[jc >> 5] >> (jc & 31)) & 1u) && (g.tvalid ? g.tvalid[t0 + jc] != 0 : true) &&
 						                (!grouped || g.tgroup[t0 + jc] == qgLow);   // same camera / FeatureVector node only
-						const uint32_t k = ((uint32_t)hamming_g<DW, MASKED>(q, qm, tp, mp) << 20) | (uint32_t)jc;
-						kk[u] = ok ? k : EMPTY;
+						const int dist = hamming_g<DW, MASKED>(q, qm, tp, mp);
+						const uint32_t k = ((uint32_t)dist << 20) | (uint32_t)jc;
+						kk[u] = ok && (!TRI || dist <= g.thLow) ? k : EMPTY;
 					}
+					if (TRI) {   // a = smallest candidate key, b2 = smallest candidate key that passes the epipolar test (evaluated only where it can lower b2;
+						         // testing every row up front to get the ray loads out early was measured slower)
 #pragma unroll
-					for (int u = 0; u < 4; ++u) { const uint32_t k = kk[u]; if (k < a) { b2 = a; a = k; } else if (k < b2) b2 = k; }
+						for (int u = 0; u < 4; ++u) {
+							const uint32_t k = kk[u];
+							if (k < a) a = k;
+							if (k < b2 && check_epipolar(r1, g.rays2 + (t0 + (k & 0xFFFFFu)) * 3, EmLow, 1e-2)) b2 = k;
+						}
+					} else {
+#pragma unroll
+						for (int u = 0; u < 4; ++u) { const uint32_t k = kk[u]; if (k < a) { b2 = a; a = k; } else if (k < b2) b2 = k; }
+					}
 				}
 				const uint32_t m1 = wave_min_u32(a);
-				const uint32_t m2 = wave_min_u32(a == m1 ? b2 : a);
+				const uint32_t m2 = TRI ? wave_min_u32(b2) : wave_min_u32(a == m1 ? b2 : a);
 				++nfallback;
 				if (lane == low) {
-					best = m1 == EMPTY ? 0x7FFFFFFF : (int)(m1 >> 20);
-					bestIdx = m1 == EMPTY ? -1 : (int)(m1 & 0xFFFFFu);
-					second = m2 == EMPTY ? 0x7FFFFFFF : (int)(m2 >> 20);
-					secondIdx = -1;   // exact: depends on nothing a lower lane can still change (there is no lower pending lane)
-					const bool pass = bestIdx >= 0 && (g.thInclusive ? best <= g.thLow : best < g.thLow);
-					state = (pass && static_cast<double>(best) < g.ratio * static_cast<double>(second)) ? 1 : 0;
+					if (TRI) {
+						secondIdx = -1;
+						bestIdx = m2 == EMPTY ? -1 : (int)(m2 & 0xFFFFFu);
+						state = (m2 != EMPTY && (int)(m2 >> 20) <= 2 * (int)(m1 >> 20)) ? 1 : 0;
+					} else {
+						best = m1 == EMPTY ? 0x7FFFFFFF : (int)(m1 >> 20);
+						bestIdx = m1 == EMPTY ? -1 : (int)(m1 & 0xFFFFFu);
+						second = m2 == EMPTY ? 0x7FFFFFFF : (int)(m2 >> 20);
+						secondIdx = -1;   // exact: depends on nothing a lower lane can still change (there is no lower pending lane)
+						const bool pass = bestIdx >= 0 && (g.thInclusive ? best <= g.thLow : best < g.thLow);
+						state = (pass && static_cast<double>(best) < g.ratio * static_cast<double>(second)) ? 1 : 0;
+					}
 				}
 			}
 			// ---- claims and finality
@@ -332,8 +395,8 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 			if (commit) {
 				if (state == 1) {
 					atomicOr(&matched[bestIdx >> 5], 1u << (bestIdx & 31));
-					if (g.mode == 0) outM[i] = bestIdx; else outM[bestIdx] = i;
-				} else if (g.mode == 0) outM[i] = -1;
+					if (g.mode != 1) outM[i] = bestIdx; else outM[bestIdx] = i;
+				} else if (g.mode != 1) outM[i] = -1;
 				resolved = true;
 			}
 			nmatches += __popcll(__ballot(commit && state == 1));
@@ -348,13 +411,17 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 
 template <int K, int DW>
 static void launch_spec_kd(const GreedyArgs& g, hipStream_t s) {
-	if (g.qm && g.tm) hipLaunchKernelGGL((k_greedy_spec<K, DW, true>), dim3(g.nsets), dim3(64), 0, s, g);
-	else hipLaunchKernelGGL((k_greedy_spec<K, DW, false>), dim3(g.nsets), dim3(64), 0, s, g);
+	const bool masked = g.qm && g.tm;
+	if (g.mode == 2) {
+		if (masked) hipLaunchKernelGGL((k_greedy_spec<K, DW, true, true>), dim3(g.nsets), dim3(64), 0, s, g);
+		else hipLaunchKernelGGL((k_greedy_spec<K, DW, false, true>), dim3(g.nsets), dim3(64), 0, s, g);
+	} else if (masked) hipLaunchKernelGGL((k_greedy_spec<K, DW, true, false>), dim3(g.nsets), dim3(64), 0, s, g);
+	else hipLaunchKernelGGL((k_greedy_spec<K, DW, false, false>), dim3(g.nsets), dim3(64), 0, s, g);
 }
 
 template <int DW>
 static void launch_dw(const GreedyArgs& g, hipStream_t s) {
-	if (g.mode != 2 && g.nt <= kClaimRows) {
+	if (g.nt <= kClaimRows && (g.mode != 2 || (g.qgroup && g.tgroup))) {
 		switch (g.K) {
 			case 1: launch_spec_kd<1, DW>(g, s); return;
 			case 2: launch_spec_kd<2, DW>(g, s); return;

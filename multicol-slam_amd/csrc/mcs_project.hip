@@ -72,31 +72,6 @@ __device__ __forceinline__ int proj_distance(const ProjArgs& a, int p, int i) {
 	return acc;
 }
 
-__global__ __launch_bounds__(64) void k_proj_candidates(ProjArgs a) {
-	__shared__ int cnt;
-	const int p = blockIdx.x, lane = threadIdx.x;
-	if (lane == 0) cnt = 0;
-	__syncthreads();
-	const Window w = make_window(a, p);
-	const int cam = a.pcam[p];
-	if (!w.empty) {
-		for (int i0 = 0; i0 < a.nfeat; i0 += 64) {
-			const int i = i0 + lane;
-			unsigned long long key = ~0ull;
-			if (i < a.nfeat) {
-				const unsigned long long mk = member_key(a, w, cam, i);
-				if (mk != ~0ull) key = ((unsigned long long)proj_distance(a, p, i) << 42) | mk;
-			}
-			if (key != ~0ull) {
-				const int slot = atomicAdd(&cnt, 1);
-				if (slot < a.cap) a.lists[(size_t)p * a.cap + slot] = key;
-			}
-		}
-	}
-	__syncthreads();
-	if (lane == 0) a.counts[p] = cnt;
-}
-
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) {
@@ -105,6 +80,51 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 		v = y < v ? y : v;
 	}
 	return v;
+}
+
+// Stage 1, one wave per probe: the kListK smallest keys (distance << 42 | cell << 20 | index, i.e. the reference's visiting order on distance ties) of
+// the window's members, ascending, written [kListK][nproj] so that stage 2 reads them coalesced, plus the member count.  Only the best and the
+// runner-up among the still-FREE members decide a probe, so a short sorted list is enough unless most of it has been taken meanwhile; then the
+// probe is rescanned exactly.  (The first version listed ALL members, up to 128 per probe, and stage 2 walked those lists from global memory in every
+// round: 2-6 ms per multi-frame, 50-70 ms once windows of 100 px overflowed the lists.)
+constexpr int kListK = kProjListK;
+__global__ __launch_bounds__(64) void k_proj_candidates(ProjArgs a) {
+	const int p = blockIdx.x, lane = threadIdx.x;
+	const unsigned long long NONE = ~0ull;
+	const Window w = make_window(a, p);
+	const int cam = a.pcam[p];
+	unsigned long long loc[kListK];   // this lane's smallest keys, ascending
+#pragma unroll
+	for (int e = 0; e < kListK; ++e) loc[e] = NONE;
+	int n = 0;
+	if (!w.empty) {
+		for (int i = lane; i < a.nfeat; i += 64) {
+			const unsigned long long mk = member_key(a, w, cam, i);
+			if (mk == NONE) continue;
+			++n;
+			const unsigned long long key = ((unsigned long long)proj_distance(a, p, i) << 42) | mk;
+			if (key < loc[kListK - 1]) {
+				loc[kListK - 1] = key;
+#pragma unroll
+				for (int e = kListK - 1; e > 0; --e) {
+					const unsigned long long lo = loc[e] < loc[e - 1] ? loc[e] : loc[e - 1], hi = loc[e] < loc[e - 1] ? loc[e - 1] : loc[e];
+					loc[e - 1] = lo; loc[e] = hi;
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+#pragma unroll
+	for (int e = 0; e < kListK; ++e) {   // the wave's e-th smallest key: keys are unique (index bits), exactly one lane owns it and pops it
+		const unsigned long long m = wave_min_u64(loc[0]);
+		if (lane == 0) a.lists[(size_t)e * a.nproj + p] = m;
+		const bool mine = loc[0] == m && m != NONE;
+#pragma unroll
+		for (int j = 0; j < kListK - 1; ++j) loc[j] = mine ? loc[j + 1] : loc[j];
+		loc[kListK - 1] = mine ? NONE : loc[kListK - 1];
+	}
+	if (lane == 0) a.counts[p] = n;
 }
 
 __global__ __launch_bounds__(64) void k_proj_greedy(ProjArgs a) {
@@ -133,22 +153,56 @@ __global__ __launch_bounds__(64) void k_proj_greedy(ProjArgs a) {
 		const int cnt = resolved ? 0 : a.counts[p];
 		if (!resolved) { a.match[p] = -1; if (a.accepted) a.accepted[p] = -1; }
 		if (!resolved && cnt == 0) resolved = true;
+		unsigned long long key[kListK];   // my probe's sorted short list (registers for all rounds)
+#pragma unroll
+		for (int e = 0; e < kListK; ++e) key[e] = resolved ? NONE : a.lists[(size_t)e * a.nproj + p];
+		const bool full = cnt > kListK;                                    // members beyond the list exist; their distance is >= dK
+		const int dK = full ? (int)(key[kListK - 1] >> 42) : 0x7FFFFFFF;
+		// verdict from best / runner-up among the free members; `bound` = the runner-up is unknown but at least that far away
+		auto decide = [&](unsigned long long k1, unsigned long long k2, bool bound, int& state, int& bestIdx, int& secondIdx, int& best) {
+			state = 0; bestIdx = -1; secondIdx = -1; best = 0;
+			if (k1 == NONE) return;
+			best = (int)(k1 >> 42);
+			bestIdx = (int)(k1 & 0xFFFFFu);
+			int second = 0x7FFFFFFF;
+			if (bound) second = dK;
+			else if (k2 != NONE) { second = (int)(k2 >> 42); secondIdx = (int)(k2 & 0xFFFFFu); }
+			if (a.rule == 0) {          // :153-163
+				const int lvl2 = secondIdx >= 0 ? a.keys[secondIdx].octave : -1;
+				const int lvl1 = a.keys[bestIdx].octave;
+				const bool ratioFails = static_cast<double>(best) > a.ratio * static_cast<double>(second);
+				if (best <= a.thHigh && !((bound || lvl1 == lvl2) && ratioFails)) state = 1;
+				else if (bound && best <= a.thHigh) state = 2;       // only a real runner-up (its level, its distance) can tell
+			} else if (a.rule == 1) {   // :416, :558-560
+				if (static_cast<double>(best) <= static_cast<double>(second) * a.ratio && best <= a.thHigh) state = 1;
+				else if (bound && best <= a.thHigh) state = 2;
+			} else if (a.rule == 2) {   // :2072 (no runner-up)
+				secondIdx = -1;
+				if (best <= a.thHigh) state = 1;
+			} else {                    // :670-672
+				if (best <= a.thLow && static_cast<double>(best) < static_cast<double>(second) * a.ratio) state = 1;
+				else if (bound && best <= a.thLow) state = 2;
+			}
+		};
 		for (int round = 0; round < 130; ++round) {
 			const unsigned long long pend = __ballot(!resolved);
 			if (pend == 0ull) break;
 			const int low = __ffsll((long long)pend) - 1;
-			// tentative best / second among the free members of my window
-			unsigned long long k1 = NONE, k2 = NONE;
-			const bool overflow = !resolved && cnt > a.cap;
-			if (!resolved && !overflow) {
-				for (int e = 0; e < cnt; ++e) {
-					const unsigned long long k = a.lists[(size_t)p * a.cap + e];
-					if (!free_for((int)(k & 0xFFFFFu), (int)(k >> 42))) continue;
-					if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+			// tentative decision from the first two FREE entries of my list
+			int state = 0, bestIdx = -1, secondIdx = -1, best = 0;   // 0 no match, 1 match, 2 needs an exact rescan
+			if (!resolved) {
+				unsigned long long k1 = NONE, k2 = NONE;
+#pragma unroll
+				for (int e = 0; e < kListK; ++e) {
+					const unsigned long long k = key[e];
+					if (k != NONE && k2 == NONE && free_for((int)(k & 0xFFFFFu), (int)(k >> 42))) { if (k1 == NONE) k1 = k; else k2 = k; }
 				}
+				if (k2 != NONE || !full || (a.rule == 2 && k1 != NONE)) decide(k1, k2, false, state, bestIdx, secondIdx, best);
+				else if (k1 != NONE) decide(k1, NONE, true, state, bestIdx, secondIdx, best);   // one free entry: the runner-up is hidden, >= dK away
+				else state = dK <= (a.rule == 3 ? a.thLow : a.thHigh) ? 2 : 0;                   // none: a hidden member could still qualify
 			}
-			// the lowest pending probe is rescanned exactly by the whole wave if its list overflowed
-			if (__shfl((int)overflow, low)) {
+			// the lowest pending probe is rescanned exactly by the whole wave if its list cannot decide
+			if (__shfl(state, low) == 2) {
 				const int pp = p0 + low;
 				const Window w = make_window(a, pp);
 				const int cam = a.pcam[pp];
@@ -163,34 +217,11 @@ __global__ __launch_bounds__(64) void k_proj_greedy(ProjArgs a) {
 				}
 				const unsigned long long m1 = wave_min_u64(b1);
 				const unsigned long long m2 = wave_min_u64(b1 == m1 ? b2 : b1);
-				if (lane == low) { k1 = m1; k2 = m2; }
-			}
-			// decision
-			int state = 0, bestIdx = -1, secondIdx = -1, best = 0;   // 0 no match, 1 match, 2 waiting for its rescan
-			if (!resolved) {
-				if (overflow && lane != low) state = 2;
-				else if (k1 != NONE) {
-					best = (int)(k1 >> 42);
-					bestIdx = (int)(k1 & 0xFFFFFu);
-					int second = 0x7FFFFFFF;
-					if (k2 != NONE) { second = (int)(k2 >> 42); secondIdx = (int)(k2 & 0xFFFFFu); }
-					if (a.rule == 0) {          // :153-163
-						const int lvl2 = k2 != NONE ? a.keys[secondIdx].octave : -1;
-						const int lvl1 = a.keys[bestIdx].octave;
-						if (best <= a.thHigh && !(lvl1 == lvl2 && static_cast<double>(best) > a.ratio * static_cast<double>(second))) state = 1;
-					} else if (a.rule == 1) {   // :416, :558-560
-						if (static_cast<double>(best) <= static_cast<double>(second) * a.ratio && best <= a.thHigh) state = 1;
-					} else if (a.rule == 2) {   // :2072 (no runner-up)
-						secondIdx = -1;
-						if (best <= a.thHigh) state = 1;
-					} else {                    // :670-672
-						if (best <= a.thLow && static_cast<double>(best) < static_cast<double>(second) * a.ratio) state = 1;
-					}
-				}
+				if (lane == low) decide(m1, m2, false, state, bestIdx, secondIdx, best);
 			}
 			// finality: no lower pending lane of this round may take my best or my second feature (accepting lanes broadcast their
 			// target one after the other; at most 64 shuffles per round)
-			bool blocked = !resolved && state == 2;
+			bool blocked = !resolved && state == 2;   // waits until it is the lowest pending probe
 			const unsigned long long acc = __ballot(!resolved && state == 1);
 			unsigned long long rest = acc;
 			while (rest) {
