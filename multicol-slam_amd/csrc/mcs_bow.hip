@@ -95,8 +95,8 @@ int mcs_bow_transform(mcs_vocabulary* v, const uint8_t* desc, int n, int stride,
 	uint8_t* buf = nullptr;
 	const bool host = kind == MCS_MEM_HOST;
 	if (host) {
-		HIPCHK(hipMalloc((void**)&buf, (size_t)n * stride + (size_t)n * 8));
-		if (hipMemcpyAsync(buf, desc, (size_t)n * stride, hipMemcpyHostToDevice, s) != hipSuccess) { (void)hipFree(buf); return fail(MCS_ERR_HIP, "H2D copy failed"); }
+		HIPCHK(ctx_arena(c, (size_t)n * stride + (size_t)n * 8, &buf));
+		if (hipMemcpyAsync(buf, desc, (size_t)n * stride, hipMemcpyHostToDevice, s) != hipSuccess) return fail(MCS_ERR_HIP, "H2D copy failed");
 		a.desc = buf; a.leaf = (int*)(buf + (size_t)n * stride); a.nid = a.leaf + n;
 	}
 	hipLaunchKernelGGL(k_bow_transform, dim3((n + 255) / 256), dim3(256), 0, s, a);
@@ -105,7 +105,6 @@ int mcs_bow_transform(mcs_vocabulary* v, const uint8_t* desc, int n, int stride,
 		if (e == hipSuccess) e = hipMemcpyAsync(leaf_node, a.leaf, (size_t)n * 4, hipMemcpyDeviceToHost, s);
 		if (e == hipSuccess) e = hipMemcpyAsync(node_at_level, a.nid, (size_t)n * 4, hipMemcpyDeviceToHost, s);
 		const hipError_t e2 = hipStreamSynchronize(s);
-		(void)hipFree(buf);
 		if (e == hipSuccess) e = e2;
 	}
 	if (e != hipSuccess) return fail(MCS_ERR_HIP, std::string("bow transform: ") + hipGetErrorString(e));

@@ -264,8 +264,8 @@ int mcs_search_by_projection(mcs_ctx* c, const mcs_projection_set* mp, const mcs
 		oMatch = reserve(np * 4); oNm = reserve(4);
 	}
 	uint8_t* buf = nullptr;
-	HIPCHK(hipMalloc((void**)&buf, o));
-	auto done = [&](int rc) { (void)hipStreamSynchronize(s); (void)hipFree(buf); return rc; };
+	HIPCHK(ctx_arena(c, o, &buf));   // persistent per context (a hipMalloc / hipFree pair per call cost more than the kernels)
+	auto done = [&](int rc) { (void)hipStreamSynchronize(s); return rc; };
 	a.lists = (unsigned long long*)(buf + oLists); a.counts = (int*)(buf + oCounts);
 	if (host) {
 #define UP(off, src, bytes) do { if ((bytes) && hipMemcpyAsync(buf + (off), (src), (bytes), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "H2D copy failed")); } while (0)

@@ -10,14 +10,21 @@ using namespace mcs;
 namespace {
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
-// one device allocation per call carved into aligned pieces; host-kind inputs are staged into it (these rows are not bench paths)
+// One device buffer per context, carved into aligned pieces per call (scratch lists + staged host-kind inputs).  It persists and only grows: every call
+// on a context runs on the context's stream, so a later call's copies and kernels are ordered behind the earlier call's, and growing goes through
+// hipFree, which waits for the device.  (A hipMalloc / hipFree pair per call cost more than the kernels of a single multi-frame.)
 struct Arena {
+	mcs_ctx* c;
 	std::vector<size_t> sizes;
 	uint8_t* base = nullptr;
+	explicit Arena(mcs_ctx* ctx) : c(ctx) {}
 	size_t add(size_t bytes) { sizes.push_back(al256(std::max<size_t>(bytes, 1))); return sizes.size() - 1; }
-	hipError_t alloc() { size_t t = 0; for (size_t v : sizes) t += v; return hipMalloc((void**)&base, t); }
+	hipError_t alloc() {
+		size_t t = 0;
+		for (size_t v : sizes) t += v;
+		return ctx_arena(c, t, &base);
+	}
 	uint8_t* at(size_t id) const { size_t o = 0; for (size_t i = 0; i < id; ++i) o += sizes[i]; return base + o; }
-	~Arena() { if (base) (void)hipFree(base); }
 };
 }  // namespace
 
@@ -50,7 +57,7 @@ static int window_common(mcs_ctx* c, const mcs_window_probes* pr, const mcs_fram
 	a.thHigh = havingMasks ? (int)floor(1.5 * dim) : 3 * dim;   // TH_HIGH_ / TH_LOW_ (src/cORBmatcher.cpp:46-65)
 	a.thLow = havingMasks ? (int)floor((double)dim) : 2 * dim;
 	if (bestMode) a.thHigh = maxDist;
-	Arena ar;
+	Arena ar(c);
 	const size_t iLists = ar.add(np * kProjListK * 8), iCounts = ar.add(np * 4), iOwner = ar.add(nf * 4), iMdist = ar.add(nf * 4), iAsg = ar.add(nf);
 	size_t iX = 0, iY = 0, iR = 0, iLo = 0, iHi = 0, iPc = 0, iPd = 0, iPm = 0, iKeys = 0, iFd = 0, iFm = 0, iFc = 0, iW = 0, iH = 0, iMatch = 0, iNm = 0;
 	if (host) {
@@ -87,7 +94,10 @@ static int window_common(mcs_ctx* c, const mcs_window_probes* pr, const mcs_fram
 	if (!f->assigned) { if (hipMemsetAsync(ar.at(iAsg), 0, std::max<size_t>(nf, 1), s) != hipSuccess) return done(fail(MCS_ERR_HIP, "memset failed")); }
 	a.accepted = wantAcc ? (host ? (int*)ar.at(iAcc) : pr->accepted_out) : nullptr;
 	int* ddist = dist ? (host ? (int*)ar.at(iDist) : dist) : nullptr;
-	if (pr->n > 0) { if (bestMode) launch_window_best(a, bestMode == 2, ddist, s); else launch_projection(a, s); }
+	if (pr->n > 0) {
+		if (bestMode) launch_window_best(a, bestMode == 2, ddist, s);
+		else { c->tic("win_candidates"); launch_proj_candidates(a, s); c->toc("win_candidates"); c->tic("win_greedy"); launch_proj_greedy(a, s); c->toc("win_greedy"); }
+	}
 	else if (!host) { if (hipMemsetAsync(nmatches, 0, 4, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "memset failed")); }
 	if (hipGetLastError() != hipSuccess) return done(fail(MCS_ERR_HIP, "window kernels failed to launch"));
 	if (host && dist && pr->n > 0 && hipMemcpyAsync(dist, ddist, np * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "D2H"));
@@ -137,7 +147,7 @@ int mcs_world_to_cam(mcs_ctx* c, const double* MtMc_inv, const mcs_ocam* cams, i
 		w[i] = m.width; h[i] = m.height;
 		if (mirror_masks && mirror_masks[i]) maskBytes += al256((size_t)m.width * m.height);
 	}
-	Arena ar;
+	Arena ar(c);
 	const size_t iM = ar.add((size_t)nr_cams * 128), iC = ar.add(sizeof(OcamDev) * nr_cams), iW = ar.add(4 * (size_t)nr_cams), iH = ar.add(4 * (size_t)nr_cams),
 	             iMp = ar.add(sizeof(void*) * nr_cams), iMk = ar.add(host ? maskBytes : 0);
 	size_t iP = 0, iPc = 0, iUv = 0, iFl = 0;
@@ -196,7 +206,7 @@ int mcs_distinctive_descriptors(mcs_ctx* c, const uint8_t* desc, const uint8_t* 
 	for (int k = 0; k < npoints; ++k)
 		if (offsets[k + 1] < offsets[k] || offsets[k + 1] - offsets[k] > 65535) return fail(MCS_ERR_INVALID, "offsets must be non-decreasing, <= 65535 rows per map point");
 	const size_t rows = (size_t)offsets[npoints];
-	Arena ar;
+	Arena ar(c);
 	const size_t iD = ar.add(rows * stride), iM = ar.add(mask ? rows * stride : 0), iO = ar.add(((size_t)npoints + 1) * 4), iB = ar.add((size_t)npoints * 4);
 	HIPCHK(ar.alloc());
 	auto done = [&](int rc) { (void)hipStreamSynchronize(s); return rc; };
@@ -244,7 +254,7 @@ int mcs_rotation_consistency(mcs_ctx* c, int variant, const float* angle_slot, i
 		return MCS_OK;
 	}
 	const size_t bs = (size_t)n * stride_slot, bp = (size_t)n_partner * stride_partner;
-	Arena ar;
+	Arena ar(c);
 	const size_t iS = ar.add(bs), iP = ar.add(bp), iA = ar.add(accepted ? (size_t)n * 4 : 0), iM = ar.add((size_t)n * 4), iR = ar.add(4);
 	HIPCHK(ar.alloc());
 	auto done = [&](int rc) { (void)hipStreamSynchronize(s); return rc; };

@@ -126,7 +126,7 @@ struct GreedyArgs {
 void launch_greedy(const GreedyArgs& g, hipStream_t s);
 
 // window matcher (SearchByProjection), mcs_project.hip
-constexpr int kProjListK = 8;         // sorted candidate keys kept per probe (mcs_project.hip); longer windows fall back to exact rescans
+constexpr int kProjListK = 16;        // sorted candidate keys kept per probe (mcs_project.hip); longer windows fall back to exact rescans
 // rule 0  SearchByProjection(F, mapPoints, th)   window from vcos / level / th, level-aware ratio test        (src/cORBmatcher.cpp:67-166)
 // rule 1  WindowSearch, SearchByProjection(F1,F2) explicit window, taken features skipped, best <= second*ratio && best <= TH_HIGH (:326-577)
 // rule 2  SearchByProjection(Cur, Last, th)       explicit window, taken features skipped, best <= TH_HIGH     (:1990-2118)
@@ -147,6 +147,8 @@ struct ProjArgs {
 };
 
 void launch_projection(const ProjArgs& a, hipStream_t s);
+void launch_proj_candidates(const ProjArgs& a, hipStream_t s);   // the two stages of launch_projection, for per-kernel timing
+void launch_proj_greedy(const ProjArgs& a, hipStream_t s);
 
 struct WorldToCamArgs {   // cMultiCamSys_::WorldToCamHom_fast + isPointInMirrorMask (src/cam_system_omni.cpp:92-133, src/cam_model_omni.cpp:163-178)
 	const double* M;              // [nrCams][16] MtMc_inv, row-major

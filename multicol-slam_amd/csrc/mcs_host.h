@@ -35,6 +35,7 @@ struct mcs_ctx {
 	int* topCnt = nullptr; size_t topCntCap = 0;
 	int* tflag = nullptr; size_t tflagCap = 0;            // per-train-row eligibility (camera group or -1) for the streamed matcher
 	uint8_t* stageOut = nullptr; size_t stageOutCap = 0;
+	uint8_t* arena = nullptr; size_t arenaCap = 0;        // scratch + host-kind staging of the window / projection / map-point entry points (mcs_capi_window.hip)
 	// Second HIP stream for the latency-bound / independent kernels (blur next to FAST+oct-tree, the greedy resolution next to the
 	// following batch's extraction): they leave most CUs idle, so overlapping them with the VALU-bound kernels is free throughput.
 	hipStream_t side = nullptr;
@@ -55,3 +56,17 @@ struct mcs_ctx {
 		t.used = true;
 	}
 };
+
+// The context's persistent scratch buffer, at least `bytes` long.  Every call on a context runs on the context's stream, so a later call's copies and
+// kernels are ordered behind the earlier call's use of it; growing goes through hipFree, which waits for the device.
+inline hipError_t ctx_arena(mcs_ctx* c, size_t bytes, uint8_t** out) {
+	if (c->arenaCap < bytes) {
+		if (c->arena) (void)hipFree(c->arena);
+		c->arena = nullptr; c->arenaCap = 0;
+		const hipError_t e = hipMalloc((void**)&c->arena, bytes + bytes / 2);
+		if (e != hipSuccess) return e;
+		c->arenaCap = bytes + bytes / 2;
+	}
+	*out = c->arena;
+	return hipSuccess;
+}

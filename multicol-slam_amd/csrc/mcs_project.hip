@@ -402,9 +402,11 @@ void launch_rotation_consistency(int variant, const float* angleSlot, int stride
 	hipLaunchKernelGGL(k_rotation_consistency, dim3(1), dim3(256), 0, s, variant, angleSlot, strideSlot, anglePartner, stridePartner, accepted, match, n, swapped, removedOut);
 }
 
+void launch_proj_candidates(const ProjArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_proj_candidates, dim3(a.nproj), dim3(64), 0, s, a); }
+void launch_proj_greedy(const ProjArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_proj_greedy, dim3(1), dim3(64), 0, s, a); }
 void launch_projection(const ProjArgs& a, hipStream_t s) {
-	hipLaunchKernelGGL(k_proj_candidates, dim3(a.nproj), dim3(64), 0, s, a);
-	hipLaunchKernelGGL(k_proj_greedy, dim3(1), dim3(64), 0, s, a);
+	launch_proj_candidates(a, s);
+	launch_proj_greedy(a, s);
 }
 
 void launch_window_best(const ProjArgs& a, bool skipTaken, int* outDist, hipStream_t s) {

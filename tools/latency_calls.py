@@ -70,12 +70,19 @@ for masks in (True, False):
 
 
 def run_w(name, fn, reps=10):
-    ts = []
+    ts, kc, kg = [], [], []
     for i in range(reps):
+        ctx.enable_timing(True)
         t = time.perf_counter()
         fn()
         ts.append(time.perf_counter() - t)
-    print("%-58s wall %7.3f ms (min %.3f)" % (name, 1e3 * np.median(ts[2:]), 1e3 * min(ts)))
+        for lst, k in ((kc, "win_candidates"), (kg, "win_greedy")):
+            try:
+                lst.append(ctx.kernel_ms(k))
+            except mcs.McsError:
+                lst.append(0.0)
+        ctx.enable_timing(False)
+    print("%-58s wall %7.3f ms   kernels: candidates %6.3f  greedy %6.3f" % (name, 1e3 * np.median(ts[2:]), np.median(kc[2:]), np.median(kg[2:])))
 
 
 for masks in (True, False):
