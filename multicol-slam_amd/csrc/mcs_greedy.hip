@@ -209,19 +209,88 @@ constexpr int kClaimRows = 16384;   // train rows per set supported by the specu
 // of an entry does not depend on the matched state, so every lane evaluates it once for its K entries (a K-bit mask); a round then only re-reads the
 // bitmap.  A decision is final if no lower lane of the round claimed a or b (rows between them can only turn from "free, fails the test" to "taken").
 // The exact rescan of the lowest lane finds a and b in ONE pass over the train rows (the epipolar test runs inside the pass).
+// The workgroup has kSpecWaves waves: wave 0 runs the rounds above, the other waves only help with the exact rescans — one wave alone pays the full
+// global-memory latency of every trip over the train rows (~30 us per rescan), eight waves split the rows and overlap it.  Protocol per round: wave 0
+// posts the query to rescan (or -1) in LDS, block barrier A, every wave scans its slice and posts its two smallest keys, block barrier B, wave 0 merges.
+// Everything else in a round touches LDS from wave 0 only and is ordered by workgroup fences instead of barriers.
+constexpr int kSpecWaves = 8;
 template <int K, int DW, bool MASKED, bool TRI>
-__global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
+__global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 	__shared__ uint32_t matched[kClaimRows / 32];
 	__shared__ uint32_t claim[kClaimRows];
-	const int set = blockIdx.x, lane = threadIdx.x;
+	__shared__ int reqQ;                                   // query to rescan this round, -1 none, -2 the set is finished
+	__shared__ uint32_t partA[kSpecWaves], partB[kSpecWaves];
+	const int set = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const size_t q0 = (size_t)set * g.qpitch, t0 = (size_t)set * g.tpitch;
-	for (int i = lane; i < (g.nt + 31) / 32; i += 64) matched[i] = 0;
-	for (int i = lane; i < g.nt; i += 64) claim[i] = 0xFFFFFFFFu;
-	int* outM = g.outMatch + (size_t)set * (g.mode == 1 ? g.nt : g.nq);
-	if (g.mode == 1) for (int j = lane; j < g.nt; j += 64) outM[j] = -1;
-	__syncthreads();
-	int nmatches = 0, nfallback = 0;
 	constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+	for (int i = threadIdx.x; i < (g.nt + 31) / 32; i += 64 * kSpecWaves) matched[i] = 0;
+	for (int i = threadIdx.x; i < g.nt; i += 64 * kSpecWaves) claim[i] = 0xFFFFFFFFu;
+	int* outM = g.outMatch + (size_t)set * (g.mode == 1 ? g.nt : g.nq);
+	if (g.mode == 1) for (int j = threadIdx.x; j < g.nt; j += 64 * kSpecWaves) outM[j] = -1;
+	__syncthreads();
+	const bool grouped = g.qgroup != nullptr && g.tgroup != nullptr;
+	// this wave's share of the exact rescan of query qi: rows wave*256 + lane + 64*u + 256*kSpecWaves*trip.  non-TRI: the slice's two smallest keys of
+	// free eligible rows; TRI: its smallest candidate key and its smallest candidate key that passes the epipolar test.
+	auto scan_slice = [&](int qi) {
+		uint32_t q[DW], qm[DW];
+		const uint32_t* qp = reinterpret_cast<const uint32_t*>(g.qd + (q0 + qi) * g.qstride);
+#pragma unroll
+		for (int w = 0; w < DW; ++w) q[w] = qp[w];
+		if (MASKED) {
+			const uint32_t* mp = reinterpret_cast<const uint32_t*>(g.qm + (q0 + qi) * g.qstride);
+#pragma unroll
+			for (int w = 0; w < DW; ++w) qm[w] = mp[w];
+		}
+		const int qgLow = grouped ? g.qgroup[q0 + qi] : 0;
+		uint32_t a = EMPTY, b2 = EMPTY;
+		double r1[3] = {0.0, 0.0, 0.0};
+		const double* EmLow = g.E;
+		if (TRI) {
+#pragma unroll
+			for (int c = 0; c < 3; ++c) r1[c] = g.rays1[(q0 + qi) * 3 + c];
+			EmLow = g.E + (size_t)9 * ((size_t)qgLow * g.nrCams + qgLow);
+		}
+		// branch-free body, 4 rows per lane and trip: all global loads of a trip are issued before the first use
+		for (int j0 = wave * 256 + lane; j0 < g.nt; j0 += 256 * kSpecWaves) {
+			uint32_t kk[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int j = j0 + 64 * u;
+				const int jc = j < g.nt ? j : g.nt - 1;
+				const uint32_t* tp = reinterpret_cast<const uint32_t*>(g.td + (t0 + jc) * g.tstride);
+				const uint32_t* mp = MASKED ? reinterpret_cast<const uint32_t*>(g.tm + (t0 + jc) * g.tstride) : tp;
+				const bool ok = j < g.nt && !((matched[jc >> 5] >> (jc & 31)) & 1u) && (g.tvalid ? g.tvalid[t0 + jc] != 0 : true) &&
+				                (!grouped || g.tgroup[t0 + jc] == qgLow);   // same camera / FeatureVector node only
+				const int dist = hamming_g<DW, MASKED>(q, qm, tp, mp);
+				const uint32_t k = ((uint32_t)dist << 20) | (uint32_t)jc;
+				kk[u] = ok && (!TRI || dist <= g.thLow) ? k : EMPTY;
+			}
+			if (TRI) {   // the epipolar test is evaluated only where it can lower b2 (testing every row up front to get the ray loads out early was slower)
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t k = kk[u];
+					if (k < a) a = k;
+					if (k < b2 && check_epipolar(r1, g.rays2 + (t0 + (k & 0xFFFFFu)) * 3, EmLow, 1e-2)) b2 = k;
+				}
+			} else {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { const uint32_t k = kk[u]; if (k < a) { b2 = a; a = k; } else if (k < b2) b2 = k; }
+			}
+		}
+		const uint32_t m1 = wave_min_u32(a);
+		const uint32_t m2 = TRI ? wave_min_u32(b2) : wave_min_u32(a == m1 ? b2 : a);
+		if (lane == 0) { partA[wave] = m1; partB[wave] = m2; }
+	};
+	if (wave > 0) {   // helper waves
+		for (;;) {
+			__syncthreads();   // A
+			const int rq = reqQ;
+			if (rq == -2) return;
+			if (rq >= 0) scan_slice(rq);
+			__syncthreads();   // B
+		}
+	}
+	int nmatches = 0, nfallback = 0;
 
 	for (int i0 = 0; i0 < g.nq; i0 += 64) {
 		const int i = i0 + lane;
@@ -249,10 +318,23 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 			Em = g.E + (size_t)9 * ((size_t)qg * g.nrCams + qg);   // same-camera rule: camIdx2 == camIdx1 (the lists are built per camera)
 #pragma unroll
 			for (int c = 0; c < 3; ++c) ray1[c] = g.rays1[(q0 + i) * 3 + c];
+			// the rays of up to 8 list entries are fetched before the first test (a dependent global round trip per entry otherwise)
+			constexpr int CH = K < 8 ? K : 8;
 #pragma unroll
-			for (int e = 0; e < K; ++e) {
-				const uint32_t k = key[e];
-				if (k != EMPTY && (int)(k >> 20) <= g.thLow && check_epipolar(ray1, g.rays2 + (t0 + (k & 0xFFFFFu)) * 3, Em, 1e-2)) epi |= 1u << e;
+			for (int e0 = 0; e0 < K; e0 += CH) {
+				double r2[CH][3];
+#pragma unroll
+				for (int u = 0; u < CH; ++u) {
+					const uint32_t k = key[e0 + u];
+					const double* rp = g.rays2 + (t0 + (k != EMPTY ? (k & 0xFFFFFu) : 0u)) * 3;
+#pragma unroll
+					for (int c = 0; c < 3; ++c) r2[u][c] = rp[c];
+				}
+#pragma unroll
+				for (int u = 0; u < CH; ++u) {
+					const uint32_t k = key[e0 + u];
+					if (k != EMPTY && (int)(k >> 20) <= g.thLow && check_epipolar(ray1, r2[u], Em, 1e-2)) epi |= 1u << (e0 + u);
+				}
 			}
 		}
 
@@ -308,58 +390,23 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 					state = pass ? 2 : 0;
 				}
 			}
-			// ---- the lowest unresolved lane may need an exact rescan of the whole train set (wave-cooperative)
-			if (__shfl(state, low) == 2) {
-				const int qi = i0 + low;
-				uint32_t q[DW], qm[DW];
-				const uint32_t* qp = reinterpret_cast<const uint32_t*>(g.qd + (q0 + qi) * g.qstride);
+			// ---- the lowest unresolved lane may need an exact rescan of the whole train set (all waves of the workgroup)
+			const bool needScan = __shfl(state, low) == 2;
+			if (lane == 0) reqQ = needScan ? i0 + low : -1;
+			__syncthreads();   // A
+			if (needScan) scan_slice(i0 + low);
+			__syncthreads();   // B
+			if (needScan) {
+				uint32_t m1 = EMPTY, m2 = EMPTY;
 #pragma unroll
-				for (int w = 0; w < DW; ++w) q[w] = qp[w];
-				if (MASKED) {
-					const uint32_t* mp = reinterpret_cast<const uint32_t*>(g.qm + (q0 + qi) * g.qstride);
-#pragma unroll
-					for (int w = 0; w < DW; ++w) qm[w] = mp[w];
-				}
-				const bool grouped = g.qgroup != nullptr && g.tgroup != nullptr;
-				const int qgLow = grouped ? g.qgroup[q0 + qi] : 0;
-				uint32_t a = EMPTY, b2 = EMPTY;
-				double r1[3] = {0.0, 0.0, 0.0};
-				const double* EmLow = g.E;
-				if (TRI) {
-#pragma unroll
-					for (int c = 0; c < 3; ++c) r1[c] = g.rays1[(q0 + qi) * 3 + c];
-					EmLow = g.E + (size_t)9 * ((size_t)qgLow * g.nrCams + qgLow);
-				}
-				// branch-free body, 4 rows per lane and trip: all global loads of a trip are issued before the first use
-				for (int j0 = lane; j0 < g.nt; j0 += 256) {
-					uint32_t kk[4];
-#pragma unroll
-					for (int u = 0; u < 4; ++u) {
-						const int j = j0 + 64 * u;
-						const int jc = j < g.nt ? j : g.nt - 1;
-						const uint32_t* tp = reinterpret_cast<const uint32_t*>(g.td + (t0 + jc) * g.tstride);
-						const uint32_t* mp = MASKED ? reinterpret_cast<const uint32_t*>(g.tm + (t0 + jc) * g.tstride) : tp;
-						const bool ok = j < g.nt && !((matched[jc >> 5] >> (jc & 31)) & 1u) && (g.tvalid ? g.tvalid[t0 + jc] != 0 : true) &&
-						                (!grouped || g.tgroup[t0 + jc] == qgLow);   // same camera / FeatureVector node only
-						const int dist = hamming_g<DW, MASKED>(q, qm, tp, mp);
-						const uint32_t k = ((uint32_t)dist << 20) | (uint32_t)jc;
-						kk[u] = ok && (!TRI || dist <= g.thLow) ? k : EMPTY;
-					}
-					if (TRI) {   // a = smallest candidate key, b2 = smallest candidate key that passes the epipolar test (evaluated only where it can lower b2;
-						         // testing every row up front to get the ray loads out early was measured slower)
-#pragma unroll
-						for (int u = 0; u < 4; ++u) {
-							const uint32_t k = kk[u];
-							if (k < a) a = k;
-							if (k < b2 && check_epipolar(r1, g.rays2 + (t0 + (k & 0xFFFFFu)) * 3, EmLow, 1e-2)) b2 = k;
-						}
-					} else {
-#pragma unroll
-						for (int u = 0; u < 4; ++u) { const uint32_t k = kk[u]; if (k < a) { b2 = a; a = k; } else if (k < b2) b2 = k; }
+				for (int w = 0; w < kSpecWaves; ++w) {
+					const uint32_t pa = partA[w], pb = partB[w];
+					if (TRI) { m1 = pa < m1 ? pa : m1; m2 = pb < m2 ? pb : m2; }
+					else {   // the two smallest of all slices' two smallest
+						if (pa < m1) { m2 = m1; m1 = pa; } else if (pa < m2) m2 = pa;
+						if (pb < m2) m2 = pb;
 					}
 				}
-				const uint32_t m1 = wave_min_u32(a);
-				const uint32_t m2 = TRI ? wave_min_u32(b2) : wave_min_u32(a == m1 ? b2 : a);
 				++nfallback;
 				if (lane == low) {
 					if (TRI) {
@@ -378,7 +425,7 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 			}
 			// ---- claims and finality
 			if (!resolved && state == 1) atomicMin(&claim[bestIdx], (uint32_t)lane);
-			__syncthreads();
+			__threadfence_block();   // wave 0 only from here to the end of the round: LDS operations of one wave are carried out in order
 			bool blocked = false;
 			if (!resolved) {
 				if (state == 2) blocked = true;
@@ -389,7 +436,7 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 			}
 			const unsigned long long blk = __ballot(blocked);
 			const int firstBlocked = blk ? __ffsll((long long)blk) - 1 : 64;
-			__syncthreads();
+			__threadfence_block();
 			if (!resolved && state == 1) claim[bestIdx] = 0xFFFFFFFFu;   // reset own claim (all claims of this round)
 			const bool commit = !resolved && lane < firstBlocked;
 			if (commit) {
@@ -400,23 +447,25 @@ __global__ __launch_bounds__(64) void k_greedy_spec(GreedyArgs g) {
 				resolved = true;
 			}
 			nmatches += __popcll(__ballot(commit && state == 1));
-			__syncthreads();
+			__threadfence_block();
 		}
 	}
 	if (lane == 0) {
 		g.outCount[set] = nmatches;
 		if (g.outFallbacks) g.outFallbacks[set] = nfallback;
+		reqQ = -2;
 	}
+	__syncthreads();   // A: releases the helper waves
 }
 
 template <int K, int DW>
 static void launch_spec_kd(const GreedyArgs& g, hipStream_t s) {
 	const bool masked = g.qm && g.tm;
 	if (g.mode == 2) {
-		if (masked) hipLaunchKernelGGL((k_greedy_spec<K, DW, true, true>), dim3(g.nsets), dim3(64), 0, s, g);
-		else hipLaunchKernelGGL((k_greedy_spec<K, DW, false, true>), dim3(g.nsets), dim3(64), 0, s, g);
-	} else if (masked) hipLaunchKernelGGL((k_greedy_spec<K, DW, true, false>), dim3(g.nsets), dim3(64), 0, s, g);
-	else hipLaunchKernelGGL((k_greedy_spec<K, DW, false, false>), dim3(g.nsets), dim3(64), 0, s, g);
+		if (masked) hipLaunchKernelGGL((k_greedy_spec<K, DW, true, true>), dim3(g.nsets), dim3(64 * kSpecWaves), 0, s, g);
+		else hipLaunchKernelGGL((k_greedy_spec<K, DW, false, true>), dim3(g.nsets), dim3(64 * kSpecWaves), 0, s, g);
+	} else if (masked) hipLaunchKernelGGL((k_greedy_spec<K, DW, true, false>), dim3(g.nsets), dim3(64 * kSpecWaves), 0, s, g);
+	else hipLaunchKernelGGL((k_greedy_spec<K, DW, false, false>), dim3(g.nsets), dim3(64 * kSpecWaves), 0, s, g);
 }
 
 template <int DW>

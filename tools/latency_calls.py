@@ -23,8 +23,6 @@ class MP:
 
 
 ctx = mcs.Context(0)
-import atexit
-atexit.register(ctx.close)
 cams = synth.lafida_cameras()
 rig = FE.cMultiCamSys_([FE.cCamModelGeneral_.from_dict(c, synth.mirror_mask(c)) for c in cams])
 ex = FE.mdBRIEFextractorOct(1000, 1.2, 8, 25, 0, 0, 32, 20, False, 2, True, True, 32, ctx=ctx)
@@ -95,3 +93,5 @@ for masks in (True, False):
     for w in (10, 50, 100):
         prev = np.stack([F[0].mvKeys["x"], F[0].mvKeys["y"]], axis=1).astype(np.float64)
         run_w(tag + "SearchForInitialization(window %d), %d probes" % (w, F[0].totalN), lambda: m.SearchForInitialization(F[0], F[1], prev.copy(), w))
+sys.stdout.flush()
+os._exit(0)   # skip interpreter teardown (extractors would be released after their context)
