@@ -95,7 +95,7 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 	(void)hipStreamSynchronize(c->stream);
 	for (auto& kv : c->timers) { if (kv.second.a) { (void)hipEventDestroy(kv.second.a); (void)hipEventDestroy(kv.second.b); } }
 	(void)hipFree(c->partial); (void)hipFree(c->partialCount); (void)hipFree(c->stage); (void)hipFree(c->dscalar);
-	(void)hipFree(c->topKeys); (void)hipFree(c->topCnt); (void)hipFree(c->stageOut); (void)hipFree(c->tflag); (void)hipFree(c->arena);
+	(void)hipFree(c->topKeys); (void)hipFree(c->topCnt); (void)hipFree(c->stageOut); (void)hipFree(c->tflag); (void)hipFree(c->arena); if (c->pinned) (void)hipHostFree(c->pinned);
 	if (c->side) {
 		(void)hipStreamSynchronize(c->side);
 		(void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evBlur); (void)hipEventDestroy(c->evMatch); (void)hipEventDestroy(c->evGreedy);

@@ -268,7 +268,9 @@ int mcs_search_by_projection(mcs_ctx* c, const mcs_projection_set* mp, const mcs
 	auto done = [&](int rc) { (void)hipStreamSynchronize(s); return rc; };
 	a.lists = (unsigned long long*)(buf + oLists); a.counts = (int*)(buf + oCounts);
 	if (host) {
-#define UP(off, src, bytes) do { if ((bytes) && hipMemcpyAsync(buf + (off), (src), (bytes), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "H2D copy failed")); } while (0)
+		PinnedUpload up;   // one H2D copy for all inputs
+		HIPCHK(up.begin(c, buf, o));
+#define UP(off, src, bytes) up.put((off), (src), (bytes))
 		UP(oPx, mp->proj_x, (size_t)mp->n * 8); UP(oPy, mp->proj_y, (size_t)mp->n * 8); UP(oVc, mp->view_cos, (size_t)mp->n * 8);
 		UP(oLv, mp->level, (size_t)mp->n * 4); UP(oPc, mp->cam, (size_t)mp->n * 4); UP(oPd, mp->desc, (size_t)mp->n * mp->stride);
 		if (havingMasks) { UP(oPm, mp->mask, (size_t)mp->n * mp->stride); UP(oFm, f->mask, (size_t)f->n * f->stride); }
@@ -276,6 +278,7 @@ int mcs_search_by_projection(mcs_ctx* c, const mcs_projection_set* mp, const mcs
 		UP(oAs, f->assigned, (size_t)f->n); UP(oW, f->width, (size_t)f->nr_cams * 4); UP(oH, f->height, (size_t)f->nr_cams * 4);
 		UP(oSc, f->scale_factors, (size_t)f->nlevels * 8);
 #undef UP
+		if (up.flush(s) != hipSuccess) return done(fail(MCS_ERR_HIP, "H2D copy failed"));
 		a.px = (const double*)(buf + oPx); a.py = (const double*)(buf + oPy); a.vcos = (const double*)(buf + oVc); a.level = (const int*)(buf + oLv);
 		a.pcam = (const int*)(buf + oPc); a.pdesc = buf + oPd; a.pmask = havingMasks ? buf + oPm : nullptr;
 		a.keys = (const mcs_keypoint*)(buf + oKeys); a.fdesc = buf + oFd; a.fmask = havingMasks ? buf + oFm : nullptr; a.fcam = (const int*)(buf + oFc);

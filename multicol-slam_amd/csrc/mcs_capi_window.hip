@@ -24,7 +24,9 @@ struct Arena {
 		for (size_t v : sizes) t += v;
 		return ctx_arena(c, t, &base);
 	}
-	uint8_t* at(size_t id) const { size_t o = 0; for (size_t i = 0; i < id; ++i) o += sizes[i]; return base + o; }
+	size_t off(size_t id) const { size_t o = 0; for (size_t i = 0; i < id; ++i) o += sizes[i]; return o; }
+	size_t total() const { size_t t = 0; for (size_t v : sizes) t += v; return t; }
+	uint8_t* at(size_t id) const { return base + off(id); }
 };
 }  // namespace
 
@@ -73,7 +75,9 @@ static int window_common(mcs_ctx* c, const mcs_window_probes* pr, const mcs_fram
 	auto done = [&](int rc) { (void)hipStreamSynchronize(s); return rc; };   // the arena is freed by its destructor after this sync
 	a.lists = (unsigned long long*)ar.at(iLists); a.counts = (int*)ar.at(iCounts); a.owner = (int*)ar.at(iOwner); a.mdist = (int*)ar.at(iMdist);
 	if (host) {
-#define UP(id, src, bytes) do { if ((bytes) && hipMemcpyAsync(ar.at(id), (src), (bytes), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail(MCS_ERR_HIP, "H2D copy failed")); } while (0)
+		PinnedUpload up;
+		HIPCHK(up.begin(c, ar.base, ar.total()));
+#define UP(id, src, bytes) up.put(ar.off(id), (src), (bytes))
 		UP(iX, pr->x, np * 8); UP(iY, pr->y, np * 8); UP(iR, pr->radius, np * 8); UP(iLo, pr->min_level, np * 4); UP(iHi, pr->max_level, np * 4);
 		UP(iPc, pr->cam, np * 4); UP(iPd, pr->desc, np * pr->stride);
 		if (havingMasks) { UP(iPm, pr->mask, np * pr->stride); UP(iFm, f->mask, nf * f->stride); }
@@ -81,6 +85,7 @@ static int window_common(mcs_ctx* c, const mcs_window_probes* pr, const mcs_fram
 		UP(iW, f->width, (size_t)f->nr_cams * 4); UP(iH, f->height, (size_t)f->nr_cams * 4);
 		if (f->assigned) UP(iAsg, f->assigned, nf);
 #undef UP
+		if (up.flush(s) != hipSuccess) return done(fail(MCS_ERR_HIP, "H2D copy failed"));
 		a.px = (const double*)ar.at(iX); a.py = (const double*)ar.at(iY); a.rad = (const double*)ar.at(iR); a.minLvl = (const int*)ar.at(iLo);
 		a.maxLvl = (const int*)ar.at(iHi); a.pcam = (const int*)ar.at(iPc); a.pdesc = ar.at(iPd); a.pmask = havingMasks ? ar.at(iPm) : nullptr;
 		a.keys = (const mcs_keypoint*)ar.at(iKeys); a.fdesc = ar.at(iFd); a.fmask = havingMasks ? ar.at(iFm) : nullptr; a.fcam = (const int*)ar.at(iFc);

@@ -2,6 +2,7 @@
 #pragma once
 #include "mcs_common.h"
 #include <cmath>
+#include <cstring>
 #include <map>
 #include <string>
 
@@ -35,6 +36,7 @@ struct mcs_ctx {
 	int* topCnt = nullptr; size_t topCntCap = 0;
 	int* tflag = nullptr; size_t tflagCap = 0;            // per-train-row eligibility (camera group or -1) for the streamed matcher
 	uint8_t* stageOut = nullptr; size_t stageOutCap = 0;
+	uint8_t* pinned = nullptr; size_t pinnedCap = 0;      // page-locked host mirror of the arena's staged inputs (PinnedUpload)
 	uint8_t* arena = nullptr; size_t arenaCap = 0;        // scratch + host-kind staging of the window / projection / map-point entry points (mcs_capi_window.hip)
 	// Second HIP stream for the latency-bound / independent kernels (blur next to FAST+oct-tree, the greedy resolution next to the
 	// following batch's extraction): they leave most CUs idle, so overlapping them with the VALU-bound kernels is free throughput.
@@ -70,3 +72,27 @@ inline hipError_t ctx_arena(mcs_ctx* c, size_t bytes, uint8_t** out) {
 	*out = c->arena;
 	return hipSuccess;
 }
+
+// Host-kind inputs of one call, gathered in a page-locked mirror of the arena and sent with ONE H2D copy: a dozen small hipMemcpyAsync calls from
+// pageable memory cost ~20 us of runtime overhead each, more than the kernels of a single multi-frame.  Only for calls that end with a stream
+// synchronisation (the mirror is reused by the next call).
+struct PinnedUpload {
+	uint8_t* dev = nullptr; uint8_t* pin = nullptr; size_t lo = ~size_t(0), hi = 0;
+	hipError_t begin(mcs_ctx* c, uint8_t* devBase, size_t total) {
+		if (c->pinnedCap < total) {
+			if (c->pinned) (void)hipHostFree(c->pinned);
+			c->pinned = nullptr; c->pinnedCap = 0;
+			const hipError_t e = hipHostMalloc((void**)&c->pinned, total + total / 2, hipHostMallocDefault);
+			if (e != hipSuccess) return e;
+			c->pinnedCap = total + total / 2;
+		}
+		dev = devBase; pin = c->pinned;
+		return hipSuccess;
+	}
+	void put(size_t off, const void* src, size_t bytes) {
+		if (!bytes) return;
+		memcpy(pin + off, src, bytes);
+		lo = off < lo ? off : lo; hi = off + bytes > hi ? off + bytes : hi;
+	}
+	hipError_t flush(hipStream_t s) { return hi > lo ? hipMemcpyAsync(dev + lo, pin + lo, hi - lo, hipMemcpyHostToDevice, s) : hipSuccess; }
+};
