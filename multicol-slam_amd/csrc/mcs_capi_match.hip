@@ -67,21 +67,24 @@ static int stage_sets(mcs_ctx* c, int nsets, const mcs_desc_set* q, size_t qpitc
 	HIPCHK(hipStreamSynchronize(s));   // staging buffer may still be in use by an earlier call
 	if (int r = ensure((void**)&c->stage, &c->stageCap, need)) return r;
 	uint8_t* st = c->stage;
-	if (qRows) HIPCHK(hipMemcpyAsync(st + oQd, q->desc, qRows * q->stride, hipMemcpyHostToDevice, s));
-	if (q->mask && qRows) HIPCHK(hipMemcpyAsync(st + oQm, q->mask, qRows * q->stride, hipMemcpyHostToDevice, s));
-	if (q->valid && qRows) HIPCHK(hipMemcpyAsync(st + oQv, q->valid, qRows, hipMemcpyHostToDevice, s));
-	if (q->group && qRows) HIPCHK(hipMemcpyAsync(st + oQg, q->group, qRows * 4, hipMemcpyHostToDevice, s));
-	if (tRows) HIPCHK(hipMemcpyAsync(st + oTd, t->desc, tRows * t->stride, hipMemcpyHostToDevice, s));
-	if (t->mask && tRows) HIPCHK(hipMemcpyAsync(st + oTm, t->mask, tRows * t->stride, hipMemcpyHostToDevice, s));
-	if (t->valid && tRows) HIPCHK(hipMemcpyAsync(st + oTv, t->valid, tRows, hipMemcpyHostToDevice, s));
-	if (t->group && tRows) HIPCHK(hipMemcpyAsync(st + oTg, t->group, tRows * 4, hipMemcpyHostToDevice, s));
+	PinnedUpload up;   // all inputs in one H2D copy (every host-kind search ends with a stream synchronisation)
+	HIPCHK(up.begin(c, st, need));
+	if (qRows) up.put(oQd, q->desc, qRows * q->stride);
+	if (q->mask && qRows) up.put(oQm, q->mask, qRows * q->stride);
+	if (q->valid && qRows) up.put(oQv, q->valid, qRows);
+	if (q->group && qRows) up.put(oQg, q->group, qRows * 4);
+	if (tRows) up.put(oTd, t->desc, tRows * t->stride);
+	if (t->mask && tRows) up.put(oTm, t->mask, tRows * t->stride);
+	if (t->valid && tRows) up.put(oTv, t->valid, tRows);
+	if (t->group && tRows) up.put(oTg, t->group, tRows * 4);
 	out->qd = st + oQd; out->qm = q->mask ? st + oQm : nullptr; out->qvalid = q->valid ? st + oQv : nullptr;
 	out->qgroup = q->group ? (const int*)(st + oQg) : nullptr;
 	out->td = st + oTd; out->tm = t->mask ? st + oTm : nullptr; out->tvalid = t->valid ? st + oTv : nullptr;
 	out->tgroup = t->group ? (const int*)(st + oTg) : nullptr;
-	if (rays1 && *rays1) { if (qRows) HIPCHK(hipMemcpyAsync(st + oR1, *rays1, qRows * 24, hipMemcpyHostToDevice, s)); *rays1 = (const double*)(st + oR1); }
-	if (rays2 && *rays2) { if (tRows) HIPCHK(hipMemcpyAsync(st + oR2, *rays2, tRows * 24, hipMemcpyHostToDevice, s)); *rays2 = (const double*)(st + oR2); }
-	if (E && *E) { HIPCHK(hipMemcpyAsync(st + oE, *E, (size_t)nE * 8, hipMemcpyHostToDevice, s)); *E = (const double*)(st + oE); }
+	if (rays1 && *rays1) { if (qRows) up.put(oR1, *rays1, qRows * 24); *rays1 = (const double*)(st + oR1); }
+	if (rays2 && *rays2) { if (tRows) up.put(oR2, *rays2, tRows * 24); *rays2 = (const double*)(st + oR2); }
+	if (E && *E) { up.put(oE, *E, (size_t)nE * 8); *E = (const double*)(st + oE); }
+	HIPCHK(up.flush(s));
 	return MCS_OK;
 }
 
