@@ -138,10 +138,14 @@ __device__ __forceinline__ void img2world(const OcamDev& cam, double u, double v
 	zo = z / norm;
 }
 
-// Blurred neighbourhood of the keypoint staged in LDS: rows row-24..row+24, 52 bytes (13 dwords) from col-24.  A keypoint
-// sits >= 25 px inside the level, so the patch is always inside the ROI; undistorted ORB offsets (|.| <= 22) and almost
-// all distorted ones land in it — a scattered 64-lane byte gather from global memory per sample was address-unit-bound.
-constexpr int kPatchR = 24, kPatchRows = 2 * kPatchR + 1, kPatchPitch = 52;
+// Blurred neighbourhood of the keypoint staged in LDS: rows row-R..row+R, 4*ceil((2R+1)/4) bytes from col-R.  A keypoint sits >= 25 px
+// inside the level, so the patch is always inside the ROI; rotated ORB offsets (pattern radius <= 21.2) and almost all distorted ones land in
+// it, the rest takes the general path of Sampler::at — a scattered 64-lane byte gather from global memory per sample was address-unit-bound.
+#ifndef MCS_PATCH_R
+#define MCS_PATCH_R 21   // 43 rows of 44 bytes: with the 8.2 KB coordinate buffer a wave then needs 10 112 B of LDS, so 16 waves fit a CU (R = 24: 14)
+#endif
+constexpr int kPatchR = MCS_PATCH_R, kPatchRows = 2 * kPatchR + 1, kPatchDw = (kPatchRows + 3) / 4, kPatchPitch = 4 * kPatchDw;
+constexpr int kPatchBytes = (kPatchRows * kPatchPitch + 15) / 16 * 16;
 
 struct Sampler {
 	const uint8_t* blur; int bstride;
@@ -189,6 +193,7 @@ __host__ __device__ constexpr int pat_doubles(int npoints) { return 2 * npoints 
 __host__ __device__ constexpr int coord_bytes(int mode, int npoints) { return mode == 0 ? 0 : (mode == 2 && MCS_MERGE_CHAINS ? 3 : 1) * pat_doubles(npoints) * 8; }
 
 template <int MODE, int NB>   // MODE 0 ORB, 1 dBRIEF, 2 mdBRIEF; NB = descSize/8 ballots
+__attribute__((amdgpu_waves_per_eu(4, 4)))
 __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffers b, int wavesPerImage) {
 	extern __shared__ __attribute__((aligned(16))) double lds[];   // MODE > 0: [waves][2 buffers][x|y][npoints]
 	const PyrDesc& d = *b.desc;
@@ -226,11 +231,11 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 		sm.blur = b.blur + (size_t)img * d.pyrBytes + L.off; sm.bstride = L.stride;
 		sm.raw = raw; sm.rstride = rstride; sm.w = L.w; sm.h = L.h;
 		{   // stage the blurred 49x52 neighbourhood (13 unaligned dwords per row, rows are in-pitch even at the right edge)
-			constexpr int kWaveLds = coord_bytes(MODE, 128 * NB) + 2560;
+			constexpr int kWaveLds = coord_bytes(MODE, 128 * NB) + kPatchBytes;
 			uint8_t* patch = reinterpret_cast<uint8_t*>(lds) + (size_t)wave * kWaveLds + coord_bytes(MODE, 128 * NB);
 			const uint8_t* bp = sm.blur + (size_t)(row - kPatchR) * sm.bstride + (col - kPatchR);
-			for (int i = lane; i < kPatchRows * 13; i += 64) {
-				const int r = i / 13, k = i - r * 13;
+			for (int i = lane; i < kPatchRows * kPatchDw; i += 64) {
+				const int r = i / kPatchDw, k = i - r * kPatchDw;
 				uint32_t v;
 				__builtin_memcpy(&v, bp + (size_t)r * sm.bstride + 4 * k, 4);
 				*reinterpret_cast<uint32_t*>(&patch[r * kPatchPitch + 4 * k]) = v;
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 	constexpr int CH = NP / (2 * NB);         // chain elements folded into one point iteration (= 64)
 	constexpr int YO = NP + 2;                // offset of the y array inside a pattern buffer (bank shift, see pat_doubles)
 	constexpr int PD = pat_doubles(NP);
-	double* buf = reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(lds) + (size_t)wave * (coord_bytes(MODE, NP) + 2560));   // [pattern][x | y][NP] distorted coordinates
+	double* buf = reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(lds) + (size_t)wave * (coord_bytes(MODE, NP) + kPatchBytes));   // [pattern][x | y][NP] distorted coordinates
 	const OcamDev& cam = b.cams[img];
 	// The camera is the same for the whole wave: pull the backward polynomial and the affine terms into SGPRs ONCE.  (The
 	// first version re-loaded every Horner coefficient through a vector global load inside a 12-trip loop per pattern point —
@@ -380,11 +385,17 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 				double u, v;
 				if (MCS_ABLATE & 2) { u = xr; v = yr; } else w2i(xr, yr, zc, u, v);
 				wb[2 * k + e] = u; wb[YO + 2 * k + e] = v;
+				// the scheduler may interleave at most 4 point evaluations: all 8 of a pattern in flight cost 156 VGPRs (3 waves per SIMD); with this
+				// fence and the 128-register cap below the kernel keeps 4 waves per SIMD with 2 spilled registers (2.64 -> 2.48 ms per 192 images)
+				if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
 			}
 		}
 		if (doChain && !(MCS_ABLATE & 1)) {
 			const double* arr = rb + (lane & 1) * YO;
-#pragma unroll 16
+#ifndef MCS_CHAIN_UNROLL
+#define MCS_CHAIN_UNROLL 16
+#endif
+#pragma unroll MCS_CHAIN_UNROLL
 			for (int p = 0; p < NP; ++p) sum += arr[p];
 		}
 		(void)CH;
@@ -444,7 +455,7 @@ static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hi
 	const int wpb = MODE == 0 ? 4 : 1;
 	const int wavesPerImage = (hd.selPerImage + wpb - 1) / wpb * wpb;
 	const int blocks = nimg * wavesPerImage / wpb;
-	const size_t ldsBytes = (size_t)wpb * (coord_bytes(MODE, hd.npoints) + 2560);   // coordinates + blurred patch per wave
+	const size_t ldsBytes = (size_t)wpb * (coord_bytes(MODE, hd.npoints) + kPatchBytes);   // coordinates + blurred patch per wave
 	const int nb = hd.descSize / 8;
 	if (nb == 2) hipLaunchKernelGGL((k_describe<MODE, 2>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 	else if (nb == 4) hipLaunchKernelGGL((k_describe<MODE, 4>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
