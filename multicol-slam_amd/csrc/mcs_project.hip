@@ -9,8 +9,8 @@
 //   cORBmatcher::RadiusByViewingCos                                               src/cORBmatcher.cpp:169-175
 // The reference visits the 64x48 grid cells of the window column by column (ix outer, iy inner) and the features of a cell
 // in insertion (= mvKeys index) order; with strict '<' updates the winner is the candidate with the smallest
-// (distance, cell, index) and the runner-up the next one.  So every (map point, camera) projection gets the list of its window
-// members keyed by  dist<<42 | cell<<20 | index  (k_proj_candidates, one wave per projection, fully parallel), and the greedy
+// (distance, cell, index) and the runner-up the next one.  So every (map point, camera) projection gets the sorted short list of its window
+// members' smallest keys  dist<<42 | cell<<20 | index  (k_proj_candidates, one wave per projection, fully parallel), and the greedy
 // part — a feature taken by an earlier projection is skipped by all later ones — runs as the same speculative wave-parallel
 // commit as the brute-force searches (k_proj_greedy).  Pure integer + IEEE double arithmetic: bit-exact.
 #include "mcs_common.h"
