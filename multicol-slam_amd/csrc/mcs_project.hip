@@ -129,6 +129,9 @@ __global__ __launch_bounds__(64) void k_proj_candidates(ProjArgs a) {
 
 __global__ __launch_bounds__(64) void k_proj_greedy(ProjArgs a) {
 	__shared__ uint32_t taken[65536 / 32];   // frame features <= 65536
+	constexpr int kClaimHash = 4096;
+	__shared__ uint32_t claimH[kClaimHash];
+	for (int i = threadIdx.x; i < kClaimHash; i += 64) claimH[i] = 0xFFFFFFFFu;
 	const int lane = threadIdx.x;
 	const bool steal = a.rule == 3;
 	if (steal) {
@@ -219,17 +222,19 @@ __global__ __launch_bounds__(64) void k_proj_greedy(ProjArgs a) {
 				const unsigned long long m2 = wave_min_u64(b1 == m1 ? b2 : b1);
 				if (lane == low) decide(m1, m2, false, state, bestIdx, secondIdx, best);
 			}
-			// finality: no lower pending lane of this round may take my best or my second feature (accepting lanes broadcast their
-			// target one after the other; at most 64 shuffles per round)
+			// finality: no lower pending lane of this round may take my best or my second feature.  Accepting lanes publish their target in a hashed
+			// LDS claim table (atomicMin of the lane id); a collision of two different features can only block a lane that was free to go, which
+			// costs a round but never changes a result, and the lowest pending lane has no claim below it.  (One shuffle per accepting lane before.)
+			const bool claims = !resolved && state == 1;
+			if (claims) atomicMin(&claimH[bestIdx & (kClaimHash - 1)], (uint32_t)lane);
+			__syncthreads();
 			bool blocked = !resolved && state == 2;   // waits until it is the lowest pending probe
-			const unsigned long long acc = __ballot(!resolved && state == 1);
-			unsigned long long rest = acc;
-			while (rest) {
-				const int l = __ffsll((long long)rest) - 1;
-				rest &= rest - 1;
-				const int tgt = __shfl(bestIdx, l);
-				if (!resolved && lane > l && (tgt == bestIdx || tgt == secondIdx)) blocked = true;
+			if (!resolved && state != 2) {
+				if (bestIdx >= 0 && claimH[bestIdx & (kClaimHash - 1)] < (uint32_t)lane) blocked = true;
+				if (secondIdx >= 0 && claimH[secondIdx & (kClaimHash - 1)] < (uint32_t)lane) blocked = true;
 			}
+			__syncthreads();
+			if (claims) claimH[bestIdx & (kClaimHash - 1)] = 0xFFFFFFFFu;
 			const unsigned long long blk = __ballot(blocked);
 			const int firstBlocked = blk ? __ffsll((long long)blk) - 1 : 64;
 			const bool commit = !resolved && lane < firstBlocked;
