@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 		uint32_t epi = 0;           // TRI: bit e = entry e is a candidate (distance <= TH_LOW) that passes the epipolar test
 		double ray1[3] = {0.0, 0.0, 0.0};
 		const double* Em = g.E;
-		if (TRI && qok) {
+		if (TRI && qok && g.nt > 0) {   // (an empty train set has no ray rows to read)
 			const int qg = g.qgroup[q0 + i];
 			Em = g.E + (size_t)9 * ((size_t)qg * g.nrCams + qg);   // same-camera rule: camIdx2 == camIdx1 (the lists are built per camera)
 #pragma unroll

@@ -101,3 +101,35 @@ def test_shared_reciprocal_division_is_bit_identical():
         bad = C.c_int32(-1)
         G.mcs.check(G.mcs.lib().mcs_selftest_shared_reciprocal(G.ctx().h, seed, 2_000_000, C.byref(bad)))
         assert bad.value == 0
+
+
+def test_searches_with_empty_sides(G):
+    """the three brute-force searches with no query rows / no train rows (the reference's loops simply do not run)"""
+    import ctypes as C
+    import importlib
+    cap = importlib.import_module("multicol-slam_amd._capi")
+    lib, ctx = G.mcs.lib(), G.ctx()
+    rng = np.random.default_rng(0)
+    P = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    d = rng.integers(0, 256, (5, 32), dtype=np.uint8)
+    m = np.full((5, 32), 255, np.uint8)
+    ok, cam = np.ones(5, np.uint8), np.zeros(5, np.int32)
+    rays = np.tile(np.array([0.0, 0.0, 1.0]), (5, 1))
+    E = np.zeros(9)
+    empty = np.zeros((0, 32), np.uint8)
+    for nq, nt in ((0, 5), (5, 0), (0, 0)):
+        q = cap.DescSet(P(d if nq else empty), P(m if nq else empty), P(ok), P(cam), nq, 32)
+        t = cap.DescSet(P(d if nt else empty), P(m if nt else empty), P(ok), P(cam), nt, 32)
+        for mode in range(3):
+            out = np.full(8, 7, np.int32); nm = np.full(1, 7, np.int32); fb = np.zeros(1, np.int32)
+            if mode == 0:
+                rc = lib.mcs_search_kf_kf(ctx.h, 1, C.byref(q), 0, C.byref(t), 0, 32, 0.9, 32, cap.MEM_HOST, P(out), P(nm), P(fb))
+                n_out = nq
+            elif mode == 1:
+                rc = lib.mcs_search_kf_f(ctx.h, 1, C.byref(q), 0, C.byref(t), 0, 32, 0.9, 32, cap.MEM_HOST, P(out), P(nm), P(fb))
+                n_out = nt
+            else:
+                rc = lib.mcs_search_triangulation(ctx.h, 1, C.byref(q), 0, C.byref(t), 0, P(rays), P(rays), P(E), 1, 32, 32, cap.MEM_HOST, P(out), P(nm), P(fb))
+                n_out = nq
+            cap.check(rc)
+            assert nm[0] == 0 and (out[:n_out] == -1).all(), (nq, nt, mode)
