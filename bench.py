@@ -180,6 +180,11 @@ def roofline(kern, mode, nimg, nkp_total, sizes, nfeat=1000):
 
 
 # ------------------------------------------------------------------------------------------------ stream workload
+def shard_frames(rank, pool):
+    """frame numbers of the synthetic stream that rank `rank` cycles through (consecutive frames of one stream, `pool` per rank)"""
+    return [rank * pool + f for f in range(pool)]
+
+
 def run_stream(args, e):
     torch, mcs, synth, lib, ctx, dev = e.torch, e.mcs, e.synth, e.lib, e.ctx, e.dev
     W, H, NCAM = 754, 480, 3
@@ -189,7 +194,9 @@ def run_stream(args, e):
     do_db, masks_on = MODES[args.mode]
     cams = synth.lafida_cameras()
     POOL = min(F, 8)
-    pool = [synth.synth_multiframe(e.rank * 1000 + f, cams) for f in range(POOL)]   # this rank's shard of the stream (untimed)
+    # this rank's shard of the stream (untimed): consecutive frames of ONE stream — the synthetic scene drifts 3 px per frame, so frame numbers far
+    # apart (an earlier rank * 1000 offset) leave ranks >= 1 with empty images; every shard must carry the same amount of work (weak scaling)
+    pool = [synth.synth_multiframe(f, cams) for f in shard_frames(e.rank, POOL)]
     imgs_np = np.stack([pool[f % POOL][c] for f in range(F) for c in range(NCAM)])
     masks_np = np.stack([synth.mirror_mask(cams[c]) for _ in range(F) for c in range(NCAM)])
     ds = 32
@@ -271,6 +278,8 @@ def run_stream(args, e):
     feats_step = sum(int(sb.last().nkp[NCAM:].sum().item()) for sb in subs)
     matches_step = sum(int(sb.last().nmatch.sum().item()) for sb in subs)
     fallbacks = sum(int(sb.last().fb.sum().item()) for sb in subs)
+    if os.environ.get("MCS_BENCH_DEBUG"):
+        print("rank %d: %.3f ms/step, %d features/step" % (e.rank, elapsed / args.steps * 1e3, feats_step), file=sys.stderr)
     elapsed_max, feats_all = e.rig.reduce_timing(elapsed, feats_step, e.red_dev, e.world)
     d_nkp, d_desc, d_dmask = subs[0].last().nkp, subs[0].last().desc, subs[0].last().dmask
     ex = subs[0].ex

@@ -64,3 +64,17 @@ def test_shards_partition():
             kfs = [rig.keyframe_shard(n, r, world) for r in range(world)]
             assert sorted(sum(kfs, [])) == list(range(n))
             assert max(len(c) for c in cams) == rig.cams_per_rank(n, world)
+
+
+def test_every_rank_of_the_stream_bench_gets_images_with_content():
+    """bench.py shards the synthetic stream over ranks; the scene drifts with the frame number, so a shard far down the stream would be empty
+    images (ranks >= 1 once extracted ~0 features).  Every rank's frames must look like rank 0's."""
+    import importlib
+    import bench
+    synth = importlib.import_module("multicol-slam_amd.synth")
+    cam = synth.lafida_cameras()[0]
+    ref = synth.synth_image(0, 0, cam).astype(np.float64).std()
+    for rank in (1, 7):
+        for f in bench.shard_frames(rank, 8)[::7]:
+            assert synth.synth_image(f, 0, cam).astype(np.float64).std() > 0.9 * ref, (rank, f)
+    assert bench.shard_frames(0, 8) == list(range(8)) and len(set(sum((bench.shard_frames(r, 8) for r in range(8)), []))) == 64
