@@ -284,6 +284,39 @@ def test_window_match_device_pointers_and_errors(G, FE, frames):
             mcs.check(mcs.lib().mcs_window_match(G.ctx().h, C.byref(q), C.byref(fv), bad_rule, 0.8, 32, mcs.MEM_DEVICE, vp(dmatch), vp(dn)))
 
 
+def test_back_to_back_device_calls_share_the_scratch(G, FE, frames):
+    """Device-kind calls only enqueue: three window searches in a row (different radii and rules) reuse the context's persistent scratch buffer while the
+    earlier ones may still be running — stream order must keep them apart.  Results are read after all three and compared with host-kind calls."""
+    mcs = G.mcs
+    cap = importlib.import_module("multicol-slam_amd._capi")
+    _, fr = frames
+    Fa, Fb = fr
+    n = Fa.totalN
+    lv = Fa.mvKeys["octave"].astype(np.int32)
+    base = dict(x=Fa.mvKeys["x"].astype(np.float64), y=Fa.mvKeys["y"].astype(np.float64), lo=lv - 1, hi=lv + 1, cam=Fa.keypoint_to_cam.astype(np.int32),
+                d=Fa.all_descriptors(), m=Fa.all_masks())
+    fh = dict(keys=np.ascontiguousarray(Fb.mvKeys), d=Fb.all_descriptors(), m=Fb.all_masks(), cam=Fb.keypoint_to_cam.astype(np.int32),
+              w=np.array(Fb.mnMaxX, np.int32), h=np.array(Fb.mnMaxY, np.int32), sc=np.array(Fb.mvScaleFactors))
+    dp = {k: G.DevBuf(v) for k, v in base.items()}
+    df = {k: G.DevBuf(v) for k, v in fh.items()}
+    vp = lambda b: b.ptr
+    jobs = [(cap.WINDOW_RATIO, 30.0), (cap.WINDOW_BEST, 120.0), (cap.WINDOW_RATIO, 8.0)]
+    outs = []
+    for rule, rad in jobs:
+        r = G.DevBuf(np.full(n, rad)); asg = G.DevBuf(np.zeros(Fb.totalN, np.uint8)); dm = G.DevBuf(np.full(n, -7, np.int32)); dn = G.DevBuf(np.zeros(1, np.int32))
+        pr = cap.WindowProbes(vp(dp["x"]), vp(dp["y"]), vp(r), vp(dp["lo"]), vp(dp["hi"]), vp(dp["cam"]), vp(dp["d"]), vp(dp["m"]), n, 32)
+        fv = cap.FrameView(vp(df["keys"]), vp(df["d"]), vp(df["m"]), vp(df["cam"]), vp(asg), Fb.totalN, 32, 3, vp(df["w"]), vp(df["h"]), vp(df["sc"]), 8)
+        mcs.check(mcs.lib().mcs_window_match(G.ctx().h, C.byref(pr), C.byref(fv), rule, 0.8, 32, mcs.MEM_DEVICE, vp(dm), vp(dn)))
+        outs.append((r, asg, dm, dn))
+    G.ctx().synchronize()
+    m = FE.cORBmatcher(0.8, False, 32, True, ctx=G.ctx())
+    for (rule, rad), (r, asg, dm, dn) in zip(jobs, outs):
+        hasg = np.zeros(Fb.totalN, np.uint8)
+        hm, hn = m._window_match(rule, base["x"], base["y"], np.full(n, rad), base["lo"], base["hi"], base["cam"], np.arange(n), Fa, Fb, hasg)
+        assert hn == int(dn.read()[0]) and np.array_equal(hm, dm.read()) and np.array_equal(hasg, asg.read()), (rule, rad)
+    assert int(outs[1][3].read()[0]) > 100
+
+
 def test_check_orientation_filters(G, FE, frames):
     """cORBmatcher(checkOri = True): the rotation-consistency pass (mcs_rotation_consistency, four bin-arithmetic variants) on the GPU vs the oracle's
     searches with the flag (embedded histograms) resp. search + orc_rotation_consistency."""
