@@ -95,7 +95,8 @@ class Extractor:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().mcs_extractor_destroy(self.h)
+            if getattr(self.ctx, "h", None):   # the extractor's device buffers belong to its context; a context closed first took them along
+                lib().mcs_extractor_destroy(self.h)
             self.h = None
 
     def __del__(self):
