@@ -121,6 +121,7 @@ extern "C" int rs_make_keyframe(void* h, int f) {
 extern "C" int rs_set_mappoints(void* h, int isKF, int idx, const uint8_t* flag, const double* pos, const int* share, int base, int refKF) {
 	Scene* s = (Scene*)h;
 	try {
+		if (refKF < 0 || (size_t)refKF >= s->kfs.size()) { std::cerr << "rs_set_mappoints: reference keyframe " << refKF << " does not exist" << std::endl; return -1; }
 		cMultiKeyFrame* ref = s->kfs[refKF];
 		const size_t n = isKF ? s->kfs[idx]->GetKeyPoints().size() : s->frames[idx]->totalN;
 		std::vector<cMapPoint*> made(n, nullptr);

@@ -144,6 +144,8 @@ def test_window_search_and_initialization(scene):
     rng = np.random.default_rng(2)
     n0, n1 = fr[0]["n"], fr[1]["n"]
     flag = rng.choice([0, 1, 2], n0, p=[0.25, 0.7, 0.05]).astype(np.uint8)
+    if "kfs" not in scene and "kf_any" not in scene:   # map points need a reference keyframe; run alone, this test has to make one
+        scene["kf_any"] = S.make_keyframe(0)
     S.set_mappoints(False, 0, flag, base=200000, ref_kf=0)
     v0, _a = view(fr[0], having, cams)
     v1, _b = view(fr[1], having, cams)
