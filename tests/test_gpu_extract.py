@@ -163,3 +163,30 @@ def test_unsupported_parameters_fail_loudly(G):
         G.mcs.Extractor(G.ctx(), 754, 480, descSize=24)
     with pytest.raises(G.mcs.McsError):
         G.mcs.Extractor(G.ctx(), 120, 90)            # too small: a level has no 30-px FAST cell
+
+
+def test_host_images_with_padded_rows_and_gaps(G):
+    """host-kind input is taken in the caller's layout (any row stride, any distance between images): the staged copy must cover exactly that span"""
+    import ctypes as C
+    imgs, masks, cams = G.frame_inputs(5)
+    oc = (G.mcs.Ocam * 3)(*[G.mcs.make_ocam(c) for c in cams])
+    ex = G.mcs.Extractor(G.ctx(), 754, 480, max_batch=3, do_dBrief=1, learnMasks=1)
+    tight = ex.extract_host(imgs, masks, list(oc))
+    stride, gap = 754 + 14, 333
+    pitch = 480 * stride + gap
+    def pad(arrs, fill):
+        buf = np.full(3 * pitch, fill, np.uint8)
+        for i, a in enumerate(arrs):
+            buf[i * pitch:i * pitch + 480 * stride].reshape(480, stride)[:, :754] = a
+        return buf
+    pi, pm = pad(imgs, 201), pad(masks, 77)
+    pi, pm = pi[:2 * pitch + 479 * stride + 754].copy(), pm[:2 * pitch + 479 * stride + 754].copy()   # nothing readable behind the last pixel
+    cap = ex.cap
+    nkp = np.zeros(3, np.int32); kps = np.zeros((3, cap), G.mcs.KP_DTYPE); d = np.zeros((3, cap, 32), np.uint8); dm = np.zeros_like(d); rays = np.zeros((3, cap, 3))
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    G.mcs.check(G.mcs.lib().mcs_extract_batch(ex.h, 3, P(pi), pitch, stride, P(pm), pitch, stride, oc, G.mcs.MEM_HOST, P(nkp), P(kps), P(d), P(dm), P(rays)))
+    for i in range(3):
+        k = int(nkp[i])
+        assert k == len(tight[i][0]) and G.first_diff(kps[i, :k], tight[i][0]) is None
+        assert G.first_diff(d[i, :k], tight[i][1]) is None and G.first_diff(dm[i, :k], tight[i][2]) is None and G.first_diff(rays[i, :k], tight[i][3]) is None
+    ex.close()
