@@ -192,10 +192,8 @@ struct Sampler {
 __host__ __device__ constexpr int pat_doubles(int npoints) { return 2 * npoints + 2; }
 __host__ __device__ constexpr int coord_bytes(int mode, int npoints) { return mode == 0 ? 0 : (mode == 2 && MCS_MERGE_CHAINS ? 3 : 1) * pat_doubles(npoints) * 8; }
 
-template <int MODE, int NB>   // MODE 0 ORB, 1 dBRIEF, 2 mdBRIEF; NB = descSize/8 ballots
-__attribute__((amdgpu_waves_per_eu(4, 4)))
-__global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffers b, int wavesPerImage) {
-	extern __shared__ __attribute__((aligned(16))) double lds[];   // MODE > 0: [waves][2 buffers][x|y][npoints]
+template <int MODE, int NB>   // MODE 0 ORB, 1 dBRIEF, 2 mdBRIEF; NB = descSize/8 ballots.  lds: MODE > 0: [waves][x|y][npoints] coordinates + patch
+__device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int wavesPerImage, double* lds) {
 	const PyrDesc& d = *b.desc;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int gw = blockIdx.x * (MODE == 0 ? 4 : 1) + wave;
@@ -449,6 +447,20 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffer
 	}
 }
 
+// Two entry points over the same body: the 128-register cap (4 waves per SIMD) pays off wherever the LDS slice of a wave lets 16 waves share a CU;
+// mdBRIEF with 64-byte descriptors needs 18 KB of LDS per wave (8 waves per CU at most), there the cap would only cost 35 spilled registers.
+template <int MODE, int NB>
+__attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffers b, int wavesPerImage) {
+	extern __shared__ __attribute__((aligned(16))) double lds[];
+	describe_wave<MODE, NB>(b, wavesPerImage, lds);
+}
+template <int MODE, int NB>
+__global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe_wide(ExtractBuffers b, int wavesPerImage) {
+	extern __shared__ __attribute__((aligned(16))) double lds[];
+	describe_wave<MODE, NB>(b, wavesPerImage, lds);
+}
+
 template <int MODE>
 static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
 	// ORB: 4 keypoints (waves) per 256-thread block.  dBRIEF/mdBRIEF: one wave per block with a private 2*NB KiB LDS slice.
@@ -459,6 +471,7 @@ static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hi
 	const int nb = hd.descSize / 8;
 	if (nb == 2) hipLaunchKernelGGL((k_describe<MODE, 2>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 	else if (nb == 4) hipLaunchKernelGGL((k_describe<MODE, 4>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
+	else if constexpr (MODE == 2) hipLaunchKernelGGL((k_describe_wide<MODE, 8>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 	else hipLaunchKernelGGL((k_describe<MODE, 8>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 }
 
