@@ -228,7 +228,7 @@ __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int waves
 		const uint8_t* raw = level_ptr(b, d, img, level, &rstride);
 		sm.blur = b.blur + (size_t)img * d.pyrBytes + L.off; sm.bstride = L.stride;
 		sm.raw = raw; sm.rstride = rstride; sm.w = L.w; sm.h = L.h;
-		{   // stage the blurred 49x52 neighbourhood (13 unaligned dwords per row, rows are in-pitch even at the right edge)
+		{   // stage the blurred (2R+1)^2 neighbourhood (kPatchDw unaligned dwords per row, rows are in-pitch even at the right edge)
 			constexpr int kWaveLds = coord_bytes(MODE, 128 * NB) + kPatchBytes;
 			uint8_t* patch = reinterpret_cast<uint8_t*>(lds) + (size_t)wave * kWaveLds + coord_bytes(MODE, 128 * NB);
 			const uint8_t* bp = sm.blur + (size_t)(row - kPatchR) * sm.bstride + (col - kPatchR);
