@@ -57,6 +57,31 @@ def test_oracle_equals_reference_code_full_size(mode):
 
 
 @have_ref
+@pytest.mark.parametrize("case", [
+    dict(scaleFactor=1.1, nlevels=8, nfeatures=600, descSize=32, do_dBrief=1, learnMasks=1),
+    dict(scaleFactor=1.5, nlevels=5, nfeatures=500, descSize=32, do_dBrief=1, learnMasks=1),
+    dict(scaleFactor=1.2, nlevels=12, nfeatures=1500, descSize=32, do_dBrief=0, learnMasks=0),
+    dict(scaleFactor=1.2, nlevels=8, nfeatures=700, descSize=16, do_dBrief=1, learnMasks=1),
+    dict(scaleFactor=1.2, nlevels=8, nfeatures=700, descSize=64, do_dBrief=1, learnMasks=1),
+    dict(scaleFactor=1.2, nlevels=8, nfeatures=300, descSize=64, do_dBrief=1, learnMasks=0),
+    dict(scaleFactor=1.3, nlevels=3, nfeatures=2000, descSize=32, do_dBrief=1, learnMasks=1, fastThreshold=9),
+])
+def test_oracle_equals_reference_code_over_the_parameter_space(case):
+    """pyramid geometry (scale factor, level count), feature budget, descriptor size and mode away from the shipped settings, on the Lafida sensor
+    size and on the 1280x800 rig of BASELINE configs 4-5 (scaled calibration)"""
+    import ref_compare as R
+    cams = synth.lafida_cameras()
+    big = synth.scaled_camera(cams[1], 1280, 800)
+    for f, cam in ((3, cams[2]), (1, big)):
+        img = synth.synth_image(f, 1, cam)
+        mask = np.ascontiguousarray(synth.mirror_mask(cam))
+        k, d, m = R.run_ref(img, mask, cam, **case)
+        ok, od, om = O.Extractor(**case)(img, mask, O.make_ocam(cam))
+        assert len(k) == len(ok) and len(k) > 100 and all(np.array_equal(k[x], ok[x]) for x in k.dtype.names), (case, cam["width"])
+        assert np.array_equal(d, od) and np.array_equal(m, om), (case, cam["width"])
+
+
+@have_ref
 def test_camera_model_equals_reference_code():
     ref = C.CDLL(REF_SO)
     dbl, dp = C.c_double, C.POINTER(C.c_double)
