@@ -190,3 +190,29 @@ def test_host_images_with_padded_rows_and_gaps(G):
         assert k == len(tight[i][0]) and G.first_diff(kps[i, :k], tight[i][0]) is None
         assert G.first_diff(d[i, :k], tight[i][1]) is None and G.first_diff(dm[i, :k], tight[i][2]) is None and G.first_diff(rays[i, :k], tight[i][3]) is None
     ex.close()
+
+
+@pytest.mark.parametrize("case", [
+    dict(scaleFactor=1.1, nlevels=8, nfeatures=600, descSize=32, do_dBrief=1, learnMasks=1),
+    dict(scaleFactor=1.5, nlevels=5, nfeatures=500, descSize=32, do_dBrief=1, learnMasks=1),
+    dict(scaleFactor=1.1, nlevels=12, nfeatures=1500, descSize=32, do_dBrief=0, learnMasks=0),
+    dict(scaleFactor=1.2, nlevels=8, nfeatures=700, descSize=16, do_dBrief=1, learnMasks=1),
+    dict(scaleFactor=1.2, nlevels=8, nfeatures=700, descSize=64, do_dBrief=1, learnMasks=1),
+    dict(scaleFactor=1.2, nlevels=8, nfeatures=300, descSize=64, do_dBrief=1, learnMasks=0),
+    dict(scaleFactor=1.3, nlevels=3, nfeatures=2000, descSize=32, do_dBrief=1, learnMasks=1, fastThreshold=9),
+])
+def test_parameter_space_matches_oracle(G, case):
+    """the cases of tests/test_oracle_vs_ref.py::test_oracle_equals_reference_code_over_the_parameter_space (there: oracle == the reference's own code),
+    here: HIP == oracle, on the Lafida sensor size and on the 1280x800 rig"""
+    cams = G.cams3()
+    big = G.synth.scaled_camera(cams[1], 1280, 800)
+    for f, cam in ((3, cams[2]), (1, big)):
+        img, mask = G.synth.synth_image(f, 1, cam), G.synth.mirror_mask(cam)
+        if case["nfeatures"] / case["nlevels"] > 900:   # features per level + 3 must stay <= 1024 (INTEGRATION.md §5)
+            pytest.skip("feature budget per level beyond the library's limit")
+        ex = G.mcs.Extractor(G.ctx(), cam["width"], cam["height"], max_batch=1, **case)
+        gk, gd, gm, gr = ex.extract_host([img], [mask], [G.mcs.make_ocam(cam)])[0]
+        _, kps, d, dm, rays = G.oracle_extract(img, mask, cam, **case)
+        assert len(kps) > 100 and G.first_diff(gk, kps) is None and G.first_diff(gd, d) is None and G.first_diff(gm, dm) is None, (case, cam["width"])
+        assert G.first_diff(gr, rays) is None
+        ex.close()

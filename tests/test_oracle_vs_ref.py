@@ -60,7 +60,7 @@ def test_oracle_equals_reference_code_full_size(mode):
 @pytest.mark.parametrize("case", [
     dict(scaleFactor=1.1, nlevels=8, nfeatures=600, descSize=32, do_dBrief=1, learnMasks=1),
     dict(scaleFactor=1.5, nlevels=5, nfeatures=500, descSize=32, do_dBrief=1, learnMasks=1),
-    dict(scaleFactor=1.2, nlevels=12, nfeatures=1500, descSize=32, do_dBrief=0, learnMasks=0),
+    dict(scaleFactor=1.1, nlevels=12, nfeatures=1500, descSize=32, do_dBrief=0, learnMasks=0),
     dict(scaleFactor=1.2, nlevels=8, nfeatures=700, descSize=16, do_dBrief=1, learnMasks=1),
     dict(scaleFactor=1.2, nlevels=8, nfeatures=700, descSize=64, do_dBrief=1, learnMasks=1),
     dict(scaleFactor=1.2, nlevels=8, nfeatures=300, descSize=64, do_dBrief=1, learnMasks=0),
