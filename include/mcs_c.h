@@ -62,7 +62,7 @@ int mcs_device_count(int* n);
 
 /* One context per (process, GPU).  stream: a hipStream_t to run on (NULL = the context creates its own). */
 int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out);
-int mcs_ctx_destroy(mcs_ctx*);
+int mcs_ctx_destroy(mcs_ctx*);                 /* also destroys the extractors still alive on this context (their handles become invalid) */
 int mcs_ctx_synchronize(mcs_ctx*);
 /* DEVICE-kind calls only enqueue work.  Internally the library forks independent / latency-bound kernels (the blur, the
  * greedy match resolution) onto a second stream so they overlap the VALU-bound ones.  Everything an extraction produces is
@@ -76,7 +76,8 @@ int mcs_ctx_join(mcs_ctx*);
  * candidate and keypoint buffers (sized once; nothing is allocated per call).                                         */
 int mcs_extractor_create(mcs_ctx*, const mcs_extractor_params*, int width, int height, int max_batch, mcs_extractor** out);
 int mcs_extractor_destroy(mcs_extractor*);
-int mcs_extractor_kp_capacity(const mcs_extractor*, int* cap);  /* rows per image in the outputs: nfeatures + 3*nlevels */
+int mcs_extractor_kp_capacity(const mcs_extractor*, int* cap);  /* rows per image in the outputs: sum over levels of max(nfeatures_level + 3, 4 * oct-tree roots);
+                                                                 * = nfeatures + 3*nlevels for every usual configuration */
 int mcs_extractor_levels(const mcs_extractor*, int* nlevels, int* widths, int* heights, int* features_per_level);
 
 /* Run mdBRIEFextractorOct::operator() on nimg images at once.
@@ -142,6 +143,23 @@ int mcs_search_kf_f(mcs_ctx*, int nsets, const mcs_desc_set* kf, size_t pitchKF_
 int mcs_search_triangulation(mcs_ctx*, int nsets, const mcs_desc_set* kf1, size_t pitch1_rows, const mcs_desc_set* kf2, size_t pitch2_rows,
                              const double* rays1, const double* rays2, const double* E, int nrCams, int dim, int K, mcs_mem_kind kind,
                              int32_t* match12, int32_t* nmatches, int32_t* fallbacks);
+
+/* Database sweeps: the loops the reference runs AROUND those searches, one call each (a set pitch of 0 rows = the same set for every pair).
+ *
+ * mcs_search_kf_f_sweep           the relocalisation loop of cTracking::Relocalisation (src/cTracking.cpp:1125-1221: for every candidate keyframe
+ *     SearchByBoW(pKF, mCurrentFrame, ...)) for nframes frames at once — BASELINE configs[2]/[4]: every multi-frame against every stored keyframe.
+ *     Pair s = f*nkf + k reads keyframe k (rows k*pitchKF_rows ...) and frame f (rows f*pitchF_rows ...);
+ *     matchF[(f*nkf + k)*nF + j] = feature of keyframe k matched to feature j of frame f, or -1;  nmatches / fallbacks[f*nkf + k].
+ *     Same semantics per pair as mcs_search_kf_f.
+ * mcs_search_triangulation_sweep  the neighbour loop of cLocalMapping::CreateNewMapPoints (src/cLocalMapping.cpp:223-270: the current keyframe against each
+ *     covisible keyframe, ComputeE per pair, then SearchForTriangulationRaw): like mcs_search_triangulation with pitch1_rows = 0 (the current keyframe
+ *     and its rays shared by all pairs) and one block of nrCams*nrCams essential matrices PER pair: pair s reads E + s*E_set_pitch (doubles; 0 = one
+ *     block for all pairs, >= 9*nrCams*nrCams otherwise).                                                                                             */
+int mcs_search_kf_f_sweep(mcs_ctx*, int nkf, const mcs_desc_set* kf, size_t pitchKF_rows, int nframes, const mcs_desc_set* frame, size_t pitchF_rows,
+                          int dim, double nnratio, int K, mcs_mem_kind kind, int32_t* matchF, int32_t* nmatches, int32_t* fallbacks);
+int mcs_search_triangulation_sweep(mcs_ctx*, int nsets, const mcs_desc_set* kf1, size_t pitch1_rows, const mcs_desc_set* kf2, size_t pitch2_rows,
+                                   const double* rays1, const double* rays2, const double* E, size_t E_set_pitch, int nrCams, int dim, int K,
+                                   mcs_mem_kind kind, int32_t* match12, int32_t* nmatches, int32_t* fallbacks);
 
 /* ------------------------------------------------------------------ window matcher (SURVEY §8f "next" row 1)
  * int cORBmatcher::SearchByProjection(cMultiFrame& F, const vector<cMapPoint*>& vpMapPoints, const double th)  (src/cORBmatcher.cpp:67-166)

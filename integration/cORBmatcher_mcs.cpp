@@ -7,8 +7,10 @@
 //   on the GPU      SearchByBoW (KF,KF) and (KF,F) incl. the vocabulary restriction, SearchForTriangulationRaw, SearchForTriangulationBetweenCameras,
 //                   WindowSearch, SearchForInitialization, SearchByProjection (F, mapPoints) / (F1, F2, window) / (Current, Last), SearchBySim3,
 //                   Fuse (pKF, curKF, points) / (pKF, points) / (pKF, Scw, points), and the mbCheckOrientation pass of each search that has one
-//   not replaced    SearchByProjection(CurrentFrame, pKF, sAlreadyFound, ...) and SearchByProjection(pKF, Scw, ...): the reference reads outside its
-//                   descriptor matrices there (see the end of this file), there is no defined result to reproduce.  They throw.
+//                   SearchByProjection(pKF, Scw, ...) (loop closing): GPU projection + window search, bounds-safe where the reference reads past
+//                   its descriptor matrices (see that function)
+//   not replaced    SearchByProjection(CurrentFrame, pKF, sAlreadyFound, ...): no caller in the reference, and it indexes the keyframe's descriptors
+//                   with the frame's feature indices; it throws.
 //                   SearchForTriangulation and Fuse(curKF, neighKFs, map) are declared in the header but defined nowhere in the reference.
 // tests/test_gpu_dropin.py builds the reference's cMultiFrame.cpp, cMultiKeyFrame.cpp, cMapPoint.cpp ... around this file and
 // mdBRIEFextractorOct_mcs.cpp and compares every search with the all-reference build.
@@ -134,6 +136,7 @@ namespace
 			o.c = cm.Get_c(); o.d = cm.Get_d(); o.e = cm.Get_e(); o.u0 = cm.Get_u0(); o.v0 = cm.Get_v0();
 			cv::Mat_<double> P = cm.Get_P(), iP = cm.Get_invP();
 			o.p_deg = cm.GetPolDeg(); o.invP_deg = cm.GetInvDeg();
+			if (o.p_deg < 1 || o.p_deg > MCS_MAX_POLY || o.invP_deg < 1 || o.invP_deg > MCS_MAX_POLY) throw std::runtime_error("camera polynomial degree outside [1, MCS_MAX_POLY]");
 			for (int i = 0; i < o.p_deg; ++i) o.p[i] = P.at<double>(i);
 			for (int i = 0; i < o.invP_deg; ++i) o.invP[i] = iP.at<double>(i);
 			o.width = (int)cm.GetWidth(); o.height = (int)cm.GetHeight();
@@ -684,11 +687,108 @@ int cORBmatcher::SearchForTriangulationBetweenCameras(cMultiKeyFrame *pKF1, cons
 	return nmatches;
 }
 
-// ---- not replaced: no defined behaviour to reproduce ----------------------------------------------------------------------------------------
-// SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:2120-2263, no caller in the reference) indexes the KEYFRAME's descriptor rows with the
-// current frame's feature indices (:2196-2197); SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (:2265-2392, cLoopClosing.cpp:401) takes the camera of
-// list position iMP from keypoint_to_cam (:2308) and reads descriptor row `idx` (the rig-wide index) of that camera's matrix (:2364) — past its end for every
-// camera but the first.  Both read outside their matrices in a multi-camera rig; their search loops are mcs_window_best (skip_taken = 1).
+// ---- SearchByProjection(pKF, Scw, vpPoints, vpMatched, th): the loop-closing matcher (:2265-2392, called from cLoopClosing.cpp:401) ---------------------
+// Projection, mirror mask, depth gate and predicted level as in the reference; the window search is mcs_window_best with skip_taken = 1 (features
+// with vpMatched[idx] set are skipped, an accepted feature is taken at once).  Two peculiarities of the reference body are kept:
+//   * the camera of list entry iMP is keypoint_to_cam[iMP] (:2308) — the LIST position looked up as a feature index.  Where iMP is no feature
+//     index of the keyframe the reference dereferences end(); such entries are skipped here.
+//   * the descriptor compared for rig-wide feature idx of camera c is row idx of mDescriptors[c] (:2364-2372), not the feature's own row.  That row
+//     exists for every feature of camera 0 (there idx IS the local row) and for those idx < rows(c) of the other cameras — reproduced literally.
+//     Beyond the matrix the reference reads foreign memory; there the feature's own row is used (the evident intent).  Bounds-safe, and identical to
+//     the reference wherever the reference is defined.
+//   * `bestIdx > 0` (:2386): feature 0 can be the best candidate but is never accepted.  The device routine has no such rule, so from the first probe
+//     that would take feature 0 on, the loop is finished on the host (same arithmetic: DescriptorDistance64[Masked] over the same rows).
+int cORBmatcher::SearchByProjection(cMultiKeyFrame* pKF, cv::Matx44d Scw, const std::vector<cMapPoint*>& vpPoints, std::vector<cMapPoint*>& vpMatched, int th)
+{
+	cMultiCamSys_ camSys = pKF->camSystem;
+	const cv::Vec3d Ow = pose_from_sim3(camSys, Scw);
+	const int nMaxLevel = pKF->GetScaleLevels() - 1;
+	vector<double> vfScaleFactors = pKF->GetScaleFactors();
+	const int dim = mbFeatDim;
+	const bool masks = havingMasks;
+	set<cMapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+	spAlreadyFound.erase(static_cast<cMapPoint*>(NULL));
+
+	std::vector<double> pts; std::vector<int32_t> pc, owner;
+	for (int iMP = 0, iend = (int)vpPoints.size(); iMP < iend; ++iMP)
+	{
+		cMapPoint* pMP = vpPoints[iMP];
+		if (!pMP || pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+		std::unordered_map<size_t, int>::const_iterator kc = pKF->keypoint_to_cam.find(iMP);
+		if (kc == pKF->keypoint_to_cam.end()) continue;
+		cv::Vec3d p3Dw = pMP->GetWorldPos();
+		pts.push_back(p3Dw(0)); pts.push_back(p3Dw(1)); pts.push_back(p3Dw(2)); pc.push_back(kc->second); owner.push_back(iMP);
+	}
+	if (owner.empty()) return 0;
+	std::vector<double> uv; std::vector<uint8_t> fl;
+	project(camSys, pts, pc, uv, fl);
+	Probes p;
+	for (size_t k = 0; k < owner.size(); ++k)
+	{
+		if (!(fl[k] & 1)) continue;
+		cMapPoint* pMP = vpPoints[owner[k]];
+		const double maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+		cv::Vec3d PO = pMP->GetWorldPos() - Ow;
+		const double dist3D = cv::norm(PO);
+		if (dist3D < minDistance || dist3D > maxDistance) continue;
+		const double ratio = dist3D / minDistance;
+		vector<double>::iterator it = std::lower_bound(vfScaleFactors.begin(), vfScaleFactors.end(), ratio);
+		const int nPredictedLevel = std::min(static_cast<int>(it - vfScaleFactors.begin()), nMaxLevel);
+		p.add(uv[2 * k], uv[2 * k + 1], th * pKF->GetScaleFactor(nPredictedLevel), nPredictedLevel - 1, nPredictedLevel, pc[k], owner[k]);
+		const uchar* dp = (const uchar*)pMP->GetDescriptorPtr();
+		p.d.insert(p.d.end(), dp, dp + dim);
+		if (masks) { const uchar* mp = (const uchar*)pMP->GetDescriptorMaskPtr(); p.m.insert(p.m.end(), mp, mp + dim); }
+	}
+	if (p.x.empty()) return 0;
+
+	// the keyframe's features with the descriptor row the reference compares for each of them (see above)
+	Flat b = flatten(pKF, dim, masks);
+	std::vector<int> rowsOfCam(camSys.GetNrCams(), 0);
+	for (int i = 0; i < b.n; ++i) ++rowsOfCam[b.cam[i]];
+	for (int i = 0; i < b.n; ++i)
+	{
+		const int c = b.cam[i];
+		if (i >= rowsOfCam[c]) continue;   // past the end of mDescriptors[c]: the feature's own row stays
+		std::memcpy(&b.d[(size_t)i * dim], pKF->GetDescriptorRowPtr(c, i), dim);
+		if (masks) std::memcpy(&b.m[(size_t)i * dim], pKF->GetDescriptorMaskRowPtr(c, i), dim);
+	}
+	std::vector<uint8_t> taken(std::max(b.n, 1), 0);
+	for (int i = 0; i < b.n && i < (int)vpMatched.size(); ++i) taken[i] = vpMatched[i] != NULL;
+	mcs_window_probes pr = p.c(dim, masks);
+	mcs_frame_view fv = view(b, taken.data(), dim, masks);
+	std::vector<int32_t> match(p.x.size(), -1);
+	int32_t nfound = 0;
+	check(mcs_window_best(ctx(), &pr, &fv, TH_LOW_, 1, dim, MCS_MEM_HOST, match.data(), nullptr, &nfound), "mcs_window_best");
+
+	size_t hostFrom = match.size();
+	for (size_t k = 0; k < match.size(); ++k) if (match[k] == 0) { hostFrom = k; break; }
+	int nmatches = 0;
+	for (size_t k = 0; k < hostFrom; ++k)
+		if (match[k] > 0) { vpMatched[match[k]] = vpPoints[p.src[k]]; ++nmatches; }
+	// the tail after a probe that preferred feature 0: the reference's loop itself, on the rows gathered above
+	for (size_t k = hostFrom; k < match.size(); ++k)
+	{
+		vector<size_t> vIndices = pKF->GetFeaturesInArea(p.cam[k], p.x[k], p.y[k], p.r[k]);
+		const uint64_t* dMP = (const uint64_t*)&p.d[k * dim];
+		const uint64_t* mMP = masks ? (const uint64_t*)&p.m[k * dim] : nullptr;
+		int bestDist = INT_MAX, bestIdx = -1;
+		for (size_t idx : vIndices)
+		{
+			if (vpMatched[idx]) continue;
+			const int kpLevel = b.keys[idx].octave;
+			if (kpLevel < p.lo[k] || kpLevel > p.hi[k]) continue;
+			const uint64_t* dKF = (const uint64_t*)&b.d[idx * dim];
+			const int dist = masks ? DescriptorDistance64Masked(dMP, dKF, mMP, (const uint64_t*)&b.m[idx * dim], dim) : DescriptorDistance64(dMP, dKF, dim);
+			if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+		}
+		if (bestDist <= TH_LOW_ && bestIdx > 0) { vpMatched[bestIdx] = vpPoints[p.src[k]]; ++nmatches; }
+	}
+	return nmatches;
+}
+
+// ---- not replaced: no caller and no defined behaviour to reproduce -------------------------------------------------------------------------------
+// SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:2120-2263) has NO caller in the reference (cTracking::Relocalisation's calls are
+// commented out) and indexes the KEYFRAME's descriptor rows with the current frame's feature indices (:2196-2197).  Its search loop is
+// mcs_window_best (skip_taken = 1); the entry point itself is left to the reference's own body.
 int cORBmatcher::SearchByProjection(cMultiFrame&, cMultiKeyFrame*, const std::set<cMapPoint*>&, double, int) { not_replaced("SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)"); }
-int cORBmatcher::SearchByProjection(cMultiKeyFrame*, cv::Matx44d, const std::vector<cMapPoint*>&, std::vector<cMapPoint*>&, int) { not_replaced("SearchByProjection(pKF, Scw, ...)"); }
 }

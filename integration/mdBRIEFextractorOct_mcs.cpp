@@ -3,9 +3,12 @@
 // Same class, same header (the reference's own include/mdBRIEFextractorOct.h, unmodified): the constructor keeps the public state the rest of the
 // system reads (GetLevels, GetScaleFactor, GetMasksLearned, GetDescriptorSize), operator() hands the image to libmcs_hip.so through its C ABI
 // (include/mcs_c.h) and returns the same keypoints / descriptors / masks.  cMultiFrame, cTracking ... compile and link against it unchanged:
-// replace the one source file in the reference's CMake target and add `-lmcs_hip`.  The header cannot grow members, so the device handles live
-// in a side table keyed by the object.  tests/test_gpu_dropin.py builds the reference's cMultiFrame.cpp around this file and compares the
+// replace the one source file in the reference's CMake target and add `-lmcs_hip`.  The header cannot grow members (and its inline destructor
+// gives no hook), so the device extractors live in a process-wide pool keyed by EVERY constructor parameter plus the image size: objects with equal
+// parameters share one device extractor (calls are serialised on the pool's stream anyway), an object built at a recycled address with other
+// parameters can never pick up a stale one, and nothing is leaked per destroyed object.  tests/test_gpu_dropin.py builds the reference's cMultiFrame.cpp around this file and compares the
 // resulting cMultiFrame with the one the reference's own extractor produces.
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -18,10 +21,15 @@ namespace MultiColSLAM
 {
 namespace
 {
-	struct Device { mcs_extractor* ex = nullptr; int w = 0, h = 0, cap = 0; };
+	struct Device { mcs_extractor* ex = nullptr; int cap = 0; };
+	struct Key   // all 13 constructor arguments + the image size (plain ints / one float, compared bytewise)
+	{
+		mcs_extractor_params p; int32_t w, h;
+		bool operator<(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) < 0; }
+	};
 	std::mutex g_mutex;
 	mcs_ctx* g_ctx = nullptr;                                   // one context (device 0, its own stream) for all extractors of the process
-	std::map<const mdBRIEFextractorOct*, Device> g_devices;
+	std::map<Key, Device> g_devices;
 
 	void check(int rc, const char* what)
 	{
@@ -52,15 +60,16 @@ void mdBRIEFextractorOct::operator()(cv::InputArray _image, cv::InputArray _mask
 	{
 		std::lock_guard<std::mutex> lock(g_mutex);
 		if (!g_ctx) check(mcs_ctx_create(0, nullptr, &g_ctx), "mcs_ctx_create");
-		Device& d = g_devices[this];
-		if (!d.ex || d.w != image.cols || d.h != image.rows)
+		Key key;
+		std::memset(&key, 0, sizeof(key));   // padding bytes take part in the comparison
+		const mcs_extractor_params p = { nfeatures, (float)scaleFactor, numlevels, edgeThreshold, firstLevel, scoreType, patchSize, fastThreshold,
+			useAgast ? 1 : 0, fastAgastType, do_dBrief ? 1 : 0, learnMasks ? 1 : 0, descSize };
+		key.p = p; key.w = image.cols; key.h = image.rows;
+		Device& d = g_devices[key];
+		if (!d.ex)
 		{
-			if (d.ex) mcs_extractor_destroy(d.ex);
-			mcs_extractor_params p = { nfeatures, (float)scaleFactor, numlevels, edgeThreshold, firstLevel, scoreType, patchSize, fastThreshold,
-				useAgast ? 1 : 0, fastAgastType, do_dBrief ? 1 : 0, learnMasks ? 1 : 0, descSize };
 			check(mcs_extractor_create(g_ctx, &p, image.cols, image.rows, 1, &d.ex), "mcs_extractor_create");
 			check(mcs_extractor_kp_capacity(d.ex, &d.cap), "mcs_extractor_kp_capacity");
-			d.w = image.cols; d.h = image.rows;
 		}
 		dev = d;
 	}

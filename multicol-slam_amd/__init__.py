@@ -95,7 +95,7 @@ class Extractor:
 
     def close(self):
         if getattr(self, "h", None):
-            if getattr(self.ctx, "h", None):   # the extractor's device buffers belong to its context; a context closed first took them along
+            if getattr(self.ctx, "h", None):   # mcs_ctx_destroy releases the extractors still alive on it: after that this handle is already gone
                 lib().mcs_extractor_destroy(self.h)
             self.h = None
 

@@ -67,7 +67,8 @@ EXPORTS = [
     "mcs_extractor_destroy", "mcs_extractor_kp_capacity", "mcs_extractor_levels", "mcs_extract_batch", "mcs_extractor_status",
     "mcs_extractor_tap_level", "mcs_extractor_tap_candidates", "mcs_extractor_tap_selected", "mcs_match_topk",
     "mcs_match_topk_batched", "mcs_descriptor_distance", "mcs_descriptor_distance_masked", "mcs_ctx_enable_timing",
-    "mcs_ctx_kernel_ms", "mcs_ctx_join", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_rows_valid",
+    "mcs_ctx_kernel_ms", "mcs_ctx_join", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_search_kf_f_sweep",
+    "mcs_search_triangulation_sweep", "mcs_rows_valid",
     "mcs_search_by_projection", "mcs_window_match", "mcs_window_best", "mcs_rotation_consistency", "mcs_world_to_cam", "mcs_distinctive_descriptors", "mcs_selftest_shared_reciprocal", "mcs_vocabulary_create", "mcs_vocabulary_destroy", "mcs_bow_transform",
 ]
 
@@ -127,6 +128,10 @@ def lib():
     L.mcs_search_kf_f.argtypes = srch
     L.mcs_search_triangulation.argtypes = [vp, C.c_int, C.POINTER(DescSet), C.c_size_t, C.POINTER(DescSet), C.c_size_t, vp, vp, vp, C.c_int,
                                            C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.mcs_search_kf_f_sweep.argtypes = [vp, C.c_int, C.POINTER(DescSet), C.c_size_t, C.c_int, C.POINTER(DescSet), C.c_size_t, C.c_int, C.c_double, C.c_int,
+                                        C.c_int, vp, vp, vp]
+    L.mcs_search_triangulation_sweep.argtypes = [vp, C.c_int, C.POINTER(DescSet), C.c_size_t, C.POINTER(DescSet), C.c_size_t, vp, vp, vp, C.c_size_t,
+                                                 C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.mcs_rows_valid.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     L.mcs_search_by_projection.argtypes = [vp, C.POINTER(ProjectionSet), C.POINTER(FrameView), C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]
     L.mcs_window_match.argtypes = [vp, C.POINTER(WindowProbes), C.POINTER(FrameView), C.c_int, C.c_double, C.c_int, C.c_int, vp, vp]

@@ -93,9 +93,10 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 	if (!c) return MCS_OK;
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
+	while (!c->extractors.empty()) (void)mcs_extractor_destroy(c->extractors.back());   // an extractor must not outlive the stream it runs on
 	for (auto& kv : c->timers) { if (kv.second.a) { (void)hipEventDestroy(kv.second.a); (void)hipEventDestroy(kv.second.b); } }
 	(void)hipFree(c->partial); (void)hipFree(c->partialCount); (void)hipFree(c->stage); (void)hipFree(c->dscalar);
-	(void)hipFree(c->topKeys); (void)hipFree(c->topCnt); (void)hipFree(c->stageOut); (void)hipFree(c->tflag); (void)hipFree(c->arena); if (c->pinned) (void)hipHostFree(c->pinned);
+	(void)hipFree(c->topKeys); (void)hipFree(c->topCnt); (void)hipFree(c->stageOut); (void)hipFree(c->arena); if (c->pinned) (void)hipHostFree(c->pinned);
 	if (c->side) {
 		(void)hipStreamSynchronize(c->side);
 		(void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evBlur); (void)hipEventDestroy(c->evMatch); (void)hipEventDestroy(c->evGreedy);
@@ -274,7 +275,10 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	}
 	hd.pyrBytes = off;
 	hd.cellsPerImage = cellBase; hd.slotsPerImage = slotBase; hd.densePerImage = denseBase; hd.selPerImage = selBase;
-	hd.kpCap = p->nfeatures + 3 * nl;
+	// rows per image: DistributeOctTree returns at most nfeat_l + 3 keys for a level (a split adds <= 3 nodes before the `>= N` test) — but its first
+	// expansion pass runs before that test, so a level can also return up to 4 * nIni keys whatever its quota (:663-700)
+	hd.kpCap = 0;
+	for (int l = 0; l < nl; ++l) hd.kpCap += std::max(hd.lv[l].nfeat + 3, 4 * hd.lv[l].nIni);
 
 	// orientation disc (IC_Angle rows v = 0, +-1..+-16 with |u| <= umax[|v|], 845 pixels)
 	int umax[kHalfPatch + 1];
@@ -315,6 +319,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
 	HIPCHK(hipMemset(e->d_pyr, 0, B * hd.pyrBytes));
 	HIPCHK(hipMemset(e->d_blur, 0, B * hd.pyrBytes));
+	ctx->extractors.push_back(e);
 	*out = e;
 	return MCS_OK;
 }
@@ -323,6 +328,10 @@ int mcs_extractor_destroy(mcs_extractor* e) {
 	if (!e) return MCS_OK;
 	(void)hipSetDevice(e->ctx->device);
 	(void)hipStreamSynchronize(e->ctx->stream);
+	{
+		std::vector<mcs_extractor*>& v = e->ctx->extractors;
+		v.erase(std::remove(v.begin(), v.end(), e), v.end());
+	}
 	void* ptrs[] = {e->d_desc, e->d_cells, e->d_taps, e->d_maskMap, e->d_pyr, e->d_blur, e->d_slots, e->d_dense, e->d_knode,
 	                e->d_sel, e->d_cellCount, e->d_denseCount, e->d_selCount, e->d_status, e->d_cams, e->d_nkp, e->d_kps, e->d_odesc,
 	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask};

@@ -8,9 +8,6 @@
 namespace mcs {
 void launch_single_distance(const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out, hipStream_t s);
 void launch_rows_valid(const int* nkp, int nimg, int cap, uint8_t* valid, hipStream_t s);
-void launch_build_tflag(const uint8_t* tvalid, const int* tgroup, size_t rows, int* out, hipStream_t s);
-void launch_match_stream(const MatchArgs& a, const int* tflag32, hipStream_t s);
-void launch_match_tail(const MatchArgs& a, hipStream_t s);
 }
 using namespace mcs;
 
@@ -31,6 +28,12 @@ struct DevSets {   // device views of a (query sets, train sets) pair
 
 static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
+// How the nsets (query set, train set) pairs of one call map onto the caller's arrays: pair s reads query set (s % qmod) and train set (s / tdiv);
+// nq_sets / nt_sets = number of distinct sets behind each pointer (what a host-kind call has to stage).
+struct SetGrid { int nsets, qmod, tdiv, nq_sets, nt_sets; };
+static SetGrid grid_batched(int nsets, size_t qpitch, size_t tpitch) { return SetGrid{nsets, nsets, 1, qpitch ? nsets : 1, tpitch ? nsets : 1}; }
+static SetGrid grid_sweep(int nq_sets, int nt_sets) { return SetGrid{nq_sets * nt_sets, nq_sets, nq_sets, nq_sets, nt_sets}; }
+
 static int validate_sets(mcs_ctx* c, int nsets, const mcs_desc_set* q, const mcs_desc_set* t, int dim, int K) {
 	if (!c || !q || !t) return fail(MCS_ERR_INVALID, "null argument");
 	if (dim != 16 && dim != 32 && dim != 64) return fail(MCS_ERR_INVALID, "dim must be 16, 32 or 64");
@@ -43,15 +46,15 @@ static int validate_sets(mcs_ctx* c, int nsets, const mcs_desc_set* q, const mcs
 }
 
 // host pointers -> staged device copies (on the context's stream); device pointers pass through
-static int stage_sets(mcs_ctx* c, int nsets, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, mcs_mem_kind kind,
-                      DevSets* out, const double** rays1, const double** rays2, const double** E, int nE) {
+static int stage_sets(mcs_ctx* c, const SetGrid& sg, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, mcs_mem_kind kind,
+                      DevSets* out, const double** rays1, const double** rays2, const double** E, size_t nE) {
 	if (kind == MCS_MEM_DEVICE) {
 		out->qd = q->desc; out->qm = q->mask; out->qvalid = q->valid; out->qgroup = q->group;
 		out->td = t->desc; out->tm = t->mask; out->tvalid = t->valid; out->tgroup = t->group;
 		return MCS_OK;
 	}
 	hipStream_t s = c->stream;
-	const size_t qRows = qpitch * (nsets - 1) + q->n, tRows = tpitch * (nsets - 1) + t->n;
+	const size_t qRows = qpitch * (sg.nq_sets - 1) + q->n, tRows = tpitch * (sg.nt_sets - 1) + t->n;
 	size_t need = 0;
 	const size_t oQd = need; need += al256(qRows * q->stride);
 	const size_t oQm = need; need += q->mask ? al256(qRows * q->stride) : 0;
@@ -63,7 +66,7 @@ static int stage_sets(mcs_ctx* c, int nsets, const mcs_desc_set* q, size_t qpitc
 	const size_t oTg = need; need += t->group ? al256(tRows * 4) : 0;
 	const size_t oR1 = need; need += (rays1 && *rays1) ? al256(qRows * 24) : 0;
 	const size_t oR2 = need; need += (rays2 && *rays2) ? al256(tRows * 24) : 0;
-	const size_t oE = need; need += (E && *E) ? al256((size_t)nE * 8) : 0;
+	const size_t oE = need; need += (E && *E) ? al256(nE * 8) : 0;
 	HIPCHK(hipStreamSynchronize(s));   // staging buffer may still be in use by an earlier call
 	if (int r = ensure((void**)&c->stage, &c->stageCap, need)) return r;
 	uint8_t* st = c->stage;
@@ -83,44 +86,39 @@ static int stage_sets(mcs_ctx* c, int nsets, const mcs_desc_set* q, size_t qpitc
 	out->tgroup = t->group ? (const int*)(st + oTg) : nullptr;
 	if (rays1 && *rays1) { if (qRows) up.put(oR1, *rays1, qRows * 24); *rays1 = (const double*)(st + oR1); }
 	if (rays2 && *rays2) { if (tRows) up.put(oR2, *rays2, tRows * 24); *rays2 = (const double*)(st + oR2); }
-	if (E && *E) { up.put(oE, *E, (size_t)nE * 8); *E = (const double*)(st + oE); }
+	if (E && *E) { up.put(oE, *E, nE * 8); *E = (const double*)(st + oE); }
 	HIPCHK(up.flush(s));
 	return MCS_OK;
 }
 
-static int run_topk(mcs_ctx* c, const DevSets& d, int nsets, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, int dim,
+static int run_topk(mcs_ctx* c, const DevSets& d, const SetGrid& sg, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, int dim,
                     int K, int count_thresh, int max_dist, int* outDist, int* outIdx, int* outCount) {
 	MatchArgs a{};
+	const int nsets = sg.nsets;
 	a.maxDist = max_dist;
 	if (c->side && c->greedyPending) { HIPCHK(hipStreamWaitEvent(c->stream, c->evGreedy, 0)); c->greedyPending = false; }
 	if (int r = ensure((void**)&c->topKeys, &c->topKeysCap, std::max<size_t>((size_t)nsets * q->n, 1) * K * sizeof(uint32_t))) return r;
 	a.keys = c->topKeys;
 	a.qd = d.qd; a.qm = d.qm; a.qvalid = d.qvalid; a.qgroup = d.qgroup; a.td = d.td; a.tm = d.tm; a.tvalid = d.tvalid; a.tgroup = d.tgroup;
 	a.nq = q->n; a.nt = t->n; a.qstride = q->stride; a.tstride = t->stride; a.qpitch = qpitch; a.tpitch = tpitch;
-	a.nsets = nsets; a.dim = dim; a.K = K; a.countThresh = count_thresh;
+	a.nsets = nsets; a.qmod = sg.qmod; a.tdiv = sg.tdiv; a.dim = dim; a.K = K; a.countThresh = count_thresh;
 	const size_t outRows = (size_t)nsets * q->n;
 	const int qTiles = (q->n + 255) / 256;
+	// Train-range splits only where the (set, query tile) grid alone cannot fill the chip (a single keyframe pair: 12 workgroups).  From kFillBlocks
+	// workgroups on (2 per CU) every workgroup walks its whole train set: no partial lists, no merge pass (their HBM traffic was 16x the algorithmic bytes).
 	static const int kTargetBlocks = getenv("MCS_MATCH_BLOCKS") ? atoi(getenv("MCS_MATCH_BLOCKS")) : 2048;
-	static const bool kStream = getenv("MCS_MATCH_STREAM") != nullptr;   // default: LDS-tiled first stage; MCS_MATCH_STREAM=1 selects the scalar-streamed one (A/B: equal speed, both int-VALU-bound)
-	int splits = (kTargetBlocks + qTiles * nsets - 1) / (qTiles * nsets);
+	static const int kFillBlocks = getenv("MCS_MATCH_FILL") ? atoi(getenv("MCS_MATCH_FILL")) : 512;
+	int splits = (long long)qTiles * nsets >= kFillBlocks ? 1 : (int)((kTargetBlocks + (long long)qTiles * nsets - 1) / ((long long)qTiles * nsets));
 	splits = std::max(1, std::min(splits, (t->n + 255) / 256));
 	a.splits = splits;
-	if (int r = ensure((void**)&c->partial, &c->partialCap, outRows * splits * K * sizeof(uint32_t))) return r;
-	if (int r = ensure((void**)&c->partialCount, &c->partialCountCap, outRows * splits * sizeof(int))) return r;
+	if (splits > 1) {
+		if (int r = ensure((void**)&c->partial, &c->partialCap, outRows * splits * K * sizeof(uint32_t))) return r;
+		if (int r = ensure((void**)&c->partialCount, &c->partialCountCap, outRows * splits * sizeof(int))) return r;
+	}
 	a.partial = c->partial; a.partialCount = c->partialCount;
 	a.outDist = outDist; a.outIdx = outIdx; a.outCount = outCount;
 	c->tic("match");
-	if (kStream) {
-		const int* tflag32 = nullptr;
-		if (d.tvalid || d.tgroup) {
-			const size_t tRows = tpitch * (nsets - 1) + t->n;
-			if (int r = ensure((void**)&c->tflag, &c->tflagCap, tRows * sizeof(int))) return r;
-			launch_build_tflag(d.tvalid, d.tgroup, tRows, c->tflag, c->stream);
-			tflag32 = c->tflag;
-		}
-		launch_match_stream(a, tflag32, c->stream);
-		launch_match_tail(a, c->stream);
-	} else launch_match(a, c->stream);
+	launch_match(a, c->stream);
 	c->toc("match");
 	HIPCHK(hipGetLastError());
 	return MCS_OK;
@@ -135,13 +133,14 @@ int mcs_match_topk_batched(mcs_ctx* c, int nsets, const mcs_desc_set* q, size_t 
 	if (q->n == 0) return MCS_OK;
 	HIPCHK(hipSetDevice(c->device));
 	DevSets d{};
-	if (int r = stage_sets(c, nsets, q, qpitch, t, tpitch, kind, &d, nullptr, nullptr, nullptr, 0)) return r;
+	const SetGrid sg = grid_batched(nsets, qpitch, tpitch);
+	if (int r = stage_sets(c, sg, q, qpitch, t, tpitch, kind, &d, nullptr, nullptr, nullptr, 0)) return r;
 	const size_t outRows = (size_t)nsets * q->n;
-	if (kind == MCS_MEM_DEVICE) return run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, count_thresh, 0x7FFFFFFF, out_dist, out_idx, out_count_le);
+	if (kind == MCS_MEM_DEVICE) return run_topk(c, d, sg, q, qpitch, t, tpitch, dim, K, count_thresh, 0x7FFFFFFF, out_dist, out_idx, out_count_le);
 	const size_t oD = 0, oI = al256(outRows * K * 4), oC = oI + al256(outRows * K * 4);
 	if (int r = ensure((void**)&c->stageOut, &c->stageOutCap, oC + al256(outRows * 4))) return r;
 	uint8_t* so = c->stageOut;
-	if (int r = run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, count_thresh, 0x7FFFFFFF, (int*)(so + oD), (int*)(so + oI), (int*)(so + oC))) return r;
+	if (int r = run_topk(c, d, sg, q, qpitch, t, tpitch, dim, K, count_thresh, 0x7FFFFFFF, (int*)(so + oD), (int*)(so + oI), (int*)(so + oC))) return r;
 	HIPCHK(hipMemcpyAsync(out_dist, so + oD, outRows * K * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(out_idx, so + oI, outRows * K * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(out_count_le, so + oC, outRows * 4, hipMemcpyDeviceToHost, c->stream));
@@ -155,9 +154,11 @@ int mcs_match_topk(mcs_ctx* c, const mcs_desc_set* q, const mcs_desc_set* t, int
 }
 
 // mode 0: SearchByBoW(KF,KF)   1: SearchByBoW(KF,F)   2: SearchForTriangulationRaw
-static int search_common(mcs_ctx* c, int mode, int nsets, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, int dim,
-                         double nnratio, int K, mcs_mem_kind kind, const double* rays1, const double* rays2, const double* E, int nrCams,
+static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, int dim,
+                         double nnratio, int K, mcs_mem_kind kind, const double* rays1, const double* rays2, const double* E, size_t Epitch, int nrCams,
                          int32_t* out_match, int32_t* out_nmatches, int32_t* out_fallbacks) {
+	const int nsets = sg.nsets;
+	if (sg.nq_sets < 1 || sg.nt_sets < 1) return fail(MCS_ERR_INVALID, "bad set count");
 	if (int r = validate_sets(c, nsets, q, t, dim, K)) return r;
 	if (!out_match || !out_nmatches) return fail(MCS_ERR_INVALID, "null output");
 	if (t->n > 131072) return fail(MCS_ERR_UNSUPPORTED, "more than 131072 train rows per set");
@@ -172,8 +173,8 @@ static int search_common(mcs_ctx* c, int mode, int nsets, const mcs_desc_set* q,
 	// thresholds of cORBmatcher::cORBmatcher (src/cORBmatcher.cpp:46-65); only TH_LOW_ is used by these three searches
 	const int thLow = havingMasks ? (int)floor((double)dim) : 2 * dim;
 	DevSets d{};
-	if (int r = stage_sets(c, nsets, q, qpitch, t, tpitch, kind, &d, mode == 2 ? &rays1 : nullptr, mode == 2 ? &rays2 : nullptr,
-	                       mode == 2 ? &E : nullptr, nrCams * nrCams * 9)) return r;
+	if (int r = stage_sets(c, sg, q, qpitch, t, tpitch, kind, &d, mode == 2 ? &rays1 : nullptr, mode == 2 ? &rays2 : nullptr,
+	                       mode == 2 ? &E : nullptr, Epitch * (size_t)(nsets - 1) + (size_t)nrCams * nrCams * 9)) return r;
 	const size_t rows = (size_t)nsets * q->n;
 	if (int r = ensure((void**)&c->topCnt, &c->topCntCap, std::max<size_t>(rows, 1) * 4)) return r;
 	{
@@ -183,14 +184,14 @@ static int search_common(mcs_ctx* c, int mode, int nsets, const mcs_desc_set* q,
 		int maxDist = thLow;
 		if (mode != 2) while (maxDist < 8 * dim && nnratio * static_cast<double>(maxDist + 1) <= static_cast<double>(thLow)) ++maxDist;
 		if (q->n > 0)
-			if (int r = run_topk(c, d, nsets, q, qpitch, t, tpitch, dim, K, -1, maxDist, nullptr, nullptr, c->topCnt)) return r;
+			if (int r = run_topk(c, d, sg, q, qpitch, t, tpitch, dim, K, -1, maxDist, nullptr, nullptr, c->topCnt)) return r;
 	}
 	GreedyArgs g{};
 	g.qd = d.qd; g.qm = d.qm; g.qvalid = d.qvalid; g.qgroup = d.qgroup; g.td = d.td; g.tm = d.tm; g.tvalid = d.tvalid; g.tgroup = d.tgroup;
 	g.nq = q->n; g.nt = t->n; g.qstride = q->stride; g.tstride = t->stride; g.qpitch = qpitch; g.tpitch = tpitch;
-	g.nsets = nsets; g.dim = dim; g.K = K; g.keys = c->topKeys;
+	g.nsets = nsets; g.qmod = sg.qmod; g.tdiv = sg.tdiv; g.dim = dim; g.K = K; g.keys = c->topKeys;
 	g.thLow = thLow; g.thInclusive = mode == 1 ? 1 : 0; g.ratio = nnratio; g.mode = mode;
-	g.rays1 = rays1; g.rays2 = rays2; g.E = E; g.nrCams = nrCams;
+	g.rays1 = rays1; g.rays2 = rays2; g.E = E; g.Epitch = Epitch; g.nrCams = nrCams;
 	const size_t outN = (size_t)nsets * (mode == 1 ? t->n : q->n);
 	if (kind == MCS_MEM_DEVICE) {
 		g.outMatch = out_match; g.outCount = out_nmatches; g.outFallbacks = out_fallbacks;
@@ -222,18 +223,32 @@ static int search_common(mcs_ctx* c, int mode, int nsets, const mcs_desc_set* q,
 
 int mcs_search_kf_kf(mcs_ctx* c, int nsets, const mcs_desc_set* kf1, size_t pitch1, const mcs_desc_set* kf2, size_t pitch2, int dim, double nnratio,
                      int K, mcs_mem_kind kind, int32_t* match12, int32_t* nmatches, int32_t* fallbacks) {
-	return search_common(c, 0, nsets, kf1, pitch1, kf2, pitch2, dim, nnratio, K, kind, nullptr, nullptr, nullptr, 0, match12, nmatches, fallbacks);
+	return search_common(c, 0, grid_batched(nsets, pitch1, pitch2), kf1, pitch1, kf2, pitch2, dim, nnratio, K, kind, nullptr, nullptr, nullptr, 0, 0, match12, nmatches, fallbacks);
 }
 
 int mcs_search_kf_f(mcs_ctx* c, int nsets, const mcs_desc_set* kf, size_t pitchKF, const mcs_desc_set* f, size_t pitchF, int dim, double nnratio, int K,
                     mcs_mem_kind kind, int32_t* matchF, int32_t* nmatches, int32_t* fallbacks) {
-	return search_common(c, 1, nsets, kf, pitchKF, f, pitchF, dim, nnratio, K, kind, nullptr, nullptr, nullptr, 0, matchF, nmatches, fallbacks);
+	return search_common(c, 1, grid_batched(nsets, pitchKF, pitchF), kf, pitchKF, f, pitchF, dim, nnratio, K, kind, nullptr, nullptr, nullptr, 0, 0, matchF, nmatches, fallbacks);
+}
+
+int mcs_search_kf_f_sweep(mcs_ctx* c, int nkf, const mcs_desc_set* kf, size_t pitchKF, int nframes, const mcs_desc_set* f, size_t pitchF, int dim,
+                          double nnratio, int K, mcs_mem_kind kind, int32_t* matchF, int32_t* nmatches, int32_t* fallbacks) {
+	if (nkf < 1 || nframes < 1 || (long long)nkf * nframes > (1 << 24)) return fail(MCS_ERR_INVALID, "bad keyframe / frame count");
+	if ((nkf > 1 && pitchKF < (size_t)(kf ? kf->n : 0)) || (nframes > 1 && pitchF < (size_t)(f ? f->n : 0))) return fail(MCS_ERR_INVALID, "set pitch smaller than the set");
+	return search_common(c, 1, grid_sweep(nkf, nframes), kf, pitchKF, f, pitchF, dim, nnratio, K, kind, nullptr, nullptr, nullptr, 0, 0, matchF, nmatches, fallbacks);
 }
 
 int mcs_search_triangulation(mcs_ctx* c, int nsets, const mcs_desc_set* kf1, size_t pitch1, const mcs_desc_set* kf2, size_t pitch2, const double* rays1,
                              const double* rays2, const double* E, int nrCams, int dim, int K, mcs_mem_kind kind, int32_t* match12,
                              int32_t* nmatches, int32_t* fallbacks) {
-	return search_common(c, 2, nsets, kf1, pitch1, kf2, pitch2, dim, 0.0, K, kind, rays1, rays2, E, nrCams, match12, nmatches, fallbacks);
+	return search_common(c, 2, grid_batched(nsets, pitch1, pitch2), kf1, pitch1, kf2, pitch2, dim, 0.0, K, kind, rays1, rays2, E, 0, nrCams, match12, nmatches, fallbacks);
+}
+
+int mcs_search_triangulation_sweep(mcs_ctx* c, int nsets, const mcs_desc_set* kf1, size_t pitch1, const mcs_desc_set* kf2, size_t pitch2, const double* rays1,
+                                   const double* rays2, const double* E, size_t E_set_pitch, int nrCams, int dim, int K, mcs_mem_kind kind,
+                                   int32_t* match12, int32_t* nmatches, int32_t* fallbacks) {
+	if (E_set_pitch != 0 && E_set_pitch < (size_t)nrCams * nrCams * 9) return fail(MCS_ERR_INVALID, "E_set_pitch smaller than one block of essential matrices");
+	return search_common(c, 2, grid_batched(nsets, pitch1, pitch2), kf1, pitch1, kf2, pitch2, dim, 0.0, K, kind, rays1, rays2, E, E_set_pitch, nrCams, match12, nmatches, fallbacks);
 }
 
 int mcs_search_by_projection(mcs_ctx* c, const mcs_projection_set* mp, const mcs_frame_view* f, double th, double nnratio, int dim, mcs_mem_kind kind,
@@ -243,6 +258,9 @@ int mcs_search_by_projection(mcs_ctx* c, const mcs_projection_set* mp, const mcs
 	if (mp->n < 0 || f->n < 0 || f->n > 65536 || f->nr_cams < 1 || f->nlevels < 1) return fail(MCS_ERR_INVALID, "bad sizes (frame features must be <= 65536)");
 	if ((mp->mask == nullptr) != (f->mask == nullptr)) return fail(MCS_ERR_INVALID, "masks must be given for both sides or neither");
 	if (mp->stride < dim || f->stride < dim || (mp->stride & 3) || (f->stride & 3)) return fail(MCS_ERR_INVALID, "descriptor stride must be >= dim and a multiple of 4");
+	if (kind == MCS_MEM_HOST)   // level[] indexes scale_factors on the device
+		for (int i = 0; i < mp->n; ++i)
+			if (mp->level[i] < 0 || mp->level[i] >= f->nlevels) return fail(MCS_ERR_INVALID, "projection level outside [0, nlevels)");
 	HIPCHK(hipSetDevice(c->device));
 	hipStream_t s = c->stream;
 	if (c->side && c->greedyPending) { HIPCHK(hipStreamWaitEvent(s, c->evGreedy, 0)); c->greedyPending = false; }
@@ -318,14 +336,14 @@ static int single_distance(mcs_ctx* c, const uint8_t* a, const uint8_t* b, const
 	if (!c || !a || !b || !out || (dim != 16 && dim != 32 && dim != 64)) return fail(MCS_ERR_INVALID, "bad argument");
 	HIPCHK(hipSetDevice(c->device));
 	uint8_t* buf = nullptr;
-	HIPCHK(hipMalloc((void**)&buf, 4 * 64));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(ctx_arena(c, 4 * 64, &buf));   // the context's persistent scratch
 	HIPCHK(hipMemcpy(buf, a, dim, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(buf + 64, b, dim, hipMemcpyHostToDevice));
 	if (ma) { HIPCHK(hipMemcpy(buf + 128, ma, dim, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(buf + 192, mb, dim, hipMemcpyHostToDevice)); }
 	launch_single_distance(buf, buf + 64, ma ? buf + 128 : nullptr, ma ? buf + 192 : nullptr, dim, c->dscalar, c->stream);
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipMemcpy(out, c->dscalar, sizeof(int), hipMemcpyDeviceToHost));
-	(void)hipFree(buf);
 	return MCS_OK;
 }
 

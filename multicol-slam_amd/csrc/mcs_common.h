@@ -102,6 +102,8 @@ struct MatchArgs {
 	const uint8_t* qd; const uint8_t* qm; const uint8_t* qvalid; const int* qgroup; int nq; int qstride; size_t qpitch;
 	const uint8_t* td; const uint8_t* tm; const uint8_t* tvalid; const int* tgroup; int nt; int tstride; size_t tpitch;
 	int nsets; int dim; int K; int countThresh;
+	int qmod, tdiv;            // set s reads query set (s % qmod) and train set (s / tdiv): plain batches qmod = nsets, tdiv = 1; a database sweep of
+	                           // nkf keyframes x nframes frames (s = f*nkf + k) qmod = tdiv = nkf
 	int maxDist;               // rows farther than this never enter a list (INT_MAX for plain top-K)
 	int splits;                // train-range splits per (set, query tile)
 	uint32_t* partial;         // [nsets][splits][K][nq] packed (dist<<20 | idx), ascending in K
@@ -117,10 +119,12 @@ struct GreedyArgs {
 	const uint8_t* qd; const uint8_t* qm; const uint8_t* qvalid; const int* qgroup; int nq; int qstride; size_t qpitch;
 	const uint8_t* td; const uint8_t* tm; const uint8_t* tvalid; const int* tgroup; int nt; int tstride; size_t tpitch;
 	int nsets; int dim; int K;
+	int qmod, tdiv;                          // as in MatchArgs
 	const uint32_t* keys;                    // [nsets][K][nq] packed (dist<<20 | idx) ascending in K, 0xFFFFFFFF = empty
 	int thLow; int thInclusive; double ratio;
 	int mode;                                // 0 SearchByBoW(KF,KF)  1 SearchByBoW(KF,F)  2 SearchForTriangulationRaw
 	const double* rays1; const double* rays2; const double* E; int nrCams;
+	size_t Epitch;                           // doubles between the essential-matrix blocks of consecutive sets (0: one block for all sets)
 	int* outMatch; int* outCount; int* outFallbacks;
 };
 void launch_greedy(const GreedyArgs& g, hipStream_t s);

@@ -51,7 +51,7 @@ template <int DW, bool MASKED>
 __global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
 	__shared__ uint32_t matched[kBitmapWords];
 	const int set = blockIdx.x, lane = threadIdx.x;
-	const size_t q0 = (size_t)set * g.qpitch, t0 = (size_t)set * g.tpitch;
+	const size_t q0 = (size_t)(set % g.qmod) * g.qpitch, t0 = (size_t)(set / g.tdiv) * g.tpitch;
 	const int K = g.K;
 	for (int i = lane; i < (g.nt + 31) / 32; i += 64) matched[i] = 0;
 	int* outM = g.outMatch + (size_t)set * (g.mode == 1 ? g.nt : g.nq);
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
 			uint32_t lastKey = 0xFFFFFFFFu;
 			bool exhausted = true;   // ran off a full list without a stop condition
 			const double* ray1 = g.rays1 + (q0 + i) * 3;
-			const double* Em = g.E + (size_t)9 * ((size_t)qg * g.nrCams + qg);   // same-camera rule: camIdx2 == camIdx1
+			const double* Em = g.E + (size_t)set * g.Epitch + (size_t)9 * ((size_t)qg * g.nrCams + qg);   // same-camera rule: camIdx2 == camIdx1
 			for (int e = 0; e < K; ++e) {
 				const int de = __shfl(d, e), ie = __shfl(idx, e);
 				if (ie < 0 || de > g.thLow) { exhausted = false; break; }
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 	__shared__ int reqQ;                                   // query to rescan this round, -1 none, -2 the set is finished
 	__shared__ uint32_t partA[kSpecWaves], partB[kSpecWaves];
 	const int set = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const size_t q0 = (size_t)set * g.qpitch, t0 = (size_t)set * g.tpitch;
+	const size_t q0 = (size_t)(set % g.qmod) * g.qpitch, t0 = (size_t)(set / g.tdiv) * g.tpitch;
 	constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 	for (int i = threadIdx.x; i < (g.nt + 31) / 32; i += 64 * kSpecWaves) matched[i] = 0;
 	for (int i = threadIdx.x; i < g.nt; i += 64 * kSpecWaves) claim[i] = 0xFFFFFFFFu;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 		if (TRI) {
 #pragma unroll
 			for (int c = 0; c < 3; ++c) r1[c] = g.rays1[(q0 + qi) * 3 + c];
-			EmLow = g.E + (size_t)9 * ((size_t)qgLow * g.nrCams + qgLow);
+			EmLow = g.E + (size_t)set * g.Epitch + (size_t)9 * ((size_t)qgLow * g.nrCams + qgLow);
 		}
 		// branch-free body, 4 rows per lane and trip: all global loads of a trip are issued before the first use
 		for (int j0 = wave * 256 + lane; j0 < g.nt; j0 += 256 * kSpecWaves) {
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 		const double* Em = g.E;
 		if (TRI && qok && g.nt > 0) {   // (an empty train set has no ray rows to read)
 			const int qg = g.qgroup[q0 + i];
-			Em = g.E + (size_t)9 * ((size_t)qg * g.nrCams + qg);   // same-camera rule: camIdx2 == camIdx1 (the lists are built per camera)
+			Em = g.E + (size_t)set * g.Epitch + (size_t)9 * ((size_t)qg * g.nrCams + qg);   // same-camera rule: camIdx2 == camIdx1 (the lists are built per camera)
 #pragma unroll
 			for (int c = 0; c < 3; ++c) ray1[c] = g.rays1[(q0 + i) * 3 + c];
 			// the rays of up to 8 list entries are fetched before the first test (a dependent global round trip per entry otherwise)

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <vector>
 
 std::string& mcs_err();
 inline int fail(int code, const std::string& msg) { mcs_err() = msg; return code; }
@@ -23,6 +24,7 @@ struct Timer { hipEvent_t a = nullptr, b = nullptr; bool used = false; };
 
 struct mcs_ctx {
 	int device = 0;
+	std::vector<mcs_extractor*> extractors;   // live extractors built on this context: mcs_ctx_destroy releases them (their buffers and stream are the context's)
 	hipStream_t stream = nullptr;
 	bool ownStream = false;
 	bool timing = false;
@@ -34,7 +36,6 @@ struct mcs_ctx {
 	int* dscalar = nullptr;
 	uint32_t* topKeys = nullptr; size_t topKeysCap = 0;   // packed [set][K][nq] top-K lists feeding the greedy kernels
 	int* topCnt = nullptr; size_t topCntCap = 0;
-	int* tflag = nullptr; size_t tflagCap = 0;            // per-train-row eligibility (camera group or -1) for the streamed matcher
 	uint8_t* stageOut = nullptr; size_t stageOutCap = 0;
 	uint8_t* pinned = nullptr; size_t pinnedCap = 0;      // page-locked host mirror of the arena's staged inputs (PinnedUpload)
 	uint8_t* arena = nullptr; size_t arenaCap = 0;        // scratch + host-kind staging of the window / projection / map-point entry points (mcs_capi_window.hip)

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	const int tid = threadIdx.x;
 	const int set = blockIdx.z, split = blockIdx.y;
 	const int qi = blockIdx.x * 256 + tid;
-	const size_t qrow0 = (size_t)set * a.qpitch, trow0 = (size_t)set * a.tpitch;
+	const size_t qrow0 = (size_t)(set % a.qmod) * a.qpitch, trow0 = (size_t)(set / a.tdiv) * a.tpitch;
 	bool qok = qi < a.nq;
 	if (qok && a.qvalid) qok = a.qvalid[qrow0 + qi] != 0;
 	uint32_t q[DW], qm[DW];
@@ -285,22 +285,6 @@ static void launch_k(const MatchArgs& a, hipStream_t s) {
 	if (a.dim == 16) launch_kd<K, 4>(a, s);
 	else if (a.dim == 32) launch_kd<K, 8>(a, s);
 	else launch_kd<K, 16>(a, s);
-}
-
-// merge + unpack stages only (used after the scalar-streamed first stage of mcs_match_stream.hip)
-void launch_match_tail(const MatchArgs& a, hipStream_t s) {
-	const dim3 grid((a.nq + 255) / 256, 1, a.nsets);
-	if (a.splits > 1) {
-		switch (a.K) {
-			case 1: hipLaunchKernelGGL((k_match_merge<1>), grid, dim3(256), 0, s, a); break;
-			case 2: hipLaunchKernelGGL((k_match_merge<2>), grid, dim3(256), 0, s, a); break;
-			case 4: hipLaunchKernelGGL((k_match_merge<4>), grid, dim3(256), 0, s, a); break;
-			case 8: hipLaunchKernelGGL((k_match_merge<8>), grid, dim3(256), 0, s, a); break;
-			case 16: hipLaunchKernelGGL((k_match_merge<16>), grid, dim3(256), 0, s, a); break;
-			default: hipLaunchKernelGGL((k_match_merge<32>), grid, dim3(256), 0, s, a); break;
-		}
-	}
-	if (a.outDist && a.outIdx) hipLaunchKernelGGL(k_match_unpack, grid, dim3(256), 0, s, a);
 }
 
 void launch_match(const MatchArgs& a, hipStream_t s) {

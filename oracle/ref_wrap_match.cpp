@@ -319,6 +319,26 @@ extern "C" int rs_sim3(void* h, int k1, int k2, double s12, const double* R12, c
 		return n;
 	} catch (const std::exception& e) { std::cerr << "rs_sim3: " << e.what() << std::endl; return -1; }
 }
+// cLoopClosing::ComputeSim3's last step (src/cLoopClosing.cpp:378-403): SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (src/cORBmatcher.cpp:2265-2392).
+// vpPoints = the first nList non-NULL map points of keyframe kSource (the caller keeps nList within the target's camera-0 feature count: the reference
+// looks the LIST position up as a feature index and reads that camera's descriptor matrix with rig-wide row numbers, which is only in bounds for camera 0).
+// preSlot[i] >= 0: vpMatched[i] holds list entry preSlot[i] on entry.  ids[i] = id of vpMatched[i] afterwards.
+extern "C" int rs_proj_scw(void* h, int kTarget, int kSource, int nList, const double* Scw, int th, const int* preSlot, int* ids) {
+	Scene* s = (Scene*)h;
+	try {
+		cORBmatcher m(0.75, false, s->dim, s->masks);
+		cMultiKeyFrame* T = s->kfs[kTarget]; cMultiKeyFrame* S = s->kfs[kSource];
+		std::vector<cMapPoint*> pts;
+		for (cMapPoint* p : S->GetMapPointMatches()) if (p && (int)pts.size() < nList) { if (!p->isBad()) p->UpdateNormalAndDepth(); pts.push_back(p); }
+		const size_t N = T->GetKeyPoints().size();
+		std::vector<cMapPoint*> matched(N, static_cast<cMapPoint*>(NULL));
+		for (size_t i = 0; i < N; ++i) if (preSlot[i] >= 0 && preSlot[i] < (int)pts.size()) matched[i] = pts[preSlot[i]];
+		cv::Matx44d M; std::memcpy(M.val, Scw, 128);
+		const int n = m.SearchByProjection(T, M, pts, matched, th);
+		for (size_t i = 0; i < N; ++i) ids[i] = id_or_minus1(s, matched[i]);
+		return n;
+	} catch (const std::exception& e) { std::cerr << "rs_proj_scw: " << e.what() << std::endl; return -1; }
+}
 // SearchForTriangulationBetweenCameras(pKF, cam1, cam2, ...) (:1158-1263, no caller in the reference): match12[idx1] = idx2 or -1
 extern "C" int rs_tri_between(void* h, int k, int cam1, int cam2, int* match12) {
 	Scene* s = (Scene*)h;

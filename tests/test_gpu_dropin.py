@@ -160,9 +160,24 @@ def _script(so, cams, masks, M_c, voc, params, imgs, poses):
     for c1, c2 in ((0, 1), (2, 0)):
         m12 = np.zeros(n0, np.int32)
         R["tri_between_%d%d" % (c1, c2)] = (S.L.rs_tri_between(S.h, k0, c1, c2, m12.ctypes.data), m12)
-    # the three Fuse overloads with whole lists: keyframe 0's map points into keyframe 1 (Replace / AddObservation surgery), each on the state the one before left
     Scw = np.ascontiguousarray(np.linalg.inv(poses[1]) @ np.diag([1.0, 1.0, 1.0, 1 / 1.01]))
     Scw[:3] *= 1.01
+    # SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) — the loop-closing matcher (cLoopClosing.cpp:401).  The list is kept within camera 0 of the
+    # target (there the reference's row indexing is in bounds, see integration/cORBmatcher_mcs.cpp).  Variant "taken0": feature 0 of the target is
+    # already matched, so the whole search runs in mcs_window_best; variant "free0": feature 0 is free and the `bestIdx > 0` rule of :2386 comes into play.
+    n0c0, n1c0 = int((fr[0]["cam"] == 0).sum()), int((fr[1]["cam"] == 0).sum())
+    n_list = int(min(n1c0, f0[:n0c0].sum()))
+    for name, take0 in (("taken0", True), ("free0", False)):
+        pre = np.full(n1, -1, np.int32)
+        slots = rng.choice(np.arange(1, n1), 40, replace=False)
+        pre[slots] = rng.integers(0, n_list, 40)
+        if take0:
+            pre[0] = n_list - 1
+        ids = np.zeros(n1, np.int32)
+        for th in (10, 4):
+            cnt = S.L.rs_proj_scw(S.h, k1, k0, n_list, Scw.ctypes.data, th, pre.ctypes.data, ids.ctypes.data)
+            R["proj_scw_%s_%d" % (name, th)] = (cnt, ids.copy())
+    # the three Fuse overloads with whole lists: keyframe 0's map points into keyframe 1 (Replace / AddObservation surgery), each on the state the one before left
     for variant, th in ((0, 2.5), (1, 2.5), (2, 4.0), (0, 10.0)):
         idsT, idsS, bad = np.zeros(n1, np.int32), np.zeros(n0, np.int32), np.zeros(n0, np.uint8)
         nf = S.L.rs_fuse(S.h, k1, k0, th, variant, Scw.ctypes.data, idsT.ctypes.data, idsS.ctypes.data, bad.ctypes.data)
@@ -198,7 +213,7 @@ def test_reference_objects_over_the_gpu_matcher(mode, tmp_path):
         for key in ("keys", "desc", "mask", "cam", "rays", "node", "grid_inv", "cell"):
             assert np.array_equal(ref["frames"][f][key], gpu["frames"][f][key]), (f, key)
     floor = dict(kfkf=50, kff0=30, tri0=5, win_60_0_0=20, init_100_0=20, proj_mp=30, proj_last0=20, proj_frames=10, fuse_probes=15)
-    floor.update({"fuse0_2.5": 50, "fuse1_2.5": 5, "fuse2_4": 5, "sim3_1": 5, "tri_between_01": 3})
+    floor.update({"fuse0_2.5": 50, "fuse1_2.5": 5, "fuse2_4": 5, "sim3_1": 5, "tri_between_01": 3, "proj_scw_taken0_10": 30, "proj_scw_free0_10": 30})
     for key in ref:
         if key == "frames":
             continue
