@@ -93,6 +93,21 @@ int mcs_extract_batch(mcs_extractor*, int nimg, const uint8_t* images, size_t im
                       const uint8_t* masks, size_t mask_pitch, int mask_stride, const mcs_ocam* cams, mcs_mem_kind kind,
                       int32_t* nkp, mcs_keypoint* keypoints, uint8_t* desc, uint8_t* descmask, double* rays);
 
+/* dBRIEF / mdBRIEF descriptors are computed in two passes (csrc/mcs_describe.hip): a fast pass whose omni-model arithmetic and pattern
+ * mean differ from the reference's roundings by less than a per-camera bound, used only for keypoints none of whose pattern coordinates lies within
+ * `guard_eps` pixels of a cvRound tie, and the reference's exact arithmetic (rotateAndDistortPattern, src/mdBRIEFextractorOct.cpp:250-283) for the
+ * rest — the outputs are bit-identical either way.
+ *   mcs_extractor_set_describe     exact_only != 0: every keypoint through the exact pass.  guard_eps: half-width of the band (0 = default 2^-24 px);
+ *                                  a camera whose bound exceeds guard_eps / 2 runs exact-only by itself.
+ *   mcs_extractor_describe_stats   keypoints the exact pass has handled since the extractor was created (fast-pass mode), and the band in use
+ *   mcs_describe_fast_bound        the worst-case coordinate difference the library assumes for a camera and descriptor size
+ *   mcs_selftest_describe_fast     n pseudo-random pattern points of camera `cam` through both arithmetics on the device: the largest difference seen
+ *                                  (must stay below mcs_describe_fast_bound)                                                                       */
+int mcs_extractor_set_describe(mcs_extractor*, int exact_only, double guard_eps);
+int mcs_extractor_describe_stats(mcs_extractor*, uint64_t* exact_pass_keypoints, double* guard_eps);
+int mcs_describe_fast_bound(const mcs_ocam* cam, int desc_size, double* bound);
+int mcs_selftest_describe_fast(mcs_ctx*, const mcs_ocam* cam, uint64_t seed, int n, double* max_abs_diff);
+
 /* synchronise and report a device-side capacity overflow of earlier DEVICE-kind batches (MCS_OK if none) */
 int mcs_extractor_status(mcs_extractor*);
 

@@ -141,6 +141,16 @@ class Extractor:
     def status(self):
         check(lib().mcs_extractor_status(self.h))
 
+    def set_describe(self, exact_only=False, guard_eps=0.0):
+        """dBRIEF / mdBRIEF: exact_only routes every keypoint through the reference's exact arithmetic; guard_eps (px, 0 = default) is the band around
+        the cvRound ties inside which the fast pass hands a keypoint to the exact pass.  The outputs are bit-identical in every setting."""
+        check(lib().mcs_extractor_set_describe(self.h, int(exact_only), float(guard_eps)))
+
+    def describe_stats(self):
+        n, eps = C.c_uint64(), C.c_double()
+        check(lib().mcs_extractor_describe_stats(self.h, C.byref(n), C.byref(eps)))
+        return n.value, eps.value
+
     # ---- stage taps (parity tests)
     def tap_level(self, img, level, blurred=False):
         w, h = self.level_sizes[level]

@@ -68,7 +68,8 @@ EXPORTS = [
     "mcs_extractor_tap_level", "mcs_extractor_tap_candidates", "mcs_extractor_tap_selected", "mcs_match_topk",
     "mcs_match_topk_batched", "mcs_descriptor_distance", "mcs_descriptor_distance_masked", "mcs_ctx_enable_timing",
     "mcs_ctx_kernel_ms", "mcs_ctx_join", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_search_kf_f_sweep",
-    "mcs_search_triangulation_sweep", "mcs_rows_valid",
+    "mcs_search_triangulation_sweep", "mcs_rows_valid", "mcs_extractor_set_describe", "mcs_extractor_describe_stats", "mcs_describe_fast_bound",
+    "mcs_selftest_describe_fast",
     "mcs_search_by_projection", "mcs_window_match", "mcs_window_best", "mcs_rotation_consistency", "mcs_world_to_cam", "mcs_distinctive_descriptors", "mcs_selftest_shared_reciprocal", "mcs_vocabulary_create", "mcs_vocabulary_destroy", "mcs_bow_transform",
 ]
 
@@ -116,6 +117,10 @@ def lib():
     L.mcs_extractor_kp_capacity.argtypes = [vp, i32p]
     L.mcs_extractor_levels.argtypes = [vp, i32p, i32p, i32p, i32p]
     L.mcs_extractor_status.argtypes = [vp]
+    L.mcs_extractor_set_describe.argtypes = [vp, C.c_int, C.c_double]
+    L.mcs_extractor_describe_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    L.mcs_describe_fast_bound.argtypes = [C.POINTER(Ocam), C.c_int, C.POINTER(C.c_double)]
+    L.mcs_selftest_describe_fast.argtypes = [vp, C.POINTER(Ocam), C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.mcs_extract_batch.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
     L.mcs_extractor_tap_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     L.mcs_extractor_tap_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, i32p]

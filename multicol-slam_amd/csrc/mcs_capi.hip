@@ -15,12 +15,44 @@
 namespace mcs {
 void upload_describe_tables(const signed char* pattern, const signed char* disc, const int* umax);
 void launch_single_distance(const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out, hipStream_t s);
+void launch_selftest_fast_model(const OcamDev* cam, unsigned long long seed, int n, int width, int height, unsigned long long* maxDiff, hipStream_t s);
 static const signed char kPattern[2048] = {
 #include "learned_pattern_64_orb.inc"
 };
 }  // namespace mcs
 
 using namespace mcs;
+
+// Guard band of the fast descriptor pass: a coordinate closer than this to a rounding tie sends its keypoint to the exact pass.  2^-24 px: ~4 of
+// 10 000 keypoints, and 30-40x above describe_fast_bound() for the Lafida cameras.
+static constexpr double kDefaultGuardEps = 5.9604644775390625e-08;
+
+// Worst-case |(fast coordinate - fast mean) - (reference coordinate - reference mean)| for one camera and npoints pattern points.
+// u = 2^-53.  Both arithmetics evaluate the same real function F(xr, yr) = affine(x/n * rho(atan(p0/n))); each differs from F by its own rounding:
+//   theta   fast: polynomial (4.1e-15, tools/gen_atan_poly.py) + rounding of its argument and of pi/2 - A  <= 1e-14;   reference: atan within 2 ulp, <= 8u
+//   rho     |d rho| <= |d theta| * S' + (roundings of the Horner chain) * u * S,   S = sum |invP_i| (pi/2)^i,  S' = sum i |invP_i| (pi/2)^(i-1)
+//           (fast: 12 FMAs + rho*r + x*g -> 32u S generously; reference: 24 roundings + 2 divisions + 2 products -> 96u S)
+//   u, v    (1 + |c| + |d| + |e|) * d rho  +  8u (|u0| + |v0|)
+//   mean    the same per-point bound, plus the reordering of the sum: sequential (npoints-1) u Umax + tree 13 u Umax, Umax = 16384 + 4096 (enforced by the kernel)
+//   minus   two more roundings of values below 8192
+// Returns +inf for a camera the fast arithmetic cannot serve (p0 = 0, non-finite coefficients).
+static double describe_fast_bound(const mcs_ocam& m, int npoints) {
+	const double u = 1.1102230246251565e-16, hp = 1.5707963267948966;
+	double S = 0, Sp = 0, pw = 1.0;
+	for (int i = 0; i < m.invP_deg; ++i) {
+		if (!std::isfinite(m.invP[i])) return INFINITY;
+		S += std::fabs(m.invP[i]) * pw;
+		if (i + 1 < m.invP_deg) Sp += (i + 1) * std::fabs(m.invP[i + 1]) * pw;
+		pw *= hp;
+	}
+	if (!(std::fabs(m.p[0]) > 1e-300) || !std::isfinite(m.p[0]) || !std::isfinite(1.0 / m.p[0])) return INFINITY;
+	const double aff = 1.0 + std::fabs(m.c) + std::fabs(m.d) + std::fabs(m.e), pp = 8 * u * (std::fabs(m.u0) + std::fabs(m.v0));
+	const double fast = aff * (1e-14 * Sp + 64 * u * S) + pp;
+	const double ref = aff * (8 * u * Sp + 96 * u * S) + pp;
+	const double point = fast + ref;
+	const double total = 2 * point + (npoints + 16) * u * 20480.0 + 4 * u * 8192.0;
+	return std::isfinite(total) ? total : INFINITY;
+}
 
 std::string& mcs_err() { static thread_local std::string e; return e; }
 
@@ -42,6 +74,9 @@ struct mcs_extractor {
 	int *d_cellCount = nullptr, *d_denseCount = nullptr, *d_selCount = nullptr, *d_status = nullptr;
 	OcamDev* d_cams = nullptr;
 	std::vector<OcamDev> h_cams;
+	// descriptor passes (mcs_describe.hip): fallback list of the fast pass, its running total, the guard band
+	int* d_fbCount = nullptr; uint32_t* d_fbList = nullptr; unsigned long long* d_fbStats = nullptr;
+	int describeMode = 0; double guardEps = kDefaultGuardEps;
 	// host-kind input staging: the caller's image / mask block as it lies in host memory (same pitch and stride), grown on demand
 	uint8_t *d_inImg = nullptr, *d_inMask = nullptr; size_t inImgCap = 0, inMaskCap = 0;
 	// host-kind output staging
@@ -306,6 +341,9 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	ALLOC(e->d_selCount, B * nl * sizeof(int));
 	ALLOC(e->d_status, sizeof(int));
 	ALLOC(e->d_cams, B * sizeof(OcamDev));
+	ALLOC(e->d_fbCount, sizeof(int));
+	ALLOC(e->d_fbList, B * (size_t)((hd.selPerImage + 3) / 4 * 4) * sizeof(uint32_t));
+	ALLOC(e->d_fbStats, sizeof(unsigned long long));
 	ALLOC(e->d_nkp, B * sizeof(int));
 	ALLOC(e->d_kps, B * hd.kpCap * sizeof(mcs_keypoint));
 	ALLOC(e->d_odesc, B * hd.kpCap * (size_t)hd.descSize);
@@ -317,6 +355,9 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	if (!taps.empty()) HIPCHK(hipMemcpy(e->d_taps, taps.data(), sizeof(ResizeTap) * taps.size(), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(e->d_maskMap, maps.data(), sizeof(short) * maps.size(), hipMemcpyHostToDevice));
 	HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
+	HIPCHK(hipMemset(e->d_fbCount, 0, sizeof(int)));
+	HIPCHK(hipMemset(e->d_fbStats, 0, sizeof(unsigned long long)));
+	if (getenv("MCS_DESCRIBE_EXACT")) e->describeMode = 1;   // A/B and debugging: the exact pass for every keypoint
 	HIPCHK(hipMemset(e->d_pyr, 0, B * hd.pyrBytes));
 	HIPCHK(hipMemset(e->d_blur, 0, B * hd.pyrBytes));
 	ctx->extractors.push_back(e);
@@ -334,7 +375,7 @@ int mcs_extractor_destroy(mcs_extractor* e) {
 	}
 	void* ptrs[] = {e->d_desc, e->d_cells, e->d_taps, e->d_maskMap, e->d_pyr, e->d_blur, e->d_slots, e->d_dense, e->d_knode,
 	                e->d_sel, e->d_cellCount, e->d_denseCount, e->d_selCount, e->d_status, e->d_cams, e->d_nkp, e->d_kps, e->d_odesc,
-	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask};
+	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_fbStats};
 	for (void* p : ptrs) (void)hipFree(p);
 	delete e;
 	return MCS_OK;
@@ -383,6 +424,7 @@ int mcs_extract_batch(mcs_extractor* e, int nimg, const uint8_t* images, size_t 
 	b.desc = e->d_desc; b.cells = e->d_cells; b.taps = e->d_taps; b.maskMap = e->d_maskMap;
 	b.pyr = e->d_pyr; b.blur = e->d_blur; b.slots = e->d_slots; b.cellCount = e->d_cellCount; b.dense = e->d_dense; b.knode = e->d_knode;
 	b.denseCount = e->d_denseCount; b.sel = e->d_sel; b.selCount = e->d_selCount; b.status = e->d_status;
+	b.fbCount = e->d_fbCount; b.fbList = e->d_fbList; b.fbStats = e->d_fbStats; b.guardEps = e->guardEps; b.describeMode = e->describeMode;
 	if (kind == MCS_MEM_HOST) {
 		// ONE linear copy per block, in the caller's own layout; the kernels take any pitch / stride for level 0.  (A pitched hipMemcpy2D from pageable
 		// host memory is carried out row by row by the runtime: 2 x 480 small transfers per image, ~9 ms per image.)
@@ -413,6 +455,9 @@ int mcs_extract_batch(mcs_extractor* e, int nimg, const uint8_t* images, size_t 
 			for (int k = 0; k < m.p_deg; ++k) o.p[k] = m.p[k];
 			for (int k = 0; k < m.invP_deg; ++k) o.invP[k] = m.invP[k];
 			o.p_deg = m.p_deg; o.invP_deg = m.invP_deg;
+			const double bound = describe_fast_bound(m, hd.npoints);
+			o.fastOk = bound <= 0.5 * e->guardEps ? 1 : 0;   // a factor 2 between the worst case and the band
+			o.invP0 = o.fastOk ? 1.0 / m.p[0] : 0.0;
 		}
 		if (e->h_cams.size() != hc.size() || memcmp(e->h_cams.data(), hc.data(), sizeof(OcamDev) * hc.size()) != 0) {
 			HIPCHK(hipStreamSynchronize(s));   // the previous batch may still read d_cams
@@ -459,6 +504,56 @@ int mcs_extractor_status(mcs_extractor* e) {
 	HIPCHK(hipStreamSynchronize(e->ctx->stream));
 	HIPCHK(hipMemcpy(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
 	if (st != 0) { (void)hipMemset(e->d_status, 0, sizeof(int)); return fail(st, "device capacity exceeded during extraction"); }
+	return MCS_OK;
+}
+
+int mcs_extractor_set_describe(mcs_extractor* e, int exact_only, double guard_eps) {
+	if (!e) return fail(MCS_ERR_INVALID, "null");
+	if (guard_eps < 0.0 || !(guard_eps < 0.5)) return fail(MCS_ERR_INVALID, "guard band must be in [0, 0.5) pixels (0 = default)");
+	HIPCHK(hipStreamSynchronize(e->ctx->stream));
+	e->describeMode = exact_only ? 1 : 0;
+	e->guardEps = guard_eps > 0.0 ? guard_eps : kDefaultGuardEps;
+	e->h_cams.clear();   // fastOk depends on the band: rebuild the device camera table on the next batch
+	return MCS_OK;
+}
+
+int mcs_extractor_describe_stats(mcs_extractor* e, uint64_t* exact_pass_keypoints, double* guard_eps) {
+	if (!e) return fail(MCS_ERR_INVALID, "null");
+	HIPCHK(hipStreamSynchronize(e->ctx->stream));
+	unsigned long long v = 0;
+	HIPCHK(hipMemcpy(&v, e->d_fbStats, sizeof(v), hipMemcpyDeviceToHost));
+	if (exact_pass_keypoints) *exact_pass_keypoints = v;
+	if (guard_eps) *guard_eps = e->guardEps;
+	return MCS_OK;
+}
+
+int mcs_describe_fast_bound(const mcs_ocam* cam, int desc_size, double* bound) {
+	if (!cam || !bound || cam->invP_deg < 1 || cam->invP_deg > MCS_MAX_POLY || cam->p_deg < 1) return fail(MCS_ERR_INVALID, "bad argument");
+	*bound = describe_fast_bound(*cam, 2 * 8 * desc_size);
+	return MCS_OK;
+}
+
+int mcs_selftest_describe_fast(mcs_ctx* c, const mcs_ocam* cam, uint64_t seed, int n, double* max_abs_diff) {
+	if (!c || !cam || !max_abs_diff || n < 1) return fail(MCS_ERR_INVALID, "bad argument");
+	if (cam->p_deg < 1 || cam->p_deg > MCS_MAX_POLY || cam->invP_deg < 1 || cam->invP_deg > MCS_MAX_POLY) return fail(MCS_ERR_INVALID, "bad polynomial degree");
+	HIPCHK(hipSetDevice(c->device));
+	OcamDev o;
+	memset(&o, 0, sizeof(o));
+	o.c = cam->c; o.d = cam->d; o.e = cam->e; o.u0 = cam->u0; o.v0 = cam->v0; o.invAffine = cam->c - cam->d * cam->e;
+	for (int k = 0; k < cam->p_deg; ++k) o.p[k] = cam->p[k];
+	for (int k = 0; k < cam->invP_deg; ++k) o.invP[k] = cam->invP[k];
+	o.p_deg = cam->p_deg; o.invP_deg = cam->invP_deg; o.invP0 = 1.0 / cam->p[0]; o.fastOk = 1;
+	uint8_t* buf = nullptr;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(ctx_arena(c, sizeof(OcamDev) + 64, &buf));
+	unsigned long long zero = 0, got = 0;
+	HIPCHK(hipMemcpy(buf, &zero, sizeof(zero), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(buf + 64, &o, sizeof(o), hipMemcpyHostToDevice));
+	launch_selftest_fast_model((const OcamDev*)(buf + 64), seed, n, cam->width, cam->height, (unsigned long long*)buf, c->stream);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipMemcpy(&got, buf, sizeof(got), hipMemcpyDeviceToHost));
+	memcpy(max_abs_diff, &got, sizeof(double));
 	return MCS_OK;
 }
 

@@ -61,6 +61,9 @@ struct OcamDev {
 	double p[MCS_MAX_POLY];
 	double invP[MCS_MAX_POLY];
 	int p_deg, invP_deg;
+	// fast pass of the descriptor kernel (mcs_describe.hip): 1 / p[0], and whether this camera's worst-case arithmetic difference stays below the guard band
+	double invP0;
+	int fastOk, pad_;
 };
 
 struct ExtractBuffers {
@@ -81,6 +84,11 @@ struct ExtractBuffers {
 	int* selCount;                // [B][nlevels]
 	const OcamDev* cams;          // [B] or nullptr
 	int* status;                  // device error word (capacity overflows)
+	// dBRIEF / mdBRIEF: fast pass + exact pass over the fast pass's fallback list (mcs_describe.hip)
+	int* fbCount; uint32_t* fbList;      // keypoint slots (image * wavesPerImage + slot) the fast pass handed to the exact pass, this batch
+	unsigned long long* fbStats;         // running total of those (all batches of the extractor)
+	double guardEps;                     // half-width of the guard band around the rounding ties
+	int describeMode;                    // 0 fast + exact fallback, 1 exact pass for every keypoint
 	// outputs
 	int* nkp; mcs_keypoint* kps; uint8_t* out_desc; uint8_t* out_mask; double* rays;
 };

@@ -18,7 +18,21 @@
 // Samples inside the level come from the blurred pyramid, samples in the 25-px frame from the unblurred level with
 // reflect-101 indices (the reference's frame is filled before the in-place blur), beyond the frame: clamped.
 // Compiled with -ffp-contract=off: no FMA contraction anywhere, like the oracle.
+//
+// dBRIEF / mdBRIEF run in TWO passes:
+//   k_describe_fast   every keypoint.  The 2*8*descSize*npat omni-model evaluations use a cheaper arithmetic (explicit FMAs, rsqrt + one cubic refinement
+//                     instead of sqrt + three divisions, a 17-term odd polynomial for atan) and the pattern mean is a wave tree sum instead of the
+//                     reference's sequential chain.  The results differ from the reference's by at most a bound delta known per camera (host,
+//                     mcs_capi.hip: describe_fast_bound) — far below half a pixel, but cvRound(coordinate - mean) only agrees for sure when no
+//                     coordinate lies within delta of a rounding tie.  Every coordinate is therefore checked against a guard band eps >= delta around
+//                     the ties (|frac - 0.5| < eps); a keypoint with ANY coordinate inside the band (or out of range / NaN) is not written, its slot
+//                     goes onto the fallback list.
+//   k_describe_list   the keypoints of the fallback list through describe_wave — the reference's exact arithmetic (below, unchanged), a few per 10^4.
+// Integer pixel offsets that pass the guard are PROVABLY the reference's, so the descriptors stay bit-identical; mcs_extractor_set_describe() can force
+// the exact pass for everything or widen the band (tests/test_gpu_describe_guard.py runs both against the oracle).
 #include "mcs_common.h"
+
+#include <algorithm>
 
 namespace mcs {
 
@@ -192,11 +206,18 @@ struct Sampler {
 __host__ __device__ constexpr int pat_doubles(int npoints) { return 2 * npoints + 2; }
 __host__ __device__ constexpr int coord_bytes(int mode, int npoints) { return mode == 0 ? 0 : (mode == 2 && MCS_MERGE_CHAINS ? 3 : 1) * pat_doubles(npoints) * 8; }
 
-template <int MODE, int NB>   // MODE 0 ORB, 1 dBRIEF, 2 mdBRIEF; NB = descSize/8 ballots.  lds: MODE > 0: [waves][x|y][npoints] coordinates + patch
-__device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int wavesPerImage, double* lds) {
+// Everything a keypoint needs before its descriptor: slot -> (level, position), the output row, the blurred patch in LDS, orientation (E5), the
+// keypoint record and ray (E8/E9).  Shared by the exact pass (describe_wave) and the fast pass (k_describe_fast); false = this wave has no keypoint.
+struct KeyPt {
+	int img, out, level, row, col;
+	float angle;
+	double rayx, rayy, rayz;
+	Sampler sm;
+};
+template <bool NEED_RAY>   // the ray is also computed when the caller asked for rays
+__device__ __forceinline__ bool kp_prologue(const ExtractBuffers& b, int wavesPerImage, int gw, uint8_t* patch, KeyPt& kp_) {
 	const PyrDesc& d = *b.desc;
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int gw = blockIdx.x * (MODE == 0 ? 4 : 1) + wave;
+	const int lane = threadIdx.x & 63;
 	const int img = gw / wavesPerImage;
 	const int s = gw - img * wavesPerImage;
 	const int* selCount = b.selCount + (size_t)img * d.nlevels;
@@ -211,14 +232,13 @@ __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int waves
 	bool active = level >= 0 && s < d.selPerImage && pos < selCount[level >= 0 ? level : 0];
 	const int out = before + pos;
 	if (active && out >= d.kpCap) { if (lane == 0) atomicExch(b.status, MCS_ERR_CAPACITY); active = false; }
-	if (!active) return;   // waves are independent (no block barriers anywhere in this kernel)
+	if (!active) return false;   // waves are independent (no block barriers anywhere in these kernels)
 
-	constexpr int nballots = NB;
 	float angle = 0.f, pxf = 0.f, pyf = 0.f;
 	double rayx = 0.0, rayy = 0.0, rayz = 0.0;
 	int row = 0, col = 0;
 	Sampler sm = {};
-	if (active) {
+	{
 		const LevelInfo& L = d.lv[level];
 		const uint32_t rec = b.sel[(size_t)img * d.selPerImage + L.selBase + pos];
 		col = (int)(rec & 0xFFF) + kMinBorder;
@@ -229,8 +249,6 @@ __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int waves
 		sm.blur = b.blur + (size_t)img * d.pyrBytes + L.off; sm.bstride = L.stride;
 		sm.raw = raw; sm.rstride = rstride; sm.w = L.w; sm.h = L.h;
 		{   // stage the blurred (2R+1)^2 neighbourhood (kPatchDw unaligned dwords per row, rows are in-pitch even at the right edge)
-			constexpr int kWaveLds = coord_bytes(MODE, 128 * NB) + kPatchBytes;
-			uint8_t* patch = reinterpret_cast<uint8_t*>(lds) + (size_t)wave * kWaveLds + coord_bytes(MODE, 128 * NB);
 			const uint8_t* bp = sm.blur + (size_t)(row - kPatchR) * sm.bstride + (col - kPatchR);
 			for (int i = lane; i < kPatchRows * kPatchDw; i += 64) {
 				const int r = i / kPatchDw, k = i - r * kPatchDw;
@@ -268,7 +286,7 @@ __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int waves
 		pxf = (float)col; pyf = (float)row;
 		if (level != 0) { pxf = pxf * L.scale; pyf = pyf * L.scale; }
 		// ImgToWorld of the keypoint: the ray of src/cMultiFrame.cpp:146-152 AND the input of undistortPointsOcam (:1306-1317)
-		if (b.cams && (b.rays || MODE != 0)) img2world(b.cams[img], (double)pxf, (double)pyf, rayx, rayy, rayz);
+		if (b.cams && (b.rays || NEED_RAY)) img2world(b.cams[img], (double)pxf, (double)pyf, rayx, rayy, rayz);
 		if (lane == 0) {
 			mcs_keypoint kp;
 			kp.x = pxf; kp.y = pyf; kp.size = L.kpSize; kp.angle = angle; kp.response = resp; kp.octave = level; kp.class_id = -1;
@@ -279,6 +297,24 @@ __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int waves
 			}
 		}
 	}
+	kp_.img = img; kp_.out = out; kp_.level = level; kp_.row = row; kp_.col = col; kp_.angle = angle;
+	kp_.rayx = rayx; kp_.rayy = rayy; kp_.rayz = rayz; kp_.sm = sm;
+	return true;
+}
+
+template <int MODE, int NB>   // MODE 0 ORB, 1 dBRIEF, 2 mdBRIEF; NB = descSize/8 ballots.  lds: MODE > 0: [waves][x|y][npoints] coordinates + patch
+__device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int wavesPerImage, double* lds, int gw) {   // gw = image * wavesPerImage + slot
+	const PyrDesc& d = *b.desc;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	constexpr int kWaveLds = coord_bytes(MODE, 128 * NB) + kPatchBytes;
+	KeyPt kp_;
+	if (!kp_prologue<MODE != 0>(b, wavesPerImage, gw, reinterpret_cast<uint8_t*>(lds) + (size_t)wave * kWaveLds + coord_bytes(MODE, 128 * NB), kp_)) return;
+	const bool active = true;
+	const int img = kp_.img, out = kp_.out, row = kp_.row, col = kp_.col;
+	const float angle = kp_.angle;
+	const double rayx = kp_.rayx, rayy = kp_.rayy, rayz = kp_.rayz;
+	const Sampler sm = kp_.sm;
+	constexpr int nballots = NB;
 	uint8_t* dout = b.out_desc + ((size_t)img * d.kpCap + out) * d.descSize;
 	uint8_t* mout = b.out_mask + ((size_t)img * d.kpCap + out) * d.descSize;
 
@@ -453,22 +489,241 @@ template <int MODE, int NB>
 __attribute__((amdgpu_waves_per_eu(4, 4)))
 __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe(ExtractBuffers b, int wavesPerImage) {
 	extern __shared__ __attribute__((aligned(16))) double lds[];
-	describe_wave<MODE, NB>(b, wavesPerImage, lds);
+	describe_wave<MODE, NB>(b, wavesPerImage, lds, blockIdx.x * (MODE == 0 ? 4 : 1) + (threadIdx.x >> 6));
 }
 template <int MODE, int NB>
 __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe_wide(ExtractBuffers b, int wavesPerImage) {
 	extern __shared__ __attribute__((aligned(16))) double lds[];
-	describe_wave<MODE, NB>(b, wavesPerImage, lds);
+	describe_wave<MODE, NB>(b, wavesPerImage, lds, blockIdx.x * (MODE == 0 ? 4 : 1) + (threadIdx.x >> 6));
+}
+
+// The exact pass over the fallback list of the fast pass (one wave per block, blocks stride over the list; the list is empty most of the time).
+template <int MODE, int NB>
+__global__ __launch_bounds__(64) void k_describe_list(ExtractBuffers b, int wavesPerImage) {
+	extern __shared__ __attribute__((aligned(16))) double lds[];
+	const int n = *b.fbCount;
+	if (blockIdx.x == 0 && threadIdx.x == 0 && b.fbStats) atomicAdd(b.fbStats, (unsigned long long)n);
+	for (int i = blockIdx.x; i < n; i += gridDim.x) describe_wave<MODE, NB>(b, wavesPerImage, lds, (int)b.fbList[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The fast pass.  Same keypoint prologue, same pattern rotation angles (one sincos call serves the three pattern angles: lanes 0..2), then per
+// pattern point
+//      xr, yr   = rotation + undistorted keypoint                     (FMA form)
+//      r        = 1 / sqrt(xr^2 + yr^2)                               v_rsq_f64 (>= 2^-23 accurate... whatever its accuracy e0, the cubic step leaves ~e0^3)
+//      theta    = atan(p0 / norm)  as  copysign(pi/2, p0) - A(norm / p0)  for norm < |p0|,  A(p0 / norm) otherwise;  A(a) = a * Q(a^2), |a| <= 1
+//      rho      = Horner(invP, theta)                                 (FMA form)
+//      u, v     = affine(xr * rho / norm, yr * rho / norm)
+// and a wave tree sum for the mean.  None of this is the reference's rounding; it is only USED when every one of the keypoint's
+// 2 * npat * 2*8*descSize coordinates (minus the mean) stays clear of the rounding ties by more than the guard band b.guardEps, which the host keeps
+// above the worst-case difference between this arithmetic and the reference's (describe_fast_bound in mcs_capi.hip).  Otherwise the
+// keypoint goes to the exact pass.  NaN / Inf (norm = 0) fail the comparisons and take the same way out.
+#ifndef MCS_FAST_FENCE
+#define MCS_FAST_FENCE 4
+#endif
+static __device__ constexpr double kAtanQ[17] = {
+#include "mcs_atan_poly.inc"
+};
+constexpr double kHalfPi = 0x1.921fb54442d18p+0;
+constexpr int kAtanN = 17;
+constexpr int kFastWaves = 4;   // independent waves (keypoints) per workgroup of the fast pass
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+	return v;
+}
+
+// one pattern point through the fast arithmetic
+struct FastCam { double cP[MCS_MAX_POLY]; int deg; double c, d, e, u0, v0, p0, invP0, hp; };
+__device__ __forceinline__ void fast_w2i(const FastCam& C, double xr, double yr, double& u, double& v) {
+	const double n2 = __builtin_fma(xr, xr, yr * yr);
+	const double r0 = __builtin_amdgcn_rsq(n2);
+	const double e1 = __builtin_fma(-(n2 * r0), r0, 1.0);                          // 1 - n2 * r0^2
+	const double r = __builtin_fma(r0 * e1, __builtin_fma(e1, 0.375, 0.5), r0);     // r0 * (1 + e/2 + 3e^2/8)
+	const double norm = n2 * r;
+	const double w = norm * C.invP0, t = C.p0 * r;
+	const bool small = fabs(w) < 1.0;
+	const double a = small ? w : t;
+	const double s2 = a * a;
+	double q = kAtanQ[kAtanN - 1];
+#pragma unroll
+	for (int i = kAtanN - 2; i >= 0; --i) q = __builtin_fma(q, s2, kAtanQ[i]);
+	const double A = a * q;
+	const double theta = small ? C.hp - A : A;
+	double rho;
+	if (C.deg == 12) {
+		rho = C.cP[11];
+#pragma unroll
+		for (int i = 10; i >= 0; --i) rho = __builtin_fma(rho, theta, C.cP[i]);
+	} else {
+		rho = C.cP[MCS_MAX_POLY - 1];
+#pragma unroll
+		for (int i = MCS_MAX_POLY - 2; i >= 0; --i) rho = __builtin_fma(rho, theta, C.cP[i]);
+	}
+	const double g = rho * r;
+	const double uu = xr * g, vv = yr * g;
+	u = __builtin_fma(uu, C.c, __builtin_fma(vv, C.d, C.u0));
+	v = __builtin_fma(uu, C.e, vv + C.v0);
+}
+
+#ifndef MCS_FAST_WAVES_PER_EU
+#define MCS_FAST_WAVES_PER_EU 4
+#endif
+template <int MODE, int NB>
+__attribute__((amdgpu_waves_per_eu(MCS_FAST_WAVES_PER_EU, MCS_FAST_WAVES_PER_EU)))
+__global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffers b, int wavesPerImage) {
+	extern __shared__ __attribute__((aligned(16))) double lds[];   // the blurred patch of each wave's keypoint
+	static_assert(MODE == 1 || MODE == 2, "the fast pass is for the distorted patterns");
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int gw = blockIdx.x * kFastWaves + wave;
+	KeyPt kp_;
+	if (!kp_prologue<true>(b, wavesPerImage, gw, reinterpret_cast<uint8_t*>(lds) + (size_t)wave * kPatchBytes, kp_)) return;
+	const PyrDesc& d = *b.desc;
+	const OcamDev& cam = b.cams[kp_.img];
+	auto to_exact = [&]() { if (lane == 0) { const int at = atomicAdd(b.fbCount, 1); b.fbList[at] = (uint32_t)gw; } };
+	if (__builtin_amdgcn_readfirstlane(cam.fastOk) == 0) { to_exact(); return; }
+
+	FastCam C;
+#pragma unroll
+	for (int i = 0; i < MCS_MAX_POLY; ++i) C.cP[i] = uniform_f64(&cam.invP[i]);
+	C.deg = __builtin_amdgcn_readfirstlane(cam.invP_deg);
+	C.c = uniform_f64(&cam.c); C.d = uniform_f64(&cam.d); C.e = uniform_f64(&cam.e); C.u0 = uniform_f64(&cam.u0); C.v0 = uniform_f64(&cam.v0);
+	C.p0 = uniform_f64(&cam.p[0]); C.invP0 = uniform_f64(&cam.invP0);
+	C.hp = C.p0 < 0.0 ? -kHalfPi : kHalfPi;
+
+	constexpr int NP = 128 * NB;
+	uint32_t ppk[NB];
+#pragma unroll
+	for (int j = 0; j < NB; ++j) ppk[j] = reinterpret_cast<const uint32_t*>(c_pattern)[j * 64 + lane];
+	// the undistorted keypoint and the pattern angles: the SAME operations as the exact pass (they feed both)
+	double ukx = 0.0, uky = 0.0;
+	if (d.undistort) {
+		ukx = -kp_.rayx / kp_.rayz * C.p0;
+		uky = -kp_.rayy / kp_.rayz * C.p0;
+	}
+	double ang0, ang1 = 0.0, ang2 = 0.0;
+	if (MODE == 1) {
+		const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
+		ang0 = (double)(kp_.angle * DEG2RADf);
+	} else {
+		const float RHOf = 180.0f / 3.1415926535897932384626f;
+		const double RHOd = 180.0 / 3.1415926535897932384626433832795028841971693993;
+		const double rot = 20.0 / RHOd;
+		ang0 = (double)(kp_.angle / RHOf);
+		ang1 = ang0 + rot; ang2 = ang0 - rot;
+	}
+	double sinA, cosA;
+	sincos(lane == 1 ? ang1 : (lane == 2 ? ang2 : ang0), &sinA, &cosA);   // the same ocml kernels as the exact pass: bit-identical ax / ay
+
+	const double lim = 0.5 - b.guardEps;
+	const int row = kp_.row, col = kp_.col;
+	const Sampler sm = kp_.sm;
+	unsigned long long bitsMain[NB], agree[NB];
+#pragma unroll
+	for (int j = 0; j < NB; ++j) { bitsMain[j] = 0ull; agree[j] = ~0ull; }
+	constexpr int npat = MODE == 2 ? 3 : 1;
+#pragma unroll
+	for (int pat = 0; pat < npat; ++pat) {
+		const double ax = __shfl(cosA, pat), ay = __shfl(sinA, pat);
+		double u[2 * NB], v[2 * NB];
+		double sumx = 0.0, sumy = 0.0;
+#pragma unroll
+		for (int t = 0; t < 2 * NB; ++t) {
+			const int e = t & 1;
+			const double ptx = (double)(int)(signed char)(ppk[t >> 1] >> (16 * e)), pty = (double)(int)(signed char)(ppk[t >> 1] >> (16 * e + 8));
+			const double xr = __builtin_fma(ptx, ax, __builtin_fma(-pty, ay, ukx));
+			const double yr = __builtin_fma(ptx, ay, __builtin_fma(pty, ax, uky));
+			fast_w2i(C, xr, yr, u[t], v[t]);
+			sumx += u[t]; sumy += v[t];
+			if ((t & (MCS_FAST_FENCE - 1)) == MCS_FAST_FENCE - 1) __builtin_amdgcn_sched_barrier(0);   // at most MCS_FAST_FENCE point evaluations in flight (registers)
+		}
+		const double meanX = wave_sum_f64(sumx) * (1.0 / (double)NP), meanY = wave_sum_f64(sumy) * (1.0 / (double)NP);
+		bool bad = !(fabs(meanX) < 16384.0) || !(fabs(meanY) < 16384.0);
+		int ix[2 * NB], iy[2 * NB];
+#pragma unroll
+		for (int t = 0; t < 2 * NB; ++t) {
+			const double dx = u[t] - meanX, dy = v[t] - meanY;
+			const double rx = __builtin_rint(dx), ry = __builtin_rint(dy);
+			bad |= !(fabs(dx - rx) < lim) || !(fabs(dy - ry) < lim);   // inside the guard band of a rounding tie (or NaN)
+			ix[t] = (int)rx; iy[t] = (int)ry;
+			bad |= (unsigned)(ix[t] + 4096) >= 8192u || (unsigned)(iy[t] + 4096) >= 8192u;
+		}
+		if (__any(bad)) { to_exact(); return; }
+#pragma unroll
+		for (int j = 0; j < NB; ++j) {
+			int t0, t1;
+			sm.pair(row, col, iy[2 * j], ix[2 * j], iy[2 * j + 1], ix[2 * j + 1], t0, t1);
+			const unsigned long long bits = __ballot(t0 < t1);
+			if (pat == 0) bitsMain[j] = bits;
+			else agree[j] &= ~(bits ^ bitsMain[j]);
+		}
+	}
+	if (lane == 0) {
+		uint8_t* dout = b.out_desc + ((size_t)kp_.img * d.kpCap + kp_.out) * d.descSize;
+		uint8_t* mout = b.out_mask + ((size_t)kp_.img * d.kpCap + kp_.out) * d.descSize;
+#pragma unroll
+		for (int j = 0; j < NB; ++j) {
+			*reinterpret_cast<unsigned long long*>(dout + 8 * j) = bitsMain[j];
+			*reinterpret_cast<unsigned long long*>(mout + 8 * j) = MODE == 2 ? agree[j] : 0ull;
+		}
+	}
+}
+
+// self-test of the fast arithmetic: n pseudo-random pattern points around random keypoints of camera `cam` through fast_w2i and through the exact
+// world2img; maxDiff[0] = the largest |u_fast - u_exact| or |v_fast - v_exact| seen (as the bits of a non-negative double, atomicMax)
+__global__ void k_selftest_fast_model(const OcamDev* camp, unsigned long long seed, int n, int width, int height, unsigned long long* maxDiff) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const OcamDev& cam = *camp;
+	unsigned long long st = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+	auto next = [&]() { st ^= st >> 12; st ^= st << 25; st ^= st >> 27; return st * 0x2545F4914F6CDD1Dull; };
+	auto unit = [&]() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); };
+	// a keypoint somewhere in the image, undistorted like the kernel does, plus a pattern offset of up to +-32 px
+	const double px = unit() * width, py = unit() * height;
+	double rx, ry, rz;
+	img2world(cam, px, py, rx, ry, rz);
+	const double p0 = cam.p[0];
+	const double xr = -rx / rz * p0 + (unit() * 64.0 - 32.0), yr = -ry / rz * p0 + (unit() * 64.0 - 32.0);
+	double ue, ve;
+	world2img(cam, xr, yr, -p0, ue, ve);
+	FastCam C;
+	for (int k = 0; k < MCS_MAX_POLY; ++k) C.cP[k] = cam.invP[k];
+	C.deg = cam.invP_deg; C.c = cam.c; C.d = cam.d; C.e = cam.e; C.u0 = cam.u0; C.v0 = cam.v0; C.p0 = p0; C.invP0 = cam.invP0;
+	C.hp = p0 < 0.0 ? -kHalfPi : kHalfPi;
+	double uf, vf;
+	fast_w2i(C, xr, yr, uf, vf);
+	double diff = fmax(fabs(uf - ue), fabs(vf - ve));
+	if (!(diff == diff)) diff = 1e300;   // NaN on either side counts as a failure unless both are non-finite for the same reason (norm = 0 cannot occur here)
+	atomicMax(maxDiff, (unsigned long long)__double_as_longlong(diff));
+}
+
+void launch_selftest_fast_model(const OcamDev* cam, unsigned long long seed, int n, int width, int height, unsigned long long* maxDiff, hipStream_t s) {
+	hipLaunchKernelGGL(k_selftest_fast_model, dim3((n + 255) / 256), dim3(256), 0, s, cam, seed, n, width, height, maxDiff);
 }
 
 template <int MODE>
 static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
-	// ORB: 4 keypoints (waves) per 256-thread block.  dBRIEF/mdBRIEF: one wave per block with a private 2*NB KiB LDS slice.
+	// ORB: 4 keypoints (waves) per 256-thread block.  dBRIEF/mdBRIEF exact pass: one wave per block with a private 2*NB KiB LDS slice.
 	const int wpb = MODE == 0 ? 4 : 1;
-	const int wavesPerImage = (hd.selPerImage + wpb - 1) / wpb * wpb;
+	const int wavesPerImage = (hd.selPerImage + 3) / 4 * 4;   // a multiple of 4 in every mode: the fast pass packs 4 waves per block
 	const int blocks = nimg * wavesPerImage / wpb;
 	const size_t ldsBytes = (size_t)wpb * (coord_bytes(MODE, hd.npoints) + kPatchBytes);   // coordinates + blurred patch per wave
 	const int nb = hd.descSize / 8;
+	if constexpr (MODE != 0) {
+		if (b.describeMode == 0) {   // fast pass + exact pass over its fallback list
+			const int fblocks = nimg * wavesPerImage / kFastWaves, lblocks = std::min(blocks, 2048);
+			const size_t fLds = (size_t)kFastWaves * kPatchBytes;
+			(void)hipMemsetAsync(b.fbCount, 0, sizeof(int), s);
+			if (nb == 2) { hipLaunchKernelGGL((k_describe_fast<MODE, 2>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage);
+			               hipLaunchKernelGGL((k_describe_list<MODE, 2>), dim3(lblocks), dim3(64), ldsBytes, s, b, wavesPerImage); }
+			else if (nb == 4) { hipLaunchKernelGGL((k_describe_fast<MODE, 4>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage);
+			                    hipLaunchKernelGGL((k_describe_list<MODE, 4>), dim3(lblocks), dim3(64), ldsBytes, s, b, wavesPerImage); }
+			else { hipLaunchKernelGGL((k_describe_fast<MODE, 8>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage);
+			       hipLaunchKernelGGL((k_describe_list<MODE, 8>), dim3(lblocks), dim3(64), ldsBytes, s, b, wavesPerImage); }
+			return;
+		}
+	}
 	if (nb == 2) hipLaunchKernelGGL((k_describe<MODE, 2>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 	else if (nb == 4) hipLaunchKernelGGL((k_describe<MODE, 4>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 	else if constexpr (MODE == 2) hipLaunchKernelGGL((k_describe_wide<MODE, 8>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);

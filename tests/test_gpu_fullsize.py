@@ -32,8 +32,11 @@ def batch(G):
     parts = []
     for b0 in range(0, NF * NCAM, 48):
         parts += ex.extract_host(imgs[b0:b0 + 48], (masks * NF)[b0:b0 + 48], (oc * NF)[b0:b0 + 48])
+    fallbacks = ex.describe_stats()[0]
+    ex.set_describe(exact_only=True)     # every keypoint through the reference's exact descriptor arithmetic (no fast pass)
+    exact = ex.extract_host(imgs, masks * NF, oc * NF)
     ex.close()
-    return dict(cams=cams, masks=masks, imgs=imgs, full=full, parts=parts)
+    return dict(cams=cams, masks=masks, imgs=imgs, full=full, parts=parts, exact=exact, fallbacks=fallbacks)
 
 
 def digest(res):
@@ -48,6 +51,9 @@ def test_batch_invariance_and_oracle_sample(G, batch):
     full, parts = batch["full"], batch["parts"]
     assert len(full) == NF * NCAM and sum(len(r[0]) for r in full) > 180000
     assert digest(full) == digest(parts)
+    # ~2.9e8 pattern points: the guarded fast descriptor pass and the exact pass agree in every bit, and the exact pass is the rare exception
+    assert digest(full) == digest(batch["exact"])
+    assert 0 < batch["fallbacks"] < 0.005 * 2 * sum(len(r[0]) for r in full), batch["fallbacks"]
     for i in (0, 95, 191):
         cam = batch["cams"][i % NCAM]
         _, kps, d, dm, rays = G.oracle_extract(batch["imgs"][i], batch["masks"][i % NCAM], cam, do_dBrief=1, learnMasks=1)
