@@ -342,7 +342,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	ALLOC(e->d_status, sizeof(int));
 	ALLOC(e->d_cams, B * sizeof(OcamDev));
 	ALLOC(e->d_fbCount, sizeof(int));
-	ALLOC(e->d_fbList, B * (size_t)((hd.selPerImage + 3) / 4 * 4) * sizeof(uint32_t));
+	ALLOC(e->d_fbList, B * (size_t)((hd.kpCap + 3) / 4 * 4) * sizeof(uint32_t));
 	ALLOC(e->d_fbStats, sizeof(unsigned long long));
 	ALLOC(e->d_nkp, B * sizeof(int));
 	ALLOC(e->d_kps, B * hd.kpCap * sizeof(mcs_keypoint));

@@ -218,20 +218,27 @@ template <bool NEED_RAY>   // the ray is also computed when the caller asked for
 __device__ __forceinline__ bool kp_prologue(const ExtractBuffers& b, int wavesPerImage, int gw, uint8_t* patch, KeyPt& kp_) {
 	const PyrDesc& d = *b.desc;
 	const int lane = threadIdx.x & 63;
+	// the slot is the same for the whole wave: say so (v_readfirstlane), and everything addressed through it — level table, selection counts, the
+	// keypoint record, the camera model — is read with scalar loads into SGPRs instead of 64 identical vector loads
+	gw = __builtin_amdgcn_readfirstlane(gw);
 	const int img = gw / wavesPerImage;
 	const int s = gw - img * wavesPerImage;
 	const int* selCount = b.selCount + (size_t)img * d.nlevels;
 
+	// slot s = the keypoint's row in the image's output block: levels in order, a level's keys in their final list order.  (Slots used to follow the
+	// per-level capacity ranges of b.sel; the ~16 % of empty slots between the levels returned at once and left their SIMD share idle until the rest of
+	// the workgroup was done.)
 	int total = 0, before = 0, level = -1, pos = 0;
 	for (int l = 0; l < d.nlevels; ++l) {
 		const int c = selCount[l];
-		if (s >= d.lv[l].selBase && s < d.lv[l].selBase + d.lv[l].selCap) { level = l; pos = s - d.lv[l].selBase; before = total; }
+		if (s >= total && s < total + c) { level = l; pos = s - total; before = total; }
 		total += c;
 	}
 	if (s == 0 && lane == 0) b.nkp[img] = total < d.kpCap ? total : d.kpCap;
-	bool active = level >= 0 && s < d.selPerImage && pos < selCount[level >= 0 ? level : 0];
+	bool active = level >= 0;
 	const int out = before + pos;
-	if (active && out >= d.kpCap) { if (lane == 0) atomicExch(b.status, MCS_ERR_CAPACITY); active = false; }
+	if (s == 0 && total > d.kpCap && lane == 0) atomicExch(b.status, MCS_ERR_CAPACITY);   // more keys selected than output rows (cannot happen with kpCap as sized by the host)
+	if (active && out >= d.kpCap) active = false;
 	if (!active) return false;   // waves are independent (no block barriers anywhere in these kernels)
 
 	float angle = 0.f, pxf = 0.f, pyf = 0.f;
@@ -521,12 +528,18 @@ __global__ __launch_bounds__(64) void k_describe_list(ExtractBuffers b, int wave
 #ifndef MCS_FAST_FENCE
 #define MCS_FAST_FENCE 4
 #endif
+#ifndef MCS_FAST_ABLATE
+#define MCS_FAST_ABLATE 0   // A/B experiments only (tools/ab_describe.sh): 1 no sampling, 2 no omni model, 4 no guard / rounding checks
+#endif
 static __device__ constexpr double kAtanQ[17] = {
 #include "mcs_atan_poly.inc"
 };
 constexpr double kHalfPi = 0x1.921fb54442d18p+0;
 constexpr int kAtanN = 17;
-constexpr int kFastWaves = 4;   // independent waves (keypoints) per workgroup of the fast pass
+#ifndef MCS_FAST_WPB
+#define MCS_FAST_WPB 4
+#endif
+constexpr int kFastWaves = MCS_FAST_WPB;   // independent waves (keypoints) per workgroup of the fast pass
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -634,7 +647,7 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 			const double ptx = (double)(int)(signed char)(ppk[t >> 1] >> (16 * e)), pty = (double)(int)(signed char)(ppk[t >> 1] >> (16 * e + 8));
 			const double xr = __builtin_fma(ptx, ax, __builtin_fma(-pty, ay, ukx));
 			const double yr = __builtin_fma(ptx, ay, __builtin_fma(pty, ax, uky));
-			fast_w2i(C, xr, yr, u[t], v[t]);
+			if (MCS_FAST_ABLATE & 2) { u[t] = xr; v[t] = yr; } else fast_w2i(C, xr, yr, u[t], v[t]);
 			sumx += u[t]; sumy += v[t];
 			if ((t & (MCS_FAST_FENCE - 1)) == MCS_FAST_FENCE - 1) __builtin_amdgcn_sched_barrier(0);   // at most MCS_FAST_FENCE point evaluations in flight (registers)
 		}
@@ -645,15 +658,15 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 		for (int t = 0; t < 2 * NB; ++t) {
 			const double dx = u[t] - meanX, dy = v[t] - meanY;
 			const double rx = __builtin_rint(dx), ry = __builtin_rint(dy);
-			bad |= !(fabs(dx - rx) < lim) || !(fabs(dy - ry) < lim);   // inside the guard band of a rounding tie (or NaN)
+			if (!(MCS_FAST_ABLATE & 4)) bad |= !(fabs(dx - rx) < lim) || !(fabs(dy - ry) < lim);   // inside the guard band of a rounding tie (or NaN)
 			ix[t] = (int)rx; iy[t] = (int)ry;
-			bad |= (unsigned)(ix[t] + 4096) >= 8192u || (unsigned)(iy[t] + 4096) >= 8192u;
+			if (!(MCS_FAST_ABLATE & 4)) bad |= (unsigned)(ix[t] + 4096) >= 8192u || (unsigned)(iy[t] + 4096) >= 8192u;
 		}
 		if (__any(bad)) { to_exact(); return; }
 #pragma unroll
 		for (int j = 0; j < NB; ++j) {
-			int t0, t1;
-			sm.pair(row, col, iy[2 * j], ix[2 * j], iy[2 * j + 1], ix[2 * j + 1], t0, t1);
+			int t0 = ix[2 * j], t1 = iy[2 * j + 1];
+			if (!(MCS_FAST_ABLATE & 1)) sm.pair(row, col, iy[2 * j], ix[2 * j], iy[2 * j + 1], ix[2 * j + 1], t0, t1);
 			const unsigned long long bits = __ballot(t0 < t1);
 			if (pat == 0) bitsMain[j] = bits;
 			else agree[j] &= ~(bits ^ bitsMain[j]);
@@ -706,7 +719,7 @@ template <int MODE>
 static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
 	// ORB: 4 keypoints (waves) per 256-thread block.  dBRIEF/mdBRIEF exact pass: one wave per block with a private 2*NB KiB LDS slice.
 	const int wpb = MODE == 0 ? 4 : 1;
-	const int wavesPerImage = (hd.selPerImage + 3) / 4 * 4;   // a multiple of 4 in every mode: the fast pass packs 4 waves per block
+	const int wavesPerImage = (hd.kpCap + 3) / 4 * 4;   // one slot per output row; a multiple of 4 in every mode (ORB and the fast pass pack 4 waves per block)
 	const int blocks = nimg * wavesPerImage / wpb;
 	const size_t ldsBytes = (size_t)wpb * (coord_bytes(MODE, hd.npoints) + kPatchBytes);   // coordinates + blurred patch per wave
 	const int nb = hd.descSize / 8;

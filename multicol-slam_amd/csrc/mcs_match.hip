@@ -12,9 +12,14 @@
 // Lists are kept as packed keys in a [set][K][query] layout: lane = query, so every list store/load is coalesced.
 #include "mcs_common.h"
 
+#include <cstdlib>
+
 namespace mcs {
 
 constexpr int MT = 256;   // train rows per LDS step
+#ifndef MCS_MATCH_PREFETCH
+#define MCS_MATCH_PREFETCH 0
+#endif
 
 // Raw popcount total of one (query, train row) pair: sum_w popc((q^t)&qm) + popc((q^t)&tm) (masked; the reference halves this total
 // ONCE, src/cORBmatcher.cpp:2452-2474) or sum_w popc(q^t).  v_bcnt_u32_b32 d, a, b = popcount(a) + b, so the running total rides on
@@ -47,6 +52,40 @@ __device__ __forceinline__ uint32_t pair_total(const uint32_t* q, const uint32_t
 	return acc;
 }
 
+// Two train rows at once, their accumulate chains interleaved word by word.  One pair alone is a chain of 2*DW DEPENDENT v_bcnt (each adds onto the
+// previous total); the compiler ran the four rows of a trip one after the other, so a wave issued one dependent bit-count after the other (~5-6 cycles
+// each instead of 4.3).  `asm volatile` keeps the a0 / a1 alternation in program order.
+template <int DW, bool MASKED>
+__device__ __forceinline__ void pair_total_x2(const uint32_t* q, const uint32_t* qm, const uint4* t0, const uint4* m0, const uint4* t1, const uint4* m1,
+                                              uint32_t& a0, uint32_t& a1) {
+#pragma unroll
+	for (int w4 = 0; w4 < DW / 4; ++w4) {
+		const uint4 tv0 = t0[w4], tv1 = t1[w4];
+		const uint32_t tw0[4] = {tv0.x, tv0.y, tv0.z, tv0.w}, tw1[4] = {tv1.x, tv1.y, tv1.z, tv1.w};
+		uint32_t mw0[4] = {0, 0, 0, 0}, mw1[4] = {0, 0, 0, 0};
+		if (MASKED) {
+			const uint4 mv0 = m0[w4], mv1 = m1[w4];
+			mw0[0] = mv0.x; mw0[1] = mv0.y; mw0[2] = mv0.z; mw0[3] = mv0.w;
+			mw1[0] = mv1.x; mw1[1] = mv1.y; mw1[2] = mv1.z; mw1[3] = mv1.w;
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int w = 4 * w4 + k;
+			const uint32_t x0 = q[w] ^ tw0[k], x1 = q[w] ^ tw1[k];
+			if (MASKED) {
+				const uint32_t xa0 = x0 & qm[w], xa1 = x1 & qm[w], xb0 = x0 & mw0[k], xb1 = x1 & mw1[k];
+				if (w == 0) { asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(a0) : "v"(xa0)); asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(a1) : "v"(xa1)); }
+				else { asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a0) : "v"(xa0)); asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a1) : "v"(xa1)); }
+				asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a0) : "v"(xb0));
+				asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a1) : "v"(xb1));
+			} else {
+				if (w == 0) { asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(a0) : "v"(x0)); asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(a1) : "v"(x1)); }
+				else { asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a0) : "v"(x0)); asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a1) : "v"(x1)); }
+			}
+		}
+	}
+}
+
 template <int DW, bool MASKED>
 __device__ __forceinline__ int hamming(const uint32_t* q, const uint32_t* qm, const uint32_t* t, const uint32_t* tm) {
 	const uint32_t acc = pair_total<DW, MASKED>(q, qm, reinterpret_cast<const uint4*>(t), reinterpret_cast<const uint4*>(tm));
@@ -61,7 +100,8 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	__shared__ __attribute__((aligned(16))) uint32_t tidx[MT + 4];    // their original train index; 0xFFFFFFFF = padding
 	__shared__ int wcnt[4];
 	constexpr int CB = 16;      // candidate column depth per lane
-	__shared__ uint32_t cand[(CB + 1) * 256];   // + one dump row
+	constexpr int CP = CB + 1;  // column pitch in dwords: odd, so the lanes' columns start in different LDS banks
+	__shared__ uint32_t cand[CP * 256];
 	const int tid = threadIdx.x;
 	const int set = blockIdx.z, split = blockIdx.y;
 	const int qi = blockIdx.x * 256 + tid;
@@ -94,19 +134,26 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	// wave whenever ANY lane hits, which at K = 32 was more than the distance arithmetic itself.
 	// `next` = index of the lane's next free slot in its column (tid, tid + 256, ...), kept as an index so that an append is
 	// compare, select (slot or dump row), store, select + add (advance)
-	const uint32_t col0 = tid, dump = CB * 256 + tid;
+	// A candidate is kept as the RAW word total << 20 | index (masked: the un-halved popcount total); the exact key (total >> 1) << 20 | index is formed
+	// when the column is merged.  Appending is: one shift-or, one compare against the raw limit, an unconditional LDS store to the lane's next slot and an
+	// add-with-carry of the compare result — a word that does not qualify is simply overwritten by the next store.
+	const uint32_t col0 = tid * CP;
 	uint32_t next = col0;
+	auto exact_key = [](uint32_t w) { return MASKED ? (((w >> 21) << 20) | (w & 0xFFFFFu)) : w; };
 	// Merge of the lane's candidate column into its sorted list.  K >= 16: the (<= CB = 16) candidates are loaded into registers
 	// (empty slots = 0xFFFFFFFF), sorted by a 16-input bitonic network, folded against the upper half of the list
 	// (m[i] = min(best[i], c[K-1-i]) holds the K smallest of both and is bitonic) and re-sorted by one bitonic MERGE — a fixed
 	// ~340 VALU ops per flush, where inserting one candidate at a time through the sorted list cost 2K ops per candidate of the
 	// fullest lane (~900 per flush at K = 32).  Smaller K keep the insertion loop.
 	auto flush = [&]() {
-		const int cnt = (int)((next - col0) >> 8);
+		const int cnt = (int)(next - col0);
 		if (K >= CB) {
 			uint32_t c[CB];
 #pragma unroll
-			for (int e = 0; e < CB; ++e) c[e] = e < cnt ? cand[e * 256 + tid] : 0xFFFFFFFFu;
+			for (int e = 0; e < CB; ++e) {   // unconditional reads (the whole column is the lane's own), stale slots masked afterwards
+				const uint32_t raw = cand[col0 + e];
+				c[e] = e < cnt ? exact_key(raw) : 0xFFFFFFFFu;
+			}
 #pragma unroll
 			for (int k = 2; k <= CB; k <<= 1)
 #pragma unroll
@@ -134,7 +181,7 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
 			for (int e = 0; e < m; ++e) {
-				uint32_t key = e < cnt ? cand[e * 256 + tid] : 0xFFFFFFFFu;
+				uint32_t key = e < cnt ? exact_key(cand[col0 + e]) : 0xFFFFFFFFu;
 				if (__any(key < best[K - 1])) {
 #pragma unroll
 					for (int p = 0; p < K; ++p) { const uint32_t lo = min(best[p], key), hi = max(best[p], key); best[p] = lo; key = hi; }
@@ -178,10 +225,11 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 		if (tid < 4) { tidx[rows + tid] = 0xFFFFFFFFu; tflag[rows + tid] = -1; }   // padding rows of the last trip
 		__syncthreads();
 		if (qok) {
-			// 4 train rows per trip.  Per pair beyond the 2 x DW (masked) bitop3 / bcnt: and + shift-or (key), compare, select (slot),
-			// add (count) — the distance threshold, the padding rows (index 0xFFFFFFFF) and "list is full" are ONE unsigned compare of
-			// the key against lim = min(K-th best key, (maxDist+1) << 20).
-			const uint32_t distCap = a.maxDist >= 4095 ? 0xFFFFFFFFu : ((uint32_t)(a.maxDist + 1) << 20);
+			// 4 train rows per trip, two at a time with interleaved accumulate chains.  The distance threshold, the padding rows (index 0xFFFFFFFF ORs the
+			// word to all ones) and "closer than the K-th best" are ONE unsigned compare of the raw word against rawLim.  Masked: the raw total t stands for
+			// distance t >> 1, so "distance <= D" is t <= 2D + 1, i.e. word < (2D + 2) << 20; entries that tie the K-th best distance with a larger index
+			// slip through and are dropped by the exact merge.
+			const uint32_t dCap = a.maxDist >= 4095 ? 4095u : (uint32_t)a.maxDist;
 			for (int r = 0; r < rows; r += 4) {
 				const uint4 ti = *reinterpret_cast<const uint4*>(&tidx[r]);
 				const uint32_t tiu[4] = {ti.x, ti.y, ti.z, ti.w};
@@ -189,26 +237,65 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 				if (useGroup) { const int4 tg = *reinterpret_cast<const int4*>(&tflag[r]); tgu[0] = tg.x; tgu[1] = tg.y; tgu[2] = tg.z; tgu[3] = tg.w; }
 				const uint4* trow = reinterpret_cast<const uint4*>(&td[r * DW]);
 				const uint4* mrow = reinterpret_cast<const uint4*>(&tm[MASKED ? r * DW : 0]);
-				const uint32_t lim = min(best[K - 1], distCap);
-				uint32_t key[4];
+				uint32_t rawLim;
+				if (MASKED) {
+					const uint32_t dl = min(best[K - 1] >> 20, dCap);
+					rawLim = dl >= 2047u ? 0xFFFFFFFFu : ((2u * dl + 2u) << 20);
+				} else rawLim = min(best[K - 1], dCap >= 4095u ? 0xFFFFFFFFu : ((dCap + 1u) << 20));
+				uint32_t acc[4];
+				constexpr int RS = DW / 4;   // uint4 per row
+#if MCS_MATCH_PREFETCH
+				// software-pipelined form: the LDS reads of phase p + 1 (one 16-byte quad of two rows, + masks) are issued before the arithmetic of phase p
+				{
+					constexpr int NPH = 2 * RS;   // phases per trip: (row pair) x (quad)
+					auto ld = [&](int ph, uint4& t0, uint4& t1, uint4& m0, uint4& m1) {
+						const int pp = ph / RS, w4 = ph % RS;
+						t0 = trow[(2 * pp) * RS + w4]; t1 = trow[(2 * pp + 1) * RS + w4];
+						if (MASKED) { m0 = mrow[(2 * pp) * RS + w4]; m1 = mrow[(2 * pp + 1) * RS + w4]; }
+					};
+					uint4 c0, c1, cm0 = {0, 0, 0, 0}, cm1 = {0, 0, 0, 0};
+					ld(0, c0, c1, cm0, cm1);
+#pragma unroll
+					for (int ph = 0; ph < NPH; ++ph) {
+						uint4 n0 = c0, n1 = c1, nm0 = cm0, nm1 = cm1;
+						if (ph + 1 < NPH) ld(ph + 1, n0, n1, nm0, nm1);
+						__builtin_amdgcn_sched_barrier(0);
+						const int pp = ph / RS, w4 = ph % RS;
+						const uint32_t tw0[4] = {c0.x, c0.y, c0.z, c0.w}, tw1[4] = {c1.x, c1.y, c1.z, c1.w};
+						const uint32_t mw0[4] = {cm0.x, cm0.y, cm0.z, cm0.w}, mw1[4] = {cm1.x, cm1.y, cm1.z, cm1.w};
+						uint32_t& a0 = acc[2 * pp];
+						uint32_t& a1 = acc[2 * pp + 1];
+#pragma unroll
+						for (int k = 0; k < 4; ++k) {
+							const int w = 4 * w4 + k;
+							const uint32_t x0 = q[w] ^ tw0[k], x1 = q[w] ^ tw1[k];
+							if (MASKED) {
+								const uint32_t xa0 = x0 & qm[w], xa1 = x1 & qm[w], xb0 = x0 & mw0[k], xb1 = x1 & mw1[k];
+								if (w == 0) { asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(a0) : "v"(xa0)); asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(a1) : "v"(xa1)); }
+								else { asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a0) : "v"(xa0)); asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a1) : "v"(xa1)); }
+								asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a0) : "v"(xb0));
+								asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a1) : "v"(xb1));
+							} else {
+								if (w == 0) { asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(a0) : "v"(x0)); asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(a1) : "v"(x1)); }
+								else { asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a0) : "v"(x0)); asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a1) : "v"(x1)); }
+							}
+						}
+						c0 = n0; c1 = n1; cm0 = nm0; cm1 = nm1;
+					}
+				}
+#else
+				pair_total_x2<DW, MASKED>(q, qm, trow, mrow, trow + RS, mrow + (MASKED ? RS : 0), acc[0], acc[1]);
+				pair_total_x2<DW, MASKED>(q, qm, trow + 2 * RS, mrow + (MASKED ? 2 * RS : 0), trow + 3 * RS, mrow + (MASKED ? 3 * RS : 0), acc[2], acc[3]);
+#endif
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
-					const uint32_t acc = pair_total<DW, MASKED>(q, qm, trow + u * (DW / 4), mrow + (MASKED ? u * (DW / 4) : 0));
-					// (acc >> 1) << 20 | idx  ==  (acc & ~1) << 19 | idx
-					key[u] = MASKED ? (((acc & ~1u) << 19) | tiu[u]) : ((acc << 20) | tiu[u]);
-					if (useGroup) key[u] = tgu[u] == qg ? key[u] : 0xFFFFFFFFu;
-					if (COUNT) countLe += (tiu[u] != 0xFFFFFFFFu && key[u] != 0xFFFFFFFFu && (int)(MASKED ? acc >> 1 : acc) <= a.countThresh) ? 1 : 0;
+					uint32_t w = (acc[u] << 20) | tiu[u];
+					if (useGroup) w = tgu[u] == qg ? w : 0xFFFFFFFFu;
+					if (COUNT) countLe += (tiu[u] != 0xFFFFFFFFu && w != 0xFFFFFFFFu && (int)(MASKED ? acc[u] >> 1 : acc[u]) <= a.countThresh) ? 1 : 0;
+					cand[next] = w;
+					next += w < rawLim ? 1u : 0u;
 				}
-				// Branch-free append: a key that cannot enter the list goes to the lane's dump slot (row CB).  On repetitive imagery
-				// ~16 % of all pairs are within maxDist, so "some lane of the wave has a candidate in these 4 rows" holds on
-				// practically every trip and a wave vote + predicated blocks only added instructions.
-#pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const bool in = key[u] < lim;
-					cand[in ? next : dump] = key[u];
-					next += in ? 256u : 0u;
-				}
-				if (__any(next > col0 + (CB - 4) * 256)) flush();
+				if (__any(next > col0 + (CB - 4))) flush();
 			}
 		}
 		__syncthreads();
@@ -270,7 +357,8 @@ static void launch_kd(const MatchArgs& a, hipStream_t s) {
 	dim3 grid((a.nq + 255) / 256, a.splits, a.nsets);
 	const bool masked = a.qm && a.tm, count = a.countThresh >= 0;   // the searches do not need count_le: skip its VALU ops per pair
 	const bool group = a.qgroup != nullptr && a.tgroup != nullptr;
-#define MCS_LAUNCH_PARTIAL(M, C, G) hipLaunchKernelGGL((k_match_partial<K, DW, M, C, G>), grid, dim3(256), 0, s, a)
+	static const int ldsPad = getenv("MCS_MATCH_LDS_PAD") ? atoi(getenv("MCS_MATCH_LDS_PAD")) : 0;   // A/B: extra dynamic LDS per workgroup (caps workgroups per CU)
+#define MCS_LAUNCH_PARTIAL(M, C, G) hipLaunchKernelGGL((k_match_partial<K, DW, M, C, G>), grid, dim3(256), ldsPad, s, a)
 	if (masked) { if (count) { if (group) MCS_LAUNCH_PARTIAL(true, true, true); else MCS_LAUNCH_PARTIAL(true, true, false); }
 	              else { if (group) MCS_LAUNCH_PARTIAL(true, false, true); else MCS_LAUNCH_PARTIAL(true, false, false); } }
 	else { if (count) { if (group) MCS_LAUNCH_PARTIAL(false, true, true); else MCS_LAUNCH_PARTIAL(false, true, false); }

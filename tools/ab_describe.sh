@@ -12,12 +12,13 @@ if [ "$mode" = build ]; then
   cp $d/multicol-slam_amd/libmcs_hip.so gpurun_ab/libmcs_hip_$name.so
 else
   for g in "$@"; do
-    MCS_HIP_LIB=$PWD/gpurun_ab/libmcs_hip_$g.so timeout 300 python bench.py --no-cpu-baseline > /tmp/ab.json 2>/tmp/ab.err
+    lib=$PWD/gpurun_ab/libmcs_hip_$g.so; [ -f $lib ] || lib=$PWD/multicol-slam_amd/libmcs_hip.so   # an unknown name benches the tree's own library (with whatever environment the caller set)
+    MCS_HIP_LIB=$lib timeout 300 python bench.py --no-cpu-baseline > /tmp/ab.json 2>/tmp/ab.err
     python - "$g" <<'PY'
 import json, sys
 try:
     d = json.load(open("/tmp/ab.json"))
-    print("%-12s" % sys.argv[1], d["value"], "Mfeat/s", d["ms_per_step"], "ms/step  describe", d["roofline"]["per_kernel_ms"]["describe"], "ms  matches", d["config"]["matches_per_step_rank0"])
+    print("%-12s" % sys.argv[1], d["value"], "Mfeat/s", d["ms_per_step"], "ms/step", d["roofline"]["per_kernel_ms"], "matches", d["config"]["matches_per_step_rank0"])
 except Exception as e:
     print(sys.argv[1], "failed", e, open("/tmp/ab.err").read()[-300:])
 PY
