@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
 """bench.py — MultiCol-SLAM feature front end + brute-force matcher on MI355X.
 
-Default workload (BASELINE.json configs[1], the configuration the metric is quoted on):
-  a "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
-  F three-camera 754x480 multi-frames -> mdBRIEF extraction (pyramid, FAST, oct-tree, orientation, blur, descriptors+masks,
-  rays) -> SearchByBoW(KF,KF) brute force (masked Hamming, ratio 0.9) of every multi-frame against the previous multi-frame
-  of the stream.  value = features extracted AND matched per second, whole job.
-  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the stream of multi-frames is sharded across ranks
-  (independent units -> weak scaling, no data-path collective); barrier + max-over-ranks timing.
+A "step" = one pass of the hot path over one batch of synthetic input already resident in HBM: F multi-frames per GPU -> extraction (pyramid, FAST,
+oct-tree, orientation, blur, descriptors + masks, rays) -> brute-force Hamming matching.  value = features extracted AND matched per second, whole job.
 
---workload rig (BASELINE configs[3]/[4] shape, not the headline): a 6-camera 1280x800 rig, 2000 features per camera, cameras
-  sharded over the ranks, ONE RCCL all-gather of the descriptor blocks per step, every multi-frame matched
-  (SearchByBoW(KF,F) without the vocabulary restriction) against this rank's shard of a stored keyframe database.
+Workloads (one engine, `Job`; --workload):
+  stream  (default)  BASELINE configs[1], the configuration the metric is quoted on: 3-camera 754x480 multi-frames, mdBRIEF, N = 1000, every
+                     multi-frame matched with SearchByBoW(KF,KF) (masked Hamming, ratio 0.9) against the multi-frame before it.
+  db                 BASELINE configs[2]: the same stream, every multi-frame against 32 stored multi-keyframes (SearchByBoW(KF,F) with the vocabulary
+                     restriction removed; the relocalisation loop src/cTracking.cpp:1125-1221) — the matcher dominates.
+  rig / rig8         BASELINE configs[3] / [4]: 6-camera (8-camera) 1280x800 rig, 2000 features per camera, against 32 (256) stored keyframes.
+  --mode orb --nfeatures 400 on any of them = the reference's shipped extractor settings (Examples/Lafida/Slam_Settings_indoor1.yaml:12-39).
+
+N > 1 (one process per GPU, torch.distributed backend nccl = RCCL): BASELINE north_star's split, see multicol-slam_amd/rig.py — the (camera, frame)
+images of a step are sharded camera-major over the ranks, ONE all-gather of descriptor|mask|count blocks per step, the gathered buffer is consumed in
+place, the (frame, keyframe) pairs are sharded.  Per-GPU work is fixed (F multi-frames and F x keyframes pairs per GPU): weak scaling.  N = 1 runs the
+same code without the collective.  Barrier + max-over-ranks timing.
 
 torch is plumbing only (device memory, stream handle, process group); all compute is libmcs_hip.so through its C ABI.
 """
@@ -30,28 +34,35 @@ import numpy as np  # noqa: E402
 
 MODES = {"orb": (0, 0), "dbrief": (1, 0), "mdbrief": (1, 1)}
 KERNELS = ("pyramid", "fast", "octree", "blur", "describe", "match", "greedy")
+POOL = 8    # distinct synthetic multi-frames the stream cycles through (the scene drifts out of the image after a few dozen frames)
+WORKLOADS = {
+    #          ncam  W     H    nfeat  F/GPU  keyframes  name in BASELINE.json
+    "stream": (3, 754, 480, 1000, 64, 0, "configs[1]"),
+    "db": (3, 754, 480, 1000, 64, 32, "configs[2]"),
+    "rig": (6, 1280, 800, 2000, 4, 32, "configs[3]"),
+    "rig8": (8, 1280, 800, 2000, 1, 256, "configs[4]"),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="stream", choices=["stream", "rig"])
-    ap.add_argument("--frames", type=int, default=0, help="multi-frames per step and GPU (default 64 stream / 4 rig)")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="stream", choices=list(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=0, help="multi-frames per step and GPU (default: per workload)")
     ap.add_argument("--mode", default="mdbrief", choices=list(MODES))
-    ap.add_argument("--nfeatures", type=int, default=0, help="features per camera (default 1000 stream / 2000 rig)")
+    ap.add_argument("--nfeatures", type=int, default=0, help="features per camera (default: per workload)")
+    ap.add_argument("--ncam", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--keyframes", type=int, default=-1, help="stored keyframes every multi-frame is matched against (0 = the multi-frame before it)")
     ap.add_argument("--topk", type=int, default=32)
-    ap.add_argument("--substreams", type=int, default=1, help="independent sub-streams (HIP streams) per GPU; measured: 1 is best (2 equal, 3-4 slower), kept for A/B")
-    ap.add_argument("--keyframes", type=int, default=32, help="rig workload: stored keyframes in the database (sharded over ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=0, help="multi-frames in the bounded CPU-baseline sample (default: cores/2, >= 48)")
-    ap.add_argument("--check", action="store_true", help="verify one multi-frame of the timed output against the oracle")
-    return ap.parse_args()
-
-
-def ptr(t, row_off=0):
-    return t.data_ptr() + row_off * (t.stride(0) * t.element_size() if t.dim() > 1 else t.element_size())
+    ap.add_argument("--no-secondary", action="store_true", help="skip the e2e / configs[2] / shipped-settings legs of the default run")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="multi-frames in the bounded CPU-baseline sample (default: 3 x cpu quota, >= 48)")
+    ap.add_argument("--check", action="store_true", help="verify one multi-frame (descriptors, masks) and one pair's match indices of the timed output against the oracle")
+    return ap.parse_args(argv)
 
 
 def cpu_model():
@@ -77,20 +88,22 @@ def setup():
     e.world = int(os.environ.get("WORLD_SIZE", "1"))
     e.local = int(os.environ.get("LOCAL_RANK", "0"))
     # MCS_BENCH_SHARE_GPU=1: functional test of the N>1 code path on a 1-GPU box (all ranks on cuda:0, gloo for the collectives)
-    share = os.environ.get("MCS_BENCH_SHARE_GPU") == "1"
-    if share:
+    e.share = os.environ.get("MCS_BENCH_SHARE_GPU") == "1"
+    if e.share:
         e.local = 0
+    e.backend = None
     if e.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if share else "nccl", rank=e.rank, world_size=e.world)
+        e.backend = "gloo" if e.share else "nccl"
+        dist.init_process_group(e.backend, rank=e.rank, world_size=e.world)
     torch.cuda.set_device(e.local)
     e.dev = torch.device("cuda", e.local)
-    e.red_dev = torch.device("cpu") if share else e.dev
+    e.red_dev = torch.device("cpu") if e.share else e.dev
     e.mcs = importlib.import_module("multicol-slam_amd")
     e.synth = importlib.import_module("multicol-slam_amd.synth")
     e.rig = importlib.import_module("multicol-slam_amd.rig")
     e.lib = e.mcs.lib()
-    # one explicit (non-default) stream shared by torch's copies and the library's kernels, so their order is the enqueue order
+    # one explicit (non-default) stream shared by torch's copies, the collective's hand-over and the library's kernels: their order is the enqueue order
     e.stream = torch.cuda.Stream(device=e.dev)
     torch.cuda.set_stream(e.stream)
     assert e.stream.cuda_stream != 0
@@ -120,6 +133,7 @@ def timed(e, step, warmup, steps, status):
 
 
 def kernel_times(e, step, reps=5):
+    """per-kernel time of one step from the library's HIP events on its own stream (side-stream overlap off while timing, so each kernel is measured alone)"""
     e.ctx.enable_timing(True)
     acc = {}
     for _ in range(reps):
@@ -134,200 +148,334 @@ def kernel_times(e, step, reps=5):
     return {k: v / reps for k, v in acc.items()}
 
 
-def measured_traffic(dom, mode, frames, nfeat):
-    """HBM bytes per launch of kernel `dom` from the committed PMC passes (profiles/pmc_traffic.json), if they were taken on this workload."""
+def pmc_entry(tag, dom):
+    """HBM bytes (FETCH_SIZE + WRITE_SIZE) and VALU wave-instructions per launch of kernel `dom` from the committed counter passes of this workload"""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        w = t["workload"]
-        if (w["frames"], w["mode"], w["nfeatures"]) != (frames, mode, nfeat):
-            return None
-        k = t["kernels"][dom]
-        return int((k["fetch_kib"] + k["write_kib"]) * 1024)
-    except (OSError, KeyError, ValueError):
-        return None
+        k = t["workloads"][tag]["kernels"][dom]
+        return int((k["fetch_kib"] + k["write_kib"]) * 1024), k.get("valu_insts")
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None
 
 
-def valu_issue(dom, mode, frames, nfeat, launch_ms):
-    """The bound that actually applies: VALU wave instructions per launch (SQ_INSTS_VALU of the committed counter pass) over the live
-    launch time, against one wave instruction per 4 cycles and SIMD (1024 SIMDs x 2.4 GHz / 4) — the rate of the FP64 and bit-count instructions
-    these kernels consist of (32-bit ALU instructions issue faster, so the fraction is a lower bound on the issue-slot use)."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        w = t["workload"]
-        if (w["frames"], w["mode"], w["nfeatures"]) != (frames, mode, nfeat):
-            return None
-        insts = t["kernels"][dom]["valu_insts"]
-    except (OSError, KeyError, ValueError):
-        return None
-    peak = 1024 * 2.4e9 / 4 / 1e9
-    ach = insts / (launch_ms * 1e-3) / 1e9
-    return {"wave_insts_per_launch": int(insts), "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s", "frac": round(ach / peak, 3)}
+# ------------------------------------------------------------------------------------------------ the job
+class Spec:
+    def __init__(self, args, world):
+        ncam, W, H, nfeat, F, D, cfg = WORKLOADS[args.workload]
+        self.name, self.cfg = args.workload, cfg
+        self.ncam = args.ncam or ncam
+        self.W, self.H = args.width or W, args.height or H
+        self.nfeat = args.nfeatures or nfeat
+        self.F = args.frames or F
+        self.D = D if args.keyframes < 0 else args.keyframes
+        self.mode, self.topk = args.mode, args.topk
+        self.world = world
+        self.tag = "%s-%s-%dx%dx%d-n%d-f%d-k%d" % (self.name, self.mode, self.ncam, self.W, self.H, self.nfeat, self.F, self.D)
 
 
-def roofline(kern, mode, nimg, nkp_total, sizes, nfeat=1000):
-    # algorithmic bytes per launch (SURVEY.md §8d / DESIGN.md §4)
-    per_kp = 845 + 512 * (3 if mode == "mdbrief" else 1) + 28 + 32 + (32 if mode == "mdbrief" else 0)
-    S = [w * h for w, h in sizes]
-    alg = {"describe": per_kp * nkp_total, "pyramid": nimg * (sum(S) - S[-1] + sum(S) - S[0]), "fast": nimg * sum(S), "blur": nimg * 2 * sum(S)}
-    dom = max(alg, key=lambda k: kern[k])
-    ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
-    return {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": measured_traffic(dom, mode, nimg // 3, nfeat),
-            "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kern[dom], 4), "per_kernel_ms": {k: round(v, 4) for k, v in kern.items()},
-            "per_kernel_alg_GBps": {k: round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) for k in alg},
-            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
-            "valu_issue": valu_issue(dom, mode, nimg // 3, nfeat, kern[dom]),
-            "note": "every kernel of this path is VALU-issue-bound, not HBM-bound (k_describe: FP64 at 16 lanes/clk; matcher: v_bitop3/v_bcnt at 16 lanes/clk), see DESIGN.md §6"}
+class Job:
+    """One rank's share of a workload: its slab of (camera, frame) images, the exchange, its share of the (frame, keyframe) pairs."""
 
+    def __init__(self, e, sp, n_image_buffers=1):
+        torch, mcs, synth, rig = e.torch, e.mcs, e.synth, e.rig
+        self.e, self.sp = e, sp
+        dev = e.dev
+        do_db, masks_on = MODES[sp.mode]
+        self.masks_on = masks_on
+        base_cams = synth.lafida_cameras()
+        self.cams = [base_cams[c % 3] if (sp.W, sp.H) == (754, 480) else synth.scaled_camera(base_cams[c % 3], sp.W, sp.H) for c in range(sp.ncam)]
+        FT = sp.F * e.world
+        # a first, tiny extractor only to learn the row capacity; the real one is sized for the slab
+        probe = mcs.Extractor(e.ctx, sp.W, sp.H, max_batch=1, nfeatures=sp.nfeat, do_dBrief=do_db, learnMasks=masks_on)
+        cap = probe.cap
+        self.level_sizes = probe.level_sizes
+        probe.close()
+        self.lay = lay = rig.RigLayout(sp.ncam, FT, e.world, cap, 32)
+        self.L, self.cap, self.FT = lay.L, cap, FT
+        self.ex = mcs.Extractor(e.ctx, sp.W, sp.H, max_batch=lay.L, nfeatures=sp.nfeat, do_dBrief=do_db, learnMasks=masks_on)
+        slab = lay.slab(e.rank)
+        self.slab = slab
+        # synthetic inputs of this rank's slab (untimed).  Global frame f shows synthetic frame f % POOL: every rank carries the same amount of work
+        cache = {}
 
-# ------------------------------------------------------------------------------------------------ stream workload
-def shard_frames(rank, pool):
-    """frame numbers of the synthetic stream that rank `rank` cycles through (consecutive frames of one stream, `pool` per rank)"""
-    return [rank * pool + f for f in range(pool)]
+        def image(c, f):
+            key = (c, f % POOL)
+            if key not in cache:
+                cache[key] = synth.synth_image(f % POOL, c, self.cams[c])
+            return cache[key]
+        self.imgs_np = np.stack([image(c, f) for c, f in slab])
+        mm = [synth.mirror_mask(cam) for cam in self.cams]
+        self.masks_np = np.stack([mm[c] for c, _ in slab])
+        self.d_imgs = [torch.from_numpy(self.imgs_np).to(dev) for _ in range(n_image_buffers)]
+        self.d_masks = torch.from_numpy(self.masks_np).to(dev)
+        self.camarr = (mcs.Ocam * lay.L)(*[mcs.make_ocam(self.cams[c]) for c, _ in slab])
+        self.sets = [self._make_set(), self._make_set()]   # ping-pong: the greedy pass of step n (library side stream) overlaps step n + 1
+        self.cur = 0
+        # stored keyframes of this rank (database sweeps): contiguous sets of ncam*cap rows, filled once from an untimed pass
+        self.kfs = lay.keyframe_shard(sp.D, e.rank) if sp.D > 0 else []
+        self.nkf = len(self.kfs)
+        if sp.D > 0:
+            nk = max(self.nkf, 1)
+            self.db = torch.zeros((nk, lay.rows_frame, lay.row_stride), dtype=torch.uint8, device=dev)
+            self.db_valid = torch.zeros((nk, lay.rows_frame), dtype=torch.uint8, device=dev)
+            self._fill_database()
 
-
-def run_stream(args, e):
-    torch, mcs, synth, lib, ctx, dev = e.torch, e.mcs, e.synth, e.lib, e.ctx, e.dev
-    W, H, NCAM = 754, 480, 3
-    F = args.frames or 64
-    nfeat = args.nfeatures or 1000
-    nimg = F * NCAM
-    do_db, masks_on = MODES[args.mode]
-    cams = synth.lafida_cameras()
-    POOL = min(F, 8)
-    # this rank's shard of the stream (untimed): consecutive frames of ONE stream — the synthetic scene drifts 3 px per frame, so frame numbers far
-    # apart (an earlier rank * 1000 offset) leave ranks >= 1 with empty images; every shard must carry the same amount of work (weak scaling)
-    pool = [synth.synth_multiframe(f, cams) for f in shard_frames(e.rank, POOL)]
-    imgs_np = np.stack([pool[f % POOL][c] for f in range(F) for c in range(NCAM)])
-    masks_np = np.stack([synth.mirror_mask(cams[c]) for _ in range(F) for c in range(NCAM)])
-    ds = 32
-
-    class Sub:
-        """One independent sub-stream of multi-frames on its own HIP stream / library context (frames [f0, f0+Fs) of every step).
-        Several sub-streams per GPU interleave on the hardware: the latency-bound phases of one (oct-tree, kernel tails, launch
-        gaps) are filled by the VALU-bound kernels of the other.  Each sub-stream matches against ITS previous multi-frame."""
-
-        def __init__(self, f0, Fs, ctx_, stream_):
-            self.ctx, self.stream, self.Fs, self.f0 = ctx_, stream_, Fs, f0
-            self.n = Fs * NCAM
-            self.ex = mcs.Extractor(ctx_, W, H, max_batch=self.n, nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)
-            self.cap = self.ex.cap
-            self.rows_f = NCAM * self.cap
-            self.imgs = torch.from_numpy(imgs_np[f0 * NCAM:(f0 + Fs) * NCAM]).to(dev)
-            self.masks = torch.from_numpy(masks_np[f0 * NCAM:(f0 + Fs) * NCAM]).to(dev)
-            self.camarr = (mcs.Ocam * self.n)(*[mcs.make_ocam(cams[i % NCAM]) for i in range(self.n)])
-            # Descriptor-side buffers carry one extra multi-frame slot: slot 0 = last multi-frame of the previous step (the stored
-            # keyframe).  Two buffer sets alternate between steps (ping-pong): the greedy match resolution of step n runs on the
-            # library's side stream while step n+1 already extracts into the other set.
-            self.sets = [self.make_set(), self.make_set()]
-            self.cur = 0
-
-        def make_set(self):
-            Fs, rows_f = self.Fs, self.rows_f
-            b = Env()
-            b.nkp = torch.zeros((Fs + 1) * NCAM, dtype=torch.int32, device=dev)
-            b.kps = torch.zeros(((Fs + 1) * rows_f, 7), dtype=torch.float32, device=dev)
-            b.desc = torch.zeros(((Fs + 1) * rows_f, ds), dtype=torch.uint8, device=dev)
-            b.dmask = torch.zeros(((Fs + 1) * rows_f, ds), dtype=torch.uint8, device=dev)
-            b.rays = torch.zeros(((Fs + 1) * rows_f, 3), dtype=torch.float64, device=dev)
-            b.valid = torch.zeros((Fs + 1) * rows_f, dtype=torch.uint8, device=dev)
-            b.match = torch.full((Fs * rows_f,), -1, dtype=torch.int32, device=dev)
-            b.nmatch = torch.zeros(Fs, dtype=torch.int32, device=dev)
-            b.fb = torch.zeros(Fs, dtype=torch.int32, device=dev)
-            b.q = mcs.DescSet(ptr(b.desc, rows_f), ptr(b.dmask, rows_f) if masks_on else None, ptr(b.valid, rows_f), None, rows_f, ds)
-            b.t = mcs.DescSet(ptr(b.desc, 0), ptr(b.dmask, 0) if masks_on else None, ptr(b.valid, 0), None, rows_f, ds)
-            return b
-
-        def step(self):
-            Fs, rows_f, cap = self.Fs, self.rows_f, self.cap
-            b, o = self.sets[self.cur], self.sets[self.cur ^ 1]
-            self.cur ^= 1
-            with torch.cuda.stream(self.stream):
-                b.nkp[:NCAM].copy_(o.nkp[Fs * NCAM:], non_blocking=True)       # previous step's last multi-frame -> slot 0 (stored keyframe)
-                b.desc[:rows_f].copy_(o.desc[Fs * rows_f:], non_blocking=True)
-                b.dmask[:rows_f].copy_(o.dmask[Fs * rows_f:], non_blocking=True)
-                self.ex.extract_device(self.n, self.imgs.data_ptr(), W * H, W, self.masks.data_ptr(), W * H, W, self.camarr, ptr(b.nkp, NCAM),
-                                       ptr(b.kps, rows_f), ptr(b.desc, rows_f), ptr(b.dmask, rows_f), ptr(b.rays, rows_f))
-                mcs.check(lib.mcs_rows_valid(self.ctx.h, C.c_void_p(ptr(b.nkp, 0)), (Fs + 1) * NCAM, cap, C.c_void_p(ptr(b.valid, 0))))
-                mcs.check(lib.mcs_search_kf_kf(self.ctx.h, Fs, C.byref(b.q), rows_f, C.byref(b.t), rows_f, ds, 0.9, args.topk, mcs.MEM_DEVICE,
-                                               C.c_void_p(b.match.data_ptr()), C.c_void_p(b.nmatch.data_ptr()), C.c_void_p(b.fb.data_ptr())))
-
-        def last(self):
-            return self.sets[self.cur ^ 1]
-
-    S = max(1, min(args.substreams, F))
-    bounds = [round(i * F / S) for i in range(S + 1)]
-    subs = []
-    for i in range(S):
-        if i == 0:
-            st, cx = e.stream, ctx
+    def _make_set(self):
+        torch, lay, dev, e = self.e.torch, self.lay, self.e.dev, self.e
+        b = Env()
+        b.G = torch.zeros(lay.images_total * lay.block_bytes, dtype=torch.uint8, device=dev)          # gathered [camera][frame][cap+1][64]
+        b.send = b.G if e.world == 1 else torch.zeros(lay.send_bytes, dtype=torch.uint8, device=dev)   # world 1: the slab IS the whole array
+        b.valid = torch.zeros(lay.images_total * lay.rows_img, dtype=torch.uint8, device=dev)
+        b.nkp = torch.zeros(lay.L, dtype=torch.int32, device=dev)
+        b.nkp_all = torch.zeros(lay.images_total, dtype=torch.int32, device=dev)
+        b.kps = torch.zeros((lay.L * self.cap, 7), dtype=torch.float32, device=dev)
+        b.rays = torch.zeros((lay.L * self.cap, 3), dtype=torch.float64, device=dev)
+        if self.sp.D > 0:
+            nk = max(len(lay.keyframe_shard(self.sp.D, e.rank)), 1)
+            b.match = torch.full((self.FT * nk * lay.rows_frame,), -1, dtype=torch.int32, device=dev)
+            b.nmatch = torch.zeros(self.FT * nk, dtype=torch.int32, device=dev)
+            b.fb = torch.zeros(self.FT * nk, dtype=torch.int32, device=dev)
         else:
-            st = torch.cuda.Stream(device=dev)
-            cx = mcs.Context(e.local, st.cuda_stream)
-        subs.append(Sub(bounds[i], bounds[i + 1] - bounds[i], cx, st))
-    cap = subs[0].cap
+            b.match = torch.full((self.sp.F * lay.rows_frame,), -1, dtype=torch.int32, device=dev)
+            b.nmatch = torch.zeros(self.sp.F, dtype=torch.int32, device=dev)
+            b.fb = torch.zeros(self.sp.F, dtype=torch.int32, device=dev)
+        return b
+
+    def frame_set(self, b, frame=0):
+        """mcs_desc_set of multi-frame `frame` inside the gathered array of buffer set b"""
+        mcs, lay = self.e.mcs, self.lay
+        doff, moff, voff, n, stride, brows, bpitch, _ = lay.frame_desc_set(frame)
+        g, v = b.G.data_ptr(), b.valid.data_ptr()
+        return mcs.DescSet(g + doff, (g + moff) if self.masks_on else None, v + voff, None, n, stride, brows, bpitch)
+
+    def extract_and_exchange(self, b, img_buf=0):
+        e, lay, lib, mcs, W, H = self.e, self.lay, self.e.lib, self.e.mcs, self.sp.W, self.sp.H
+        sp_ = b.send.data_ptr()
+        self.ex.extract_strided(lay.L, self.d_imgs[img_buf].data_ptr(), W * H, W, self.d_masks.data_ptr(), W * H, W, self.camarr, b.nkp.data_ptr(),
+                                b.kps.data_ptr(), sp_, sp_ + lay.desc_size, b.rays.data_ptr(), lay.rows_img, lay.row_stride)
+        mcs.check(lib.mcs_rig_pack_headers(e.ctx.h, C.c_void_p(b.nkp.data_ptr()), lay.L, self.cap, C.c_void_p(sp_), lay.row_stride))
+        if e.world > 1:   # the one exchange step: descriptor | mask | count blocks of every rank's slab
+            if e.backend == "nccl":
+                e.dist.all_gather_into_tensor(b.G, b.send)
+            else:
+                b.G.copy_(e.rig.all_gather_blocks(b.send, e.world))
+        mcs.check(lib.mcs_rig_rows_valid(e.ctx.h, C.c_void_p(b.G.data_ptr()), lay.images_total, self.cap, lay.row_stride, C.c_void_p(b.valid.data_ptr()),
+                                         C.c_void_p(b.nkp_all.data_ptr())))
+
+    def _fill_database(self):
+        """untimed: the stored keyframes are earlier multi-frames of the same synthetic stream (keyframe k = multi-frame k % frames_total of one pass)"""
+        torch, lay = self.e.torch, self.lay
+        b = self.sets[0]
+        self.extract_and_exchange(b)
+        torch.cuda.synchronize(self.e.dev)
+        rows = b.G.view(lay.images_total, lay.rows_img, lay.row_stride)
+        val = b.valid.view(lay.images_total, lay.rows_img)
+        for j, k in enumerate(self.kfs):
+            f = k % self.FT
+            for c in range(lay.ncam):
+                x = lay.image_index(c, f)
+                self.db[j, c * self.cap:(c + 1) * self.cap] = rows[x, :self.cap]
+                self.db_valid[j, c * self.cap:(c + 1) * self.cap] = val[x, :self.cap]
+        torch.cuda.synchronize(self.e.dev)
+
+    def match(self, b):
+        e, lay, lib, mcs, sp = self.e, self.lay, self.e.lib, self.e.mcs, self.sp
+        fr = self.frame_set(b, 0)
+        if sp.D == 0:   # every multi-frame of this rank's range against the one before it (a ring over the step's frames)
+            mcs.check(lib.mcs_search_kf_kf_ring(e.ctx.h, self.FT, e.rank * sp.F, sp.F, C.byref(fr), lay.rows_img, 32, 0.9, sp.topk, mcs.MEM_DEVICE,
+                                                C.c_void_p(b.match.data_ptr()), C.c_void_p(b.nmatch.data_ptr()), C.c_void_p(b.fb.data_ptr())))
+        elif self.nkf:  # every multi-frame of the step against every stored keyframe of this rank
+            d = self.db.data_ptr()
+            kf = mcs.DescSet(d, (d + lay.desc_size) if self.masks_on else None, self.db_valid.data_ptr(), None, lay.rows_frame, lay.row_stride)
+            mcs.check(lib.mcs_search_kf_f_sweep(e.ctx.h, self.nkf, C.byref(kf), lay.rows_frame, self.FT, C.byref(fr), lay.rows_img, 32, 0.9, sp.topk,
+                                                mcs.MEM_DEVICE, C.c_void_p(b.match.data_ptr()), C.c_void_p(b.nmatch.data_ptr()), C.c_void_p(b.fb.data_ptr())))
+
+    def step(self, img_buf=0):
+        b = self.sets[self.cur]
+        self.cur ^= 1
+        self.extract_and_exchange(b, img_buf)
+        self.match(b)
+        return b
+
+    def last(self):
+        return self.sets[self.cur ^ 1]
+
+    def status(self):
+        self.ex.status()
+
+    # ---- accounting
+    def local_features(self):
+        return int(self.last().nkp.sum().item())
+
+    def pairs_per_step_local(self):
+        b = self.last()
+        nk = b.nkp_all.view(self.lay.ncam, self.FT).sum(0).to(self.e.torch.float64)   # features per multi-frame
+        if self.sp.D == 0:
+            fr = [f for f, _ in self.lay.frame_pairs(self.e.rank)]
+            pr = [p for _, p in self.lay.frame_pairs(self.e.rank)]
+            return float((nk[fr] * nk[pr]).sum().item())
+        return float(self.db_valid.sum().item()) * float(nk.sum().item()) if self.nkf else 0.0
+
+    def close(self):
+        self.ex.close()
+
+
+def roofline_block(sp, job, kern, feats_local, pairs_local):
+    """`roofline` of the dominant kernel of one step on this rank: algorithmic bytes per launch (SURVEY.md §8d / DESIGN.md §4) over its measured duration"""
+    nimg = job.L
+    per_kp = 845 + 512 * (3 if sp.mode == "mdbrief" else 1) + 28 + 32 + (32 if sp.mode == "mdbrief" else 0)
+    S = [w * h for w, h in job.level_sizes]
+    rows = job.lay.rows_frame
+    nsets = sp.F if sp.D == 0 else job.nkf * job.FT
+    width = 64 if job.masks_on else 32
+    alg = {"describe": per_kp * feats_local, "pyramid": nimg * (sum(S) - S[-1] + sum(S) - S[0]), "fast": nimg * sum(S), "blur": nimg * 2 * sum(S),
+           # matcher: every set pair reads its query and train rows once (descriptor + mask) and writes K list entries per query row
+           "match": (nsets * 2 * rows * width + nsets * rows * 4 * sp.topk) if "match" in kern else 0}
+    dom = max((k for k in alg if k in kern), key=lambda k: kern[k])
+    ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
+    traffic, valu = pmc_entry(sp.tag, dom)
+    out = {"kernel": "k_" + ("match_partial" if dom == "match" else dom), "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
+           "frac": round(ach / 8000.0, 5), "traffic": traffic, "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kern[dom], 4),
+           "per_kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+           "per_kernel_alg_GBps": {k: round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) for k in alg if k in kern and kern[k] > 0},
+           "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" if traffic else None,
+           "note": "no kernel of this path is HBM-bound (k_describe: FP64 at 16 lanes/clk; matcher: v_bitop3 / v_bcnt); the bound that applies is VALU issue, DESIGN.md §6"}
+    if valu:
+        peak = 1024 * 2.4e9 / 4 / 1e9
+        a = valu / (kern[dom] * 1e-3) / 1e9
+        out["valu_issue"] = {"wave_insts_per_launch": int(valu), "achieved": round(a, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s", "frac": round(a / peak, 3)}
+    if "match" in kern and pairs_local > 0:
+        # 2 x 8 bit-ops (2.4 cycles) + 2 x 8 bit-counts (4.3 cycles) per 64 masked pairs and SIMD (tools/valu_latency.hip): the arithmetic alone
+        cyc = (16 * 2.4 + 16 * 4.3) if job.masks_on else (8 * 2.4 + 8 * 4.3)
+        ceiling = 1024 * 2.4e9 / cyc * 64
+        pps = pairs_local / (kern["match"] * 1e-3)
+        out["matcher"] = {"pair_distances_per_launch": pairs_local, "Tpairs_per_s": round(pps / 1e12, 3), "valu_ceiling_Tpairs_per_s": round(ceiling / 1e12, 3),
+                          "frac": round(pps / ceiling, 3)}
+    return out
+
+
+def run_job(e, sp, args, steps, warmup, want_roofline=True):
+    job = Job(e, sp)
+    elapsed = timed(e, job.step, warmup, steps, job.status)
+    feats_local = job.local_features()
+    pairs_local = job.pairs_per_step_local()
+    b = job.last()
+    matches = int(b.nmatch.sum().item())
+    rescans = int(b.fb.sum().item())
+    elapsed_max, feats_all = e.rig.reduce_timing(elapsed, feats_local, e.red_dev, e.world)
+    _, pairs_all = e.rig.reduce_timing(elapsed, pairs_local, e.red_dev, e.world)
+    kern = kernel_times(e, job.step) if want_roofline else None   # every rank: step() contains the collective
+    roof = roofline_block(sp, job, kern, feats_local, pairs_local) if (want_roofline and e.rank == 0) else None
+    value = feats_all * steps / elapsed_max / 1e6
+    what = ("cORBmatcher BF-Hamming SearchByBoW(KF,KF) vs the multi-frame before it" if sp.D == 0 else
+            "cORBmatcher BF-Hamming SearchByBoW(KF,F) (vocabulary restriction removed) vs %d stored keyframes" % sp.D)
+    cfg = {"workload": "BASELINE %s: %d-camera %dx%d multi-frames, %s extract (N=%d, 8 levels, FAST 20) + %s; %d multi-frames (%d images) per step per GPU, "
+                       "inputs resident in HBM" % (sp.cfg, sp.ncam, sp.W, sp.H, sp.mode, sp.nfeat, what, sp.F, sp.F * sp.ncam),
+           "multi_frames_per_step_per_gpu": sp.F, "distinct_multi_frames_in_the_stream": POOL, "features_per_step": int(feats_all),
+           "pair_distances_per_step": pairs_all, "Gpairs_per_s": round(pairs_all * steps / elapsed_max / 1e9, 1),
+           "matches_per_step_rank0": matches, "greedy_rescans_rank0": rescans, "topk": sp.topk, "stored_keyframes": sp.D,
+           "n_ranks": e.world, "collective_backend": e.backend,
+           "parallelism": ("single GPU, no collective" if e.world == 1 else
+                           "camera-major image slabs x%d + 1 all-gather of descriptor blocks per step (%d KiB per rank) + (frame, keyframe) pairs sharded x%d"
+                           % (e.world, job.lay.send_bytes // 1024, e.world))}
+    out = {"metric": "Mfeatures/s extract+match, %d-cam %dx%d multi-frame" % (sp.ncam, sp.W, sp.H), "value": round(value, 3), "unit": "Mfeatures/s",
+           "n_gpus": e.world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed_max / steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u8+i32 (images, Hamming) / f64 (omni model)", "data": "synthetic", "config": cfg, "roofline": roof}
+    return job, out
+
+
+# ------------------------------------------------------------------------------------------------ end-to-end (host buffers in and out)
+def run_e2e(e, sp, steps, warmup):
+    """The same step with the boundary's host buffers: images start in page-locked host memory (double-buffered H2D on a copy stream), keypoints,
+    descriptor | mask blocks, counts and match arrays end in page-locked host memory (D2H on a second copy stream), both overlapped with the compute of
+    the neighbouring steps.  N = 1 only."""
+    torch = e.torch
+    job = Job(e, sp, n_image_buffers=2)
+    cin, cout = torch.cuda.Stream(device=e.dev), torch.cuda.Stream(device=e.dev)
+    h_img = [torch.from_numpy(job.imgs_np.copy()).pin_memory() for _ in range(2)]
+    outs = []
+    for b in job.sets:
+        outs.append([(t, torch.empty(t.shape, dtype=t.dtype).pin_memory()) for t in (b.send, b.nkp, b.kps, b.match, b.nmatch)])
+    ev_in = [torch.cuda.Event() for _ in range(2)]
+    ev_free = [torch.cuda.Event() for _ in range(2)]      # compute no longer reads image buffer i
+    ev_done = [torch.cuda.Event() for _ in range(2)]      # outputs of buffer set i complete
+    ev_out = [torch.cuda.Event() for _ in range(2)]       # outputs of buffer set i copied out
+    state = {"i": 0}
+
+    def upload(i):   # images of buffer i: page-locked host memory -> device, on the copy stream, once the kernels no longer read the buffer
+        with torch.cuda.stream(cin):
+            cin.wait_event(ev_free[i])
+            job.d_imgs[i].copy_(h_img[i], non_blocking=True)
+            ev_in[i].record(cin)
 
     def step():
-        for sb in subs:
-            sb.step()
+        i = state["i"] & 1
+        state["i"] += 1
+        e.stream.wait_event(ev_in[i])                     # this step's images (uploaded while the previous step computed)
+        e.stream.wait_event(ev_out[job.cur])              # the output set about to be overwritten has been copied out
+        k = job.cur
+        job.step(i)
+        ev_free[i].record(e.stream)
+        upload(i ^ 1)                                     # the next step's images travel while this step computes
+        e.mcs.check(e.lib.mcs_ctx_join(e.ctx.h))          # match arrays are written on the library's side stream
+        ev_done[k].record(e.stream)
+        with torch.cuda.stream(cout):
+            cout.wait_event(ev_done[k])
+            for src, dst in outs[k]:
+                dst.copy_(src, non_blocking=True)
+            ev_out[k].record(cout)
 
-    def status():
-        for sb in subs:
-            sb.ex.status()
-
-    elapsed = timed(e, step, args.warmup, args.steps, status)
-    feats_step = sum(int(sb.last().nkp[NCAM:].sum().item()) for sb in subs)
-    matches_step = sum(int(sb.last().nmatch.sum().item()) for sb in subs)
-    fallbacks = sum(int(sb.last().fb.sum().item()) for sb in subs)
-    if os.environ.get("MCS_BENCH_DEBUG"):
-        print("rank %d: %.3f ms/step, %d features/step" % (e.rank, elapsed / args.steps * 1e3, feats_step), file=sys.stderr)
-    elapsed_max, feats_all = e.rig.reduce_timing(elapsed, feats_step, e.red_dev, e.world)
-    d_nkp, d_desc, d_dmask = subs[0].last().nkp, subs[0].last().desc, subs[0].last().dmask
-    ex = subs[0].ex
-    # per-kernel times for the roofline block are measured on ONE stream over the whole batch (so kernels are timed alone)
-    if S == 1:
-        full = subs[0]
-    elif e.rank == 0:
-        full = Sub(0, F, ctx, e.stream)
-        full.step()
-    kstep = (lambda: full.step()) if (S == 1 or e.rank == 0) else None
-
-    roof = check = cpu = None
-    if e.rank == 0:
-        roof = roofline(kernel_times(e, kstep), args.mode, nimg, feats_step, ex.level_sizes, nfeat)
-    if args.check and e.rank == 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O
-        nk, dd, mm = d_nkp.cpu().numpy(), d_desc.cpu().numpy(), d_dmask.cpu().numpy()
-        ok, f = True, 1
-        for c in range(NCAM):
-            _, od, om = O.Extractor(nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)(imgs_np[f * NCAM + c], masks_np[c], O.make_ocam(cams[c]))
-            i = (f + 1) * NCAM + c
-            ok = ok and nk[i] == len(od) and (dd[i * cap:i * cap + len(od)] == od).all() and (mm[i * cap:i * cap + len(od)] == om).all()
-        check = bool(ok)
-    if e.rank == 0 and e.world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, pool, POOL, cams, NCAM, W, H, nfeat, do_db, masks_on, synth)
-    if e.rank == 0:
-        value = feats_all * args.steps / elapsed_max / 1e6
-        out = {"metric": "Mfeatures/s extract+match, 3-cam 754x480 multi-frame", "value": round(value, 3), "unit": "Mfeatures/s", "n_gpus": e.world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "u8+i32 (images, Hamming) / f64 (omni model)", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[1]: 3-camera 754x480 multi-frames, %s extract (N=%d, 8 levels, FAST 20) + cORBmatcher BF-Hamming "
-                                      "SearchByBoW(KF,KF) vs the previous multi-frame, %d multi-frames (%d images) per step per GPU, inputs resident in HBM"
-                                      % (args.mode, nfeat, F, nimg), "multi_frames_per_step_per_gpu": F, "features_per_step": int(feats_all),
-                          "matches_per_step_rank0": matches_step, "greedy_rescans_rank0": fallbacks, "topk": args.topk, "substreams_per_gpu": S,
-                          "parallelism": "stream-shard x%d" % e.world},
-               "roofline": roof, "cpu_baseline": cpu}
-        if check is not None:
-            out["oracle_check"] = check
-        if cpu:
-            out["speedup_vs_cpu_all_cores"] = round(value / cpu["value"], 2)
-        print(json.dumps(out))
+    for ev in ev_free + ev_out:
+        ev.record(e.stream)
+    upload(0)
+    elapsed = timed(e, step, warmup, steps, job.status)
+    feats = job.local_features()
+    h2d = job.imgs_np.nbytes
+    d2h = sum(dst.numel() * dst.element_size() for _, dst in outs[0])
+    job.close()
+    return {"value": round(feats * steps / elapsed / 1e6, 3), "unit": "Mfeatures/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "h2d_bytes_per_step": int(h2d), "d2h_bytes_per_step": int(d2h),
+            "what": "host buffers at the boundary: images H2D from page-locked memory (double-buffered, copy stream), keypoints + descriptor|mask blocks + counts + "
+                    "match arrays D2H to page-locked memory (second copy stream), overlapped with the neighbouring steps' kernels"}
 
 
-def cpu_baseline(args, pool, POOL, cams, NCAM, W, H, nfeat, do_db, masks_on, synth):
+# ------------------------------------------------------------------------------------------------ oracle legs
+def check_against_oracle(e, sp, job):
+    """one multi-frame of the timed output (descriptors, masks, counts) and the match indices of one pair, bit for bit"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    lay, rig = job.lay, e.rig
+    do_db, masks_on = MODES[sp.mode]
+    b = job.last()
+    e.torch.cuda.synchronize(e.dev)
+    G = b.G.cpu().numpy().reshape(lay.images_total, lay.rows_img, lay.row_stride)
+    ok = True
+    want = {}
+    for f in (1, 0):
+        d, m, v = rig.unpack_frame(lay, G, f)
+        want[f] = (d, m, v)
+        for c in range(sp.ncam):
+            _, od, om = O.Extractor(nfeatures=sp.nfeat, do_dBrief=do_db, learnMasks=masks_on)(e.synth.synth_image(f % POOL, c, job.cams[c]),
+                                                                                               e.synth.mirror_mask(job.cams[c]), O.make_ocam(job.cams[c]))
+            lo = c * lay.cap
+            ok = ok and int(v[lo:lo + lay.cap].sum()) == len(od) and (d[lo:lo + len(od)] == od).all() and (m[lo:lo + len(od)] == om).all()
+    if sp.D == 0 and e.rank == 0:
+        # pair (frame 1, frame 0) is set 1 of rank 0's ring call
+        (d1, m1, v1), (d0, m0, v0) = want[1], want[0]
+        ones = np.full_like(d1, 255)
+        n, m12 = O.search_kf_kf(d1, m1 if masks_on else ones, v1, d0, m0 if masks_on else ones, v0, bool(masks_on), 0.9)
+        got = b.match.cpu().numpy().reshape(sp.F, lay.rows_frame)[1]
+        ok = ok and n == int(b.nmatch[1].item()) and np.array_equal(got, m12)
+    return bool(ok)
+
+
+def cpu_baseline(args, e, sp, job):
     """The oracle (kind 'port') timed on this box's host cores on a bounded sample of the same stream."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
+    synth = e.synth
+    do_db, masks_on = MODES[sp.mode]
+    NCAM, W, H, nfeat = sp.ncam, sp.W, sp.H, sp.nfeat
     nproc = os.cpu_count() or 1
     quota = nproc            # CPU time this process may actually use: cgroup v2 cpu.max (the GPU box grants 16 of its 256 hardware threads)
     try:
@@ -337,11 +485,12 @@ def cpu_baseline(args, pool, POOL, cams, NCAM, W, H, nfeat, do_db, masks_on, syn
     except (OSError, ValueError):
         pass
     nf = args.cpu_frames or max(48, 3 * quota)
+    pool = [[synth.synth_image(f, c, job.cams[c]) for c in range(NCAM)] for f in range(POOL)]
     flat = [np.ascontiguousarray(pool[f % POOL][c]) for f in range(nf) for c in range(NCAM)]
-    mk = [np.ascontiguousarray(synth.mirror_mask(cams[c])) for c in range(NCAM)]
+    mk = [np.ascontiguousarray(synth.mirror_mask(job.cams[c])) for c in range(NCAM)]
     iptr = (C.c_void_p * len(flat))(*[a.ctypes.data for a in flat])
     mptr = (C.c_void_p * len(flat))(*[mk[i % NCAM].ctypes.data for i in range(len(flat))])
-    ocs = (O.Ocam * len(flat))(*[O.make_ocam(cams[i % NCAM]) for i in range(len(flat))])
+    ocs = (O.Ocam * len(flat))(*[O.make_ocam(job.cams[i % NCAM]) for i in range(len(flat))])
     prm = O.make_params(nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)
     nmatch = (C.c_int * nf)()
     secs = (C.c_double * 2)()
@@ -366,114 +515,58 @@ def cpu_baseline(args, pool, POOL, cams, NCAM, W, H, nfeat, do_db, masks_on, syn
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import ref_compare as R
-            msk = [np.ascontiguousarray(m) for m in mk]
             t0 = time.perf_counter()
             for i in range(6):
-                R.run_ref(flat[i], msk[i % NCAM], cams[i % NCAM], nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)
+                R.run_ref(flat[i], mk[i % NCAM], job.cams[i % NCAM], nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)
             t1 = time.perf_counter()
             exo = [O.Extractor(nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on) for _ in range(NCAM)]
             for i in range(6):
-                exo[i % NCAM](flat[i], msk[i % NCAM], O.make_ocam(cams[i % NCAM]))
+                exo[i % NCAM](flat[i], mk[i % NCAM], O.make_ocam(job.cams[i % NCAM]))
             t2 = time.perf_counter()
             side = {"reference_sources_ms_per_image_1thread": round((t1 - t0) / 6 * 1e3, 1), "port_ms_per_image_1thread": round((t2 - t1) / 6 * 1e3, 1)}
-        except Exception as e:   # the side measurement is optional
-            side = {"error": str(e)[:120]}
-    return {"extract_1thread": side,"value": round(per_frame * (nf - 1) / wall / 1e6, 4), "unit": "Mfeatures/s", "cores": threads, "kind": "port",
+        except Exception as ex:   # the side measurement is optional
+            side = {"error": str(ex)[:120]}
+    return {"extract_1thread": side, "value": round(per_frame * (nf - 1) / wall / 1e6, 4), "unit": "Mfeatures/s", "cores": threads, "kind": "port",
             "sample": "%d multi-frames (%d images) of the same synthetic stream: oracle extract (%s) %.2fs + SearchByBoW(KF,KF) vs previous frame %.2fs wall, "
                       "OpenMP over images/frames on %d threads (cgroup CPU quota of this box: %d of %d hardware threads; best of quota and 2x quota, 2 passes each)"
-                      % (nf, nf * NCAM, args.mode, se, sm, threads, quota, nproc),
+                      % (nf, nf * NCAM, sp.mode, se, sm, threads, quota, nproc),
             "cpu_model": cpu_model(), "cpu_quota": quota, "nproc": nproc}
 
 
-# ------------------------------------------------------------------------------------------------ rig workload
-def run_rig(args, e):
-    torch, mcs, synth, lib, ctx, dev, rig = e.torch, e.mcs, e.synth, e.lib, e.ctx, e.dev, e.rig
-    W, H, NCAM = 1280, 800, 6
-    F = args.frames or 4
-    nfeat = args.nfeatures or 2000
-    do_db, masks_on = MODES[args.mode]
-    cams = [synth.scaled_camera(c, W, H) for c in synth.lafida_cameras()]
-    mine = rig.camera_shard(NCAM, e.rank, e.world)
-    lc = len(mine)
-    nimg = F * max(lc, 1)
-    imgs_np = np.stack([synth.synth_image(f, c, cams[c % 3]) for f in range(F) for c in mine]) if lc else np.zeros((1, H, W), np.uint8)
-    masks_np = np.stack([synth.mirror_mask(cams[c % 3]) for _ in range(F) for c in mine]) if lc else np.zeros((1, H, W), np.uint8)
-    ex = mcs.Extractor(ctx, W, H, max_batch=nimg, nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)
-    cap, ds = ex.cap, 32
-    d_imgs, d_masks = torch.from_numpy(imgs_np).to(dev), torch.from_numpy(masks_np).to(dev)
-    camarr = (mcs.Ocam * nimg)(*[mcs.make_ocam(cams[mine[i % lc] % 3] if lc else cams[0]) for i in range(nimg)])
-    d_nkp = torch.zeros((F, max(lc, 1)), dtype=torch.int32, device=dev)
-    d_kps = torch.zeros((nimg * cap, 7), dtype=torch.float32, device=dev)
-    d_desc = torch.zeros((F, max(lc, 1), cap, ds), dtype=torch.uint8, device=dev)
-    d_dmask = torch.zeros_like(d_desc)
-    rows_f = NCAM * cap
-    # keyframe database shard of this rank (contents: earlier synthetic multi-frames, filled by one untimed pass below)
-    kfs = rig.keyframe_shard(args.keyframes, e.rank, e.world)
-    nk = max(len(kfs), 1)
-    db_desc = torch.zeros((nk, rows_f, ds), dtype=torch.uint8, device=dev)
-    db_mask = torch.zeros_like(db_desc)
-    db_valid = torch.zeros((nk, rows_f), dtype=torch.uint8, device=dev)
-    d_valid = torch.zeros((F, rows_f), dtype=torch.uint8, device=dev)
-    d_matchF = torch.full((F, nk, rows_f), -1, dtype=torch.int32, device=dev)
-    d_nm = torch.zeros((F, nk), dtype=torch.int32, device=dev)
-    d_fb = torch.zeros((F, nk), dtype=torch.int32, device=dev)
-    state = {}
-
-    def extract_and_gather():
-        if lc:
-            ex.extract_device(nimg, d_imgs.data_ptr(), W * H, W, d_masks.data_ptr(), W * H, W, camarr, d_nkp.data_ptr(), d_kps.data_ptr(), d_desc.data_ptr(),
-                              d_dmask.data_ptr(), None)
-        ad, am, an = rig.allgather_rig(d_desc[:, :lc], d_dmask[:, :lc], d_nkp[:, :lc], NCAM, e.rank, e.world)   # the one exchange step
-        ad, am, an = ad.contiguous(), am.contiguous(), an.contiguous()
-        mcs.check(lib.mcs_rows_valid(ctx.h, C.c_void_p(an.data_ptr()), F * NCAM, cap, C.c_void_p(d_valid.data_ptr())))
-        state.update(ad=ad, am=am, an=an)
-        return ad, am, an
-
-    def step():
-        ad, am, an = extract_and_gather()
-        if not kfs:
-            return
-        for f in range(F):   # every multi-frame against every keyframe of this rank's shard: one launch per multi-frame
-            qs = mcs.DescSet(db_desc.data_ptr(), db_mask.data_ptr() if masks_on else None, db_valid.data_ptr(), None, rows_f, ds)
-            ts = mcs.DescSet(ptr(ad.view(F * rows_f, ds), f * rows_f), ptr(am.view(F * rows_f, ds), f * rows_f) if masks_on else None,
-                             ptr(d_valid.view(-1), f * rows_f), None, rows_f, ds)
-            mcs.check(lib.mcs_search_kf_f(ctx.h, len(kfs), C.byref(qs), rows_f, C.byref(ts), 0, ds, 0.9, args.topk, mcs.MEM_DEVICE,
-                                          C.c_void_p(d_matchF[f].data_ptr()), C.c_void_p(d_nm[f].data_ptr()), C.c_void_p(d_fb[f].data_ptr())))
-
-    ad, am, an = extract_and_gather()   # untimed: fill the database shard with the extracted multi-frames (cyclically)
-    torch.cuda.synchronize(dev)
-    for j, _k in enumerate(kfs):
-        f = j % F
-        db_desc[j].copy_(ad[f].reshape(rows_f, ds))
-        db_mask[j].copy_(am[f].reshape(rows_f, ds))
-        db_valid[j].copy_(d_valid[f])
-    elapsed = timed(e, step, args.warmup, args.steps, ex.status)
-    feats_step = int(state["an"].sum().item())        # identical on every rank (gathered): counted once
-    nq = int(db_valid.sum().item()) if kfs else 0                     # keyframe features of this rank's shard (queries)
-    pairs_local = float(nq) * float(state["an"].sum().item())         # x frame features of the F multi-frames of a step
-    elapsed_max, pairs_all = rig.reduce_timing(elapsed, pairs_local, e.red_dev, e.world)
-    kern = kernel_times(e, step)   # every rank: step() contains the all-gather (a collective), so all ranks must keep calling it
-    if e.rank == 0:
-        value = feats_step * args.steps / elapsed_max / 1e6
-        out = {"metric": "Mfeatures/s extract+match, 6-cam 1280x800 rig vs keyframe database", "value": round(value, 3), "unit": "Mfeatures/s", "n_gpus": e.world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "u8+i32 (images, Hamming) / f64 (omni model)", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[3]: 6-camera 1280x800 rig, %s extract (N=%d/cam), cameras sharded over %d GPU(s) + RCCL all-gather of "
-                                      "descriptor blocks, SearchByBoW(KF,F) brute force vs %d stored keyframes (sharded), %d multi-frames per step"
-                                      % (args.mode, nfeat, e.world, args.keyframes, F), "features_per_step": feats_step,
-                          "pair_distances_per_step_all_ranks": pairs_all * 1.0, "Gpairs_per_s": round(pairs_all * args.steps / elapsed_max / 1e9, 2),
-                          "parallelism": "camera-shard + keyframe-shard x%d, 1 all-gather/step" % e.world},
-               "roofline": {"per_kernel_ms": {k: round(v, 4) for k, v in kern.items()}}, "cpu_baseline": None}
-        print(json.dumps(out))
+def secondary_args(args, **kw):
+    a = argparse.Namespace(**vars(args))
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
 
 
 def main():
     args = parse()
     e = setup()
-    if args.workload == "stream":
-        run_stream(args, e)
-    else:
-        run_rig(args, e)
+    sp = Spec(args, e.world)
+    job, out = run_job(e, sp, args, args.steps, args.warmup)
+    headline = args.workload == "stream" and args.mode == "mdbrief" and not (args.ncam or args.width or args.height or args.nfeatures or args.keyframes >= 0)
+    if args.check and e.rank == 0:
+        out["oracle_check"] = check_against_oracle(e, sp, job)
+    cpu = None
+    if e.rank == 0 and e.world == 1 and headline and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, e, sp, job)
+    out["cpu_baseline"] = cpu
+    if cpu:
+        out["speedup_vs_cpu_all_cores"] = round(out["value"] / cpu["value"], 2)
+    job.close()
+    if e.world == 1 and headline and not args.no_secondary:
+        # further legs of the default run, each bounded: host buffers at the boundary; the matcher-dominated BASELINE configs[2]; the reference's shipped settings
+        s2 = min(args.steps, 10)
+        out["e2e"] = run_e2e(e, sp, args.steps, args.warmup)
+        sec = []
+        for a in (secondary_args(args, workload="db", frames=16), secondary_args(args, mode="orb", nfeatures=400)):
+            j2, o2 = run_job(e, Spec(a, e.world), a, s2, 2)
+            j2.close()
+            sec.append({k: o2[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline")})
+        out["secondary"] = sec
+    if e.rank == 0:
+        print(json.dumps(out))
     if e.world > 1:
         e.dist.barrier()
         e.dist.destroy_process_group()

@@ -138,6 +138,16 @@ class Extractor:
                                       C.c_void_p(nkp_ptr), C.c_void_p(kps_ptr), C.c_void_p(desc_ptr), C.c_void_p(dmask_ptr),
                                       C.c_void_p(rays_ptr) if rays_ptr else None))
 
+    def extract_strided(self, n, images_ptr, image_pitch, image_stride, masks_ptr, mask_pitch, mask_stride, cams, nkp_ptr, kps_ptr, desc_ptr, dmask_ptr,
+                        rays_ptr, out_image_pitch_rows, out_row_stride):
+        """extract_device with the descriptor / mask rows written at (image * out_image_pitch_rows + k) * out_row_stride (the rig's exchange blocks)"""
+        camarr = None
+        if cams is not None:
+            camarr = cams if isinstance(cams, C.Array) else (Ocam * n)(*cams)
+        check(lib().mcs_extract_batch_strided(self.h, n, C.c_void_p(images_ptr), image_pitch, image_stride, C.c_void_p(masks_ptr) if masks_ptr else None,
+                                              mask_pitch, mask_stride, camarr, C.c_void_p(nkp_ptr), C.c_void_p(kps_ptr), C.c_void_p(desc_ptr),
+                                              C.c_void_p(dmask_ptr), C.c_void_p(rays_ptr) if rays_ptr else None, out_image_pitch_rows, out_row_stride))
+
     def status(self):
         check(lib().mcs_extractor_status(self.h))
 

@@ -46,7 +46,7 @@ class ExtractorParams(C.Structure):
 
 class DescSet(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("mask", C.c_void_p), ("valid", C.c_void_p), ("group", C.c_void_p), ("n", C.c_int32),
-                ("stride", C.c_int32)]
+                ("stride", C.c_int32), ("block_rows", C.c_int32), ("block_pitch_rows", C.c_int64)]
 
 
 def make_ocam(cam):
@@ -68,8 +68,8 @@ EXPORTS = [
     "mcs_extractor_tap_level", "mcs_extractor_tap_candidates", "mcs_extractor_tap_selected", "mcs_match_topk",
     "mcs_match_topk_batched", "mcs_descriptor_distance", "mcs_descriptor_distance_masked", "mcs_ctx_enable_timing",
     "mcs_ctx_kernel_ms", "mcs_ctx_join", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_search_kf_f_sweep",
-    "mcs_search_triangulation_sweep", "mcs_rows_valid", "mcs_extractor_set_describe", "mcs_extractor_describe_stats", "mcs_describe_fast_bound",
-    "mcs_selftest_describe_fast",
+    "mcs_search_triangulation_sweep", "mcs_search_kf_kf_ring", "mcs_rows_valid", "mcs_extractor_set_describe", "mcs_extractor_describe_stats", "mcs_describe_fast_bound",
+    "mcs_selftest_describe_fast", "mcs_extract_batch_strided", "mcs_rig_pack_headers", "mcs_rig_rows_valid",
     "mcs_search_by_projection", "mcs_window_match", "mcs_window_best", "mcs_rotation_consistency", "mcs_world_to_cam", "mcs_distinctive_descriptors", "mcs_selftest_shared_reciprocal", "mcs_vocabulary_create", "mcs_vocabulary_destroy", "mcs_bow_transform",
 ]
 
@@ -122,6 +122,9 @@ def lib():
     L.mcs_describe_fast_bound.argtypes = [C.POINTER(Ocam), C.c_int, C.POINTER(C.c_double)]
     L.mcs_selftest_describe_fast.argtypes = [vp, C.POINTER(Ocam), C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.mcs_extract_batch.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.mcs_extract_batch_strided.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_int]
+    L.mcs_rig_pack_headers.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int]
+    L.mcs_rig_rows_valid.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.mcs_extractor_tap_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     L.mcs_extractor_tap_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, i32p]
     L.mcs_extractor_tap_selected.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, i32p]
@@ -133,6 +136,7 @@ def lib():
     L.mcs_search_kf_f.argtypes = srch
     L.mcs_search_triangulation.argtypes = [vp, C.c_int, C.POINTER(DescSet), C.c_size_t, C.POINTER(DescSet), C.c_size_t, vp, vp, vp, C.c_int,
                                            C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.mcs_search_kf_kf_ring.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(DescSet), C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_int, vp, vp, vp]
     L.mcs_search_kf_f_sweep.argtypes = [vp, C.c_int, C.POINTER(DescSet), C.c_size_t, C.c_int, C.POINTER(DescSet), C.c_size_t, C.c_int, C.c_double, C.c_int,
                                         C.c_int, vp, vp, vp]
     L.mcs_search_triangulation_sweep.argtypes = [vp, C.c_int, C.POINTER(DescSet), C.c_size_t, C.POINTER(DescSet), C.c_size_t, vp, vp, vp, C.c_size_t,

@@ -407,9 +407,9 @@ static int grow(uint8_t** p, size_t* cap, size_t need) {   // device buffer of a
 	return MCS_OK;
 }
 
-int mcs_extract_batch(mcs_extractor* e, int nimg, const uint8_t* images, size_t image_pitch, int image_stride, const uint8_t* masks,
-                      size_t mask_pitch, int mask_stride, const mcs_ocam* cams, mcs_mem_kind kind, int32_t* nkp, mcs_keypoint* keypoints,
-                      uint8_t* desc, uint8_t* descmask, double* rays) {
+static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_t image_pitch, int image_stride, const uint8_t* masks,
+                        size_t mask_pitch, int mask_stride, const mcs_ocam* cams, mcs_mem_kind kind, int32_t* nkp, mcs_keypoint* keypoints,
+                        uint8_t* desc, uint8_t* descmask, double* rays, size_t out_image_pitch_rows, int out_row_stride) {
 	if (!e || !images || !nkp || !keypoints || !desc || !descmask) return fail(MCS_ERR_INVALID, "null argument");
 	if (nimg < 1 || nimg > e->maxBatch) return fail(MCS_ERR_INVALID, "nimg exceeds the extractor's max_batch");
 	const PyrDesc& hd = e->hd;
@@ -425,6 +425,10 @@ int mcs_extract_batch(mcs_extractor* e, int nimg, const uint8_t* images, size_t 
 	b.pyr = e->d_pyr; b.blur = e->d_blur; b.slots = e->d_slots; b.cellCount = e->d_cellCount; b.dense = e->d_dense; b.knode = e->d_knode;
 	b.denseCount = e->d_denseCount; b.sel = e->d_sel; b.selCount = e->d_selCount; b.status = e->d_status;
 	b.fbCount = e->d_fbCount; b.fbList = e->d_fbList; b.fbStats = e->d_fbStats; b.guardEps = e->guardEps; b.describeMode = e->describeMode;
+	b.outImgPitch = out_image_pitch_rows ? out_image_pitch_rows : (size_t)hd.kpCap;
+	b.outRowStride = out_row_stride ? out_row_stride : hd.descSize;
+	if (b.outImgPitch < (size_t)hd.kpCap || b.outRowStride < hd.descSize) return fail(MCS_ERR_INVALID, "output image pitch / row stride smaller than the rows they hold");
+	if (kind == MCS_MEM_HOST && (b.outImgPitch != (size_t)hd.kpCap || b.outRowStride != hd.descSize)) return fail(MCS_ERR_UNSUPPORTED, "strided descriptor outputs need device memory");
 	if (kind == MCS_MEM_HOST) {
 		// ONE linear copy per block, in the caller's own layout; the kernels take any pitch / stride for level 0.  (A pitched hipMemcpy2D from pageable
 		// host memory is carried out row by row by the runtime: 2 x 480 small transfers per image, ~9 ms per image.)
@@ -496,6 +500,19 @@ int mcs_extract_batch(mcs_extractor* e, int nimg, const uint8_t* images, size_t 
 		if (st != 0) { (void)hipMemset(e->d_status, 0, sizeof(int)); return fail(st, "device capacity exceeded during extraction"); }
 	}
 	return MCS_OK;
+}
+
+int mcs_extract_batch(mcs_extractor* e, int nimg, const uint8_t* images, size_t image_pitch, int image_stride, const uint8_t* masks,
+                      size_t mask_pitch, int mask_stride, const mcs_ocam* cams, mcs_mem_kind kind, int32_t* nkp, mcs_keypoint* keypoints,
+                      uint8_t* desc, uint8_t* descmask, double* rays) {
+	return extract_impl(e, nimg, images, image_pitch, image_stride, masks, mask_pitch, mask_stride, cams, kind, nkp, keypoints, desc, descmask, rays, 0, 0);
+}
+
+int mcs_extract_batch_strided(mcs_extractor* e, int nimg, const uint8_t* images, size_t image_pitch, int image_stride, const uint8_t* masks,
+                              size_t mask_pitch, int mask_stride, const mcs_ocam* cams, int32_t* nkp, mcs_keypoint* keypoints, uint8_t* desc,
+                              uint8_t* descmask, double* rays, size_t out_image_pitch_rows, int out_row_stride) {
+	return extract_impl(e, nimg, images, image_pitch, image_stride, masks, mask_pitch, mask_stride, cams, MCS_MEM_DEVICE, nkp, keypoints, desc, descmask, rays,
+	                    out_image_pitch_rows, out_row_stride);
 }
 
 int mcs_extractor_status(mcs_extractor* e) {

@@ -8,6 +8,8 @@
 namespace mcs {
 void launch_single_distance(const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out, hipStream_t s);
 void launch_rows_valid(const int* nkp, int nimg, int cap, uint8_t* valid, hipStream_t s);
+void launch_rig_pack_headers(const int* nkp, int nimg, int cap, uint8_t* blocks, int rowStride, hipStream_t s);
+void launch_rig_rows_valid(const uint8_t* blocks, int nimg, int cap, int rowStride, uint8_t* valid, int* nkpOut, hipStream_t s);
 }
 using namespace mcs;
 
@@ -30,9 +32,15 @@ static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 // How the nsets (query set, train set) pairs of one call map onto the caller's arrays: pair s reads query set (s % qmod) and train set (s / tdiv);
 // nq_sets / nt_sets = number of distinct sets behind each pointer (what a host-kind call has to stage).
-struct SetGrid { int nsets, qmod, tdiv, nq_sets, nt_sets; };
-static SetGrid grid_batched(int nsets, size_t qpitch, size_t tpitch) { return SetGrid{nsets, nsets, 1, qpitch ? nsets : 1, tpitch ? nsets : 1}; }
-static SetGrid grid_sweep(int nq_sets, int nt_sets) { return SetGrid{nq_sets * nt_sets, nq_sets, nq_sets, nq_sets, nt_sets}; }
+struct SetGrid { int nsets, qmod, tdiv, nq_sets, nt_sets; int toff = 0, tmod = 0x7FFFFFFF; };
+static size_t set_span(const mcs_desc_set* d) {   // rows from a set's first to one past its last row
+	if (d->block_rows == 0 || d->n == 0) return (size_t)d->n;
+	return (size_t)(d->n / d->block_rows - 1) * (size_t)d->block_pitch_rows + (size_t)d->block_rows;
+}
+static SetGrid grid_batched(int nsets, size_t qpitch, size_t tpitch) { SetGrid g; g.nsets = nsets; g.qmod = nsets; g.tdiv = 1; g.nq_sets = qpitch ? nsets : 1; g.nt_sets = tpitch ? nsets : 1; return g; }
+static SetGrid grid_sweep(int nq_sets, int nt_sets) { SetGrid g; g.nsets = nq_sets * nt_sets; g.qmod = nq_sets; g.tdiv = nq_sets; g.nq_sets = nq_sets; g.nt_sets = nt_sets; return g; }
+// pairs (frame first + s, its predecessor in a ring of `total` frames), s = 0 .. count-1; both pointers at frame 0 of the ring
+static SetGrid grid_ring(int total, int first, int count) { SetGrid g; g.nsets = count; g.qmod = count; g.tdiv = 1; g.nq_sets = total; g.nt_sets = total; g.toff = first + total - 1; g.tmod = total; return g; }
 
 static int validate_sets(mcs_ctx* c, int nsets, const mcs_desc_set* q, const mcs_desc_set* t, int dim, int K) {
 	if (!c || !q || !t) return fail(MCS_ERR_INVALID, "null argument");
@@ -42,6 +50,9 @@ static int validate_sets(mcs_ctx* c, int nsets, const mcs_desc_set* q, const mcs
 	if (q->stride < dim || t->stride < dim || (q->stride & 3) || (t->stride & 3)) return fail(MCS_ERR_INVALID, "descriptor stride must be >= dim and a multiple of 4");
 	if ((q->mask == nullptr) != (t->mask == nullptr)) return fail(MCS_ERR_INVALID, "masks must be given for both sets or neither");
 	if ((q->n > 0 && !q->desc) || (t->n > 0 && !t->desc)) return fail(MCS_ERR_INVALID, "null descriptors");
+	for (const mcs_desc_set* d : {q, t})
+		if (d->block_rows != 0 && (d->block_rows < 1 || d->n % d->block_rows != 0 || d->block_pitch_rows < d->block_rows))
+			return fail(MCS_ERR_INVALID, "block_rows must divide n and block_pitch_rows must be >= block_rows");
 	return MCS_OK;
 }
 
@@ -54,14 +65,16 @@ static int stage_sets(mcs_ctx* c, const SetGrid& sg, const mcs_desc_set* q, size
 		return MCS_OK;
 	}
 	hipStream_t s = c->stream;
-	const size_t qRows = qpitch * (sg.nq_sets - 1) + q->n, tRows = tpitch * (sg.nt_sets - 1) + t->n;
+	const size_t qRows = qpitch * (sg.nq_sets - 1) + set_span(q), tRows = tpitch * (sg.nt_sets - 1) + set_span(t);
 	size_t need = 0;
 	const size_t oQd = need; need += al256(qRows * q->stride);
-	const size_t oQm = need; need += q->mask ? al256(qRows * q->stride) : 0;
+	// descriptor | mask interleaved in one row (the rig's exchange blocks): the mask rides along with the descriptor copy
+	const bool qInter = q->mask && q->mask > q->desc && q->mask - q->desc < q->stride, tInter = t->mask && t->mask > t->desc && t->mask - t->desc < t->stride;
+	const size_t oQm = need; need += (q->mask && !qInter) ? al256(qRows * q->stride) : 0;
 	const size_t oQv = need; need += q->valid ? al256(qRows) : 0;
 	const size_t oQg = need; need += q->group ? al256(qRows * 4) : 0;
 	const size_t oTd = need; need += al256(tRows * t->stride);
-	const size_t oTm = need; need += t->mask ? al256(tRows * t->stride) : 0;
+	const size_t oTm = need; need += (t->mask && !tInter) ? al256(tRows * t->stride) : 0;
 	const size_t oTv = need; need += t->valid ? al256(tRows) : 0;
 	const size_t oTg = need; need += t->group ? al256(tRows * 4) : 0;
 	const size_t oR1 = need; need += (rays1 && *rays1) ? al256(qRows * 24) : 0;
@@ -73,16 +86,16 @@ static int stage_sets(mcs_ctx* c, const SetGrid& sg, const mcs_desc_set* q, size
 	PinnedUpload up;   // all inputs in one H2D copy (every host-kind search ends with a stream synchronisation)
 	HIPCHK(up.begin(c, st, need));
 	if (qRows) up.put(oQd, q->desc, qRows * q->stride);
-	if (q->mask && qRows) up.put(oQm, q->mask, qRows * q->stride);
+	if (q->mask && !qInter && qRows) up.put(oQm, q->mask, qRows * q->stride);
 	if (q->valid && qRows) up.put(oQv, q->valid, qRows);
 	if (q->group && qRows) up.put(oQg, q->group, qRows * 4);
 	if (tRows) up.put(oTd, t->desc, tRows * t->stride);
-	if (t->mask && tRows) up.put(oTm, t->mask, tRows * t->stride);
+	if (t->mask && !tInter && tRows) up.put(oTm, t->mask, tRows * t->stride);
 	if (t->valid && tRows) up.put(oTv, t->valid, tRows);
 	if (t->group && tRows) up.put(oTg, t->group, tRows * 4);
-	out->qd = st + oQd; out->qm = q->mask ? st + oQm : nullptr; out->qvalid = q->valid ? st + oQv : nullptr;
+	out->qd = st + oQd; out->qm = q->mask ? (qInter ? st + oQd + (q->mask - q->desc) : st + oQm) : nullptr; out->qvalid = q->valid ? st + oQv : nullptr;
 	out->qgroup = q->group ? (const int*)(st + oQg) : nullptr;
-	out->td = st + oTd; out->tm = t->mask ? st + oTm : nullptr; out->tvalid = t->valid ? st + oTv : nullptr;
+	out->td = st + oTd; out->tm = t->mask ? (tInter ? st + oTd + (t->mask - t->desc) : st + oTm) : nullptr; out->tvalid = t->valid ? st + oTv : nullptr;
 	out->tgroup = t->group ? (const int*)(st + oTg) : nullptr;
 	if (rays1 && *rays1) { if (qRows) up.put(oR1, *rays1, qRows * 24); *rays1 = (const double*)(st + oR1); }
 	if (rays2 && *rays2) { if (tRows) up.put(oR2, *rays2, tRows * 24); *rays2 = (const double*)(st + oR2); }
@@ -102,6 +115,8 @@ static int run_topk(mcs_ctx* c, const DevSets& d, const SetGrid& sg, const mcs_d
 	a.qd = d.qd; a.qm = d.qm; a.qvalid = d.qvalid; a.qgroup = d.qgroup; a.td = d.td; a.tm = d.tm; a.tvalid = d.tvalid; a.tgroup = d.tgroup;
 	a.nq = q->n; a.nt = t->n; a.qstride = q->stride; a.tstride = t->stride; a.qpitch = qpitch; a.tpitch = tpitch;
 	a.nsets = nsets; a.qmod = sg.qmod; a.tdiv = sg.tdiv; a.dim = dim; a.K = K; a.countThresh = count_thresh;
+	a.qblk = q->block_rows; a.qbpitch = (size_t)q->block_pitch_rows; a.tblk = t->block_rows; a.tbpitch = (size_t)t->block_pitch_rows;
+	a.toff = sg.toff; a.tmod = sg.tmod;
 	const size_t outRows = (size_t)nsets * q->n;
 	const int qTiles = (q->n + 255) / 256;
 	// Train-range splits only where the (set, query tile) grid alone cannot fill the chip (a single keyframe pair: 12 workgroups).  From kFillBlocks
@@ -190,6 +205,8 @@ static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc
 	g.qd = d.qd; g.qm = d.qm; g.qvalid = d.qvalid; g.qgroup = d.qgroup; g.td = d.td; g.tm = d.tm; g.tvalid = d.tvalid; g.tgroup = d.tgroup;
 	g.nq = q->n; g.nt = t->n; g.qstride = q->stride; g.tstride = t->stride; g.qpitch = qpitch; g.tpitch = tpitch;
 	g.nsets = nsets; g.qmod = sg.qmod; g.tdiv = sg.tdiv; g.dim = dim; g.K = K; g.keys = c->topKeys;
+	g.qblk = q->block_rows; g.qbpitch = (size_t)q->block_pitch_rows; g.tblk = t->block_rows; g.tbpitch = (size_t)t->block_pitch_rows;
+	g.toff = sg.toff; g.tmod = sg.tmod;
 	g.thLow = thLow; g.thInclusive = mode == 1 ? 1 : 0; g.ratio = nnratio; g.mode = mode;
 	g.rays1 = rays1; g.rays2 = rays2; g.E = E; g.Epitch = Epitch; g.nrCams = nrCams;
 	const size_t outN = (size_t)nsets * (mode == 1 ? t->n : q->n);
@@ -226,6 +243,21 @@ int mcs_search_kf_kf(mcs_ctx* c, int nsets, const mcs_desc_set* kf1, size_t pitc
 	return search_common(c, 0, grid_batched(nsets, pitch1, pitch2), kf1, pitch1, kf2, pitch2, dim, nnratio, K, kind, nullptr, nullptr, nullptr, 0, 0, match12, nmatches, fallbacks);
 }
 
+int mcs_search_kf_kf_ring(mcs_ctx* c, int nframes_total, int first, int count, const mcs_desc_set* frames, size_t pitch_rows, int dim, double nnratio, int K,
+                          mcs_mem_kind kind, int32_t* match12, int32_t* nmatches, int32_t* fallbacks) {
+	if (nframes_total < 2 || first < 0 || count < 1 || first + count > nframes_total) return fail(MCS_ERR_INVALID, "bad ring range");
+	if (kind != MCS_MEM_DEVICE) return fail(MCS_ERR_UNSUPPORTED, "the ring form takes device memory");
+	if (!frames) return fail(MCS_ERR_INVALID, "null argument");
+	// the query side starts at frame `first`: shift its pointers, the train side stays at frame 0 and is addressed through (first + s - 1) mod total
+	mcs_desc_set q = *frames;
+	const size_t shift = (size_t)first * pitch_rows;
+	q.desc += shift * frames->stride;
+	if (q.mask) q.mask += shift * frames->stride;
+	if (q.valid) q.valid += shift;
+	if (q.group) q.group += shift;
+	return search_common(c, 0, grid_ring(nframes_total, first, count), &q, pitch_rows, frames, pitch_rows, dim, nnratio, K, kind, nullptr, nullptr, nullptr, 0, 0, match12, nmatches, fallbacks);
+}
+
 int mcs_search_kf_f(mcs_ctx* c, int nsets, const mcs_desc_set* kf, size_t pitchKF, const mcs_desc_set* f, size_t pitchF, int dim, double nnratio, int K,
                     mcs_mem_kind kind, int32_t* matchF, int32_t* nmatches, int32_t* fallbacks) {
 	return search_common(c, 1, grid_batched(nsets, pitchKF, pitchF), kf, pitchKF, f, pitchF, dim, nnratio, K, kind, nullptr, nullptr, nullptr, 0, 0, matchF, nmatches, fallbacks);
@@ -234,7 +266,8 @@ int mcs_search_kf_f(mcs_ctx* c, int nsets, const mcs_desc_set* kf, size_t pitchK
 int mcs_search_kf_f_sweep(mcs_ctx* c, int nkf, const mcs_desc_set* kf, size_t pitchKF, int nframes, const mcs_desc_set* f, size_t pitchF, int dim,
                           double nnratio, int K, mcs_mem_kind kind, int32_t* matchF, int32_t* nmatches, int32_t* fallbacks) {
 	if (nkf < 1 || nframes < 1 || (long long)nkf * nframes > (1 << 24)) return fail(MCS_ERR_INVALID, "bad keyframe / frame count");
-	if ((nkf > 1 && pitchKF < (size_t)(kf ? kf->n : 0)) || (nframes > 1 && pitchF < (size_t)(f ? f->n : 0))) return fail(MCS_ERR_INVALID, "set pitch smaller than the set");
+	auto rows_of = [](const mcs_desc_set* d) { return (size_t)(d ? (d->block_rows ? d->block_rows : d->n) : 0); };   // interleaved blocks: only a block must fit
+	if ((nkf > 1 && pitchKF < rows_of(kf)) || (nframes > 1 && pitchF < rows_of(f))) return fail(MCS_ERR_INVALID, "set pitch smaller than the set");
 	return search_common(c, 1, grid_sweep(nkf, nframes), kf, pitchKF, f, pitchF, dim, nnratio, K, kind, nullptr, nullptr, nullptr, 0, 0, matchF, nmatches, fallbacks);
 }
 
@@ -328,6 +361,22 @@ int mcs_rows_valid(mcs_ctx* c, const int32_t* nkp_dev, int nimg, int cap, uint8_
 	if (!c || !nkp_dev || !valid_dev || nimg < 1 || cap < 1) return fail(MCS_ERR_INVALID, "bad argument");
 	HIPCHK(hipSetDevice(c->device));
 	launch_rows_valid(nkp_dev, nimg, cap, valid_dev, c->stream);
+	HIPCHK(hipGetLastError());
+	return MCS_OK;
+}
+
+int mcs_rig_pack_headers(mcs_ctx* c, const int32_t* nkp_dev, int nimg, int cap, uint8_t* blocks_dev, int row_stride) {
+	if (!c || !nkp_dev || !blocks_dev || nimg < 1 || cap < 1 || row_stride < 4 || (row_stride & 3)) return fail(MCS_ERR_INVALID, "bad argument");
+	HIPCHK(hipSetDevice(c->device));
+	launch_rig_pack_headers(nkp_dev, nimg, cap, blocks_dev, row_stride, c->stream);
+	HIPCHK(hipGetLastError());
+	return MCS_OK;
+}
+
+int mcs_rig_rows_valid(mcs_ctx* c, const uint8_t* blocks_dev, int nimg, int cap, int row_stride, uint8_t* valid_dev, int32_t* nkp_out_dev) {
+	if (!c || !blocks_dev || !valid_dev || nimg < 1 || cap < 1 || row_stride < 4 || (row_stride & 3)) return fail(MCS_ERR_INVALID, "bad argument");
+	HIPCHK(hipSetDevice(c->device));
+	launch_rig_rows_valid(blocks_dev, nimg, cap, row_stride, valid_dev, nkp_out_dev, c->stream);
 	HIPCHK(hipGetLastError());
 	return MCS_OK;
 }

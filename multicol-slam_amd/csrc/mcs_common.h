@@ -91,6 +91,7 @@ struct ExtractBuffers {
 	int describeMode;                    // 0 fast + exact fallback, 1 exact pass for every keypoint
 	// outputs
 	int* nkp; mcs_keypoint* kps; uint8_t* out_desc; uint8_t* out_mask; double* rays;
+	size_t outImgPitch; int outRowStride;   // descriptor / mask row k of image i at (i * outImgPitch + k) * outRowStride (default kpCap rows, descSize bytes)
 };
 
 __host__ __device__ inline const uint8_t* level_ptr(const ExtractBuffers& b, const PyrDesc& d, int img, int level, int* stride) {
@@ -106,10 +107,23 @@ void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStre
 void launch_blur(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
 void launch_describe(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
 
+// Row i of a descriptor set -> row of the caller's array.  A set is either contiguous (blk = 0) or made of blocks of `blk` rows lying `bpitch` rows
+// apart (mcs_desc_set.block_rows / block_pitch_rows: the cameras of one multi-frame inside a gathered [camera][frame][row] buffer).
+struct RowMap {
+	size_t base; int blk; size_t bpitch;
+	__device__ __forceinline__ size_t operator()(int i) const {
+		if (blk == 0) return base + (size_t)i;
+		const int b = i / blk;
+		return base + (size_t)b * bpitch + (size_t)(i - b * blk);
+	}
+};
+
 struct MatchArgs {
 	const uint8_t* qd; const uint8_t* qm; const uint8_t* qvalid; const int* qgroup; int nq; int qstride; size_t qpitch;
 	const uint8_t* td; const uint8_t* tm; const uint8_t* tvalid; const int* tgroup; int nt; int tstride; size_t tpitch;
 	int nsets; int dim; int K; int countThresh;
+	int qblk, tblk; size_t qbpitch, tbpitch;   // block structure of a set's rows (RowMap), 0 = contiguous
+	int toff, tmod;            // train set of pair s = ((s / tdiv) + toff) % tmod: a ring of multi-frames, each against its predecessor (toff = 0, tmod = INT_MAX otherwise)
 	int qmod, tdiv;            // set s reads query set (s % qmod) and train set (s / tdiv): plain batches qmod = nsets, tdiv = 1; a database sweep of
 	                           // nkf keyframes x nframes frames (s = f*nkf + k) qmod = tdiv = nkf
 	int maxDist;               // rows farther than this never enter a list (INT_MAX for plain top-K)
@@ -127,6 +141,8 @@ struct GreedyArgs {
 	const uint8_t* qd; const uint8_t* qm; const uint8_t* qvalid; const int* qgroup; int nq; int qstride; size_t qpitch;
 	const uint8_t* td; const uint8_t* tm; const uint8_t* tvalid; const int* tgroup; int nt; int tstride; size_t tpitch;
 	int nsets; int dim; int K;
+	int qblk, tblk; size_t qbpitch, tbpitch; // as in MatchArgs
+	int toff, tmod;                          // as in MatchArgs
 	int qmod, tdiv;                          // as in MatchArgs
 	const uint32_t* keys;                    // [nsets][K][nq] packed (dist<<20 | idx) ascending in K, 0xFFFFFFFF = empty
 	int thLow; int thInclusive; double ratio;

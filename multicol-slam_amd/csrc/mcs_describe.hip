@@ -322,8 +322,8 @@ __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int waves
 	const double rayx = kp_.rayx, rayy = kp_.rayy, rayz = kp_.rayz;
 	const Sampler sm = kp_.sm;
 	constexpr int nballots = NB;
-	uint8_t* dout = b.out_desc + ((size_t)img * d.kpCap + out) * d.descSize;
-	uint8_t* mout = b.out_mask + ((size_t)img * d.kpCap + out) * d.descSize;
+	uint8_t* dout = b.out_desc + ((size_t)img * b.outImgPitch + out) * b.outRowStride;
+	uint8_t* mout = b.out_mask + ((size_t)img * b.outImgPitch + out) * b.outRowStride;
 
 	if (MODE == 0) {
 		const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
@@ -673,8 +673,8 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 		}
 	}
 	if (lane == 0) {
-		uint8_t* dout = b.out_desc + ((size_t)kp_.img * d.kpCap + kp_.out) * d.descSize;
-		uint8_t* mout = b.out_mask + ((size_t)kp_.img * d.kpCap + kp_.out) * d.descSize;
+		uint8_t* dout = b.out_desc + ((size_t)kp_.img * b.outImgPitch + kp_.out) * b.outRowStride;
+		uint8_t* mout = b.out_mask + ((size_t)kp_.img * b.outImgPitch + kp_.out) * b.outRowStride;
 #pragma unroll
 		for (int j = 0; j < NB; ++j) {
 			*reinterpret_cast<unsigned long long*>(dout + 8 * j) = bitsMain[j];

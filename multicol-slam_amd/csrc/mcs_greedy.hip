@@ -51,7 +51,7 @@ template <int DW, bool MASKED>
 __global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
 	__shared__ uint32_t matched[kBitmapWords];
 	const int set = blockIdx.x, lane = threadIdx.x;
-	const size_t q0 = (size_t)(set % g.qmod) * g.qpitch, t0 = (size_t)(set / g.tdiv) * g.tpitch;
+	const RowMap QR{(size_t)(set % g.qmod) * g.qpitch, g.qblk, g.qbpitch}, TR{(size_t)((set / g.tdiv + g.toff) % g.tmod) * g.tpitch, g.tblk, g.tbpitch};
 	const int K = g.K;
 	for (int i = lane; i < (g.nt + 31) / 32; i += 64) matched[i] = 0;
 	int* outM = g.outMatch + (size_t)set * (g.mode == 1 ? g.nt : g.nq);
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
 	int nmatches = 0, nfallback = 0;
 
 	for (int i = 0; i < g.nq; ++i) {
-		const bool qok = g.qvalid ? g.qvalid[q0 + i] != 0 : true;   // uniform
+		const bool qok = g.qvalid ? g.qvalid[QR(i)] != 0 : true;   // uniform
 		if (!qok) { if (g.mode != 1 && lane == 0) outM[i] = -1; continue; }
 		int d = 0x7FFFFFFF, idx = -1;
 		if (lane < K) {
@@ -72,18 +72,18 @@ __global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
 		const unsigned long long bal = __ballot(freeE);
 		const int lastIdx = __shfl(idx, K - 1), dK = __shfl(d, K - 1);
 		const bool full = lastIdx >= 0;
-		const int qg = useGroup ? g.qgroup[q0 + i] : 0;
+		const int qg = useGroup ? g.qgroup[QR(i)] : 0;
 
 		// lazily loaded query row for rescans
 		uint32_t q[DW], qm[DW];
 		bool qLoaded = false;
 		auto load_q = [&]() {
 			if (qLoaded) return;
-			const uint32_t* qp = reinterpret_cast<const uint32_t*>(g.qd + (q0 + i) * g.qstride);
+			const uint32_t* qp = reinterpret_cast<const uint32_t*>(g.qd + QR(i) * g.qstride);
 #pragma unroll
 			for (int w = 0; w < DW; ++w) q[w] = qp[w];
 			if (MASKED) {
-				const uint32_t* mp = reinterpret_cast<const uint32_t*>(g.qm + (q0 + i) * g.qstride);
+				const uint32_t* mp = reinterpret_cast<const uint32_t*>(g.qm + QR(i) * g.qstride);
 #pragma unroll
 				for (int w = 0; w < DW; ++w) qm[w] = mp[w];
 			}
@@ -95,10 +95,10 @@ __global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
 			uint32_t a = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
 			for (int j = lane; j < g.nt; j += 64) {
 				if ((matched[j >> 5] >> (j & 31)) & 1u) continue;
-				if (g.tvalid && g.tvalid[t0 + j] == 0) continue;
-				if (useGroup && g.tgroup[t0 + j] != qg) continue;
-				const uint32_t* tp = reinterpret_cast<const uint32_t*>(g.td + (t0 + j) * g.tstride);
-				const uint32_t* mp = MASKED ? reinterpret_cast<const uint32_t*>(g.tm + (t0 + j) * g.tstride) : tp;
+				if (g.tvalid && g.tvalid[TR(j)] == 0) continue;
+				if (useGroup && g.tgroup[TR(j)] != qg) continue;
+				const uint32_t* tp = reinterpret_cast<const uint32_t*>(g.td + TR(j) * g.tstride);
+				const uint32_t* mp = MASKED ? reinterpret_cast<const uint32_t*>(g.tm + TR(j) * g.tstride) : tp;
 				const int dist = hamming_g<DW, MASKED>(q, qm, tp, mp);
 				if (dist > bound) continue;
 				const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)j;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
 			int bestDist = -1, distTh = 0x7FFFFFFF, found = -1;
 			uint32_t lastKey = 0xFFFFFFFFu;
 			bool exhausted = true;   // ran off a full list without a stop condition
-			const double* ray1 = g.rays1 + (q0 + i) * 3;
+			const double* ray1 = g.rays1 + QR(i) * 3;
 			const double* Em = g.E + (size_t)set * g.Epitch + (size_t)9 * ((size_t)qg * g.nrCams + qg);   // same-camera rule: camIdx2 == camIdx1
 			for (int e = 0; e < K; ++e) {
 				const int de = __shfl(d, e), ie = __shfl(idx, e);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
 				if ((matched[ie >> 5] >> (ie & 31)) & 1u) continue;
 				if (bestDist < 0) { bestDist = de; distTh = 2 * de; }
 				if (de > distTh) { exhausted = false; break; }
-				if (check_epipolar(ray1, g.rays2 + (t0 + ie) * 3, Em, 1e-2)) { found = ie; exhausted = false; break; }
+				if (check_epipolar(ray1, g.rays2 + TR(ie) * 3, Em, 1e-2)) { found = ie; exhausted = false; break; }
 			}
 			if (exhausted && full) {
 				for (int guard = 0; guard < g.nt; ++guard) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
 					const int de = (int)(k1 >> 20), ie = (int)(k1 & 0xFFFFFu);
 					if (bestDist < 0) { bestDist = de; distTh = 2 * de; }
 					if (de > distTh) break;
-					if (check_epipolar(ray1, g.rays2 + (t0 + ie) * 3, Em, 1e-2)) { found = ie; break; }
+					if (check_epipolar(ray1, g.rays2 + TR(ie) * 3, Em, 1e-2)) { found = ie; break; }
 					lastKey = k1;
 				}
 			}
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 	__shared__ int reqQ;                                   // query to rescan this round, -1 none, -2 the set is finished
 	__shared__ uint32_t partA[kSpecWaves], partB[kSpecWaves];
 	const int set = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const size_t q0 = (size_t)(set % g.qmod) * g.qpitch, t0 = (size_t)(set / g.tdiv) * g.tpitch;
+	const RowMap QR{(size_t)(set % g.qmod) * g.qpitch, g.qblk, g.qbpitch}, TR{(size_t)((set / g.tdiv + g.toff) % g.tmod) * g.tpitch, g.tblk, g.tbpitch};
 	constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 	for (int i = threadIdx.x; i < (g.nt + 31) / 32; i += 64 * kSpecWaves) matched[i] = 0;
 	for (int i = threadIdx.x; i < g.nt; i += 64 * kSpecWaves) claim[i] = 0xFFFFFFFFu;
@@ -233,21 +233,21 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 	// free eligible rows; TRI: its smallest candidate key and its smallest candidate key that passes the epipolar test.
 	auto scan_slice = [&](int qi) {
 		uint32_t q[DW], qm[DW];
-		const uint32_t* qp = reinterpret_cast<const uint32_t*>(g.qd + (q0 + qi) * g.qstride);
+		const uint32_t* qp = reinterpret_cast<const uint32_t*>(g.qd + QR(qi) * g.qstride);
 #pragma unroll
 		for (int w = 0; w < DW; ++w) q[w] = qp[w];
 		if (MASKED) {
-			const uint32_t* mp = reinterpret_cast<const uint32_t*>(g.qm + (q0 + qi) * g.qstride);
+			const uint32_t* mp = reinterpret_cast<const uint32_t*>(g.qm + QR(qi) * g.qstride);
 #pragma unroll
 			for (int w = 0; w < DW; ++w) qm[w] = mp[w];
 		}
-		const int qgLow = grouped ? g.qgroup[q0 + qi] : 0;
+		const int qgLow = grouped ? g.qgroup[QR(qi)] : 0;
 		uint32_t a = EMPTY, b2 = EMPTY;
 		double r1[3] = {0.0, 0.0, 0.0};
 		const double* EmLow = g.E;
 		if (TRI) {
 #pragma unroll
-			for (int c = 0; c < 3; ++c) r1[c] = g.rays1[(q0 + qi) * 3 + c];
+			for (int c = 0; c < 3; ++c) r1[c] = g.rays1[QR(qi) * 3 + c];
 			EmLow = g.E + (size_t)set * g.Epitch + (size_t)9 * ((size_t)qgLow * g.nrCams + qgLow);
 		}
 		// branch-free body, 4 rows per lane and trip: all global loads of a trip are issued before the first use
@@ -257,10 +257,10 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 			for (int u = 0; u < 4; ++u) {
 				const int j = j0 + 64 * u;
 				const int jc = j < g.nt ? j : g.nt - 1;
-				const uint32_t* tp = reinterpret_cast<const uint32_t*>(g.td + (t0 + jc) * g.tstride);
-				const uint32_t* mp = MASKED ? reinterpret_cast<const uint32_t*>(g.tm + (t0 + jc) * g.tstride) : tp;
-				const bool ok = j < g.nt && !((matched[jc >> 5] >> (jc & 31)) & 1u) && (g.tvalid ? g.tvalid[t0 + jc] != 0 : true) &&
-				                (!grouped || g.tgroup[t0 + jc] == qgLow);   // same camera / FeatureVector node only
+				const uint32_t* tp = reinterpret_cast<const uint32_t*>(g.td + TR(jc) * g.tstride);
+				const uint32_t* mp = MASKED ? reinterpret_cast<const uint32_t*>(g.tm + TR(jc) * g.tstride) : tp;
+				const bool ok = j < g.nt && !((matched[jc >> 5] >> (jc & 31)) & 1u) && (g.tvalid ? g.tvalid[TR(jc)] != 0 : true) &&
+				                (!grouped || g.tgroup[TR(jc)] == qgLow);   // same camera / FeatureVector node only
 				const int dist = hamming_g<DW, MASKED>(q, qm, tp, mp);
 				const uint32_t k = ((uint32_t)dist << 20) | (uint32_t)jc;
 				kk[u] = ok && (!TRI || dist <= g.thLow) ? k : EMPTY;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 				for (int u = 0; u < 4; ++u) {
 					const uint32_t k = kk[u];
 					if (k < a) a = k;
-					if (k < b2 && check_epipolar(r1, g.rays2 + (t0 + (k & 0xFFFFFu)) * 3, EmLow, 1e-2)) b2 = k;
+					if (k < b2 && check_epipolar(r1, g.rays2 + TR((int)(k & 0xFFFFFu)) * 3, EmLow, 1e-2)) b2 = k;
 				}
 			} else {
 #pragma unroll
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 		const int i = i0 + lane;
 		const bool inRange = i < g.nq;
 		bool qok = inRange;
-		if (qok && g.qvalid) qok = g.qvalid[q0 + i] != 0;
+		if (qok && g.qvalid) qok = g.qvalid[QR(i)] != 0;
 		uint32_t key[K];
 #pragma unroll
 		for (int e = 0; e < K; ++e) key[e] = EMPTY;
@@ -314,10 +314,10 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 		double ray1[3] = {0.0, 0.0, 0.0};
 		const double* Em = g.E;
 		if (TRI && qok && g.nt > 0) {   // (an empty train set has no ray rows to read)
-			const int qg = g.qgroup[q0 + i];
+			const int qg = g.qgroup[QR(i)];
 			Em = g.E + (size_t)set * g.Epitch + (size_t)9 * ((size_t)qg * g.nrCams + qg);   // same-camera rule: camIdx2 == camIdx1 (the lists are built per camera)
 #pragma unroll
-			for (int c = 0; c < 3; ++c) ray1[c] = g.rays1[(q0 + i) * 3 + c];
+			for (int c = 0; c < 3; ++c) ray1[c] = g.rays1[QR(i) * 3 + c];
 			// the rays of up to 8 list entries are fetched before the first test (a dependent global round trip per entry otherwise)
 			constexpr int CH = K < 8 ? K : 8;
 #pragma unroll
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 #pragma unroll
 				for (int u = 0; u < CH; ++u) {
 					const uint32_t k = key[e0 + u];
-					const double* rp = g.rays2 + (t0 + (k != EMPTY ? (k & 0xFFFFFu) : 0u)) * 3;
+					const double* rp = g.rays2 + TR(k != EMPTY ? (int)(k & 0xFFFFFu) : 0) * 3;
 #pragma unroll
 					for (int c = 0; c < 3; ++c) r2[u][c] = rp[c];
 				}
@@ -493,6 +493,26 @@ void launch_greedy(const GreedyArgs& g, hipStream_t s) {
 __global__ void k_rows_valid(const int* nkp, int nimg, int cap, uint8_t* valid) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < nimg * cap) valid[i] = (i % cap) < nkp[i / cap] ? 1 : 0;
+}
+
+// Exchange blocks of the camera-sharded rig (rig.py): image block = cap descriptor rows + ONE header row whose first 4 bytes hold the image's keypoint count.
+__global__ void k_rig_pack_headers(const int* nkp, int nimg, int cap, uint8_t* blocks, int rowStride) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nimg) *reinterpret_cast<int*>(blocks + ((size_t)i * (cap + 1) + cap) * rowStride) = nkp[i];
+}
+__global__ void k_rig_rows_valid(const uint8_t* blocks, int nimg, int cap, int rowStride, uint8_t* valid, int* nkpOut) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nimg * (cap + 1)) return;
+	const int img = i / (cap + 1), k = i - img * (cap + 1);
+	const int n = *reinterpret_cast<const int*>(blocks + ((size_t)img * (cap + 1) + cap) * rowStride);
+	valid[i] = k < n && k < cap ? 1 : 0;   // the header row itself is never a feature
+	if (nkpOut && k == 0) nkpOut[img] = n;
+}
+void launch_rig_pack_headers(const int* nkp, int nimg, int cap, uint8_t* blocks, int rowStride, hipStream_t s) {
+	hipLaunchKernelGGL(k_rig_pack_headers, dim3((nimg + 255) / 256), dim3(256), 0, s, nkp, nimg, cap, blocks, rowStride);
+}
+void launch_rig_rows_valid(const uint8_t* blocks, int nimg, int cap, int rowStride, uint8_t* valid, int* nkpOut, hipStream_t s) {
+	hipLaunchKernelGGL(k_rig_rows_valid, dim3((nimg * (cap + 1) + 255) / 256), dim3(256), 0, s, blocks, nimg, cap, rowStride, valid, nkpOut);
 }
 
 void launch_rows_valid(const int* nkp, int nimg, int cap, uint8_t* valid, hipStream_t s) {

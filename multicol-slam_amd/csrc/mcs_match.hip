@@ -105,21 +105,21 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	const int tid = threadIdx.x;
 	const int set = blockIdx.z, split = blockIdx.y;
 	const int qi = blockIdx.x * 256 + tid;
-	const size_t qrow0 = (size_t)(set % a.qmod) * a.qpitch, trow0 = (size_t)(set / a.tdiv) * a.tpitch;
+	const RowMap QR{(size_t)(set % a.qmod) * a.qpitch, a.qblk, a.qbpitch}, TR{(size_t)((set / a.tdiv + a.toff) % a.tmod) * a.tpitch, a.tblk, a.tbpitch};
 	bool qok = qi < a.nq;
-	if (qok && a.qvalid) qok = a.qvalid[qrow0 + qi] != 0;
+	if (qok && a.qvalid) qok = a.qvalid[QR(qi)] != 0;
 	uint32_t q[DW], qm[DW];
 	int qg = 0;
 	if (qok) {
-		const uint32_t* qp = reinterpret_cast<const uint32_t*>(a.qd + (qrow0 + qi) * a.qstride);
+		const uint32_t* qp = reinterpret_cast<const uint32_t*>(a.qd + QR(qi) * a.qstride);
 #pragma unroll
 		for (int w = 0; w < DW; ++w) q[w] = qp[w];
 		if (MASKED) {
-			const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.qm + (qrow0 + qi) * a.qstride);
+			const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.qm + QR(qi) * a.qstride);
 #pragma unroll
 			for (int w = 0; w < DW; ++w) qm[w] = mp[w];
 		}
-		if (a.qgroup) qg = a.qgroup[qrow0 + qi];
+		if (a.qgroup) qg = a.qgroup[QR(qi)];
 	} else {
 #pragma unroll
 		for (int w = 0; w < DW; ++w) { q[w] = 0; qm[w] = 0; }
@@ -201,8 +201,8 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 		const int j = base + tid;
 		int flag = -1;
 		if (j < t1) {
-			const bool ok = a.tvalid ? a.tvalid[trow0 + j] != 0 : true;
-			flag = ok ? (a.tgroup ? a.tgroup[trow0 + j] : 0) : -1;
+			const bool ok = a.tvalid ? a.tvalid[TR(j)] != 0 : true;
+			flag = ok ? (a.tgroup ? a.tgroup[TR(j)] : 0) : -1;
 		}
 		const unsigned long long bal = __ballot(flag >= 0);
 		if (lane == 0) wcnt[wv] = __popcll(bal);
@@ -211,11 +211,11 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 		for (int w = 0; w < wv; ++w) pos += wcnt[w];
 		const int rows = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 		if (flag >= 0) {
-			const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.td + (trow0 + j) * a.tstride);
+			const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.td + TR(j) * a.tstride);
 #pragma unroll
 			for (int w = 0; w < DW; ++w) td[pos * DW + w] = tp[w];
 			if (MASKED) {
-				const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.tm + (trow0 + j) * a.tstride);
+				const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.tm + TR(j) * a.tstride);
 #pragma unroll
 				for (int w = 0; w < DW; ++w) tm[pos * DW + w] = mp[w];
 			}

@@ -1,76 +1,108 @@
-"""Multi-GPU sharding of the hot path, one process per GPU over torch.distributed (nccl = RCCL on ROCm).
+"""Multi-GPU split of the hot path (BASELINE north_star): one process per GPU over torch.distributed (backend nccl = RCCL over xGMI).
 
-Two independent partitions, as in the reference's own parallel structure (one extractor per camera thread,
-src/cMultiFrame.cpp:128-164; keyframes are independent in the brute-force database searches):
+  extraction   the (camera, frame) images of a step are sharded over the ranks, camera-major: image x = camera * frames_total + frame, rank r owns the
+               contiguous slab x in [r*L, (r+1)*L), L = ncam * frames_total / world.  The cameras of one multi-frame therefore sit on different
+               GPUs as soon as world > 1 — the reference's own parallel axis (one extractor per camera thread, src/cMultiFrame.cpp:128-164) — and
+               the slabs are equal for every camera count and world size.
+  exchange     ONE all-gather per step.  A rank's send buffer is L image blocks, each (cap + 1) rows of 2*descSize bytes: row k = descriptor | mask of
+               keypoint k (the extractor writes them interleaved, mcs_extract_batch_strided), row cap = header holding the image's keypoint count
+               (mcs_rig_pack_headers).  Because the slabs are contiguous in x, the gathered buffer IS the global [camera][frame][row] array — nothing
+               is permuted or copied afterwards.
+  matching     a multi-frame is a block-structured descriptor set inside that array (mcs_desc_set.block_rows = cap, block_pitch_rows =
+               frames_total * (cap + 1); consecutive frames lie cap + 1 rows apart), consumed in place by the searches.  The (frame, keyframe) pairs
+               are sharded: stored keyframe k -> rank k % world (database sweeps, BASELINE configs[2]/[4]), or frame f -> rank f // F when every frame
+               is matched against its predecessor (configs[1]).  Match results stay on the rank that produced them.
 
-  * extraction   camera c of every multi-frame  -> rank  c % world           (camera_shard)
-  * matching     stored keyframe k              -> rank  k % world           (keyframe_shard)
-
-and exactly ONE exchange step between them: every rank needs the descriptors (+ masks, + per-camera counts) of ALL cameras
-of the current multi-frames before it can match them against its keyframe shard.  That is an all-gather of fixed-size
-blocks (cap rows per camera, zero-padded; ranks owning fewer cameras pad to ceil(ncam/world) blocks) — a latency-bound
-message of tens of KiB per GPU, done with one all_gather_into_tensor per tensor.  Match results stay sharded by keyframe.
-torch is plumbing here (buffers + process group); the compute is libmcs_hip.so.
+RigLayout is pure index arithmetic (shared by bench.py and the world-size-2 gloo test, which runs it with the oracle as compute); torch is plumbing
+(buffers + the process group), the compute is libmcs_hip.so.
 """
-import torch
-import torch.distributed as dist
+import numpy as np
 
 
-def camera_shard(ncam, rank, world):
-    return [c for c in range(ncam) if c % world == rank]
+class RigLayout:
+    def __init__(self, ncam, frames_total, world, cap, desc_size=32):
+        if (ncam * frames_total) % world:
+            raise ValueError("ncam * frames_total must be a multiple of the world size")
+        self.ncam, self.frames_total, self.world, self.cap, self.desc_size = ncam, frames_total, world, cap, desc_size
+        self.images_total = ncam * frames_total
+        self.L = self.images_total // world            # images per rank
+        self.rows_img = cap + 1                        # descriptor rows + the header row
+        self.row_stride = 2 * desc_size                # descriptor | mask
+        self.block_bytes = self.rows_img * self.row_stride
+        self.send_bytes = self.L * self.block_bytes
+        self.rows_frame = ncam * cap                   # logical rows of one multi-frame (what match indices refer to)
+
+    # ---- extraction shard
+    def slab(self, rank):
+        """(camera, frame) of the images rank `rank` extracts, in send order"""
+        return [(x // self.frames_total, x % self.frames_total) for x in range(rank * self.L, (rank + 1) * self.L)]
+
+    def image_index(self, cam, frame):
+        return cam * self.frames_total + frame
+
+    # ---- a multi-frame inside the gathered array
+    def frame_desc_set(self, frame):
+        """byte offsets and geometry of multi-frame `frame` in the gathered array / the valid array:
+        (desc_off, mask_off, valid_off, n, stride, block_rows, block_pitch_rows, set_pitch_rows)"""
+        return (frame * self.block_bytes, frame * self.block_bytes + self.desc_size, frame * self.rows_img, self.rows_frame, self.row_stride,
+                self.cap, self.frames_total * self.rows_img, self.rows_img)
+
+    def frame_rows(self, frame):
+        """physical row (of rows_img-row image blocks) of every logical row of multi-frame `frame`: the same mapping mcs_desc_set's block fields express"""
+        i = np.arange(self.rows_frame)
+        return frame * self.rows_img + (i // self.cap) * (self.frames_total * self.rows_img) + i % self.cap
+
+    # ---- matching shards
+    def keyframe_shard(self, nkf, rank):
+        return [k for k in range(nkf) if k % self.world == rank]
+
+    def frame_pairs(self, rank):
+        """(frame, predecessor) pairs rank `rank` matches when every multi-frame meets the one before it (cyclic within the step)"""
+        F = self.frames_total // self.world
+        return [(f, (f - 1) % self.frames_total) for f in range(rank * F, (rank + 1) * F)]
 
 
-def keyframe_shard(nkf, rank, world):
-    return [k for k in range(nkf) if k % world == rank]
+def pack_blocks(layout, desc, mask, nkp):
+    """numpy restatement of the send buffer (what mcs_extract_batch_strided + mcs_rig_pack_headers produce on the device):
+    desc / mask [L][cap][ds] uint8, nkp [L] -> [L][cap + 1][2*ds] uint8"""
+    L, cap, ds = desc.shape
+    out = np.zeros((L, cap + 1, 2 * ds), np.uint8)
+    out[:, :cap, :ds] = desc
+    out[:, :cap, ds:] = mask
+    out[:, cap, :4] = np.ascontiguousarray(nkp, "<i4").view(np.uint8).reshape(L, 4)
+    return out
 
 
-def cams_per_rank(ncam, world):
-    return (ncam + world - 1) // world
+def unpack_frame(layout, gathered, frame):
+    """numpy view of multi-frame `frame` of a gathered [images_total][cap + 1][2*ds] array: (desc [rows_frame][ds], mask, valid [rows_frame])"""
+    ds, cap = layout.desc_size, layout.cap
+    rows = gathered.reshape(-1, layout.row_stride)
+    phys = layout.frame_rows(frame)
+    d, m = rows[phys, :ds], rows[phys, ds:]
+    counts = np.array([int(gathered[layout.image_index(c, frame), cap, :4].view("<i4")[0]) for c in range(layout.ncam)])
+    valid = (np.arange(layout.rows_frame) % cap) < np.repeat(counts, cap)
+    return np.ascontiguousarray(d), np.ascontiguousarray(m), valid.astype(np.uint8)
 
 
-def allgather_rig(desc, dmask, nkp, ncam, rank, world, group=None):
-    """desc/dmask: [F, local_cams, cap, ds] uint8, nkp: [F, local_cams] int32 for the cameras camera_shard(ncam, rank, world).
-    Returns (desc_all [F, ncam, cap, ds], dmask_all, nkp_all [F, ncam]) in global camera order on every rank."""
-    F, lc, cap, ds = desc.shape
-    cpr = cams_per_rank(ncam, world)
+def all_gather_blocks(send, world, group=None):
+    """ONE all-gather of the ranks' send buffers (torch uint8 tensors of identical size) -> [world * len(send)] on every rank.
+    A CUDA tensor under the gloo backend (functional runs of the N > 1 path on a single GPU) bounces through host memory."""
+    import torch
+    import torch.distributed as dist
     if world == 1:
-        return desc, dmask, nkp
-    dev = desc.device
-
-    def pad(t, fill=0):
-        if lc == cpr:
-            return t.contiguous()
-        shape = list(t.shape)
-        shape[1] = cpr
-        out = torch.full(shape, fill, dtype=t.dtype, device=dev)
-        out[:, :lc] = t
-        return out
-
-    send_d, send_m, send_n = pad(desc), pad(dmask), pad(nkp)
-    host_bounce = send_d.is_cuda and dist.get_backend(group) == "gloo"   # functional tests of the N>1 path on one GPU
-
-    def gather(send):   # concatenated-along-dim-0 output form (accepted by both nccl/RCCL and gloo), viewed as [world, ...]
-        if host_bounce:
-            send = send.cpu()
-        out = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-        dist.all_gather_into_tensor(out, send, group=group)
-        return out.view((world,) + tuple(send.shape)).to(dev)
-
-    out_d, out_m, out_n = gather(send_d), gather(send_m), gather(send_n)
-    # rank r, slot j  ->  camera r + j*world   (camera_shard order)
-    desc_all = torch.zeros((F, ncam, cap, ds), dtype=desc.dtype, device=dev)
-    mask_all = torch.zeros((F, ncam, cap, ds), dtype=dmask.dtype, device=dev)
-    nkp_all = torch.zeros((F, ncam), dtype=nkp.dtype, device=dev)
-    for r in range(world):
-        for j, c in enumerate(camera_shard(ncam, r, world)):
-            desc_all[:, c] = out_d[r, :, j]
-            mask_all[:, c] = out_m[r, :, j]
-            nkp_all[:, c] = out_n[r, :, j]
-    return desc_all, mask_all, nkp_all
+        return send
+    flat = send.reshape(-1)
+    bounce = flat.is_cuda and dist.get_backend(group) == "gloo"
+    src = flat.cpu() if bounce else flat
+    out = torch.empty(world * src.numel(), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src, group=group)
+    return out.to(flat.device) if bounce else out
 
 
 def reduce_timing(elapsed_s, units, device, world):
     """max-over-ranks time and summed units (bench contract)."""
+    import torch
+    import torch.distributed as dist
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     u = torch.tensor([units], dtype=torch.float64, device=device)
     if world > 1:

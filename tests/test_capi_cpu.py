@@ -45,7 +45,7 @@ def test_struct_layouts(pkg):
     assert C.sizeof(pkg._capi.KeyPoint) == 28 and pkg.KP_DTYPE.itemsize == 28       # cv::KeyPoint
     assert C.sizeof(pkg._capi.ExtractorParams) == 13 * 4
     assert C.sizeof(pkg._capi.Ocam) == 5 * 8 + 16 * 8 + 8 + 16 * 8 + 8 + 8
-    assert C.sizeof(pkg._capi.DescSet) == 4 * 8 + 8
+    assert C.sizeof(pkg._capi.DescSet) == 4 * 8 + 8 + 8 + 8   # + block_rows (int32, padded) + block_pitch_rows (int64)
 
 
 def test_product_never_touches_the_oracle():

@@ -1,4 +1,6 @@
-"""world_size-2 (and 3) CPU tests of the N>1 path (gloo backend): camera / keyframe sharding and the descriptor all-gather."""
+"""world_size-2 (and 3) CPU tests of the N > 1 path (gloo backend): the camera-major slab sharding, the ONE all-gather of descriptor | mask | count
+blocks, in-place consumption of the gathered buffer and the sharded (frame, keyframe) pairs — multicol-slam_amd/rig.py, with the oracle as compute
+(there is no GPU here).  The matched output of the ranks together must equal a single-process oracle run over the same stream."""
 import importlib
 import os
 import socket
@@ -18,63 +20,145 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ncam, F, cap, ds, q):
+CAP, DS = 40, 32
+
+
+def _truth(ncam, FT, seed=5):
+    """every rank can regenerate the full stream: per image a random number of descriptors, later frames are noisy copies of frame 0 (so they match)"""
+    rng = np.random.default_rng(seed)
+    base_d = rng.integers(0, 256, (ncam, CAP, DS), dtype=np.uint8)
+    desc = np.zeros((ncam, FT, CAP, DS), np.uint8)
+    mask = np.packbits(rng.random((ncam, FT, CAP, DS * 8)) < 0.9, axis=3)
+    nkp = rng.integers(CAP // 2, CAP + 1, (ncam, FT)).astype(np.int32)
+    for f in range(FT):
+        noise = np.packbits(rng.random((ncam, CAP, DS * 8)) < 0.03, axis=2)
+        perm = rng.permutation(CAP)
+        desc[:, f] = (base_d ^ noise)[:, perm]
+    return desc, mask, nkp
+
+
+def _frame(desc, mask, nkp, f):
+    """multi-frame f as the reference sees it: cameras concatenated, CAP rows per camera, rows beyond a camera's count invalid"""
+    ncam = desc.shape[0]
+    d = desc[:, f].reshape(ncam * CAP, DS)
+    m = mask[:, f].reshape(ncam * CAP, DS)
+    v = (np.arange(CAP)[None, :] < nkp[:, f][:, None]).reshape(-1).astype(np.uint8)
+    return np.ascontiguousarray(d), np.ascontiguousarray(m), v
+
+
+def _worker(rank, world, port, ncam, F, nkf, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_lib as O
     rig = importlib.import_module("multicol-slam_amd.rig")
-    rng = np.random.default_rng(123)                      # every rank can regenerate the full truth
-    full_d = rng.integers(0, 256, (F, ncam, cap, ds)).astype(np.uint8)
-    full_m = rng.integers(0, 256, (F, ncam, cap, ds)).astype(np.uint8)
-    full_n = rng.integers(0, cap + 1, (F, ncam)).astype(np.int32)
-    mine = rig.camera_shard(ncam, rank, world)
-    d = torch.from_numpy(full_d[:, mine].copy())
-    m = torch.from_numpy(full_m[:, mine].copy())
-    n = torch.from_numpy(full_n[:, mine].copy())
-    ad, am, an = rig.allgather_rig(d, m, n, ncam, rank, world)
-    ok = bool((ad.numpy() == full_d).all() and (am.numpy() == full_m).all() and (an.numpy() == full_n).all())
+    FT = F * world
+    lay = rig.RigLayout(ncam, FT, world, CAP, DS)
+    desc, mask, nkp = _truth(ncam, FT)
+    # ---- this rank's slab -> send blocks -> ONE all-gather
+    slab = lay.slab(rank)
+    send = rig.pack_blocks(lay, np.stack([desc[c, f] for c, f in slab]), np.stack([mask[c, f] for c, f in slab]), np.array([nkp[c, f] for c, f in slab]))
+    G = rig.all_gather_blocks(torch.from_numpy(send), world).numpy().reshape(lay.images_total, lay.rows_img, lay.row_stride)
+    ok = True
+    # the gathered buffer IS the global [camera][frame] array: every multi-frame is read in place through the block mapping
+    for f in range(FT):
+        d, m, v = rig.unpack_frame(lay, G, f)
+        ed, em, ev = _frame(desc, mask, nkp, f)
+        ok = ok and (d[ev != 0] == ed[ev != 0]).all() and (m[ev != 0] == em[ev != 0]).all() and (v == ev).all()
+    # ---- sharded matching with the oracle: (a) every frame of this rank's range against its predecessor, (b) every frame against this rank's keyframes
+    res = {}
+    for f, p in lay.frame_pairs(rank):
+        d1, m1, v1 = rig.unpack_frame(lay, G, f)
+        d0, m0, v0 = rig.unpack_frame(lay, G, p)
+        res[("ring", f)] = O.search_kf_kf(d1, m1, v1, d0, m0, v0, True, 0.9)
+    for k in lay.keyframe_shard(nkf, rank):
+        dk, mk, vk = rig.unpack_frame(lay, G, k % FT)      # stored keyframe k = multi-frame k % FT (as bench.py fills its database)
+        for f in range(FT):
+            df, mf, vf = rig.unpack_frame(lay, G, f)
+            keep = np.flatnonzero(vf)
+            n, m = O.search_kf_f(dk, mk, vk, np.ascontiguousarray(df[keep]), np.ascontiguousarray(mf[keep]), True, 0.9)
+            full = np.full(lay.rows_frame, -1, np.int32)
+            full[keep] = m
+            res[("db", k, f)] = (n, full)
     t, u = rig.reduce_timing(1.0 + rank, 10.0 * (rank + 1), torch.device("cpu"), world)
     ok = ok and t == float(world) and u == 10.0 * world * (world + 1) / 2
-    q.put((rank, ok))
+    q.put((rank, bool(ok), {k: (int(v[0]), v[1].tolist()) for k, v in res.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,ncam", [(2, 3), (2, 6), (3, 8)])
-def test_allgather_rig_gloo(world, ncam):
+@pytest.mark.parametrize("world,ncam,F,nkf", [(2, 3, 2, 5), (2, 6, 1, 4), (3, 8, 1, 4)])
+def test_rig_matched_output_equals_single_process_oracle(oracle, world, ncam, F, nkf):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ncam, 2, 7, 32, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ncam, F, nkf, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(r for r, _ in res) == list(range(world)) and all(ok for _, ok in res)
+    assert sorted(r for r, _, _ in res) == list(range(world)) and all(ok for _, ok, _ in res)
+    merged = {}
+    for _, _, part in res:
+        assert not (set(part) & set(merged))          # the pairs are partitioned, nothing is computed twice
+        merged.update(part)
+    # single process, no sharding, no exchange: the same searches straight on the stream
+    import oracle_lib as O
+    FT = F * world
+    desc, mask, nkp = _truth(ncam, FT)
+    n_ring = n_db = 0
+    for f in range(FT):
+        d1, m1, v1 = _frame(desc, mask, nkp, f)
+        d0, m0, v0 = _frame(desc, mask, nkp, (f - 1) % FT)
+        n, m = O.search_kf_kf(d1, m1, v1, d0, m0, v0, True, 0.9)
+        assert merged[("ring", f)] == (n, m.tolist())
+        n_ring += n
+    for k in range(nkf):
+        dk, mk, vk = _frame(desc, mask, nkp, k % FT)
+        for f in range(FT):
+            df, mf, vf = _frame(desc, mask, nkp, f)
+            keep = np.flatnonzero(vf)
+            n, m = O.search_kf_f(dk, mk, vk, np.ascontiguousarray(df[keep]), np.ascontiguousarray(mf[keep]), True, 0.9)
+            full = np.full(ncam * CAP, -1, np.int32)
+            full[keep] = m
+            assert merged[("db", k, f)] == (n, full.tolist())
+            n_db += n
+    assert len(merged) == FT + nkf * FT and n_ring > 10 * FT and n_db > 10 * nkf * FT
 
 
-def test_shards_partition():
+def test_layout_partitions_and_block_mapping():
     rig = importlib.import_module("multicol-slam_amd.rig")
     for world in (1, 2, 4, 8):
-        for n in (3, 6, 8, 256):
-            cams = [rig.camera_shard(n, r, world) for r in range(world)]
-            assert sorted(sum(cams, [])) == list(range(n))
-            kfs = [rig.keyframe_shard(n, r, world) for r in range(world)]
-            assert sorted(sum(kfs, [])) == list(range(n))
-            assert max(len(c) for c in cams) == rig.cams_per_rank(n, world)
+        for ncam, F in ((3, 64), (6, 4), (8, 1), (3, 1)):
+            FT = F * world
+            lay = rig.RigLayout(ncam, FT, world, 1024)
+            slabs = [lay.slab(r) for r in range(world)]
+            assert all(len(s) == lay.L for s in slabs)                                  # equal work for every camera count and world size
+            flat = sum(slabs, [])
+            assert flat == [(c, f) for c in range(ncam) for f in range(FT)]             # contiguous camera-major slabs: the gathered buffer needs no permutation
+            if world > 1 and ncam >= world:
+                assert all(len({r for r in range(world) for (c, f) in slabs[r] if f == ff}) > 1 for ff in range(FT))   # a multi-frame's cameras span GPUs
+            kfs = [lay.keyframe_shard(256, r) for r in range(world)]
+            assert sorted(sum(kfs, [])) == list(range(256))
+            pairs = sum((lay.frame_pairs(r) for r in range(world)), [])
+            assert sorted(f for f, _ in pairs) == list(range(FT)) and all(p == (f - 1) % FT for f, p in pairs)
+            # the numpy row mapping and the mcs_desc_set block fields describe the same rows
+            doff, moff, voff, n, stride, brows, bpitch, spitch = lay.frame_desc_set(3 % FT)
+            i = np.arange(n)
+            assert (lay.frame_rows(3 % FT) == voff + (i // brows) * bpitch + i % brows).all()
+            assert doff == voff * stride and moff == doff + 32 and spitch == lay.rows_img and n == ncam * 1024
 
 
-def test_every_rank_of_the_stream_bench_gets_images_with_content():
-    """bench.py shards the synthetic stream over ranks; the scene drifts with the frame number, so a shard far down the stream would be empty
-    images (ranks >= 1 once extracted ~0 features).  Every rank's frames must look like rank 0's."""
-    import importlib
+def test_synthetic_stream_keeps_content_for_every_rank():
+    """bench.py shows synthetic frame f % POOL as global frame f: the scene drifts out of the image after a few dozen frames, a rank far down the
+    stream would otherwise extract ~0 features"""
     import bench
     synth = importlib.import_module("multicol-slam_amd.synth")
     cam = synth.lafida_cameras()[0]
     ref = synth.synth_image(0, 0, cam).astype(np.float64).std()
-    for rank in (1, 7):
-        for f in bench.shard_frames(rank, 8)[::7]:
-            assert synth.synth_image(f, 0, cam).astype(np.float64).std() > 0.9 * ref, (rank, f)
-    assert bench.shard_frames(0, 8) == list(range(8)) and len(set(sum((bench.shard_frames(r, 8) for r in range(8)), []))) == 64
+    for f in range(bench.POOL):
+        assert synth.synth_image(f, 0, cam).astype(np.float64).std() > 0.9 * ref
