@@ -374,7 +374,7 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True):
            "multi_frames_per_step_per_gpu": sp.F, "distinct_multi_frames_in_the_stream": POOL, "features_per_step": int(feats_all),
            "pair_distances_per_step": pairs_all, "Gpairs_per_s": round(pairs_all * steps / elapsed_max / 1e9, 1),
            "matches_per_step_rank0": matches, "greedy_rescans_rank0": rescans, "topk": sp.topk, "stored_keyframes": sp.D,
-           "n_ranks": e.world, "collective_backend": e.backend,
+           "n_ranks": e.world, "collective_backend": e.backend, "tag": sp.tag,
            "parallelism": ("single GPU, no collective" if e.world == 1 else
                            "camera-major image slabs x%d + 1 all-gather of descriptor blocks per step (%d KiB per rank) + (frame, keyframe) pairs sharded x%d"
                            % (e.world, job.lay.send_bytes // 1024, e.world))}
@@ -408,16 +408,7 @@ def run_e2e(e, sp, steps, warmup):
             job.d_imgs[i].copy_(h_img[i], non_blocking=True)
             ev_in[i].record(cin)
 
-    def step():
-        i = state["i"] & 1
-        state["i"] += 1
-        e.stream.wait_event(ev_in[i])                     # this step's images (uploaded while the previous step computed)
-        e.stream.wait_event(ev_out[job.cur])              # the output set about to be overwritten has been copied out
-        k = job.cur
-        job.step(i)
-        ev_free[i].record(e.stream)
-        upload(i ^ 1)                                     # the next step's images travel while this step computes
-        e.mcs.check(e.lib.mcs_ctx_join(e.ctx.h))          # match arrays are written on the library's side stream
+    def download(k):   # outputs of buffer set k -> page-locked host memory on the second copy stream
         ev_done[k].record(e.stream)
         with torch.cuda.stream(cout):
             cout.wait_event(ev_done[k])
@@ -425,16 +416,45 @@ def run_e2e(e, sp, steps, warmup):
                 dst.copy_(src, non_blocking=True)
             ev_out[k].record(cout)
 
+    def step():
+        i = state["i"] & 1
+        state["i"] += 1
+        e.stream.wait_event(ev_in[i])                     # this step's images (uploaded while the previous step computed)
+        e.stream.wait_event(ev_out[job.cur])              # the output set about to be overwritten has been copied out
+        b = job.sets[job.cur]
+        k = job.cur
+        job.cur ^= 1
+        job.extract_and_exchange(b, i)
+        ev_free[i].record(e.stream)
+        upload(i ^ 1)                                     # the next step's images travel while this step computes
+        if state["i"] > 1:
+            e.mcs.check(e.lib.mcs_ctx_join(e.ctx.h))      # the previous step's greedy pass ran beside this extraction: its match arrays are complete
+            download(k ^ 1)                               # they leave now, while this step's matcher runs
+        job.match(b)
+
     for ev in ev_free + ev_out:
         ev.record(e.stream)
     upload(0)
     elapsed = timed(e, step, warmup, steps, job.status)
+    e.mcs.check(e.lib.mcs_ctx_join(e.ctx.h))
+    download(job.cur ^ 1)                                 # the last step's outputs
+    torch.cuda.synchronize(e.dev)
     feats = job.local_features()
     h2d = job.imgs_np.nbytes
     d2h = sum(dst.numel() * dst.element_size() for _, dst in outs[0])
+
+    def rate(fn, nbytes, reps=10):   # the copies alone, nothing else running
+        torch.cuda.synchronize(e.dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(e.dev)
+        return round(nbytes * reps / (time.perf_counter() - t0) / 1e9, 1)
+    h2d_rate = rate(lambda: job.d_imgs[0].copy_(h_img[0], non_blocking=True), h2d)
+    d2h_rate = rate(lambda: [dst.copy_(src, non_blocking=True) for src, dst in outs[0]], d2h)
     job.close()
     return {"value": round(feats * steps / elapsed / 1e6, 3), "unit": "Mfeatures/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
-            "h2d_bytes_per_step": int(h2d), "d2h_bytes_per_step": int(d2h),
+            "h2d_bytes_per_step": int(h2d), "d2h_bytes_per_step": int(d2h), "h2d_GBps_alone": h2d_rate, "d2h_GBps_alone": d2h_rate,
             "what": "host buffers at the boundary: images H2D from page-locked memory (double-buffered, copy stream), keypoints + descriptor|mask blocks + counts + "
                     "match arrays D2H to page-locked memory (second copy stream), overlapped with the neighbouring steps' kernels"}
 

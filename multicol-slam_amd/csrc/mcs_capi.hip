@@ -108,7 +108,10 @@ int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
 	HIPCHK(hipMalloc(&c->dscalar, 64));
 	if (getenv("MCS_NO_OVERLAP") == nullptr) {
 		HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+		HIPCHK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
 		HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&c->evPyr1, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&c->evPyr, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&c->evBlur, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&c->evMatch, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&c->evGreedy, hipEventDisableTiming));
@@ -134,7 +137,9 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 	(void)hipFree(c->topKeys); (void)hipFree(c->topCnt); (void)hipFree(c->stageOut); (void)hipFree(c->arena); if (c->pinned) (void)hipHostFree(c->pinned);
 	if (c->side) {
 		(void)hipStreamSynchronize(c->side);
-		(void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evBlur); (void)hipEventDestroy(c->evMatch); (void)hipEventDestroy(c->evGreedy);
+		(void)hipStreamSynchronize(c->side2);
+		(void)hipStreamDestroy(c->side2);
+		(void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evPyr1); (void)hipEventDestroy(c->evPyr); (void)hipEventDestroy(c->evBlur); (void)hipEventDestroy(c->evMatch); (void)hipEventDestroy(c->evGreedy);
 		(void)hipStreamDestroy(c->side);
 	}
 	if (c->ownStream) (void)hipStreamDestroy(c->stream);
@@ -145,7 +150,7 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 int mcs_ctx_synchronize(mcs_ctx* c) {
 	if (!c) return fail(MCS_ERR_INVALID, "null ctx");
 	HIPCHK(hipStreamSynchronize(c->stream));
-	if (c->side) { HIPCHK(hipStreamSynchronize(c->side)); c->greedyPending = false; }
+	if (c->side) { HIPCHK(hipStreamSynchronize(c->side)); HIPCHK(hipStreamSynchronize(c->side2)); c->greedyPending = false; }
 	return MCS_OK;
 }
 
@@ -470,16 +475,27 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		}
 		b.cams = e->d_cams;
 	}
-	c->tic("pyramid"); launch_pyramid(b, hd, nimg, s); c->toc("pyramid");
-	if (c->overlap()) {   // blur only needs the pyramid: run it beside FAST + oct-tree (the oct-tree leaves most CUs idle)
+	if (c->overlap()) {
+		// Two chains until the descriptors: the side stream runs the resize chain (7 dependent, latency-bound launches) and then the blur, which needs
+		// nothing else; the main stream starts FAST on level 0 — the input image itself, a third of all FAST work — at once, picks up the other levels
+		// when the pyramid is there, and runs the oct-tree.  Both chains leave most of the chip idle on their own.
 		HIPCHK(hipEventRecord(c->evFork, s));
 		HIPCHK(hipStreamWaitEvent(c->side, c->evFork, 0));
+		launch_pyramid(b, hd, nimg, c->side, 1, 2);
+		HIPCHK(hipEventRecord(c->evPyr1, c->side));
+		launch_pyramid(b, hd, nimg, c->side, 2, hd.nlevels);
+		HIPCHK(hipEventRecord(c->evPyr, c->side));
 		launch_blur(b, hd, nimg, c->side);
 		HIPCHK(hipEventRecord(c->evBlur, c->side));
-		launch_fast(b, hd, nimg, s);
+		launch_fast(b, hd, nimg, s, 0, 1);           // levels 0 and 1 carry more than half of the FAST work: the rest of the resize chain finishes behind them
+		HIPCHK(hipStreamWaitEvent(s, c->evPyr1, 0));
+		launch_fast(b, hd, nimg, s, 1, 2);
+		HIPCHK(hipStreamWaitEvent(s, c->evPyr, 0));
+		launch_fast(b, hd, nimg, s, 2, hd.nlevels);
 		launch_octree(b, hd, nimg, s);
 		HIPCHK(hipStreamWaitEvent(s, c->evBlur, 0));
 	} else {
+		c->tic("pyramid"); launch_pyramid(b, hd, nimg, s); c->toc("pyramid");
 		c->tic("fast"); launch_fast(b, hd, nimg, s); c->toc("fast");
 		c->tic("octree"); launch_octree(b, hd, nimg, s); c->toc("octree");
 		c->tic("blur"); launch_blur(b, hd, nimg, s); c->toc("blur");

@@ -217,9 +217,9 @@ static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc
 			// enqueues next on the main stream (the next batch's extraction) fills the idle CUs.  mcs_ctx_join / the next search /
 			// mcs_ctx_synchronize order later work behind it.
 			HIPCHK(hipEventRecord(c->evMatch, s));
-			HIPCHK(hipStreamWaitEvent(c->side, c->evMatch, 0));
-			launch_greedy(g, c->side);
-			HIPCHK(hipEventRecord(c->evGreedy, c->side));
+			HIPCHK(hipStreamWaitEvent(c->side2, c->evMatch, 0));
+			launch_greedy(g, c->side2);
+			HIPCHK(hipEventRecord(c->evGreedy, c->side2));
 			c->greedyPending = true;
 		} else { c->tic("greedy"); launch_greedy(g, s); c->toc("greedy"); }
 		HIPCHK(hipGetLastError());

@@ -255,13 +255,17 @@ __device__ __forceinline__ bool kp_prologue(const ExtractBuffers& b, int wavesPe
 		const uint8_t* raw = level_ptr(b, d, img, level, &rstride);
 		sm.blur = b.blur + (size_t)img * d.pyrBytes + L.off; sm.bstride = L.stride;
 		sm.raw = raw; sm.rstride = rstride; sm.w = L.w; sm.h = L.h;
-		{   // stage the blurred (2R+1)^2 neighbourhood (kPatchDw unaligned dwords per row, rows are in-pitch even at the right edge)
+		// Stage the blurred (2R+1)^2 neighbourhood (kPatchDw unaligned dwords per row, rows are in-pitch even at the right edge): the loads are ISSUED
+		// here and written to LDS only after the orientation and the keypoint's ray are done — their round trip hides behind that arithmetic.
+		constexpr int kPatchTrips = (kPatchRows * kPatchDw + 63) / 64;
+		uint32_t pv[kPatchTrips];
+		{
 			const uint8_t* bp = sm.blur + (size_t)(row - kPatchR) * sm.bstride + (col - kPatchR);
-			for (int i = lane; i < kPatchRows * kPatchDw; i += 64) {
+#pragma unroll
+			for (int t = 0; t < kPatchTrips; ++t) {
+				const int i = min(lane + 64 * t, kPatchRows * kPatchDw - 1);
 				const int r = i / kPatchDw, k = i - r * kPatchDw;
-				uint32_t v;
-				__builtin_memcpy(&v, bp + (size_t)r * sm.bstride + 4 * k, 4);
-				*reinterpret_cast<uint32_t*>(&patch[r * kPatchPitch + 4 * k]) = v;
+				__builtin_memcpy(&pv[t], bp + (size_t)r * sm.bstride + 4 * k, 4);
 			}
 			sm.patch = patch; sm.prow = row - kPatchR; sm.pcol = col - kPatchR;
 		}
@@ -302,6 +306,12 @@ __device__ __forceinline__ bool kp_prologue(const ExtractBuffers& b, int wavesPe
 				double* rp = b.rays + ((size_t)img * d.kpCap + out) * 3;
 				rp[0] = rayx; rp[1] = rayy; rp[2] = rayz;
 			}
+		}
+#pragma unroll
+		for (int t = 0; t < kPatchTrips; ++t) {   // the patch, now that its loads have had time to arrive (the last trip's surplus lanes rewrite the last dword)
+			const int i = min(lane + 64 * t, kPatchRows * kPatchDw - 1);
+			const int r = i / kPatchDw, k = i - r * kPatchDw;
+			*reinterpret_cast<uint32_t*>(&patch[r * kPatchPitch + 4 * k]) = pv[t];
 		}
 	}
 	kp_.img = img; kp_.out = out; kp_.level = level; kp_.row = row; kp_.col = col; kp_.angle = angle;

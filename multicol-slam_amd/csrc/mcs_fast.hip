@@ -68,7 +68,7 @@ __device__ __forceinline__ int fast_score(const uint8_t* c /* centre in LDS tile
 	return best > t ? best - 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd) {
+__global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd, int cell0, int ncells) {
 	__shared__ __attribute__((aligned(16))) uint8_t tile[kTileRows * kTilePitch];
 	__shared__ __attribute__((aligned(16))) uint8_t sc[kScRows * kScPitch];
 	__shared__ uint32_t keepBits[128];   // NMS + mask verdict per pixel of the cell (row-major bit index), 60*60 <= 4096 bits
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 	const int logical = (blockIdx.x % kNumXCD) * perXcd + blockIdx.x / kNumXCD;
 	if (logical >= nblocks) return;
 	const PyrDesc& d = *b.desc;
-	const int img = logical / d.cellsPerImage;
-	const int ci = logical - img * d.cellsPerImage;
+	const int img = logical / ncells;                  // this launch covers cells [cell0, cell0 + ncells) of every image (a range of pyramid levels)
+	const int ci = cell0 + (logical - img * ncells);
 	const CellInfo cell = b.cells[ci];
 	const LevelInfo& L = d.lv[cell.level];
 	const int tid = threadIdx.x;
@@ -190,10 +190,17 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 	(void)sw;
 }
 
-void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
-	const int nblocks = nimg * hd.cellsPerImage;
+// cells of pyramid levels [level0, level1): level 0 needs no pyramid, so the caller can run it beside the resize chain
+void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0, int level1) {
+	if (level1 > hd.nlevels) level1 = hd.nlevels;
+	if (level0 >= level1) return;
+	const int cell0 = hd.lv[level0].cellBase;
+	const int cellEnd = level1 < hd.nlevels ? hd.lv[level1].cellBase : hd.cellsPerImage;
+	const int ncells = cellEnd - cell0;
+	const int nblocks = nimg * ncells;
+	if (nblocks <= 0) return;
 	const int perXcd = (nblocks + kNumXCD - 1) / kNumXCD;
-	hipLaunchKernelGGL(k_fast_cells, dim3(perXcd * kNumXCD), dim3(256), 0, s, b, nimg, nblocks, perXcd);
+	hipLaunchKernelGGL(k_fast_cells, dim3(perXcd * kNumXCD), dim3(256), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);
 }
 
 }  // namespace mcs

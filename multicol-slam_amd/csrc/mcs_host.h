@@ -41,8 +41,9 @@ struct mcs_ctx {
 	uint8_t* arena = nullptr; size_t arenaCap = 0;        // scratch + host-kind staging of the window / projection / map-point entry points (mcs_capi_window.hip)
 	// Second HIP stream for the latency-bound / independent kernels (blur next to FAST+oct-tree, the greedy resolution next to the
 	// following batch's extraction): they leave most CUs idle, so overlapping them with the VALU-bound kernels is free throughput.
-	hipStream_t side = nullptr;
-	hipEvent_t evFork = nullptr, evBlur = nullptr, evMatch = nullptr, evGreedy = nullptr;
+	hipStream_t side = nullptr;    // extraction fork: resize chain + blur beside FAST + oct-tree
+	hipStream_t side2 = nullptr;   // the greedy match resolution (its own stream: it must not hold up the next batch's resize chain)
+	hipEvent_t evFork = nullptr, evPyr1 = nullptr, evPyr = nullptr, evBlur = nullptr, evMatch = nullptr, evGreedy = nullptr;
 	bool greedyPending = false;
 	bool overlap() const { return side != nullptr && !timing; }   // per-kernel timing runs everything in order on the main stream
 

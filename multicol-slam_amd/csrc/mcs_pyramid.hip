@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void k_resize_level(ExtractBuffers b, int leve
 	}
 }
 
-void launch_pyramid(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
-	for (int level = 1; level < hd.nlevels; ++level) {
+void launch_pyramid(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0, int level1) {   // levels [level0, level1), level0 >= 1
+	for (int level = level0 < 1 ? 1 : level0; level < hd.nlevels && level < level1; ++level) {
 		const LevelInfo& L = hd.lv[level];
 		const int tilesX = (L.w + PT_W - 1) / PT_W, tilesY = (L.h + PT_H - 1) / PT_H;
 		hipLaunchKernelGGL(k_resize_level, dim3(nimg * tilesX * tilesY), dim3(256), 0, s, b, level, tilesX, tilesY);
