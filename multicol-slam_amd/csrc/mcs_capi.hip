@@ -75,7 +75,7 @@ struct mcs_extractor {
 	OcamDev* d_cams = nullptr;
 	std::vector<OcamDev> h_cams;
 	// descriptor passes (mcs_describe.hip): fallback list of the fast pass, its running total, the guard band
-	int* d_fbCount = nullptr; uint32_t* d_fbList = nullptr; unsigned long long* d_fbStats = nullptr;
+	int* d_fbCount = nullptr; uint32_t* d_fbList = nullptr; unsigned long long* d_fbStats = nullptr; KpAux* d_aux = nullptr;
 	int describeMode = 0; double guardEps = kDefaultGuardEps;
 	// host-kind input staging: the caller's image / mask block as it lies in host memory (same pitch and stride), grown on demand
 	uint8_t *d_inImg = nullptr, *d_inMask = nullptr; size_t inImgCap = 0, inMaskCap = 0;
@@ -349,6 +349,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	ALLOC(e->d_fbCount, sizeof(int));
 	ALLOC(e->d_fbList, B * (size_t)((hd.kpCap + 3) / 4 * 4) * sizeof(uint32_t));
 	ALLOC(e->d_fbStats, sizeof(unsigned long long));
+	ALLOC(e->d_aux, B * (size_t)((hd.kpCap + 3) / 4 * 4) * describe_aux_bytes());
 	ALLOC(e->d_nkp, B * sizeof(int));
 	ALLOC(e->d_kps, B * hd.kpCap * sizeof(mcs_keypoint));
 	ALLOC(e->d_odesc, B * hd.kpCap * (size_t)hd.descSize);
@@ -380,7 +381,7 @@ int mcs_extractor_destroy(mcs_extractor* e) {
 	}
 	void* ptrs[] = {e->d_desc, e->d_cells, e->d_taps, e->d_maskMap, e->d_pyr, e->d_blur, e->d_slots, e->d_dense, e->d_knode,
 	                e->d_sel, e->d_cellCount, e->d_denseCount, e->d_selCount, e->d_status, e->d_cams, e->d_nkp, e->d_kps, e->d_odesc,
-	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_fbStats};
+	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_fbStats, e->d_aux};
 	for (void* p : ptrs) (void)hipFree(p);
 	delete e;
 	return MCS_OK;
@@ -429,7 +430,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 	b.desc = e->d_desc; b.cells = e->d_cells; b.taps = e->d_taps; b.maskMap = e->d_maskMap;
 	b.pyr = e->d_pyr; b.blur = e->d_blur; b.slots = e->d_slots; b.cellCount = e->d_cellCount; b.dense = e->d_dense; b.knode = e->d_knode;
 	b.denseCount = e->d_denseCount; b.sel = e->d_sel; b.selCount = e->d_selCount; b.status = e->d_status;
-	b.fbCount = e->d_fbCount; b.fbList = e->d_fbList; b.fbStats = e->d_fbStats; b.guardEps = e->guardEps; b.describeMode = e->describeMode;
+	b.aux = e->d_aux; b.fbCount = e->d_fbCount; b.fbList = e->d_fbList; b.fbStats = e->d_fbStats; b.guardEps = e->guardEps; b.describeMode = e->describeMode;
 	b.outImgPitch = out_image_pitch_rows ? out_image_pitch_rows : (size_t)hd.kpCap;
 	b.outRowStride = out_row_stride ? out_row_stride : hd.descSize;
 	if (b.outImgPitch < (size_t)hd.kpCap || b.outRowStride < hd.descSize) return fail(MCS_ERR_INVALID, "output image pitch / row stride smaller than the rows they hold");

@@ -66,6 +66,7 @@ struct OcamDev {
 	int fastOk, pad_;
 };
 
+struct KpAux;   // per-keypoint scratch of the descriptor passes (mcs_describe.hip)
 struct ExtractBuffers {
 	const PyrDesc* desc;          // device copy
 	const CellInfo* cells;        // [cellsPerImage]
@@ -85,6 +86,7 @@ struct ExtractBuffers {
 	const OcamDev* cams;          // [B] or nullptr
 	int* status;                  // device error word (capacity overflows)
 	// dBRIEF / mdBRIEF: fast pass + exact pass over the fast pass's fallback list (mcs_describe.hip)
+	KpAux* aux;                          // [B][roundup4(kpCap)] orientation / ray / pattern-angle records prepared for the fast pass
 	int* fbCount; uint32_t* fbList;      // keypoint slots (image * wavesPerImage + slot) the fast pass handed to the exact pass, this batch
 	unsigned long long* fbStats;         // running total of those (all batches of the extractor)
 	double guardEps;                     // half-width of the guard band around the rounding ties
@@ -106,6 +108,7 @@ void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream
 void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
 void launch_blur(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
 void launch_describe(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
+size_t describe_aux_bytes();   // sizeof(KpAux)
 
 // Row i of a descriptor set -> row of the caller's array.  A set is either contiguous (blk = 0) or made of blocks of `blk` rows lying `bpitch` rows
 // apart (mcs_desc_set.block_rows / block_pitch_rows: the cameras of one multi-frame inside a gathered [camera][frame][row] buffer).

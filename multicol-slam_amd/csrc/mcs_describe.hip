@@ -208,12 +208,75 @@ __host__ __device__ constexpr int coord_bytes(int mode, int npoints) { return mo
 
 // Everything a keypoint needs before its descriptor: slot -> (level, position), the output row, the blurred patch in LDS, orientation (E5), the
 // keypoint record and ray (E8/E9).  Shared by the exact pass (describe_wave) and the fast pass (k_describe_fast); false = this wave has no keypoint.
+constexpr int kPatchTrips = (kPatchRows * kPatchDw + 63) / 64;
 struct KeyPt {
 	int img, out, level, row, col;
 	float angle;
 	double rayx, rayy, rayz;
 	Sampler sm;
 };
+
+// slot s of an image -> (level, position in the level's selection): slot = the keypoint's row in the image's output block, levels in order, a level's
+// keys in their final list order.  `total` = all selected keys of the image.
+__device__ __forceinline__ void find_slot(const PyrDesc& d, const int* selCount, int s, int& level, int& pos, int& total) {
+	total = 0; level = -1; pos = 0;
+	for (int l = 0; l < d.nlevels; ++l) {
+		const int c = selCount[l];
+		if (s >= total && s < total + c) { level = l; pos = s - total; }
+		total += c;
+	}
+}
+
+// IC_Angle (src/mdBRIEFextractorOct.cpp:221-248) by one wave: lane l < 33 owns disc row v = l - 16 (9 independent unaligned dword loads), int32 moments
+// reduced with cross-lane shuffles (exact, order-free), then cv::fastAtan2
+__device__ __forceinline__ float ic_angle_wave(const uint8_t* raw, int rstride, int row, int col) {
+	const int lane = threadIdx.x & 63;
+	int m10 = 0, m01 = 0;
+	if (lane <= 2 * kHalfPatch) {
+		const int v = lane - kHalfPatch;
+		const int um = c_umax[v < 0 ? -v : v];
+		const uint8_t* rp = raw + (size_t)(row + v) * rstride + (col - kHalfPatch);
+		uint32_t w[9];
+#pragma unroll
+		for (int k = 0; k < 9; ++k) __builtin_memcpy(&w[k], rp + 4 * k, 4);
+		int rowSum = 0, rowMom = 0;
+#pragma unroll
+		for (int j = 0; j <= 2 * kHalfPatch; ++j) {
+			const int u = j - kHalfPatch;
+			int val = (int)((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+			val = (u >= -um && u <= um) ? val : 0;
+			rowSum += val;
+			rowMom += u * val;
+		}
+		m10 = rowMom;
+		m01 = v * rowSum;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+	return fast_atan2_deg((float)m01, (float)m10);
+}
+
+// issue the loads of the blurred (2R+1)^2 neighbourhood (kPatchDw unaligned dwords per row, rows are in-pitch even at the right edge) / write them to LDS
+__device__ __forceinline__ void patch_load(const uint8_t* blur, int bstride, int row, int col, uint32_t (&pv)[kPatchTrips]) {
+	const int lane = threadIdx.x & 63;
+	const uint8_t* bp = blur + (size_t)(row - kPatchR) * bstride + (col - kPatchR);
+#pragma unroll
+	for (int t = 0; t < kPatchTrips; ++t) {
+		const int i = min(lane + 64 * t, kPatchRows * kPatchDw - 1);
+		const int r = i / kPatchDw, k = i - r * kPatchDw;
+		__builtin_memcpy(&pv[t], bp + (size_t)r * bstride + 4 * k, 4);
+	}
+}
+__device__ __forceinline__ void patch_store(uint8_t* patch, const uint32_t (&pv)[kPatchTrips]) {   // lane-private slots; every later read is by the same wave
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int t = 0; t < kPatchTrips; ++t) {
+		const int i = min(lane + 64 * t, kPatchRows * kPatchDw - 1);   // the last trip's surplus lanes rewrite the last dword
+		const int r = i / kPatchDw, k = i - r * kPatchDw;
+		*reinterpret_cast<uint32_t*>(&patch[r * kPatchPitch + 4 * k]) = pv[t];
+	}
+}
+
 template <bool NEED_RAY>   // the ray is also computed when the caller asked for rays
 __device__ __forceinline__ bool kp_prologue(const ExtractBuffers& b, int wavesPerImage, int gw, uint8_t* patch, KeyPt& kp_) {
 	const PyrDesc& d = *b.desc;
@@ -225,18 +288,11 @@ __device__ __forceinline__ bool kp_prologue(const ExtractBuffers& b, int wavesPe
 	const int s = gw - img * wavesPerImage;
 	const int* selCount = b.selCount + (size_t)img * d.nlevels;
 
-	// slot s = the keypoint's row in the image's output block: levels in order, a level's keys in their final list order.  (Slots used to follow the
-	// per-level capacity ranges of b.sel; the ~16 % of empty slots between the levels returned at once and left their SIMD share idle until the rest of
-	// the workgroup was done.)
-	int total = 0, before = 0, level = -1, pos = 0;
-	for (int l = 0; l < d.nlevels; ++l) {
-		const int c = selCount[l];
-		if (s >= total && s < total + c) { level = l; pos = s - total; before = total; }
-		total += c;
-	}
+	int total, level, pos;
+	find_slot(d, selCount, s, level, pos, total);
 	if (s == 0 && lane == 0) b.nkp[img] = total < d.kpCap ? total : d.kpCap;
 	bool active = level >= 0;
-	const int out = before + pos;
+	const int out = s;
 	if (s == 0 && total > d.kpCap && lane == 0) atomicExch(b.status, MCS_ERR_CAPACITY);   // more keys selected than output rows (cannot happen with kpCap as sized by the host)
 	if (active && out >= d.kpCap) active = false;
 	if (!active) return false;   // waves are independent (no block barriers anywhere in these kernels)
@@ -255,44 +311,11 @@ __device__ __forceinline__ bool kp_prologue(const ExtractBuffers& b, int wavesPe
 		const uint8_t* raw = level_ptr(b, d, img, level, &rstride);
 		sm.blur = b.blur + (size_t)img * d.pyrBytes + L.off; sm.bstride = L.stride;
 		sm.raw = raw; sm.rstride = rstride; sm.w = L.w; sm.h = L.h;
-		// Stage the blurred (2R+1)^2 neighbourhood (kPatchDw unaligned dwords per row, rows are in-pitch even at the right edge): the loads are ISSUED
-		// here and written to LDS only after the orientation and the keypoint's ray are done — their round trip hides behind that arithmetic.
-		constexpr int kPatchTrips = (kPatchRows * kPatchDw + 63) / 64;
+		// the patch loads are ISSUED here and written to LDS only after the orientation and the keypoint's ray are done: their round trip hides behind that arithmetic
 		uint32_t pv[kPatchTrips];
-		{
-			const uint8_t* bp = sm.blur + (size_t)(row - kPatchR) * sm.bstride + (col - kPatchR);
-#pragma unroll
-			for (int t = 0; t < kPatchTrips; ++t) {
-				const int i = min(lane + 64 * t, kPatchRows * kPatchDw - 1);
-				const int r = i / kPatchDw, k = i - r * kPatchDw;
-				__builtin_memcpy(&pv[t], bp + (size_t)r * sm.bstride + 4 * k, 4);
-			}
-			sm.patch = patch; sm.prow = row - kPatchR; sm.pcol = col - kPatchR;
-		}
-		// ---- IC_Angle: lane l < 33 owns disc row v = l - 16 (9 independent unaligned dword loads), int32 moments
-		int m10 = 0, m01 = 0;
-		if (lane <= 2 * kHalfPatch) {
-			const int v = lane - kHalfPatch;
-			const int um = c_umax[v < 0 ? -v : v];
-			const uint8_t* rp = raw + (size_t)(row + v) * rstride + (col - kHalfPatch);
-			uint32_t w[9];
-#pragma unroll
-			for (int k = 0; k < 9; ++k) __builtin_memcpy(&w[k], rp + 4 * k, 4);
-			int rowSum = 0, rowMom = 0;
-#pragma unroll
-			for (int j = 0; j <= 2 * kHalfPatch; ++j) {
-				const int u = j - kHalfPatch;
-				int val = (int)((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
-				val = (u >= -um && u <= um) ? val : 0;
-				rowSum += val;
-				rowMom += u * val;
-			}
-			m10 = rowMom;
-			m01 = v * rowSum;
-		}
-#pragma unroll
-		for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-		angle = fast_atan2_deg((float)m01, (float)m10);
+		patch_load(sm.blur, sm.bstride, row, col, pv);
+		sm.patch = patch; sm.prow = row - kPatchR; sm.pcol = col - kPatchR;
+		angle = ic_angle_wave(raw, rstride, row, col);
 		// ---- keypoint record (E8): level coordinates -> image coordinates with the FLOAT scale (:1305,1331)
 		pxf = (float)col; pyf = (float)row;
 		if (level != 0) { pxf = pxf * L.scale; pyf = pyf * L.scale; }
@@ -307,12 +330,7 @@ __device__ __forceinline__ bool kp_prologue(const ExtractBuffers& b, int wavesPe
 				rp[0] = rayx; rp[1] = rayy; rp[2] = rayz;
 			}
 		}
-#pragma unroll
-		for (int t = 0; t < kPatchTrips; ++t) {   // the patch, now that its loads have had time to arrive (the last trip's surplus lanes rewrite the last dword)
-			const int i = min(lane + 64 * t, kPatchRows * kPatchDw - 1);
-			const int r = i / kPatchDw, k = i - r * kPatchDw;
-			*reinterpret_cast<uint32_t*>(&patch[r * kPatchPitch + 4 * k]) = pv[t];
-		}
+		patch_store(patch, pv);
 	}
 	kp_.img = img; kp_.out = out; kp_.level = level; kp_.row = row; kp_.col = col; kp_.angle = angle;
 	kp_.rayx = rayx; kp_.rayy = rayy; kp_.rayz = rayz; kp_.sm = sm;
@@ -590,54 +608,149 @@ __device__ __forceinline__ void fast_w2i(const FastCam& C, double xr, double yr,
 	v = __builtin_fma(uu, C.e, vv + C.v0);
 }
 
+// ---- what the fast pass needs per keypoint besides the patch, prepared by two small kernels at full occupancy --------------------------------------
+// The fast pass runs 4 waves per SIMD (registers), and a wave used to spend a quarter of its instructions on work that is either only 33 lanes wide
+// (IC_Angle) or identical in all 64 lanes (ImgToWorld of the keypoint, the sincos of the pattern angles).  Now
+//   k_orient_a   one wave per output row: slot -> (level, position), IC_Angle, the keypoint record (E8), row / column / angle into KpAux
+//   k_orient_b   one THREAD per output row: ImgToWorld (ray, E9), the undistorted keypoint, the pattern angles and their sin / cos into KpAux
+// The arithmetic is the exact pass's, statement for statement (the exact pass still does all of it itself and writes the same values).
+struct KpAux {
+	int level;            // -1: no keypoint in this slot
+	int row, col;
+	float angle, pxf, pyf;
+	int pad_[2];
+	double ray[3];
+	double ukx, uky;
+	double cs[6];         // cos, sin of the (up to) three pattern angles
+};
+
+__global__ __launch_bounds__(256) void k_orient_a(ExtractBuffers b, int wavesPerImage, int nslots) {
+	const PyrDesc& d = *b.desc;
+	const int lane = threadIdx.x & 63;
+	int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (gw >= nslots) return;
+	gw = __builtin_amdgcn_readfirstlane(gw);
+	const int img = gw / wavesPerImage, s = gw - img * wavesPerImage;
+	int total, level, pos;
+	find_slot(d, b.selCount + (size_t)img * d.nlevels, s, level, pos, total);
+	if (s == 0 && lane == 0) {
+		b.nkp[img] = total < d.kpCap ? total : d.kpCap;
+		if (total > d.kpCap) atomicExch(b.status, MCS_ERR_CAPACITY);
+	}
+	KpAux* aux = b.aux + gw;
+	if (level < 0 || s >= d.kpCap) { if (lane == 0) aux->level = -1; return; }
+	const LevelInfo& L = d.lv[level];
+	const uint32_t rec = b.sel[(size_t)img * d.selPerImage + L.selBase + pos];
+	const int col = (int)(rec & 0xFFF) + kMinBorder, row = (int)((rec >> 12) & 0xFFF) + kMinBorder;
+	int rstride;
+	const uint8_t* raw = level_ptr(b, d, img, level, &rstride);
+	const float angle = ic_angle_wave(raw, rstride, row, col);
+	float pxf = (float)col, pyf = (float)row;
+	if (level != 0) { pxf = pxf * L.scale; pyf = pyf * L.scale; }
+	if (lane == 0) {
+		mcs_keypoint kp;
+		kp.x = pxf; kp.y = pyf; kp.size = L.kpSize; kp.angle = angle; kp.response = (float)(rec >> 24); kp.octave = level; kp.class_id = -1;
+		b.kps[(size_t)img * d.kpCap + s] = kp;
+		aux->level = level; aux->row = row; aux->col = col; aux->angle = angle; aux->pxf = pxf; aux->pyf = pyf;
+	}
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_orient_b(ExtractBuffers b, int wavesPerImage, int nslots) {
+	const int gw = blockIdx.x * 256 + threadIdx.x;
+	if (gw >= nslots) return;
+	KpAux* aux = b.aux + gw;
+	if (aux->level < 0) return;
+	const PyrDesc& d = *b.desc;
+	const int img = gw / wavesPerImage, s = gw - img * wavesPerImage;
+	const OcamDev& cam = b.cams[img];
+	double rayx, rayy, rayz;
+	img2world(cam, (double)aux->pxf, (double)aux->pyf, rayx, rayy, rayz);
+	if (b.rays) {
+		double* rp = b.rays + ((size_t)img * d.kpCap + s) * 3;
+		rp[0] = rayx; rp[1] = rayy; rp[2] = rayz;
+	}
+	aux->ray[0] = rayx; aux->ray[1] = rayy; aux->ray[2] = rayz;
+	double ukx = 0.0, uky = 0.0;
+	if (d.undistort) {
+		const double p0 = cam.p[0];
+		ukx = -rayx / rayz * p0;
+		uky = -rayy / rayz * p0;
+	}
+	aux->ukx = ukx; aux->uky = uky;
+	const float angle = aux->angle;
+	double ang[3] = {0.0, 0.0, 0.0};
+	if (MODE == 1) {
+		const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
+		ang[0] = (double)(angle * DEG2RADf);
+	} else {
+		const float RHOf = 180.0f / 3.1415926535897932384626f;
+		const double RHOd = 180.0 / 3.1415926535897932384626433832795028841971693993;
+		const double rot = 20.0 / RHOd;
+		ang[0] = (double)(angle / RHOf);
+		ang[1] = ang[0] + rot; ang[2] = ang[0] - rot;
+	}
+#pragma unroll
+	for (int k = 0; k < (MODE == 2 ? 3 : 1); ++k) {
+		double sn, cs;
+		sincos(ang[k], &sn, &cs);
+		aux->cs[2 * k] = cs; aux->cs[2 * k + 1] = sn;
+	}
+}
+
 #ifndef MCS_FAST_WAVES_PER_EU
 #define MCS_FAST_WAVES_PER_EU 4
 #endif
 template <int MODE, int NB>
 __attribute__((amdgpu_waves_per_eu(MCS_FAST_WAVES_PER_EU, MCS_FAST_WAVES_PER_EU)))
-__global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffers b, int wavesPerImage) {
+__global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffers b, int wavesPerImage, int nslots) {
 	extern __shared__ __attribute__((aligned(16))) double lds[];   // the blurred patch of each wave's keypoint
 	static_assert(MODE == 1 || MODE == 2, "the fast pass is for the distorted patterns");
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int gw = blockIdx.x * kFastWaves + wave;
 	KeyPt kp_;
-	if (!kp_prologue<true>(b, wavesPerImage, gw, reinterpret_cast<uint8_t*>(lds) + (size_t)wave * kPatchBytes, kp_)) return;
+	uint8_t* const patchLds = reinterpret_cast<uint8_t*>(lds) + (size_t)wave * kPatchBytes;
 	const PyrDesc& d = *b.desc;
+	// this keypoint, as the two orientation kernels left it (wave-uniform: scalar loads)
+	const int gwu = __builtin_amdgcn_readfirstlane(gw);
+	if (gwu >= nslots) return;
+	const KpAux& ax = b.aux[gwu];
+	const int level = ax.level;
+	if (level < 0) return;
+	kp_.img = gwu / wavesPerImage; kp_.out = gwu - kp_.img * wavesPerImage; kp_.level = level; kp_.row = ax.row; kp_.col = ax.col;
+	{
+		const LevelInfo& L = d.lv[level];
+		Sampler& sm = kp_.sm;
+		int rstride;
+		sm.raw = level_ptr(b, d, kp_.img, level, &rstride);
+		sm.rstride = rstride;
+		sm.blur = b.blur + (size_t)kp_.img * d.pyrBytes + L.off; sm.bstride = L.stride;
+		sm.w = L.w; sm.h = L.h;
+		sm.patch = patchLds; sm.prow = kp_.row - kPatchR; sm.pcol = kp_.col - kPatchR;
+	}
+	uint32_t pv[kPatchTrips];
+	patch_load(kp_.sm.blur, kp_.sm.bstride, kp_.row, kp_.col, pv);   // in flight while the camera constants arrive
 	const OcamDev& cam = b.cams[kp_.img];
-	auto to_exact = [&]() { if (lane == 0) { const int at = atomicAdd(b.fbCount, 1); b.fbList[at] = (uint32_t)gw; } };
-	if (__builtin_amdgcn_readfirstlane(cam.fastOk) == 0) { to_exact(); return; }
+	auto to_exact = [&]() { if (lane == 0) { const int at = atomicAdd(b.fbCount, 1); b.fbList[at] = (uint32_t)gwu; } };
+	if (cam.fastOk == 0) { to_exact(); return; }
 
 	FastCam C;
 #pragma unroll
-	for (int i = 0; i < MCS_MAX_POLY; ++i) C.cP[i] = uniform_f64(&cam.invP[i]);
-	C.deg = __builtin_amdgcn_readfirstlane(cam.invP_deg);
-	C.c = uniform_f64(&cam.c); C.d = uniform_f64(&cam.d); C.e = uniform_f64(&cam.e); C.u0 = uniform_f64(&cam.u0); C.v0 = uniform_f64(&cam.v0);
-	C.p0 = uniform_f64(&cam.p[0]); C.invP0 = uniform_f64(&cam.invP0);
+	for (int i = 0; i < MCS_MAX_POLY; ++i) C.cP[i] = cam.invP[i];
+	C.deg = cam.invP_deg;
+	C.c = cam.c; C.d = cam.d; C.e = cam.e; C.u0 = cam.u0; C.v0 = cam.v0;
+	C.p0 = cam.p[0]; C.invP0 = cam.invP0;
 	C.hp = C.p0 < 0.0 ? -kHalfPi : kHalfPi;
 
 	constexpr int NP = 128 * NB;
 	uint32_t ppk[NB];
 #pragma unroll
 	for (int j = 0; j < NB; ++j) ppk[j] = reinterpret_cast<const uint32_t*>(c_pattern)[j * 64 + lane];
-	// the undistorted keypoint and the pattern angles: the SAME operations as the exact pass (they feed both)
-	double ukx = 0.0, uky = 0.0;
-	if (d.undistort) {
-		ukx = -kp_.rayx / kp_.rayz * C.p0;
-		uky = -kp_.rayy / kp_.rayz * C.p0;
-	}
-	double ang0, ang1 = 0.0, ang2 = 0.0;
-	if (MODE == 1) {
-		const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
-		ang0 = (double)(kp_.angle * DEG2RADf);
-	} else {
-		const float RHOf = 180.0f / 3.1415926535897932384626f;
-		const double RHOd = 180.0 / 3.1415926535897932384626433832795028841971693993;
-		const double rot = 20.0 / RHOd;
-		ang0 = (double)(kp_.angle / RHOf);
-		ang1 = ang0 + rot; ang2 = ang0 - rot;
-	}
-	double sinA, cosA;
-	sincos(lane == 1 ? ang1 : (lane == 2 ? ang2 : ang0), &sinA, &cosA);   // the same ocml kernels as the exact pass: bit-identical ax / ay
+	const double ukx = ax.ukx, uky = ax.uky;
+	double axc[3], ays[3];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) { axc[k] = ax.cs[2 * k]; ays[k] = ax.cs[2 * k + 1]; }
+	patch_store(patchLds, pv);
 
 	const double lim = 0.5 - b.guardEps;
 	const int row = kp_.row, col = kp_.col;
@@ -648,7 +761,7 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 	constexpr int npat = MODE == 2 ? 3 : 1;
 #pragma unroll
 	for (int pat = 0; pat < npat; ++pat) {
-		const double ax = __shfl(cosA, pat), ay = __shfl(sinA, pat);
+		const double ax = axc[pat], ay = ays[pat];
 		double u[2 * NB], v[2 * NB];
 		double sumx = 0.0, sumy = 0.0;
 #pragma unroll
@@ -737,12 +850,15 @@ static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hi
 		if (b.describeMode == 0) {   // fast pass + exact pass over its fallback list
 			const int fblocks = nimg * wavesPerImage / kFastWaves, lblocks = std::min(blocks, 2048);
 			const size_t fLds = (size_t)kFastWaves * kPatchBytes;
+			const int nslots = nimg * wavesPerImage;
 			(void)hipMemsetAsync(b.fbCount, 0, sizeof(int), s);
-			if (nb == 2) { hipLaunchKernelGGL((k_describe_fast<MODE, 2>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage);
+			hipLaunchKernelGGL(k_orient_a, dim3((nslots + 3) / 4), dim3(256), 0, s, b, wavesPerImage, nslots);
+			hipLaunchKernelGGL((k_orient_b<MODE>), dim3((nslots + 255) / 256), dim3(256), 0, s, b, wavesPerImage, nslots);
+			if (nb == 2) { hipLaunchKernelGGL((k_describe_fast<MODE, 2>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage, nslots);
 			               hipLaunchKernelGGL((k_describe_list<MODE, 2>), dim3(lblocks), dim3(64), ldsBytes, s, b, wavesPerImage); }
-			else if (nb == 4) { hipLaunchKernelGGL((k_describe_fast<MODE, 4>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage);
+			else if (nb == 4) { hipLaunchKernelGGL((k_describe_fast<MODE, 4>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage, nslots);
 			                    hipLaunchKernelGGL((k_describe_list<MODE, 4>), dim3(lblocks), dim3(64), ldsBytes, s, b, wavesPerImage); }
-			else { hipLaunchKernelGGL((k_describe_fast<MODE, 8>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage);
+			else { hipLaunchKernelGGL((k_describe_fast<MODE, 8>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage, nslots);
 			       hipLaunchKernelGGL((k_describe_list<MODE, 8>), dim3(lblocks), dim3(64), ldsBytes, s, b, wavesPerImage); }
 			return;
 		}
@@ -752,6 +868,8 @@ static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hi
 	else if constexpr (MODE == 2) hipLaunchKernelGGL((k_describe_wide<MODE, 8>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 	else hipLaunchKernelGGL((k_describe<MODE, 8>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 }
+
+size_t describe_aux_bytes() { return sizeof(KpAux); }
 
 void launch_describe(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
 	if (hd.mode == 0) launch_mode<0>(b, hd, nimg, s);

@@ -13,7 +13,7 @@ if [ "$mode" = build ]; then
 else
   for g in "$@"; do
     lib=$PWD/gpurun_ab/libmcs_hip_$g.so; [ -f $lib ] || lib=$PWD/multicol-slam_amd/libmcs_hip.so   # an unknown name benches the tree's own library (with whatever environment the caller set)
-    MCS_HIP_LIB=$lib timeout 300 python bench.py --no-cpu-baseline > /tmp/ab.json 2>/tmp/ab.err
+    MCS_HIP_LIB=$lib timeout 300 python bench.py --no-cpu-baseline --no-secondary --steps 30 > /tmp/ab.json 2>/tmp/ab.err
     python - "$g" <<'PY'
 import json, sys
 try:
