@@ -109,6 +109,7 @@ int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
 	if (getenv("MCS_NO_OVERLAP") == nullptr) {
 		HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
 		HIPCHK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
+
 		HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&c->evPyr1, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&c->evPyr, hipEventDisableTiming));
@@ -493,7 +494,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		launch_fast(b, hd, nimg, s, 1, 2);
 		HIPCHK(hipStreamWaitEvent(s, c->evPyr, 0));
 		launch_fast(b, hd, nimg, s, 2, hd.nlevels);
-		launch_octree(b, hd, nimg, s);
+		launch_octree(b, hd, nimg, s);   // (oct-trees of levels 0 / 1 on a further stream beside FAST of the rest: measured, no gain)
 		HIPCHK(hipStreamWaitEvent(s, c->evBlur, 0));
 	} else {
 		c->tic("pyramid"); launch_pyramid(b, hd, nimg, s); c->toc("pyramid");

@@ -105,7 +105,7 @@ __host__ __device__ inline const uint8_t* level_ptr(const ExtractBuffers& b, con
 // kernel launchers (each enqueues on `s`)
 void launch_pyramid(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0 = 1, int level1 = MCS_MAX_LEVELS);
 void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0 = 0, int level1 = MCS_MAX_LEVELS);
-void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
+void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0 = 0, int level1 = MCS_MAX_LEVELS);
 void launch_blur(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
 void launch_describe(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
 size_t describe_aux_bytes();   // sizeof(KpAux)

@@ -624,35 +624,67 @@ struct KpAux {
 	double cs[6];         // cos, sin of the (up to) three pattern angles
 };
 
+// Four keypoints per wave (16 lanes each: lane j of a group owns disc rows j - 16, j and — lane 0 — 16): a wave per keypoint spent its life waiting
+// for three dependent memory round trips (counts -> record -> pixels) with 33 busy lanes.
 __global__ __launch_bounds__(256) void k_orient_a(ExtractBuffers b, int wavesPerImage, int nslots) {
 	const PyrDesc& d = *b.desc;
-	const int lane = threadIdx.x & 63;
-	int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (gw >= nslots) return;
-	gw = __builtin_amdgcn_readfirstlane(gw);
-	const int img = gw / wavesPerImage, s = gw - img * wavesPerImage;
+	const int lane = threadIdx.x & 63, j = lane & 15;
+	const int gw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+	const bool inRange = gw < nslots;
+	const int gwc = inRange ? gw : nslots - 1;
+	const int img = gwc / wavesPerImage, s = gwc - img * wavesPerImage;
 	int total, level, pos;
 	find_slot(d, b.selCount + (size_t)img * d.nlevels, s, level, pos, total);
-	if (s == 0 && lane == 0) {
+	if (inRange && s == 0 && j == 0) {
 		b.nkp[img] = total < d.kpCap ? total : d.kpCap;
 		if (total > d.kpCap) atomicExch(b.status, MCS_ERR_CAPACITY);
 	}
-	KpAux* aux = b.aux + gw;
-	if (level < 0 || s >= d.kpCap) { if (lane == 0) aux->level = -1; return; }
-	const LevelInfo& L = d.lv[level];
-	const uint32_t rec = b.sel[(size_t)img * d.selPerImage + L.selBase + pos];
+	const bool active = inRange && level >= 0 && s < d.kpCap;
+	KpAux* aux = b.aux + gwc;
+	if (inRange && !active && j == 0) aux->level = -1;
+	const int lv = active ? level : 0;
+	const LevelInfo& L = d.lv[lv];
+	uint32_t rec = 0;
+	if (active) rec = b.sel[(size_t)img * d.selPerImage + L.selBase + pos];
 	const int col = (int)(rec & 0xFFF) + kMinBorder, row = (int)((rec >> 12) & 0xFFF) + kMinBorder;
 	int rstride;
-	const uint8_t* raw = level_ptr(b, d, img, level, &rstride);
-	const float angle = ic_angle_wave(raw, rstride, row, col);
+	const uint8_t* raw = level_ptr(b, d, img, lv, &rstride);
+	int m10 = 0, m01 = 0;
+	if (active) {
+#pragma unroll
+		for (int t = 0; t < 3; ++t) {
+			const int r = j + 16 * t;          // disc row index 0..32
+			if (r <= 2 * kHalfPatch) {
+				const int v = r - kHalfPatch;
+				const int um = c_umax[v < 0 ? -v : v];
+				const uint8_t* rp = raw + (size_t)(row + v) * rstride + (col - kHalfPatch);
+				uint32_t w[9];
+#pragma unroll
+				for (int k = 0; k < 9; ++k) __builtin_memcpy(&w[k], rp + 4 * k, 4);
+				int rowSum = 0, rowMom = 0;
+#pragma unroll
+				for (int jj = 0; jj <= 2 * kHalfPatch; ++jj) {
+					const int u = jj - kHalfPatch;
+					int val = (int)((w[jj >> 2] >> (8 * (jj & 3))) & 0xffu);
+					val = (u >= -um && u <= um) ? val : 0;
+					rowSum += val;
+					rowMom += u * val;
+				}
+				m10 += rowMom;
+				m01 += v * rowSum;
+			}
+		}
+	}
+#pragma unroll
+	for (int o = 8; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }   // within the 16-lane group (exact integer sums: order-free)
+	if (!active || j != 0) return;
+	const float angle = fast_atan2_deg((float)m01, (float)m10);
 	float pxf = (float)col, pyf = (float)row;
 	if (level != 0) { pxf = pxf * L.scale; pyf = pyf * L.scale; }
-	if (lane == 0) {
-		mcs_keypoint kp;
-		kp.x = pxf; kp.y = pyf; kp.size = L.kpSize; kp.angle = angle; kp.response = (float)(rec >> 24); kp.octave = level; kp.class_id = -1;
-		b.kps[(size_t)img * d.kpCap + s] = kp;
-		aux->level = level; aux->row = row; aux->col = col; aux->angle = angle; aux->pxf = pxf; aux->pyf = pyf;
-	}
+	mcs_keypoint kp;
+	kp.x = pxf; kp.y = pyf; kp.size = L.kpSize; kp.angle = angle; kp.response = (float)(rec >> 24); kp.octave = level; kp.class_id = -1;
+	b.kps[(size_t)img * d.kpCap + s] = kp;
+	aux->level = level; aux->row = row; aux->col = col; aux->angle = angle; aux->pxf = pxf; aux->pyf = pyf;
 }
 
 template <int MODE>
@@ -852,7 +884,7 @@ static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hi
 			const size_t fLds = (size_t)kFastWaves * kPatchBytes;
 			const int nslots = nimg * wavesPerImage;
 			(void)hipMemsetAsync(b.fbCount, 0, sizeof(int), s);
-			hipLaunchKernelGGL(k_orient_a, dim3((nslots + 3) / 4), dim3(256), 0, s, b, wavesPerImage, nslots);
+			hipLaunchKernelGGL(k_orient_a, dim3((nslots + 15) / 16), dim3(256), 0, s, b, wavesPerImage, nslots);
 			hipLaunchKernelGGL((k_orient_b<MODE>), dim3((nslots + 255) / 256), dim3(256), 0, s, b, wavesPerImage, nslots);
 			if (nb == 2) { hipLaunchKernelGGL((k_describe_fast<MODE, 2>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage, nslots);
 			               hipLaunchKernelGGL((k_describe_list<MODE, 2>), dim3(lblocks), dim3(64), ldsBytes, s, b, wavesPerImage); }

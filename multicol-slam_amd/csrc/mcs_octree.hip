@@ -56,7 +56,7 @@ __device__ int block_exscan(int* a, int n, int* wsum) {
 }
 
 template <int MAXN, int KCACHE>
-__global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg) {
+__global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int level0) {
 	__shared__ NodeBuf<MAXN> nb[2];
 	__shared__ uint32_t kd[KCACHE];          // LDS copy of the level's candidate records ...
 	__shared__ unsigned short kn[KCACHE];    // ... and of the node position of every key, when the level fits
@@ -70,8 +70,9 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg) {
 	__shared__ int shR;
 
 	const PyrDesc& d = *b.desc;
-	const int img = blockIdx.x / d.nlevels;
-	const int level = blockIdx.x - img * d.nlevels;
+	// level-major over the launch's level range: the big levels (most candidates, most passes) start first and the small ones fill the tail
+	const int level = level0 + blockIdx.x / nimg;
+	const int img = blockIdx.x - (level - level0) * nimg;
 	const LevelInfo& Lv = d.lv[level];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int N = Lv.nfeat;
@@ -295,11 +296,14 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg) {
 	if (tid == 0) *selCount = L;
 }
 
-void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
+void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0, int level1) {   // levels [level0, level1)
+	if (level1 > hd.nlevels) level1 = hd.nlevels;
+	if (level0 >= level1) return;
+	const int nl = level1 - level0;
 	int need = 0;
 	for (int l = 0; l < hd.nlevels; ++l) need = need > hd.lv[l].nfeat + 3 ? need : hd.lv[l].nfeat + 3, need = need > 4 * hd.lv[l].nIni ? need : 4 * hd.lv[l].nIni;
-	if (need <= 512) hipLaunchKernelGGL((k_octree<512, 3072>), dim3(nimg * hd.nlevels), dim3(256), 0, s, b, nimg);   // 50 KB LDS: 3 workgroups per CU
-	else hipLaunchKernelGGL((k_octree<1024, 2048>), dim3(nimg * hd.nlevels), dim3(256), 0, s, b, nimg);
+	if (need <= 512) hipLaunchKernelGGL((k_octree<512, 3072>), dim3(nimg * nl), dim3(256), 0, s, b, nimg, level0);   // 50 KB LDS: 3 workgroups per CU
+	else hipLaunchKernelGGL((k_octree<1024, 2048>), dim3(nimg * nl), dim3(256), 0, s, b, nimg, level0);
 }
 
 }  // namespace mcs
