@@ -152,8 +152,11 @@ def pmc_entry(tag, dom):
     """HBM bytes (FETCH_SIZE + WRITE_SIZE) and VALU wave-instructions per launch of kernel `dom` from the committed counter passes of this workload"""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        k = t["workloads"][tag]["kernels"][dom]
-        return int((k["fetch_kib"] + k["write_kib"]) * 1024), k.get("valu_insts")
+        ks = t["workloads"][tag]["kernels"]
+        parts = [ks[n] for n in (("describe", "orient_a", "orient_b", "describe_list") if dom == "describe" else (dom,)) if n in ks]   # "describe" = the whole descriptor stage
+        if not parts:
+            return None, None
+        return int(sum(k["fetch_kib"] + k["write_kib"] for k in parts) * 1024), sum(k.get("valu_insts", 0) for k in parts)
     except (OSError, KeyError, ValueError, TypeError):
         return None, None
 
@@ -219,6 +222,10 @@ class Job:
             self.db = torch.zeros((nk, lay.rows_frame, lay.row_stride), dtype=torch.uint8, device=dev)
             self.db_valid = torch.zeros((nk, lay.rows_frame), dtype=torch.uint8, device=dev)
             self._fill_database()
+        self.matched_set = self.sets[0]
+        if e.world > 1:   # prime the pipeline: the first step() matches the multi-frames exchanged here
+            self.extract_and_exchange(self.sets[1])
+            torch.cuda.synchronize(dev)
 
     def _make_set(self):
         torch, lay, dev, e = self.e.torch, self.lay, self.e.dev, self.e
@@ -248,19 +255,33 @@ class Job:
         g, v = b.G.data_ptr(), b.valid.data_ptr()
         return mcs.DescSet(g + doff, (g + moff) if self.masks_on else None, v + voff, None, n, stride, brows, bpitch)
 
-    def extract_and_exchange(self, b, img_buf=0):
+    def extract(self, b, img_buf=0):
         e, lay, lib, mcs, W, H = self.e, self.lay, self.e.lib, self.e.mcs, self.sp.W, self.sp.H
         sp_ = b.send.data_ptr()
         self.ex.extract_strided(lay.L, self.d_imgs[img_buf].data_ptr(), W * H, W, self.d_masks.data_ptr(), W * H, W, self.camarr, b.nkp.data_ptr(),
                                 b.kps.data_ptr(), sp_, sp_ + lay.desc_size, b.rays.data_ptr(), lay.rows_img, lay.row_stride)
         mcs.check(lib.mcs_rig_pack_headers(e.ctx.h, C.c_void_p(b.nkp.data_ptr()), lay.L, self.cap, C.c_void_p(sp_), lay.row_stride))
-        if e.world > 1:   # the one exchange step: descriptor | mask | count blocks of every rank's slab
-            if e.backend == "nccl":
-                e.dist.all_gather_into_tensor(b.G, b.send)
-            else:
-                b.G.copy_(e.rig.all_gather_blocks(b.send, e.world))
+
+    def exchange_begin(self, b):
+        """the one exchange step: descriptor | mask | count blocks of every rank's slab.  RCCL: asynchronous (its own stream, ordered behind the extraction)."""
+        e = self.e
+        if e.world == 1:
+            return None
+        if e.backend == "nccl":
+            return e.dist.all_gather_into_tensor(b.G, b.send, async_op=True)
+        b.G.copy_(e.rig.all_gather_blocks(b.send, e.world))   # gloo: functional runs on one shared GPU
+        return None
+
+    def exchange_end(self, b, work):
+        e, lay, lib, mcs = self.e, self.lay, self.e.lib, self.e.mcs
+        if work is not None:
+            work.wait()                                        # a stream-side wait: later work on our stream is ordered behind the collective
         mcs.check(lib.mcs_rig_rows_valid(e.ctx.h, C.c_void_p(b.G.data_ptr()), lay.images_total, self.cap, lay.row_stride, C.c_void_p(b.valid.data_ptr()),
                                          C.c_void_p(b.nkp_all.data_ptr())))
+
+    def extract_and_exchange(self, b, img_buf=0):
+        self.extract(b, img_buf)
+        self.exchange_end(b, self.exchange_begin(b))
 
     def _fill_database(self):
         """untimed: the stored keyframes are earlier multi-frames of the same synthetic stream (keyframe k = multi-frame k % frames_total of one pass)"""
@@ -291,14 +312,27 @@ class Job:
                                                 mcs.MEM_DEVICE, C.c_void_p(b.match.data_ptr()), C.c_void_p(b.nmatch.data_ptr()), C.c_void_p(b.fb.data_ptr())))
 
     def step(self, img_buf=0):
+        """One step.  N = 1: extract, match.  N > 1: extract this step's slab, START its all-gather, match the PREVIOUS step's (gathered) multi-frames
+        while the collective runs, then finish the exchange — one extraction, one exchange and one matching pass per call, the all-gather hidden behind
+        the matcher (results one step late)."""
         b = self.sets[self.cur]
         self.cur ^= 1
-        self.extract_and_exchange(b, img_buf)
-        self.match(b)
+        if self.e.world == 1:
+            self.extract_and_exchange(b, img_buf)
+            self.match(b)
+            self.matched_set = b
+            return b
+        p = self.sets[self.cur]          # the other buffer set: gathered and flagged at the end of the previous call
+        self.extract(b, img_buf)
+        work = self.exchange_begin(b)
+        self.match(p)
+        self.matched_set = p
+        self.exchange_end(b, work)
         return b
 
     def last(self):
-        return self.sets[self.cur ^ 1]
+        """the buffer set whose matching pass was issued last"""
+        return self.matched_set
 
     def status(self):
         self.ex.status()
@@ -357,6 +391,9 @@ def roofline_block(sp, job, kern, feats_local, pairs_local):
 def run_job(e, sp, args, steps, warmup, want_roofline=True):
     job = Job(e, sp)
     elapsed = timed(e, job.step, warmup, steps, job.status)
+    x0 = job.ex.describe_stats()[0]
+    job.step()
+    exact_kp = job.ex.describe_stats()[0] - x0   # keypoints the guarded fast descriptor pass handed to the exact pass in one (untimed) step
     feats_local = job.local_features()
     pairs_local = job.pairs_per_step_local()
     b = job.last()
@@ -374,6 +411,7 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True):
            "multi_frames_per_step_per_gpu": sp.F, "distinct_multi_frames_in_the_stream": POOL, "features_per_step": int(feats_all),
            "pair_distances_per_step": pairs_all, "Gpairs_per_s": round(pairs_all * steps / elapsed_max / 1e9, 1),
            "matches_per_step_rank0": matches, "greedy_rescans_rank0": rescans, "topk": sp.topk, "stored_keyframes": sp.D,
+           "descriptor_exact_pass_keypoints_per_step_rank0": exact_kp,
            "n_ranks": e.world, "collective_backend": e.backend, "tag": sp.tag,
            "parallelism": ("single GPU, no collective" if e.world == 1 else
                            "camera-major image slabs x%d + 1 all-gather of descriptor blocks per step (%d KiB per rank) + (frame, keyframe) pairs sharded x%d"
