@@ -68,7 +68,11 @@ __device__ __forceinline__ int fast_score(const uint8_t* c /* centre in LDS tile
 	return best > t ? best - 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd, int cell0, int ncells) {
+#ifndef MCS_FAST_BS
+#define MCS_FAST_BS 256   // threads per cell workgroup (A/B: 128, 256, 512)
+#endif
+constexpr int kFastBS = MCS_FAST_BS;
+__global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd, int cell0, int ncells) {
 	__shared__ __attribute__((aligned(16))) uint8_t tile[kTileRows * kTilePitch];
 	__shared__ __attribute__((aligned(16))) uint8_t sc[kScRows * kScPitch];
 	__shared__ uint32_t keepBits[128];   // NMS + mask verdict per pixel of the cell (row-major bit index), 60*60 <= 4096 bits
@@ -99,15 +103,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 	// i / ndw by multiplication: ndw <= 17 and i < 17 * 66, so with M = ceil(2^16 / ndw) the error term i * (M*ndw - 2^16) < 2^16 and
 	// (i * M) >> 16 is exact; 32-bit offsets keep the address arithmetic out of 64-bit multiplies.
 	const unsigned rowM = (65536u + (unsigned)ndw - 1u) / (unsigned)ndw;
-	for (int i = tid; i < ndw * th; i += 256) {
+	for (int i = tid; i < ndw * th; i += kFastBS) {
 		const unsigned ty = ((unsigned)i * rowM) >> 16, kx = (unsigned)i - ty * (unsigned)ndw;
 		uint32_t v;
 		__builtin_memcpy(&v, src + (ty * (unsigned)stride + 4u * kx), 4);
 		*reinterpret_cast<uint32_t*>(&tile[ty * kTilePitch + 4 * kx]) = v;
 	}
 	const int sw = cw + 2, sh = ch + 2;
-	for (int i = tid; i < sh * (kScPitch / 4); i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;   // score tile cleared as dwords
-	if (tid < 128) keepBits[tid] = 0;
+	for (int i = tid; i < sh * (kScPitch / 4); i += kFastBS) reinterpret_cast<uint32_t*>(sc)[i] = 0;   // score tile cleared as dwords
+	for (int i = tid; i < 128; i += kFastBS) keepBits[i] = 0;
 	if (tid == 0) { runBase = 0; nSurv = 0; }
 	__syncthreads();
 
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 	const int lane = tid & 63, wave = tid >> 6;
 	// pass 1: cheap compass test on every pixel; survivors are compacted into an LDS list (order is irrelevant here) so that
 	// pass 2 — the full 16-pixel arc score, ~10x the work — runs with all lanes busy instead of diverging inside each wave
-	for (int base = 0; base < npx; base += 256) {
+	for (int base = 0; base < npx; base += kFastBS) {
 		const int p = base + tid;
 		bool pass = false;
 		if (p < npx) {
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 	}
 	__syncthreads();
 	const int ns = nSurv;
-	for (int i = tid; i < ns; i += 256) {
+	for (int i = tid; i < ns; i += kFastBS) {
 		const int p = surv[i];
 		const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
 		sc[(py + 1) * kScPitch + px + 1] = (uint8_t)fast_score(&tile[(py + 3) * kTilePitch + px + 3], t);
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 	const uint8_t* mask = b.mask0 ? b.mask0 + (size_t)img * b.mask0Pitch : nullptr;
 	// pass 3a: non-max suppression + mirror mask, only for the pixels that have a score at all (the compass survivors); the verdicts go
 	// into a bitmap indexed by the pixel's row-major number inside the cell
-	for (int i = tid; i < ns; i += 256) {
+	for (int i = tid; i < ns; i += kFastBS) {
 		const int p = surv[i];
 		const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
 		const uint8_t* q = &sc[(py + 1) * kScPitch + px + 1];
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractBuffers b, int nimg, 
 		if (lane == 63) runBase = incl;
 	}
 	__syncthreads();
-	for (int g = wave; g < ngroups; g += 4) {
+	for (int g = wave; g < ngroups; g += kFastBS / 64) {
 		const unsigned long long bal = (unsigned long long)keepBits[2 * g] | ((unsigned long long)keepBits[2 * g + 1] << 32);
 		if ((bal >> lane) & 1ull) {
 			const int p = g * 64 + lane;
@@ -200,7 +204,7 @@ void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream
 	const int nblocks = nimg * ncells;
 	if (nblocks <= 0) return;
 	const int perXcd = (nblocks + kNumXCD - 1) / kNumXCD;
-	hipLaunchKernelGGL(k_fast_cells, dim3(perXcd * kNumXCD), dim3(256), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);
+	hipLaunchKernelGGL(k_fast_cells, dim3(perXcd * kNumXCD), dim3(kFastBS), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);
 }
 
 }  // namespace mcs

@@ -34,6 +34,34 @@ __global__ __launch_bounds__(256) void k(double* out, int iters) {
 				for (int j = 0; j < 8; ++j) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
 			}
 			if (MODE == 7) { asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(u[0]) : "v"(u[1])); }                            // dependent bcnt
+			if (MODE == 9) {                                                                                                  // 8 independent v_bitop3 ((a ^ b) & c)
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x60" : "+v"(u[j]) : "v"(u[(j + 1) & 7]), "v"(u[(j + 2) & 7]));
+			}
+			if (MODE == 10) {                                                                                                 // 8 independent v_xor
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 11) {                                                                                                 // 8 independent v_lshl_or
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 12) {                                                                                                 // 8 independent v_rndne_f64
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_rndne_f64 %0, %0" : "+v"(f[j]));
+			}
+			if (MODE == 13) {                                                                                                 // 8 independent v_rsq_f64
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_rsq_f64 %0, %0" : "+v"(f[j]));
+			}
+			if (MODE == 14) {                                                                                                 // 8 independent v_cvt_i32_f64
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(u[j]) : "v"(f[j]));
+			}
+			if (MODE == 15) {                                                                                                 // 8 independent v_and_or
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[j]) : "v"(u[(j + 1) & 7]), "v"(u[(j + 2) & 7]));
+			}
 			if (MODE == 8) {                                                                                                  // 8 independent FP64 mul
 #pragma unroll
 				for (int j = 0; j < 8; ++j) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(f[j]) : "v"(c));
@@ -75,5 +103,12 @@ int main() {
 	run<5>("8 independent v_mov_b32", 8, d);
 	run<7>("dependent v_bcnt_u32_b32", 1, d);
 	run<6>("8 independent v_bcnt_u32_b32", 8, d);
+	run<9>("8 independent v_bitop3_b32", 8, d);
+	run<10>("8 independent v_xor_b32", 8, d);
+	run<11>("8 independent v_lshl_or_b32", 8, d);
+	run<15>("8 independent v_and_or_b32", 8, d);
+	run<12>("8 independent v_rndne_f64", 8, d);
+	run<13>("8 independent v_rsq_f64", 8, d);
+	run<14>("8 independent v_cvt_i32_f64", 8, d);
 	return 0;
 }
