@@ -17,9 +17,6 @@
 namespace mcs {
 
 constexpr int MT = 256;   // train rows per LDS step
-#ifndef MCS_MATCH_PREFETCH
-#define MCS_MATCH_PREFETCH 0
-#endif
 
 // Raw popcount total of one (query, train row) pair: sum_w popc((q^t)&qm) + popc((q^t)&tm) (masked; the reference halves this total
 // ONCE, src/cORBmatcher.cpp:2452-2474) or sum_w popc(q^t).  v_bcnt_u32_b32 d, a, b = popcount(a) + b, so the running total rides on
@@ -100,8 +97,9 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	__shared__ __attribute__((aligned(16))) uint32_t tidx[MT + 4];    // their original train index; 0xFFFFFFFF = padding
 	__shared__ int wcnt[4];
 	constexpr int CB = 16;      // candidate column depth per lane
-	constexpr int CP = CB + 1;  // column pitch in dwords: odd, so the lanes' columns start in different LDS banks
-	__shared__ uint32_t cand[CP * 256];
+	// slot e of lane tid at cand[e * 256 + tid]: whatever slots the lanes of a wave are at, lane l always hits bank l % 32 (a [tid][CB + 1] layout with
+	// a +1 advance cost 38 M bank-conflict cycles per launch)
+	__shared__ uint32_t cand[(CB + 1) * 256];
 	const int tid = threadIdx.x;
 	const int set = blockIdx.z, split = blockIdx.y;
 	const int qi = blockIdx.x * 256 + tid;
@@ -135,9 +133,9 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	// `next` = index of the lane's next free slot in its column (tid, tid + 256, ...), kept as an index so that an append is
 	// compare, select (slot or dump row), store, select + add (advance)
 	// A candidate is kept as the RAW word total << 20 | index (masked: the un-halved popcount total); the exact key (total >> 1) << 20 | index is formed
-	// when the column is merged.  Appending is: one shift-or, one compare against the raw limit, an unconditional LDS store to the lane's next slot and an
-	// add-with-carry of the compare result — a word that does not qualify is simply overwritten by the next store.
-	const uint32_t col0 = tid * CP;
+	// when the column is merged.  Appending is: one shift-or, one compare against the raw limit, an unconditional LDS store to the lane's next slot and a
+	// conditional advance of the slot — a word that does not qualify is simply overwritten by the next store.
+	const uint32_t col0 = tid;
 	uint32_t next = col0;
 	auto exact_key = [](uint32_t w) { return MASKED ? (((w >> 21) << 20) | (w & 0xFFFFFu)) : w; };
 	// Merge of the lane's candidate column into its sorted list.  K >= 16: the (<= CB = 16) candidates are loaded into registers
@@ -146,12 +144,12 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 	// ~340 VALU ops per flush, where inserting one candidate at a time through the sorted list cost 2K ops per candidate of the
 	// fullest lane (~900 per flush at K = 32).  Smaller K keep the insertion loop.
 	auto flush = [&]() {
-		const int cnt = (int)(next - col0);
+		const int cnt = (int)((next - col0) >> 8);
 		if (K >= CB) {
 			uint32_t c[CB];
 #pragma unroll
 			for (int e = 0; e < CB; ++e) {   // unconditional reads (the whole column is the lane's own), stale slots masked afterwards
-				const uint32_t raw = cand[col0 + e];
+				const uint32_t raw = cand[e * 256 + tid];
 				c[e] = e < cnt ? exact_key(raw) : 0xFFFFFFFFu;
 			}
 #pragma unroll
@@ -181,7 +179,7 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
 			for (int e = 0; e < m; ++e) {
-				uint32_t key = e < cnt ? exact_key(cand[col0 + e]) : 0xFFFFFFFFu;
+				uint32_t key = e < cnt ? exact_key(cand[e * 256 + tid]) : 0xFFFFFFFFu;
 				if (__any(key < best[K - 1])) {
 #pragma unroll
 					for (int p = 0; p < K; ++p) { const uint32_t lo = min(best[p], key), hi = max(best[p], key); best[p] = lo; key = hi; }
@@ -244,58 +242,19 @@ __global__ __launch_bounds__(256) void k_match_partial(MatchArgs a) {
 				} else rawLim = min(best[K - 1], dCap >= 4095u ? 0xFFFFFFFFu : ((dCap + 1u) << 20));
 				uint32_t acc[4];
 				constexpr int RS = DW / 4;   // uint4 per row
-#if MCS_MATCH_PREFETCH
-				// software-pipelined form: the LDS reads of phase p + 1 (one 16-byte quad of two rows, + masks) are issued before the arithmetic of phase p
-				{
-					constexpr int NPH = 2 * RS;   // phases per trip: (row pair) x (quad)
-					auto ld = [&](int ph, uint4& t0, uint4& t1, uint4& m0, uint4& m1) {
-						const int pp = ph / RS, w4 = ph % RS;
-						t0 = trow[(2 * pp) * RS + w4]; t1 = trow[(2 * pp + 1) * RS + w4];
-						if (MASKED) { m0 = mrow[(2 * pp) * RS + w4]; m1 = mrow[(2 * pp + 1) * RS + w4]; }
-					};
-					uint4 c0, c1, cm0 = {0, 0, 0, 0}, cm1 = {0, 0, 0, 0};
-					ld(0, c0, c1, cm0, cm1);
-#pragma unroll
-					for (int ph = 0; ph < NPH; ++ph) {
-						uint4 n0 = c0, n1 = c1, nm0 = cm0, nm1 = cm1;
-						if (ph + 1 < NPH) ld(ph + 1, n0, n1, nm0, nm1);
-						__builtin_amdgcn_sched_barrier(0);
-						const int pp = ph / RS, w4 = ph % RS;
-						const uint32_t tw0[4] = {c0.x, c0.y, c0.z, c0.w}, tw1[4] = {c1.x, c1.y, c1.z, c1.w};
-						const uint32_t mw0[4] = {cm0.x, cm0.y, cm0.z, cm0.w}, mw1[4] = {cm1.x, cm1.y, cm1.z, cm1.w};
-						uint32_t& a0 = acc[2 * pp];
-						uint32_t& a1 = acc[2 * pp + 1];
-#pragma unroll
-						for (int k = 0; k < 4; ++k) {
-							const int w = 4 * w4 + k;
-							const uint32_t x0 = q[w] ^ tw0[k], x1 = q[w] ^ tw1[k];
-							if (MASKED) {
-								const uint32_t xa0 = x0 & qm[w], xa1 = x1 & qm[w], xb0 = x0 & mw0[k], xb1 = x1 & mw1[k];
-								if (w == 0) { asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(a0) : "v"(xa0)); asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(a1) : "v"(xa1)); }
-								else { asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a0) : "v"(xa0)); asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a1) : "v"(xa1)); }
-								asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a0) : "v"(xb0));
-								asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a1) : "v"(xb1));
-							} else {
-								if (w == 0) { asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(a0) : "v"(x0)); asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(a1) : "v"(x1)); }
-								else { asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a0) : "v"(x0)); asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a1) : "v"(x1)); }
-							}
-						}
-						c0 = n0; c1 = n1; cm0 = nm0; cm1 = nm1;
-					}
-				}
-#else
 				pair_total_x2<DW, MASKED>(q, qm, trow, mrow, trow + RS, mrow + (MASKED ? RS : 0), acc[0], acc[1]);
 				pair_total_x2<DW, MASKED>(q, qm, trow + 2 * RS, mrow + (MASKED ? 2 * RS : 0), trow + 3 * RS, mrow + (MASKED ? 3 * RS : 0), acc[2], acc[3]);
-#endif
+				uint32_t w[4];
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
-					uint32_t w = (acc[u] << 20) | tiu[u];
-					if (useGroup) w = tgu[u] == qg ? w : 0xFFFFFFFFu;
-					if (COUNT) countLe += (tiu[u] != 0xFFFFFFFFu && w != 0xFFFFFFFFu && (int)(MASKED ? acc[u] >> 1 : acc[u]) <= a.countThresh) ? 1 : 0;
-					cand[next] = w;
-					next += w < rawLim ? 1u : 0u;
+					w[u] = (acc[u] << 20) | tiu[u];
+					if (useGroup) w[u] = tgu[u] == qg ? w[u] : 0xFFFFFFFFu;
+					if (COUNT) countLe += (tiu[u] != 0xFFFFFFFFu && w[u] != 0xFFFFFFFFu && (int)(MASKED ? acc[u] >> 1 : acc[u]) <= a.countThresh) ? 1 : 0;
 				}
-				if (__any(next > col0 + (CB - 4))) flush();
+				// (a wave vote on the smallest of the four words before the appends was measured: slower — some lane qualifies on practically every trip)
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { cand[next] = w[u]; next += w[u] < rawLim ? 256u : 0u; }
+				if (__any(next > col0 + (CB - 4) * 256)) flush();
 			}
 		}
 		__syncthreads();
@@ -357,8 +316,7 @@ static void launch_kd(const MatchArgs& a, hipStream_t s) {
 	dim3 grid((a.nq + 255) / 256, a.splits, a.nsets);
 	const bool masked = a.qm && a.tm, count = a.countThresh >= 0;   // the searches do not need count_le: skip its VALU ops per pair
 	const bool group = a.qgroup != nullptr && a.tgroup != nullptr;
-	static const int ldsPad = getenv("MCS_MATCH_LDS_PAD") ? atoi(getenv("MCS_MATCH_LDS_PAD")) : 0;   // A/B: extra dynamic LDS per workgroup (caps workgroups per CU)
-#define MCS_LAUNCH_PARTIAL(M, C, G) hipLaunchKernelGGL((k_match_partial<K, DW, M, C, G>), grid, dim3(256), ldsPad, s, a)
+#define MCS_LAUNCH_PARTIAL(M, C, G) hipLaunchKernelGGL((k_match_partial<K, DW, M, C, G>), grid, dim3(256), 0, s, a)
 	if (masked) { if (count) { if (group) MCS_LAUNCH_PARTIAL(true, true, true); else MCS_LAUNCH_PARTIAL(true, true, false); }
 	              else { if (group) MCS_LAUNCH_PARTIAL(true, false, true); else MCS_LAUNCH_PARTIAL(true, false, false); } }
 	else { if (count) { if (group) MCS_LAUNCH_PARTIAL(false, true, true); else MCS_LAUNCH_PARTIAL(false, true, false); }

@@ -1,0 +1,61 @@
+"""-m gpu: the run-time switches of libmcs_hip.so select code paths the default run does not take — MCS_NO_OVERLAP=1 (everything in order on one stream, the
+path per-kernel timing uses), MCS_MATCH_FILL / MCS_MATCH_BLOCKS (train-range splits + k_match_merge even for a deep batch), MCS_DESCRIBE_EXACT=1 (the
+exact descriptor pass for every keypoint).  Each is run in a fresh process (the switches are read once) on the same inputs; every output must equal the
+default run's, bit for bit."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import ctypes as C, hashlib, importlib, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import gpu_common as G
+cap = importlib.import_module("multicol-slam_amd._capi")
+imgs, masks, cams = [], [], []
+for f in range(3):
+    i, m, c = G.frame_inputs(f)
+    imgs += i; masks += m; cams += c
+ex = G.mcs.Extractor(G.ctx(), 754, 480, max_batch=len(imgs), nfeatures=500, do_dBrief=1, learnMasks=1)
+res = ex.extract_host(imgs, masks, [G.mcs.make_ocam(c) for c in cams])
+h = hashlib.sha256()
+for kps, d, m, rays in res:
+    for a in (kps, d, m, rays):
+        h.update(np.ascontiguousarray(a).tobytes())
+# 8 (frame, keyframe) pairs in one call: deep enough that the default takes the no-split path
+rows = max(len(r[0]) for r in res)
+D = np.zeros((len(res), rows, 32), np.uint8); M = np.zeros_like(D); V = np.zeros((len(res), rows), np.uint8)
+for i, (kps, d, m, rays) in enumerate(res):
+    D[i, :len(d)], M[i, :len(d)], V[i, :len(d)] = d, m, 1
+P = lambda a: a.ctypes.data_as(C.c_void_p)
+ns = len(res) - 1
+q = cap.DescSet(P(D[1:]), P(M[1:]), P(V[1:]), None, rows, 32)
+t = cap.DescSet(P(D[:-1]), P(M[:-1]), P(V[:-1]), None, rows, 32)
+m12 = np.full((ns, rows), -1, np.int32); nm = np.zeros(ns, np.int32)
+cap.check(G.mcs.lib().mcs_search_kf_kf(G.ctx().h, ns, C.byref(q), rows, C.byref(t), rows, 32, 0.9, 32, cap.MEM_HOST, P(m12), P(nm), None))
+h.update(m12.tobytes()); h.update(nm.tobytes())
+print("DIGEST", h.hexdigest(), int(nm.sum()))
+'''
+
+
+def _run(env):
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1].split()
+    return line[1], int(line[2])
+
+
+def test_run_time_switches_do_not_change_any_output():
+    ref, nmatch = _run({})
+    assert nmatch > 1000
+    for env in ({"MCS_NO_OVERLAP": "1"}, {"MCS_MATCH_FILL": "100000000", "MCS_MATCH_BLOCKS": "4096"}, {"MCS_DESCRIBE_EXACT": "1"}):
+        got, n = _run(env)
+        assert (got, n) == (ref, nmatch), env
