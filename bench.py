@@ -509,7 +509,7 @@ def check_against_oracle(e, sp, job):
     G = b.G.cpu().numpy().reshape(lay.images_total, lay.rows_img, lay.row_stride)
     ok = True
     want = {}
-    for f in (1, 0):
+    for f in ((1, 0) if job.FT > 1 else (0,)):
         d, m, v = rig.unpack_frame(lay, G, f)
         want[f] = (d, m, v)
         for c in range(sp.ncam):
@@ -524,6 +524,21 @@ def check_against_oracle(e, sp, job):
         n, m12 = O.search_kf_kf(d1, m1 if masks_on else ones, v1, d0, m0 if masks_on else ones, v0, bool(masks_on), 0.9)
         got = b.match.cpu().numpy().reshape(sp.F, lay.rows_frame)[1]
         ok = ok and n == int(b.nmatch[1].item()) and np.array_equal(got, m12)
+    if sp.D > 0 and job.nkf:
+        # database sweep: this rank's first stored keyframe against multi-frame 0 (and 1) = pairs (f, k = 0) of the sweep call
+        db = job.db[0].cpu().numpy()
+        dk, mk, vk = np.ascontiguousarray(db[:, :lay.desc_size]), np.ascontiguousarray(db[:, lay.desc_size:]), job.db_valid[0].cpu().numpy()
+        got_m = b.match.cpu().numpy().reshape(job.FT, job.nkf, lay.rows_frame)
+        got_n = b.nmatch.cpu().numpy().reshape(job.FT, job.nkf)
+        for f in want:
+            df, mf, vf = want[f]
+            keep = np.flatnonzero(vf)
+            ones_k, ones_f = np.full_like(dk, 255), np.full((len(keep), lay.desc_size), 255, np.uint8)
+            n, mm = O.search_kf_f(dk, mk if masks_on else ones_k, vk, np.ascontiguousarray(df[keep]), np.ascontiguousarray(mf[keep]) if masks_on else ones_f,
+                                  bool(masks_on), 0.9)
+            full = np.full(lay.rows_frame, -1, np.int32)
+            full[keep] = mm
+            ok = ok and n == int(got_n[f, 0]) and np.array_equal(got_m[f, 0], full)
     return bool(ok)
 
 

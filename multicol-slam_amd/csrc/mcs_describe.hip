@@ -6,7 +6,7 @@
 //
 //   orientation   845-pixel disc of the UNBLURRED level: lane r owns disc row r-15 (half-width c_umax[|v|]), int32 moments
 //                 reduced with cross-lane shuffles (exact, order-free), then the float polynomial of cv::fastAtan2.
-//   patch         the 49x49 blurred neighbourhood every sample can touch is staged once in LDS (row stride 52).
+//   patch         the (2R+1)^2 blurred neighbourhood (R = 21: 43 rows of 44 bytes) almost every sample touches is staged once in LDS.
 //   descriptor    lane l owns pattern pairs l, l+64, l+128, ... ; one __ballot per 64 pairs yields 8 descriptor bytes
 //                 (bit k -> byte k/8, LSB first, exactly the reference's packing).
 //   dBRIEF        every pattern point goes through the Scaramuzza model in FP64 (sqrt, atan, Horner); the camera's
