@@ -179,7 +179,7 @@ class Spec:
 class Job:
     """One rank's share of a workload: its slab of (camera, frame) images, the exchange, its share of the (frame, keyframe) pairs."""
 
-    def __init__(self, e, sp, n_image_buffers=1):
+    def __init__(self, e, sp, n_image_buffers=1, n_sets=0):
         torch, mcs, synth, rig = e.torch, e.mcs, e.synth, e.rig
         self.e, self.sp = e, sp
         dev = e.dev
@@ -212,7 +212,10 @@ class Job:
         self.d_imgs = [torch.from_numpy(self.imgs_np).to(dev) for _ in range(n_image_buffers)]
         self.d_masks = torch.from_numpy(self.masks_np).to(dev)
         self.camarr = (mcs.Ocam * lay.L)(*[mcs.make_ocam(self.cams[c]) for c, _ in slab])
-        self.sets = [self._make_set(), self._make_set()]   # ping-pong: the greedy pass of step n (library side stream) overlaps step n + 1
+        # Buffer sets in rotation: the matcher of step n (library side stream) runs beside the extraction of step n + 1.  Two sets when a step extracts
+        # and matches the same set (N = 1); three when the matcher runs one step late (N > 1: behind the exchange; the host-buffer leg: outputs leave late).
+        self.nsets = n_sets or (2 if e.world == 1 else 3)
+        self.sets = [self._make_set() for _ in range(self.nsets)]
         self.cur = 0
         # stored keyframes of this rank (database sweeps): contiguous sets of ncam*cap rows, filled once from an untimed pass
         self.kfs = lay.keyframe_shard(sp.D, e.rank) if sp.D > 0 else []
@@ -223,8 +226,12 @@ class Job:
             self.db_valid = torch.zeros((nk, lay.rows_frame), dtype=torch.uint8, device=dev)
             self._fill_database()
         self.matched_set = self.sets[0]
+        # deferred searches: lists + greedy pass of step n run on the library's own stream beside the extraction of step n + 1; the fence before a buffer
+        # set is reused gives back the ordering a single stream would have had (include/mcs_c.h: mcs_ctx_set_async_search)
+        self.async_search = os.environ.get("MCS_BENCH_ASYNC_SEARCH", "1") != "0"
+        mcs.check(e.lib.mcs_ctx_set_async_search(e.ctx.h, 1 if self.async_search else 0))
         if e.world > 1:   # prime the pipeline: the first step() matches the multi-frames exchanged here
-            self.extract_and_exchange(self.sets[1])
+            self.extract_and_exchange(self.sets[self.nsets - 1])
             torch.cuda.synchronize(dev)
 
     def _make_set(self):
@@ -316,13 +323,17 @@ class Job:
         while the collective runs, then finish the exchange — one extraction, one exchange and one matching pass per call, the all-gather hidden behind
         the matcher (results one step late)."""
         b = self.sets[self.cur]
-        self.cur ^= 1
+        prev = self.sets[(self.cur - 1) % self.nsets]
+        self.cur = (self.cur + 1) % self.nsets
+        # the search that last read b is the one issued before the latest (two sets, N = 1: step n - 2; three sets, N > 1: the matcher of step n - 2,
+        # which read the set extracted in step n - 3)
+        self.e.mcs.check(self.e.lib.mcs_ctx_search_fence(self.e.ctx.h, 1))
         if self.e.world == 1:
             self.extract_and_exchange(b, img_buf)
             self.match(b)
             self.matched_set = b
             return b
-        p = self.sets[self.cur]          # the other buffer set: gathered and flagged at the end of the previous call
+        p = prev                         # the set extracted, gathered and flagged in the previous call
         self.extract(b, img_buf)
         work = self.exchange_begin(b)
         self.match(p)
@@ -428,7 +439,8 @@ def run_e2e(e, sp, steps, warmup):
     descriptor | mask blocks, counts and match arrays end in page-locked host memory (D2H on a second copy stream), both overlapped with the compute of
     the neighbouring steps.  N = 1 only."""
     torch = e.torch
-    job = Job(e, sp, n_image_buffers=2)
+    job = Job(e, sp, n_image_buffers=2, n_sets=3)
+    NS = job.nsets
     cin, cout = torch.cuda.Stream(device=e.dev), torch.cuda.Stream(device=e.dev)
     h_img = [torch.from_numpy(job.imgs_np.copy()).pin_memory() for _ in range(2)]
     outs = []
@@ -436,8 +448,8 @@ def run_e2e(e, sp, steps, warmup):
         outs.append([(t, torch.empty(t.shape, dtype=t.dtype).pin_memory()) for t in (b.send, b.nkp, b.kps, b.match, b.nmatch)])
     ev_in = [torch.cuda.Event() for _ in range(2)]
     ev_free = [torch.cuda.Event() for _ in range(2)]      # compute no longer reads image buffer i
-    ev_done = [torch.cuda.Event() for _ in range(2)]      # outputs of buffer set i complete
-    ev_out = [torch.cuda.Event() for _ in range(2)]       # outputs of buffer set i copied out
+    ev_done = [torch.cuda.Event() for _ in range(NS)]     # outputs of buffer set k complete
+    ev_out = [torch.cuda.Event() for _ in range(NS)]      # outputs of buffer set k copied out
     state = {"i": 0}
 
     def upload(i):   # images of buffer i: page-locked host memory -> device, on the copy stream, once the kernels no longer read the buffer
@@ -455,27 +467,32 @@ def run_e2e(e, sp, steps, warmup):
             ev_out[k].record(cout)
 
     def step():
-        i = state["i"] & 1
+        n = state["i"]
+        i = n & 1
         state["i"] += 1
+        k = n % NS
         e.stream.wait_event(ev_in[i])                     # this step's images (uploaded while the previous step computed)
-        e.stream.wait_event(ev_out[job.cur])              # the output set about to be overwritten has been copied out
-        b = job.sets[job.cur]
-        k = job.cur
-        job.cur ^= 1
+        e.stream.wait_event(ev_out[k])                    # the output set about to be overwritten has been copied out
+        e.mcs.check(e.lib.mcs_ctx_search_fence(e.ctx.h, 1))   # the deferred search of step n - 2 is complete (it ran beside the extraction of step n - 1)
+        if n >= 2:
+            download((n - 2) % NS)                        # ... so its match arrays (and the rest of that set) leave now, two steps late
+        b = job.sets[k]
+        job.cur = (k + 1) % NS
         job.extract_and_exchange(b, i)
         ev_free[i].record(e.stream)
         upload(i ^ 1)                                     # the next step's images travel while this step computes
-        if state["i"] > 1:
-            e.mcs.check(e.lib.mcs_ctx_join(e.ctx.h))      # the previous step's greedy pass ran beside this extraction: its match arrays are complete
-            download(k ^ 1)                               # they leave now, while this step's matcher runs
         job.match(b)
+        job.matched_set = b
 
     for ev in ev_free + ev_out:
         ev.record(e.stream)
     upload(0)
     elapsed = timed(e, step, warmup, steps, job.status)
     e.mcs.check(e.lib.mcs_ctx_join(e.ctx.h))
-    download(job.cur ^ 1)                                 # the last step's outputs
+    n = state["i"]
+    for m in (n - 2, n - 1):                              # the last two steps' outputs
+        if m >= 0:
+            download(m % NS)
     torch.cuda.synchronize(e.dev)
     feats = job.local_features()
     h2d = job.imgs_np.nbytes

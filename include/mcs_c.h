@@ -70,6 +70,14 @@ int mcs_ctx_synchronize(mcs_ctx*);
  * are complete for later work on the context's stream only after mcs_ctx_join (a stream-side wait, no host block), after
  * the next mcs_search_* / mcs_match_* call, or after mcs_ctx_synchronize.  MCS_NO_OVERLAP=1 in the environment disables the fork. */
 int mcs_ctx_join(mcs_ctx*);
+/* Deferred searches (optional, device memory only).  With mcs_ctx_set_async_search(ctx, 1) a mcs_search_* call runs ENTIRELY beside the context's stream
+ * (top-K lists and greedy pass on the library's own stream, ordered behind everything enqueued on the context's stream before the call and behind the
+ * previous search): the caller's stream continues at once, so the next batch's extraction overlaps the matcher.  The caller then owes the ordering a
+ * plain stream would have given it: the search's INPUT buffers must not be overwritten, and its outputs not read, before
+ *   mcs_ctx_search_fence(ctx, lag)   the context's stream waits for the search issued `lag` calls before the latest one (0 = the latest = mcs_ctx_join)
+ * (a stream-side wait, no host block).  bench.py alternates two buffer sets and fences with lag 1 before it reuses a set. */
+int mcs_ctx_set_async_search(mcs_ctx*, int on);
+int mcs_ctx_search_fence(mcs_ctx*, int lag);
 
 /* ------------------------------------------------------------------ extractor
  * An extractor is built for one image size and a maximum batch (images per launch).  It owns the device pyramid,

@@ -67,7 +67,7 @@ EXPORTS = [
     "mcs_extractor_destroy", "mcs_extractor_kp_capacity", "mcs_extractor_levels", "mcs_extract_batch", "mcs_extractor_status",
     "mcs_extractor_tap_level", "mcs_extractor_tap_candidates", "mcs_extractor_tap_selected", "mcs_match_topk",
     "mcs_match_topk_batched", "mcs_descriptor_distance", "mcs_descriptor_distance_masked", "mcs_ctx_enable_timing",
-    "mcs_ctx_kernel_ms", "mcs_ctx_join", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_search_kf_f_sweep",
+    "mcs_ctx_kernel_ms", "mcs_ctx_join", "mcs_ctx_set_async_search", "mcs_ctx_search_fence", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_search_kf_f_sweep",
     "mcs_search_triangulation_sweep", "mcs_search_kf_kf_ring", "mcs_rows_valid", "mcs_extractor_set_describe", "mcs_extractor_describe_stats", "mcs_describe_fast_bound",
     "mcs_selftest_describe_fast", "mcs_extract_batch_strided", "mcs_rig_pack_headers", "mcs_rig_rows_valid",
     "mcs_search_by_projection", "mcs_window_match", "mcs_window_best", "mcs_rotation_consistency", "mcs_world_to_cam", "mcs_distinctive_descriptors", "mcs_selftest_shared_reciprocal", "mcs_vocabulary_create", "mcs_vocabulary_destroy", "mcs_bow_transform",
@@ -110,6 +110,8 @@ def lib():
     L.mcs_ctx_destroy.argtypes = [vp]
     L.mcs_ctx_synchronize.argtypes = [vp]
     L.mcs_ctx_join.argtypes = [vp]
+    L.mcs_ctx_set_async_search.argtypes = [vp, C.c_int]
+    L.mcs_ctx_search_fence.argtypes = [vp, C.c_int]
     L.mcs_ctx_enable_timing.argtypes = [vp, C.c_int]
     L.mcs_ctx_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float)]
     L.mcs_extractor_create.argtypes = [vp, C.POINTER(ExtractorParams), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]

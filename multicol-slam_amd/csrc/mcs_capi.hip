@@ -116,6 +116,7 @@ int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
 		HIPCHK(hipEventCreateWithFlags(&c->evBlur, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&c->evMatch, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&c->evGreedy, hipEventDisableTiming));
+		for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&c->evSearch[i], hipEventDisableTiming));
 	}
 	*out = c;
 	return MCS_OK;
@@ -125,6 +126,23 @@ int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
 int mcs_ctx_join(mcs_ctx* c) {
 	if (!c) return fail(MCS_ERR_INVALID, "null ctx");
 	if (c->side && c->greedyPending) { HIPCHK(hipStreamWaitEvent(c->stream, c->evGreedy, 0)); c->greedyPending = false; }
+	return MCS_OK;
+}
+
+int mcs_ctx_set_async_search(mcs_ctx* c, int on) {
+	if (!c) return fail(MCS_ERR_INVALID, "null ctx");
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (c->side2) HIPCHK(hipStreamSynchronize(c->side2));
+	c->asyncSearch = on != 0 && c->side2 != nullptr;
+	return MCS_OK;
+}
+
+int mcs_ctx_search_fence(mcs_ctx* c, int lag) {
+	if (!c || lag < 0 || lag > 2) return fail(MCS_ERR_INVALID, "lag must be 0, 1 or 2");
+	if (!c->asyncSearch) return lag == 0 ? mcs_ctx_join(c) : MCS_OK;   // in-order searches: only the latest greedy pass can still be running
+	const long long want = c->searchSeq - 1 - lag;
+	if (want >= 0) HIPCHK(hipStreamWaitEvent(c->stream, c->evSearch[want & 3], 0));
+	if (lag == 0) c->greedyPending = false;
 	return MCS_OK;
 }
 
@@ -140,6 +158,7 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 		(void)hipStreamSynchronize(c->side);
 		(void)hipStreamSynchronize(c->side2);
 		(void)hipStreamDestroy(c->side2);
+		for (int i = 0; i < 4; ++i) if (c->evSearch[i]) (void)hipEventDestroy(c->evSearch[i]);
 		(void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evPyr1); (void)hipEventDestroy(c->evPyr); (void)hipEventDestroy(c->evBlur); (void)hipEventDestroy(c->evMatch); (void)hipEventDestroy(c->evGreedy);
 		(void)hipStreamDestroy(c->side);
 	}

@@ -105,11 +105,13 @@ static int stage_sets(mcs_ctx* c, const SetGrid& sg, const mcs_desc_set* q, size
 }
 
 static int run_topk(mcs_ctx* c, const DevSets& d, const SetGrid& sg, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, int dim,
-                    int K, int count_thresh, int max_dist, int* outDist, int* outIdx, int* outCount) {
+                    int K, int count_thresh, int max_dist, int* outDist, int* outIdx, int* outCount, hipStream_t ls = nullptr) {
 	MatchArgs a{};
 	const int nsets = sg.nsets;
 	a.maxDist = max_dist;
-	if (c->side && c->greedyPending) { HIPCHK(hipStreamWaitEvent(c->stream, c->evGreedy, 0)); c->greedyPending = false; }
+	const bool deferred = ls != nullptr;   // launched on the greedy stream itself: ordered behind the previous search without any wait
+	if (!deferred) ls = c->stream;
+	if (!deferred && c->side && c->greedyPending) { HIPCHK(hipStreamWaitEvent(c->stream, c->evGreedy, 0)); c->greedyPending = false; }
 	if (int r = ensure((void**)&c->topKeys, &c->topKeysCap, std::max<size_t>((size_t)nsets * q->n, 1) * K * sizeof(uint32_t))) return r;
 	a.keys = c->topKeys;
 	a.qd = d.qd; a.qm = d.qm; a.qvalid = d.qvalid; a.qgroup = d.qgroup; a.td = d.td; a.tm = d.tm; a.tvalid = d.tvalid; a.tgroup = d.tgroup;
@@ -133,7 +135,7 @@ static int run_topk(mcs_ctx* c, const DevSets& d, const SetGrid& sg, const mcs_d
 	a.partial = c->partial; a.partialCount = c->partialCount;
 	a.outDist = outDist; a.outIdx = outIdx; a.outCount = outCount;
 	c->tic("match");
-	launch_match(a, c->stream);
+	launch_match(a, ls);
 	c->toc("match");
 	HIPCHK(hipGetLastError());
 	return MCS_OK;
@@ -180,7 +182,13 @@ static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc
 	if (mode == 2 && (!rays1 || !rays2 || !E || nrCams < 1)) return fail(MCS_ERR_INVALID, "triangulation search needs rays and essential matrices");
 	HIPCHK(hipSetDevice(c->device));
 	hipStream_t s = c->stream;
-	if (c->side && c->greedyPending) {   // the previous search's greedy pass (side stream) still reads the shared list buffers
+	// Deferred form (mcs_ctx_set_async_search, device memory): lists AND greedy pass run on the greedy stream, ordered behind the inputs by an event and
+	// behind the previous search by the stream itself; the caller's stream goes on at once (the next batch's extraction fills the matcher's stalls).
+	const bool deferred = kind == MCS_MEM_DEVICE && c->overlap() && c->asyncSearch;
+	if (deferred) {
+		HIPCHK(hipEventRecord(c->evMatch, s));
+		HIPCHK(hipStreamWaitEvent(c->side2, c->evMatch, 0));
+	} else if (c->side && c->greedyPending) {   // the previous search's greedy pass (side stream) still reads the shared list buffers
 		HIPCHK(hipStreamWaitEvent(s, c->evGreedy, 0));
 		c->greedyPending = false;
 	}
@@ -199,7 +207,7 @@ static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc
 		int maxDist = thLow;
 		if (mode != 2) while (maxDist < 8 * dim && nnratio * static_cast<double>(maxDist + 1) <= static_cast<double>(thLow)) ++maxDist;
 		if (q->n > 0)
-			if (int r = run_topk(c, d, sg, q, qpitch, t, tpitch, dim, K, -1, maxDist, nullptr, nullptr, c->topCnt)) return r;
+			if (int r = run_topk(c, d, sg, q, qpitch, t, tpitch, dim, K, -1, maxDist, nullptr, nullptr, c->topCnt, deferred ? c->side2 : nullptr)) return r;
 	}
 	GreedyArgs g{};
 	g.qd = d.qd; g.qm = d.qm; g.qvalid = d.qvalid; g.qgroup = d.qgroup; g.td = d.td; g.tm = d.tm; g.tvalid = d.tvalid; g.tgroup = d.tgroup;
@@ -212,7 +220,13 @@ static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc
 	const size_t outN = (size_t)nsets * (mode == 1 ? t->n : q->n);
 	if (kind == MCS_MEM_DEVICE) {
 		g.outMatch = out_match; g.outCount = out_nmatches; g.outFallbacks = out_fallbacks;
-		if (c->overlap()) {
+		if (deferred) {
+			launch_greedy(g, c->side2);
+			HIPCHK(hipEventRecord(c->evGreedy, c->side2));
+			HIPCHK(hipEventRecord(c->evSearch[c->searchSeq & 3], c->side2));
+			++c->searchSeq;
+			c->greedyPending = true;
+		} else if (c->overlap()) {
 			// the greedy resolution is one wave per set pair (latency-bound): run it on the side stream so that whatever the caller
 			// enqueues next on the main stream (the next batch's extraction) fills the idle CUs.  mcs_ctx_join / the next search /
 			// mcs_ctx_synchronize order later work behind it.

@@ -45,6 +45,10 @@ struct mcs_ctx {
 	hipStream_t side2 = nullptr;   // the greedy match resolution (its own stream: it must not hold up the next batch's resize chain)
 	hipEvent_t evFork = nullptr, evPyr1 = nullptr, evPyr = nullptr, evBlur = nullptr, evMatch = nullptr, evGreedy = nullptr;
 	bool greedyPending = false;
+	// deferred searches (mcs_ctx_set_async_search): top-K lists AND greedy pass of a device-memory search on side2, completion events in a ring
+	bool asyncSearch = false;
+	hipEvent_t evSearch[4] = {nullptr, nullptr, nullptr, nullptr};
+	long long searchSeq = 0;
 	bool overlap() const { return side != nullptr && !timing; }   // per-kernel timing runs everything in order on the main stream
 
 	void tic(const char* name) {

@@ -207,3 +207,36 @@ def test_sweep_argument_checks(G, cap):
     rays = np.zeros((4, 3)); E = np.zeros(9)
     g = cap.DescSet(P(d), None, None, P(np.zeros(4, np.int32)), 4, DIM)
     assert lib.mcs_search_triangulation_sweep(ctx.h, 2, C.byref(g), 0, C.byref(g), 0, P(rays), P(rays), P(E), 5, 1, DIM, 8, cap.MEM_HOST, P(out), P(out), None) == cap.MCS_ERR_INVALID
+
+
+def test_deferred_searches_equal_in_order_searches(G, cap):
+    """mcs_ctx_set_async_search: lists + greedy pass of device-memory searches run on the library's own stream; three searches on different inputs are
+    issued back to back without any synchronisation, mcs_ctx_search_fence orders the caller's stream behind them.  Results = the in-order results."""
+    lib = G.mcs.lib()
+    ctx = G.mcs.Context(0)
+    nF, nK, pitchK = 640, 600, 640
+    jobs = []
+    for seed in (1, 2, 3):
+        fd, fm, fv, kd, km, kv = make_db(40 + seed, 1, nF, nK, nF, pitchK, True)
+        bufs = [G.DevBuf(a) for a in (kd, km, kv, fd, fm, fv)]
+        dp = lambda b: C.c_void_p(b.ptr.value)
+        q = cap.DescSet(dp(bufs[0]), dp(bufs[1]), dp(bufs[2]), None, nK, DIM)
+        t = cap.DescSet(dp(bufs[3]), dp(bufs[4]), dp(bufs[5]), None, nF, DIM)
+        jobs.append((bufs, q, t))
+    results = {}
+    for mode in (0, 1):
+        cap.check(lib.mcs_ctx_set_async_search(ctx.h, mode))
+        outs = []
+        for bufs, q, t in jobs:
+            o_m, o_n = G.DevBuf(np.full((NKF, nF), -7, np.int32)), G.DevBuf(np.full(NKF, -7, np.int32))
+            cap.check(lib.mcs_search_kf_f(ctx.h, NKF, C.byref(q), pitchK, C.byref(t), 0, DIM, 0.9, 8, cap.MEM_DEVICE, o_m.ptr, o_n.ptr, None))
+            outs.append((o_m, o_n))
+        for lag in (2, 1, 0):
+            cap.check(lib.mcs_ctx_search_fence(ctx.h, lag))
+        ctx.synchronize()
+        results[mode] = [(m.read(), n.read()) for m, n in outs]
+    cap.check(lib.mcs_ctx_set_async_search(ctx.h, 0))
+    for (m0, n0), (m1, n1) in zip(results[0], results[1]):
+        assert n0.sum() > 1000 and np.array_equal(n0, n1) and np.array_equal(m0, m1)
+    assert lib.mcs_ctx_search_fence(ctx.h, 3) == cap.MCS_ERR_INVALID
+    ctx.close()
