@@ -232,6 +232,7 @@ class Job:
         mcs.check(e.lib.mcs_ctx_set_async_search(e.ctx.h, 1 if self.async_search else 0))
         if e.world > 1:   # prime the pipeline: the first step() matches the multi-frames exchanged here
             self.extract_and_exchange(self.sets[self.nsets - 1])
+            self.sets[self.nsets - 1].work = "done"
             torch.cuda.synchronize(dev)
 
     def _make_set(self):
@@ -275,7 +276,11 @@ class Job:
         if e.world == 1:
             return None
         if e.backend == "nccl":
-            return e.dist.all_gather_into_tensor(b.G, b.send, async_op=True)
+            try:
+                return e.dist.all_gather_into_tensor(b.G, b.send, async_op=True)
+            except (TypeError, RuntimeError):   # a build without asynchronous collectives: the blocking form (no overlap, same result)
+                e.dist.all_gather_into_tensor(b.G, b.send)
+                return None
         b.G.copy_(e.rig.all_gather_blocks(b.send, e.world))   # gloo: functional runs on one shared GPU
         return None
 
@@ -319,9 +324,9 @@ class Job:
                                                 mcs.MEM_DEVICE, C.c_void_p(b.match.data_ptr()), C.c_void_p(b.nmatch.data_ptr()), C.c_void_p(b.fb.data_ptr())))
 
     def step(self, img_buf=0):
-        """One step.  N = 1: extract, match.  N > 1: extract this step's slab, START its all-gather, match the PREVIOUS step's (gathered) multi-frames
-        while the collective runs, then finish the exchange — one extraction, one exchange and one matching pass per call, the all-gather hidden behind
-        the matcher (results one step late)."""
+        """One step.  N = 1: extract, match.  N > 1: extract this step's slab, START its all-gather, then finish the exchange of the PREVIOUS step's slab
+        (its collective had a whole step to complete) and match those multi-frames — one extraction, one exchange and one matching pass per call, the
+        all-gather hidden behind a step's worth of kernels (results one step late)."""
         b = self.sets[self.cur]
         prev = self.sets[(self.cur - 1) % self.nsets]
         self.cur = (self.cur + 1) % self.nsets
@@ -333,12 +338,14 @@ class Job:
             self.match(b)
             self.matched_set = b
             return b
-        p = prev                         # the set extracted, gathered and flagged in the previous call
         self.extract(b, img_buf)
-        work = self.exchange_begin(b)
+        b.work = self.exchange_begin(b)  # in flight until the NEXT call needs it
+        p = prev                         # the set extracted in the previous call: finish its exchange, then match it
+        if getattr(p, "work", "done") != "done":
+            self.exchange_end(p, p.work)
+            p.work = "done"
         self.match(p)
         self.matched_set = p
-        self.exchange_end(b, work)
         return b
 
     def last(self):
