@@ -55,31 +55,43 @@ __global__ __launch_bounds__(256) void k_blur(ExtractBuffers b, int tilesPerImag
 		}
 	}
 	__syncthreads();
-	// horizontal 5-sums, 4 adjacent columns per thread from two aligned dword reads
+	// horizontal 5-sums, 4 adjacent columns per thread from two aligned dword reads: v_sad_u8 sums the four bytes of a window in one instruction,
+	// v_alignbyte slides the window (window k = bytes k..k+3 of the 8, the fifth byte is the sad's addend)
 	for (int i = tid; i < BI_H * (BT_W / 4); i += 256) {
 		const int r = i / (BT_W / 4), c = (i - r * (BT_W / 4)) * 4;
 		const uint32_t a = *reinterpret_cast<const uint32_t*>(&in[r][c]), bq = *reinterpret_cast<const uint32_t*>(&in[r][c + 4]);
-		const int p0 = a & 0xff, p1 = (a >> 8) & 0xff, p2 = (a >> 16) & 0xff, p3 = a >> 24;
-		const int p4 = bq & 0xff, p5 = (bq >> 8) & 0xff, p6 = (bq >> 16) & 0xff, p7 = bq >> 24;
-		const int s0 = p0 + p1 + p2 + p3 + p4;
-		const int s1 = s0 - p0 + p5, s2 = s1 - p1 + p6, s3 = s2 - p2 + p7;
-		*reinterpret_cast<uint2*>(&hs[r][c]) = make_uint2((uint32_t)s0 | ((uint32_t)s1 << 16), (uint32_t)s2 | ((uint32_t)s3 << 16));
+		const uint32_t s0 = __builtin_amdgcn_sad_u8(a, 0u, bq & 0xffu);
+		const uint32_t s1 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(bq, a, 1), 0u, (bq >> 8) & 0xffu);
+		const uint32_t s2 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(bq, a, 2), 0u, (bq >> 16) & 0xffu);
+		const uint32_t s3 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(bq, a, 3), 0u, bq >> 24);
+		*reinterpret_cast<uint2*>(&hs[r][c]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
 	}
 	__syncthreads();
-	const int ox = (tid & 31) * 4;
+	// vertical: a thread owns 4 adjacent columns x 4 CONSECUTIVE rows and slides the 5-row window down (packed 16-bit adds: two columns per
+	// instruction; a 5x5 sum is <= 6375).  (s + 12) / 25 == ((s + 12) * 5243) >> 17 for s + 12 <= 6387: 25 * 5243 = 2^17 + 3, so the quotient's error
+	// 3q / 2^17 <= 0.006 never carries a remainder of at most 24/25 over the next integer.
+	typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+	const int ox = (tid & 31) * 4, oy0 = (tid >> 5) * 4;
 	const int x = tx0 + ox;
 	if (x >= L.w) return;
 	uint8_t* dst = b.blur + (size_t)img * d.pyrBytes + L.off;
-	for (int oy = tid >> 5; oy < BT_H; oy += 8) {
-		const int y = ty0 + oy;
-		if (y >= L.h) break;
-		uint32_t packed = 0;
+	auto row2 = [&](int r, us2& lo, us2& hi) {
+		const uint2 v = *reinterpret_cast<const uint2*>(&hs[r][ox]);
+		lo = __builtin_bit_cast(us2, v.x); hi = __builtin_bit_cast(us2, v.y);
+	};
+	us2 rl[8], rh[8];
 #pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			const int s = hs[oy][ox + i] + hs[oy + 1][ox + i] + hs[oy + 2][ox + i] + hs[oy + 3][ox + i] + hs[oy + 4][ox + i];
-			packed |= (uint32_t)((s + 12) / 25) << (8 * i);
+	for (int k = 0; k < 8; ++k) row2(oy0 + k, rl[k], rh[k]);
+	us2 sl = rl[0] + rl[1] + rl[2] + rl[3] + rl[4], sh = rh[0] + rh[1] + rh[2] + rh[3] + rh[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const int y = ty0 + oy0 + k;
+		if (y < L.h) {
+			const uint32_t q0 = ((uint32_t)sl.x * 5243u + 12u * 5243u) >> 17, q1 = ((uint32_t)sl.y * 5243u + 12u * 5243u) >> 17;
+			const uint32_t q2 = ((uint32_t)sh.x * 5243u + 12u * 5243u) >> 17, q3 = ((uint32_t)sh.y * 5243u + 12u * 5243u) >> 17;
+			*reinterpret_cast<uint32_t*>(dst + (size_t)y * L.stride + x) = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);   // pitch is a multiple of 64: tail bytes stay in-pitch
 		}
-		*reinterpret_cast<uint32_t*>(dst + (size_t)y * L.stride + x) = packed;   // pitch is a multiple of 64: tail bytes stay in-pitch
+		if (k < 3) { sl = sl + rl[k + 5] - rl[k]; sh = sh + rh[k + 5] - rh[k]; }
 	}
 }
 
