@@ -386,7 +386,9 @@ def roofline_block(sp, job, kern, feats_local, pairs_local):
     dom = max((k for k in alg if k in kern), key=lambda k: kern[k])
     ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
     traffic, valu = pmc_entry(sp.tag, dom)
-    out = {"kernel": "k_" + ("match_partial" if dom == "match" else dom), "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
+    kname = {"match": "k_match_partial", "describe": "k_describe" if sp.mode == "orb" else "k_describe_fast (descriptor stage: + k_orient_a, k_orient_b, k_describe_list)",
+             "pyramid": "k_resize_level (x7)", "fast": "k_fast_cells (x3)", "blur": "k_blur"}[dom]
+    out = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
            "frac": round(ach / 8000.0, 5), "traffic": traffic, "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kern[dom], 4),
            "per_kernel_ms": {k: round(v, 4) for k, v in kern.items()},
            "per_kernel_alg_GBps": {k: round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) for k in alg if k in kern and kern[k] > 0},
