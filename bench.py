@@ -176,6 +176,9 @@ class Spec:
         self.tag = "%s-%s-%dx%dx%d-n%d-f%d-k%d" % (self.name, self.mode, self.ncam, self.W, self.H, self.nfeat, self.F, self.D)
 
 
+_IMAGE_CACHE = {}
+
+
 class Job:
     """One rank's share of a workload: its slab of (camera, frame) images, the exchange, its share of the (frame, keyframe) pairs."""
 
@@ -199,13 +202,11 @@ class Job:
         slab = lay.slab(e.rank)
         self.slab = slab
         # synthetic inputs of this rank's slab (untimed).  Global frame f shows synthetic frame f % POOL: every rank carries the same amount of work
-        cache = {}
-
-        def image(c, f):
-            key = (c, f % POOL)
-            if key not in cache:
-                cache[key] = synth.synth_image(f % POOL, c, self.cams[c])
-            return cache[key]
+        def image(c, f):   # the legs of one bench run share their synthetic images
+            key = (sp.W, sp.H, c, f % POOL)
+            if key not in _IMAGE_CACHE:
+                _IMAGE_CACHE[key] = synth.synth_image(f % POOL, c, self.cams[c])
+            return _IMAGE_CACHE[key]
         self.imgs_np = np.stack([image(c, f) for c, f in slab])
         mm = [synth.mirror_mask(cam) for cam in self.cams]
         self.masks_np = np.stack([mm[c] for c, _ in slab])
@@ -584,7 +585,7 @@ def cpu_baseline(args, e, sp, job):
     except (OSError, ValueError):
         pass
     nf = args.cpu_frames or max(48, 3 * quota)
-    pool = [[synth.synth_image(f, c, job.cams[c]) for c in range(NCAM)] for f in range(POOL)]
+    pool = [[_IMAGE_CACHE.get((W, H, c, f)) if (W, H, c, f) in _IMAGE_CACHE else synth.synth_image(f, c, job.cams[c]) for c in range(NCAM)] for f in range(POOL)]
     flat = [np.ascontiguousarray(pool[f % POOL][c]) for f in range(nf) for c in range(NCAM)]
     mk = [np.ascontiguousarray(synth.mirror_mask(job.cams[c])) for c in range(NCAM)]
     iptr = (C.c_void_p * len(flat))(*[a.ctypes.data for a in flat])
