@@ -103,11 +103,18 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	// i / ndw by multiplication: ndw <= 17 and i < 17 * 66, so with M = ceil(2^16 / ndw) the error term i * (M*ndw - 2^16) < 2^16 and
 	// (i * M) >> 16 is exact; 32-bit offsets keep the address arithmetic out of 64-bit multiplies.
 	const unsigned rowM = (65536u + (unsigned)ndw - 1u) / (unsigned)ndw;
-	for (int i = tid; i < ndw * th; i += kFastBS) {
+	// two dwords per thread and trip (a ~30x30 cell is 370 dwords: one trip): both loads are in flight before the first LDS store waits
+	const int ndwTile = ndw * th;
+	for (int i = tid; i < ndwTile; i += 2 * kFastBS) {
+		const int i2 = i + kFastBS;
+		const bool has2 = i2 < ndwTile;
 		const unsigned ty = ((unsigned)i * rowM) >> 16, kx = (unsigned)i - ty * (unsigned)ndw;
-		uint32_t v;
+		const unsigned ty2 = ((unsigned)i2 * rowM) >> 16, kx2 = (unsigned)i2 - ty2 * (unsigned)ndw;
+		uint32_t v, v2 = 0;
 		__builtin_memcpy(&v, src + (ty * (unsigned)stride + 4u * kx), 4);
+		if (has2) __builtin_memcpy(&v2, src + (ty2 * (unsigned)stride + 4u * kx2), 4);
 		*reinterpret_cast<uint32_t*>(&tile[ty * kTilePitch + 4 * kx]) = v;
+		if (has2) *reinterpret_cast<uint32_t*>(&tile[ty2 * kTilePitch + 4 * kx2]) = v2;
 	}
 	const int sw = cw + 2, sh = ch + 2;
 	for (int i = tid; i < sh * (kScPitch / 4); i += kFastBS) reinterpret_cast<uint32_t*>(sc)[i] = 0;   // score tile cleared as dwords
@@ -166,9 +173,8 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 		if (keep) atomicOr(&keepBits[p >> 5], 1u << (p & 31));
 	}
 	__syncthreads();
-	// 64 consecutive pixels = one wave's ballot = two bitmap words: the emission order (row-major inside the cell, the reference's) is an
-	// exclusive prefix sum over <= 57 group counts (one wave), then every kept pixel writes its record — two barriers for the whole cell
-	// instead of three per 256-pixel slab.
+	// the emission order (row-major inside the cell, the reference's) is an exclusive prefix sum over the kept-pixel counts of <= 57 groups of
+	// 64 pixels (two bitmap words each; one wave does it) — two barriers for the whole cell instead of three per 256-pixel slab.
 	const int ngroups = (npx + 63) >> 6;
 	if (wave == 0) {
 		const int v = lane < ngroups ? __popc(keepBits[2 * lane]) + __popc(keepBits[2 * lane + 1]) : 0;
@@ -179,17 +185,18 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 		if (lane == 63) runBase = incl;
 	}
 	__syncthreads();
-	for (int g = wave; g < ngroups; g += kFastBS / 64) {
-		const unsigned long long bal = (unsigned long long)keepBits[2 * g] | ((unsigned long long)keepBits[2 * g + 1] << 32);
-		if ((bal >> lane) & 1ull) {
-			const int p = g * 64 + lane;
+	// every kept survivor writes its record at (kept pixels before it in row-major order): group prefix + kept bits below it in its own 64-pixel group
+	for (int i = tid; i < ns; i += kFastBS) {
+		const int p = surv[i];
+		const uint32_t w = keepBits[p >> 5];
+		if ((w >> (p & 31)) & 1u) {
+			const int g = p >> 6;
+			const uint32_t below = (p & 32) ? __popc(keepBits[2 * g]) + __popc(w & ((1u << (p & 31)) - 1u)) : __popc(w & ((1u << (p & 31)) - 1u));
 			const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
 			const int s0 = sc[(py + 1) * kScPitch + px + 1];
-			const int off = groupOff[g] + __popcll(bal & ((1ull << lane) - 1ull));
-			slots[off] = (uint32_t)(cell.x0 + px - kMinBorder) | ((uint32_t)(cell.y0 + py - kMinBorder) << 12) | ((uint32_t)s0 << 24);
+			slots[groupOff[g] + (int)below] = (uint32_t)(cell.x0 + px - kMinBorder) | ((uint32_t)(cell.y0 + py - kMinBorder) << 12) | ((uint32_t)s0 << 24);
 		}
 	}
-	__syncthreads();
 	if (tid == 0) *countOut = runBase;
 	(void)sw;
 }
