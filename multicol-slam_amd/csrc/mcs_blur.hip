@@ -39,20 +39,34 @@ __global__ __launch_bounds__(256) void k_blur(ExtractBuffers b, int tilesPerImag
 	int stride;
 	const uint8_t* src = level_ptr(b, d, img, level, &stride);
 	const int tid = threadIdx.x;
-	const bool interior = tx0 >= 2 && ty0 >= 2 && tx0 + BT_W + 2 <= L.w && ty0 + BT_H + 2 <= L.h;
-	if (interior) {   // 33 dwords per input row, coalesced (global addresses may be unaligned; LDS rows are 4-byte aligned)
-		for (int i = tid; i < BI_H * (BI_W / 4); i += 256) {
-			const int r = i / (BI_W / 4), k = i - r * (BI_W / 4);
-			uint32_t v;
-			__builtin_memcpy(&v, src + (size_t)(ty0 + r - 2) * stride + (tx0 - 2) + 4 * k, 4);
-			*reinterpret_cast<uint32_t*>(&in[r][4 * k]) = v;
+	// 33 dwords per input row, coalesced (global addresses may be unaligned; LDS rows are 4-byte aligned).  Rows are reflected per row; a dword that
+	// lies inside the level's columns is one load whatever the tile — only the <= 2 dwords per row that straddle the left / right border gather their
+	// bytes through reflected indices, and dwords wholly past column w + 1 (never part of a stored pixel's window) are zero.
+	// All five dwords of a thread are requested before the first LDS store waits for one: a load -> store loop would pay the memory latency five times over.
+	constexpr int kStage = (BI_H * (BI_W / 4) + 255) / 256;
+	uint32_t sv[kStage];
+#pragma unroll
+	for (int u = 0; u < kStage; ++u) {
+		const int i = u * 256 + tid;
+		const int r = (int)(((unsigned)i * 1986u) >> 16), k = i - r * (BI_W / 4);   // i / 33 exactly for i < 32768 (33 * 1986 = 2^16 + 2)
+		const int y = reflect101(min(ty0 + r - 2, L.h + 1), L.h);
+		const int xs = tx0 - 2 + 4 * k;
+		const uint8_t* row = src + (unsigned)y * (unsigned)stride;
+		uint32_t v = 0;
+		if (i < BI_H * (BI_W / 4)) {
+			if (xs >= 0 && xs + 3 < L.w) __builtin_memcpy(&v, row + xs, 4);
+			else if (xs < L.w + 2) {
+#pragma unroll
+				for (int e = 0; e < 4; ++e) v |= (uint32_t)row[reflect101(min(xs + e, L.w + 1), L.w)] << (8 * e);
+			}
 		}
-	} else {
-		for (int i = tid; i < BI_H * BI_W; i += 256) {
-			const int r = i / BI_W, c = i - r * BI_W;
-			const int y = reflect101(min(ty0 + r - 2, L.h + 1), L.h), x = reflect101(min(tx0 + c - 2, L.w + 1), L.w);
-			in[r][c] = src[(size_t)y * stride + x];
-		}
+		sv[u] = v;
+	}
+#pragma unroll
+	for (int u = 0; u < kStage; ++u) {
+		const int i = u * 256 + tid;
+		const int r = (int)(((unsigned)i * 1986u) >> 16), k = i - r * (BI_W / 4);
+		if (i < BI_H * (BI_W / 4)) *reinterpret_cast<uint32_t*>(&in[r][4 * k]) = sv[u];
 	}
 	__syncthreads();
 	// horizontal 5-sums, 4 adjacent columns per thread from two aligned dword reads: v_sad_u8 sums the four bytes of a window in one instruction,

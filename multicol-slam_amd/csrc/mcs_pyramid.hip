@@ -44,60 +44,99 @@ __global__ __launch_bounds__(256) void k_resize_level(ExtractBuffers b, int leve
 	const int ncols = sxb - sxa + 1;
 	const int ndw = (ncols + 3) >> 2;
 	const int tid = threadIdx.x;
-	if (nrows <= PS_ROWS && ndw * 4 <= PS_PITCH) {
-		for (int i = tid; i < nrows * ndw; i += 256) {
-			const int r = i / ndw, k = i - r * ndw;
-			const uint8_t* gp = src + (size_t)(sya + r) * sstride + sxa + 4 * k;
-			uint32_t v;
-			if (sxa + 4 * k + 3 < P.w) v = load_u32_unaligned(gp);
-			else {   // row tail: never read past the last pixel of the source row
-				v = 0;
-				for (int e = 0; e < 4; ++e) if (sxa + 4 * k + e < P.w) v |= (uint32_t)gp[e] << (8 * e);
+	// the thread's own column taps (4 adjacent destination columns) are requested first so that they arrive with the tile
+	const int lx = (tid & 31) * 4;
+	const int x4 = x0 + lx;
+	ResizeTap txv[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) txv[i] = tapX[min(x4 + i, L.w - 1)];
+	const bool inLds = nrows <= PS_ROWS && ndw * 4 + 4 <= PS_PITCH;   // + 4: the right neighbour of the last column is read (with weight 0) even past the footprint
+	if (inLds) {
+		// i / ndw by multiplication: ndw <= 47 and i < 50 * 47, so with M = ceil(2^18 / ndw) the error term i * (M*ndw - 2^18) < i * ndw < 2^18 and (i * M) >> 18 is exact
+		const unsigned rowM = (262144u + (unsigned)ndw - 1u) / (unsigned)ndw;
+		// four dwords per thread are requested before the first LDS store waits (a load -> store loop pays the memory latency once per trip)
+		const int ndwTile = nrows * ndw;
+		for (int base = 0; base < ndwTile; base += 4 * 256) {
+			uint32_t sv[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int i = base + u * 256 + tid;
+				const int r = (int)(((unsigned)i * rowM) >> 18), k = i - r * ndw;
+				const uint8_t* gp = src + ((unsigned)(sya + r) * (unsigned)sstride + (unsigned)(sxa + 4 * k));
+				uint32_t v = 0;
+				if (i < ndwTile) {
+					if (sxa + 4 * k + 3 < P.w) v = load_u32_unaligned(gp);
+					else   // row tail: never read past the last pixel of the source row
+						for (int e = 0; e < 4; ++e) if (sxa + 4 * k + e < P.w) v |= (uint32_t)gp[e] << (8 * e);
+				}
+				sv[u] = v;
 			}
-			*reinterpret_cast<uint32_t*>(&src_t[r * PS_PITCH + 4 * k]) = v;
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int i = base + u * 256 + tid;
+				const int r = (int)(((unsigned)i * rowM) >> 18), k = i - r * ndw;
+				if (i < ndwTile) *reinterpret_cast<uint32_t*>(&src_t[r * PS_PITCH + 4 * k]) = sv[u];
+			}
 		}
 	}
 	__syncthreads();
-	const int lx = (tid & 31) * 4;
-	const int x4 = x0 + lx;
 	if (x4 >= L.w) return;
-	const bool inLds = nrows <= PS_ROWS && ndw * 4 <= PS_PITCH;
-	ResizeTap txv[4];
-	int sxc[4], sx1c[4];
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		const int x = min(x4 + i, L.w - 1);
-		txv[i] = tapX[x];
-		sxc[i] = txv[i].ofs;
-		sx1c[i] = sxc[i] + 1 < P.w ? sxc[i] + 1 : P.w - 1;   // a1 == 0 whenever sx+1 is out of range (dx >= xmax)
-	}
 	uint8_t* dst = b.pyr + (size_t)img * d.pyrBytes + L.off;
-	for (int ly = tid >> 5; ly < PT_H; ly += 8) {
-		const int y = y0 + ly;
-		if (y >= L.h) break;
-		const ResizeTap tyv = tapY[y];
-		int sy0 = tyv.ofs, sy1 = tyv.ofs + 1;
-		sy0 = sy0 < 0 ? 0 : (sy0 >= P.h ? P.h - 1 : sy0);   // clip(sy, 0, ssize.height)
-		sy1 = sy1 < 0 ? 0 : (sy1 >= P.h ? P.h - 1 : sy1);
+	// out = ((b0 * ((p00*a0 + p01*a1) >> 4)) >> 16) + ((b1 * ((p10*a0 + p11*a1) >> 4)) >> 16) + 2) >> 2, all in int32 like the reference's fixed-point path
+	uint32_t live = 0;   // bytes of the thread's dword that are pixels of the level (the rest is row padding, stored as 0)
+#pragma unroll
+	for (int i = 0; i < 4; ++i) live |= (x4 + i < L.w) ? 0xffu << (8 * i) : 0u;
+	auto emit = [&](int y, const ResizeTap tyv, auto&& px) {
 		uint32_t packed = 0;
+		int p00[4], p01[4], p10[4], p11[4];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) px(i, p00[i], p01[i], p10[i], p11[i]);   // all sixteen reads in flight before the first multiply waits
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			int p00, p01, p10, p11;
-			if (inLds) {   // LDS indices are formed without ever stepping outside the array (no negative LDS base pointers)
-				const int o0 = (sy0 - sya) * PS_PITCH, o1 = (sy1 - sya) * PS_PITCH;
-				p00 = src_t[o0 + sxc[i] - sxa]; p01 = src_t[o0 + sx1c[i] - sxa];
-				p10 = src_t[o1 + sxc[i] - sxa]; p11 = src_t[o1 + sx1c[i] - sxa];
-			} else {       // generic path for scale factors whose footprint does not fit the LDS tile
-				const uint8_t* r0 = src + (size_t)sy0 * sstride;
-				const uint8_t* r1 = src + (size_t)sy1 * sstride;
-				p00 = r0[sxc[i]]; p01 = r0[sx1c[i]]; p10 = r1[sxc[i]]; p11 = r1[sx1c[i]];
-			}
-			const int t0 = p00 * txv[i].a0 + p01 * txv[i].a1;
-			const int t1 = p10 * txv[i].a0 + p11 * txv[i].a1;
+			const int t0 = p00[i] * txv[i].a0 + p01[i] * txv[i].a1;
+			const int t1 = p10[i] * txv[i].a0 + p11[i] * txv[i].a1;
 			const int v = ((((int)tyv.a0 * (t0 >> 4)) >> 16) + (((int)tyv.a1 * (t1 >> 4)) >> 16) + 2) >> 2;
-			packed |= (x4 + i < L.w) ? (uint32_t)(v & 0xff) << (8 * i) : 0u;
+			packed |= (uint32_t)(v & 0xff) << (8 * i);
 		}
-		*reinterpret_cast<uint32_t*>(dst + (size_t)y * L.stride + x4) = packed;   // row pitch is a multiple of 64: the tail dword stays in-pitch
+		*reinterpret_cast<uint32_t*>(dst + (unsigned)y * (unsigned)L.stride + (unsigned)x4) = packed & live;   // row pitch is a multiple of 64: the tail dword stays in-pitch
+	};
+	if (inLds) {
+		// LDS path (every shipped scale factor): the right neighbour is always column + 1 — where that is past the source row its weight a1 is 0
+		// (dx >= xmax in the reference's table), so whatever the tile holds there is multiplied away
+		int col[4], col1[4];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			col[i] = txv[i].ofs - sxa;
+			col1[i] = col[i] + 1;
+			asm volatile("" : "+v"(col1[i]));   // keeps the two reads byte-sized: fused into one 16-bit LDS read they land on odd addresses
+		}
+#pragma unroll 1   // rolled: unrolled, the four rows' reads cost ~30 registers and two resident workgroups per CU (0.29 vs 0.235 ms)
+		for (int j = 0; j < PT_H / 8; ++j) {
+			const int y = y0 + (tid >> 5) + 8 * j;
+			if (y >= L.h) break;
+			const ResizeTap tyv = tapY[y];
+			const int sy0 = min(max((int)tyv.ofs, 0), P.h - 1), sy1 = min(max((int)tyv.ofs + 1, 0), P.h - 1);   // clip(sy, 0, ssize.height)
+			const uint8_t* r0 = &src_t[(sy0 - sya) * PS_PITCH];
+			const uint8_t* r1 = &src_t[(sy1 - sya) * PS_PITCH];
+			emit(y, tyv, [&](int i, int& p00, int& p01, int& p10, int& p11) {
+				p00 = r0[col[i]]; p01 = r0[col1[i]]; p10 = r1[col[i]]; p11 = r1[col1[i]];
+			});
+		}
+	} else {
+		// generic path for scale factors whose footprint does not fit the LDS tile: straight from global memory
+#pragma unroll 1   // rolled: unrolled, the four rows' reads cost ~30 registers and two resident workgroups per CU (0.29 vs 0.235 ms)
+		for (int j = 0; j < PT_H / 8; ++j) {
+			const int y = y0 + (tid >> 5) + 8 * j;
+			if (y >= L.h) break;
+			const ResizeTap tyv = tapY[y];
+			const int sy0 = min(max((int)tyv.ofs, 0), P.h - 1), sy1 = min(max((int)tyv.ofs + 1, 0), P.h - 1);
+			const uint8_t* r0 = src + (size_t)sy0 * sstride;
+			const uint8_t* r1 = src + (size_t)sy1 * sstride;
+			emit(y, tyv, [&](int i, int& p00, int& p01, int& p10, int& p11) {
+				const int sx = txv[i].ofs, sx1 = sx + 1 < P.w ? sx + 1 : P.w - 1;
+				p00 = r0[sx]; p01 = r0[sx1]; p10 = r1[sx]; p11 = r1[sx1];
+			});
+		}
 	}
 }
 
