@@ -15,7 +15,7 @@
 namespace mcs {
 void upload_describe_tables(const signed char* pattern, const signed char* disc, const int* umax);
 void launch_single_distance(const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out, hipStream_t s);
-void launch_selftest_fast_model(const OcamDev* cam, unsigned long long seed, int n, int width, int height, unsigned long long* maxDiff, hipStream_t s);
+void launch_selftest_fast_model(const OcamDev* cam, const double* tab, unsigned long long seed, int n, int width, int height, unsigned long long* maxDiff, hipStream_t s);
 static const signed char kPattern[2048] = {
 #include "learned_pattern_64_orb.inc"
 };
@@ -27,16 +27,80 @@ using namespace mcs;
 // 10 000 keypoints, and 30-40x above describe_fast_bound() for the Lafida cameras.
 static constexpr double kDefaultGuardEps = 5.9604644775390625e-08;
 
+// The fast pass's table of rho(theta(a)) for one camera (layout: mcs_common.h kRho*), built in long double, and the bound on what its truncated Taylor
+// rows leave out.  Row of bin i, half h: centre c = sigma * i / kRhoK (sigma = sign p0), theta(c + t) = theta0 + s * (atan(c + t) - atan c) with
+// theta0 = sigma * pi/2 - atan c, s = -1 (h = 0: |norm / p0| < 1) or theta0 = atan c, s = +1 (h = 1);  rho(theta0 + y) = sum_k p_k y^k is invP
+// re-expanded at theta0;  the row is the composition truncated at t^kRhoDeg, rescaled to the kernel's variable x - i = sigma * kRhoK * t.
+// Tail: the Taylor coefficients of atan at any real c are at most 1/k in magnitude, so atan(c + t) - atan c is dominated coefficient by coefficient by
+// t / (1 - t), and the composition by sum_k |p_k| (t / (1 - t))^k, whose t^j coefficient is M_j = sum_k |p_k| C(j-1, k-1).  With |t| <= 1 / (2 kRhoK)
+// the truncated tail is at most sum_{j > kRhoDeg} M_j |t|^j (evaluated to j = 96; the rest is below S * (2|t|)^96).  Returns that bound (max over the
+// rows), or +inf if a coefficient is not finite.
+static double build_rho_table(const mcs_ocam& m, double* tab) {
+	typedef long double LD;
+	const int n = m.invP_deg;
+	const LD sigma = m.p[0] < 0 ? -1.0L : 1.0L, halfPi = sigma * (acosl(-1.0L) / 2);
+	const double tmax = 1.0 / (2.0 * kRhoK);
+	double worst = 0.0;
+	LD binom[MCS_MAX_POLY][MCS_MAX_POLY];
+	for (int i = 0; i < MCS_MAX_POLY; ++i)
+		for (int k = 0; k <= i; ++k) binom[i][k] = (k == 0 || k == i) ? 1.0L : binom[i - 1][k - 1] + binom[i - 1][k];
+	for (int h = 0; h < 2; ++h)
+		for (int i = 0; i < kRhoBins; ++i) {
+			const LD c = sigma * (LD)i / (LD)kRhoK, at = atanl(c), theta0 = h == 0 ? halfPi - at : at, sgn = h == 0 ? -1.0L : 1.0L;
+			// y(t) = sgn * (atan(c + t) - atan c) = sum_{k>=1} y_k t^k:  d/dt atan = 1 / ((1 + c^2) + 2c t + t^2) = sum f_k t^k
+			LD f[kRhoDeg + 1], y[kRhoDeg + 1];
+			const LD d0 = 1.0L + c * c;
+			f[0] = 1.0L / d0;
+			for (int k = 1; k <= kRhoDeg; ++k) f[k] = -(2.0L * c * f[k - 1] + (k >= 2 ? f[k - 2] : 0.0L)) / d0;
+			y[0] = 0.0L;
+			for (int k = 1; k <= kRhoDeg; ++k) y[k] = sgn * f[k - 1] / (LD)k;
+			// invP re-expanded at theta0
+			LD pk[MCS_MAX_POLY];
+			for (int k = 0; k < n; ++k) {
+				LD acc = 0.0L, pw = 1.0L;
+				for (int j = k; j < n; ++j) { acc += binom[j][k] * (LD)m.invP[j] * pw; pw *= theta0; }
+				pk[k] = acc;
+			}
+			// H(t) = sum_k pk[k] y(t)^k by Horner in y, series truncated at degree kRhoDeg
+			LD H[kRhoDeg + 1] = {0};
+			H[0] = pk[n - 1];
+			for (int k = n - 2; k >= 0; --k) {
+				LD T[kRhoDeg + 1] = {0};
+				for (int a = 0; a <= kRhoDeg; ++a)
+					for (int bq = 1; a + bq <= kRhoDeg; ++bq) T[a + bq] += H[a] * y[bq];
+				for (int a = 0; a <= kRhoDeg; ++a) H[a] = T[a];
+				H[0] += pk[k];
+			}
+			double* row = tab + ((size_t)h * kRhoBins + i) * kRhoRow;
+			LD sc = 1.0L;
+			for (int j = 0; j <= kRhoDeg; ++j) { row[j] = (double)(H[j] * sc); sc /= sigma * (LD)kRhoK; if (!std::isfinite(row[j])) return INFINITY; }
+			// the tail
+			double tail = 0.0, S = 0.0, tp = 1.0;
+			for (int k = 1; k < n; ++k) S += std::fabs((double)pk[k]);
+			for (int j = 1; j <= 96; ++j) {
+				tp *= tmax;
+				if (j <= kRhoDeg) continue;
+				double Mj = 0.0, cb = 1.0;   // cb = C(j-1, k-1)
+				for (int k = 1; k < n && k <= j; ++k) { Mj += std::fabs((double)pk[k]) * cb; cb = cb * (double)(j - k) / (double)k; }
+				tail += Mj * tp;
+			}
+			tail += S * std::pow(2.0 * tmax, 96);
+			worst = std::max(worst, tail);
+		}
+	return worst * 1.01;   // the sums above are in rounded arithmetic
+}
+
 // Worst-case |(fast coordinate - fast mean) - (reference coordinate - reference mean)| for one camera and npoints pattern points.
 // u = 2^-53.  Both arithmetics evaluate the same real function F(xr, yr) = affine(x/n * rho(atan(p0/n))); each differs from F by its own rounding:
-//   theta   fast: polynomial (4.1e-15, tools/gen_atan_poly.py) + rounding of its argument and of pi/2 - A  <= 1e-14;   reference: atan within 2 ulp, <= 8u
-//   rho     |d rho| <= |d theta| * S' + (roundings of the Horner chain) * u * S,   S = sum |invP_i| (pi/2)^i,  S' = sum i |invP_i| (pi/2)^(i-1)
-//           (fast: 12 FMAs + rho*r + x*g -> 32u S generously; reference: 24 roundings + 2 divisions + 2 products -> 96u S)
+//   rho     fast: the table row's truncated tail (tabTail, from build_rho_table) + its argument's roundings (n2, the refined rsq, two products: <= 1e-14
+//           in a, and |d rho / d a| <= S') + the row's Horner chain, rho*r and x*g (64u * 1.1 S generously: the row's partial sums stay below
+//           sum |invP_i| (pi/2 + 0.008)^i <= 1.1 S);   reference: atan within 2 ulp (8u S') + 24 roundings + 2 divisions + 2 products -> 96u S
+//           S = sum |invP_i| (pi/2)^i,  S' = sum i |invP_i| (pi/2)^(i-1)
 //   u, v    (1 + |c| + |d| + |e|) * d rho  +  8u (|u0| + |v0|)
 //   mean    the same per-point bound, plus the reordering of the sum: sequential (npoints-1) u Umax + tree 13 u Umax, Umax = 16384 + 4096 (enforced by the kernel)
 //   minus   two more roundings of values below 8192
 // Returns +inf for a camera the fast arithmetic cannot serve (p0 = 0, non-finite coefficients).
-static double describe_fast_bound(const mcs_ocam& m, int npoints) {
+static double describe_fast_bound(const mcs_ocam& m, int npoints, double tabTail) {
 	const double u = 1.1102230246251565e-16, hp = 1.5707963267948966;
 	double S = 0, Sp = 0, pw = 1.0;
 	for (int i = 0; i < m.invP_deg; ++i) {
@@ -45,9 +109,10 @@ static double describe_fast_bound(const mcs_ocam& m, int npoints) {
 		if (i + 1 < m.invP_deg) Sp += (i + 1) * std::fabs(m.invP[i + 1]) * pw;
 		pw *= hp;
 	}
-	if (!(std::fabs(m.p[0]) > 1e-300) || !std::isfinite(m.p[0]) || !std::isfinite(1.0 / m.p[0])) return INFINITY;
+	if (!(std::fabs(m.p[0]) > 1e-300) || !std::isfinite(m.p[0]) || !std::isfinite(1.0 / m.p[0]) || !std::isfinite(tabTail)) return INFINITY;
+	if (!std::isfinite((double)kRhoK / m.p[0]) || !std::isfinite((double)kRhoK * m.p[0])) return INFINITY;
 	const double aff = 1.0 + std::fabs(m.c) + std::fabs(m.d) + std::fabs(m.e), pp = 8 * u * (std::fabs(m.u0) + std::fabs(m.v0));
-	const double fast = aff * (1e-14 * Sp + 64 * u * S) + pp;
+	const double fast = aff * (tabTail + 1e-14 * Sp + 64 * u * 1.1 * S) + pp;
 	const double ref = aff * (8 * u * Sp + 96 * u * S) + pp;
 	const double point = fast + ref;
 	const double total = 2 * point + (npoints + 16) * u * 20480.0 + 4 * u * 8192.0;
@@ -77,6 +142,10 @@ struct mcs_extractor {
 	// descriptor passes (mcs_describe.hip): fallback list of the fast pass, its running total, the guard band
 	int* d_fbCount = nullptr; uint32_t* d_fbList = nullptr; unsigned long long* d_fbStats = nullptr; KpAux* d_aux = nullptr;
 	int describeMode = 0; double guardEps = kDefaultGuardEps;
+	// rho tables of the cameras seen so far (a rig has a handful), and the per-image copy the fast pass reads
+	struct CamFast { OcamDev key; double tail; std::vector<double> tab; };
+	std::vector<CamFast> camCache;
+	double* d_rhoTab = nullptr;
 	// host-kind input staging: the caller's image / mask block as it lies in host memory (same pitch and stride), grown on demand
 	uint8_t *d_inImg = nullptr, *d_inMask = nullptr; size_t inImgCap = 0, inMaskCap = 0;
 	// host-kind output staging
@@ -370,6 +439,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	ALLOC(e->d_fbList, B * (size_t)((hd.kpCap + 3) / 4 * 4) * sizeof(uint32_t));
 	ALLOC(e->d_fbStats, sizeof(unsigned long long));
 	ALLOC(e->d_aux, B * (size_t)((hd.kpCap + 3) / 4 * 4) * describe_aux_bytes());
+	ALLOC(e->d_rhoTab, B * (size_t)kRhoTabDoubles * sizeof(double));
 	ALLOC(e->d_nkp, B * sizeof(int));
 	ALLOC(e->d_kps, B * hd.kpCap * sizeof(mcs_keypoint));
 	ALLOC(e->d_odesc, B * hd.kpCap * (size_t)hd.descSize);
@@ -401,7 +471,7 @@ int mcs_extractor_destroy(mcs_extractor* e) {
 	}
 	void* ptrs[] = {e->d_desc, e->d_cells, e->d_taps, e->d_maskMap, e->d_pyr, e->d_blur, e->d_slots, e->d_dense, e->d_knode,
 	                e->d_sel, e->d_cellCount, e->d_denseCount, e->d_selCount, e->d_status, e->d_cams, e->d_nkp, e->d_kps, e->d_odesc,
-	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_fbStats, e->d_aux};
+	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_fbStats, e->d_aux, e->d_rhoTab};
 	for (void* p : ptrs) (void)hipFree(p);
 	delete e;
 	return MCS_OK;
@@ -450,7 +520,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 	b.desc = e->d_desc; b.cells = e->d_cells; b.taps = e->d_taps; b.maskMap = e->d_maskMap;
 	b.pyr = e->d_pyr; b.blur = e->d_blur; b.slots = e->d_slots; b.cellCount = e->d_cellCount; b.dense = e->d_dense; b.knode = e->d_knode;
 	b.denseCount = e->d_denseCount; b.sel = e->d_sel; b.selCount = e->d_selCount; b.status = e->d_status;
-	b.aux = e->d_aux; b.fbCount = e->d_fbCount; b.fbList = e->d_fbList; b.fbStats = e->d_fbStats; b.guardEps = e->guardEps; b.describeMode = e->describeMode;
+	b.rhoTab = e->d_rhoTab; b.aux = e->d_aux; b.fbCount = e->d_fbCount; b.fbList = e->d_fbList; b.fbStats = e->d_fbStats; b.guardEps = e->guardEps; b.describeMode = e->describeMode;
 	b.outImgPitch = out_image_pitch_rows ? out_image_pitch_rows : (size_t)hd.kpCap;
 	b.outRowStride = out_row_stride ? out_row_stride : hd.descSize;
 	if (b.outImgPitch < (size_t)hd.kpCap || b.outRowStride < hd.descSize) return fail(MCS_ERR_INVALID, "output image pitch / row stride smaller than the rows they hold");
@@ -476,6 +546,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 	}
 	if (cams) {
 		std::vector<OcamDev> hc(nimg);
+		std::vector<int> which(nimg);
 		for (int i = 0; i < nimg; ++i) {
 			const mcs_ocam& m = cams[i];
 			if (m.p_deg < 1 || m.p_deg > MCS_MAX_POLY || m.invP_deg < 1 || m.invP_deg > MCS_MAX_POLY) return fail(MCS_ERR_INVALID, "bad polynomial degree");
@@ -485,13 +556,31 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 			for (int k = 0; k < m.p_deg; ++k) o.p[k] = m.p[k];
 			for (int k = 0; k < m.invP_deg; ++k) o.invP[k] = m.invP[k];
 			o.p_deg = m.p_deg; o.invP_deg = m.invP_deg;
-			const double bound = describe_fast_bound(m, hd.npoints);
+			// the camera's rho table and its tail bound: built once per distinct camera
+			int w = -1;
+			for (size_t k = 0; k < e->camCache.size() && w < 0; ++k) if (memcmp(&e->camCache[k].key, &o, sizeof(o)) == 0) w = (int)k;
+			if (w < 0) {
+				if (e->camCache.size() >= 64) e->camCache.clear();
+				mcs_extractor::CamFast cf;
+				cf.key = o; cf.tab.assign(kRhoTabDoubles, 0.0);
+				cf.tail = build_rho_table(m, cf.tab.data());
+				if (!std::isfinite(cf.tail)) cf.tab.assign(kRhoTabDoubles, 0.0);
+				e->camCache.push_back(std::move(cf));
+				w = (int)e->camCache.size() - 1;
+			}
+			which[i] = w;
+			const double bound = describe_fast_bound(m, hd.npoints, e->camCache[w].tail);
 			o.fastOk = bound <= 0.5 * e->guardEps ? 1 : 0;   // a factor 2 between the worst case and the band
 			o.invP0 = o.fastOk ? 1.0 / m.p[0] : 0.0;
+			o.wK = o.fastOk ? (double)kRhoK / std::fabs(m.p[0]) : 0.0;
+			o.tK = o.fastOk ? (double)kRhoK * std::fabs(m.p[0]) : 0.0;
 		}
 		if (e->h_cams.size() != hc.size() || memcmp(e->h_cams.data(), hc.data(), sizeof(OcamDev) * hc.size()) != 0) {
-			HIPCHK(hipStreamSynchronize(s));   // the previous batch may still read d_cams
+			HIPCHK(hipStreamSynchronize(s));   // the previous batch may still read d_cams / d_rhoTab
 			HIPCHK(hipMemcpy(e->d_cams, hc.data(), sizeof(OcamDev) * hc.size(), hipMemcpyHostToDevice));
+			std::vector<double> tabs((size_t)nimg * kRhoTabDoubles);
+			for (int i = 0; i < nimg; ++i) memcpy(&tabs[(size_t)i * kRhoTabDoubles], e->camCache[which[i]].tab.data(), kRhoTabDoubles * sizeof(double));
+			HIPCHK(hipMemcpy(e->d_rhoTab, tabs.data(), tabs.size() * sizeof(double), hipMemcpyHostToDevice));
 			e->h_cams = hc;
 		}
 		b.cams = e->d_cams;
@@ -583,7 +672,8 @@ int mcs_extractor_describe_stats(mcs_extractor* e, uint64_t* exact_pass_keypoint
 
 int mcs_describe_fast_bound(const mcs_ocam* cam, int desc_size, double* bound) {
 	if (!cam || !bound || cam->invP_deg < 1 || cam->invP_deg > MCS_MAX_POLY || cam->p_deg < 1) return fail(MCS_ERR_INVALID, "bad argument");
-	*bound = describe_fast_bound(*cam, 2 * 8 * desc_size);
+	std::vector<double> tab(kRhoTabDoubles, 0.0);
+	*bound = describe_fast_bound(*cam, 2 * 8 * desc_size, build_rho_table(*cam, tab.data()));
 	return MCS_OK;
 }
 
@@ -597,13 +687,18 @@ int mcs_selftest_describe_fast(mcs_ctx* c, const mcs_ocam* cam, uint64_t seed, i
 	for (int k = 0; k < cam->p_deg; ++k) o.p[k] = cam->p[k];
 	for (int k = 0; k < cam->invP_deg; ++k) o.invP[k] = cam->invP[k];
 	o.p_deg = cam->p_deg; o.invP_deg = cam->invP_deg; o.invP0 = 1.0 / cam->p[0]; o.fastOk = 1;
+	o.wK = (double)kRhoK / std::fabs(cam->p[0]); o.tK = (double)kRhoK * std::fabs(cam->p[0]);
+	std::vector<double> tab(kRhoTabDoubles, 0.0);
+	if (!std::isfinite(build_rho_table(*cam, tab.data()))) return fail(MCS_ERR_UNSUPPORTED, "the fast pass does not serve this camera");
 	uint8_t* buf = nullptr;
 	HIPCHK(hipStreamSynchronize(c->stream));
-	HIPCHK(ctx_arena(c, sizeof(OcamDev) + 64, &buf));
+	const size_t tabOff = (64 + sizeof(OcamDev) + 63) / 64 * 64;
+	HIPCHK(ctx_arena(c, tabOff + kRhoTabDoubles * sizeof(double), &buf));
 	unsigned long long zero = 0, got = 0;
 	HIPCHK(hipMemcpy(buf, &zero, sizeof(zero), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(buf + 64, &o, sizeof(o), hipMemcpyHostToDevice));
-	launch_selftest_fast_model((const OcamDev*)(buf + 64), seed, n, cam->width, cam->height, (unsigned long long*)buf, c->stream);
+	HIPCHK(hipMemcpy(buf + tabOff, tab.data(), kRhoTabDoubles * sizeof(double), hipMemcpyHostToDevice));
+	launch_selftest_fast_model((const OcamDev*)(buf + 64), (const double*)(buf + tabOff), seed, n, cam->width, cam->height, (unsigned long long*)buf, c->stream);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipMemcpy(&got, buf, sizeof(got), hipMemcpyDeviceToHost));

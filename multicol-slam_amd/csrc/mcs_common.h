@@ -64,7 +64,12 @@ struct OcamDev {
 	// fast pass of the descriptor kernel (mcs_describe.hip): 1 / p[0], and whether this camera's worst-case arithmetic difference stays below the guard band
 	double invP0;
 	int fastOk, pad_;
+	double wK, tK;          // kRhoK / |p0| and kRhoK * |p0|: |norm / p0| and |p0 / norm| in bins of the rho table
 };
+
+// Per-camera table of rho(theta(a)) for the fast descriptor pass: two halves (theta = +-pi/2 - atan a for |norm / p0| < 1, theta = atan a otherwise), each
+// kRhoBins rows of kRhoRow Taylor coefficients in (|a| * kRhoK - bin).  Built by build_rho_table() in mcs_capi.hip, which also bounds the truncated tail.
+constexpr int kRhoK = 64, kRhoDeg = 5, kRhoBins = kRhoK + 1, kRhoRow = kRhoDeg + 1, kRhoTabDoubles = 2 * kRhoBins * kRhoRow;
 
 struct KpAux;   // per-keypoint scratch of the descriptor passes (mcs_describe.hip)
 struct ExtractBuffers {
@@ -86,6 +91,7 @@ struct ExtractBuffers {
 	const OcamDev* cams;          // [B] or nullptr
 	int* status;                  // device error word (capacity overflows)
 	// dBRIEF / mdBRIEF: fast pass + exact pass over the fast pass's fallback list (mcs_describe.hip)
+	const double* rhoTab;                // [B][kRhoTabDoubles] the images' camera tables
 	KpAux* aux;                          // [B][roundup4(kpCap)] orientation / ray / pattern-angle records prepared for the fast pass
 	int* fbCount; uint32_t* fbList;      // keypoint slots (image * wavesPerImage + slot) the fast pass handed to the exact pass, this batch
 	unsigned long long* fbStats;         // running total of those (all batches of the extractor)

@@ -546,8 +546,8 @@ __global__ __launch_bounds__(64) void k_describe_list(ExtractBuffers b, int wave
 // pattern point
 //      xr, yr   = rotation + undistorted keypoint                     (FMA form)
 //      r        = 1 / sqrt(xr^2 + yr^2)                               v_rsq_f64 (>= 2^-23 accurate... whatever its accuracy e0, the cubic step leaves ~e0^3)
-//      theta    = atan(p0 / norm)  as  copysign(pi/2, p0) - A(norm / p0)  for norm < |p0|,  A(p0 / norm) otherwise;  A(a) = a * Q(a^2), |a| <= 1
-//      rho      = Horner(invP, theta)                                 (FMA form)
+//      rho      = invP(atan(p0 / norm))                               from the camera's table: a = norm / p0 or p0 / norm (|a| <= 1), the bin's Taylor
+//                                                                     polynomial of rho(theta(a)) — degree kRhoDeg instead of a 17-term atan and the 11 FMAs of invP
 //      u, v     = affine(xr * rho / norm, yr * rho / norm)
 // and a wave tree sum for the mean.  None of this is the reference's rounding; it is only USED when every one of the keypoint's
 // 2 * npat * 2*8*descSize coordinates (minus the mean) stays clear of the rounding ties by more than the guard band b.guardEps, which the host keeps
@@ -559,11 +559,6 @@ __global__ __launch_bounds__(64) void k_describe_list(ExtractBuffers b, int wave
 #ifndef MCS_FAST_ABLATE
 #define MCS_FAST_ABLATE 0   // A/B experiments only (tools/ab_describe.sh): 1 no sampling, 2 no omni model, 4 no guard / rounding checks
 #endif
-static __device__ constexpr double kAtanQ[17] = {
-#include "mcs_atan_poly.inc"
-};
-constexpr double kHalfPi = 0x1.921fb54442d18p+0;
-constexpr int kAtanN = 17;
 #ifndef MCS_FAST_WPB
 #define MCS_FAST_WPB 4
 #endif
@@ -575,35 +570,34 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 	return v;
 }
 
-// one pattern point through the fast arithmetic
-struct FastCam { double cP[MCS_MAX_POLY]; int deg; double c, d, e, u0, v0, p0, invP0, hp; };
-__device__ __forceinline__ void fast_w2i(const FastCam& C, double xr, double yr, double& u, double& v) {
+// one pattern point through the fast arithmetic.  rho(theta(a)) comes from a per-camera table (mcs_common.h kRho*: built by the host in long double,
+// its truncation error bounded there): a = norm / p0 where |norm / p0| < 1 (theta = +-pi/2 - atan a), else a = p0 / norm (theta = atan a); |a| <= 1 is
+// cut into kRhoK bins, x = |a| * kRhoK, the bin is rint(x) (its low mantissa bits after adding 1.5 * 2^52), and the row holds the Taylor coefficients
+// of rho in (x - bin), degree kRhoDeg.  x - bin is exact, so the only approximation is the truncated tail.
+struct FastCam { double c, d, e, u0, v0, wK, tK; };
+template <class Tab>
+__device__ __forceinline__ void fast_w2i(const FastCam& C, Tab tab, double xr, double yr, double& u, double& v) {
 	const double n2 = __builtin_fma(xr, xr, yr * yr);
 	const double r0 = __builtin_amdgcn_rsq(n2);
 	const double e1 = __builtin_fma(-(n2 * r0), r0, 1.0);                          // 1 - n2 * r0^2
 	const double r = __builtin_fma(r0 * e1, __builtin_fma(e1, 0.375, 0.5), r0);     // r0 * (1 + e/2 + 3e^2/8)
 	const double norm = n2 * r;
-	const double w = norm * C.invP0, t = C.p0 * r;
-	const bool small = fabs(w) < 1.0;
-	const double a = small ? w : t;
-	const double s2 = a * a;
-	double q = kAtanQ[kAtanN - 1];
+	const double wq = norm * C.wK, tq = C.tK * r;                                   // |norm / p0| * kRhoK,  |p0 / norm| * kRhoK
+	const bool small = wq < (double)kRhoK;
+	const double x = small ? wq : tq;
+	const double sft = x + 0x1.8p52;
+	const double dx = x - (sft - 0x1.8p52);
+	int bin = (int)(unsigned)__double_as_longlong(sft);
+	bin = bin < 0 ? 0 : (bin > kRhoK ? kRhoK : bin);                                // NaN / overflow cannot index outside the table (they fail the guard later)
+	const auto g = tab + (small ? 0 : kRhoBins * kRhoRow) + bin * kRhoRow;
+	double gc[kRhoRow];
 #pragma unroll
-	for (int i = kAtanN - 2; i >= 0; --i) q = __builtin_fma(q, s2, kAtanQ[i]);
-	const double A = a * q;
-	const double theta = small ? C.hp - A : A;
-	double rho;
-	if (C.deg == 12) {
-		rho = C.cP[11];
+	for (int i = 0; i < kRhoRow; ++i) gc[i] = g[i];
+	double rho = gc[kRhoDeg];
 #pragma unroll
-		for (int i = 10; i >= 0; --i) rho = __builtin_fma(rho, theta, C.cP[i]);
-	} else {
-		rho = C.cP[MCS_MAX_POLY - 1];
-#pragma unroll
-		for (int i = MCS_MAX_POLY - 2; i >= 0; --i) rho = __builtin_fma(rho, theta, C.cP[i]);
-	}
-	const double g = rho * r;
-	const double uu = xr * g, vv = yr * g;
+	for (int i = kRhoDeg - 1; i >= 0; --i) rho = __builtin_fma(rho, dx, gc[i]);
+	const double gg = rho * r;
+	const double uu = xr * gg, vv = yr * gg;
 	u = __builtin_fma(uu, C.c, __builtin_fma(vv, C.d, C.u0));
 	v = __builtin_fma(uu, C.e, vv + C.v0);
 }
@@ -736,21 +730,23 @@ __global__ __launch_bounds__(256) void k_orient_b(ExtractBuffers b, int wavesPer
 template <int MODE, int NB>
 __attribute__((amdgpu_waves_per_eu(MCS_FAST_WAVES_PER_EU, MCS_FAST_WAVES_PER_EU)))
 __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffers b, int wavesPerImage, int nslots) {
-	extern __shared__ __attribute__((aligned(16))) double lds[];   // the blurred patch of each wave's keypoint
+	extern __shared__ __attribute__((aligned(16))) double lds[];   // the blurred patch of each wave's keypoint, then the camera's rho table (shared)
 	static_assert(MODE == 1 || MODE == 2, "the fast pass is for the distorted patterns");
+	static_assert(4 % kFastWaves == 0, "the waves of a block must belong to one image (slots per image are a multiple of 4)");
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int gw = blockIdx.x * kFastWaves + wave;
 	KeyPt kp_;
 	uint8_t* const patchLds = reinterpret_cast<uint8_t*>(lds) + (size_t)wave * kPatchBytes;
+	double* const tabLds = reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(lds) + (size_t)kFastWaves * kPatchBytes);
 	const PyrDesc& d = *b.desc;
 	// this keypoint, as the two orientation kernels left it (wave-uniform: scalar loads)
 	const int gwu = __builtin_amdgcn_readfirstlane(gw);
-	if (gwu >= nslots) return;
-	const KpAux& ax = b.aux[gwu];
-	const int level = ax.level;
-	if (level < 0) return;
+	const bool inRange = gwu < nslots;
+	const KpAux& ax = b.aux[inRange ? gwu : 0];
+	const int level = inRange ? ax.level : -1;
 	kp_.img = gwu / wavesPerImage; kp_.out = gwu - kp_.img * wavesPerImage; kp_.level = level; kp_.row = ax.row; kp_.col = ax.col;
-	{
+	uint32_t pv[kPatchTrips];
+	if (level >= 0) {
 		const LevelInfo& L = d.lv[level];
 		Sampler& sm = kp_.sm;
 		int rstride;
@@ -759,20 +755,27 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 		sm.blur = b.blur + (size_t)kp_.img * d.pyrBytes + L.off; sm.bstride = L.stride;
 		sm.w = L.w; sm.h = L.h;
 		sm.patch = patchLds; sm.prow = kp_.row - kPatchR; sm.pcol = kp_.col - kPatchR;
+		patch_load(kp_.sm.blur, kp_.sm.bstride, kp_.row, kp_.col, pv);   // in flight while the table and the camera constants arrive
 	}
-	uint32_t pv[kPatchTrips];
-	patch_load(kp_.sm.blur, kp_.sm.bstride, kp_.row, kp_.col, pv);   // in flight while the camera constants arrive
+	{   // the block's camera table (every wave of a block is a keypoint of the same image): 6 KB, both trips in flight before the first store
+		const int bimg = (int)(blockIdx.x * kFastWaves) / wavesPerImage;
+		const double2* gt = reinterpret_cast<const double2*>(b.rhoTab + (size_t)bimg * kRhoTabDoubles);
+		constexpr int n2 = kRhoTabDoubles / 2, trips = (n2 + 64 * kFastWaves - 1) / (64 * kFastWaves);
+		double2 tv[trips];
+#pragma unroll
+		for (int t = 0; t < trips; ++t) { const int i = t * 64 * kFastWaves + (int)threadIdx.x; tv[t] = i < n2 ? gt[i] : double2{0.0, 0.0}; }
+#pragma unroll
+		for (int t = 0; t < trips; ++t) { const int i = t * 64 * kFastWaves + (int)threadIdx.x; if (i < n2) reinterpret_cast<double2*>(tabLds)[i] = tv[t]; }
+	}
+	__syncthreads();
+	if (level < 0) return;
 	const OcamDev& cam = b.cams[kp_.img];
 	auto to_exact = [&]() { if (lane == 0) { const int at = atomicAdd(b.fbCount, 1); b.fbList[at] = (uint32_t)gwu; } };
 	if (cam.fastOk == 0) { to_exact(); return; }
 
 	FastCam C;
-#pragma unroll
-	for (int i = 0; i < MCS_MAX_POLY; ++i) C.cP[i] = cam.invP[i];
-	C.deg = cam.invP_deg;
 	C.c = cam.c; C.d = cam.d; C.e = cam.e; C.u0 = cam.u0; C.v0 = cam.v0;
-	C.p0 = cam.p[0]; C.invP0 = cam.invP0;
-	C.hp = C.p0 < 0.0 ? -kHalfPi : kHalfPi;
+	C.wK = cam.wK; C.tK = cam.tK;
 
 	constexpr int NP = 128 * NB;
 	uint32_t ppk[NB];
@@ -802,7 +805,7 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 			const double ptx = (double)(int)(signed char)(ppk[t >> 1] >> (16 * e)), pty = (double)(int)(signed char)(ppk[t >> 1] >> (16 * e + 8));
 			const double xr = __builtin_fma(ptx, ax, __builtin_fma(-pty, ay, ukx));
 			const double yr = __builtin_fma(ptx, ay, __builtin_fma(pty, ax, uky));
-			if (MCS_FAST_ABLATE & 2) { u[t] = xr; v[t] = yr; } else fast_w2i(C, xr, yr, u[t], v[t]);
+			if (MCS_FAST_ABLATE & 2) { u[t] = xr; v[t] = yr; } else fast_w2i(C, tabLds, xr, yr, u[t], v[t]);
 			sumx += u[t]; sumy += v[t];
 			if ((t & (MCS_FAST_FENCE - 1)) == MCS_FAST_FENCE - 1) __builtin_amdgcn_sched_barrier(0);   // at most MCS_FAST_FENCE point evaluations in flight (registers)
 		}
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 
 // self-test of the fast arithmetic: n pseudo-random pattern points around random keypoints of camera `cam` through fast_w2i and through the exact
 // world2img; maxDiff[0] = the largest |u_fast - u_exact| or |v_fast - v_exact| seen (as the bits of a non-negative double, atomicMax)
-__global__ void k_selftest_fast_model(const OcamDev* camp, unsigned long long seed, int n, int width, int height, unsigned long long* maxDiff) {
+__global__ void k_selftest_fast_model(const OcamDev* camp, const double* tab, unsigned long long seed, int n, int width, int height, unsigned long long* maxDiff) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const OcamDev& cam = *camp;
@@ -856,18 +859,16 @@ __global__ void k_selftest_fast_model(const OcamDev* camp, unsigned long long se
 	double ue, ve;
 	world2img(cam, xr, yr, -p0, ue, ve);
 	FastCam C;
-	for (int k = 0; k < MCS_MAX_POLY; ++k) C.cP[k] = cam.invP[k];
-	C.deg = cam.invP_deg; C.c = cam.c; C.d = cam.d; C.e = cam.e; C.u0 = cam.u0; C.v0 = cam.v0; C.p0 = p0; C.invP0 = cam.invP0;
-	C.hp = p0 < 0.0 ? -kHalfPi : kHalfPi;
+	C.c = cam.c; C.d = cam.d; C.e = cam.e; C.u0 = cam.u0; C.v0 = cam.v0; C.wK = cam.wK; C.tK = cam.tK;
 	double uf, vf;
-	fast_w2i(C, xr, yr, uf, vf);
+	fast_w2i(C, tab, xr, yr, uf, vf);
 	double diff = fmax(fabs(uf - ue), fabs(vf - ve));
 	if (!(diff == diff)) diff = 1e300;   // NaN on either side counts as a failure unless both are non-finite for the same reason (norm = 0 cannot occur here)
 	atomicMax(maxDiff, (unsigned long long)__double_as_longlong(diff));
 }
 
-void launch_selftest_fast_model(const OcamDev* cam, unsigned long long seed, int n, int width, int height, unsigned long long* maxDiff, hipStream_t s) {
-	hipLaunchKernelGGL(k_selftest_fast_model, dim3((n + 255) / 256), dim3(256), 0, s, cam, seed, n, width, height, maxDiff);
+void launch_selftest_fast_model(const OcamDev* cam, const double* tab, unsigned long long seed, int n, int width, int height, unsigned long long* maxDiff, hipStream_t s) {
+	hipLaunchKernelGGL(k_selftest_fast_model, dim3((n + 255) / 256), dim3(256), 0, s, cam, tab, seed, n, width, height, maxDiff);
 }
 
 template <int MODE>
@@ -881,7 +882,7 @@ static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hi
 	if constexpr (MODE != 0) {
 		if (b.describeMode == 0) {   // fast pass + exact pass over its fallback list
 			const int fblocks = nimg * wavesPerImage / kFastWaves, lblocks = std::min(blocks, 2048);
-			const size_t fLds = (size_t)kFastWaves * kPatchBytes;
+			const size_t fLds = (size_t)kFastWaves * kPatchBytes + kRhoTabDoubles * sizeof(double);
 			const int nslots = nimg * wavesPerImage;
 			(void)hipMemsetAsync(b.fbCount, 0, sizeof(int), s);
 			hipLaunchKernelGGL(k_orient_a, dim3((nslots + 15) / 16), dim3(256), 0, s, b, wavesPerImage, nslots);
