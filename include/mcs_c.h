@@ -137,7 +137,8 @@ int mcs_extractor_tap_selected(mcs_extractor*, int img, int level, uint32_t* out
  *   (SearchForTriangulationRaw's same-camera rule, cORBmatcher.cpp:1047).
  * Queries with q_valid[i] == 0 get count 0.  Distances are DescriptorDistance64 (masks NULL) or
  * DescriptorDistance64Masked.  out_dist/out_idx are [nq*K] (unused tail: dist = INT32_MAX, idx = -1);
- * out_count_le[i] = number of eligible train rows with distance <= count_thresh (to detect K overflow).
+ * out_count_le[i] = number of eligible train rows with distance <= count_thresh (to detect K overflow); count_thresh < 0: not wanted (out_count_le is
+ * zero-filled) — without it and without camera groups, 16- and 32-byte descriptors take the matrix-core kernel (csrc/mcs_match_mfma.hip).
  * dim = descriptor bytes (16/32/64).  The greedy, order-dependent part of the reference's searches is host logic
  * in the facade (include/mcs/cORBmatcher.hpp) on top of these lists.                                                */
 typedef struct {

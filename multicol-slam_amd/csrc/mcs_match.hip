@@ -311,6 +311,13 @@ __global__ __launch_bounds__(256) void k_match_unpack(MatchArgs a) {
 	}
 }
 
+// after the partial-list kernel: merge of the per-split lists, the public (dist, idx) form
+template <int K>
+static void launch_post(const MatchArgs& a, hipStream_t s) {
+	if (a.splits > 1) hipLaunchKernelGGL((k_match_merge<K>), dim3((a.nq + 255) / 256, 1, a.nsets), dim3(256), 0, s, a);
+	if (a.outDist && a.outIdx) hipLaunchKernelGGL(k_match_unpack, dim3((a.nq + 255) / 256, 1, a.nsets), dim3(256), 0, s, a);
+}
+
 template <int K, int DW>
 static void launch_kd(const MatchArgs& a, hipStream_t s) {
 	dim3 grid((a.nq + 255) / 256, a.splits, a.nsets);
@@ -322,8 +329,7 @@ static void launch_kd(const MatchArgs& a, hipStream_t s) {
 	else { if (count) { if (group) MCS_LAUNCH_PARTIAL(false, true, true); else MCS_LAUNCH_PARTIAL(false, true, false); }
 	       else { if (group) MCS_LAUNCH_PARTIAL(false, false, true); else MCS_LAUNCH_PARTIAL(false, false, false); } }
 #undef MCS_LAUNCH_PARTIAL
-	if (a.splits > 1) hipLaunchKernelGGL((k_match_merge<K>), dim3((a.nq + 255) / 256, 1, a.nsets), dim3(256), 0, s, a);
-	if (a.outDist && a.outIdx) hipLaunchKernelGGL(k_match_unpack, dim3((a.nq + 255) / 256, 1, a.nsets), dim3(256), 0, s, a);
+	launch_post<K>(a, s);
 }
 
 template <int K>
@@ -333,7 +339,24 @@ static void launch_k(const MatchArgs& a, hipStream_t s) {
 	else launch_kd<K, 16>(a, s);
 }
 
+// mcs_match_mfma.hip: the same partial lists from the matrix cores (16 / 32-byte descriptors, no count_le, no camera groups)
+bool match_mfma_serves(const MatchArgs& a);
+void launch_match_mfma(const MatchArgs& a, hipStream_t s);
+
 void launch_match(const MatchArgs& a, hipStream_t s) {
+	static const bool valuOnly = getenv("MCS_MATCH_VALU") != nullptr;   // run-time switch: the v_bcnt kernel for every shape (tests compare the two)
+	if (!valuOnly && match_mfma_serves(a)) {
+		launch_match_mfma(a, s);
+		switch (a.K) {
+			case 1: launch_post<1>(a, s); break;
+			case 2: launch_post<2>(a, s); break;
+			case 4: launch_post<4>(a, s); break;
+			case 8: launch_post<8>(a, s); break;
+			case 16: launch_post<16>(a, s); break;
+			default: launch_post<32>(a, s); break;
+		}
+		return;
+	}
 	switch (a.K) {
 		case 1: launch_k<1>(a, s); break;
 		case 2: launch_k<2>(a, s); break;

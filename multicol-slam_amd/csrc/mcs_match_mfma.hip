@@ -1,0 +1,330 @@
+// mcs_match_mfma.hip — the brute-force top-K matcher of mcs_match.hip with the pair distances on the matrix cores.
+// Reference: DescriptorDistance64 / DescriptorDistance64Masked src/cORBmatcher.cpp:2438-2474 (see mcs_match.hip for the call sites).
+//
+// A (masked) Hamming total is a bilinear form in the bits.  With x = q ^ t:
+//     popc(x & mq) = popc(mq & q) + sum_i t_i * mq_i (1 - 2 q_i)          popc(x & mt) = popc(mt & t) + sum_i q_i * mt_i (1 - 2 t_i)
+// so   total(q, t) = cq + ct + < [uq ; q] , [t ; vt] >,   uq = mq (1 - 2q), vt = mt (1 - 2t) in {-1, 0, +1},  cq = popc(mq & q), ct = popc(mt & t)
+// (unmasked: popc(q ^ t) = popc(q) + < 1 - 2q, t >).  Entries 0 / +-1 are exact in FP4 (E2M1: +1 = 0x2, -1 = 0xA), products and sums of at most 1024 of
+// them are exact in the f32 accumulators: v_mfma_f32_32x32x64_f8f6f4 gives 32 x 32 exact totals per instruction and 64 bits of K.  A 32-byte masked pair
+// is K = 512: 8 instructions (256 cycles) per 1024 pairs, where the v_xor / v_and / v_bcnt chain of mcs_match.hip issues for ~1700.
+// (tools/mfma_fp4_probe.hip pins the operand and result layout used here on the device.)
+//
+// Workgroup = 4 waves, 32 queries per wave (one query column per lane pair: lane = column + 32 * k-half).  The query operands stay in registers
+// (4 VGPRs per K step).  Train rows are staged like in mcs_match.hip (eligible rows only, compacted in order), then expanded bit -> nibble through a
+// 256-entry LDS table into the A-operand layout [tile of 32 rows][K step][lane] so that every wave's operand read is one conflict-free ds_read_b128.
+// The result registers of a lane are 16 train rows of its query: each becomes (total << 20 | index) — ct and the index ride in one word per row —
+// and goes through the same append / bitonic-merge list as mcs_match.hip.  The two lanes of a query merge their lists at the end.
+#include "mcs_common.h"
+
+namespace mcs {
+
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+
+constexpr int XT = 128;        // train rows compacted per outer step (64: 4 workgroups per CU by LDS, but only one wave loads rows — measured slower)
+constexpr int XQ = 128;        // queries per workgroup
+// Index word of a padding row and the cap on every limit: the f32 result of any staged row (real or stale bits, always 0 / +-1 operands) lies in
+// [-512, 768], so a padding row's word has a distance field in [0xA00, 0xF00] — never below the cap, never wrapping — and real totals (<= 512) are below it.
+constexpr uint32_t kPadWord = 0xC00FFFFFu, kLimCap = 0xA00u << 20;
+
+// bit k of the byte -> nibble k = 1
+__device__ __forceinline__ uint32_t spread8(uint32_t b) {
+	uint32_t v = b;
+	v = (v | (v << 12)) & 0x000F000Fu;
+	v = (v | (v << 6)) & 0x03030303u;
+	v = (v | (v << 3)) & 0x11111111u;
+	return v;
+}
+
+// 32 bits -> 32 FP4 values (4 dwords).  plain: bit -> +1.0;  signed: m & ~x -> +1.0, m & x -> -1.0, ~m -> 0
+__device__ __forceinline__ uint4 expand01(const uint32_t* lut, uint32_t x) {
+	uint4 o;
+	o.x = lut[x & 0xff] << 1; o.y = lut[(x >> 8) & 0xff] << 1; o.z = lut[(x >> 16) & 0xff] << 1; o.w = lut[x >> 24] << 1;
+	return o;
+}
+__device__ __forceinline__ uint4 expandpm(const uint32_t* lut, uint32_t m, uint32_t x) {
+	const uint32_t n = m & x;
+	uint4 o;
+	o.x = (lut[m & 0xff] << 1) | (lut[n & 0xff] << 3);
+	o.y = (lut[(m >> 8) & 0xff] << 1) | (lut[(n >> 8) & 0xff] << 3);
+	o.z = (lut[(m >> 16) & 0xff] << 1) | (lut[(n >> 16) & 0xff] << 3);
+	o.w = (lut[m >> 24] << 1) | (lut[n >> 24] << 3);
+	return o;
+}
+
+template <int K, int DW, bool MASKED>
+__global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
+	constexpr int HS = DW / 2;                       // K steps per segment (64 bits each)
+	constexpr int NS = (MASKED ? 2 : 1) * HS;        // K steps per pair
+	constexpr int CB = 16;                           // candidate column depth per lane
+	__shared__ __attribute__((aligned(16))) uint32_t tdT[DW * XT];                 // compacted train rows, transposed [dword][row]
+	__shared__ __attribute__((aligned(16))) uint32_t tmT[MASKED ? DW * XT : 4];
+	__shared__ __attribute__((aligned(16))) uint32_t wrow[XT + 64];               // (ct << 20) | original index;  kPadWord past the staged rows
+	// A operands of a stage (two 32-row tiles).  One buffer and a barrier more per stage: with two (expansion of stage g + 1 beside the arithmetic of
+	// stage g) the workgroup needs 60 KB and only two fit a CU — measured 18.4 ms against 14.2 ms per configs[2] step with three.
+	__shared__ __attribute__((aligned(16))) uint4 ex[2][NS][64];
+	__shared__ uint32_t lut[256];
+	__shared__ int wcnt[4];
+	__shared__ uint32_t cand[(CB + 1) * 256];
+	static_assert(K * XQ <= (CB + 1) * 256, "the final exchange of the two half lists re-uses the candidate columns");
+
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, kh = lane >> 5;
+	const int set = blockIdx.z, split = blockIdx.y;
+	const int qi = blockIdx.x * XQ + wv * 32 + col;
+	const RowMap QR{(size_t)(set % a.qmod) * a.qpitch, a.qblk, a.qbpitch}, TR{(size_t)((set / a.tdiv + a.toff) % a.tmod) * a.tpitch, a.tblk, a.tbpitch};
+	lut[tid] = spread8((uint32_t)tid);
+
+	bool qok = qi < a.nq;
+	if (qok && a.qvalid) qok = a.qvalid[QR(qi)] != 0;
+	// the query's operands: step s = segment * HS + j covers dwords 2j (k-half 0) and 2j + 1 (k-half 1) of the segment's bit vector
+	v8i_t bq[NS];
+	float cq = 0.f;
+	{
+		uint32_t q[DW], qm[DW];
+#pragma unroll
+		for (int w = 0; w < DW; ++w) { q[w] = 0; qm[w] = 0; }
+		if (qok) {
+			const uint32_t* qp = reinterpret_cast<const uint32_t*>(a.qd + QR(qi) * a.qstride);
+#pragma unroll
+			for (int w = 0; w < DW; ++w) q[w] = qp[w];
+			if (MASKED) {
+				const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.qm + QR(qi) * a.qstride);
+#pragma unroll
+				for (int w = 0; w < DW; ++w) qm[w] = mp[w];
+			}
+		}
+		int c = 0;
+#pragma unroll
+		for (int w = 0; w < DW; ++w) c += __popc(MASKED ? (q[w] & qm[w]) : q[w]);
+		cq = (float)c;
+		__syncthreads();   // lut
+#pragma unroll
+		for (int j = 0; j < HS; ++j) {
+			const uint32_t x = kh ? q[2 * j + 1] : q[2 * j], m = MASKED ? (kh ? qm[2 * j + 1] : qm[2 * j]) : 0xFFFFFFFFu;
+			const uint4 u = expandpm(lut, m, x);
+			bq[j] = v8i_t{(int)u.x, (int)u.y, (int)u.z, (int)u.w, 0, 0, 0, 0};
+			if (MASKED) {
+				const uint4 p = expand01(lut, x);
+				bq[HS + j] = v8i_t{(int)p.x, (int)p.y, (int)p.z, (int)p.w, 0, 0, 0, 0};
+			}
+		}
+	}
+	v16f_t cqv;   // cq enters as the accumulator's start value
+#pragma unroll
+	for (int r = 0; r < 16; ++r) cqv[r] = cq;
+
+	uint32_t best[K];
+#pragma unroll
+	for (int p = 0; p < K; ++p) best[p] = 0xFFFFFFFFu;
+	const uint32_t col0 = tid;
+	uint32_t next = col0;
+	auto exact_key = [](uint32_t w) { return MASKED ? (((w >> 21) << 20) | (w & 0xFFFFFu)) : w; };
+	auto bitonic_merge_best = [&]() {
+#pragma unroll
+		for (int j = K >> 1; j > 0; j >>= 1)
+#pragma unroll
+			for (int i = 0; i < K; ++i) {
+				const int l = i ^ j;
+				if (l > i) { const uint32_t lo = min(best[i], best[l]), hi = max(best[i], best[l]); best[i] = lo; best[l] = hi; }
+			}
+	};
+	auto flush = [&]() {   // as in mcs_match.hip
+		const int cnt = (int)((next - col0) >> 8);
+		if (K >= CB) {
+			uint32_t c[CB];
+#pragma unroll
+			for (int e = 0; e < CB; ++e) {
+				const uint32_t raw = cand[e * 256 + tid];
+				c[e] = e < cnt ? exact_key(raw) : 0xFFFFFFFFu;
+			}
+#pragma unroll
+			for (int k = 2; k <= CB; k <<= 1)
+#pragma unroll
+				for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+					for (int i = 0; i < CB; ++i) {
+						const int l = i ^ j;
+						if (l > i) {
+							const uint32_t lo = min(c[i], c[l]), hi = max(c[i], c[l]);
+							const bool up = (i & k) == 0;
+							c[i] = up ? lo : hi; c[l] = up ? hi : lo;
+						}
+					}
+#pragma unroll
+			for (int i = 0; i < CB; ++i) best[K - 1 - i] = min(best[K - 1 - i], c[i]);
+			bitonic_merge_best();
+		} else {
+			int m = cnt;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+			for (int e = 0; e < m; ++e) {
+				uint32_t key = e < cnt ? exact_key(cand[e * 256 + tid]) : 0xFFFFFFFFu;
+				if (__any(key < best[K - 1])) {
+#pragma unroll
+					for (int p = 0; p < K; ++p) { const uint32_t lo = min(best[p], key), hi = max(best[p], key); best[p] = lo; key = hi; }
+				}
+			}
+		}
+		next = col0;
+	};
+
+	const int per = ((a.nt + a.splits - 1) / a.splits + 63) / 64 * 64;
+	const int t0 = split * per, t1 = min(a.nt, t0 + per);
+	const uint32_t dCap = a.maxDist >= 4095 ? 4095u : (uint32_t)a.maxDist;
+	// the rows of a step are requested one step ahead (registers), so that their memory latency hides behind the previous step's arithmetic
+	uint32_t ptw[DW], pmw[DW];
+	bool pok = false;
+	auto request = [&](int base) {   // the row is requested whether or not it is eligible: its flag arrives with it instead of one memory round trip earlier
+		const int j = base + tid;
+		pok = false;
+		if (tid < XT && j < t1) {
+			const size_t row = TR(j);
+			const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.td + row * a.tstride);
+#pragma unroll
+			for (int w = 0; w < DW; ++w) ptw[w] = tp[w];
+			if (MASKED) {
+				const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.tm + row * a.tstride);
+#pragma unroll
+				for (int w = 0; w < DW; ++w) pmw[w] = mp[w];
+			}
+			pok = a.tvalid ? a.tvalid[row] != 0 : true;
+		}
+	};
+	request(t0);
+	for (int base = t0; base < t1; base += XT) {
+		// eligible rows of this step, compacted in order (ballot prefix); ct and the original index in one word per row
+		const int j = base + tid;
+		const bool ok = pok;
+		const unsigned long long bal = __ballot(ok);
+		if (lane == 0) wcnt[wv] = __popcll(bal);
+		__syncthreads();   // also: every wave is done with the previous step's rows
+		int pos = __popcll(bal & ((1ull << lane) - 1ull));
+		for (int w = 0; w < wv; ++w) pos += wcnt[w];
+		const int rows = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+		if (ok) {
+			int ct = 0;
+			if (MASKED) {
+#pragma unroll
+				for (int w = 0; w < DW; ++w) ct += __popc(pmw[w] & ptw[w]);
+			}
+#pragma unroll
+			for (int w = 0; w < DW; ++w) { tdT[w * XT + pos] = ptw[w]; if (MASKED) tmT[w * XT + pos] = pmw[w]; }
+			wrow[pos] = ((uint32_t)ct << 20) | (uint32_t)j;
+		}
+		if (tid < 64) wrow[rows + tid] = kPadWord;
+		if (base + XT < t1) request(base + XT);
+		__syncthreads();
+		const int nstage = (rows + 63) >> 6;
+		// expansion of stage g (64 rows) into ex: item = (row of the stage, segment, dword) -> the 16 bytes of lane (row & 31) + 32 * (dword & 1), step
+		// segment * HS + dword / 2, tile row >> 5.  Rows past `rows` expand stale data: their index word is kPadWord.
+		auto expand_stage = [&](int g) {
+			constexpr int items = 64 * (MASKED ? 2 : 1) * DW;
+#pragma unroll
+			for (int it = 0; it < items / 256; ++it) {
+				const int e = it * 256 + tid;
+				const int r = e & 63, q = e >> 6, seg = q / DW, dw = q - seg * DW;
+				const int src = (g << 6) + r;
+				const uint32_t x = tdT[dw * XT + src];
+				uint4 o;
+				if (MASKED) { const uint32_t m = tmT[dw * XT + src]; o = seg == 0 ? expand01(lut, x) : expandpm(lut, m, x); }
+				else o = expand01(lut, x);
+				ex[r >> 5][seg * HS + (dw >> 1)][(r & 31) + 32 * (dw & 1)] = o;
+			}
+		};
+		for (int g = 0; g < nstage; ++g) {
+			expand_stage(g);
+			__syncthreads();
+#pragma unroll
+			for (int tile = 0; tile < 2; ++tile) {
+				const int row0 = (g << 6) + (tile << 5);
+				if (row0 < rows) {
+					v16f_t acc = cqv;
+#pragma unroll
+					for (int s = 0; s < NS; ++s) {
+						const uint4 av = ex[tile][s][lane];
+						const v8i_t va{(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
+						acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, bq[s], acc, 4, 4, 0, 0, 0, 0);
+					}
+					// result register r = train row (r & 3) + 8 (r >> 2) + 4 * k-half of the tile, for this lane's query
+#pragma unroll
+					for (int half = 0; half < 2; ++half) {
+						uint32_t rawLim;
+						const uint32_t kth = best[K - 1];   // (also bounding by the other half list's K-th best: measured, no change)
+						if (MASKED) {
+							const uint32_t dl = min(kth >> 20, dCap);
+							rawLim = dl >= 1279u ? kLimCap : ((2u * dl + 2u) << 20);
+						} else rawLim = min(min(kth, dCap >= 4095u ? 0xFFFFFFFFu : ((dCap + 1u) << 20)), kLimCap);
+						if (!qok) rawLim = 0;
+#pragma unroll
+						for (int jj = 0; jj < 2; ++jj) {
+							const int j4 = 2 * half + jj;
+							const uint4 wv4 = *reinterpret_cast<const uint4*>(&wrow[row0 + 8 * j4 + 4 * kh]);
+							const uint32_t wr[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+#pragma unroll
+							for (int u = 0; u < 4; ++u) {
+								const uint32_t w = ((uint32_t)(int)acc[4 * j4 + u] << 20) + wr[u];
+								cand[next] = w;
+								next += w < rawLim ? 256u : 0u;
+							}
+						}
+						if (__any(next > col0 + (CB - 8) * 256)) flush();
+					}
+				}
+			}
+			__syncthreads();
+		}
+	}
+	flush();
+	// the two lanes of a query hold the K best of disjoint train rows: k-half 1 hands its list over, k-half 0 folds it in (the K smallest of two ascending
+	// lists are min(a[i], b[K-1-i]), a bitonic sequence) and stores
+	__syncthreads();
+	uint32_t* xch = cand;
+	if (kh == 1) {
+#pragma unroll
+		for (int p = 0; p < K; ++p) xch[p * XQ + wv * 32 + col] = best[p];
+	}
+	__syncthreads();
+	if (kh == 0) {
+#pragma unroll
+		for (int p = 0; p < K; ++p) best[p] = min(best[p], xch[(K - 1 - p) * XQ + wv * 32 + col]);
+		bitonic_merge_best();
+		if (qi < a.nq) {
+			uint32_t* dst = a.splits == 1 ? a.keys + (size_t)set * K * a.nq : a.partial + ((size_t)set * a.splits + split) * K * a.nq;
+#pragma unroll
+			for (int p = 0; p < K; ++p) dst[(size_t)p * a.nq + qi] = best[p];
+			if (a.splits == 1) a.outCount[(size_t)set * a.nq + qi] = 0;
+			else a.partialCount[((size_t)set * a.splits + split) * a.nq + qi] = 0;
+		}
+	}
+}
+
+template <int K, int DW>
+static void launch_mfma_kd(const MatchArgs& a, hipStream_t s) {
+	dim3 grid((a.nq + XQ - 1) / XQ, a.splits, a.nsets);
+	if (a.qm && a.tm) hipLaunchKernelGGL((k_match_mfma<K, DW, true>), grid, dim3(256), 0, s, a);
+	else hipLaunchKernelGGL((k_match_mfma<K, DW, false>), grid, dim3(256), 0, s, a);
+}
+
+template <int K>
+static void launch_mfma_k(const MatchArgs& a, hipStream_t s) {
+	if (a.dim == 16) launch_mfma_kd<K, 4>(a, s);
+	else launch_mfma_kd<K, 8>(a, s);
+}
+
+// the partial-list kernel of launch_match() for the shapes the matrix-core form serves: 16 / 32-byte descriptors, no count_le output, no camera groups
+bool match_mfma_serves(const MatchArgs& a) {
+	return (a.dim == 16 || a.dim == 32) && a.countThresh < 0 && !(a.qgroup && a.tgroup);
+}
+
+void launch_match_mfma(const MatchArgs& a, hipStream_t s) {
+	switch (a.K) {
+		case 1: launch_mfma_k<1>(a, s); break;
+		case 2: launch_mfma_k<2>(a, s); break;
+		case 4: launch_mfma_k<4>(a, s); break;
+		case 8: launch_mfma_k<8>(a, s); break;
+		case 16: launch_mfma_k<16>(a, s); break;
+		default: launch_mfma_k<32>(a, s); break;
+	}
+}
+
+}  // namespace mcs
