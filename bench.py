@@ -387,14 +387,21 @@ def roofline_block(sp, job, kern, feats_local, pairs_local):
     dom = max((k for k in alg if k in kern), key=lambda k: kern[k])
     ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
     traffic, valu = pmc_entry(sp.tag, dom)
-    kname = {"match": "k_match_partial", "describe": "k_describe" if sp.mode == "orb" else "k_describe_fast (descriptor stage: + k_orient_a, k_orient_b, k_describe_list)",
+    mfma = "match" in kern and job.lay.desc_size in (16, 32) and not os.environ.get("MCS_MATCH_VALU")   # launch_match(): no count_le, no camera groups here
+    kname = {"match": "k_match_mfma" if mfma else "k_match_partial", "describe": "k_describe" if sp.mode == "orb" else "k_describe_fast (descriptor stage: + k_orient_a, k_orient_b, k_describe_list)",
              "pyramid": "k_resize_level (x7)", "fast": "k_fast_cells (x3)", "blur": "k_blur"}[dom]
     out = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
            "frac": round(ach / 8000.0, 5), "traffic": traffic, "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kern[dom], 4),
            "per_kernel_ms": {k: round(v, 4) for k, v in kern.items()},
            "per_kernel_alg_GBps": {k: round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) for k in alg if k in kern and kern[k] > 0},
            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" if traffic else None,
-           "note": "no kernel of this path is HBM-bound (k_describe: FP64 at 16 lanes/clk; matcher: v_bitop3 / v_bcnt); the bound that applies is VALU issue, DESIGN.md §6"}
+           "note": "no kernel of this path is HBM-bound (descriptor stage: FP64 at 16 lanes/clk; matcher: FP4 MFMA dot products + a VALU-bound K-best selection); "
+                   "the bounds that apply are VALU issue and, for the matcher, the matrix cores: DESIGN.md §6"}
+    flop_pair = 2 * 8 * job.lay.desc_size * (2 if job.masks_on else 1)   # a pair distance = one dot product over K = 8 * bytes (x2 with masks), DESIGN.md §4c
+    if dom == "match" and mfma:   # the dominant kernel runs on the matrix cores: price it against the dense FP4 MFMA peak
+        tf = pairs_local * flop_pair / (kern[dom] * 1e-3) / 1e12
+        out.update({"bound": "mfma", "achieved": round(tf, 1), "peak": 10000.0, "unit": "TFLOP/s", "frac": round(tf / 10000.0, 4),
+                    "alg_flop_per_launch": int(pairs_local * flop_pair), "hbm_alg_GBps": round(ach, 2)})
     if valu:
         peak = 1024 * 2.4e9 / 4 / 1e9
         a = valu / (kern[dom] * 1e-3) / 1e9
@@ -404,8 +411,10 @@ def roofline_block(sp, job, kern, feats_local, pairs_local):
         cyc = (16 * 2.4 + 16 * 4.3) if job.masks_on else (8 * 2.4 + 8 * 4.3)
         ceiling = 1024 * 2.4e9 / cyc * 64
         pps = pairs_local / (kern["match"] * 1e-3)
-        out["matcher"] = {"pair_distances_per_launch": pairs_local, "Tpairs_per_s": round(pps / 1e12, 3), "valu_ceiling_Tpairs_per_s": round(ceiling / 1e12, 3),
-                          "frac": round(pps / ceiling, 3)}
+        out["matcher"] = {"kernel": "k_match_mfma" if mfma else "k_match_partial", "pair_distances_per_launch": pairs_local, "Tpairs_per_s": round(pps / 1e12, 3),
+                          "valu_kernel_ceiling_Tpairs_per_s": round(ceiling / 1e12, 3), "vs_valu_kernel_ceiling": round(pps / ceiling, 3)}
+        if mfma:
+            out["matcher"].update({"mfma_ceiling_Tpairs_per_s": round(1e16 / flop_pair / 1e12, 2), "mfma_frac": round(pps * flop_pair / 1e16, 4)})
     return out
 
 

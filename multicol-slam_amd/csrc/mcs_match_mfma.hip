@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 					}
 					// result register r = train row (r & 3) + 8 (r >> 2) + 4 * k-half of the tile, for this lane's query
 #pragma unroll
-					for (int half = 0; half < 2; ++half) {
+					for (int j4 = 0; j4 < 4; ++j4) {   // four rows at a time: a column has room for 16, so a merge is due once a lane holds more than 12
 						uint32_t rawLim;
 						const uint32_t kth = best[K - 1];   // (also bounding by the other half list's K-th best: measured, no change)
 						if (MASKED) {
@@ -255,19 +255,15 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 							rawLim = dl >= 1279u ? kLimCap : ((2u * dl + 2u) << 20);
 						} else rawLim = min(min(kth, dCap >= 4095u ? 0xFFFFFFFFu : ((dCap + 1u) << 20)), kLimCap);
 						if (!qok) rawLim = 0;
+						const uint4 wv4 = *reinterpret_cast<const uint4*>(&wrow[row0 + 8 * j4 + 4 * kh]);
+						const uint32_t wr[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
 #pragma unroll
-						for (int jj = 0; jj < 2; ++jj) {
-							const int j4 = 2 * half + jj;
-							const uint4 wv4 = *reinterpret_cast<const uint4*>(&wrow[row0 + 8 * j4 + 4 * kh]);
-							const uint32_t wr[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
-#pragma unroll
-							for (int u = 0; u < 4; ++u) {
-								const uint32_t w = ((uint32_t)(int)acc[4 * j4 + u] << 20) + wr[u];
-								cand[next] = w;
-								next += w < rawLim ? 256u : 0u;
-							}
+						for (int u = 0; u < 4; ++u) {
+							const uint32_t w = ((uint32_t)(int)acc[4 * j4 + u] << 20) + wr[u];
+							cand[next] = w;
+							next += w < rawLim ? 256u : 0u;
 						}
-						if (__any(next > col0 + (CB - 8) * 256)) flush();
+						if (__any(next > col0 + (CB - 4) * 256)) flush();
 					}
 				}
 			}
