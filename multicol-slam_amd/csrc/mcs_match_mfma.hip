@@ -9,11 +9,14 @@
 // is K = 512: 8 instructions (256 cycles) per 1024 pairs, where the v_xor / v_and / v_bcnt chain of mcs_match.hip issues for ~1700.
 // (tools/mfma_fp4_probe.hip pins the operand and result layout used here on the device.)
 //
-// Workgroup = 4 waves, 32 queries per wave (one query column per lane pair: lane = column + 32 * k-half).  The query operands stay in registers
-// (4 VGPRs per K step).  Train rows are staged like in mcs_match.hip (eligible rows only, compacted in order), then expanded bit -> nibble through a
-// 256-entry LDS table into the A-operand layout [tile of 32 rows][K step][lane] so that every wave's operand read is one conflict-free ds_read_b128.
-// The result registers of a lane are 16 train rows of its query: each becomes (total << 20 | index) — ct and the index ride in one word per row —
-// and goes through the same append / bitonic-merge list as mcs_match.hip.  The two lanes of a query merge their lists at the end.
+// Workgroup = 4 waves, 64 queries per wave as two 32-column operand sets (B operand lane = column + 32 * k-half; 4 VGPRs per K step and set, in
+// registers for the whole kernel).  Train rows are staged like in mcs_match.hip (eligible rows only, compacted in order), then expanded bit -> nibble
+// through a 256-entry LDS table into the A-operand layout [tile of 32 rows][K step][lane] so that every wave's operand read is one conflict-free
+// ds_read_b128, used for both query sets.  An MFMA result puts 16 of a column's 32 rows in lane c and the other 16 in lane c + 32; one
+// v_permlane32_swap per register between the two sets' results leaves lane c with all 32 rows of query c of the first set and lane c + 32 with all 32
+// rows of query c of the second: ONE query per lane, so its K-best list sees every train row (two half lists per query appended 1.7x as many
+// candidates, and merged as often).  A result becomes (total << 20 | index) — ct and the index ride in one word per row — and goes through the same
+// append / bitonic-merge list as mcs_match.hip.
 #include "mcs_common.h"
 
 namespace mcs {
@@ -22,10 +25,12 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 
 constexpr int XT = 128;        // train rows compacted per outer step (64: 4 workgroups per CU by LDS, but only one wave loads rows — measured slower)
-constexpr int XQ = 128;        // queries per workgroup
-// Index word of a padding row and the cap on every limit: the f32 result of any staged row (real or stale bits, always 0 / +-1 operands) lies in
-// [-512, 768], so a padding row's word has a distance field in [0xA00, 0xF00] — never below the cap, never wrapping — and real totals (<= 512) are below it.
-constexpr uint32_t kPadWord = 0xC00FFFFFu, kLimCap = 0xA00u << 20;
+constexpr int XQ = 256;        // queries per workgroup
+// Words in the candidate columns are BIASED: (dot + ct + 256) << 20 | index, i.e. the total minus the query's own cq (<= 256) plus 256 — never negative —
+// so that cq costs nothing per pair: it is subtracted from the limit once per group and added back when a column is merged.  The f32 dot product of any
+// staged row (real or stale bits, always 0 / +-1 operands) lies in [-512, 512], so a padding row's word (index word kPadWord) has a distance field in
+// [0xA00, 0xE00]: never below a biased limit (<= kLimCap + 256 << 20 = 0xA00 << 20), never wrapping; real totals (<= 512) stay below kLimCap.
+constexpr uint32_t kPadWord = 0xC00FFFFFu, kLimCap = 0x900u << 20, kBias = 256u << 20;
 
 // bit k of the byte -> nibble k = 1
 __device__ __forceinline__ uint32_t spread8(uint32_t b) {
@@ -52,7 +57,10 @@ __device__ __forceinline__ uint4 expandpm(const uint32_t* lut, uint32_t m, uint3
 	return o;
 }
 
+// Three waves per SIMD (168 registers; the LDS allows three workgroups per CU): left alone the compiler takes 228 registers for K = 32 and two waves —
+// with ~30 spilled dwords the three-wave build is 17 % faster on the configs[2] sweep (13.4 -> 11.4 ms).
 template <int K, int DW, bool MASKED>
+__attribute__((amdgpu_waves_per_eu(3, 3)))
 __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 	constexpr int HS = DW / 2;                       // K steps per segment (64 bits each)
 	constexpr int NS = (MASKED ? 2 : 1) * HS;        // K steps per pair
@@ -66,29 +74,34 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 	__shared__ uint32_t lut[256];
 	__shared__ int wcnt[4];
 	__shared__ uint32_t cand[(CB + 1) * 256];
-	static_assert(K * XQ <= (CB + 1) * 256, "the final exchange of the two half lists re-uses the candidate columns");
 
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, kh = lane >> 5;
 	const int set = blockIdx.z, split = blockIdx.y;
-	const int qi = blockIdx.x * XQ + wv * 32 + col;
+	const int qbase = blockIdx.x * XQ + wv * 64;
+	const int qi = qbase + lane;   // the query this lane OWNS after the half swap (set 0: lanes 0..31, set 1: lanes 32..63)
 	const RowMap QR{(size_t)(set % a.qmod) * a.qpitch, a.qblk, a.qbpitch}, TR{(size_t)((set / a.tdiv + a.toff) % a.tmod) * a.tpitch, a.tblk, a.tbpitch};
 	lut[tid] = spread8((uint32_t)tid);
+	__syncthreads();
 
-	bool qok = qi < a.nq;
-	if (qok && a.qvalid) qok = a.qvalid[QR(qi)] != 0;
-	// the query's operands: step s = segment * HS + j covers dwords 2j (k-half 0) and 2j + 1 (k-half 1) of the segment's bit vector
-	v8i_t bq[NS];
-	float cq = 0.f;
-	{
+	// the operands of query (set u, column col): step s = segment * HS + j covers dwords 2j (k-half 0) and 2j + 1 (k-half 1) of the segment's bit vector
+	v8i_t bq[2][NS];
+	uint32_t cq20 = 0;   // popc(mq & q) << 20 of the lane's OWN query (k-half = set)
+	bool qok = false;
+#pragma unroll
+	for (int u = 0; u < 2; ++u) {
+		const int qu = qbase + 32 * u + col;
+		bool ok = qu < a.nq;
+		if (ok && a.qvalid) ok = a.qvalid[QR(qu)] != 0;
+		if (u == kh) qok = ok;
 		uint32_t q[DW], qm[DW];
 #pragma unroll
 		for (int w = 0; w < DW; ++w) { q[w] = 0; qm[w] = 0; }
-		if (qok) {
-			const uint32_t* qp = reinterpret_cast<const uint32_t*>(a.qd + QR(qi) * a.qstride);
+		if (ok) {
+			const uint32_t* qp = reinterpret_cast<const uint32_t*>(a.qd + QR(qu) * a.qstride);
 #pragma unroll
 			for (int w = 0; w < DW; ++w) q[w] = qp[w];
 			if (MASKED) {
-				const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.qm + QR(qi) * a.qstride);
+				const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.qm + QR(qu) * a.qstride);
 #pragma unroll
 				for (int w = 0; w < DW; ++w) qm[w] = mp[w];
 			}
@@ -96,29 +109,25 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 		int c = 0;
 #pragma unroll
 		for (int w = 0; w < DW; ++w) c += __popc(MASKED ? (q[w] & qm[w]) : q[w]);
-		cq = (float)c;
-		__syncthreads();   // lut
+		if (u == kh) cq20 = (uint32_t)c << 20;
 #pragma unroll
 		for (int j = 0; j < HS; ++j) {
 			const uint32_t x = kh ? q[2 * j + 1] : q[2 * j], m = MASKED ? (kh ? qm[2 * j + 1] : qm[2 * j]) : 0xFFFFFFFFu;
-			const uint4 u = expandpm(lut, m, x);
-			bq[j] = v8i_t{(int)u.x, (int)u.y, (int)u.z, (int)u.w, 0, 0, 0, 0};
+			const uint4 e = expandpm(lut, m, x);
+			bq[u][j] = v8i_t{(int)e.x, (int)e.y, (int)e.z, (int)e.w, 0, 0, 0, 0};
 			if (MASKED) {
 				const uint4 p = expand01(lut, x);
-				bq[HS + j] = v8i_t{(int)p.x, (int)p.y, (int)p.z, (int)p.w, 0, 0, 0, 0};
+				bq[u][HS + j] = v8i_t{(int)p.x, (int)p.y, (int)p.z, (int)p.w, 0, 0, 0, 0};
 			}
 		}
 	}
-	v16f_t cqv;   // cq enters as the accumulator's start value
-#pragma unroll
-	for (int r = 0; r < 16; ++r) cqv[r] = cq;
 
 	uint32_t best[K];
 #pragma unroll
 	for (int p = 0; p < K; ++p) best[p] = 0xFFFFFFFFu;
 	const uint32_t col0 = tid;
 	uint32_t next = col0;
-	auto exact_key = [](uint32_t w) { return MASKED ? (((w >> 21) << 20) | (w & 0xFFFFFu)) : w; };
+	auto exact_key = [&](uint32_t wb) { const uint32_t w = wb - kBias + cq20; return MASKED ? (((w >> 21) << 20) | (w & 0xFFFFFu)) : w; };   // un-bias, then as in mcs_match.hip
 	auto bitonic_merge_best = [&]() {
 #pragma unroll
 		for (int j = K >> 1; j > 0; j >>= 1)
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 			}
 #pragma unroll
 			for (int w = 0; w < DW; ++w) { tdT[w * XT + pos] = ptw[w]; if (MASKED) tmT[w * XT + pos] = pmw[w]; }
-			wrow[pos] = ((uint32_t)ct << 20) | (uint32_t)j;
+			wrow[pos] = (((uint32_t)ct << 20) | (uint32_t)j) + kBias;
 		}
 		if (tid < 64) wrow[rows + tid] = kPadWord;
 		if (base + XT < t1) request(base + XT);
@@ -238,32 +247,44 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 			for (int tile = 0; tile < 2; ++tile) {
 				const int row0 = (g << 6) + (tile << 5);
 				if (row0 < rows) {
-					v16f_t acc = cqv;
+					v16f_t acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
 					for (int s = 0; s < NS; ++s) {
 						const uint4 av = ex[tile][s][lane];
 						const v8i_t va{(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
-						acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, bq[s], acc, 4, 4, 0, 0, 0, 0);
+						acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, bq[0][s], acc0, 4, 4, 0, 0, 0, 0);
+						acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, bq[1][s], acc1, 4, 4, 0, 0, 0, 0);
 					}
-					// result register r = train row (r & 3) + 8 (r >> 2) + 4 * k-half of the tile, for this lane's query
+					// result register r of a lane = train row (r & 3) + 8 (r >> 2) + 4 * k-half of the tile, for column (lane & 31) of its set.  The swap
+					// exchanges the upper half of set 0's register with the lower half of set 1's: afterwards lo[r] is row (r & 3) + 8 (r >> 2) and
+					// hi[r] row (r & 3) + 8 (r >> 2) + 4 of the lane's OWN query, in every lane
 #pragma unroll
-					for (int j4 = 0; j4 < 4; ++j4) {   // four rows at a time: a column has room for 16, so a merge is due once a lane holds more than 12
-						uint32_t rawLim;
-						const uint32_t kth = best[K - 1];   // (also bounding by the other half list's K-th best: measured, no change)
-						if (MASKED) {
-							const uint32_t dl = min(kth >> 20, dCap);
-							rawLim = dl >= 1279u ? kLimCap : ((2u * dl + 2u) << 20);
-						} else rawLim = min(min(kth, dCap >= 4095u ? 0xFFFFFFFFu : ((dCap + 1u) << 20)), kLimCap);
-						if (!qok) rawLim = 0;
-						const uint4 wv4 = *reinterpret_cast<const uint4*>(&wrow[row0 + 8 * j4 + 4 * kh]);
-						const uint32_t wr[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+					for (int jp = 0; jp < 4; ++jp) {
+						int lo[4], hi[4];
 #pragma unroll
 						for (int u = 0; u < 4; ++u) {
-							const uint32_t w = ((uint32_t)(int)acc[4 * j4 + u] << 20) + wr[u];
-							cand[next] = w;
-							next += w < rawLim ? 256u : 0u;
+							const auto sw = __builtin_amdgcn_permlane32_swap((int)acc0[4 * jp + u], (int)acc1[4 * jp + u], false, false);
+							lo[u] = sw[0]; hi[u] = sw[1];
 						}
-						if (__any(next > col0 + (CB - 4) * 256)) flush();
+#pragma unroll
+						for (int h = 0; h < 2; ++h) {   // four rows at a time: a column has room for 16, so a merge is due once a lane holds more than 12
+							uint32_t rawLim;
+							const uint32_t kth = best[K - 1];
+							if (MASKED) {
+								const uint32_t dl = min(kth >> 20, dCap);
+								rawLim = dl >= 1151u ? kLimCap : ((2u * dl + 2u) << 20);
+							} else rawLim = min(min(kth, dCap >= 4095u ? 0xFFFFFFFFu : ((dCap + 1u) << 20)), kLimCap);
+							rawLim = qok ? rawLim + kBias - cq20 : 0u;   // the biased words carry total - cq + 256
+							const uint4 wv4 = *reinterpret_cast<const uint4*>(&wrow[row0 + 8 * jp + 4 * h]);   // rows 8 jp + 4 h ..+3: the same address in every lane
+							const uint32_t wr[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+#pragma unroll
+							for (int u = 0; u < 4; ++u) {
+								const uint32_t w = ((uint32_t)(h ? hi[u] : lo[u]) << 20) + wr[u];
+								cand[next] = w;
+								next += w < rawLim ? 256u : 0u;
+							}
+							if (__any(next > col0 + (CB - 4) * 256)) flush();
+						}
 					}
 				}
 			}
@@ -271,26 +292,13 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 		}
 	}
 	flush();
-	// the two lanes of a query hold the K best of disjoint train rows: k-half 1 hands its list over, k-half 0 folds it in (the K smallest of two ascending
-	// lists are min(a[i], b[K-1-i]), a bitonic sequence) and stores
-	__syncthreads();
-	uint32_t* xch = cand;
-	if (kh == 1) {
+	if (qi < a.nq) {
+		// splits == 1: these are the final lists; otherwise a partial list per split
+		uint32_t* dst = a.splits == 1 ? a.keys + (size_t)set * K * a.nq : a.partial + ((size_t)set * a.splits + split) * K * a.nq;
 #pragma unroll
-		for (int p = 0; p < K; ++p) xch[p * XQ + wv * 32 + col] = best[p];
-	}
-	__syncthreads();
-	if (kh == 0) {
-#pragma unroll
-		for (int p = 0; p < K; ++p) best[p] = min(best[p], xch[(K - 1 - p) * XQ + wv * 32 + col]);
-		bitonic_merge_best();
-		if (qi < a.nq) {
-			uint32_t* dst = a.splits == 1 ? a.keys + (size_t)set * K * a.nq : a.partial + ((size_t)set * a.splits + split) * K * a.nq;
-#pragma unroll
-			for (int p = 0; p < K; ++p) dst[(size_t)p * a.nq + qi] = best[p];
-			if (a.splits == 1) a.outCount[(size_t)set * a.nq + qi] = 0;
-			else a.partialCount[((size_t)set * a.splits + split) * a.nq + qi] = 0;
-		}
+		for (int p = 0; p < K; ++p) dst[(size_t)p * a.nq + qi] = best[p];
+		if (a.splits == 1) a.outCount[(size_t)set * a.nq + qi] = 0;
+		else a.partialCount[((size_t)set * a.splits + split) * a.nq + qi] = 0;
 	}
 }
 
