@@ -180,6 +180,18 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 	const int per = ((a.nt + a.splits - 1) / a.splits + 63) / 64 * 64;
 	const int t0 = split * per, t1 = min(a.nt, t0 + per);
 	const uint32_t dCap = a.maxDist >= 4095 ? 4095u : (uint32_t)a.maxDist;
+	// The distance threshold, the padding rows and "closer than the K-th best" are ONE unsigned compare of the biased word against rawLim (masked: the raw
+	// total t stands for distance t >> 1, so "distance <= D" is t <= 2D + 1).  The K-th best only changes in a merge: the limit is recomputed there.
+	auto limit = [&]() -> uint32_t {
+		uint32_t lim;
+		const uint32_t kth = best[K - 1];
+		if (MASKED) {
+			const uint32_t dl = min(kth >> 20, dCap);
+			lim = dl >= 1151u ? kLimCap : ((2u * dl + 2u) << 20);
+		} else lim = min(min(kth, dCap >= 4095u ? 0xFFFFFFFFu : ((dCap + 1u) << 20)), kLimCap);
+		return qok ? lim + kBias - cq20 : 0u;   // the biased words carry total - cq + 256
+	};
+	uint32_t rawLim = limit();
 	// the rows of a step are requested one step ahead (registers), so that their memory latency hides behind the previous step's arithmetic
 	uint32_t ptw[DW], pmw[DW];
 	bool pok = false;
@@ -268,13 +280,6 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 						}
 #pragma unroll
 						for (int h = 0; h < 2; ++h) {   // four rows at a time: a column has room for 16, so a merge is due once a lane holds more than 12
-							uint32_t rawLim;
-							const uint32_t kth = best[K - 1];
-							if (MASKED) {
-								const uint32_t dl = min(kth >> 20, dCap);
-								rawLim = dl >= 1151u ? kLimCap : ((2u * dl + 2u) << 20);
-							} else rawLim = min(min(kth, dCap >= 4095u ? 0xFFFFFFFFu : ((dCap + 1u) << 20)), kLimCap);
-							rawLim = qok ? rawLim + kBias - cq20 : 0u;   // the biased words carry total - cq + 256
 							const uint4 wv4 = *reinterpret_cast<const uint4*>(&wrow[row0 + 8 * jp + 4 * h]);   // rows 8 jp + 4 h ..+3: the same address in every lane
 							const uint32_t wr[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
 #pragma unroll
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 								cand[next] = w;
 								next += w < rawLim ? 256u : 0u;
 							}
-							if (__any(next > col0 + (CB - 4) * 256)) flush();
+							if (__any(next > col0 + (CB - 4) * 256)) { flush(); rawLim = limit(); }
 						}
 					}
 				}
