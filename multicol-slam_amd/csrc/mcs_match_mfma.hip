@@ -192,48 +192,46 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 		return qok ? lim + kBias - cq20 : 0u;   // the biased words carry total - cq + 256
 	};
 	uint32_t rawLim = limit();
-	// the rows of a step are requested one step ahead (registers), so that their memory latency hides behind the previous step's arithmetic
-	uint32_t ptw[DW], pmw[DW];
-	bool pok = false;
-	auto request = [&](int base) {   // the row is requested whether or not it is eligible: its flag arrives with it instead of one memory round trip earlier
+	for (int base = t0; base < t1; base += XT) {
+		// The rows of this step: row and flag are requested together (one memory round trip), parked in LDS as they come (the operand buffer is free between
+		// stages), then the eligible ones are compacted in order (ballot prefix) — holding 16 row dwords in registers across the prefix and its barrier
+		// spilled them.  ct and the original index go into one word per row.
+		uint32_t* park = reinterpret_cast<uint32_t*>(&ex[0][0][0]);   // [2 * DW][XT] dwords
 		const int j = base + tid;
-		pok = false;
+		bool ok = false;
+		uint32_t word = 0;
 		if (tid < XT && j < t1) {
 			const size_t row = TR(j);
 			const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.td + row * a.tstride);
+			uint32_t tw[DW], mw[DW];
 #pragma unroll
-			for (int w = 0; w < DW; ++w) ptw[w] = tp[w];
+			for (int w = 0; w < DW; ++w) tw[w] = tp[w];
 			if (MASKED) {
 				const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.tm + row * a.tstride);
 #pragma unroll
-				for (int w = 0; w < DW; ++w) pmw[w] = mp[w];
+				for (int w = 0; w < DW; ++w) mw[w] = mp[w];
 			}
-			pok = a.tvalid ? a.tvalid[row] != 0 : true;
+			ok = a.tvalid ? a.tvalid[row] != 0 : true;
+			int ct = 0;
+#pragma unroll
+			for (int w = 0; w < DW; ++w) {
+				park[w * XT + tid] = tw[w];
+				if (MASKED) { park[(DW + w) * XT + tid] = mw[w]; ct += __popc(mw[w] & tw[w]); }
+			}
+			word = (((uint32_t)ct << 20) | (uint32_t)j) + kBias;
 		}
-	};
-	request(t0);
-	for (int base = t0; base < t1; base += XT) {
-		// eligible rows of this step, compacted in order (ballot prefix); ct and the original index in one word per row
-		const int j = base + tid;
-		const bool ok = pok;
 		const unsigned long long bal = __ballot(ok);
 		if (lane == 0) wcnt[wv] = __popcll(bal);
-		__syncthreads();   // also: every wave is done with the previous step's rows
+		__syncthreads();
 		int pos = __popcll(bal & ((1ull << lane) - 1ull));
 		for (int w = 0; w < wv; ++w) pos += wcnt[w];
 		const int rows = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 		if (ok) {
-			int ct = 0;
-			if (MASKED) {
 #pragma unroll
-				for (int w = 0; w < DW; ++w) ct += __popc(pmw[w] & ptw[w]);
-			}
-#pragma unroll
-			for (int w = 0; w < DW; ++w) { tdT[w * XT + pos] = ptw[w]; if (MASKED) tmT[w * XT + pos] = pmw[w]; }
-			wrow[pos] = (((uint32_t)ct << 20) | (uint32_t)j) + kBias;
+			for (int w = 0; w < DW; ++w) { tdT[w * XT + pos] = park[w * XT + tid]; if (MASKED) tmT[w * XT + pos] = park[(DW + w) * XT + tid]; }
+			wrow[pos] = word;
 		}
 		if (tid < 64) wrow[rows + tid] = kPadWord;
-		if (base + XT < t1) request(base + XT);
 		__syncthreads();
 		const int nstage = (rows + 63) >> 6;
 		// expansion of stage g (64 rows) into ex: item = (row of the stage, segment, dword) -> the 16 bytes of lane (row & 31) + 32 * (dword & 1), step
