@@ -14,16 +14,22 @@
 // Candidate record: x | y<<12 | score<<24 with x,y relative to minBorder (22), like vToDistributeKeys.
 #include "mcs_common.h"
 
+#include <algorithm>
+
 namespace mcs {
 
-constexpr int kTilePitch = 68;   // >= wCell_max(60) + 6, multiple of 4
-constexpr int kTileRows = 66;
-constexpr int kScPitch = 64;     // >= wCell_max + 2
-constexpr int kScRows = 62;
+// LDS geometry for cells of at most CW x CW processed pixels (the level's wCell / hCell): tile = cell + 3-px ring, score tile = cell + 1-px zero frame.
+// Two instances: CW = 36 (6.5 KB per workgroup: every level with five or more cell columns — all but the smallest levels) and CW = 60 (any cell).
+template <int CW> struct FastGeom {
+	static constexpr int kTilePitch = (CW + 6 + 3) / 4 * 4, kTileRows = CW + 6;
+	static constexpr int kScPitch = (CW + 2 + 3) / 4 * 4, kScRows = CW + 2;
+	static constexpr int kBitWords = (CW * CW + 63) / 64 * 2, kGroups = (CW * CW + 63) / 64;
+};
 
 // Necessary condition for a 9-of-16 arc: it covers at least two ADJACENT compass points (k = 0, 4, 8, 12), so two
 // adjacent compass pixels must both be darker (d > t) or both be brighter (d < -t) than the centre.  Stricter than
 // cv::FAST's opposite-pair test and never rejects a corner.
+template <int kTilePitch>
 __device__ __forceinline__ bool fast_quick(const uint8_t* c, int t) {
 	const int v = c[0];
 	const int d0 = v - c[3 * kTilePitch], d8 = v - c[-3 * kTilePitch], d4 = v - c[3], d12 = v - c[-3];
@@ -32,6 +38,7 @@ __device__ __forceinline__ bool fast_quick(const uint8_t* c, int t) {
 	return (h0 & h4) | (h4 & h8) | (h8 & h12) | (h12 & h0) | (l0 & l4) | (l4 & l8) | (l8 & l12) | (l12 & l0);
 }
 
+template <int kTilePitch>
 __device__ __forceinline__ int fast_score(const uint8_t* c /* centre in LDS tile */, int t) {
 	const int v = c[0];
 	int d[16];
@@ -68,18 +75,17 @@ __device__ __forceinline__ int fast_score(const uint8_t* c /* centre in LDS tile
 	return best > t ? best - 1 : 0;
 }
 
-#ifndef MCS_FAST_BS
-#define MCS_FAST_BS 256   // threads per cell workgroup (A/B: 128, 256, 512)
-#endif
-constexpr int kFastBS = MCS_FAST_BS;
+template <int CW, int kFastBS>
 __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd, int cell0, int ncells) {
+	typedef FastGeom<CW> Geo;
+	constexpr int kTilePitch = Geo::kTilePitch, kTileRows = Geo::kTileRows, kScPitch = Geo::kScPitch, kScRows = Geo::kScRows;
 	__shared__ __attribute__((aligned(16))) uint8_t tile[kTileRows * kTilePitch];
 	__shared__ __attribute__((aligned(16))) uint8_t sc[kScRows * kScPitch];
-	__shared__ uint32_t keepBits[128];   // NMS + mask verdict per pixel of the cell (row-major bit index), 60*60 <= 4096 bits
+	__shared__ uint32_t keepBits[Geo::kBitWords];   // NMS + mask verdict per pixel of the cell (row-major bit index)
 	__shared__ int groupOff[64];         // exclusive prefix of the kept-pixel counts per 64-pixel group
 	__shared__ int runBase;
 	__shared__ int nSurv;
-	__shared__ unsigned short surv[60 * 60];   // pixel indices that pass the compass test (cell processed region <= 60x60)
+	__shared__ unsigned short surv[CW * CW];   // pixel indices that pass the compass test
 
 	// XCD-aware mapping: hardware places block i on XCD i%8; give every XCD a contiguous run of cells so that the
 	// overlapping cell rings / shared cache lines of neighbouring cells hit the same L2.
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	}
 	const int sw = cw + 2, sh = ch + 2;
 	for (int i = tid; i < sh * (kScPitch / 4); i += kFastBS) reinterpret_cast<uint32_t*>(sc)[i] = 0;   // score tile cleared as dwords
-	for (int i = tid; i < 128; i += kFastBS) keepBits[i] = 0;
+	for (int i = tid; i < Geo::kBitWords; i += kFastBS) keepBits[i] = 0;
 	if (tid == 0) { runBase = 0; nSurv = 0; }
 	__syncthreads();
 
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 		bool pass = false;
 		if (p < npx) {
 			const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
-			pass = fast_quick(&tile[(py + 3) * kTilePitch + px + 3], t);
+			pass = fast_quick<kTilePitch>(&tile[(py + 3) * kTilePitch + px + 3], t);
 		}
 		const unsigned long long bal = __ballot(pass);
 		int wbase = 0;
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	for (int i = tid; i < ns; i += kFastBS) {
 		const int p = surv[i];
 		const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
-		sc[(py + 1) * kScPitch + px + 1] = (uint8_t)fast_score(&tile[(py + 3) * kTilePitch + px + 3], t);
+		sc[(py + 1) * kScPitch + px + 1] = (uint8_t)fast_score<kTilePitch>(&tile[(py + 3) * kTilePitch + px + 3], t);
 	}
 	__syncthreads();
 
@@ -211,7 +217,13 @@ void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream
 	const int nblocks = nimg * ncells;
 	if (nblocks <= 0) return;
 	const int perXcd = (nblocks + kNumXCD - 1) / kNumXCD;
-	hipLaunchKernelGGL(k_fast_cells, dim3(perXcd * kNumXCD), dim3(kFastBS), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);
+	int cellMax = 0;
+	for (int l = level0; l < level1; ++l) cellMax = std::max(cellMax, std::max(hd.lv[l].wCell, hd.lv[l].hCell));
+#ifndef MCS_FAST_BS_SMALL
+#define MCS_FAST_BS_SMALL 64
+#endif
+	if (cellMax <= 36) hipLaunchKernelGGL((k_fast_cells<36, MCS_FAST_BS_SMALL>), dim3(perXcd * kNumXCD), dim3(MCS_FAST_BS_SMALL), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);
+	else hipLaunchKernelGGL((k_fast_cells<60, 256>), dim3(perXcd * kNumXCD), dim3(256), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);
 }
 
 }  // namespace mcs
