@@ -95,6 +95,19 @@ def test_no_mask_and_odd_sizes(G):
     ex.close()
 
 
+def test_small_levels_with_cells_wider_than_40_px(G):
+    """400x300, 8 levels: level 6 is 134x100, one cell row of 56 px — the FAST launch of levels 2.. takes the 60x60 LDS instance (four waves per cell)
+    instead of the 40x40 one the usual level sizes get (csrc/mcs_fast.hip)"""
+    cam = G.synth.scaled_camera(G.cams3()[1], 400, 300)
+    img, mask = G.synth.synth_image(3, 1, cam), G.synth.mirror_mask(cam)
+    ex = G.mcs.Extractor(G.ctx(), 400, 300, max_batch=1, nfeatures=600, nlevels=8, do_dBrief=1, learnMasks=1)
+    (gk, gd, gm, gr), = ex.extract_host([img], [mask], [G.mcs.make_ocam(cam)])
+    _, kps, d, dm, rays = G.oracle_extract(img, mask, cam, nfeatures=600, nlevels=8, do_dBrief=1, learnMasks=1)
+    assert len(kps) > 100
+    assert G.first_diff(gk, kps) is None and G.first_diff(gd, d) is None and G.first_diff(gm, dm) is None and G.first_diff(gr, rays) is None
+    ex.close()
+
+
 def test_empty_image_gives_no_keypoints(G):
     ex = G.mcs.Extractor(G.ctx(), 754, 480, max_batch=1)
     res = ex.extract_host([np.zeros((480, 754), np.uint8)], None, None, want_rays=False)
