@@ -62,6 +62,30 @@ __global__ __launch_bounds__(256) void k(double* out, int iters) {
 #pragma unroll
 				for (int j = 0; j < 8; ++j) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[j]) : "v"(u[(j + 1) & 7]), "v"(u[(j + 2) & 7]));
 			}
+			if (MODE == 16) {                                                                                                 // 8 independent v_mul_lo_u32
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 17) {                                                                                                 // 8 independent v_mul_u32_u24
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 18) {                                                                                                 // 8 independent v_mad_u32_u24
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(u[j]) : "v"(u[(j + 1) & 7]), "v"(u[(j + 2) & 7]));
+			}
+			if (MODE == 19) {                                                                                                 // 8 independent v_pk_min_i16
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 20) {                                                                                                 // 8 independent v_min_i32
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_min_i32 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 21) {                                                                                                 // 8 independent v_mad_u64_u32 (64-bit address arithmetic)
+#pragma unroll
+				for (int j = 0; j < 4; ++j) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(f[j]) : "v"(f[(j + 1) & 3]));
+			}
 			if (MODE == 8) {                                                                                                  // 8 independent FP64 mul
 #pragma unroll
 				for (int j = 0; j < 8; ++j) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(f[j]) : "v"(c));
@@ -110,5 +134,11 @@ int main() {
 	run<12>("8 independent v_rndne_f64", 8, d);
 	run<13>("8 independent v_rsq_f64", 8, d);
 	run<14>("8 independent v_cvt_i32_f64", 8, d);
+	run<16>("8 independent v_mul_lo_u32", 8, d);
+	run<17>("8 independent v_mul_u32_u24", 8, d);
+	run<18>("8 independent v_mad_u32_u24", 8, d);
+	run<19>("8 independent v_pk_min_i16", 8, d);
+	run<20>("8 independent v_min_i32", 8, d);
+	run<21>("4 independent v_lshl_add_u64", 4, d);
 	return 0;
 }
