@@ -34,7 +34,7 @@ import numpy as np  # noqa: E402
 
 MODES = {"orb": (0, 0), "dbrief": (1, 0), "mdbrief": (1, 1)}
 KERNELS = ("pyramid", "fast", "octree", "blur", "describe", "match", "greedy")
-POOL = 8    # distinct synthetic multi-frames the stream cycles through (the scene drifts out of the image after a few dozen frames)
+POOL = 64   # distinct synthetic multi-frames the stream cycles through: 8 scenes of 8 frames each ((3,1)-px shifts), synth.stream_image
 WORKLOADS = {
     #          ncam  W     H    nfeat  F/GPU  keyframes  name in BASELINE.json
     "stream": (3, 754, 480, 1000, 64, 0, "configs[1]"),
@@ -47,7 +47,7 @@ WORKLOADS = {
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="stream", choices=list(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="multi-frames per step and GPU (default: per workload)")
@@ -61,7 +61,11 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the e2e / configs[2] / shipped-settings legs of the default run")
     ap.add_argument("--cpu-frames", type=int, default=0, help="multi-frames in the bounded CPU-baseline sample (default: 3 x cpu quota, >= 48)")
-    ap.add_argument("--check", action="store_true", help="verify one multi-frame (descriptors, masks) and one pair's match indices of the timed output against the oracle")
+    ap.add_argument("--check", action="store_true", help="(default; kept for old command lines) verify the timed output against the oracle")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the timed output (profiling runs)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "nccl1"],
+                    help="nccl1: run the N > 1 code path (separate send buffers, asynchronous all_gather_into_tensor on RCCL, work.wait(), three buffer sets, "
+                         "matching one step late) at world size 1 over the nccl backend")
     return ap.parse_args(argv)
 
 
@@ -92,6 +96,7 @@ def setup():
     if e.share:
         e.local = 0
     e.backend = None
+    e.exchange = e.world > 1          # the step runs the exchange (send buffer -> all-gather -> late matching); world 1 normally has nothing to exchange
     if e.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         e.backend = "gloo" if e.share else "nccl"
@@ -108,7 +113,25 @@ def setup():
     torch.cuda.set_stream(e.stream)
     assert e.stream.cuda_stream != 0
     e.ctx = e.mcs.Context(e.local, e.stream.cuda_stream)
+    e.async_collectives = None        # probed by the first exchange
     return e
+
+
+def force_exchange_world1(e):
+    """--exchange nccl1: a one-rank RCCL process group, and the step takes the N > 1 code path"""
+    if e.world != 1:
+        raise SystemExit("--exchange nccl1 is a world-size-1 run")
+    if not e.dist.is_initialized():
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
+        e.dist.init_process_group("nccl", rank=0, world_size=1)
+    e.backend = "nccl"
+    e.exchange = True
 
 
 def sync_all(e):
@@ -205,7 +228,7 @@ class Job:
         def image(c, f):   # the legs of one bench run share their synthetic images
             key = (sp.W, sp.H, c, f % POOL)
             if key not in _IMAGE_CACHE:
-                _IMAGE_CACHE[key] = synth.synth_image(f % POOL, c, self.cams[c])
+                _IMAGE_CACHE[key] = synth.stream_image(f, c, self.cams[c], POOL)
             return _IMAGE_CACHE[key]
         self.imgs_np = np.stack([image(c, f) for c, f in slab])
         mm = [synth.mirror_mask(cam) for cam in self.cams]
@@ -215,7 +238,7 @@ class Job:
         self.camarr = (mcs.Ocam * lay.L)(*[mcs.make_ocam(self.cams[c]) for c, _ in slab])
         # Buffer sets in rotation: the matcher of step n (library side stream) runs beside the extraction of step n + 1.  Two sets when a step extracts
         # and matches the same set (N = 1); three when the matcher runs one step late (N > 1: behind the exchange; the host-buffer leg: outputs leave late).
-        self.nsets = n_sets or (2 if e.world == 1 else 3)
+        self.nsets = n_sets or (3 if e.exchange else 2)
         self.sets = [self._make_set() for _ in range(self.nsets)]
         self.cur = 0
         # stored keyframes of this rank (database sweeps): contiguous sets of ncam*cap rows, filled once from an untimed pass
@@ -231,7 +254,7 @@ class Job:
         # set is reused gives back the ordering a single stream would have had (include/mcs_c.h: mcs_ctx_set_async_search)
         self.async_search = os.environ.get("MCS_BENCH_ASYNC_SEARCH", "1") != "0"
         mcs.check(e.lib.mcs_ctx_set_async_search(e.ctx.h, 1 if self.async_search else 0))
-        if e.world > 1:   # prime the pipeline: the first step() matches the multi-frames exchanged here
+        if e.exchange:   # prime the pipeline: the first step() matches the multi-frames exchanged here
             self.extract_and_exchange(self.sets[self.nsets - 1])
             self.sets[self.nsets - 1].work = "done"
             torch.cuda.synchronize(dev)
@@ -240,7 +263,7 @@ class Job:
         torch, lay, dev, e = self.e.torch, self.lay, self.e.dev, self.e
         b = Env()
         b.G = torch.zeros(lay.images_total * lay.block_bytes, dtype=torch.uint8, device=dev)          # gathered [camera][frame][cap+1][64]
-        b.send = b.G if e.world == 1 else torch.zeros(lay.send_bytes, dtype=torch.uint8, device=dev)   # world 1: the slab IS the whole array
+        b.send = torch.zeros(lay.send_bytes, dtype=torch.uint8, device=dev) if e.exchange else b.G   # no exchange: the slab IS the whole array
         b.valid = torch.zeros(lay.images_total * lay.rows_img, dtype=torch.uint8, device=dev)
         b.nkp = torch.zeros(lay.L, dtype=torch.int32, device=dev)
         b.nkp_all = torch.zeros(lay.images_total, dtype=torch.int32, device=dev)
@@ -274,14 +297,20 @@ class Job:
     def exchange_begin(self, b):
         """the one exchange step: descriptor | mask | count blocks of every rank's slab.  RCCL: asynchronous (its own stream, ordered behind the extraction)."""
         e = self.e
-        if e.world == 1:
+        if not e.exchange:
             return None
         if e.backend == "nccl":
-            try:
+            if e.async_collectives is None:   # probed once: a torch without the async_op keyword takes the blocking form (no overlap, same result);
+                try:                          # any other failure of the collective propagates
+                    w = e.dist.all_gather_into_tensor(b.G, b.send, async_op=True)
+                    e.async_collectives = True
+                    return w
+                except TypeError:
+                    e.async_collectives = False
+            if e.async_collectives:
                 return e.dist.all_gather_into_tensor(b.G, b.send, async_op=True)
-            except (TypeError, RuntimeError):   # a build without asynchronous collectives: the blocking form (no overlap, same result)
-                e.dist.all_gather_into_tensor(b.G, b.send)
-                return None
+            e.dist.all_gather_into_tensor(b.G, b.send)
+            return None
         b.G.copy_(e.rig.all_gather_blocks(b.send, e.world))   # gloo: functional runs on one shared GPU
         return None
 
@@ -334,7 +363,7 @@ class Job:
         # the search that last read b is the one issued before the latest (two sets, N = 1: step n - 2; three sets, N > 1: the matcher of step n - 2,
         # which read the set extracted in step n - 3)
         self.e.mcs.check(self.e.lib.mcs_ctx_search_fence(self.e.ctx.h, 1))
-        if self.e.world == 1:
+        if not self.e.exchange:
             self.extract_and_exchange(b, img_buf)
             self.match(b)
             self.matched_set = b
@@ -418,7 +447,7 @@ def roofline_block(sp, job, kern, feats_local, pairs_local):
     return out
 
 
-def run_job(e, sp, args, steps, warmup, want_roofline=True):
+def run_job(e, sp, args, steps, warmup, want_roofline=True, check=True):
     job = Job(e, sp)
     elapsed = timed(e, job.step, warmup, steps, job.status)
     x0 = job.ex.describe_stats()[0]
@@ -431,6 +460,7 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True):
     rescans = int(b.fb.sum().item())
     elapsed_max, feats_all = e.rig.reduce_timing(elapsed, feats_local, e.red_dev, e.world)
     _, pairs_all = e.rig.reduce_timing(elapsed, pairs_local, e.red_dev, e.world)
+    checked = check_against_oracle(e, sp, job) if (check and e.rank == 0) else None   # before the per-kernel passes: the output of the timed configuration
     kern = kernel_times(e, job.step) if want_roofline else None   # every rank: step() contains the collective
     roof = roofline_block(sp, job, kern, feats_local, pairs_local) if (want_roofline and e.rank == 0) else None
     value = feats_all * steps / elapsed_max / 1e6
@@ -443,17 +473,21 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True):
            "matches_per_step_rank0": matches, "greedy_rescans_rank0": rescans, "topk": sp.topk, "stored_keyframes": sp.D,
            "descriptor_exact_pass_keypoints_per_step_rank0": exact_kp,
            "n_ranks": e.world, "collective_backend": e.backend, "tag": sp.tag,
-           "parallelism": ("single GPU, no collective" if e.world == 1 else
-                           "camera-major image slabs x%d + 1 all-gather of descriptor blocks per step (%d KiB per rank) + (frame, keyframe) pairs sharded x%d"
-                           % (e.world, job.lay.send_bytes // 1024, e.world))}
+           "parallelism": ("single GPU, no collective" if not e.exchange else
+                           "camera-major image slabs x%d + 1 all-gather of descriptor blocks per step (%d KiB per rank, %s) + (frame, keyframe) pairs sharded x%d"
+                           % (e.world, job.lay.send_bytes // 1024, "asynchronous, finished one step later" if e.async_collectives else "blocking", e.world))}
+    if checked is not None:
+        cfg["oracle_checked"] = job.checked
     out = {"metric": "Mfeatures/s extract+match, %d-cam %dx%d multi-frame" % (sp.ncam, sp.W, sp.H), "value": round(value, 3), "unit": "Mfeatures/s",
            "n_gpus": e.world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed_max / steps * 1e3, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u8+i32 (images, Hamming) / f64 (omni model)", "data": "synthetic", "config": cfg, "roofline": roof}
+    if checked is not None:
+        out["oracle_check"] = checked
     return job, out
 
 
 # ------------------------------------------------------------------------------------------------ end-to-end (host buffers in and out)
-def run_e2e(e, sp, steps, warmup):
+def run_e2e(e, sp, steps, warmup, check=True):
     """The same step with the boundary's host buffers: images start in page-locked host memory (double-buffered H2D on a copy stream), keypoints,
     descriptor | mask blocks, counts and match arrays end in page-locked host memory (D2H on a second copy stream), both overlapped with the compute of
     the neighbouring steps.  N = 1 only."""
@@ -514,6 +548,9 @@ def run_e2e(e, sp, steps, warmup):
             download(m % NS)
     torch.cuda.synchronize(e.dev)
     feats = job.local_features()
+    last = outs[(n - 1) % NS]                             # page-locked host copies of the last step's buffer set: (send = gathered array, nkp, kps, match, nmatch)
+    job.matched_set = job.sets[(n - 1) % NS]
+    checked = check_against_oracle(e, sp, job, host={"G": last[0][1], "kps": last[2][1], "match": last[3][1], "nmatch": last[4][1]}) if check else None
     h2d = job.imgs_np.nbytes
     d2h = sum(dst.numel() * dst.element_size() for _, dst in outs[0])
 
@@ -527,55 +564,74 @@ def run_e2e(e, sp, steps, warmup):
     h2d_rate = rate(lambda: job.d_imgs[0].copy_(h_img[0], non_blocking=True), h2d)
     d2h_rate = rate(lambda: [dst.copy_(src, non_blocking=True) for src, dst in outs[0]], d2h)
     job.close()
-    return {"value": round(feats * steps / elapsed / 1e6, 3), "unit": "Mfeatures/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
+    return {"value": round(feats * steps / elapsed / 1e6, 3), "unit": "Mfeatures/s", "ms_per_step": round(elapsed / steps * 1e3, 4), "oracle_check": checked,
+            "oracle_checked": "the page-locked HOST copies of the last step's outputs: %s" % getattr(job, "checked", None),
             "h2d_bytes_per_step": int(h2d), "d2h_bytes_per_step": int(d2h), "h2d_GBps_alone": h2d_rate, "d2h_GBps_alone": d2h_rate,
             "what": "host buffers at the boundary: images H2D from page-locked memory (double-buffered, copy stream), keypoints + descriptor|mask blocks + counts + "
                     "match arrays D2H to page-locked memory (second copy stream), overlapped with the neighbouring steps' kernels"}
 
 
 # ------------------------------------------------------------------------------------------------ oracle legs
-def check_against_oracle(e, sp, job):
-    """one multi-frame of the timed output (descriptors, masks, counts) and the match indices of one pair, bit for bit"""
+def check_against_oracle(e, sp, job, host=None):
+    """The timed output against the oracle, bit for bit: two multi-frames (every camera: keypoint records, descriptors, masks, counts) and the match
+    indices of the (frame, keyframe) pairs they take part in — pair (1, 0) of the ring, or frames 0 and 1 against this rank's first two stored keyframes.
+    `host`: the page-locked host copies of a buffer set (the e2e leg) instead of the device buffers."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     lay, rig = job.lay, e.rig
     do_db, masks_on = MODES[sp.mode]
     b = job.last()
     e.torch.cuda.synchronize(e.dev)
-    G = b.G.cpu().numpy().reshape(lay.images_total, lay.rows_img, lay.row_stride)
-    ok = True
+    src = host or {"G": b.G, "kps": b.kps, "match": b.match, "nmatch": b.nmatch}
+    G = src["G"].cpu().numpy().reshape(lay.images_total, lay.rows_img, lay.row_stride)
+    kps = src["kps"].cpu().numpy().view(np.uint8).reshape(lay.L, lay.cap, 28)
+    match, nmatch = src["match"].cpu().numpy(), src["nmatch"].cpu().numpy()
+    mine = {cf: i for i, cf in enumerate(job.slab)}   # (camera, frame) -> local image (keypoint records stay on the rank that extracted them)
+    bad = []
     want = {}
     for f in ((1, 0) if job.FT > 1 else (0,)):
         d, m, v = rig.unpack_frame(lay, G, f)
         want[f] = (d, m, v)
         for c in range(sp.ncam):
-            _, od, om = O.Extractor(nfeatures=sp.nfeat, do_dBrief=do_db, learnMasks=masks_on)(e.synth.synth_image(f % POOL, c, job.cams[c]),
-                                                                                               e.synth.mirror_mask(job.cams[c]), O.make_ocam(job.cams[c]))
+            ok_, od, om = O.Extractor(nfeatures=sp.nfeat, do_dBrief=do_db, learnMasks=masks_on)(e.synth.stream_image(f, c, job.cams[c], POOL),
+                                                                                                 e.synth.mirror_mask(job.cams[c]), O.make_ocam(job.cams[c]))
             lo = c * lay.cap
-            ok = ok and int(v[lo:lo + lay.cap].sum()) == len(od) and (d[lo:lo + len(od)] == od).all() and (m[lo:lo + len(od)] == om).all()
-    if sp.D == 0 and e.rank == 0:
+            if not (int(v[lo:lo + lay.cap].sum()) == len(od) and (d[lo:lo + len(od)] == od).all() and (m[lo:lo + len(od)] == om).all()):
+                bad.append("descriptors/masks/count of frame %d camera %d" % (f, c))
+            if (c, f) in mine and not np.array_equal(kps[mine[(c, f)], :len(ok_)].reshape(-1), np.ascontiguousarray(ok_).view(np.uint8).reshape(-1)):
+                bad.append("keypoint records of frame %d camera %d" % (f, c))
+    pairs = 0
+    if sp.D == 0 and e.rank == 0 and job.FT > 1:
         # pair (frame 1, frame 0) is set 1 of rank 0's ring call
         (d1, m1, v1), (d0, m0, v0) = want[1], want[0]
         ones = np.full_like(d1, 255)
         n, m12 = O.search_kf_kf(d1, m1 if masks_on else ones, v1, d0, m0 if masks_on else ones, v0, bool(masks_on), 0.9)
-        got = b.match.cpu().numpy().reshape(sp.F, lay.rows_frame)[1]
-        ok = ok and n == int(b.nmatch[1].item()) and np.array_equal(got, m12)
+        got = match.reshape(sp.F, lay.rows_frame)[1]
+        pairs += 1
+        if not (n == int(nmatch[1]) and np.array_equal(got, m12)):
+            bad.append("match indices of the pair (frame 1, frame 0)")
     if sp.D > 0 and job.nkf:
-        # database sweep: this rank's first stored keyframe against multi-frame 0 (and 1) = pairs (f, k = 0) of the sweep call
-        db = job.db[0].cpu().numpy()
-        dk, mk, vk = np.ascontiguousarray(db[:, :lay.desc_size]), np.ascontiguousarray(db[:, lay.desc_size:]), job.db_valid[0].cpu().numpy()
-        got_m = b.match.cpu().numpy().reshape(job.FT, job.nkf, lay.rows_frame)
-        got_n = b.nmatch.cpu().numpy().reshape(job.FT, job.nkf)
-        for f in want:
-            df, mf, vf = want[f]
-            keep = np.flatnonzero(vf)
-            ones_k, ones_f = np.full_like(dk, 255), np.full((len(keep), lay.desc_size), 255, np.uint8)
-            n, mm = O.search_kf_f(dk, mk if masks_on else ones_k, vk, np.ascontiguousarray(df[keep]), np.ascontiguousarray(mf[keep]) if masks_on else ones_f,
-                                  bool(masks_on), 0.9)
-            full = np.full(lay.rows_frame, -1, np.int32)
-            full[keep] = mm
-            ok = ok and n == int(got_n[f, 0]) and np.array_equal(got_m[f, 0], full)
-    return bool(ok)
+        # database sweep: this rank's first two stored keyframes against multi-frames 0 and 1 = pairs (f, k) of the sweep call
+        got_m = match.reshape(job.FT, job.nkf, lay.rows_frame)
+        got_n = nmatch.reshape(job.FT, job.nkf)
+        for k in range(min(2, job.nkf)):
+            db = job.db[k].cpu().numpy()
+            dk, mk, vk = np.ascontiguousarray(db[:, :lay.desc_size]), np.ascontiguousarray(db[:, lay.desc_size:]), job.db_valid[k].cpu().numpy()
+            for f in want:
+                df, mf, vf = want[f]
+                keep = np.flatnonzero(vf)
+                ones_k, ones_f = np.full_like(dk, 255), np.full((len(keep), lay.desc_size), 255, np.uint8)
+                n, mm = O.search_kf_f(dk, mk if masks_on else ones_k, vk, np.ascontiguousarray(df[keep]), np.ascontiguousarray(mf[keep]) if masks_on else ones_f,
+                                      bool(masks_on), 0.9)
+                full = np.full(lay.rows_frame, -1, np.int32)
+                full[keep] = mm
+                pairs += 1
+                if not (n == int(got_n[f, k]) and np.array_equal(got_m[f, k], full)):
+                    bad.append("match indices of the pair (frame %d, stored keyframe %d)" % (f, job.kfs[k]))
+    for msg in bad:
+        print("oracle check FAILED [%s]: %s" % (sp.tag, msg), file=sys.stderr)
+    job.checked = {"multi_frames": len(want), "images": len(want) * sp.ncam, "pairs": pairs}
+    return not bad
 
 
 def cpu_baseline(args, e, sp, job):
@@ -594,7 +650,8 @@ def cpu_baseline(args, e, sp, job):
     except (OSError, ValueError):
         pass
     nf = args.cpu_frames or max(48, 3 * quota)
-    pool = [[_IMAGE_CACHE.get((W, H, c, f)) if (W, H, c, f) in _IMAGE_CACHE else synth.synth_image(f, c, job.cams[c]) for c in range(NCAM)] for f in range(POOL)]
+    pool = [[_IMAGE_CACHE.get((W, H, c, f)) if (W, H, c, f) in _IMAGE_CACHE else synth.stream_image(f, c, job.cams[c], POOL) for c in range(NCAM)]
+            for f in range(min(POOL, nf))]
     flat = [np.ascontiguousarray(pool[f % POOL][c]) for f in range(nf) for c in range(NCAM)]
     mk = [np.ascontiguousarray(synth.mirror_mask(job.cams[c])) for c in range(NCAM)]
     iptr = (C.c_void_p * len(flat))(*[a.ctypes.data for a in flat])
@@ -616,6 +673,13 @@ def cpu_baseline(args, e, sp, job):
                 best = (wall, secs[0], secs[1], tot, threads)
     wall, se, sm, tot, threads = best
     per_frame = tot / nf
+    # the reference's own threading: one thread per camera of a multi-frame (#pragma omp parallel for num_threads(nrCams), src/cMultiFrame.cpp:128), the
+    # multi-frames one after the other, the matcher single-threaded — NCAM images in flight at any time
+    nf_f = max(4, min(nf, 12))
+    tot_f = L.orc_extract_match_many(C.byref(prm), nf_f, NCAM, iptr, W, H, W, mptr, ocs, NCAM, 0.9, nmatch, secs)
+    faithful = {"value": round(tot_f / nf_f * (nf_f - 1) / (secs[0] + secs[1]) / 1e6, 4), "unit": "Mfeatures/s", "cores": NCAM,
+                "sample": "%d multi-frames one after the other on %d threads (extraction: one thread per camera, the reference's threading; the frame pairs of the "
+                          "matcher share the same threads): extract %.2fs + match %.2fs" % (nf_f, NCAM, secs[0], secs[1])}
     # the same extractor as the REFERENCE's own sources (oracle/_ref = src/mdBRIEFextractorOct.cpp compiled unmodified against oracle/cvshim, its image
     # primitives are the oracle's), single thread, next to the oracle single thread: the port is not slower than the code it restates
     side = None
@@ -635,7 +699,7 @@ def cpu_baseline(args, e, sp, job):
             side = {"reference_sources_ms_per_image_1thread": round((t1 - t0) / 6 * 1e3, 1), "port_ms_per_image_1thread": round((t2 - t1) / 6 * 1e3, 1)}
         except Exception as ex:   # the side measurement is optional
             side = {"error": str(ex)[:120]}
-    return {"extract_1thread": side, "value": round(per_frame * (nf - 1) / wall / 1e6, 4), "unit": "Mfeatures/s", "cores": threads, "kind": "port",
+    return {"extract_1thread": side, "reference_threading": faithful, "value": round(per_frame * (nf - 1) / wall / 1e6, 4), "unit": "Mfeatures/s", "cores": threads, "kind": "port",
             "sample": "%d multi-frames (%d images) of the same synthetic stream: oracle extract (%s) %.2fs + SearchByBoW(KF,KF) vs previous frame %.2fs wall, "
                       "OpenMP over images/frames on %d threads (cgroup CPU quota of this box: %d of %d hardware threads; best of quota and 2x quota, 2 passes each)"
                       % (nf, nf * NCAM, sp.mode, se, sm, threads, quota, nproc),
@@ -652,33 +716,65 @@ def secondary_args(args, **kw):
 def main():
     args = parse()
     e = setup()
+    if args.exchange == "nccl1":
+        force_exchange_world1(e)
     sp = Spec(args, e.world)
-    job, out = run_job(e, sp, args, args.steps, args.warmup)
-    headline = args.workload == "stream" and args.mode == "mdbrief" and not (args.ncam or args.width or args.height or args.nfeatures or args.keyframes >= 0)
-    if args.check and e.rank == 0:
-        out["oracle_check"] = check_against_oracle(e, sp, job)
+    check = not args.no_check
+    job, out = run_job(e, sp, args, args.steps, args.warmup, check=check)
+    headline = args.workload == "stream" and args.mode == "mdbrief" and not (args.ncam or args.width or args.height or args.nfeatures or args.keyframes >= 0
+                                                                               or args.frames or args.exchange != "auto")
     cpu = None
     if e.rank == 0 and e.world == 1 and headline and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, e, sp, job)
     out["cpu_baseline"] = cpu
     if cpu:
         out["speedup_vs_cpu_all_cores"] = round(out["value"] / cpu["value"], 2)
+        out["speedup_vs_cpu_reference_threading"] = round(out["value"] / cpu["reference_threading"]["value"], 2)
     job.close()
+    checks = [out.get("oracle_check")]
     if e.world == 1 and headline and not args.no_secondary:
-        # further legs of the default run, each bounded: host buffers at the boundary; the matcher-dominated BASELINE configs[2]; the reference's shipped settings
+        # further legs of the default run, each bounded: host buffers at the boundary (configs[1] and [2]); the matcher-dominated BASELINE configs[2]; the
+        # reference's shipped settings; the N > 1 code path at world size 1 over RCCL
         s2 = min(args.steps, 10)
-        out["e2e"] = run_e2e(e, sp, args.steps, args.warmup)
+        out["e2e"] = run_e2e(e, sp, args.steps, args.warmup, check)
+        checks.append(out["e2e"]["oracle_check"])
         sec = []
         for a in (secondary_args(args, workload="db", frames=16), secondary_args(args, mode="orb", nfeatures=400)):
-            j2, o2 = run_job(e, Spec(a, e.world), a, s2, 2)
+            j2, o2 = run_job(e, Spec(a, e.world), a, s2, 2, check=check)
             j2.close()
-            sec.append({k: o2[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline")})
+            sec.append({k: o2[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "oracle_check") if k in o2})
+            checks.append(o2.get("oracle_check"))
+        a = secondary_args(args, workload="db", frames=16)
+        sec[0]["e2e"] = run_e2e(e, Spec(a, e.world), s2, 2, check)
+        checks.append(sec[0]["e2e"]["oracle_check"])
         out["secondary"] = sec
-    if e.rank == 0:
-        print(json.dumps(out))
-    if e.world > 1:
+        try:   # a one-rank RCCL group: the code path of the N > 1 runs (the driver's SCALE run) on this box's own RCCL
+            force_exchange_world1(e)
+            j3, o3 = run_job(e, sp, args, s2, 2, want_roofline=False, check=check)
+            j3.close()
+            out["exchange_world1"] = {k: o3[k] for k in ("value", "unit", "steps", "ms_per_step", "oracle_check") if k in o3}
+            out["exchange_world1"]["parallelism"] = o3["config"]["parallelism"]
+            out["exchange_world1"]["what"] = ("the N > 1 step (send buffer -> asynchronous all_gather_into_tensor on RCCL -> work.wait() -> row flags -> matching one "
+                                              "step late, three buffer sets) at world size 1, backend nccl")
+            checks.append(o3.get("oracle_check"))
+        except Exception as ex:   # an environment without a usable RCCL is reported, not hidden; a wrong RESULT is a failed check above
+            out["exchange_world1"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+        e.exchange = False
+    failed = check and e.rank == 0 and any(c is False for c in checks)
+    if e.dist.is_initialized():
         e.dist.barrier()
         e.dist.destroy_process_group()
+    if e.rank == 0:
+        # the JSON line is the LAST line of stdout: RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION on these boxes), flush that first
+        sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)
+        except (OSError, AttributeError):
+            pass
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if failed:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

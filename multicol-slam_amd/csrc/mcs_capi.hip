@@ -524,6 +524,16 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 	b.outImgPitch = out_image_pitch_rows ? out_image_pitch_rows : (size_t)hd.kpCap;
 	b.outRowStride = out_row_stride ? out_row_stride : hd.descSize;
 	if (b.outImgPitch < (size_t)hd.kpCap || b.outRowStride < hd.descSize) return fail(MCS_ERR_INVALID, "output image pitch / row stride smaller than the rows they hold");
+	// the descriptor kernels store rows as 8-byte words
+	if (b.outRowStride % 8 != 0 || (kind != MCS_MEM_HOST && (((uintptr_t)desc | (uintptr_t)descmask) & 7) != 0))
+		return fail(MCS_ERR_INVALID, "descriptor / mask rows must be 8-byte aligned (row stride a multiple of 8)");
+	if (kind != MCS_MEM_HOST && (out_image_pitch_rows || out_row_stride)) {
+		// strided outputs: mask rows either interleaved with the descriptor rows (inside the same stride, behind the descriptor) or a separate array
+		const uintptr_t lo = std::min((uintptr_t)desc, (uintptr_t)descmask), hi = std::max((uintptr_t)desc, (uintptr_t)descmask);
+		const size_t span = ((size_t)(nimg - 1) * b.outImgPitch + (size_t)hd.kpCap - 1) * (size_t)b.outRowStride + (size_t)hd.descSize;
+		const bool interleaved = hi - lo >= (uintptr_t)hd.descSize && hi - lo + (uintptr_t)hd.descSize <= (uintptr_t)b.outRowStride;
+		if (!interleaved && hi - lo < span) return fail(MCS_ERR_INVALID, "descriptor and mask rows overlap for this pitch / stride");
+	}
 	if (kind == MCS_MEM_HOST && (b.outImgPitch != (size_t)hd.kpCap || b.outRowStride != hd.descSize)) return fail(MCS_ERR_UNSUPPORTED, "strided descriptor outputs need device memory");
 	if (kind == MCS_MEM_HOST) {
 		// ONE linear copy per block, in the caller's own layout; the kernels take any pitch / stride for level 0.  (A pitched hipMemcpy2D from pageable
@@ -560,7 +570,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 			int w = -1;
 			for (size_t k = 0; k < e->camCache.size() && w < 0; ++k) if (memcmp(&e->camCache[k].key, &o, sizeof(o)) == 0) w = (int)k;
 			if (w < 0) {
-				if (e->camCache.size() >= 64) e->camCache.clear();
+				// (no eviction here: which[] of the earlier images of this batch indexes the cache — it is trimmed after the batch's tables are copied)
 				mcs_extractor::CamFast cf;
 				cf.key = o; cf.tab.assign(kRhoTabDoubles, 0.0);
 				cf.tail = build_rho_table(m, cf.tab.data());
@@ -583,6 +593,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 			HIPCHK(hipMemcpy(e->d_rhoTab, tabs.data(), tabs.size() * sizeof(double), hipMemcpyHostToDevice));
 			e->h_cams = hc;
 		}
+		if (e->camCache.size() > 64) e->camCache.clear();   // a rig has a handful of cameras; a caller that streams distinct models rebuilds (which[] is dead here)
 		b.cams = e->d_cams;
 	}
 	if (c->overlap()) {

@@ -23,6 +23,8 @@ class RigLayout:
     def __init__(self, ncam, frames_total, world, cap, desc_size=32):
         if (ncam * frames_total) % world:
             raise ValueError("ncam * frames_total must be a multiple of the world size")
+        if frames_total % world:
+            raise ValueError("frames_total must be a multiple of the world size (frame_pairs / the ring call give every rank frames_total / world frames)")
         self.ncam, self.frames_total, self.world, self.cap, self.desc_size = ncam, frames_total, world, cap, desc_size
         self.images_total = ncam * frames_total
         self.L = self.images_total // world            # images per rank
