@@ -27,80 +27,162 @@ using namespace mcs;
 // 10 000 keypoints, and 30-40x above describe_fast_bound() for the Lafida cameras.
 static constexpr double kDefaultGuardEps = 5.9604644775390625e-08;
 
-// The fast pass's table of rho(theta(a)) for one camera (layout: mcs_common.h kRho*), built in long double, and the bound on what its truncated Taylor
-// rows leave out.  Row of bin i, half h: centre c = sigma * i / kRhoK (sigma = sign p0), theta(c + t) = theta0 + s * (atan(c + t) - atan c) with
-// theta0 = sigma * pi/2 - atan c, s = -1 (h = 0: |norm / p0| < 1) or theta0 = atan c, s = +1 (h = 1);  rho(theta0 + y) = sum_k p_k y^k is invP
-// re-expanded at theta0;  the row is the composition truncated at t^kRhoDeg, rescaled to the kernel's variable x - i = sigma * kRhoK * t.
-// Tail: the Taylor coefficients of atan at any real c are at most 1/k in magnitude, so atan(c + t) - atan c is dominated coefficient by coefficient by
-// t / (1 - t), and the composition by sum_k |p_k| (t / (1 - t))^k, whose t^j coefficient is M_j = sum_k |p_k| C(j-1, k-1).  With |t| <= 1 / (2 kRhoK)
-// the truncated tail is at most sum_{j > kRhoDeg} M_j |t|^j (evaluated to j = 96; the rest is below S * (2|t|)^96).  Returns that bound (max over the
-// rows), or +inf if a coefficient is not finite.
-static double build_rho_table(const mcs_ocam& m, double* tab) {
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The fast pass's table of G(s) = rho(theta) / sqrt(s), theta = atan(p0 / sqrt(s)), for one camera (layout: mcs_common.h kG*), built in long double, with
+// the bound on what its truncated Taylor rows leave out and the few magnitudes describe_fast_bound() needs.
+//
+// Row (e, k): s = 2^e (kappa + tau), kappa = 1 + (k + 1/2) / 2^kGM, |tau| <= 2^-(kGM+1); centre c = 2^e kappa, eps = tau / kappa = (s - c) / c.
+//   N(eps)      = (1 + eps)^(-1/2) = sum b_j eps^j                        (1 / sqrt(s) = N / sqrt(c))
+//   z(eps)      = z_c N(eps),  z_c = p0 / sqrt(c);   y = z - z_c
+//   atan(z_c+y) = theta_c + sum_k A_k y^k,  A_k from 1 / ((1 + z_c^2) + 2 z_c y + y^2)
+//   rho         = sum_k p_k (theta - theta_c)^k,  p_k = invP re-expanded at theta_c
+//   G           = N * rho / sqrt(c), truncated at eps^kGDeg, stored in the kernel's variable tau (coefficient j divided by kappa^j).
+// Tail (coefficient-wise majorants, "<<"):  |b_j| <= 1/2 (j >= 1), so y << |z_c| (eps/2) / (1 - eps);  the Taylor coefficients of atan at the real point z_c
+// are (1/k) Im-parts of (z_c -+ i)^-k, at most R^-k / k with R = sqrt(1 + z_c^2), so theta - theta_c << (Y/R) / (1 - Y/R) = a eps / (1 - b eps) with
+// q = |z_c| / R, a = q / 2, b = 1 + q / 2;  rho - p_0 << sum_k |p_k| (a eps / (1 - b eps))^k, whose eps^i coefficient is P_i = sum_k |p_k| a^k b^(i-k) C(i-1, k-1);
+// G << c^(-1/2) N~ (|p_0| + P) with N~ = sum |b_j| eps^j:  W_j = c^(-1/2) (|p_0| |b_j| + sum_{i=1..j} P_i |b_(j-i)|).  The truncated tail of a row is at most
+// sum_{j > kGDeg} W_j epsmax^j (summed to j = 80; the rest is below c^(-1/2) (|p_0| + sum |p_k|) 3 (3 epsmax)^81 / (1 - 3 epsmax) since P_i <= sum|p_k| (2b)^i, 2b <= 3).
+// What the pixel coordinates see is sqrt(s) times that: tailU.
+struct GTabInfo {
+	double tailU = INFINITY;   // max over the rows of sqrt(s) * (truncated tail of the row)                       [pixels]
+	double rhoB = 0;           // max sqrt(s) * sum_j |g_j| |eps|^j  (>= |rho| on the table's range)
+	double dB = 0;             // max sqrt(s) * |s G'(s)|
+	double lip = 0;            // max (|G| + 2 |s G'(s)|) >= both eigenvalues of d(x G, y G) / d(x, y)
+	double seen = 0;           // largest |row polynomial - G| (times sqrt(s)) at the sample points checked against direct long double evaluation
+};
+
+static GTabInfo build_g_table(const mcs_ocam& m, double* tab) {
 	typedef long double LD;
-	const int n = m.invP_deg;
-	const LD sigma = m.p[0] < 0 ? -1.0L : 1.0L, halfPi = sigma * (acosl(-1.0L) / 2);
-	const double tmax = 1.0 / (2.0 * kRhoK);
-	double worst = 0.0;
+	GTabInfo info;
+	const int n = m.invP_deg, D = kGDeg, J = 80;
+	if (n < 1 || n > MCS_MAX_POLY || !(std::fabs(m.p[0]) > 1e-300) || !std::isfinite(m.p[0])) return info;
+	for (int i = 0; i < n; ++i) if (!std::isfinite(m.invP[i])) return info;
 	LD binom[MCS_MAX_POLY][MCS_MAX_POLY];
 	for (int i = 0; i < MCS_MAX_POLY; ++i)
 		for (int k = 0; k <= i; ++k) binom[i][k] = (k == 0 || k == i) ? 1.0L : binom[i - 1][k - 1] + binom[i - 1][k];
-	for (int h = 0; h < 2; ++h)
-		for (int i = 0; i < kRhoBins; ++i) {
-			const LD c = sigma * (LD)i / (LD)kRhoK, at = atanl(c), theta0 = h == 0 ? halfPi - at : at, sgn = h == 0 ? -1.0L : 1.0L;
-			// y(t) = sgn * (atan(c + t) - atan c) = sum_{k>=1} y_k t^k:  d/dt atan = 1 / ((1 + c^2) + 2c t + t^2) = sum f_k t^k
-			LD f[kRhoDeg + 1], y[kRhoDeg + 1];
-			const LD d0 = 1.0L + c * c;
+	LD bj[J + 1];   // (1 + eps)^(-1/2)
+	bj[0] = 1.0L;
+	for (int j = 1; j <= J; ++j) bj[j] = bj[j - 1] * (-(LD)(2 * j - 1) / (LD)(2 * j));
+	auto mul = [&](const LD* A, const LD* B, LD* C) {   // series product truncated at degree D
+		LD T[D + 1];
+		for (int i = 0; i <= D; ++i) { T[i] = 0; for (int k = 0; k <= i; ++k) T[i] += A[k] * B[i - k]; }
+		for (int i = 0; i <= D; ++i) C[i] = T[i];
+	};
+	const LD p0 = (LD)m.p[0];
+	auto direct = [&](LD sv) {   // G(s) itself
+		const LD nn = sqrtl(sv), th = atanl(p0 / nn);
+		LD r = 0;
+		for (int i = n - 1; i >= 0; --i) r = r * th + (LD)m.invP[i];
+		return r / nn;
+	};
+	double tailU = 0, rhoB = 0, dB = 0, lip = 0, seen = 0;
+	for (int e = kGE0; e < kGE1; ++e)
+		for (int k = 0; k < (1 << kGM); ++k) {
+			const LD kappa = 1.0L + ((LD)k + 0.5L) / (LD)(1 << kGM), c = ldexpl(kappa, e), sqc = sqrtl(c), zc = p0 / sqc, thc = atanl(zc);
+			const double epsmax = (double)(ldexpl(1.0L, -(kGM + 1)) / kappa) * (1.0 + 1e-15);
+			// y(eps), atan coefficients, composition
+			LD y[D + 1], A[D + 1], f[D + 1];
+			y[0] = 0;
+			for (int j = 1; j <= D; ++j) y[j] = zc * bj[j];
+			const LD d0 = 1.0L + zc * zc;
 			f[0] = 1.0L / d0;
-			for (int k = 1; k <= kRhoDeg; ++k) f[k] = -(2.0L * c * f[k - 1] + (k >= 2 ? f[k - 2] : 0.0L)) / d0;
-			y[0] = 0.0L;
-			for (int k = 1; k <= kRhoDeg; ++k) y[k] = sgn * f[k - 1] / (LD)k;
-			// invP re-expanded at theta0
+			for (int j = 1; j <= D; ++j) f[j] = -(2.0L * zc * f[j - 1] + (j >= 2 ? f[j - 2] : 0.0L)) / d0;
+			for (int j = 1; j <= D; ++j) A[j] = f[j - 1] / (LD)j;
+			LD Th[D + 1] = {0}, Yp[D + 1];
+			for (int j = 0; j <= D; ++j) Yp[j] = y[j];
+			for (int kk = 1; kk <= D; ++kk) {
+				for (int j = 0; j <= D; ++j) Th[j] += A[kk] * Yp[j];
+				mul(Yp, y, Yp);
+			}
 			LD pk[MCS_MAX_POLY];
-			for (int k = 0; k < n; ++k) {
+			for (int kk = 0; kk < n; ++kk) {
 				LD acc = 0.0L, pw = 1.0L;
-				for (int j = k; j < n; ++j) { acc += binom[j][k] * (LD)m.invP[j] * pw; pw *= theta0; }
-				pk[k] = acc;
+				for (int j = kk; j < n; ++j) { acc += binom[j][kk] * (LD)m.invP[j] * pw; pw *= thc; }
+				pk[kk] = acc;
 			}
-			// H(t) = sum_k pk[k] y(t)^k by Horner in y, series truncated at degree kRhoDeg
-			LD H[kRhoDeg + 1] = {0};
+			LD H[D + 1] = {0};
 			H[0] = pk[n - 1];
-			for (int k = n - 2; k >= 0; --k) {
-				LD T[kRhoDeg + 1] = {0};
-				for (int a = 0; a <= kRhoDeg; ++a)
-					for (int bq = 1; a + bq <= kRhoDeg; ++bq) T[a + bq] += H[a] * y[bq];
-				for (int a = 0; a <= kRhoDeg; ++a) H[a] = T[a];
-				H[0] += pk[k];
+			for (int kk = n - 2; kk >= 0; --kk) { mul(H, Th, H); H[0] += pk[kk]; }
+			LD Gs[D + 1], Nn[D + 1];
+			for (int j = 0; j <= D; ++j) Nn[j] = bj[j];
+			mul(Nn, H, Gs);
+			double* row = tab + (size_t)((e - kGE0) * (1 << kGM) + k) * kGRow;
+			LD kp = 1.0L;
+			for (int j = 0; j <= D; ++j) {
+				Gs[j] /= sqc;
+				row[j] = (double)(Gs[j] / kp);
+				kp *= kappa;
+				if (!std::isfinite(row[j])) return info;
 			}
-			double* row = tab + ((size_t)h * kRhoBins + i) * kRhoRow;
-			LD sc = 1.0L;
-			for (int j = 0; j <= kRhoDeg; ++j) { row[j] = (double)(H[j] * sc); sc /= sigma * (LD)kRhoK; if (!std::isfinite(row[j])) return INFINITY; }
-			// the tail
-			double tail = 0.0, S = 0.0, tp = 1.0;
-			for (int k = 1; k < n; ++k) S += std::fabs((double)pk[k]);
-			for (int j = 1; j <= 96; ++j) {
-				tp *= tmax;
-				if (j <= kRhoDeg) continue;
-				double Mj = 0.0, cb = 1.0;   // cb = C(j-1, k-1)
-				for (int k = 1; k < n && k <= j; ++k) { Mj += std::fabs((double)pk[k]) * cb; cb = cb * (double)(j - k) / (double)k; }
-				tail += Mj * tp;
+			// the majorant series W_j and the row's tail
+			const double q = (double)(fabsl(zc) / sqrtl(d0)), a = 0.5 * q, b = 1.0 + 0.5 * q;
+			double apk[MCS_MAX_POLY], Spk = 0;
+			for (int kk = 0; kk < n; ++kk) { apk[kk] = (double)fabsl(pk[kk]) * (1.0 + 1e-15); if (kk) Spk += apk[kk]; }
+			double P[J + 1];
+			P[0] = 0;
+			for (int i = 1; i <= J; ++i) {
+				double acc = 0, cb = 1.0;   // cb = C(i-1, kk-1)
+				for (int kk = 1; kk < n && kk <= i; ++kk) { acc += apk[kk] * std::pow(a, kk) * std::pow(b, i - kk) * cb; cb = cb * (double)(i - kk) / (double)kk; }
+				P[i] = acc;
 			}
-			tail += S * std::pow(2.0 * tmax, 96);
-			worst = std::max(worst, tail);
+			const double isc = (double)(1.0L / sqc) * (1.0 + 1e-15);
+			double tail = 0, tailD = 0, ep = 1.0;   // sum W_j eps^j and sum j W_j eps^(j-1) over j > D
+			for (int j = 1; j <= J; ++j) {
+				const double epm1 = ep;
+				ep *= epsmax;
+				if (j <= D) continue;
+				double Wj = apk[0] * (double)fabsl(bj[j]);
+				for (int i = 1; i <= j; ++i) Wj += P[i] * (double)fabsl(bj[j - i]);
+				Wj *= isc;
+				tail += Wj * ep;
+				tailD += (double)j * Wj * epm1;
+			}
+			const double rest = isc * (apk[0] + Spk) * 3.0 * std::pow(3.0 * epsmax, J + 1) / (1.0 - 3.0 * epsmax);
+			tail = (tail + rest) * 1.01;                        // the sums above are in rounded arithmetic
+			tailD = (tailD + (J + 2) * rest / epsmax) * 1.01;
+			if (!std::isfinite(tail) || !std::isfinite(tailD)) return info;
+			double gabs = 0, gder = 0;
+			ep = 1.0;
+			for (int j = 0; j <= D; ++j) {
+				gabs += (double)fabsl(Gs[j]) * ep;
+				if (j + 1 <= D) gder += (double)(j + 1) * (double)fabsl(Gs[j + 1]) * ep;
+				ep *= epsmax;
+			}
+			gabs += tail;
+			gder = (gder + tailD) * (1.0 + epsmax);             // |s G'(s)| = |(1 + eps) dG/d eps|
+			const double sq = (double)sqc * std::sqrt(1.0 + epsmax) * (1.0 + 1e-15);
+			tailU = std::max(tailU, sq * tail);
+			rhoB = std::max(rhoB, sq * gabs);
+			dB = std::max(dB, sq * gder);
+			lip = std::max(lip, gabs + 2.0 * gder);
+			// sanity: the row against G itself at both ends of the bin and in the middle
+			for (int t = -2; t <= 2; ++t) {
+				const LD tau = (LD)t * ldexpl(1.0L, -(kGM + 2)) * (1.0L - 1e-9L), sv = ldexpl(kappa + tau, e);
+				LD pv = 0;
+				for (int j = D; j >= 0; --j) pv = pv * tau + (LD)row[j];
+				seen = std::max(seen, (double)(fabsl(pv - direct(sv)) * sqrtl(sv)));
+			}
 		}
-	return worst * 1.01;   // the sums above are in rounded arithmetic
+	info.tailU = tailU; info.rhoB = rhoB * 1.01; info.dB = dB * 1.01; info.lip = lip * 1.01; info.seen = seen;
+	if (!(seen <= tailU + 64 * 1.1102230246251565e-16 * rhoB)) info.tailU = INFINITY;   // the rows must reproduce G within the bound they claim (plus their own rounding to double)
+	return info;
 }
 
 // Worst-case |(fast coordinate - fast mean) - (reference coordinate - reference mean)| for one camera and npoints pattern points.
-// u = 2^-53.  Both arithmetics evaluate the same real function F(xr, yr) = affine(x/n * rho(atan(p0/n))); each differs from F by its own rounding:
-//   rho     fast: the table row's truncated tail (tabTail, from build_rho_table) + its argument's roundings (n2, the refined rsq, two products: <= 1e-14
-//           in a, and |d rho / d a| <= S') + the row's Horner chain, rho*r and x*g (64u * 1.1 S generously: the row's partial sums stay below
-//           sum |invP_i| (pi/2 + 0.008)^i <= 1.1 S);   reference: atan within 2 ulp (8u S') + 24 roundings + 2 divisions + 2 products -> 96u S
-//           S = sum |invP_i| (pi/2)^i,  S' = sum i |invP_i| (pi/2)^(i-1)
-//   u, v    (1 + |c| + |d| + |e|) * d rho  +  8u (|u0| + |v0|)
-//   mean    the same per-point bound, plus the reordering of the sum: sequential (npoints-1) u Umax + tree 13 u Umax, Umax = 16384 + 4096 (enforced by the kernel)
-//   minus   two more roundings of values below 8192
-// Returns +inf for a camera the fast arithmetic cannot serve (p0 = 0, non-finite coefficients).
-static double describe_fast_bound(const mcs_ocam& m, int npoints, double tabTail) {
+// u = 2^-53.  Both arithmetics evaluate the same real function F(X, Y) = affine(X G(s), Y G(s)), s = X^2 + Y^2, of the same real rotated pattern point
+// (X, Y) = R(angle) (ptx, pty) + undistorted keypoint; each differs from it by its own rounding:
+//   inputs  |X|, |Y| < 4096 (the table ends at s = 2^24; a point outside sends the keypoint to the exact pass).  Reference: 3 roundings per coordinate,
+//           fast: 2 (two FMAs).  F moves by at most aff * lip per unit of either input (lip >= |G| and |d rho / d n|, from the table).
+//   fast    s: 2 roundings (2.01 u relative, G moves by |s G'(s)| per relative unit: dB);  the row: truncated tail (tailU) + coefficients rounded to double +
+//           6 FMAs (13 u of sum |g_j| |eps|^j: rhoB);  x G, y G: u each;  the affine map without the principal point (it cancels against the mean): 2 more
+//   ref     atan's argument and atan itself (12 u S' generously: ocml / glibc stay within 2 ulp) + 24 roundings of the Horner chain, 2 divisions, 2 products
+//           (96 u S) + the affine map with the principal point (8 u (|u0| + |v0|));   S = sum |invP_i| (pi/2)^i,  S' = sum i |invP_i| (pi/2)^(i-1)
+//   mean    the same per-point bound, plus the order of the sum: reference npoints - 1 sequential additions and a division, fast 2 NB - 1 per lane, 6 shuffle
+//           levels and a product -> (npoints + 2 NB + 7) u Umax, Umax = 16384 + 4096 (enforced by the kernel)
+//   minus   reference: one rounding of a value below 8192;  fast: the subtraction happens in fixed point (coordinate + (1.5 * 2^20 + 0.5 - mean), two
+//           roundings of 2^-33 each)
+// Returns +inf for a camera the fast arithmetic cannot serve (p0 = 0, non-finite coefficients, a table that fails its own check).
+static double describe_fast_bound(const mcs_ocam& m, int npoints, const GTabInfo& g) {
 	const double u = 1.1102230246251565e-16, hp = 1.5707963267948966;
 	double S = 0, Sp = 0, pw = 1.0;
 	for (int i = 0; i < m.invP_deg; ++i) {
@@ -109,13 +191,14 @@ static double describe_fast_bound(const mcs_ocam& m, int npoints, double tabTail
 		if (i + 1 < m.invP_deg) Sp += (i + 1) * std::fabs(m.invP[i + 1]) * pw;
 		pw *= hp;
 	}
-	if (!(std::fabs(m.p[0]) > 1e-300) || !std::isfinite(m.p[0]) || !std::isfinite(1.0 / m.p[0]) || !std::isfinite(tabTail)) return INFINITY;
-	if (!std::isfinite((double)kRhoK / m.p[0]) || !std::isfinite((double)kRhoK * m.p[0])) return INFINITY;
+	if (!(std::fabs(m.p[0]) > 1e-300) || !std::isfinite(m.p[0]) || !std::isfinite(g.tailU) || !std::isfinite(g.rhoB) || !std::isfinite(g.dB) || !std::isfinite(g.lip)) return INFINITY;
 	const double aff = 1.0 + std::fabs(m.c) + std::fabs(m.d) + std::fabs(m.e), pp = 8 * u * (std::fabs(m.u0) + std::fabs(m.v0));
-	const double fast = aff * (tabTail + 1e-14 * Sp + 64 * u * 1.1 * S) + pp;
-	const double ref = aff * (8 * u * Sp + 96 * u * S) + pp;
-	const double point = fast + ref;
-	const double total = 2 * point + (npoints + 16) * u * 20480.0 + 4 * u * 8192.0;
+	const int nb = npoints / 128;
+	const double inputs = aff * g.lip * (2 * (2 + 3) * u * 4096.0 * 1.01);
+	const double fast = aff * (g.tailU + 16 * u * g.rhoB + 2.01 * u * g.dB);
+	const double ref = aff * (12 * u * Sp + 96 * u * S) + pp;
+	const double point = inputs + fast + ref;
+	const double total = 2 * point + (npoints + 2 * nb + 7) * u * 20480.0 + 2 * u * 8192.0 + 2.3283064365386963e-10 * 1.001;
 	return std::isfinite(total) ? total : INFINITY;
 }
 
@@ -140,12 +223,12 @@ struct mcs_extractor {
 	OcamDev* d_cams = nullptr;
 	std::vector<OcamDev> h_cams;
 	// descriptor passes (mcs_describe.hip): fallback list of the fast pass, its running total, the guard band
-	int* d_fbCount = nullptr; uint32_t* d_fbList = nullptr; unsigned long long* d_fbStats = nullptr; KpAux* d_aux = nullptr;
+	int* d_fbCount = nullptr; uint32_t *d_fbList = nullptr, *d_preList = nullptr; unsigned long long* d_fbStats = nullptr; void* d_aux = nullptr;   // d_fbCount: [0] fallback list, [1] pre-list
 	int describeMode = 0; double guardEps = kDefaultGuardEps;
 	// rho tables of the cameras seen so far (a rig has a handful), and the per-image copy the fast pass reads
-	struct CamFast { OcamDev key; double tail; std::vector<double> tab; };
+	struct CamFast { OcamDev key; GTabInfo info; std::vector<double> tab; };
 	std::vector<CamFast> camCache;
-	double* d_rhoTab = nullptr;
+	double* d_gTab = nullptr;
 	// host-kind input staging: the caller's image / mask block as it lies in host memory (same pitch and stride), grown on demand
 	uint8_t *d_inImg = nullptr, *d_inMask = nullptr; size_t inImgCap = 0, inMaskCap = 0;
 	// host-kind output staging
@@ -185,6 +268,8 @@ int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
 		HIPCHK(hipEventCreateWithFlags(&c->evBlur, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&c->evMatch, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&c->evGreedy, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&c->evDescFork, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&c->evDescJoin, hipEventDisableTiming));
 		for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&c->evSearch[i], hipEventDisableTiming));
 	}
 	*out = c;
@@ -229,6 +314,7 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 		(void)hipStreamDestroy(c->side2);
 		for (int i = 0; i < 4; ++i) if (c->evSearch[i]) (void)hipEventDestroy(c->evSearch[i]);
 		(void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evPyr1); (void)hipEventDestroy(c->evPyr); (void)hipEventDestroy(c->evBlur); (void)hipEventDestroy(c->evMatch); (void)hipEventDestroy(c->evGreedy);
+		(void)hipEventDestroy(c->evDescFork); (void)hipEventDestroy(c->evDescJoin);
 		(void)hipStreamDestroy(c->side);
 	}
 	if (c->ownStream) (void)hipStreamDestroy(c->stream);
@@ -435,11 +521,13 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	ALLOC(e->d_selCount, B * nl * sizeof(int));
 	ALLOC(e->d_status, sizeof(int));
 	ALLOC(e->d_cams, B * sizeof(OcamDev));
-	ALLOC(e->d_fbCount, sizeof(int));
-	ALLOC(e->d_fbList, B * (size_t)((hd.kpCap + 3) / 4 * 4) * sizeof(uint32_t));
+	const size_t slotsPerImage = (size_t)(hd.kpCap + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
+	ALLOC(e->d_fbCount, 2 * sizeof(int));
+	ALLOC(e->d_fbList, B * slotsPerImage * sizeof(uint32_t));
+	ALLOC(e->d_preList, B * slotsPerImage * sizeof(uint32_t));
 	ALLOC(e->d_fbStats, sizeof(unsigned long long));
-	ALLOC(e->d_aux, B * (size_t)((hd.kpCap + 3) / 4 * 4) * describe_aux_bytes());
-	ALLOC(e->d_rhoTab, B * (size_t)kRhoTabDoubles * sizeof(double));
+	ALLOC(e->d_aux, B * slotsPerImage * describe_aux_bytes());
+	ALLOC(e->d_gTab, B * (size_t)kGTabDoubles * sizeof(double));
 	ALLOC(e->d_nkp, B * sizeof(int));
 	ALLOC(e->d_kps, B * hd.kpCap * sizeof(mcs_keypoint));
 	ALLOC(e->d_odesc, B * hd.kpCap * (size_t)hd.descSize);
@@ -451,7 +539,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	if (!taps.empty()) HIPCHK(hipMemcpy(e->d_taps, taps.data(), sizeof(ResizeTap) * taps.size(), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(e->d_maskMap, maps.data(), sizeof(short) * maps.size(), hipMemcpyHostToDevice));
 	HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
-	HIPCHK(hipMemset(e->d_fbCount, 0, sizeof(int)));
+	HIPCHK(hipMemset(e->d_fbCount, 0, 2 * sizeof(int)));
 	HIPCHK(hipMemset(e->d_fbStats, 0, sizeof(unsigned long long)));
 	if (getenv("MCS_DESCRIBE_EXACT")) e->describeMode = 1;   // A/B and debugging: the exact pass for every keypoint
 	HIPCHK(hipMemset(e->d_pyr, 0, B * hd.pyrBytes));
@@ -471,7 +559,7 @@ int mcs_extractor_destroy(mcs_extractor* e) {
 	}
 	void* ptrs[] = {e->d_desc, e->d_cells, e->d_taps, e->d_maskMap, e->d_pyr, e->d_blur, e->d_slots, e->d_dense, e->d_knode,
 	                e->d_sel, e->d_cellCount, e->d_denseCount, e->d_selCount, e->d_status, e->d_cams, e->d_nkp, e->d_kps, e->d_odesc,
-	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_fbStats, e->d_aux, e->d_rhoTab};
+	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_preList, e->d_fbStats, e->d_aux, e->d_gTab};
 	for (void* p : ptrs) (void)hipFree(p);
 	delete e;
 	return MCS_OK;
@@ -520,7 +608,9 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 	b.desc = e->d_desc; b.cells = e->d_cells; b.taps = e->d_taps; b.maskMap = e->d_maskMap;
 	b.pyr = e->d_pyr; b.blur = e->d_blur; b.slots = e->d_slots; b.cellCount = e->d_cellCount; b.dense = e->d_dense; b.knode = e->d_knode;
 	b.denseCount = e->d_denseCount; b.sel = e->d_sel; b.selCount = e->d_selCount; b.status = e->d_status;
-	b.rhoTab = e->d_rhoTab; b.aux = e->d_aux; b.fbCount = e->d_fbCount; b.fbList = e->d_fbList; b.fbStats = e->d_fbStats; b.guardEps = e->guardEps; b.describeMode = e->describeMode;
+	b.gTab = e->d_gTab; b.aux = e->d_aux; b.fbCount = e->d_fbCount; b.fbList = e->d_fbList; b.preCount = e->d_fbCount + 1; b.preList = e->d_preList;
+	b.fbStats = e->d_fbStats; b.guardEps = e->guardEps; b.describeMode = e->describeMode;
+	b.sideStream = nullptr; b.evDescFork = nullptr; b.evDescJoin = nullptr;
 	b.outImgPitch = out_image_pitch_rows ? out_image_pitch_rows : (size_t)hd.kpCap;
 	b.outRowStride = out_row_stride ? out_row_stride : hd.descSize;
 	if (b.outImgPitch < (size_t)hd.kpCap || b.outRowStride < hd.descSize) return fail(MCS_ERR_INVALID, "output image pitch / row stride smaller than the rows they hold");
@@ -556,7 +646,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 	}
 	if (cams) {
 		std::vector<OcamDev> hc(nimg);
-		std::vector<int> which(nimg);
+		std::vector<int> which(nimg), uniq;   // uniq: the cache entries this batch uses, in order of first use (their tables are uploaded once each)
 		for (int i = 0; i < nimg; ++i) {
 			const mcs_ocam& m = cams[i];
 			if (m.p_deg < 1 || m.p_deg > MCS_MAX_POLY || m.invP_deg < 1 || m.invP_deg > MCS_MAX_POLY) return fail(MCS_ERR_INVALID, "bad polynomial degree");
@@ -572,25 +662,25 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 			if (w < 0) {
 				// (no eviction here: which[] of the earlier images of this batch indexes the cache — it is trimmed after the batch's tables are copied)
 				mcs_extractor::CamFast cf;
-				cf.key = o; cf.tab.assign(kRhoTabDoubles, 0.0);
-				cf.tail = build_rho_table(m, cf.tab.data());
-				if (!std::isfinite(cf.tail)) cf.tab.assign(kRhoTabDoubles, 0.0);
+				cf.key = o; cf.tab.assign(kGTabDoubles, 0.0);
+				cf.info = build_g_table(m, cf.tab.data());
+				if (!std::isfinite(cf.info.tailU)) cf.tab.assign(kGTabDoubles, 0.0);
 				e->camCache.push_back(std::move(cf));
 				w = (int)e->camCache.size() - 1;
 			}
 			which[i] = w;
-			const double bound = describe_fast_bound(m, hd.npoints, e->camCache[w].tail);
+			const double bound = describe_fast_bound(m, hd.npoints, e->camCache[w].info);
 			o.fastOk = bound <= 0.5 * e->guardEps ? 1 : 0;   // a factor 2 between the worst case and the band
-			o.invP0 = o.fastOk ? 1.0 / m.p[0] : 0.0;
-			o.wK = o.fastOk ? (double)kRhoK / std::fabs(m.p[0]) : 0.0;
-			o.tK = o.fastOk ? (double)kRhoK * std::fabs(m.p[0]) : 0.0;
+			size_t up = std::find(uniq.begin(), uniq.end(), w) - uniq.begin();
+			if (up == uniq.size()) uniq.push_back(w);
+			o.tabIdx = (int)up;
 		}
 		if (e->h_cams.size() != hc.size() || memcmp(e->h_cams.data(), hc.data(), sizeof(OcamDev) * hc.size()) != 0) {
 			HIPCHK(hipStreamSynchronize(s));   // the previous batch may still read d_cams / d_rhoTab
 			HIPCHK(hipMemcpy(e->d_cams, hc.data(), sizeof(OcamDev) * hc.size(), hipMemcpyHostToDevice));
-			std::vector<double> tabs((size_t)nimg * kRhoTabDoubles);
-			for (int i = 0; i < nimg; ++i) memcpy(&tabs[(size_t)i * kRhoTabDoubles], e->camCache[which[i]].tab.data(), kRhoTabDoubles * sizeof(double));
-			HIPCHK(hipMemcpy(e->d_rhoTab, tabs.data(), tabs.size() * sizeof(double), hipMemcpyHostToDevice));
+			std::vector<double> tabs(uniq.size() * (size_t)kGTabDoubles);
+			for (size_t i = 0; i < uniq.size(); ++i) memcpy(&tabs[i * kGTabDoubles], e->camCache[uniq[i]].tab.data(), kGTabDoubles * sizeof(double));
+			HIPCHK(hipMemcpy(e->d_gTab, tabs.data(), tabs.size() * sizeof(double), hipMemcpyHostToDevice));
 			e->h_cams = hc;
 		}
 		if (e->camCache.size() > 64) e->camCache.clear();   // a rig has a handful of cameras; a caller that streams distinct models rebuilds (which[] is dead here)
@@ -621,6 +711,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		c->tic("octree"); launch_octree(b, hd, nimg, s); c->toc("octree");
 		c->tic("blur"); launch_blur(b, hd, nimg, s); c->toc("blur");
 	}
+	if (c->overlap()) { b.sideStream = c->side; b.evDescFork = c->evDescFork; b.evDescJoin = c->evDescJoin; }   // the side stream is idle again: the main stream has waited for the blur
 	c->tic("describe"); launch_describe(b, hd, nimg, s); c->toc("describe");
 	HIPCHK(hipGetLastError());
 	e->last = b; e->lastN = nimg;
@@ -683,8 +774,21 @@ int mcs_extractor_describe_stats(mcs_extractor* e, uint64_t* exact_pass_keypoint
 
 int mcs_describe_fast_bound(const mcs_ocam* cam, int desc_size, double* bound) {
 	if (!cam || !bound || cam->invP_deg < 1 || cam->invP_deg > MCS_MAX_POLY || cam->p_deg < 1) return fail(MCS_ERR_INVALID, "bad argument");
-	std::vector<double> tab(kRhoTabDoubles, 0.0);
-	*bound = describe_fast_bound(*cam, 2 * 8 * desc_size, build_rho_table(*cam, tab.data()));
+	std::vector<double> tab(kGTabDoubles, 0.0);
+	*bound = describe_fast_bound(*cam, 2 * 8 * desc_size, build_g_table(*cam, tab.data()));
+	return MCS_OK;
+}
+
+int mcs_describe_fast_table(const mcs_ocam* cam, double* table, int* rows, int* row_len, int* e0, int* bins_per_octave, double* info5) {
+	if (!cam || cam->invP_deg < 1 || cam->invP_deg > MCS_MAX_POLY || cam->p_deg < 1) return fail(MCS_ERR_INVALID, "bad argument");
+	std::vector<double> tab(kGTabDoubles, 0.0);
+	const GTabInfo g = build_g_table(*cam, tab.data());
+	if (table) memcpy(table, tab.data(), tab.size() * sizeof(double));
+	if (rows) *rows = kGRows;
+	if (row_len) *row_len = kGRow;
+	if (e0) *e0 = kGE0;
+	if (bins_per_octave) *bins_per_octave = 1 << kGM;
+	if (info5) { info5[0] = g.tailU; info5[1] = g.rhoB; info5[2] = g.dB; info5[3] = g.lip; info5[4] = g.seen; }
 	return MCS_OK;
 }
 
@@ -697,18 +801,17 @@ int mcs_selftest_describe_fast(mcs_ctx* c, const mcs_ocam* cam, uint64_t seed, i
 	o.c = cam->c; o.d = cam->d; o.e = cam->e; o.u0 = cam->u0; o.v0 = cam->v0; o.invAffine = cam->c - cam->d * cam->e;
 	for (int k = 0; k < cam->p_deg; ++k) o.p[k] = cam->p[k];
 	for (int k = 0; k < cam->invP_deg; ++k) o.invP[k] = cam->invP[k];
-	o.p_deg = cam->p_deg; o.invP_deg = cam->invP_deg; o.invP0 = 1.0 / cam->p[0]; o.fastOk = 1;
-	o.wK = (double)kRhoK / std::fabs(cam->p[0]); o.tK = (double)kRhoK * std::fabs(cam->p[0]);
-	std::vector<double> tab(kRhoTabDoubles, 0.0);
-	if (!std::isfinite(build_rho_table(*cam, tab.data()))) return fail(MCS_ERR_UNSUPPORTED, "the fast pass does not serve this camera");
+	o.p_deg = cam->p_deg; o.invP_deg = cam->invP_deg; o.fastOk = 1;
+	std::vector<double> tab(kGTabDoubles, 0.0);
+	if (!std::isfinite(build_g_table(*cam, tab.data()).tailU)) return fail(MCS_ERR_UNSUPPORTED, "the fast pass does not serve this camera");
 	uint8_t* buf = nullptr;
 	HIPCHK(hipStreamSynchronize(c->stream));
 	const size_t tabOff = (64 + sizeof(OcamDev) + 63) / 64 * 64;
-	HIPCHK(ctx_arena(c, tabOff + kRhoTabDoubles * sizeof(double), &buf));
+	HIPCHK(ctx_arena(c, tabOff + kGTabDoubles * sizeof(double), &buf));
 	unsigned long long zero = 0, got = 0;
 	HIPCHK(hipMemcpy(buf, &zero, sizeof(zero), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(buf + 64, &o, sizeof(o), hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(buf + tabOff, tab.data(), kRhoTabDoubles * sizeof(double), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(buf + tabOff, tab.data(), kGTabDoubles * sizeof(double), hipMemcpyHostToDevice));
 	launch_selftest_fast_model((const OcamDev*)(buf + 64), (const double*)(buf + tabOff), seed, n, cam->width, cam->height, (unsigned long long*)buf, c->stream);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(c->stream));

@@ -61,17 +61,41 @@ struct OcamDev {
 	double p[MCS_MAX_POLY];
 	double invP[MCS_MAX_POLY];
 	int p_deg, invP_deg;
-	// fast pass of the descriptor kernel (mcs_describe.hip): 1 / p[0], and whether this camera's worst-case arithmetic difference stays below the guard band
-	double invP0;
-	int fastOk, pad_;
-	double wK, tK;          // kRhoK / |p0| and kRhoK * |p0|: |norm / p0| and |p0 / norm| in bins of the rho table
+	// fast pass of the descriptor kernel (mcs_describe.hip): whether this camera's worst-case arithmetic difference stays below the guard band
+	int fastOk;
+	int tabIdx;             // this camera's G table among the batch's distinct tables (ExtractBuffers.gTab)
 };
 
-// Per-camera table of rho(theta(a)) for the fast descriptor pass: two halves (theta = +-pi/2 - atan a for |norm / p0| < 1, theta = atan a otherwise), each
-// kRhoBins rows of kRhoRow Taylor coefficients in (|a| * kRhoK - bin).  Built by build_rho_table() in mcs_capi.hip, which also bounds the truncated tail.
-constexpr int kRhoK = 64, kRhoDeg = 5, kRhoBins = kRhoK + 1, kRhoRow = kRhoDeg + 1, kRhoTabDoubles = 2 * kRhoBins * kRhoRow;
+// Per-camera table of G(s) = rho(theta(s)) / sqrt(s), s = x^2 + y^2 the squared norm of an undistorted pattern point, theta = atan(p0 / sqrt(s)), for the
+// fast descriptor pass: u, v = affine(x * G, y * G) needs neither the square root, the reciprocal nor atan.  Log-spaced bins: row = exponent and top kGM
+// mantissa bits of s (read from the bit pattern), s in [2^kGE0, 2^kGE1); a row holds the degree-kGDeg Taylor coefficients of G about the bin centre in the
+// variable tau = (low mantissa fraction of s) - 2^-(kGM+1), which is exact.  Built by build_g_table() in mcs_capi.hip, which also bounds the truncated tail.
+#ifndef MCS_G_M
+#define MCS_G_M 5     // 32 bins per octave, degree 6: 56-byte rows, 54 KB (64 bins, degree 5: 48-byte rows, 0.675 against 0.696 ms, but 92 KB for the same range; 16 bins, degree 8: 0.753 ms)
+#define MCS_G_DEG 6
+#endif
+constexpr int kGM = MCS_G_M, kGDeg = MCS_G_DEG, kGE0 = -6, kGE1 = 24, kGRows = (kGE1 - kGE0) << kGM, kGRow = kGDeg + 1, kGTabDoubles = kGRows * kGRow;
+// The table starts at s = 2^kGE0, i.e. 1/8 pixel from the optical axis: G has a sqrt-type branch point at s = 0 (rho(theta) of a fitted backward polynomial
+// does not vanish exactly on the axis), so only log-spaced bins reach down there.  One keypoint in 200 has the axis inside its pattern's footprint, and of
+// those one in 20 a point within 1/8 px of it: that keypoint takes the exact pass.  (Starting the table at s = 16 sent 1 % of all keypoints there.)
+constexpr int kSlotAlign = 8;       // keypoint slots per image are a multiple of this (the fast pass walks groups of 8 keypoints of ONE image, a wave each)
 
-struct KpAux;   // per-keypoint scratch of the descriptor passes (mcs_describe.hip)
+// Per-keypoint scratch of the descriptor passes (mcs_describe.hip), one array per field over all keypoint slots of the batch (thread-per-keypoint kernels
+// write full cache lines).  lvl: -1 no keypoint, else level | kAuxExact if the keypoint is on the exact pass's list already.
+constexpr int kAuxExact = 0x100;
+struct KpAuxSoA {
+	int* lvl; int* rc;                  // level / flags;  row | col << 16
+	float* ang; float* pxf; float* pyf; // orientation, keypoint in image coordinates
+	double* d8;                         // [8][slots]: undistorted keypoint x, y; cos, sin of the (up to) three pattern angles
+	int slots;
+	__host__ __device__ static size_t bytes_per_slot() { return 2 * sizeof(int) + 3 * sizeof(float) + 8 * sizeof(double); }
+	__host__ __device__ void carve(void* base, int nslots) {   // nslots is a multiple of kSlotAlign
+		slots = nslots;
+		d8 = reinterpret_cast<double*>(base);
+		lvl = reinterpret_cast<int*>(d8 + (size_t)8 * nslots); rc = lvl + nslots;
+		ang = reinterpret_cast<float*>(rc + nslots); pxf = ang + nslots; pyf = pxf + nslots;
+	}
+};
 struct ExtractBuffers {
 	const PyrDesc* desc;          // device copy
 	const CellInfo* cells;        // [cellsPerImage]
@@ -91,10 +115,12 @@ struct ExtractBuffers {
 	const OcamDev* cams;          // [B] or nullptr
 	int* status;                  // device error word (capacity overflows)
 	// dBRIEF / mdBRIEF: fast pass + exact pass over the fast pass's fallback list (mcs_describe.hip)
-	const double* rhoTab;                // [B][kRhoTabDoubles] the images' camera tables
-	KpAux* aux;                          // [B][roundup4(kpCap)] orientation / ray / pattern-angle records prepared for the fast pass
+	const double* gTab;                  // [distinct cameras of the batch][kGTabDoubles], indexed by OcamDev.tabIdx
+	void* aux;                           // KpAuxSoA over [B][roundup(kpCap, kSlotAlign)] slots: orientation / undistorted keypoint / pattern angles for the fast pass
 	int* fbCount; uint32_t* fbList;      // keypoint slots (image * wavesPerImage + slot) the fast pass handed to the exact pass, this batch
-	unsigned long long* fbStats;         // running total of those (all batches of the extractor)
+	int* preCount; uint32_t* preList;    // ... and the ones k_orient_b sent there before the fast pass ran (camera not served, keypoint next to the optical axis)
+	unsigned long long* fbStats;         // running total of both (all batches of the extractor)
+	hipStream_t sideStream; hipEvent_t evDescFork, evDescJoin;   // optional: the exact pass over preList runs here, beside the fast pass
 	double guardEps;                     // half-width of the guard band around the rounding ties
 	int describeMode;                    // 0 fast + exact fallback, 1 exact pass for every keypoint
 	// outputs
@@ -114,7 +140,7 @@ void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream
 void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0 = 0, int level1 = MCS_MAX_LEVELS);
 void launch_blur(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
 void launch_describe(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);
-size_t describe_aux_bytes();   // sizeof(KpAux)
+size_t describe_aux_bytes();   // scratch bytes per keypoint slot
 
 // Row i of a descriptor set -> row of the caller's array.  A set is either contiguous (blk = 0) or made of blocks of `blk` rows lying `bpitch` rows
 // apart (mcs_desc_set.block_rows / block_pitch_rows: the cameras of one multi-frame inside a gathered [camera][frame][row] buffer).

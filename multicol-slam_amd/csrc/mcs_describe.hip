@@ -532,37 +532,38 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe_wide(ExtractB
 	describe_wave<MODE, NB>(b, wavesPerImage, lds, blockIdx.x * (MODE == 0 ? 4 : 1) + (threadIdx.x >> 6));
 }
 
-// The exact pass over the fallback list of the fast pass (one wave per block, blocks stride over the list; the list is empty most of the time).
+// The exact pass over a list of keypoint slots (one wave per block, blocks stride over the list; the lists are short): the fast pass's fallback list, and the
+// pre-list k_orient_b fills.
 template <int MODE, int NB>
-__global__ __launch_bounds__(64) void k_describe_list(ExtractBuffers b, int wavesPerImage) {
+__global__ __launch_bounds__(64) void k_describe_list(ExtractBuffers b, int wavesPerImage, const int* count, const uint32_t* list) {
 	extern __shared__ __attribute__((aligned(16))) double lds[];
-	const int n = *b.fbCount;
+	const int n = *count;
 	if (blockIdx.x == 0 && threadIdx.x == 0 && b.fbStats) atomicAdd(b.fbStats, (unsigned long long)n);
-	for (int i = blockIdx.x; i < n; i += gridDim.x) describe_wave<MODE, NB>(b, wavesPerImage, lds, (int)b.fbList[i]);
+	for (int i = blockIdx.x; i < n; i += gridDim.x) describe_wave<MODE, NB>(b, wavesPerImage, lds, (int)list[i]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
-// The fast pass.  Same keypoint prologue, same pattern rotation angles (one sincos call serves the three pattern angles: lanes 0..2), then per
-// pattern point
+// The fast pass.  Same pattern rotation angles (prepared by k_orient_b), then per pattern point
 //      xr, yr   = rotation + undistorted keypoint                     (FMA form)
-//      r        = 1 / sqrt(xr^2 + yr^2)                               v_rsq_f64 (>= 2^-23 accurate... whatever its accuracy e0, the cubic step leaves ~e0^3)
-//      rho      = invP(atan(p0 / norm))                               from the camera's table: a = norm / p0 or p0 / norm (|a| <= 1), the bin's Taylor
-//                                                                     polynomial of rho(theta(a)) — degree kRhoDeg instead of a 17-term atan and the 11 FMAs of invP
-//      u, v     = affine(xr * rho / norm, yr * rho / norm)
+//      s        = xr^2 + yr^2
+//      G        = rho(atan(p0 / sqrt(s))) / sqrt(s)                   from the camera's table (mcs_common.h kG*): row = exponent and top mantissa bits of s,
+//                                                                     read from its bit pattern; the row's Taylor polynomial in the low mantissa fraction
+//                                                                     (exact) — no square root, no reciprocal, no atan, no backward polynomial
+//      u, v     = affine(xr * G, yr * G)                              without the principal point: it cancels against the pattern mean
 // and a wave tree sum for the mean.  None of this is the reference's rounding; it is only USED when every one of the keypoint's
 // 2 * npat * 2*8*descSize coordinates (minus the mean) stays clear of the rounding ties by more than the guard band b.guardEps, which the host keeps
 // above the worst-case difference between this arithmetic and the reference's (describe_fast_bound in mcs_capi.hip).  Otherwise the
-// keypoint goes to the exact pass.  NaN / Inf (norm = 0) fail the comparisons and take the same way out.
+// keypoint goes to the exact pass.  A point outside the table (s < 2^kGE0, s >= 2^kGE1, NaN / Inf) takes the same way out.
 #ifndef MCS_FAST_FENCE
 #define MCS_FAST_FENCE 4
 #endif
 #ifndef MCS_FAST_ABLATE
 #define MCS_FAST_ABLATE 0   // A/B experiments only (tools/ab_describe.sh): 1 no sampling, 2 no omni model, 4 no guard / rounding checks
 #endif
-#ifndef MCS_FAST_WPB
-#define MCS_FAST_WPB 4
+#ifndef MCS_FAST_WAVES
+#define MCS_FAST_WAVES 8
 #endif
-constexpr int kFastWaves = MCS_FAST_WPB;   // independent waves (keypoints) per workgroup of the fast pass
+constexpr int kFastWaves = MCS_FAST_WAVES;   // waves per workgroup of the fast pass (each with its own keypoints, all of one image): they share the camera's table in LDS
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -570,58 +571,73 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 	return v;
 }
 
-// one pattern point through the fast arithmetic.  rho(theta(a)) comes from a per-camera table (mcs_common.h kRho*: built by the host in long double,
-// its truncation error bounded there): a = norm / p0 where |norm / p0| < 1 (theta = +-pi/2 - atan a), else a = p0 / norm (theta = atan a); |a| <= 1 is
-// cut into kRhoK bins, x = |a| * kRhoK, the bin is rint(x) (its low mantissa bits after adding 1.5 * 2^52), and the row holds the Taylor coefficients
-// of rho in (x - bin), degree kRhoDeg.  x - bin is exact, so the only approximation is the truncated tail.
-struct FastCam { double c, d, e, u0, v0, wK, tK; };
+// Both coordinate sums of a pattern over the wave, on the VALU (the ds_bpermute form above is six dependent LDS round trips per sum): the halves of the
+// wave exchange so that lanes 0..31 carry x partial sums and lanes 32..63 y partial sums (v_permlane32_swap), the row pairs are folded
+// (v_permlane16_swap) and the 16 lanes of a row by four DPP rotations; the totals are read back as wave-uniform scalars.  A balanced tree of depth 6 per
+// sum, like the shuffle form (describe_fast_bound counts its roundings, not its order).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wave_sum2_f64(double sx, double sy, double& totx, double& toty) {
+	// lanes < 32: x.lo + x.hi ; lanes >= 32: y.lo + y.hi        (v_permlane32_swap: lanes 32..63 of the first operand <-> lanes 0..31 of the second)
+	const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(sx), __double2loint(sy), false, false);
+	const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(sx), __double2hiint(sy), false, false);
+	double z = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+	// rows (16 lanes) 0 + 1 and 2 + 3                             (v_permlane16_swap: odd rows of the first operand <-> even rows of the second)
+	const auto l2 = __builtin_amdgcn_permlane16_swap(__double2loint(z), __double2loint(z), false, false);
+	const auto h2 = __builtin_amdgcn_permlane16_swap(__double2hiint(z), __double2hiint(z), false, false);
+	z = __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+	z += dpp_f64<0x128>(z);   // row_ror:8
+	z += dpp_f64<0x124>(z);   // row_ror:4
+	z += dpp_f64<0x122>(z);   // row_ror:2
+	z += dpp_f64<0x121>(z);   // row_ror:1
+	totx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(z), 0), __builtin_amdgcn_readlane(__double2loint(z), 0));
+	toty = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(z), 32), __builtin_amdgcn_readlane(__double2loint(z), 32));
+}
+
+// one pattern point through the fast arithmetic; `bad` collects points the table does not cover.  (Requesting the row of point t + 1 before the Horner
+// chain of point t — a hand-made software pipeline — was built and measured: 0.712 against 0.705 ms, not kept.)
+struct FastCam { double c, d, e; };
 template <class Tab>
-__device__ __forceinline__ void fast_w2i(const FastCam& C, Tab tab, double xr, double yr, double& u, double& v) {
-	const double n2 = __builtin_fma(xr, xr, yr * yr);
-	const double r0 = __builtin_amdgcn_rsq(n2);
-	const double e1 = __builtin_fma(-(n2 * r0), r0, 1.0);                          // 1 - n2 * r0^2
-	const double r = __builtin_fma(r0 * e1, __builtin_fma(e1, 0.375, 0.5), r0);     // r0 * (1 + e/2 + 3e^2/8)
-	const double norm = n2 * r;
-	const double wq = norm * C.wK, tq = C.tK * r;                                   // |norm / p0| * kRhoK,  |p0 / norm| * kRhoK
-	const bool small = wq < (double)kRhoK;
-	const double x = small ? wq : tq;
-	const double sft = x + 0x1.8p52;
-	const double dx = x - (sft - 0x1.8p52);
-	int bin = (int)(unsigned)__double_as_longlong(sft);
-	bin = bin < 0 ? 0 : (bin > kRhoK ? kRhoK : bin);                                // NaN / overflow cannot index outside the table (they fail the guard later)
-	const auto g = tab + (small ? 0 : kRhoBins * kRhoRow) + bin * kRhoRow;
-	double gc[kRhoRow];
+__device__ __forceinline__ void fast_w2i(const FastCam& C, Tab tab, double xr, double yr, double& u, double& v, bool& bad) {
+	const double s = __builtin_fma(xr, xr, yr * yr);
+	const unsigned hi = (unsigned)__double2hiint(s), lo = (unsigned)__double2loint(s);
+	const unsigned idx = (hi >> (20 - kGM)) - (unsigned)((1023 + kGE0) << kGM);            // (exponent - kGE0) * 2^kGM + top kGM mantissa bits
+	bad |= idx >= (unsigned)kGRows;                                                       // below / above the table, negative, NaN, Inf
+	unsigned row = idx < (unsigned)kGRows ? idx : (unsigned)(kGRows - 1);
+	if (MCS_FAST_ABLATE & 16) row = 0;   // A/B: every lane reads the same row (LDS broadcast: no bank conflicts, no gather)
+	const double frac = __hiloint2double((int)((hi & ((1u << (20 - kGM)) - 1u)) | 0x3FF00000u), (int)lo);   // 1 + the mantissa bits below the bin index
+	const double tau = frac - (1.0 + 1.0 / (double)(2 << kGM));                           // exact
+	const auto g = tab + row * kGRow;
+	double gc[kGRow];
 #pragma unroll
-	for (int i = 0; i < kRhoRow; ++i) gc[i] = g[i];
-	double rho = gc[kRhoDeg];
+	for (int i = 0; i < kGRow; ++i) gc[i] = g[i];
+	double G = gc[kGDeg];
 #pragma unroll
-	for (int i = kRhoDeg - 1; i >= 0; --i) rho = __builtin_fma(rho, dx, gc[i]);
-	const double gg = rho * r;
-	const double uu = xr * gg, vv = yr * gg;
-	u = __builtin_fma(uu, C.c, __builtin_fma(vv, C.d, C.u0));
-	v = __builtin_fma(uu, C.e, vv + C.v0);
+	for (int i = kGDeg - 1; i >= 0; --i) G = __builtin_fma(G, tau, gc[i]);
+	const double uu = xr * G, vv = yr * G;
+	u = __builtin_fma(uu, C.c, vv * C.d);
+	v = __builtin_fma(uu, C.e, vv);
 }
 
 // ---- what the fast pass needs per keypoint besides the patch, prepared by two small kernels at full occupancy --------------------------------------
 // The fast pass runs 4 waves per SIMD (registers), and a wave used to spend a quarter of its instructions on work that is either only 33 lanes wide
 // (IC_Angle) or identical in all 64 lanes (ImgToWorld of the keypoint, the sincos of the pattern angles).  Now
-//   k_orient_a   one wave per output row: slot -> (level, position), IC_Angle, the keypoint record (E8), row / column / angle into KpAux
-//   k_orient_b   one THREAD per output row: ImgToWorld (ray, E9), the undistorted keypoint, the pattern angles and their sin / cos into KpAux
-// The arithmetic is the exact pass's, statement for statement (the exact pass still does all of it itself and writes the same values).
-struct KpAux {
-	int level;            // -1: no keypoint in this slot
-	int row, col;
-	float angle, pxf, pyf;
-	int pad_[2];
-	double ray[3];
-	double ukx, uky;
-	double cs[6];         // cos, sin of the (up to) three pattern angles
-};
+//   k_orient_a   4 keypoints per wave: slot -> (level, position), IC_Angle, the keypoint record (E8), row / column / angle into the scratch arrays
+//   k_orient_b   one THREAD per output row: ImgToWorld (ray, E9), the undistorted keypoint, the pattern angles and their sin / cos; it also decides which
+//                keypoints the fast pass cannot serve at all (camera beyond the band, non-finite undistorted position) and puts them on the exact
+//                pass's pre-list, which runs BESIDE the fast pass
+// The arithmetic is the exact pass's, statement for statement (the exact pass still does all of it itself and writes the same values).  The scratch is one
+// array per field (KpAuxSoA): a thread-per-keypoint kernel then writes whole cache lines (120-byte records cost 2.3x their size in HBM writes).
 
 // Four keypoints per wave (16 lanes each: lane j of a group owns disc rows j - 16, j and — lane 0 — 16): a wave per keypoint spent its life waiting
 // for three dependent memory round trips (counts -> record -> pixels) with 33 busy lanes.
 __global__ __launch_bounds__(256) void k_orient_a(ExtractBuffers b, int wavesPerImage, int nslots) {
 	const PyrDesc& d = *b.desc;
+	KpAuxSoA A; A.carve(b.aux, nslots);
 	const int lane = threadIdx.x & 63, j = lane & 15;
 	const int gw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
 	const bool inRange = gw < nslots;
@@ -634,8 +650,7 @@ __global__ __launch_bounds__(256) void k_orient_a(ExtractBuffers b, int wavesPer
 		if (total > d.kpCap) atomicExch(b.status, MCS_ERR_CAPACITY);
 	}
 	const bool active = inRange && level >= 0 && s < d.kpCap;
-	KpAux* aux = b.aux + gwc;
-	if (inRange && !active && j == 0) aux->level = -1;
+	if (inRange && !active && j == 0) A.lvl[gwc] = -1;
 	const int lv = active ? level : 0;
 	const LevelInfo& L = d.lv[lv];
 	uint32_t rec = 0;
@@ -678,33 +693,42 @@ __global__ __launch_bounds__(256) void k_orient_a(ExtractBuffers b, int wavesPer
 	mcs_keypoint kp;
 	kp.x = pxf; kp.y = pyf; kp.size = L.kpSize; kp.angle = angle; kp.response = (float)(rec >> 24); kp.octave = level; kp.class_id = -1;
 	b.kps[(size_t)img * d.kpCap + s] = kp;
-	aux->level = level; aux->row = row; aux->col = col; aux->angle = angle; aux->pxf = pxf; aux->pyf = pyf;
+	A.lvl[gwc] = level; A.rc[gwc] = row | (col << 16); A.ang[gwc] = angle; A.pxf[gwc] = pxf; A.pyf[gwc] = pyf;
 }
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_orient_b(ExtractBuffers b, int wavesPerImage, int nslots) {
 	const int gw = blockIdx.x * 256 + threadIdx.x;
 	if (gw >= nslots) return;
-	KpAux* aux = b.aux + gw;
-	if (aux->level < 0) return;
+	KpAuxSoA A; A.carve(b.aux, nslots);
+	const int level = A.lvl[gw];
+	if (level < 0) return;
 	const PyrDesc& d = *b.desc;
 	const int img = gw / wavesPerImage, s = gw - img * wavesPerImage;
 	const OcamDev& cam = b.cams[img];
 	double rayx, rayy, rayz;
-	img2world(cam, (double)aux->pxf, (double)aux->pyf, rayx, rayy, rayz);
+	img2world(cam, (double)A.pxf[gw], (double)A.pyf[gw], rayx, rayy, rayz);
 	if (b.rays) {
 		double* rp = b.rays + ((size_t)img * d.kpCap + s) * 3;
 		rp[0] = rayx; rp[1] = rayy; rp[2] = rayz;
 	}
-	aux->ray[0] = rayx; aux->ray[1] = rayy; aux->ray[2] = rayz;
 	double ukx = 0.0, uky = 0.0;
 	if (d.undistort) {
 		const double p0 = cam.p[0];
 		ukx = -rayx / rayz * p0;
 		uky = -rayy / rayz * p0;
 	}
-	aux->ukx = ukx; aux->uky = uky;
-	const float angle = aux->angle;
+	double* D8 = A.d8 + gw;
+	const size_t S = (size_t)nslots;
+	D8[0] = ukx; D8[S] = uky;
+	// a camera beyond the guard band, or a keypoint whose undistorted position is not finite (a ray in the image plane): not for the fast pass
+	const double n2 = ukx * ukx + uky * uky;
+	if (cam.fastOk == 0 || !(n2 < 1.0e300)) {
+		A.lvl[gw] = level | kAuxExact;
+		b.preList[atomicAdd(b.preCount, 1)] = (uint32_t)gw;
+		return;   // the exact pass computes its own angles
+	}
+	const float angle = A.ang[gw];
 	double ang[3] = {0.0, 0.0, 0.0};
 	if (MODE == 1) {
 		const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
@@ -720,77 +744,60 @@ __global__ __launch_bounds__(256) void k_orient_b(ExtractBuffers b, int wavesPer
 	for (int k = 0; k < (MODE == 2 ? 3 : 1); ++k) {
 		double sn, cs;
 		sincos(ang[k], &sn, &cs);
-		aux->cs[2 * k] = cs; aux->cs[2 * k + 1] = sn;
+		D8[(2 + 2 * k) * S] = cs; D8[(3 + 2 * k) * S] = sn;
 	}
 }
 
 #ifndef MCS_FAST_WAVES_PER_EU
 #define MCS_FAST_WAVES_PER_EU 4
 #endif
+#ifndef MCS_FAST_BLOCKS
+#define MCS_FAST_BLOCKS 512   // 256 CUs x 2 resident workgroups
+#endif
+constexpr int kFastBlocks = MCS_FAST_BLOCKS;
+static_assert(kSlotAlign % kFastWaves == 0, "a group's keypoint slots must belong to one image");
+
+// The fast pass's sampler: the LDS patch serves practically every sample; the general path (blurred level / bordered raw level) looks its level up only
+// when it is taken, so that none of it occupies registers in the hot loop.
+struct LazySampler {
+	const ExtractBuffers* b; int img, level;
+	const uint8_t* patch;
+	__device__ __forceinline__ void pair(int row, int col, int dy0, int dx0, int dy1, int dx1, int& t0, int& t1) const {
+		const unsigned r0 = (unsigned)(dy0 + kPatchR), c0 = (unsigned)(dx0 + kPatchR), r1 = (unsigned)(dy1 + kPatchR), c1 = (unsigned)(dx1 + kPatchR);
+		const bool inside = max(max(r0, c0), max(r1, c1)) < (unsigned)kPatchRows;
+		if (!__any(!inside)) {
+			t0 = patch[r0 * kPatchPitch + c0];
+			t1 = patch[r1 * kPatchPitch + c1];
+		} else {
+			const PyrDesc& d = *b->desc;
+			const LevelInfo& L = d.lv[level];
+			Sampler sm;
+			int rstride;
+			sm.raw = level_ptr(*b, d, img, level, &rstride);
+			sm.rstride = rstride;
+			sm.blur = b->blur + (size_t)img * d.pyrBytes + L.off; sm.bstride = L.stride;
+			sm.w = L.w; sm.h = L.h;
+			sm.patch = patch; sm.prow = row - kPatchR; sm.pcol = col - kPatchR;
+			t0 = sm.at(row + dy0, col + dx0);
+			t1 = sm.at(row + dy1, col + dx1);
+		}
+	}
+};
+
+// One keypoint of the fast pass by one wave: the patch is in LDS, (ukx, uky) and the pattern angles' cos / sin come from k_orient_b.  Returns false if the
+// keypoint has to take the exact pass (a coordinate in the guard band, a point outside the table, out of range).
 template <int MODE, int NB>
-__attribute__((amdgpu_waves_per_eu(MCS_FAST_WAVES_PER_EU, MCS_FAST_WAVES_PER_EU)))
-__global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffers b, int wavesPerImage, int nslots) {
-	extern __shared__ __attribute__((aligned(16))) double lds[];   // the blurred patch of each wave's keypoint, then the camera's rho table (shared)
-	static_assert(MODE == 1 || MODE == 2, "the fast pass is for the distorted patterns");
-	static_assert(4 % kFastWaves == 0, "the waves of a block must belong to one image (slots per image are a multiple of 4)");
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int gw = blockIdx.x * kFastWaves + wave;
-	KeyPt kp_;
-	uint8_t* const patchLds = reinterpret_cast<uint8_t*>(lds) + (size_t)wave * kPatchBytes;
-	double* const tabLds = reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(lds) + (size_t)kFastWaves * kPatchBytes);
-	const PyrDesc& d = *b.desc;
-	// this keypoint, as the two orientation kernels left it (wave-uniform: scalar loads)
-	const int gwu = __builtin_amdgcn_readfirstlane(gw);
-	const bool inRange = gwu < nslots;
-	const KpAux& ax = b.aux[inRange ? gwu : 0];
-	const int level = inRange ? ax.level : -1;
-	kp_.img = gwu / wavesPerImage; kp_.out = gwu - kp_.img * wavesPerImage; kp_.level = level; kp_.row = ax.row; kp_.col = ax.col;
-	uint32_t pv[kPatchTrips];
-	if (level >= 0) {
-		const LevelInfo& L = d.lv[level];
-		Sampler& sm = kp_.sm;
-		int rstride;
-		sm.raw = level_ptr(b, d, kp_.img, level, &rstride);
-		sm.rstride = rstride;
-		sm.blur = b.blur + (size_t)kp_.img * d.pyrBytes + L.off; sm.bstride = L.stride;
-		sm.w = L.w; sm.h = L.h;
-		sm.patch = patchLds; sm.prow = kp_.row - kPatchR; sm.pcol = kp_.col - kPatchR;
-		patch_load(kp_.sm.blur, kp_.sm.bstride, kp_.row, kp_.col, pv);   // in flight while the table and the camera constants arrive
-	}
-	{   // the block's camera table (every wave of a block is a keypoint of the same image): 6 KB, both trips in flight before the first store
-		const int bimg = (int)(blockIdx.x * kFastWaves) / wavesPerImage;
-		const double2* gt = reinterpret_cast<const double2*>(b.rhoTab + (size_t)bimg * kRhoTabDoubles);
-		constexpr int n2 = kRhoTabDoubles / 2, trips = (n2 + 64 * kFastWaves - 1) / (64 * kFastWaves);
-		double2 tv[trips];
-#pragma unroll
-		for (int t = 0; t < trips; ++t) { const int i = t * 64 * kFastWaves + (int)threadIdx.x; tv[t] = i < n2 ? gt[i] : double2{0.0, 0.0}; }
-#pragma unroll
-		for (int t = 0; t < trips; ++t) { const int i = t * 64 * kFastWaves + (int)threadIdx.x; if (i < n2) reinterpret_cast<double2*>(tabLds)[i] = tv[t]; }
-	}
-	__syncthreads();
-	if (level < 0) return;
-	const OcamDev& cam = b.cams[kp_.img];
-	auto to_exact = [&]() { if (lane == 0) { const int at = atomicAdd(b.fbCount, 1); b.fbList[at] = (uint32_t)gwu; } };
-	if (cam.fastOk == 0) { to_exact(); return; }
-
-	FastCam C;
-	C.c = cam.c; C.d = cam.d; C.e = cam.e; C.u0 = cam.u0; C.v0 = cam.v0;
-	C.wK = cam.wK; C.tK = cam.tK;
-
+__device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const FastCam& C, const double* tabLds, const LazySampler& sm, int row, int col,
+                                              double ukx, double uky, const double (&axc)[3], const double (&ays)[3], const uint32_t (&ppk_)[NB],
+                                              unsigned long long (&bitsMain)[NB], unsigned long long (&agree)[NB]) {
 	constexpr int NP = 128 * NB;
-	uint32_t ppk[NB];
-#pragma unroll
-	for (int j = 0; j < NB; ++j) ppk[j] = reinterpret_cast<const uint32_t*>(c_pattern)[j * 64 + lane];
-	const double ukx = ax.ukx, uky = ax.uky;
-	double axc[3], ays[3];
-#pragma unroll
-	for (int k = 0; k < 3; ++k) { axc[k] = ax.cs[2 * k]; ays[k] = ax.cs[2 * k + 1]; }
-	patch_store(patchLds, pv);
-
-	const double lim = 0.5 - b.guardEps;
-	const int row = kp_.row, col = kp_.col;
-	const Sampler sm = kp_.sm;
-	unsigned long long bitsMain[NB], agree[NB];
+	// The rounding and its guard in fixed point: y = coordinate - mean + 1.5 * 2^20 + 0.5 lies in [2^20, 2^21) where one unit of the high word is one pixel and
+	// the low word is the fraction in units of 2^-32.  floor(y) is the rounded offset (ties are excluded by the guard), the fraction within guardUnits of 0 /
+	// 2^32 means the coordinate is within the band of a tie, and high word - hiword(1.5 * 2^20 - 4096) is offset + 4096, in [0, 8192) iff |offset| <= 4096
+	// (NaN, Inf and anything outside the binade give a huge value).  Costs two roundings of 2^-33 (describe_fast_bound adds them).
+	const double kFix = 1572864.5;                 // 1.5 * 2^20 + 0.5
+	const unsigned kHiBase = 0x4137F000u;          // high word of 1.5 * 2^20 - 4096
+	const unsigned guardUnits = (unsigned)__builtin_ceil(b.guardEps * 4294967296.0);
 #pragma unroll
 	for (int j = 0; j < NB; ++j) { bitsMain[j] = 0ull; agree[j] = ~0ull; }
 	constexpr int npat = MODE == 2 ? 3 : 1;
@@ -799,50 +806,148 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 		const double ax = axc[pat], ay = ays[pat];
 		double u[2 * NB], v[2 * NB];
 		double sumx = 0.0, sumy = 0.0;
+		bool bad = false;
+		// the packed pattern bytes are widened to double at the point of use, for every pattern and keypoint again: hoisted out of the loops the 4 NB doubles
+		// would cost 8 NB registers (the compiler does hoist them unless the packed words are opaque here, and then spills)
+		uint32_t ppk[NB];
 #pragma unroll
-		for (int t = 0; t < 2 * NB; ++t) {
+		for (int j = 0; j < NB; ++j) { ppk[j] = ppk_[j]; asm volatile("" : "+v"(ppk[j])); }
+		auto rotate = [&](int t, double& xr, double& yr) {
 			const int e = t & 1;
 			const double ptx = (double)(int)(signed char)(ppk[t >> 1] >> (16 * e)), pty = (double)(int)(signed char)(ppk[t >> 1] >> (16 * e + 8));
-			const double xr = __builtin_fma(ptx, ax, __builtin_fma(-pty, ay, ukx));
-			const double yr = __builtin_fma(ptx, ay, __builtin_fma(pty, ax, uky));
-			if (MCS_FAST_ABLATE & 2) { u[t] = xr; v[t] = yr; } else fast_w2i(C, tabLds, xr, yr, u[t], v[t]);
-			sumx += u[t]; sumy += v[t];
-			if ((t & (MCS_FAST_FENCE - 1)) == MCS_FAST_FENCE - 1) __builtin_amdgcn_sched_barrier(0);   // at most MCS_FAST_FENCE point evaluations in flight (registers)
-		}
-		const double meanX = wave_sum_f64(sumx) * (1.0 / (double)NP), meanY = wave_sum_f64(sumy) * (1.0 / (double)NP);
-		bool bad = !(fabs(meanX) < 16384.0) || !(fabs(meanY) < 16384.0);
-		int ix[2 * NB], iy[2 * NB];
+			xr = __builtin_fma(ptx, ax, __builtin_fma(-pty, ay, ukx));
+			yr = __builtin_fma(ptx, ay, __builtin_fma(pty, ax, uky));
+		};
+		if (MCS_FAST_ABLATE & 2) {
 #pragma unroll
-		for (int t = 0; t < 2 * NB; ++t) {
-			const double dx = u[t] - meanX, dy = v[t] - meanY;
-			const double rx = __builtin_rint(dx), ry = __builtin_rint(dy);
-			if (!(MCS_FAST_ABLATE & 4)) bad |= !(fabs(dx - rx) < lim) || !(fabs(dy - ry) < lim);   // inside the guard band of a rounding tie (or NaN)
-			ix[t] = (int)rx; iy[t] = (int)ry;
-			if (!(MCS_FAST_ABLATE & 4)) bad |= (unsigned)(ix[t] + 4096) >= 8192u || (unsigned)(iy[t] + 4096) >= 8192u;
+			for (int t = 0; t < 2 * NB; ++t) { rotate(t, u[t], v[t]); sumx += u[t]; sumy += v[t]; }
+		} else {
+#pragma unroll
+			for (int t = 0; t < 2 * NB; ++t) {
+				double xr, yr;
+				rotate(t, xr, yr);
+				fast_w2i(C, tabLds, xr, yr, u[t], v[t], bad);
+				sumx += u[t]; sumy += v[t];
+				if ((t & (MCS_FAST_FENCE - 1)) == MCS_FAST_FENCE - 1) __builtin_amdgcn_sched_barrier(0);   // at most MCS_FAST_FENCE point evaluations in flight (registers)
+			}
 		}
-		if (__any(bad)) { to_exact(); return; }
+		double totx, toty;
+		wave_sum2_f64(sumx, sumy, totx, toty);
+		const double meanX = totx * (1.0 / (double)NP), meanY = toty * (1.0 / (double)NP);
+		bad |= !(fabs(meanX) < 16384.0) || !(fabs(meanY) < 16384.0);
+		const double cmx = kFix - meanX, cmy = kFix - meanY;
+		unsigned reach = 0;
+		// rounding, guard and the pair's test in one sweep (the samples of a keypoint that turns out to need the exact pass are wasted, nothing else: its
+		// bits are not written)
 #pragma unroll
 		for (int j = 0; j < NB; ++j) {
-			int t0 = ix[2 * j], t1 = iy[2 * j + 1];
-			if (!(MCS_FAST_ABLATE & 1)) sm.pair(row, col, iy[2 * j], ix[2 * j], iy[2 * j + 1], ix[2 * j + 1], t0, t1);
+			int ix[2], iy[2];
+#pragma unroll
+			for (int e = 0; e < 2; ++e) {
+				const double yx = u[2 * j + e] + cmx, yy = v[2 * j + e] + cmy;
+				const unsigned hx = (unsigned)__double2hiint(yx) - kHiBase, hy = (unsigned)__double2hiint(yy) - kHiBase;
+				if (!(MCS_FAST_ABLATE & 4)) bad |= ((unsigned)__double2loint(yx) + guardUnits < 2u * guardUnits) || ((unsigned)__double2loint(yy) + guardUnits < 2u * guardUnits);
+				reach |= hx | hy;
+				ix[e] = (int)hx - 4096; iy[e] = (int)hy - 4096;
+			}
+			int t0 = ix[0], t1 = iy[1];
+			if (!(MCS_FAST_ABLATE & 1)) sm.pair(row, col, iy[0], ix[0], iy[1], ix[1], t0, t1);
 			const unsigned long long bits = __ballot(t0 < t1);
 			if (pat == 0) bitsMain[j] = bits;
 			else agree[j] &= ~(bits ^ bitsMain[j]);
 		}
+		if (!(MCS_FAST_ABLATE & 4)) bad |= reach >= 8192u;
+		if (__any(bad)) return false;
 	}
-	if (lane == 0) {
-		uint8_t* dout = b.out_desc + ((size_t)kp_.img * b.outImgPitch + kp_.out) * b.outRowStride;
-		uint8_t* mout = b.out_mask + ((size_t)kp_.img * b.outImgPitch + kp_.out) * b.outRowStride;
+	return true;
+}
+
+// Persistent workgroups: a workgroup of kFastWaves waves walks a contiguous range of keypoint GROUPS (kFastWaves consecutive slots of one image, one per
+// wave).  The camera's table is loaded into LDS when the camera changes — once per workgroup for a camera-major batch — and there is no barrier inside the
+// walk, so the waves drift apart and one wave's memory round trips (slot record -> patch) hide behind the others' arithmetic.  (One workgroup per 8
+// keypoints spent half its life in the load -> LDS -> barrier prologue: the kernel without model, sampling and guard took 0.36 of 0.71 ms.)
+template <int MODE, int NB>
+__attribute__((amdgpu_waves_per_eu(MCS_FAST_WAVES_PER_EU, MCS_FAST_WAVES_PER_EU)))
+__global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffers b, int wavesPerImage, int nslots, int groupsPerBlock) {
+	extern __shared__ __attribute__((aligned(16))) double lds[];   // the camera's G table (shared, at offset 0: its reads then need no address arithmetic), then the blurred patch of each wave's keypoint
+	static_assert(MODE == 1 || MODE == 2, "the fast pass is for the distorted patterns");
+	const int wave = threadIdx.x >> 6;
+	uint8_t* const patchLds = reinterpret_cast<uint8_t*>(lds) + kGTabDoubles * sizeof(double) + (size_t)wave * kPatchBytes;
+	double* const tabLds = lds;
+	const PyrDesc& d = *b.desc;
+	KpAuxSoA A; A.carve(b.aux, nslots);
+	const int ngroups = nslots / kFastWaves;
+	const int g0 = (int)blockIdx.x * groupsPerBlock, g1 = min(g0 + groupsPerBlock, ngroups);
+	const size_t S = (size_t)nslots;
+	int curTab = -1;
+#pragma unroll 1
+	for (int g = g0; g < g1; ++g) {
+		const int base = g * kFastWaves;
+		const int bimg = base / wavesPerImage;   // every slot of a group is a keypoint of the same image
+		const OcamDev& cam = b.cams[bimg];
+		const int tabIdx = cam.tabIdx;
+		if (tabIdx != curTab) {   // uniform over the workgroup: every wave walks the same groups
+			if (curTab >= 0) __syncthreads();   // nobody reads the old table any more
+			if (!(MCS_FAST_ABLATE & 8)) {
+				const double2* gt = reinterpret_cast<const double2*>(b.gTab + (size_t)tabIdx * kGTabDoubles);
+				constexpr int n2 = kGTabDoubles / 2, trips = (n2 + 64 * kFastWaves - 1) / (64 * kFastWaves);
+				double2 tv[trips];
 #pragma unroll
-		for (int j = 0; j < NB; ++j) {
-			*reinterpret_cast<unsigned long long*>(dout + 8 * j) = bitsMain[j];
-			*reinterpret_cast<unsigned long long*>(mout + 8 * j) = MODE == 2 ? agree[j] : 0ull;
+				for (int t = 0; t < trips; ++t) { const int i = t * 64 * kFastWaves + (int)threadIdx.x; tv[t] = i < n2 ? gt[i] : double2{0.0, 0.0}; }
+#pragma unroll
+				for (int t = 0; t < trips; ++t) { const int i = t * 64 * kFastWaves + (int)threadIdx.x; if (i < n2) reinterpret_cast<double2*>(tabLds)[i] = tv[t]; }
+			}
+			__syncthreads();
+			curTab = tabIdx;
+		}
+		// this wave's keypoint as the orientation kernels left it (wave-uniform: scalar loads)
+		const int gwu = __builtin_amdgcn_readfirstlane(base + wave);
+		const int lvlRaw = A.lvl[gwu];
+		if (lvlRaw < 0 || (lvlRaw & kAuxExact)) continue;   // nothing here, or already on the exact pass's pre-list
+		const int level = lvlRaw;
+		const int rc = A.rc[gwu];
+		const int row = rc & 0xFFFF, col = (int)((unsigned)rc >> 16);
+		{
+			const LevelInfo& L = d.lv[level];
+			uint32_t pv[kPatchTrips];
+			patch_load(b.blur + (size_t)bimg * d.pyrBytes + L.off, L.stride, row, col, pv);
+			patch_store(patchLds, pv);   // the previous keypoint's samples are done: same wave, LDS operations stay in order
+		}
+		int lane = threadIdx.x & 63;
+		asm volatile("" : "+v"(lane));   // opaque per trip: nothing derived from the lane id is worth holding in registers across the walk
+		FastCam C;
+		C.c = cam.c; C.d = cam.d; C.e = cam.e;
+		uint32_t ppk[NB];
+#pragma unroll
+		for (int j = 0; j < NB; ++j) ppk[j] = reinterpret_cast<const uint32_t*>(c_pattern)[j * 64 + lane];
+		LazySampler sm;
+		sm.b = &b; sm.img = bimg; sm.level = level; sm.patch = patchLds;
+		const double* D8 = A.d8 + gwu;
+		const double ukx = D8[0], uky = D8[S];
+		double axc[3], ays[3];
+#pragma unroll
+		for (int k = 0; k < 3; ++k) { axc[k] = D8[(2 + 2 * k) * S]; ays[k] = D8[(3 + 2 * k) * S]; }
+		unsigned long long bitsMain[NB], agree[NB];
+		const bool ok = fast_keypoint<MODE, NB>(b, C, tabLds, sm, row, col, ukx, uky, axc, ays, ppk, bitsMain, agree);
+		if (lane == 0) {
+			if (!ok) { const int at = atomicAdd(b.fbCount, 1); b.fbList[at] = (uint32_t)gwu; }
+			else {
+				const int out = gwu - bimg * wavesPerImage;
+				uint8_t* dout = b.out_desc + ((size_t)bimg * b.outImgPitch + out) * b.outRowStride;
+				uint8_t* mout = b.out_mask + ((size_t)bimg * b.outImgPitch + out) * b.outRowStride;
+#pragma unroll
+				for (int j = 0; j < NB; ++j) {
+					*reinterpret_cast<unsigned long long*>(dout + 8 * j) = bitsMain[j];
+					*reinterpret_cast<unsigned long long*>(mout + 8 * j) = MODE == 2 ? agree[j] : 0ull;
+				}
+			}
 		}
 	}
 }
 
 // self-test of the fast arithmetic: n pseudo-random pattern points around random keypoints of camera `cam` through fast_w2i and through the exact
-// world2img; maxDiff[0] = the largest |u_fast - u_exact| or |v_fast - v_exact| seen (as the bits of a non-negative double, atomicMax)
+// world2img; maxDiff[0] = the largest |u_fast - u_exact| or |v_fast - v_exact| seen (as the bits of a non-negative double, atomicMax).  Points the table
+// does not cover (the kernel sends their keypoints to the exact pass) are skipped.
 __global__ void k_selftest_fast_model(const OcamDev* camp, const double* tab, unsigned long long seed, int n, int width, int height, unsigned long long* maxDiff) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -859,11 +964,13 @@ __global__ void k_selftest_fast_model(const OcamDev* camp, const double* tab, un
 	double ue, ve;
 	world2img(cam, xr, yr, -p0, ue, ve);
 	FastCam C;
-	C.c = cam.c; C.d = cam.d; C.e = cam.e; C.u0 = cam.u0; C.v0 = cam.v0; C.wK = cam.wK; C.tK = cam.tK;
+	C.c = cam.c; C.d = cam.d; C.e = cam.e;
 	double uf, vf;
-	fast_w2i(C, tab, xr, yr, uf, vf);
-	double diff = fmax(fabs(uf - ue), fabs(vf - ve));
-	if (!(diff == diff)) diff = 1e300;   // NaN on either side counts as a failure unless both are non-finite for the same reason (norm = 0 cannot occur here)
+	bool bad = false;
+	fast_w2i(C, tab, xr, yr, uf, vf, bad);
+	if (bad) return;
+	double diff = fmax(fabs(uf + cam.u0 - ue), fabs(vf + cam.v0 - ve));   // one extra rounding here (the kernel never adds the principal point)
+	if (!(diff == diff)) diff = 1e300;   // NaN on either side counts as a failure
 	atomicMax(maxDiff, (unsigned long long)__double_as_longlong(diff));
 }
 
@@ -871,28 +978,40 @@ void launch_selftest_fast_model(const OcamDev* cam, const double* tab, unsigned 
 	hipLaunchKernelGGL(k_selftest_fast_model, dim3((n + 255) / 256), dim3(256), 0, s, cam, tab, seed, n, width, height, maxDiff);
 }
 
+template <int MODE, int NB>
+static void launch_fast_passes(const ExtractBuffers& b, int nimg, int wavesPerImage, size_t listLds, hipStream_t s) {
+	const int nslots = nimg * wavesPerImage, ngroups = nslots / kFastWaves, lblocks = std::min(nslots, 2048);
+	// two workgroups of 8 waves fit a CU (registers: 4 waves per SIMD): one resident generation of workgroups walks the whole batch
+	const int groupsPerBlock = std::max(1, (ngroups + kFastBlocks - 1) / kFastBlocks), fblocks = (ngroups + groupsPerBlock - 1) / groupsPerBlock;
+	const size_t fLds = (size_t)kFastWaves * kPatchBytes + kGTabDoubles * sizeof(double);
+	(void)hipMemsetAsync(b.fbCount, 0, 2 * sizeof(int), s);   // fbCount and preCount are neighbours
+	hipLaunchKernelGGL(k_orient_a, dim3((nslots + 15) / 16), dim3(256), 0, s, b, wavesPerImage, nslots);
+	hipLaunchKernelGGL((k_orient_b<MODE>), dim3((nslots + 255) / 256), dim3(256), 0, s, b, wavesPerImage, nslots);
+	// the pre-list (about one keypoint in a hundred: the ones next to the optical axis) through the exact pass BESIDE the fast pass
+	hipStream_t ps = b.sideStream ? b.sideStream : s;
+	if (b.sideStream) { (void)hipEventRecord(b.evDescFork, s); (void)hipStreamWaitEvent(ps, b.evDescFork, 0); }
+	hipLaunchKernelGGL((k_describe_list<MODE, NB>), dim3(lblocks), dim3(64), listLds, ps, b, wavesPerImage, b.preCount, b.preList);
+	if (b.sideStream) (void)hipEventRecord(b.evDescJoin, ps);
+	static bool ldsAttr = false;   // more than the default 64 KB of dynamic LDS per workgroup
+	if (!ldsAttr && fLds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_describe_fast<MODE, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fLds); ldsAttr = true; }
+	hipLaunchKernelGGL((k_describe_fast<MODE, NB>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage, nslots, groupsPerBlock);
+	hipLaunchKernelGGL((k_describe_list<MODE, NB>), dim3(lblocks), dim3(64), listLds, s, b, wavesPerImage, b.fbCount, b.fbList);
+	if (b.sideStream) (void)hipStreamWaitEvent(s, b.evDescJoin, 0);
+}
+
 template <int MODE>
 static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
 	// ORB: 4 keypoints (waves) per 256-thread block.  dBRIEF/mdBRIEF exact pass: one wave per block with a private 2*NB KiB LDS slice.
 	const int wpb = MODE == 0 ? 4 : 1;
-	const int wavesPerImage = (hd.kpCap + 3) / 4 * 4;   // one slot per output row; a multiple of 4 in every mode (ORB and the fast pass pack 4 waves per block)
+	const int wavesPerImage = (hd.kpCap + kSlotAlign - 1) / kSlotAlign * kSlotAlign;   // one slot per output row; a multiple of kSlotAlign in every mode
 	const int blocks = nimg * wavesPerImage / wpb;
 	const size_t ldsBytes = (size_t)wpb * (coord_bytes(MODE, hd.npoints) + kPatchBytes);   // coordinates + blurred patch per wave
 	const int nb = hd.descSize / 8;
 	if constexpr (MODE != 0) {
-		if (b.describeMode == 0) {   // fast pass + exact pass over its fallback list
-			const int fblocks = nimg * wavesPerImage / kFastWaves, lblocks = std::min(blocks, 2048);
-			const size_t fLds = (size_t)kFastWaves * kPatchBytes + kRhoTabDoubles * sizeof(double);
-			const int nslots = nimg * wavesPerImage;
-			(void)hipMemsetAsync(b.fbCount, 0, sizeof(int), s);
-			hipLaunchKernelGGL(k_orient_a, dim3((nslots + 15) / 16), dim3(256), 0, s, b, wavesPerImage, nslots);
-			hipLaunchKernelGGL((k_orient_b<MODE>), dim3((nslots + 255) / 256), dim3(256), 0, s, b, wavesPerImage, nslots);
-			if (nb == 2) { hipLaunchKernelGGL((k_describe_fast<MODE, 2>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage, nslots);
-			               hipLaunchKernelGGL((k_describe_list<MODE, 2>), dim3(lblocks), dim3(64), ldsBytes, s, b, wavesPerImage); }
-			else if (nb == 4) { hipLaunchKernelGGL((k_describe_fast<MODE, 4>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage, nslots);
-			                    hipLaunchKernelGGL((k_describe_list<MODE, 4>), dim3(lblocks), dim3(64), ldsBytes, s, b, wavesPerImage); }
-			else { hipLaunchKernelGGL((k_describe_fast<MODE, 8>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage, nslots);
-			       hipLaunchKernelGGL((k_describe_list<MODE, 8>), dim3(lblocks), dim3(64), ldsBytes, s, b, wavesPerImage); }
+		if (b.describeMode == 0) {   // fast pass + exact pass over the two lists
+			if (nb == 2) launch_fast_passes<MODE, 2>(b, nimg, wavesPerImage, ldsBytes, s);
+			else if (nb == 4) launch_fast_passes<MODE, 4>(b, nimg, wavesPerImage, ldsBytes, s);
+			else launch_fast_passes<MODE, 8>(b, nimg, wavesPerImage, ldsBytes, s);
 			return;
 		}
 	}
@@ -902,7 +1021,7 @@ static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hi
 	else hipLaunchKernelGGL((k_describe<MODE, 8>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 }
 
-size_t describe_aux_bytes() { return sizeof(KpAux); }
+size_t describe_aux_bytes() { return KpAuxSoA::bytes_per_slot(); }
 
 void launch_describe(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s) {
 	if (hd.mode == 0) launch_mode<0>(b, hd, nimg, s);

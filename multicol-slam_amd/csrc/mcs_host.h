@@ -44,6 +44,7 @@ struct mcs_ctx {
 	hipStream_t side = nullptr;    // extraction fork: resize chain + blur beside FAST + oct-tree
 	hipStream_t side2 = nullptr;   // the greedy match resolution (its own stream: it must not hold up the next batch's resize chain)
 	hipEvent_t evFork = nullptr, evPyr1 = nullptr, evPyr = nullptr, evBlur = nullptr, evMatch = nullptr, evGreedy = nullptr;
+	hipEvent_t evDescFork = nullptr, evDescJoin = nullptr;   // the exact descriptor pass over the pre-list on `side`, beside the fast pass
 	bool greedyPending = false;
 	// deferred searches (mcs_ctx_set_async_search): top-K lists AND greedy pass of a device-memory search on side2, completion events in a ring
 	bool asyncSearch = false;
