@@ -362,7 +362,8 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	if (!ctx || !p || !out) return fail(MCS_ERR_INVALID, "null argument");
 	if (p->nlevels < 1 || p->nlevels > MCS_MAX_LEVELS) return fail(MCS_ERR_INVALID, "nlevels out of range");
 	if (p->descSize != 16 && p->descSize != 32 && p->descSize != 64) return fail(MCS_ERR_INVALID, "descSize must be 16, 32 or 64");
-	if (p->useAgast || p->fastAgastType != 2) return fail(MCS_ERR_UNSUPPORTED, "only FAST TYPE_9_16 (fastAgastType 2, useAgast 0) is implemented");
+	if (p->useAgast) return fail(MCS_ERR_UNSUPPORTED, "AGAST is not implemented (OpenCV's generated decision trees are not part of the reference tree); use FAST (useAgast 0)");
+	if (p->fastAgastType < 0 || p->fastAgastType > 2) return fail(MCS_ERR_INVALID, "fastAgastType must be 0 (TYPE_5_8), 1 (TYPE_7_12) or 2 (TYPE_9_16)");
 	if (!(p->scaleFactor > 1.0f)) return fail(MCS_ERR_INVALID, "scaleFactor must be > 1");
 	if (max_batch < 1 || width < 1 || height < 1 || p->nfeatures < 1) return fail(MCS_ERR_INVALID, "bad size");
 	HIPCHK(hipSetDevice(ctx->device));
@@ -373,6 +374,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	const int nl = p->nlevels;
 	hd.nlevels = nl; hd.width = width; hd.height = height;
 	hd.fastThreshold = std::min(std::max(p->fastThreshold, 0), 255);
+	hd.fastRing = p->fastAgastType == 2 ? 16 : (p->fastAgastType == 1 ? 12 : 8);
 	hd.descSize = p->descSize; hd.npoints = 2 * 8 * p->descSize;
 	hd.mode = p->learnMasks ? 2 : (p->do_dBrief ? 1 : 0);
 	hd.undistort = p->do_dBrief ? 1 : 0;

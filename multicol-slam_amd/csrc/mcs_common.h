@@ -44,6 +44,7 @@ struct PyrDesc {
 	int cellsPerImage, slotsPerImage, densePerImage, selPerImage;
 	int kpCap;              // output rows per image
 	int fastThreshold;
+	int fastRing;           // 16 / 12 / 8: FastFeatureDetector TYPE_9_16 / TYPE_7_12 / TYPE_5_8
 	int descSize, npoints;
 	int mode;               // 0 ORB, 1 dBRIEF, 2 mdBRIEF
 	int undistort;          // do_dBrief (reference gates undistortion on it only, Appendix B.1)

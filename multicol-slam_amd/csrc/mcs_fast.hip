@@ -1,4 +1,4 @@
-// mcs_fast.hip — E2: grid-cell FAST-9/16 + non-max suppression + mirror-mask filter.
+// mcs_fast.hip — E2: grid-cell FAST (9/16, and the 7/12 and 5/8 rings) + non-max suppression + mirror-mask filter.
 // Reference: src/mdBRIEFextractorOct.cpp:863-949 (one cv::FastFeatureDetector(th, nonmax=true, TYPE_9_16)->detect()
 // per ~30x30 cell view with its mask view); FAST arithmetic per SURVEY Appendix A.3.
 //
@@ -26,6 +26,72 @@ template <int CW> struct FastGeom {
 	static constexpr int kScPitch = (CW + 2 + 3) / 4 * 4, kScRows = CW + 2;
 	static constexpr int kBitWords = (CW * CW + 63) / 64 * 2, kGroups = (CW * CW + 63) / 64;
 };
+
+// ---- the two small rings (FastFeatureDetector TYPE_7_12 / TYPE_5_8, reference src/mdBRIEFextractorOct.cpp:869-872) -------------------------------------
+// OpenCV 3.x's FAST_t<patternSize> keeps the 3-pixel border for every ring, and its quick rejection test always reads entries 0|8, 2|10, 4|12, 6|14, 1|9,
+// 3|11, 5|13, 7|15 of a 25-entry offset table that has wrapped around for the small rings (pixel[k] = pixel[k - patternSize]).  So a pixel is a corner iff
+//   ring 12:  the pairs (0,8) (2,10) (4,0) (6,2) (1,9) (3,11) (5,1) (7,3) each hold a darker pixel AND a run of 7 contiguous darker pixels exists (or the same
+//             with brighter);
+//   ring 8:   all 8 ring pixels are darker, or all are brighter (the wrapped table pairs every entry with itself; the 5-run then always exists).
+// Score: cornerScore<12> / <8> = max over the arcs of 7 / 5 contiguous ring pixels of min d (or of min -d), minus 1.
+template <int P, int kTilePitch> struct Ring;
+template <int kTilePitch> struct Ring<12, kTilePitch> {
+	static __device__ __forceinline__ void diffs(const uint8_t* c, int (&d)[12]) {
+		const int v = c[0];
+		d[0] = v - c[2 * kTilePitch]; d[1] = v - c[2 * kTilePitch + 1]; d[2] = v - c[kTilePitch + 2]; d[3] = v - c[2];
+		d[4] = v - c[-kTilePitch + 2]; d[5] = v - c[-2 * kTilePitch + 1]; d[6] = v - c[-2 * kTilePitch]; d[7] = v - c[-2 * kTilePitch - 1];
+		d[8] = v - c[-kTilePitch - 2]; d[9] = v - c[-2]; d[10] = v - c[kTilePitch - 2]; d[11] = v - c[2 * kTilePitch - 1];
+	}
+};
+template <int kTilePitch> struct Ring<8, kTilePitch> {
+	static __device__ __forceinline__ void diffs(const uint8_t* c, int (&d)[8]) {
+		const int v = c[0];
+		d[0] = v - c[kTilePitch]; d[1] = v - c[kTilePitch + 1]; d[2] = v - c[1]; d[3] = v - c[-kTilePitch + 1];
+		d[4] = v - c[-kTilePitch]; d[5] = v - c[-kTilePitch - 1]; d[6] = v - c[-1]; d[7] = v - c[kTilePitch - 1];
+	}
+};
+// the quick test of the small rings: bit 0 = the darker branch may hold a corner, bit 1 = the brighter branch
+template <int P>
+__device__ __forceinline__ int small_ring_pretest(const int (&d)[P], int t) {
+	if (P == 8) {
+		bool dk = true, br = true;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) { dk &= d[k] > t; br &= d[k] < -t; }
+		return (dk ? 1 : 0) | (br ? 2 : 0);
+	}
+	constexpr int pa[8] = {0, 2, 4, 6, 1, 3, 5, 7}, pb[8] = {8, 10, 0, 2, 9, 11, 1, 3};   // entries 8..15 of the wrapped table, modulo 12
+	bool dk = true, br = true;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		dk &= (d[pa[i] % P] > t) | (d[pb[i] % P] > t);
+		br &= (d[pa[i] % P] < -t) | (d[pb[i] % P] < -t);
+	}
+	return (dk ? 1 : 0) | (br ? 2 : 0);
+}
+template <int P, int kTilePitch>
+__device__ __forceinline__ bool small_ring_quick(const uint8_t* c, int t) {
+	int d[P];
+	Ring<P, kTilePitch>::diffs(c, d);
+	return small_ring_pretest<P>(d, t) != 0;
+}
+template <int P, int kTilePitch>
+__device__ __forceinline__ int small_ring_score(const uint8_t* c, int t) {
+	int d[P];
+	Ring<P, kTilePitch>::diffs(c, d);
+	const int pre = small_ring_pretest<P>(d, t);
+	constexpr int R = P / 2 + 1;   // arc length: 7 of 12, 5 of 8
+	int A = -256, Bn = 256;
+#pragma unroll
+	for (int k = 0; k < P; ++k) {
+		int lo = d[k], hi = d[k];
+#pragma unroll
+		for (int j = 1; j < R; ++j) { lo = min(lo, d[(k + j) % P]); hi = max(hi, d[(k + j) % P]); }
+		A = max(A, lo);
+		Bn = min(Bn, hi);
+	}
+	const bool corner = ((pre & 1) && A > t) || ((pre & 2) && -Bn > t);
+	return corner ? max(A, -Bn) - 1 : 0;
+}
 
 // Necessary condition for a 9-of-16 arc: it covers at least two ADJACENT compass points (k = 0, 4, 8, 12), so two
 // adjacent compass pixels must both be darker (d > t) or both be brighter (d < -t) than the centre.  Stricter than
@@ -76,7 +142,7 @@ __device__ __forceinline__ int fast_score(const uint8_t* c /* centre in LDS tile
 	return best > t ? best - 1 : 0;
 }
 
-template <int CW, int kFastBS>
+template <int CW, int kFastBS, int P>   // P = ring size: 16 (TYPE_9_16), 12 (TYPE_7_12), 8 (TYPE_5_8)
 __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd, int cell0, int ncells) {
 	typedef FastGeom<CW> Geo;
 	constexpr int kTilePitch = Geo::kTilePitch, kTileRows = Geo::kTileRows, kScPitch = Geo::kScPitch, kScRows = Geo::kScRows;
@@ -142,7 +208,9 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 		bool pass = false;
 		if (p < npx) {
 			const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
-			pass = fast_quick<kTilePitch>(&tile[(py + 3) * kTilePitch + px + 3], t);
+			const uint8_t* c = &tile[(py + 3) * kTilePitch + px + 3];
+			if constexpr (P == 16) pass = fast_quick<kTilePitch>(c, t);
+			else pass = small_ring_quick<P, kTilePitch>(c, t);
 		}
 		const unsigned long long bal = __ballot(pass);
 		int wbase = 0;
@@ -155,7 +223,11 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	for (int i = tid; i < ns; i += kFastBS) {
 		const int p = surv[i];
 		const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
-		sc[(py + 1) * kScPitch + px + 1] = (uint8_t)fast_score<kTilePitch>(&tile[(py + 3) * kTilePitch + px + 3], t);
+		const uint8_t* c = &tile[(py + 3) * kTilePitch + px + 3];
+		int score;
+		if constexpr (P == 16) score = fast_score<kTilePitch>(c, t);
+		else score = small_ring_score<P, kTilePitch>(c, t);
+		sc[(py + 1) * kScPitch + px + 1] = (uint8_t)score;
 	}
 	__syncthreads();
 
@@ -221,8 +293,16 @@ void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream
 	int cellMax = 0;
 	for (int l = level0; l < level1; ++l) cellMax = std::max(cellMax, std::max(hd.lv[l].wCell, hd.lv[l].hCell));
 	// two waves per cell for the small instance: alone 0.46 ms against 0.52 (one wave) and 0.55 (four waves); in the overlapped step one and two waves are within 1 %
-	if (cellMax <= 40) hipLaunchKernelGGL((k_fast_cells<40, 128>), dim3(perXcd * kNumXCD), dim3(128), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);
-	else hipLaunchKernelGGL((k_fast_cells<60, 256>), dim3(perXcd * kNumXCD), dim3(256), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);
+	const dim3 grid(perXcd * kNumXCD);
+#define MCS_FAST_LAUNCH(P)                                                                                                                      \
+	do {                                                                                                                                        \
+		if (cellMax <= 40) hipLaunchKernelGGL((k_fast_cells<40, 128, P>), grid, dim3(128), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);     \
+		else hipLaunchKernelGGL((k_fast_cells<60, 256, P>), grid, dim3(256), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);                   \
+	} while (0)
+	if (hd.fastRing == 16) MCS_FAST_LAUNCH(16);
+	else if (hd.fastRing == 12) MCS_FAST_LAUNCH(12);
+	else MCS_FAST_LAUNCH(8);
+#undef MCS_FAST_LAUNCH
 }
 
 }  // namespace mcs

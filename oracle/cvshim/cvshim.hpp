@@ -304,10 +304,10 @@ public:
 		auto p = std::make_shared<FastFeatureDetector>(); p->threshold = threshold; p->nonmax = nonmaxSuppression; p->type = type; return p; }
 	void setThreshold(int t) { threshold = t; }
 	void detect(const Mat& image, std::vector<KeyPoint>& keypoints, const Mat& mask = Mat()) {
-		if (type != TYPE_9_16 || !nonmax) throw std::runtime_error("cvshim: only FAST TYPE_9_16 with non-max suppression is restated");
+		if (type < TYPE_5_8 || type > TYPE_9_16 || !nonmax) throw std::runtime_error("cvshim: FAST is restated with non-max suppression only");
 		std::vector<orc_keypoint> out((size_t)image.rows * image.cols + 1);
-		const int n = orc_fast9_16(image.data, image.cols, image.rows, (int)image.step, mask.empty() ? nullptr : mask.data, mask.empty() ? 0 : (int)mask.step, threshold,
-		                           out.data(), (int)out.size());
+		const int n = orc_fast_type(type, image.data, image.cols, image.rows, (int)image.step, mask.empty() ? nullptr : mask.data, mask.empty() ? 0 : (int)mask.step, threshold,
+		                            out.data(), (int)out.size());
 		keypoints.clear();
 		for (int i = 0; i < n; ++i) keypoints.push_back(KeyPoint(out[i].x, out[i].y, out[i].size, out[i].angle, out[i].response, out[i].octave, out[i].class_id));
 	}

@@ -210,13 +210,24 @@ void orc_border_reflect101(uint8_t* buf, int w, int h, int stride, int b) {
 	}
 }
 
-// ---------------------------------------------------------------- A.3 FAST-9/16
-static const int kCircle[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
-                                   {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+// ---------------------------------------------------------------- A.3 FAST: FAST_t<patternSize> and cornerScore<patternSize>, patternSize 16 / 12 / 8
+// (FastFeatureDetector TYPE_9_16 = 2, TYPE_7_12 = 1, TYPE_5_8 = 0; reference: src/mdBRIEFextractorOct.cpp:869-872, 912-914).  Restated from OpenCV 3.x
+// modules/features2d/src/fast.cpp / fast_score.cpp, generic C++ path.  Two properties of that code matter for the two small rings and are kept literally:
+//   * every pattern size skips a 3-pixel border (rows 3 .. rows-4, columns 3 .. cols-4), although the rings of TYPE_7_12 / TYPE_5_8 have radius 2 / 1;
+//   * the quick rejection test always reads ring entries 0|8, 2|10, 4|12, 6|14, 1|9, 3|11, 5|13, 7|15 of the 25-entry offset table, which for the small
+//     rings has wrapped around (pixel[k] = pixel[k - patternSize] for k >= patternSize).  For patternSize 8 the test therefore demands ALL 8 ring pixels
+//     darker (or all brighter) than the centre, for patternSize 12 the pairs are (0,8) (2,10) (4,0) (6,2) (1,9) (3,11) (5,1) (7,3) — both stricter than the
+//     5-of-8 / 7-of-12 segment criterion their names suggest.
+static const int kCircle16[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
+                                     {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+static const int kCircle12[12][2] = {{0, 2}, {1, 2}, {2, 1}, {2, 0}, {2, -1}, {1, -2}, {0, -2}, {-1, -2}, {-2, -1}, {-2, 0}, {-2, 1}, {-1, 2}};
+static const int kCircle8[8][2] = {{0, 1}, {1, 1}, {1, 0}, {1, -1}, {0, -1}, {-1, -1}, {-1, 0}, {-1, 1}};
 
-static inline void make_offsets(int pixel[25], int stride) {
-	for (int k = 0; k < 16; k++) pixel[k] = kCircle[k][0] + kCircle[k][1] * stride;
-	for (int k = 16; k < 25; k++) pixel[k] = pixel[k - 16];
+static inline void make_offsets(int pixel[25], int stride, int patternSize) {   // makeOffsets
+	const int(*offsets)[2] = patternSize == 16 ? kCircle16 : patternSize == 12 ? kCircle12 : kCircle8;
+	int k = 0;
+	for (; k < patternSize; k++) pixel[k] = offsets[k][0] + offsets[k][1] * stride;
+	for (; k < 25; k++) pixel[k] = pixel[k - patternSize];
 }
 
 static int corner_score16(const uint8_t* ptr, const int pixel[25], int threshold) {  // cornerScore<16>
@@ -254,18 +265,86 @@ static int corner_score16(const uint8_t* ptr, const int pixel[25], int threshold
 	return threshold;
 }
 
+static int corner_score12(const uint8_t* ptr, const int pixel[25], int threshold) {  // cornerScore<12>
+	const int K = 6, N = K * 3 + 1;
+	int k, v = ptr[0];
+	short d[N + 4];
+	for (k = 0; k < N; k++) d[k] = (short)(v - ptr[pixel[k]]);
+	int a0 = threshold;
+	for (k = 0; k < 12; k += 2) {
+		int a = std::min((int)d[k + 1], (int)d[k + 2]);
+		if (a <= a0) continue;
+		a = std::min(a, (int)d[k + 3]);
+		a = std::min(a, (int)d[k + 4]);
+		a = std::min(a, (int)d[k + 5]);
+		a = std::min(a, (int)d[k + 6]);
+		a0 = std::max(a0, std::min(a, (int)d[k]));
+		a0 = std::max(a0, std::min(a, (int)d[k + 7]));
+	}
+	int b0 = -a0;
+	for (k = 0; k < 12; k += 2) {
+		int b = std::max((int)d[k + 1], (int)d[k + 2]);
+		b = std::max(b, (int)d[k + 3]);
+		b = std::max(b, (int)d[k + 4]);
+		if (b >= b0) continue;
+		b = std::max(b, (int)d[k + 5]);
+		b = std::max(b, (int)d[k + 6]);
+		b0 = std::min(b0, std::max(b, (int)d[k]));
+		b0 = std::min(b0, std::max(b, (int)d[k + 7]));
+	}
+	threshold = -b0 - 1;
+	return threshold;
+}
+
+static int corner_score8(const uint8_t* ptr, const int pixel[25], int threshold) {  // cornerScore<8>
+	const int K = 4, N = K * 3 + 1;
+	int k, v = ptr[0];
+	short d[N];
+	for (k = 0; k < N; k++) d[k] = (short)(v - ptr[pixel[k]]);
+	int a0 = threshold;
+	for (k = 0; k < 8; k += 2) {
+		int a = std::min((int)d[k + 1], (int)d[k + 2]);
+		if (a <= a0) continue;
+		a = std::min(a, (int)d[k + 3]);
+		a = std::min(a, (int)d[k + 4]);
+		a0 = std::max(a0, std::min(a, (int)d[k]));
+		a0 = std::max(a0, std::min(a, (int)d[k + 5]));
+	}
+	int b0 = -a0;
+	for (k = 0; k < 8; k += 2) {
+		int b = std::max((int)d[k + 1], (int)d[k + 2]);
+		b = std::max(b, (int)d[k + 3]);
+		if (b >= b0) continue;
+		b = std::max(b, (int)d[k + 4]);
+		b0 = std::min(b0, std::max(b, (int)d[k]));
+		b0 = std::min(b0, std::max(b, (int)d[k + 5]));
+	}
+	threshold = -b0 - 1;
+	return threshold;
+}
+
+static inline int corner_score(int patternSize, const uint8_t* ptr, const int pixel[25], int threshold) {
+	return patternSize == 16 ? corner_score16(ptr, pixel, threshold) : patternSize == 12 ? corner_score12(ptr, pixel, threshold) : corner_score8(ptr, pixel, threshold);
+}
+
 int orc_fast_score(const uint8_t* center, int stride, int threshold) {
 	int pixel[25];
-	make_offsets(pixel, stride);
+	make_offsets(pixel, stride, 16);
 	return corner_score16(center, pixel, threshold);
 }
 
-// FAST_t<16>(img, kps, threshold, nonmax=true) followed by KeyPointsFilter::runByPixelsMask
-int orc_fast9_16(const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride, int threshold,
-                 orc_keypoint* out, int cap) {
-	const int K = 8, N = 25;
+int orc_fast_score_type(int type, const uint8_t* center, int stride, int threshold) {
+	const int patternSize = type == 2 ? 16 : type == 1 ? 12 : 8;
 	int pixel[25];
-	make_offsets(pixel, stride);
+	make_offsets(pixel, stride, patternSize);
+	return corner_score(patternSize, center, pixel, threshold);
+}
+
+// FAST_t<patternSize>(img, kps, threshold, nonmax=true) followed by KeyPointsFilter::runByPixelsMask
+static int fast_t(int patternSize, const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride, int threshold, orc_keypoint* out, int cap) {
+	const int K = patternSize / 2, N = patternSize + K + 1;
+	int pixel[25];
+	make_offsets(pixel, stride, patternSize);
 	threshold = std::min(std::max(threshold, 0), 255);
 	uint8_t threshold_tab[512];
 	for (int i = -255; i <= 255; i++) threshold_tab[i + 255] = (uint8_t)(i < -threshold ? 1 : i > threshold ? 2 : 0);
@@ -303,7 +382,7 @@ int orc_fast9_16(const uint8_t* img, int w, int h, int stride, const uint8_t* ma
 						if (x < vt) {
 							if (++count > K) {
 								cornerpos[ncorners++] = j;
-								curr[j] = (uint8_t)corner_score16(ptr, pixel, threshold);
+								curr[j] = (uint8_t)corner_score(patternSize, ptr, pixel, threshold);
 								break;
 							}
 						} else
@@ -317,7 +396,7 @@ int orc_fast9_16(const uint8_t* img, int w, int h, int stride, const uint8_t* ma
 						if (x > vt) {
 							if (++count > K) {
 								cornerpos[ncorners++] = j;
-								curr[j] = (uint8_t)corner_score16(ptr, pixel, threshold);
+								curr[j] = (uint8_t)corner_score(patternSize, ptr, pixel, threshold);
 								break;
 							}
 						} else
@@ -348,6 +427,16 @@ int orc_fast9_16(const uint8_t* img, int w, int h, int stride, const uint8_t* ma
 		}
 	}
 	return nout;
+}
+
+int orc_fast9_16(const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride, int threshold, orc_keypoint* out, int cap) {
+	return fast_t(16, img, w, h, stride, mask, mstride, threshold, out, cap);
+}
+
+// FastFeatureDetector::create(threshold, true, type)->detect(img, kps, mask): type 0 = TYPE_5_8, 1 = TYPE_7_12, 2 = TYPE_9_16
+int orc_fast_type(int type, const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride, int threshold, orc_keypoint* out, int cap) {
+	if (type < 0 || type > 2) return -1;
+	return fast_t(type == 2 ? 16 : type == 1 ? 12 : 8, img, w, h, stride, mask, mstride, threshold, out, cap);
 }
 
 // ---------------------------------------------------------------- A.4 5x5 normalised box filter, in place on a ROI
@@ -636,7 +725,7 @@ struct orc_extractor {
 
 orc_extractor* orc_extractor_create(const orc_params* p) {
 	if (p->nlevels < 1 || p->descSize < 1 || 2 * 2 * 8 * p->descSize > 2048) return nullptr;
-	if (p->useAgast || p->fastAgastType != 2) return nullptr;  // only FAST TYPE_9_16 (the shipped setting) is restated
+	if (p->useAgast || p->fastAgastType < 0 || p->fastAgastType > 2) return nullptr;  // AGAST (OpenCV's generated decision trees) is not restated
 	orc_extractor* e = new orc_extractor;
 	e->p = *p;
 	scale_tables(p->scaleFactor, p->nlevels, e->mvScaleFactor, e->mvInvScaleFactor);
@@ -711,8 +800,8 @@ static void ComputeKeyPointsOctTree(orc_extractor* e, std::vector<std::vector<or
 				int y0 = (int)iniY, y1 = (int)maxY, x0 = (int)iniX, x1 = (int)maxX;
 				const uint8_t* view = L.roi() + (ptrdiff_t)y0 * L.stride + x0;
 				const uint8_t* mview = e->has_mask ? M.roi() + (ptrdiff_t)y0 * M.stride + x0 : nullptr;
-				int n = orc_fast9_16(view, x1 - x0, y1 - y0, L.stride, mview, M.stride, e->p.fastThreshold, cell.data(),
-				                     (int)cell.size());
+				int n = orc_fast_type(e->p.fastAgastType, view, x1 - x0, y1 - y0, L.stride, mview, M.stride, e->p.fastThreshold, cell.data(),
+				                      (int)cell.size());
 				for (int k = 0; k < n; ++k) {
 					orc_keypoint kp = cell[k];
 					kp.x += j * wCell;

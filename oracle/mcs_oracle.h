@@ -61,6 +61,9 @@ void  orc_border_reflect101(uint8_t* buf, int w, int h, int stride, int border);
 int   orc_fast9_16(const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride,
                    int threshold, orc_keypoint* out, int cap);
 int   orc_fast_score(const uint8_t* center, int stride, int threshold);
+int   orc_fast_score_type(int type, const uint8_t* center, int stride, int threshold);   /* cornerScore<8 / 12 / 16> for type 0 / 1 / 2 */
+int   orc_fast_type(int type, const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride,
+                    int threshold, orc_keypoint* out, int cap);                          /* FastFeatureDetector TYPE_5_8 / 7_12 / 9_16 */
 void  orc_box5_inplace(uint8_t* roi, int w, int h, int stride); /* roi sits inside a >=2px frame */
 float orc_fastAtan2(float y, float x);
 int   orc_cvRound(double v);

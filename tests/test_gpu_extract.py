@@ -171,7 +171,7 @@ def test_unsupported_parameters_fail_loudly(G):
     with pytest.raises(G.mcs.McsError):
         G.mcs.Extractor(G.ctx(), 754, 480, useAgast=1)
     with pytest.raises(G.mcs.McsError):
-        G.mcs.Extractor(G.ctx(), 754, 480, fastAgastType=1)
+        G.mcs.Extractor(G.ctx(), 754, 480, fastAgastType=3)      # 0 / 1 / 2 = TYPE_5_8 / 7_12 / 9_16 (tests/test_gpu_fast_types.py)
     with pytest.raises(G.mcs.McsError):
         G.mcs.Extractor(G.ctx(), 754, 480, descSize=24)
     with pytest.raises(G.mcs.McsError):
