@@ -83,6 +83,11 @@ class Env:
     pass
 
 
+def torch_empty_like_cpu(t):
+    import torch
+    return torch.empty(t.shape, dtype=t.dtype)
+
+
 def setup():
     import torch
     import torch.distributed as dist
@@ -221,6 +226,10 @@ class Job:
         probe.close()
         self.lay = lay = rig.RigLayout(sp.ncam, FT, e.world, cap, 32)
         self.L, self.cap, self.FT = lay.L, cap, FT
+        # what a rank holds after the exchange: the whole [camera][frame] array (all-gather: the database sweeps need every multi-frame), or — when every
+        # multi-frame only meets its predecessor — just its own frames and one predecessor, sent point to point (rig.RingExchange)
+        self.ring = rig.RingExchange(lay) if (e.exchange and sp.D == 0 and os.environ.get("MCS_BENCH_RING_ALLGATHER") != "1") else None
+        self.view = self.ring.view if self.ring else lay
         self.ex = mcs.Extractor(e.ctx, sp.W, sp.H, max_batch=lay.L, nfeatures=sp.nfeat, do_dBrief=do_db, learnMasks=masks_on)
         slab = lay.slab(e.rank)
         self.slab = slab
@@ -262,11 +271,12 @@ class Job:
     def _make_set(self):
         torch, lay, dev, e = self.e.torch, self.lay, self.e.dev, self.e
         b = Env()
-        b.G = torch.zeros(lay.images_total * lay.block_bytes, dtype=torch.uint8, device=dev)          # gathered [camera][frame][cap+1][64]
+        view = self.view
+        b.G = torch.zeros(view.images_total * lay.block_bytes, dtype=torch.uint8, device=dev)         # gathered [camera][frame][cap+1][64] (ring exchange: F + 1 local frames)
         b.send = torch.zeros(lay.send_bytes, dtype=torch.uint8, device=dev) if e.exchange else b.G   # no exchange: the slab IS the whole array
-        b.valid = torch.zeros(lay.images_total * lay.rows_img, dtype=torch.uint8, device=dev)
+        b.valid = torch.zeros(view.images_total * lay.rows_img, dtype=torch.uint8, device=dev)
         b.nkp = torch.zeros(lay.L, dtype=torch.int32, device=dev)
-        b.nkp_all = torch.zeros(lay.images_total, dtype=torch.int32, device=dev)
+        b.nkp_all = torch.zeros(view.images_total, dtype=torch.int32, device=dev)
         b.kps = torch.zeros((lay.L * self.cap, 7), dtype=torch.float32, device=dev)
         b.rays = torch.zeros((lay.L * self.cap, 3), dtype=torch.float64, device=dev)
         if self.sp.D > 0:
@@ -282,7 +292,7 @@ class Job:
 
     def frame_set(self, b, frame=0):
         """mcs_desc_set of multi-frame `frame` inside the gathered array of buffer set b"""
-        mcs, lay = self.e.mcs, self.lay
+        mcs, lay = self.e.mcs, self.view
         doff, moff, voff, n, stride, brows, bpitch, _ = lay.frame_desc_set(frame)
         g, v = b.G.data_ptr(), b.valid.data_ptr()
         return mcs.DescSet(g + doff, (g + moff) if self.masks_on else None, v + voff, None, n, stride, brows, bpitch)
@@ -298,6 +308,13 @@ class Job:
         """the one exchange step: descriptor | mask | count blocks of every rank's slab.  RCCL: asynchronous (its own stream, ordered behind the extraction)."""
         e = self.e
         if not e.exchange:
+            return None
+        if self.ring is not None:   # point to point: only the blocks this rank's pairs read
+            if e.backend == "nccl":   # at world size 1 the rank's own blocks go through RCCL as well (a self send / receive), so that the path runs there
+                return e.rig.ring_exchange_begin(self.ring, e.rank, b.send, b.G, self_via_p2p=e.world == 1)
+            send_h, recv_h = b.send.cpu(), torch_empty_like_cpu(b.G)   # gloo: functional runs on one shared GPU bounce through host memory
+            e.rig.ring_exchange_end(e.rig.ring_exchange_begin(self.ring, e.rank, send_h, recv_h))
+            b.G.copy_(recv_h)
             return None
         if e.backend == "nccl":
             if e.async_collectives is None:   # probed once: a torch without the async_op keyword takes the blocking form (no overlap, same result);
@@ -316,9 +333,11 @@ class Job:
 
     def exchange_end(self, b, work):
         e, lay, lib, mcs = self.e, self.lay, self.e.lib, self.e.mcs
-        if work is not None:
+        if isinstance(work, list):
+            e.rig.ring_exchange_end(work)
+        elif work is not None:
             work.wait()                                        # a stream-side wait: later work on our stream is ordered behind the collective
-        mcs.check(lib.mcs_rig_rows_valid(e.ctx.h, C.c_void_p(b.G.data_ptr()), lay.images_total, self.cap, lay.row_stride, C.c_void_p(b.valid.data_ptr()),
+        mcs.check(lib.mcs_rig_rows_valid(e.ctx.h, C.c_void_p(b.G.data_ptr()), self.view.images_total, self.cap, lay.row_stride, C.c_void_p(b.valid.data_ptr()),
                                          C.c_void_p(b.nkp_all.data_ptr())))
 
     def extract_and_exchange(self, b, img_buf=0):
@@ -344,8 +363,9 @@ class Job:
     def match(self, b):
         e, lay, lib, mcs, sp = self.e, self.lay, self.e.lib, self.e.mcs, self.sp
         fr = self.frame_set(b, 0)
-        if sp.D == 0:   # every multi-frame of this rank's range against the one before it (a ring over the step's frames)
-            mcs.check(lib.mcs_search_kf_kf_ring(e.ctx.h, self.FT, e.rank * sp.F, sp.F, C.byref(fr), lay.rows_img, 32, 0.9, sp.topk, mcs.MEM_DEVICE,
+        if sp.D == 0:   # every multi-frame of this rank's range against the one before it (a ring over the step's frames; local array: frames 1 .. F)
+            nft, first = (sp.F + 1, 1) if self.ring else (self.FT, e.rank * sp.F)
+            mcs.check(lib.mcs_search_kf_kf_ring(e.ctx.h, nft, first, sp.F, C.byref(fr), lay.rows_img, 32, 0.9, sp.topk, mcs.MEM_DEVICE,
                                                 C.c_void_p(b.match.data_ptr()), C.c_void_p(b.nmatch.data_ptr()), C.c_void_p(b.fb.data_ptr())))
         elif self.nkf:  # every multi-frame of the step against every stored keyframe of this rank
             d = self.db.data_ptr()
@@ -391,6 +411,9 @@ class Job:
 
     def pairs_per_step_local(self):
         b = self.last()
+        if self.ring:
+            nk = b.nkp_all.view(self.lay.ncam, self.sp.F + 1).sum(0).to(self.e.torch.float64)
+            return float((nk[1:] * nk[:-1]).sum().item())
         nk = b.nkp_all.view(self.lay.ncam, self.FT).sum(0).to(self.e.torch.float64)   # features per multi-frame
         if self.sp.D == 0:
             fr = [f for f, _ in self.lay.frame_pairs(self.e.rank)]
@@ -474,6 +497,9 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True, check=True):
            "descriptor_exact_pass_keypoints_per_step_rank0": exact_kp,
            "n_ranks": e.world, "collective_backend": e.backend, "tag": sp.tag,
            "parallelism": ("single GPU, no collective" if not e.exchange else
+                           ("camera-major image slabs x%d + 1 point-to-point exchange per step of the camera blocks of this rank's frames and one predecessor "
+                            "(%d KiB received per rank; the all-gather would deliver %d KiB) + frame pairs sharded x%d"
+                            % (e.world, job.ring.bytes_received(e.rank) // 1024, job.lay.send_bytes * (e.world - 1) // 1024, e.world)) if job.ring else
                            "camera-major image slabs x%d + 1 all-gather of descriptor blocks per step (%d KiB per rank, %s) + (frame, keyframe) pairs sharded x%d"
                            % (e.world, job.lay.send_bytes // 1024, "asynchronous, finished one step later" if e.async_collectives else "blocking", e.world))}
     if checked is not None:
@@ -578,19 +604,20 @@ def check_against_oracle(e, sp, job, host=None):
     `host`: the page-locked host copies of a buffer set (the e2e leg) instead of the device buffers."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    lay, rig = job.lay, e.rig
+    lay, rig, view = job.lay, e.rig, job.view
     do_db, masks_on = MODES[sp.mode]
     b = job.last()
     e.torch.cuda.synchronize(e.dev)
     src = host or {"G": b.G, "kps": b.kps, "match": b.match, "nmatch": b.nmatch}
-    G = src["G"].cpu().numpy().reshape(lay.images_total, lay.rows_img, lay.row_stride)
+    G = src["G"].cpu().numpy().reshape(view.images_total, lay.rows_img, lay.row_stride)
+    local = (lambda f: f + 1) if job.ring else (lambda f: f)   # ring exchange (rank 0): global frame f is local frame f + 1 of the rank's array
     kps = src["kps"].cpu().numpy().view(np.uint8).reshape(lay.L, lay.cap, 28)
     match, nmatch = src["match"].cpu().numpy(), src["nmatch"].cpu().numpy()
     mine = {cf: i for i, cf in enumerate(job.slab)}   # (camera, frame) -> local image (keypoint records stay on the rank that extracted them)
     bad = []
     want = {}
-    for f in ((1, 0) if job.FT > 1 else (0,)):
-        d, m, v = rig.unpack_frame(lay, G, f)
+    for f in ((1, 0) if (job.FT > 1 and (not job.ring or sp.F > 1)) else (0,)):
+        d, m, v = rig.unpack_frame(view, G, local(f))
         want[f] = (d, m, v)
         for c in range(sp.ncam):
             ok_, od, om = O.Extractor(nfeatures=sp.nfeat, do_dBrief=do_db, learnMasks=masks_on)(e.synth.stream_image(f, c, job.cams[c], POOL),
@@ -601,7 +628,7 @@ def check_against_oracle(e, sp, job, host=None):
             if (c, f) in mine and not np.array_equal(kps[mine[(c, f)], :len(ok_)].reshape(-1), np.ascontiguousarray(ok_).view(np.uint8).reshape(-1)):
                 bad.append("keypoint records of frame %d camera %d" % (f, c))
     pairs = 0
-    if sp.D == 0 and e.rank == 0 and job.FT > 1:
+    if sp.D == 0 and e.rank == 0 and len(want) > 1:
         # pair (frame 1, frame 0) is set 1 of rank 0's ring call
         (d1, m1, v1), (d0, m0, v0) = want[1], want[0]
         ones = np.full_like(d1, 255)

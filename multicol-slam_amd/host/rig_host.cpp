@@ -1,0 +1,257 @@
+// rig_host.cpp — native host of the camera-sharded rig: ONE process, one host thread + one mcs_ctx per GPU, RCCL communicators from ncclCommInitAll.
+//
+// The reference runs the cameras of a multi-frame on one OpenMP thread each inside one process (#pragma omp parallel for num_threads(nrCams),
+// src/cMultiFrame.cpp:128-164); this is the same shape with a GPU behind every thread.  Everything the step computes goes through the C ABI of
+// libmcs_hip.so (include/mcs_c.h); the exchange is issued HERE, on the context's own stream, with the caller's communicator — the library never links RCCL:
+//
+//     mcs_extract_batch_strided   this rank's slab of (camera, frame) images -> descriptor | mask rows in exchange blocks      (all device memory)
+//     mcs_rig_pack_headers        keypoint counts into the blocks' header rows
+//     ncclAllGather               database sweeps (every rank needs every multi-frame), or
+//     ncclSend / ncclRecv group   frame ring (a rank needs its own frames and one predecessor: multicol-slam_amd/rig.py RingExchange, restated below)
+//     mcs_rig_rows_valid          row flags from the received headers
+//     mcs_search_kf_f_sweep       every multi-frame x this rank's stored keyframes (k -> rank k mod N), or
+//     mcs_search_kf_kf_ring       this rank's frames against their predecessors
+//
+// Input: a key / value text file (see tests/test_gpu_rig_host.py) naming raw binary inputs — images [camera][frame][H][W] u8 for the whole job, one mask per
+// camera, one mcs_ocam per camera.  Output: per rank its received array, keypoints, counts and match arrays as raw files + one JSON line on stdout
+// (steps, ms per step = max over ranks between two barriers).  No Python, no torch.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <pthread.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mcs_c.h"
+
+#define HIPOK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); exit(2); } } while (0)
+#define NCCLOK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, ncclGetErrorString(r_)); exit(3); } } while (0)
+#define MCSOK(x) do { int r_ = (x); if (r_ != MCS_OK) { fprintf(stderr, "%s:%d %s: %d %s\n", __FILE__, __LINE__, #x, r_, mcs_last_error()); exit(4); } } while (0)
+
+// ---- the layout arithmetic of multicol-slam_amd/rig.py (RigLayout, RingExchange), restated -------------------------------------------------------------
+struct Layout {
+	int ncam, FT, world, cap, ds;
+	int images_total, L, rows_img, row_stride, rows_frame;
+	size_t block_bytes, send_bytes;
+	Layout(int ncam_, int FT_, int world_, int cap_, int ds_ = 32) : ncam(ncam_), FT(FT_), world(world_), cap(cap_), ds(ds_) {
+		images_total = ncam * FT; L = images_total / world; rows_img = cap + 1; row_stride = 2 * ds; rows_frame = ncam * cap;
+		block_bytes = (size_t)rows_img * row_stride; send_bytes = (size_t)L * block_bytes;
+	}
+	int image_index(int cam, int frame) const { return cam * FT + frame; }
+	// multi-frame `frame` of a [camera][FT][rows_img] array as a block-structured descriptor set
+	mcs_desc_set frame_set(const uint8_t* G, const uint8_t* valid, int frame, bool masks) const {
+		mcs_desc_set s;
+		memset(&s, 0, sizeof(s));
+		s.desc = G + (size_t)frame * block_bytes; s.mask = masks ? s.desc + ds : nullptr; s.valid = valid + (size_t)frame * rows_img; s.group = nullptr;
+		s.n = rows_frame; s.stride = row_stride; s.block_rows = cap; s.block_pitch_rows = (int64_t)FT * rows_img;
+		return s;
+	}
+};
+struct Run { int owner, src, dst, n; };   // blocks [src, src+n) of the owner's send buffer -> blocks [dst, dst+n) of the receiver's local array
+static std::vector<Run> ring_runs(const Layout& lay, int rank) {
+	const int F = lay.FT / lay.world;
+	auto gframe = [&](int j) { return ((rank * F - 1 + j) % lay.FT + lay.FT) % lay.FT; };
+	std::vector<Run> out;
+	for (int c = 0; c < lay.ncam; ++c)
+		for (int j = 0; j <= F;) {
+			const int x = lay.image_index(c, gframe(j)), owner = x / lay.L;
+			int n = 1;
+			while (j + n <= F && lay.image_index(c, gframe(j + n)) == x + n && (x + n) / lay.L == owner) ++n;
+			out.push_back({owner, x - owner * lay.L, c * (F + 1) + j, n});
+			j += n;
+		}
+	return out;
+}
+
+static std::map<std::string, std::string> read_config(const char* path) {
+	std::map<std::string, std::string> m;
+	std::ifstream f(path);
+	std::string k, v;
+	while (f >> k >> v) m[k] = v;
+	return m;
+}
+static std::vector<uint8_t> read_file(const std::string& p) {
+	std::ifstream f(p, std::ios::binary);
+	if (!f) { fprintf(stderr, "cannot read %s\n", p.c_str()); exit(1); }
+	return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+static void write_file(const std::string& p, const void* d, size_t n) { std::ofstream f(p, std::ios::binary); f.write((const char*)d, (std::streamsize)n); }
+template <class T> static T* dalloc(size_t n) { void* p = nullptr; HIPOK(hipMalloc(&p, std::max<size_t>(n * sizeof(T), 16))); HIPOK(hipMemset(p, 0, std::max<size_t>(n * sizeof(T), 16))); return (T*)p; }
+
+struct Job {
+	int ncam, W, H, nfeat, mode, F, D, world, steps, warmup, topk;
+	std::vector<uint8_t> images, masks, cams;
+	std::string out;
+};
+
+static pthread_barrier_t g_barrier;
+static std::vector<double> g_ms;
+
+static void rank_main(const Job& J, int rank, ncclComm_t comm) {
+	HIPOK(hipSetDevice(rank));
+	hipStream_t stream;
+	HIPOK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+	mcs_ctx* ctx = nullptr;
+	MCSOK(mcs_ctx_create(rank, stream, &ctx));
+	const bool masksOn = J.mode == 2;
+	mcs_extractor_params prm = {J.nfeat, 1.2f, 8, 25, 0, 0, 32, 20, 0, 2, J.mode >= 1 ? 1 : 0, masksOn ? 1 : 0, 32};
+	const int FT = J.F * J.world;
+	mcs_extractor* probe = nullptr;
+	MCSOK(mcs_extractor_create(ctx, &prm, J.W, J.H, 1, &probe));
+	int cap = 0;
+	MCSOK(mcs_extractor_kp_capacity(probe, &cap));
+	MCSOK(mcs_extractor_destroy(probe));
+	const Layout lay(J.ncam, FT, J.world, cap);
+	const bool ring = J.D == 0;
+	const Layout view = ring ? Layout(J.ncam, J.F + 1, 1, cap) : lay;   // what this rank holds after the exchange
+	mcs_extractor* ex = nullptr;
+	MCSOK(mcs_extractor_create(ctx, &prm, J.W, J.H, lay.L, &ex));
+
+	// ---- this rank's slab: images x in [rank*L, (rank+1)*L) of the camera-major job, their masks and camera models
+	const size_t px = (size_t)J.W * J.H;
+	uint8_t* d_img = dalloc<uint8_t>(lay.L * px);
+	uint8_t* d_msk = dalloc<uint8_t>(lay.L * px);
+	std::vector<mcs_ocam> cam(lay.L);
+	HIPOK(hipMemcpy(d_img, J.images.data() + (size_t)rank * lay.L * px, lay.L * px, hipMemcpyHostToDevice));
+	for (int i = 0; i < lay.L; ++i) {
+		const int c = (rank * lay.L + i) / FT;
+		HIPOK(hipMemcpy(d_msk + i * px, J.masks.data() + c * px, px, hipMemcpyHostToDevice));
+		memcpy(&cam[i], J.cams.data() + (size_t)c * sizeof(mcs_ocam), sizeof(mcs_ocam));
+	}
+	uint8_t* d_send = dalloc<uint8_t>(lay.send_bytes);
+	uint8_t* d_G = dalloc<uint8_t>(view.images_total * view.block_bytes);
+	uint8_t* d_valid = dalloc<uint8_t>((size_t)view.images_total * view.rows_img);
+	int32_t* d_nkp = dalloc<int32_t>(lay.L);
+	int32_t* d_nkpAll = dalloc<int32_t>(view.images_total);
+	mcs_keypoint* d_kps = dalloc<mcs_keypoint>((size_t)lay.L * cap);
+	double* d_rays = dalloc<double>((size_t)lay.L * cap * 3);
+
+	std::vector<int> kfs;
+	for (int k = 0; k < J.D; ++k) if (k % J.world == rank) kfs.push_back(k);
+	const int nkf = (int)kfs.size(), npairs = ring ? J.F : FT * std::max(nkf, 1);
+	uint8_t* d_db = dalloc<uint8_t>((size_t)std::max(nkf, 1) * lay.rows_frame * lay.row_stride);
+	uint8_t* d_dbValid = dalloc<uint8_t>((size_t)std::max(nkf, 1) * lay.rows_frame);
+	int32_t* d_match = dalloc<int32_t>((size_t)npairs * lay.rows_frame);
+	int32_t* d_nmatch = dalloc<int32_t>(npairs);
+	int32_t* d_fb = dalloc<int32_t>(npairs);
+
+	const std::vector<Run> mine = ring ? ring_runs(lay, rank) : std::vector<Run>();
+	std::vector<std::vector<Run> > theirs(J.world);   // what every destination needs (to find my sends, in the receiver's order)
+	if (ring) for (int r = 0; r < J.world; ++r) theirs[r] = ring_runs(lay, r);
+
+	auto extract_and_exchange = [&]() {
+		MCSOK(mcs_extract_batch_strided(ex, lay.L, d_img, px, J.W, d_msk, px, J.W, cam.data(), d_nkp, d_kps, d_send, d_send + lay.ds, d_rays, lay.rows_img, lay.row_stride));
+		MCSOK(mcs_rig_pack_headers(ctx, d_nkp, lay.L, cap, d_send, lay.row_stride));
+		if (!ring) NCCLOK(ncclAllGather(d_send, d_G, lay.send_bytes, ncclUint8, comm, stream));
+		else {
+			NCCLOK(ncclGroupStart());
+			for (const Run& r : mine) NCCLOK(ncclRecv(d_G + (size_t)r.dst * lay.block_bytes, (size_t)r.n * lay.block_bytes, ncclUint8, r.owner, comm, stream));
+			for (int dest = 0; dest < J.world; ++dest)
+				for (const Run& r : theirs[dest])
+					if (r.owner == rank) NCCLOK(ncclSend(d_send + (size_t)r.src * lay.block_bytes, (size_t)r.n * lay.block_bytes, ncclUint8, dest, comm, stream));
+			NCCLOK(ncclGroupEnd());
+		}
+		MCSOK(mcs_rig_rows_valid(ctx, d_G, view.images_total, cap, lay.row_stride, d_valid, d_nkpAll));
+	};
+	auto match = [&]() {
+		const mcs_desc_set fr = view.frame_set(d_G, d_valid, 0, masksOn);
+		if (ring) MCSOK(mcs_search_kf_kf_ring(ctx, J.F + 1, 1, J.F, &fr, view.rows_img, 32, 0.9, J.topk, MCS_MEM_DEVICE, d_match, d_nmatch, d_fb));
+		else if (nkf) {
+			mcs_desc_set kf;
+			memset(&kf, 0, sizeof(kf));
+			kf.desc = d_db; kf.mask = masksOn ? d_db + lay.ds : nullptr; kf.valid = d_dbValid; kf.n = lay.rows_frame; kf.stride = lay.row_stride;
+			MCSOK(mcs_search_kf_f_sweep(ctx, nkf, &kf, lay.rows_frame, FT, &fr, lay.rows_img, 32, 0.9, J.topk, MCS_MEM_DEVICE, d_match, d_nmatch, d_fb));
+		}
+	};
+
+	if (!ring) {   // untimed: stored keyframe k = multi-frame k % FT of one pass (as bench.py fills its database)
+		extract_and_exchange();
+		for (int j = 0; j < nkf; ++j)
+			for (int c = 0; c < J.ncam; ++c) {
+				const size_t x = lay.image_index(c, kfs[j] % FT);
+				HIPOK(hipMemcpyAsync(d_db + ((size_t)j * lay.rows_frame + (size_t)c * cap) * lay.row_stride, d_G + x * lay.block_bytes, (size_t)cap * lay.row_stride, hipMemcpyDeviceToDevice, stream));
+				HIPOK(hipMemcpyAsync(d_dbValid + (size_t)j * lay.rows_frame + (size_t)c * cap, d_valid + x * lay.rows_img, cap, hipMemcpyDeviceToDevice, stream));
+			}
+		HIPOK(hipStreamSynchronize(stream));
+	}
+	auto step = [&]() { extract_and_exchange(); match(); };
+	for (int i = 0; i < J.warmup; ++i) step();
+	MCSOK(mcs_ctx_synchronize(ctx));
+	pthread_barrier_wait(&g_barrier);
+	const auto t0 = std::chrono::steady_clock::now();
+	for (int i = 0; i < J.steps; ++i) step();
+	MCSOK(mcs_ctx_synchronize(ctx));
+	pthread_barrier_wait(&g_barrier);
+	g_ms[rank] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / std::max(J.steps, 1);
+	MCSOK(mcs_extractor_status(ex));
+
+	// ---- results of the last step, as this rank holds them
+	auto dump = [&](const char* name, const void* dptr, size_t bytes) {
+		std::vector<uint8_t> h(bytes);
+		HIPOK(hipMemcpy(h.data(), dptr, bytes, hipMemcpyDeviceToHost));
+		write_file(J.out + ".r" + std::to_string(rank) + "." + name, h.data(), bytes);
+	};
+	dump("G", d_G, view.images_total * view.block_bytes);
+	dump("valid", d_valid, (size_t)view.images_total * view.rows_img);
+	dump("kps", d_kps, (size_t)lay.L * cap * sizeof(mcs_keypoint));
+	dump("nkp", d_nkp, lay.L * sizeof(int32_t));
+	dump("match", d_match, (size_t)npairs * lay.rows_frame * sizeof(int32_t));
+	dump("nmatch", d_nmatch, npairs * sizeof(int32_t));
+	if (!ring && nkf) { dump("db", d_db, (size_t)nkf * lay.rows_frame * lay.row_stride); dump("dbvalid", d_dbValid, (size_t)nkf * lay.rows_frame); }
+	if (rank == 0) {
+		FILE* f = fopen((J.out + ".layout").c_str(), "w");
+		fprintf(f, "cap %d\nview_frames %d\nrows_img %d\nrow_stride %d\nL %d\n", cap, view.FT, view.rows_img, view.row_stride, lay.L);
+		fclose(f);
+	}
+	MCSOK(mcs_extractor_destroy(ex));
+	MCSOK(mcs_ctx_destroy(ctx));
+	for (void* p : {(void*)d_img, (void*)d_msk, (void*)d_send, (void*)d_G, (void*)d_valid, (void*)d_nkp, (void*)d_nkpAll, (void*)d_kps, (void*)d_rays, (void*)d_db, (void*)d_dbValid,
+	                (void*)d_match, (void*)d_nmatch, (void*)d_fb})
+		(void)hipFree(p);
+	HIPOK(hipStreamDestroy(stream));
+}
+
+int main(int argc, char** argv) {
+	if (argc < 2) { fprintf(stderr, "usage: rig_host <config>\n"); return 1; }
+	auto cfg = read_config(argv[1]);
+	auto geti = [&](const char* k, int def) { return cfg.count(k) ? atoi(cfg[k].c_str()) : def; };
+	Job J;
+	J.ncam = geti("ncam", 3); J.W = geti("width", 754); J.H = geti("height", 480); J.nfeat = geti("nfeatures", 1000); J.mode = geti("mode", 2);
+	J.F = geti("frames", 2); J.D = geti("keyframes", 0); J.steps = geti("steps", 2); J.warmup = geti("warmup", 1); J.topk = geti("topk", 32);
+	int ndev = 0;
+	HIPOK(hipGetDeviceCount(&ndev));
+	J.world = std::min(geti("gpus", ndev), ndev);
+	if (J.world < 1) { fprintf(stderr, "no HIP device\n"); return 1; }
+	if ((J.ncam * J.F * J.world) % J.world) { fprintf(stderr, "bad split\n"); return 1; }
+	J.images = read_file(cfg["images"]); J.masks = read_file(cfg["masks"]); J.cams = read_file(cfg["cams"]); J.out = cfg["out"];
+	const size_t need = (size_t)J.ncam * J.F * J.world * J.W * J.H;
+	if (J.images.size() != need || J.masks.size() != (size_t)J.ncam * J.W * J.H || J.cams.size() != (size_t)J.ncam * sizeof(mcs_ocam)) {
+		fprintf(stderr, "input sizes do not match the configuration (images %zu, want %zu)\n", J.images.size(), need);
+		return 1;
+	}
+	std::vector<ncclComm_t> comms(J.world);
+	std::vector<int> devs(J.world);
+	for (int i = 0; i < J.world; ++i) devs[i] = i;
+	NCCLOK(ncclCommInitAll(comms.data(), J.world, devs.data()));
+	pthread_barrier_init(&g_barrier, nullptr, J.world);
+	g_ms.assign(J.world, 0.0);
+	std::vector<std::thread> th;
+	for (int r = 0; r < J.world; ++r) th.emplace_back(rank_main, std::cref(J), r, comms[r]);
+	for (auto& t : th) t.join();
+	for (auto c : comms) NCCLOK(ncclCommDestroy(c));
+	const double ms = *std::max_element(g_ms.begin(), g_ms.end());
+	printf("{\"host\": \"rig_host (C++, one process, one thread per GPU, RCCL from ncclCommInitAll)\", \"n_gpus\": %d, \"steps\": %d, \"ms_per_step\": %.4f, "
+	       "\"exchange\": \"%s\", \"multi_frames_per_step_per_gpu\": %d, \"stored_keyframes\": %d}\n",
+	       J.world, J.steps, ms, J.D == 0 ? "ncclSend/ncclRecv group (frame ring)" : "ncclAllGather", J.F, J.D);
+	return 0;
+}

@@ -64,6 +64,78 @@ class RigLayout:
         return [(f, (f - 1) % self.frames_total) for f in range(rank * F, (rank + 1) * F)]
 
 
+class RingExchange:
+    """What a rank RECEIVES when every multi-frame only meets its predecessor (BASELINE configs[1]): rank r matches frames [r*F, (r+1)*F), so it needs the
+    camera blocks of frames r*F - 1 .. (r+1)*F - 1 and nothing else — 1/world of what the all-gather delivers.  The receive buffer is the local array
+    [camera][F + 1 frames][cap + 1 rows] (local frame 0 = the predecessor of the rank's first frame, cyclic), again consumed in place: `view` is the
+    RigLayout of that array (world 1, frames_total F + 1), so frame_desc_set / frame_rows / unpack_frame apply unchanged with LOCAL frame numbers and
+    mcs_search_kf_kf_ring runs on it with first = 1, count = F.  The transfers are runs of consecutive image blocks (consecutive frames of one camera lie
+    next to each other both in the owner's send buffer and in the receiver's array): `recvs(r)` / `sends(r)` list them as
+    (peer, offset in MY buffer in blocks, number of blocks), identically ordered on both sides — point-to-point sends grouped into one exchange step
+    (ncclSend / ncclRecv inside ncclGroupStart / End; torch: batch_isend_irecv), runs a rank owns itself are plain copies.
+    Blocks are sent whole (cap rows, not the image's keypoint count): a count-sized transfer would need the counts on the host, i.e. a device-to-host round
+    trip per step; with cap = nfeatures + 3 * nlevels the padding is 2 % here."""
+
+    def __init__(self, layout):
+        lay = layout
+        self.lay = lay
+        self.F = lay.frames_total // lay.world
+        self.view = RigLayout(lay.ncam, self.F + 1, 1, lay.cap, lay.desc_size)
+
+    def global_frame(self, rank, j):
+        """local frame j of rank `rank` shows this global frame"""
+        return (rank * self.F - 1 + j) % self.lay.frames_total
+
+    def _runs(self, rank):
+        """(owner, first block in the owner's send buffer, first block in rank's local array, blocks) for everything rank needs"""
+        lay, out = self.lay, []
+        for c in range(lay.ncam):
+            j = 0
+            while j <= self.F:
+                x = lay.image_index(c, self.global_frame(rank, j))
+                owner = x // lay.L
+                n = 1   # extend the run while the global image index stays consecutive and inside the owner's slab
+                while j + n <= self.F and lay.image_index(c, self.global_frame(rank, j + n)) == x + n and (x + n) // lay.L == owner:
+                    n += 1
+                out.append((owner, x - owner * lay.L, c * (self.F + 1) + j, n))
+                j += n
+        return out
+
+    def recvs(self, rank):
+        return [(owner, dst, n) for owner, _, dst, n in self._runs(rank)]
+
+    def sends(self, rank):
+        return [(dest, src, n) for dest in range(self.lay.world) for owner, src, _, n in self._runs(dest) if owner == rank]
+
+    def bytes_received(self, rank):
+        return sum(n for owner, _, n in self.recvs(rank) if owner != rank) * self.lay.block_bytes
+
+
+def ring_exchange_begin(ex, rank, send, recv, group=None, self_via_p2p=False):
+    """start the ring exchange of one step: send / recv are flat uint8 torch tensors (the rank's send blocks, its local [camera][F + 1] array).  Local runs
+    are copied at once (self_via_p2p: sent through the backend like the others — a one-rank RCCL run then exercises the transport); returns the list of
+    pending point-to-point requests (wait() on each: ring_exchange_end)."""
+    import torch.distributed as dist
+    bb = ex.lay.block_bytes
+    ops = []
+    for (peer, off, n) in ex.recvs(rank):
+        if peer != rank or self_via_p2p:
+            ops.append(dist.P2POp(dist.irecv, recv[off * bb:(off + n) * bb], peer, group))
+    for (peer, off, n) in ex.sends(rank):
+        if peer != rank or self_via_p2p:
+            ops.append(dist.P2POp(dist.isend, send[off * bb:(off + n) * bb], peer, group))
+    if not self_via_p2p:
+        for owner, src, dst, n in ex._runs(rank):
+            if owner == rank:
+                recv[dst * bb:(dst + n) * bb].copy_(send[src * bb:(src + n) * bb])
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def ring_exchange_end(reqs):
+    for r in reqs:
+        r.wait()
+
+
 def pack_blocks(layout, desc, mask, nkp):
     """numpy restatement of the send buffer (what mcs_extract_batch_strided + mcs_rig_pack_headers produce on the device):
     desc / mask [L][cap][ds] uint8, nkp [L] -> [L][cap + 1][2*ds] uint8"""

@@ -54,7 +54,7 @@ def test_exchange_path_on_rccl_at_world_size_1(args):
     out = run_bench("--exchange", "nccl1", "--steps", "4", "--warmup", "2", *args)
     cfg = out["config"]
     assert cfg["collective_backend"] == "nccl" and cfg["n_ranks"] == 1
-    assert "all-gather" in cfg["parallelism"]
+    assert ("1 all-gather" if args else "point-to-point exchange") in cfg["parallelism"]
     assert out["oracle_check"] is True and cfg["oracle_checked"]["pairs"] >= 1
     assert cfg["matches_per_step_rank0"] > 0
 
