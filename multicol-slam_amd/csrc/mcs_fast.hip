@@ -22,7 +22,8 @@ namespace mcs {
 // Two instances: CW = 40 (7.8 KB per workgroup: every level with four or more cell columns AND rows — a 30-px grid on w px gives cells of
 // ceil(w / floor(w / 30)) <= 40 from 120 px on) and CW = 60 (any cell).
 template <int CW> struct FastGeom {
-	static constexpr int kTilePitch = (CW + 6 + 3) / 4 * 4, kTileRows = CW + 6;
+	static constexpr int kTileX = 4;   // tile column of the cell's first processed pixel: a 4-byte left margin (3 ring pixels + 1), so that groups of 4 pixels are aligned dwords
+	static constexpr int kTilePitch = (CW + kTileX + 3 + 4 + 3) / 4 * 4, kTileRows = CW + 6;   // + 4: the packed compass test reads one dword past the right ring
 	static constexpr int kScPitch = (CW + 2 + 3) / 4 * 4, kScRows = CW + 2;
 	static constexpr int kBitWords = (CW * CW + 63) / 64 * 2, kGroups = (CW * CW + 63) / 64;
 };
@@ -105,6 +106,35 @@ __device__ __forceinline__ bool fast_quick(const uint8_t* c, int t) {
 	return (h0 & h4) | (h4 & h8) | (h8 & h12) | (h12 & h0) | (l0 & l4) | (l4 & l8) | (l8 & l12) | (l12 & l0);
 }
 
+// The same test for 4 horizontally adjacent pixels at once (an aligned group of the tile row): five aligned LDS dwords instead of 20 byte reads, the
+// differences as packed 16-bit pairs (v_pk_sub_i16 / v_pk_min_i16 / v_pk_max_i16).  With d = centre - ring pixel: two adjacent compass points darker
+// <=> min(d_a, d_b) > t, brighter <=> min(-d_a, -d_b) > t, so pass <=> max over the four adjacent pairs of max(min(d_a, d_b), -max(d_a, d_b)) > t.
+// Returns bit j = pixel 4g + j passes.
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s as_v2s(uint32_t x) { union { uint32_t u; v2s v; } c; c.u = x; return c.v; }
+template <int kTilePitch>
+__device__ __forceinline__ int fast_quick4(const uint8_t* rowc /* tile row of the centres, at the group's first pixel (4-aligned) */, int t) {
+	const uint32_t A = *reinterpret_cast<const uint32_t*>(rowc - 4), Cc = *reinterpret_cast<const uint32_t*>(rowc), B = *reinterpret_cast<const uint32_t*>(rowc + 4);
+	const uint32_t U = *reinterpret_cast<const uint32_t*>(rowc - 3 * kTilePitch), D = *reinterpret_cast<const uint32_t*>(rowc + 3 * kTilePitch);
+	const uint32_t Lf = __builtin_amdgcn_alignbyte(Cc, A, 1);   // the pixels 3 to the left of each centre:  A[1] A[2] A[3] C[0]
+	const uint32_t Rt = __builtin_amdgcn_alignbyte(B, Cc, 3);   // 3 to the right:                           C[3] B[0] B[1] B[2]
+	int bits = 0;
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {   // h = 0: bytes 0 and 2 of every dword, h = 1: bytes 1 and 3
+		const uint32_t m = 0x00FF00FFu;
+		const v2s v = as_v2s((Cc >> (8 * h)) & m);
+		const v2s d0 = v - as_v2s((D >> (8 * h)) & m), d8 = v - as_v2s((U >> (8 * h)) & m), d4 = v - as_v2s((Rt >> (8 * h)) & m), d12 = v - as_v2s((Lf >> (8 * h)) & m);
+		const v2s lo = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(d0, d4), __builtin_elementwise_min(d4, d8)),
+		                                         __builtin_elementwise_max(__builtin_elementwise_min(d8, d12), __builtin_elementwise_min(d12, d0)));
+		const v2s hi = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(d0, d4), __builtin_elementwise_max(d4, d8)),
+		                                         __builtin_elementwise_min(__builtin_elementwise_max(d8, d12), __builtin_elementwise_max(d12, d0)));
+		const v2s best = __builtin_elementwise_max(lo, -hi);
+		bits |= (best.x > t ? 1 : 0) << h;
+		bits |= (best.y > t ? 1 : 0) << (2 + h);
+	}
+	return bits;
+}
+
 template <int kTilePitch>
 __device__ __forceinline__ int fast_score(const uint8_t* c /* centre in LDS tile */, int t) {
 	const int v = c[0];
@@ -170,8 +200,8 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 
 	int stride;
 	const uint8_t* src = level_ptr(b, d, img, cell.level, &stride);
-	src += (size_t)(cell.y0 - 3) * stride + (cell.x0 - 3);
-	const int tw = cw + 6, th = ch + 6;
+	src += (size_t)(cell.y0 - 3) * stride + (cell.x0 - Geo::kTileX);
+	const int tw = cw + Geo::kTileX + 3, th = ch + 6;
 	const int ndw = (tw + 3) >> 2;   // unaligned dword loads; the <= 3 bytes of over-read per row stay inside the image row
 	// i / ndw by multiplication: ndw <= 17 and i < 17 * 66, so with M = ceil(2^16 / ndw) the error term i * (M*ndw - 2^16) < 2^16 and
 	// (i * M) >> 16 is exact; 32-bit offsets keep the address arithmetic out of 64-bit multiplies.
@@ -203,12 +233,42 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	const int lane = tid & 63, wave = tid >> 6;
 	// pass 1: cheap compass test on every pixel; survivors are compacted into an LDS list (order is irrelevant here) so that
 	// pass 2 — the full 16-pixel arc score, ~10x the work — runs with all lanes busy instead of diverging inside each wave
+	if constexpr (P == 16) {
+		// pass 1, 16-pixel ring: four adjacent pixels per thread (fast_quick4), one list reservation per wave and trip for the four ballots
+		const int gpr = (cw + 3) >> 2, ngrp = gpr * ch;   // groups per row: gpr <= 15, g < 15 * 60: M = ceil(2^16 / gpr) is exact
+		const unsigned gM = (65536u + (unsigned)gpr - 1u) / (unsigned)gpr;
+		for (int base = 0; base < ngrp; base += kFastBS) {
+			const int g = base + tid;
+			int bits = 0, py = 0, gx = 0;
+			if (g < ngrp) {
+				py = (int)(((unsigned)g * gM) >> 16); gx = g - py * gpr;
+				bits = fast_quick4<kTilePitch>(&tile[(py + 3) * kTilePitch + 4 * gx + Geo::kTileX], t);
+				const int left = cw - 4 * gx;   // pixels of the group inside the cell (the last group of a row may be partial)
+				if (left < 4) bits &= (1 << left) - 1;
+			}
+			unsigned long long bal[4];
+			int cnt[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { bal[j] = __ballot((bits >> j) & 1); cnt[j] = __popcll(bal[j]); }
+			const int total = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+			int wbase = 0;
+			if (lane == 0 && total) wbase = atomicAdd(&nSurv, total);
+			wbase = __shfl(wbase, 0);
+			const int p0 = py * cw + 4 * gx;
+			const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				if ((bits >> j) & 1) surv[wbase + __popcll(bal[j] & below)] = (unsigned short)(p0 + j);
+				wbase += cnt[j];
+			}
+		}
+	} else
 	for (int base = 0; base < npx; base += kFastBS) {
 		const int p = base + tid;
 		bool pass = false;
 		if (p < npx) {
 			const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
-			const uint8_t* c = &tile[(py + 3) * kTilePitch + px + 3];
+			const uint8_t* c = &tile[(py + 3) * kTilePitch + px + Geo::kTileX];
 			if constexpr (P == 16) pass = fast_quick<kTilePitch>(c, t);
 			else pass = small_ring_quick<P, kTilePitch>(c, t);
 		}
@@ -223,7 +283,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	for (int i = tid; i < ns; i += kFastBS) {
 		const int p = surv[i];
 		const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
-		const uint8_t* c = &tile[(py + 3) * kTilePitch + px + 3];
+		const uint8_t* c = &tile[(py + 3) * kTilePitch + px + Geo::kTileX];
 		int score;
 		if constexpr (P == 16) score = fast_score<kTilePitch>(c, t);
 		else score = small_ring_score<P, kTilePitch>(c, t);
@@ -280,6 +340,9 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	(void)sw;
 }
 
+// (A strip form — one workgroup per run of 8 cells of a cell row, per-wave survivor queues instead of the list + atomics, the score tile rescanned as dwords
+// for the non-max suppression, four barriers per 8 cells — was built and measured in round 3: bit-exact, but 0.69 -> 1.10 ms per step under the profiler: 32 KB
+// of LDS per workgroup halves the waves per CU, and a wave's 50 dependent trips of test -> ballot -> queue are a longer chain than the cell form's 10.)
 // cells of pyramid levels [level0, level1): level 0 needs no pyramid, so the caller can run it beside the resize chain
 void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0, int level1) {
 	if (level1 > hd.nlevels) level1 = hd.nlevels;
