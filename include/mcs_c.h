@@ -113,13 +113,13 @@ int mcs_extract_batch(mcs_extractor*, int nimg, const uint8_t* images, size_t im
  *                                  (must stay below mcs_describe_fast_bound)
  *   mcs_describe_fast_table        (host only, no device needed) the camera's table of G(s) = rho(atan(p0 / sqrt(s))) / sqrt(s) the fast pass reads: `rows`
  *                                  rows of `row_len` Taylor coefficients, row = (exponent of s - e0) * bins_per_octave + top mantissa bits, variable =
- *                                  low mantissa fraction - half a bin;  info5 = {tail bound in pixels, max |rho|, max sqrt(s)|s G'|, Lipschitz bound of
- *                                  (x G, y G), largest row error the builder itself measured}; any output may be NULL                                */
+ *                                  low mantissa fraction - half a bin;  info6 = {tail bound in pixels, max |rho|, max sqrt(s)|s G'|, Lipschitz bound of
+ *                                  (x G, y G), largest row error the builder itself measured, max Lipschitz bound x (sqrt(s) + 44)}; any output may be NULL                                */
 int mcs_extractor_set_describe(mcs_extractor*, int exact_only, double guard_eps);
 int mcs_extractor_describe_stats(mcs_extractor*, uint64_t* exact_pass_keypoints, double* guard_eps);
 int mcs_describe_fast_bound(const mcs_ocam* cam, int desc_size, double* bound);
 int mcs_selftest_describe_fast(mcs_ctx*, const mcs_ocam* cam, uint64_t seed, int n, double* max_abs_diff);
-int mcs_describe_fast_table(const mcs_ocam* cam, double* table, int* rows, int* row_len, int* e0, int* bins_per_octave, double* info5);
+int mcs_describe_fast_table(const mcs_ocam* cam, double* table, int* rows, int* row_len, int* e0, int* bins_per_octave, double* info6);
 
 /* mcs_extract_batch (device memory) with the descriptor / mask rows laid out for an exchange: row k of image i is written at
  * desc + (i * out_image_pitch_rows + k) * out_row_stride (descmask alike); 0 = the defaults (capacity rows, descSize bytes).  The camera-sharded rig

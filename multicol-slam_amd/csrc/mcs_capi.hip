@@ -48,6 +48,8 @@ struct GTabInfo {
 	double rhoB = 0;           // max sqrt(s) * sum_j |g_j| |eps|^j  (>= |rho| on the table's range)
 	double dB = 0;             // max sqrt(s) * |s G'(s)|
 	double lip = 0;            // max (|G| + 2 |s G'(s)|) >= both eigenvalues of d(x G, y G) / d(x, y)
+	double inB = 0;            // max (|G| + 2 |s G'(s)|) * (sqrt(s) + 44): what one relative rounding of the rotated pattern point moves (x G, y G) by — a point
+	                           // at distance n from the axis belongs to a keypoint within n + 22 of it, and the rotated offset is within 22: |terms| <= n + 44
 	double seen = 0;           // largest |row polynomial - G| (times sqrt(s)) at the sample points checked against direct long double evaluation
 };
 
@@ -75,7 +77,7 @@ static GTabInfo build_g_table(const mcs_ocam& m, double* tab) {
 		for (int i = n - 1; i >= 0; --i) r = r * th + (LD)m.invP[i];
 		return r / nn;
 	};
-	double tailU = 0, rhoB = 0, dB = 0, lip = 0, seen = 0;
+	double tailU = 0, rhoB = 0, dB = 0, lip = 0, inB = 0, seen = 0;
 	for (int e = kGE0; e < kGE1; ++e)
 		for (int k = 0; k < (1 << kGM); ++k) {
 			const LD kappa = 1.0L + ((LD)k + 0.5L) / (LD)(1 << kGM), c = ldexpl(kappa, e), sqc = sqrtl(c), zc = p0 / sqc, thc = atanl(zc);
@@ -155,6 +157,7 @@ static GTabInfo build_g_table(const mcs_ocam& m, double* tab) {
 			rhoB = std::max(rhoB, sq * gabs);
 			dB = std::max(dB, sq * gder);
 			lip = std::max(lip, gabs + 2.0 * gder);
+			inB = std::max(inB, (gabs + 2.0 * gder) * (sq + 44.0));
 			// sanity: the row against G itself at both ends of the bin and in the middle
 			for (int t = -2; t <= 2; ++t) {
 				const LD tau = (LD)t * ldexpl(1.0L, -(kGM + 2)) * (1.0L - 1e-9L), sv = ldexpl(kappa + tau, e);
@@ -163,7 +166,7 @@ static GTabInfo build_g_table(const mcs_ocam& m, double* tab) {
 				seen = std::max(seen, (double)(fabsl(pv - direct(sv)) * sqrtl(sv)));
 			}
 		}
-	info.tailU = tailU; info.rhoB = rhoB * 1.01; info.dB = dB * 1.01; info.lip = lip * 1.01; info.seen = seen;
+	info.tailU = tailU; info.rhoB = rhoB * 1.01; info.dB = dB * 1.01; info.lip = lip * 1.01; info.inB = inB * 1.01; info.seen = seen;
 	if (!(seen <= tailU + 64 * 1.1102230246251565e-16 * rhoB)) info.tailU = INFINITY;   // the rows must reproduce G within the bound they claim (plus their own rounding to double)
 	return info;
 }
@@ -171,8 +174,9 @@ static GTabInfo build_g_table(const mcs_ocam& m, double* tab) {
 // Worst-case |(fast coordinate - fast mean) - (reference coordinate - reference mean)| for one camera and npoints pattern points.
 // u = 2^-53.  Both arithmetics evaluate the same real function F(X, Y) = affine(X G(s), Y G(s)), s = X^2 + Y^2, of the same real rotated pattern point
 // (X, Y) = R(angle) (ptx, pty) + undistorted keypoint; each differs from it by its own rounding:
-//   inputs  |X|, |Y| < 4096 (the table ends at s = 2^24; a point outside sends the keypoint to the exact pass).  Reference: 3 roundings per coordinate,
-//           fast: 2 (two FMAs).  F moves by at most aff * lip per unit of either input (lip >= |G| and |d rho / d n|, from the table).
+//   inputs  X = ptx ax - pty ay + ukx: reference 3 roundings, fast 2 (two FMAs), each relative to |ptx ax| + |pty ay| + |ukx| <= n + 44 for a point at distance
+//           n from the axis (the keypoint lies within n + 22 of it, the rotated offset within 22).  F moves by at most aff * (|G| + 2 |s G'|) per unit of
+//           either input; the product with n + 44 is maximised over the table's rows (inB): near the axis G ~ rho(axis) / n is large where n + 44 is small.
 //   fast    s: 2 roundings (2.01 u relative, G moves by |s G'(s)| per relative unit: dB);  the row: truncated tail (tailU) + coefficients rounded to double +
 //           6 FMAs (13 u of sum |g_j| |eps|^j: rhoB);  x G, y G: u each;  the affine map without the principal point (it cancels against the mean): 2 more
 //   ref     atan's argument and atan itself (12 u S' generously: ocml / glibc stay within 2 ulp) + 24 roundings of the Horner chain, 2 divisions, 2 products
@@ -191,10 +195,10 @@ static double describe_fast_bound(const mcs_ocam& m, int npoints, const GTabInfo
 		if (i + 1 < m.invP_deg) Sp += (i + 1) * std::fabs(m.invP[i + 1]) * pw;
 		pw *= hp;
 	}
-	if (!(std::fabs(m.p[0]) > 1e-300) || !std::isfinite(m.p[0]) || !std::isfinite(g.tailU) || !std::isfinite(g.rhoB) || !std::isfinite(g.dB) || !std::isfinite(g.lip)) return INFINITY;
+	if (!(std::fabs(m.p[0]) > 1e-300) || !std::isfinite(m.p[0]) || !std::isfinite(g.tailU) || !std::isfinite(g.rhoB) || !std::isfinite(g.dB) || !std::isfinite(g.lip) || !std::isfinite(g.inB)) return INFINITY;
 	const double aff = 1.0 + std::fabs(m.c) + std::fabs(m.d) + std::fabs(m.e), pp = 8 * u * (std::fabs(m.u0) + std::fabs(m.v0));
 	const int nb = npoints / 128;
-	const double inputs = aff * g.lip * (2 * (2 + 3) * u * 4096.0 * 1.01);
+	const double inputs = aff * g.inB * (2 * (2 + 3) * u * 1.01);
 	const double fast = aff * (g.tailU + 16 * u * g.rhoB + 2.01 * u * g.dB);
 	const double ref = aff * (12 * u * Sp + 96 * u * S) + pp;
 	const double point = inputs + fast + ref;
@@ -259,6 +263,7 @@ int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
 	else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownStream = true; }
 	HIPCHK(hipMalloc(&c->dscalar, 64));
 	if (getenv("MCS_NO_OVERLAP") == nullptr) {
+		// (stream priorities — resize chain urgent, deferred matcher least urgent, and every other combination — change nothing measurable: 2.32 ms either way)
 		HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
 		HIPCHK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
 
@@ -270,6 +275,7 @@ int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
 		HIPCHK(hipEventCreateWithFlags(&c->evGreedy, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&c->evDescFork, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&c->evDescJoin, hipEventDisableTiming));
+
 		for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&c->evSearch[i], hipEventDisableTiming));
 	}
 	*out = c;
@@ -688,6 +694,8 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		if (e->camCache.size() > 64) e->camCache.clear();   // a rig has a handful of cameras; a caller that streams distinct models rebuilds (which[] is dead here)
 		b.cams = e->d_cams;
 	}
+	// (Other launch orders measured in round 3: the whole resize chain first on the main stream, then FAST on all levels in one launch with the blur beside it:
+	// 2.55 instead of 2.21 ms per step; level 1 first, then FAST on levels 0 and 1 beside the rest of the chain: 2.51.)
 	if (c->overlap()) {
 		// Two chains until the descriptors: the side stream runs the resize chain (7 dependent, latency-bound launches) and then the blur, which needs
 		// nothing else; the main stream starts FAST on level 0 — the input image itself, a third of all FAST work — at once, picks up the other levels
@@ -705,6 +713,8 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		launch_fast(b, hd, nimg, s, 1, 2);
 		HIPCHK(hipStreamWaitEvent(s, c->evPyr, 0));
 		launch_fast(b, hd, nimg, s, 2, hd.nlevels);
+		// (holding the previous step's deferred matcher back until here, so that it runs beside the oct-tree / orientation / descriptor kernels instead of
+		// beside FAST and the resize chain: measured, 2.22 -> 2.55 ms per step — the descriptor kernel on the critical path suffers more from the company)
 		launch_octree(b, hd, nimg, s);   // (oct-trees of levels 0 / 1 on a further stream beside FAST of the rest: measured, no gain)
 		HIPCHK(hipStreamWaitEvent(s, c->evBlur, 0));
 	} else {
@@ -781,7 +791,7 @@ int mcs_describe_fast_bound(const mcs_ocam* cam, int desc_size, double* bound) {
 	return MCS_OK;
 }
 
-int mcs_describe_fast_table(const mcs_ocam* cam, double* table, int* rows, int* row_len, int* e0, int* bins_per_octave, double* info5) {
+int mcs_describe_fast_table(const mcs_ocam* cam, double* table, int* rows, int* row_len, int* e0, int* bins_per_octave, double* info6) {
 	if (!cam || cam->invP_deg < 1 || cam->invP_deg > MCS_MAX_POLY || cam->p_deg < 1) return fail(MCS_ERR_INVALID, "bad argument");
 	std::vector<double> tab(kGTabDoubles, 0.0);
 	const GTabInfo g = build_g_table(*cam, tab.data());
@@ -790,7 +800,7 @@ int mcs_describe_fast_table(const mcs_ocam* cam, double* table, int* rows, int* 
 	if (row_len) *row_len = kGRow;
 	if (e0) *e0 = kGE0;
 	if (bins_per_octave) *bins_per_octave = 1 << kGM;
-	if (info5) { info5[0] = g.tailU; info5[1] = g.rhoB; info5[2] = g.dB; info5[3] = g.lip; info5[4] = g.seen; }
+	if (info6) { info6[0] = g.tailU; info6[1] = g.rhoB; info6[2] = g.dB; info6[3] = g.lip; info6[4] = g.seen; info6[5] = g.inB; }
 	return MCS_OK;
 }
 

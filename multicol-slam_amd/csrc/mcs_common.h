@@ -75,10 +75,11 @@ struct OcamDev {
 #define MCS_G_M 5     // 32 bins per octave, degree 6: 56-byte rows, 54 KB (64 bins, degree 5: 48-byte rows, 0.675 against 0.696 ms, but 92 KB for the same range; 16 bins, degree 8: 0.753 ms)
 #define MCS_G_DEG 6
 #endif
-constexpr int kGM = MCS_G_M, kGDeg = MCS_G_DEG, kGE0 = -6, kGE1 = 24, kGRows = (kGE1 - kGE0) << kGM, kGRow = kGDeg + 1, kGTabDoubles = kGRows * kGRow;
-// The table starts at s = 2^kGE0, i.e. 1/8 pixel from the optical axis: G has a sqrt-type branch point at s = 0 (rho(theta) of a fitted backward polynomial
+constexpr int kGM = MCS_G_M, kGDeg = MCS_G_DEG, kGE0 = -10, kGE1 = 24, kGRows = (kGE1 - kGE0) << kGM, kGRow = kGDeg + 1, kGTabDoubles = kGRows * kGRow;
+// The table starts at s = 2^kGE0, i.e. 1/32 pixel from the optical axis: G has a sqrt-type branch point at s = 0 (rho(theta) of a fitted backward polynomial
 // does not vanish exactly on the axis), so only log-spaced bins reach down there.  One keypoint in 200 has the axis inside its pattern's footprint, and of
-// those one in 20 a point within 1/8 px of it: that keypoint takes the exact pass.  (Starting the table at s = 16 sent 1 % of all keypoints there.)
+// those one in 300 a point within 1/32 px of it: that keypoint takes the exact pass.  (Starting the table at s = 16 sent 1 % of all keypoints there, at
+// s = 2^-6 still 60 per 193 000.)
 constexpr int kSlotAlign = 8;       // keypoint slots per image are a multiple of this (the fast pass walks groups of 8 keypoints of ONE image, a wave each)
 
 // Per-keypoint scratch of the descriptor passes (mcs_describe.hip), one array per field over all keypoint slots of the batch (thread-per-keypoint kernels

@@ -537,6 +537,9 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64) void k_describe_wide(ExtractB
 template <int MODE, int NB>
 __global__ __launch_bounds__(64) void k_describe_list(ExtractBuffers b, int wavesPerImage, const int* count, const uint32_t* list) {
 	extern __shared__ __attribute__((aligned(16))) double lds[];
+	// A handful of single waves on the critical path of the step, each a long dependent chain: raise their issue priority over whatever else shares the
+	// SIMD (the deferred matcher of the previous step runs beside them: 0.19 ms average, 0.56 ms worst for ~100 keypoints without this, 0.03 ms alone).
+	__builtin_amdgcn_s_setprio(3);
 	const int n = *count;
 	if (blockIdx.x == 0 && threadIdx.x == 0 && b.fbStats) atomicAdd(b.fbStats, (unsigned long long)n);
 	for (int i = blockIdx.x; i < n; i += gridDim.x) describe_wave<MODE, NB>(b, wavesPerImage, lds, (int)list[i]);
@@ -877,11 +880,17 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 	const PyrDesc& d = *b.desc;
 	KpAuxSoA A; A.carve(b.aux, nslots);
 	const int ngroups = nslots / kFastWaves;
-	const int g0 = (int)blockIdx.x * groupsPerBlock, g1 = min(g0 + groupsPerBlock, ngroups);
+	// Trip k of the walk: the resident workgroups together cover the groups [k * gridDim.x, (k + 1) * gridDim.x) — 4096 consecutive keypoints, a handful of
+	// images whose blurred levels then sit in L2 / Infinity Cache for everybody (a contiguous range of groups PER workgroup had every workgroup in a different
+	// image: 711 instead of 365 MB fetched from HBM per launch).  Within a trip an XCD (blockIdx.x % 8: its own L2) takes a contiguous eighth.
+	const int nb = (int)gridDim.x, perXcd = (nb + kNumXCD - 1) / kNumXCD;
+	const int logical = nb % kNumXCD == 0 ? ((int)blockIdx.x % kNumXCD) * perXcd + (int)blockIdx.x / kNumXCD : (int)blockIdx.x;   // a bijection on [0, nb) either way
 	const size_t S = (size_t)nslots;
 	int curTab = -1;
 #pragma unroll 1
-	for (int g = g0; g < g1; ++g) {
+	for (int k = 0; k < groupsPerBlock; ++k) {
+		const int g = k * nb + logical;
+		if (g >= ngroups) break;   // uniform over the workgroup
 		const int base = g * kFastWaves;
 		const int bimg = base / wavesPerImage;   // every slot of a group is a keypoint of the same image
 		const OcamDev& cam = b.cams[bimg];
@@ -982,7 +991,9 @@ template <int MODE, int NB>
 static void launch_fast_passes(const ExtractBuffers& b, int nimg, int wavesPerImage, size_t listLds, hipStream_t s) {
 	const int nslots = nimg * wavesPerImage, ngroups = nslots / kFastWaves, lblocks = std::min(nslots, 2048);
 	// two workgroups of 8 waves fit a CU (registers: 4 waves per SIMD): one resident generation of workgroups walks the whole batch
-	const int groupsPerBlock = std::max(1, (ngroups + kFastBlocks - 1) / kFastBlocks), fblocks = (ngroups + groupsPerBlock - 1) / groupsPerBlock;
+	const int groupsPerBlock = std::max(1, (ngroups + kFastBlocks - 1) / kFastBlocks);
+	int fblocks = (ngroups + groupsPerBlock - 1) / groupsPerBlock;
+	if (fblocks >= kNumXCD) fblocks = (fblocks + kNumXCD - 1) / kNumXCD * kNumXCD;   // whole XCD rounds: the kernel's block -> group mapping is XCD-contiguous
 	const size_t fLds = (size_t)kFastWaves * kPatchBytes + kGTabDoubles * sizeof(double);
 	(void)hipMemsetAsync(b.fbCount, 0, 2 * sizeof(int), s);   // fbCount and preCount are neighbours
 	hipLaunchKernelGGL(k_orient_a, dim3((nslots + 15) / 16), dim3(256), 0, s, b, wavesPerImage, nslots);

@@ -30,11 +30,11 @@ def _cams():
 def _table(cam):
     oc = mcs.make_ocam(cam)
     rows, rl, e0, bpo = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-    info = (C.c_double * 5)()
+    info = (C.c_double * 6)()
     mcs.check(mcs.lib().mcs_describe_fast_table(C.byref(oc), None, C.byref(rows), C.byref(rl), C.byref(e0), C.byref(bpo), info))
     tab = np.zeros((rows.value, rl.value))
     mcs.check(mcs.lib().mcs_describe_fast_table(C.byref(oc), tab.ctypes.data_as(C.c_void_p), None, None, None, None, None))
-    return tab, e0.value, bpo.value, dict(zip(("tailU", "rhoB", "dB", "lip", "seen"), list(info)))
+    return tab, e0.value, bpo.value, dict(zip(("tailU", "rhoB", "dB", "lip", "seen", "inB"), list(info)))
 
 
 def _G(cam, s):
@@ -94,6 +94,7 @@ def test_claimed_magnitudes_hold_against_finite_differences():
         assert float((np.abs(sG) * n).max()) <= info["dB"] * (1 + 1e-6)
         drho = G + 2 * sG                                                # d(n G(n^2)) / dn
         assert float(np.maximum(np.abs(G), np.abs(drho)).max()) <= info["lip"] * (1 + 1e-6)
+        assert float((np.maximum(np.abs(G), np.abs(drho)) * (n + 44)).max()) <= info["inB"] * (1 + 1e-6)
 
 
 def _majorant_tail(cam, e0, nrows, bpo, DEG):
@@ -138,7 +139,8 @@ def _bound(cam, npoints, info, tailU):
     Sp = sum(i * v * hp ** (i - 1) for i, v in enumerate(a) if i)
     aff = 1 + abs(cam["c"]) + abs(cam["d"]) + abs(cam["e"])
     pp = 8 * u * (abs(cam["u0"]) + abs(cam["v0"]))
-    inputs = aff * info["lip"] * (2 * (2 + 3) * u * 4096 * 1.01)          # reference 3 roundings, fast 2, both coordinates
+    # reference 3 roundings, fast 2, both coordinates, each relative to |ptx ax| + |pty ay| + |ukx| <= n + 44; inB = max (|G| + 2 |s G'|) (n + 44)
+    inputs = aff * info["inB"] * (2 * (2 + 3) * u * 1.01)
     fast = aff * (tailU + 16 * u * info["rhoB"] + 2.01 * u * info["dB"])
     ref = aff * (12 * u * Sp + 96 * u * S) + pp
     nb = npoints // 128
