@@ -21,6 +21,9 @@ namespace mcs {
 // LDS geometry for cells of at most CW x CW processed pixels (the level's wCell / hCell): tile = cell + 3-px ring, score tile = cell + 1-px zero frame.
 // Two instances: CW = 40 (7.8 KB per workgroup: every level with four or more cell columns AND rows — a 30-px grid on w px gives cells of
 // ceil(w / floor(w / 30)) <= 40 from 120 px on) and CW = 60 (any cell).
+#ifndef MCS_FAST_BS
+#define MCS_FAST_BS 128
+#endif
 template <int CW> struct FastGeom {
 	static constexpr int kTileX = 4;   // tile column of the cell's first processed pixel: a 4-byte left margin (3 ring pixels + 1), so that groups of 4 pixels are aligned dwords
 	static constexpr int kTilePitch = (CW + kTileX + 3 + 4 + 3) / 4 * 4, kTileRows = CW + 6;   // + 4: the packed compass test reads one dword past the right ring
@@ -359,7 +362,7 @@ void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream
 	const dim3 grid(perXcd * kNumXCD);
 #define MCS_FAST_LAUNCH(P)                                                                                                                      \
 	do {                                                                                                                                        \
-		if (cellMax <= 40) hipLaunchKernelGGL((k_fast_cells<40, 128, P>), grid, dim3(128), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);     \
+		if (cellMax <= 40) hipLaunchKernelGGL((k_fast_cells<40, MCS_FAST_BS, P>), grid, dim3(MCS_FAST_BS), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);     \
 		else hipLaunchKernelGGL((k_fast_cells<60, 256, P>), grid, dim3(256), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);                   \
 	} while (0)
 	if (hd.fastRing == 16) MCS_FAST_LAUNCH(16);
