@@ -181,7 +181,8 @@ def pmc_entry(tag, dom):
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         ks = t["workloads"][tag]["kernels"]
-        parts = [ks[n] for n in (("describe", "orient_a", "orient_b", "describe_list") if dom == "describe" else (dom,)) if n in ks]   # "describe" = the whole descriptor stage
+        # "keypoints" = the keypoint stage: oct-tree + orientation (its tail), keypoint records / rays, descriptors
+        parts = [ks[n] for n in (("octree", "orient_a", "orient_b", "describe", "describe_list", "describe_exact") if dom == "keypoints" else (dom,)) if n in ks]
         if not parts:
             return None, None
         return int(sum(k["fetch_kib"] + k["write_kib"] for k in parts) * 1024), sum(k.get("valu_insts", 0) for k in parts)
@@ -433,21 +434,28 @@ def roofline_block(sp, job, kern, feats_local, pairs_local):
     rows = job.lay.rows_frame
     nsets = sp.F if sp.D == 0 else job.nkf * job.FT
     width = 64 if job.masks_on else 32
-    alg = {"describe": per_kp * feats_local, "pyramid": nimg * (sum(S) - S[-1] + sum(S) - S[0]), "fast": nimg * sum(S), "blur": nimg * 2 * sum(S),
+    # The per-keypoint bytes of SURVEY.md §8d (orientation disc 845 B + pattern samples + keypoint + descriptor [+ mask]) belong to the KEYPOINT STAGE: the oct-tree
+    # kernel (selection + the orientation of the selected keys in its tail), k_orient_b (records, rays) and the descriptor kernels.  It is priced as one unit
+    # ("keypoints"); "describe" alone carries the bytes without the disc.
+    kern = dict(kern)
+    if "octree" in kern and "describe" in kern:
+        kern["keypoints"] = kern["octree"] + kern["describe"]
+    alg = {"keypoints": per_kp * feats_local, "describe": (per_kp - 845) * feats_local, "pyramid": nimg * (sum(S) - S[-1] + sum(S) - S[0]), "fast": nimg * sum(S), "blur": nimg * 2 * sum(S),
            # matcher: every set pair reads its query and train rows once (descriptor + mask) and writes K list entries per query row
            "match": (nsets * 2 * rows * width + nsets * rows * 4 * sp.topk) if "match" in kern else 0}
-    dom = max((k for k in alg if k in kern), key=lambda k: kern[k])
+    dom = max((k for k in alg if k in kern and not (k == "describe" and "keypoints" in kern)), key=lambda k: kern[k])
     ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
     traffic, valu = pmc_entry(sp.tag, dom)
     mfma = "match" in kern and job.lay.desc_size in (16, 32) and not os.environ.get("MCS_MATCH_VALU")   # launch_match(): no count_le, no camera groups here
-    kname = {"match": "k_match_mfma" if mfma else "k_match_partial", "describe": "k_describe" if sp.mode == "orb" else "k_describe_fast (descriptor stage: + k_orient_a, k_orient_b, k_describe_list)",
+    kname = {"match": "k_match_mfma" if mfma else "k_match_partial", "describe": "k_describe" if sp.mode == "orb" else "k_describe_fast",
+             "keypoints": "keypoint stage: k_octree (selection + orientation of the selected keys) + " + ("k_describe" if sp.mode == "orb" else "k_orient_b + k_describe_fast + k_describe_list"),
              "pyramid": "k_resize_level (x7)", "fast": "k_fast_cells (x3)", "blur": "k_blur"}[dom]
     out = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
            "frac": round(ach / 8000.0, 5), "traffic": traffic, "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kern[dom], 4),
-           "per_kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+           "per_kernel_ms": {k: round(v, 4) for k, v in kern.items() if k != "keypoints"},
            "per_kernel_alg_GBps": {k: round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) for k in alg if k in kern and kern[k] > 0},
            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" if traffic else None,
-           "note": "no kernel of this path is HBM-bound (descriptor stage: FP64 at 16 lanes/clk; matcher: FP4 MFMA dot products + a VALU-bound K-best selection); "
+           "note": "no kernel of this path is HBM-bound (descriptor kernel: LDS gather of the camera table + FP64 at 16 lanes/clk; matcher: FP4 MFMA dot products + a VALU-bound K-best selection); "
                    "the bounds that apply are VALU issue and, for the matcher, the matrix cores: DESIGN.md §6"}
     flop_pair = 2 * 8 * job.lay.desc_size * (2 if job.masks_on else 1)   # a pair distance = one dot product over K = 8 * bytes (x2 with masks), DESIGN.md §4c
     if dom == "match" and mfma:   # the dominant kernel runs on the matrix cores: price it against the dense FP4 MFMA peak

@@ -13,7 +13,7 @@
 #include <vector>
 
 namespace mcs {
-void upload_describe_tables(const signed char* pattern, const signed char* disc, const int* umax);
+void upload_describe_tables(const signed char* pattern);
 void launch_single_distance(const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out, hipStream_t s);
 void launch_selftest_fast_model(const OcamDev* cam, const double* tab, unsigned long long seed, int n, int width, int height, unsigned long long* maxDiff, hipStream_t s);
 static const signed char kPattern[2048] = {
@@ -222,6 +222,7 @@ struct mcs_extractor {
 	short* d_maskMap = nullptr;
 	uint8_t *d_pyr = nullptr, *d_blur = nullptr;
 	uint32_t *d_slots = nullptr, *d_dense = nullptr, *d_sel = nullptr;
+	float* d_selAngle = nullptr;
 	unsigned short* d_knode = nullptr;
 	int *d_cellCount = nullptr, *d_denseCount = nullptr, *d_selCount = nullptr, *d_status = nullptr;
 	OcamDev* d_cams = nullptr;
@@ -510,7 +511,8 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	for (int v = -kHalfPatch; v <= kHalfPatch; ++v)
 		for (int u = -umax[std::abs(v)]; u <= umax[std::abs(v)]; ++u) { disc.push_back((signed char)u); disc.push_back((signed char)v); }
 	if (disc.size() != 845 * 2) { delete e; return fail(MCS_ERR_INVALID, "internal: disc size"); }
-	upload_describe_tables(kPattern, disc.data(), umax);
+	for (int v = 0; v <= kHalfPatch; ++v) hd.umax[v] = umax[v];
+	upload_describe_tables(kPattern);
 
 	const size_t B = max_batch;
 #define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) { mcs_extractor_destroy(e); return fail(MCS_ERR_HIP, std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(_e)); } } while (0)
@@ -524,6 +526,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	ALLOC(e->d_dense, B * hd.densePerImage * sizeof(uint32_t));
 	ALLOC(e->d_knode, B * hd.densePerImage * sizeof(unsigned short));
 	ALLOC(e->d_sel, B * hd.selPerImage * sizeof(uint32_t));
+	ALLOC(e->d_selAngle, B * hd.selPerImage * sizeof(float));
 	ALLOC(e->d_cellCount, B * hd.cellsPerImage * sizeof(int));
 	ALLOC(e->d_denseCount, B * nl * sizeof(int));
 	ALLOC(e->d_selCount, B * nl * sizeof(int));
@@ -567,7 +570,7 @@ int mcs_extractor_destroy(mcs_extractor* e) {
 	}
 	void* ptrs[] = {e->d_desc, e->d_cells, e->d_taps, e->d_maskMap, e->d_pyr, e->d_blur, e->d_slots, e->d_dense, e->d_knode,
 	                e->d_sel, e->d_cellCount, e->d_denseCount, e->d_selCount, e->d_status, e->d_cams, e->d_nkp, e->d_kps, e->d_odesc,
-	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_preList, e->d_fbStats, e->d_aux, e->d_gTab};
+	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_preList, e->d_fbStats, e->d_aux, e->d_gTab, e->d_selAngle};
 	for (void* p : ptrs) (void)hipFree(p);
 	delete e;
 	return MCS_OK;
@@ -615,7 +618,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 	ExtractBuffers b{};
 	b.desc = e->d_desc; b.cells = e->d_cells; b.taps = e->d_taps; b.maskMap = e->d_maskMap;
 	b.pyr = e->d_pyr; b.blur = e->d_blur; b.slots = e->d_slots; b.cellCount = e->d_cellCount; b.dense = e->d_dense; b.knode = e->d_knode;
-	b.denseCount = e->d_denseCount; b.sel = e->d_sel; b.selCount = e->d_selCount; b.status = e->d_status;
+	b.denseCount = e->d_denseCount; b.sel = e->d_sel; b.selCount = e->d_selCount; b.selAngle = e->d_selAngle; b.status = e->d_status;
 	b.gTab = e->d_gTab; b.aux = e->d_aux; b.fbCount = e->d_fbCount; b.fbList = e->d_fbList; b.preCount = e->d_fbCount + 1; b.preList = e->d_preList;
 	b.fbStats = e->d_fbStats; b.guardEps = e->guardEps; b.describeMode = e->describeMode;
 	b.sideStream = nullptr; b.evDescFork = nullptr; b.evDescJoin = nullptr;

@@ -46,6 +46,7 @@ struct PyrDesc {
 	int fastThreshold;
 	int fastRing;           // 16 / 12 / 8: FastFeatureDetector TYPE_9_16 / TYPE_7_12 / TYPE_5_8
 	int descSize, npoints;
+	int umax[kHalfPatch + 1];   // half-width of orientation-disc row |v| (reference :187-202)
 	int mode;               // 0 ORB, 1 dBRIEF, 2 mdBRIEF
 	int undistort;          // do_dBrief (reference gates undistortion on it only, Appendix B.1)
 	LevelInfo lv[MCS_MAX_LEVELS];
@@ -87,15 +88,13 @@ constexpr int kSlotAlign = 8;       // keypoint slots per image are a multiple o
 constexpr int kAuxExact = 0x100;
 struct KpAuxSoA {
 	int* lvl; int* rc;                  // level / flags;  row | col << 16
-	float* ang; float* pxf; float* pyf; // orientation, keypoint in image coordinates
 	double* d8;                         // [8][slots]: undistorted keypoint x, y; cos, sin of the (up to) three pattern angles
 	int slots;
-	__host__ __device__ static size_t bytes_per_slot() { return 2 * sizeof(int) + 3 * sizeof(float) + 8 * sizeof(double); }
+	__host__ __device__ static size_t bytes_per_slot() { return 2 * sizeof(int) + 8 * sizeof(double); }
 	__host__ __device__ void carve(void* base, int nslots) {   // nslots is a multiple of kSlotAlign
 		slots = nslots;
 		d8 = reinterpret_cast<double*>(base);
 		lvl = reinterpret_cast<int*>(d8 + (size_t)8 * nslots); rc = lvl + nslots;
-		ang = reinterpret_cast<float*>(rc + nslots); pxf = ang + nslots; pyf = pxf + nslots;
 	}
 };
 struct ExtractBuffers {
@@ -114,6 +113,7 @@ struct ExtractBuffers {
 	int* denseCount;              // [B][nlevels]
 	uint32_t* sel;                // [B][selPerImage] selected keys in final list order
 	int* selCount;                // [B][nlevels]
+	float* selAngle;              // [B][selPerImage] orientation of the selected keys (degrees), written by the oct-tree kernel
 	const OcamDev* cams;          // [B] or nullptr
 	int* status;                  // device error word (capacity overflows)
 	// dBRIEF / mdBRIEF: fast pass + exact pass over the fast pass's fallback list (mcs_describe.hip)

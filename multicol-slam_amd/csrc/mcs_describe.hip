@@ -4,7 +4,7 @@
 // omni model src/cam_model_omni.cpp:49-67,146-161, include/cam_model_omni.h:127-145, include/misc.h:115-122;
 // rays src/cMultiFrame.cpp:146-152.  cv::fastAtan2 per SURVEY Appendix A.5.
 //
-//   orientation   845-pixel disc of the UNBLURRED level: lane r owns disc row r-15 (half-width c_umax[|v|]), int32 moments
+//   orientation   845-pixel disc of the UNBLURRED level (mcs_orient.h; computed in the tail of the oct-tree kernel, read here): int32 moments
 //                 reduced with cross-lane shuffles (exact, order-free), then the float polynomial of cv::fastAtan2.
 //   patch         the (2R+1)^2 blurred neighbourhood (R = 21: 43 rows of 44 bytes) almost every sample touches is staged once in LDS.
 //   descriptor    lane l owns pattern pairs l, l+64, l+128, ... ; one __ballot per 64 pairs yields 8 descriptor bytes
@@ -31,40 +31,16 @@
 // Integer pixel offsets that pass the guard are PROVABLY the reference's, so the descriptors stay bit-identical; mcs_extractor_set_describe() can force
 // the exact pass for everything or widen the band (tests/test_gpu_describe_guard.py runs both against the oracle).
 #include "mcs_common.h"
+#include "mcs_orient.h"
 
 #include <algorithm>
 
 namespace mcs {
 
 __constant__ __attribute__((aligned(16))) signed char c_pattern[2048];
-__constant__ signed char c_disc[845 * 2];   // (u, v) offsets of the orientation disc, row-major in v (kept for reference / taps)
-__constant__ int c_umax[kHalfPatch + 1];      // half-width of disc row |v|
 
-void upload_describe_tables(const signed char* pattern, const signed char* disc, const int* umax) {
-	if (umax) (void)hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax, sizeof(int) * (kHalfPatch + 1));
+void upload_describe_tables(const signed char* pattern) {
 	if (pattern) (void)hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), pattern, 2048);
-	if (disc) (void)hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc, 845 * 2);
-}
-
-__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
-	const float K = (float)(180 / 3.1415926535897932384626433832795);
-	const float p1 = 0.9997878412794807f * K, p3 = -0.3258083974640975f * K, p5 = 0.1555786518463281f * K,
-	            p7 = -0.04432655554792128f * K;
-	const float eps = (float)2.2204460492503131e-16;
-	float ax = fabsf(x), ay = fabsf(y);
-	float a, c, c2;
-	if (ax >= ay) {
-		c = ay / (ax + eps);
-		c2 = c * c;
-		a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-	} else {
-		c = ax / (ay + eps);
-		c2 = c * c;
-		a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-	}
-	if (x < 0) a = 180.f - a;
-	if (y < 0) a = 360.f - a;
-	return a;
 }
 
 // Division by a shared denominator: the compiler's own f64 division expansion (rcp, two Newton steps, q0 = n*r,
@@ -227,35 +203,6 @@ __device__ __forceinline__ void find_slot(const PyrDesc& d, const int* selCount,
 	}
 }
 
-// IC_Angle (src/mdBRIEFextractorOct.cpp:221-248) by one wave: lane l < 33 owns disc row v = l - 16 (9 independent unaligned dword loads), int32 moments
-// reduced with cross-lane shuffles (exact, order-free), then cv::fastAtan2
-__device__ __forceinline__ float ic_angle_wave(const uint8_t* raw, int rstride, int row, int col) {
-	const int lane = threadIdx.x & 63;
-	int m10 = 0, m01 = 0;
-	if (lane <= 2 * kHalfPatch) {
-		const int v = lane - kHalfPatch;
-		const int um = c_umax[v < 0 ? -v : v];
-		const uint8_t* rp = raw + (size_t)(row + v) * rstride + (col - kHalfPatch);
-		uint32_t w[9];
-#pragma unroll
-		for (int k = 0; k < 9; ++k) __builtin_memcpy(&w[k], rp + 4 * k, 4);
-		int rowSum = 0, rowMom = 0;
-#pragma unroll
-		for (int j = 0; j <= 2 * kHalfPatch; ++j) {
-			const int u = j - kHalfPatch;
-			int val = (int)((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
-			val = (u >= -um && u <= um) ? val : 0;
-			rowSum += val;
-			rowMom += u * val;
-		}
-		m10 = rowMom;
-		m01 = v * rowSum;
-	}
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-	return fast_atan2_deg((float)m01, (float)m10);
-}
-
 // issue the loads of the blurred (2R+1)^2 neighbourhood (kPatchDw unaligned dwords per row, rows are in-pitch even at the right edge) / write them to LDS
 __device__ __forceinline__ void patch_load(const uint8_t* blur, int bstride, int row, int col, uint32_t (&pv)[kPatchTrips]) {
 	const int lane = threadIdx.x & 63;
@@ -315,7 +262,7 @@ __device__ __forceinline__ bool kp_prologue(const ExtractBuffers& b, int wavesPe
 		uint32_t pv[kPatchTrips];
 		patch_load(sm.blur, sm.bstride, row, col, pv);
 		sm.patch = patch; sm.prow = row - kPatchR; sm.pcol = col - kPatchR;
-		angle = ic_angle_wave(raw, rstride, row, col);
+		angle = b.selAngle[(size_t)img * d.selPerImage + L.selBase + pos];   // IC_Angle: computed by the oct-tree kernel's tail (mcs_orient.h)
 		// ---- keypoint record (E8): level coordinates -> image coordinates with the FLOAT scale (:1305,1331)
 		pxf = (float)col; pyf = (float)row;
 		if (level != 0) { pxf = pxf * L.scale; pyf = pyf * L.scale; }
@@ -626,91 +573,43 @@ __device__ __forceinline__ void fast_w2i(const FastCam& C, Tab tab, double xr, d
 	v = __builtin_fma(uu, C.e, vv);
 }
 
-// ---- what the fast pass needs per keypoint besides the patch, prepared by two small kernels at full occupancy --------------------------------------
-// The fast pass runs 4 waves per SIMD (registers), and a wave used to spend a quarter of its instructions on work that is either only 33 lanes wide
-// (IC_Angle) or identical in all 64 lanes (ImgToWorld of the keypoint, the sincos of the pattern angles).  Now
-//   k_orient_a   4 keypoints per wave: slot -> (level, position), IC_Angle, the keypoint record (E8), row / column / angle into the scratch arrays
-//   k_orient_b   one THREAD per output row: ImgToWorld (ray, E9), the undistorted keypoint, the pattern angles and their sin / cos; it also decides which
+// ---- what the fast pass needs per keypoint besides the patch --------------------------------------------------------------------------------------
+// The fast pass runs 4 waves per SIMD (registers); work that is only 33 lanes wide (IC_Angle: now in the oct-tree kernel's tail, mcs_orient.h) or identical
+// in all 64 lanes (ImgToWorld of the keypoint, the sincos of the pattern angles) is prepared ahead of it:
+//   k_orient_b   one THREAD per output row: slot -> (level, position in the level's selection), the keypoint record (E8: level coordinates -> image coordinates
+//                with the FLOAT scale, :1305,1331), ImgToWorld (ray, E9), the undistorted keypoint, the pattern angles and their sin / cos; it also decides which
 //                keypoints the fast pass cannot serve at all (camera beyond the band, non-finite undistorted position) and puts them on the exact
 //                pass's pre-list, which runs BESIDE the fast pass
 // The arithmetic is the exact pass's, statement for statement (the exact pass still does all of it itself and writes the same values).  The scratch is one
 // array per field (KpAuxSoA): a thread-per-keypoint kernel then writes whole cache lines (120-byte records cost 2.3x their size in HBM writes).
-
-// Four keypoints per wave (16 lanes each: lane j of a group owns disc rows j - 16, j and — lane 0 — 16): a wave per keypoint spent its life waiting
-// for three dependent memory round trips (counts -> record -> pixels) with 33 busy lanes.
-__global__ __launch_bounds__(256) void k_orient_a(ExtractBuffers b, int wavesPerImage, int nslots) {
-	const PyrDesc& d = *b.desc;
-	KpAuxSoA A; A.carve(b.aux, nslots);
-	const int lane = threadIdx.x & 63, j = lane & 15;
-	const int gw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-	const bool inRange = gw < nslots;
-	const int gwc = inRange ? gw : nslots - 1;
-	const int img = gwc / wavesPerImage, s = gwc - img * wavesPerImage;
-	int total, level, pos;
-	find_slot(d, b.selCount + (size_t)img * d.nlevels, s, level, pos, total);
-	if (inRange && s == 0 && j == 0) {
-		b.nkp[img] = total < d.kpCap ? total : d.kpCap;
-		if (total > d.kpCap) atomicExch(b.status, MCS_ERR_CAPACITY);
-	}
-	const bool active = inRange && level >= 0 && s < d.kpCap;
-	if (inRange && !active && j == 0) A.lvl[gwc] = -1;
-	const int lv = active ? level : 0;
-	const LevelInfo& L = d.lv[lv];
-	uint32_t rec = 0;
-	if (active) rec = b.sel[(size_t)img * d.selPerImage + L.selBase + pos];
-	const int col = (int)(rec & 0xFFF) + kMinBorder, row = (int)((rec >> 12) & 0xFFF) + kMinBorder;
-	int rstride;
-	const uint8_t* raw = level_ptr(b, d, img, lv, &rstride);
-	int m10 = 0, m01 = 0;
-	if (active) {
-#pragma unroll
-		for (int t = 0; t < 3; ++t) {
-			const int r = j + 16 * t;          // disc row index 0..32
-			if (r <= 2 * kHalfPatch) {
-				const int v = r - kHalfPatch;
-				const int um = c_umax[v < 0 ? -v : v];
-				const uint8_t* rp = raw + (size_t)(row + v) * rstride + (col - kHalfPatch);
-				uint32_t w[9];
-#pragma unroll
-				for (int k = 0; k < 9; ++k) __builtin_memcpy(&w[k], rp + 4 * k, 4);
-				int rowSum = 0, rowMom = 0;
-#pragma unroll
-				for (int jj = 0; jj <= 2 * kHalfPatch; ++jj) {
-					const int u = jj - kHalfPatch;
-					int val = (int)((w[jj >> 2] >> (8 * (jj & 3))) & 0xffu);
-					val = (u >= -um && u <= um) ? val : 0;
-					rowSum += val;
-					rowMom += u * val;
-				}
-				m10 += rowMom;
-				m01 += v * rowSum;
-			}
-		}
-	}
-#pragma unroll
-	for (int o = 8; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }   // within the 16-lane group (exact integer sums: order-free)
-	if (!active || j != 0) return;
-	const float angle = fast_atan2_deg((float)m01, (float)m10);
-	float pxf = (float)col, pyf = (float)row;
-	if (level != 0) { pxf = pxf * L.scale; pyf = pyf * L.scale; }
-	mcs_keypoint kp;
-	kp.x = pxf; kp.y = pyf; kp.size = L.kpSize; kp.angle = angle; kp.response = (float)(rec >> 24); kp.octave = level; kp.class_id = -1;
-	b.kps[(size_t)img * d.kpCap + s] = kp;
-	A.lvl[gwc] = level; A.rc[gwc] = row | (col << 16); A.ang[gwc] = angle; A.pxf[gwc] = pxf; A.pyf[gwc] = pyf;
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256) void k_orient_b(ExtractBuffers b, int wavesPerImage, int nslots) {
 	const int gw = blockIdx.x * 256 + threadIdx.x;
 	if (gw >= nslots) return;
 	KpAuxSoA A; A.carve(b.aux, nslots);
-	const int level = A.lvl[gw];
-	if (level < 0) return;
 	const PyrDesc& d = *b.desc;
 	const int img = gw / wavesPerImage, s = gw - img * wavesPerImage;
+	int total, level, pos;
+	find_slot(d, b.selCount + (size_t)img * d.nlevels, s, level, pos, total);
+	if (s == 0) {
+		b.nkp[img] = total < d.kpCap ? total : d.kpCap;
+		if (total > d.kpCap) atomicExch(b.status, MCS_ERR_CAPACITY);
+	}
+	if (level < 0 || s >= d.kpCap) { A.lvl[gw] = -1; return; }
+	const LevelInfo& L = d.lv[level];
+	const size_t si = (size_t)img * d.selPerImage + L.selBase + pos;
+	const uint32_t rec = b.sel[si];
+	const float angle = b.selAngle[si];
+	const int col = (int)(rec & 0xFFF) + kMinBorder, row = (int)((rec >> 12) & 0xFFF) + kMinBorder;
+	float pxf = (float)col, pyf = (float)row;
+	if (level != 0) { pxf = pxf * L.scale; pyf = pyf * L.scale; }
+	mcs_keypoint kp;
+	kp.x = pxf; kp.y = pyf; kp.size = L.kpSize; kp.angle = angle; kp.response = (float)(rec >> 24); kp.octave = level; kp.class_id = -1;
+	b.kps[(size_t)img * d.kpCap + s] = kp;
+	A.rc[gw] = row | (col << 16);
 	const OcamDev& cam = b.cams[img];
 	double rayx, rayy, rayz;
-	img2world(cam, (double)A.pxf[gw], (double)A.pyf[gw], rayx, rayy, rayz);
+	img2world(cam, (double)pxf, (double)pyf, rayx, rayy, rayz);
 	if (b.rays) {
 		double* rp = b.rays + ((size_t)img * d.kpCap + s) * 3;
 		rp[0] = rayx; rp[1] = rayy; rp[2] = rayz;
@@ -731,7 +630,7 @@ __global__ __launch_bounds__(256) void k_orient_b(ExtractBuffers b, int wavesPer
 		b.preList[atomicAdd(b.preCount, 1)] = (uint32_t)gw;
 		return;   // the exact pass computes its own angles
 	}
-	const float angle = A.ang[gw];
+	A.lvl[gw] = level;
 	double ang[3] = {0.0, 0.0, 0.0};
 	if (MODE == 1) {
 		const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
@@ -996,7 +895,6 @@ static void launch_fast_passes(const ExtractBuffers& b, int nimg, int wavesPerIm
 	if (fblocks >= kNumXCD) fblocks = (fblocks + kNumXCD - 1) / kNumXCD * kNumXCD;   // whole XCD rounds: the kernel's block -> group mapping is XCD-contiguous
 	const size_t fLds = (size_t)kFastWaves * kPatchBytes + kGTabDoubles * sizeof(double);
 	(void)hipMemsetAsync(b.fbCount, 0, 2 * sizeof(int), s);   // fbCount and preCount are neighbours
-	hipLaunchKernelGGL(k_orient_a, dim3((nslots + 15) / 16), dim3(256), 0, s, b, wavesPerImage, nslots);
 	hipLaunchKernelGGL((k_orient_b<MODE>), dim3((nslots + 255) / 256), dim3(256), 0, s, b, wavesPerImage, nslots);
 	// the pre-list (about one keypoint in a hundred: the ones next to the optical axis) through the exact pass BESIDE the fast pass
 	hipStream_t ps = b.sideStream ? b.sideStream : s;

@@ -16,6 +16,7 @@
 // Prologue: the per-cell candidate slots written by the FAST kernel are compacted into the level's dense list in the
 // reference's order (cell row-major, then row-major inside the cell) with a prefix sum over the cell counts.
 #include "mcs_common.h"
+#include "mcs_orient.h"
 
 namespace mcs {
 
@@ -294,6 +295,13 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int 
 	if (L > Lv.selCap) { if (tid == 0) { atomicExch(b.status, MCS_ERR_CAPACITY); *selCount = 0; } return; }
 	for (int i = tid; i < L; i += 256) sel[i] = dense[0xFFFFFFu - (best[i] & 0xFFFFFFu)];
 	if (tid == 0) *selCount = L;
+	// ---------------------------------------------------------------- E5: orientation of the selected keys (IC_Angle, :221-248)
+	// Here rather than in a kernel of its own: a separate launch ran 0.115 ms with nothing beside it, three dependent memory round trips per key; in this
+	// tail they hide behind the other (image, level) workgroups' passes.
+	__syncthreads();
+	int rstride;
+	const uint8_t* raw = level_ptr(b, d, img, level, &rstride);
+	orient_selected(raw, rstride, d.umax, sel, L, b.selAngle + (size_t)img * d.selPerImage + Lv.selBase);
 }
 
 void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0, int level1) {   // levels [level0, level1)
