@@ -31,6 +31,11 @@ extern "C" {
 #define MCS_ERR_CAPACITY (-3)  /* an output / internal capacity was exceeded */
 #define MCS_ERR_UNSUPPORTED (-4)
 
+/* ABI revision of this header: bumped whenever a struct layout or an entry point's signature changes (3: mcs_desc_set carries block_rows / block_pitch_rows
+ * since round 2 — callers built against an older header must be recompiled; mcs_describe_fast_table, FAST types 0 / 1 in round 3).  mcs_abi_version() returns
+ * the value the LIBRARY was built with: compare it with MCS_ABI_VERSION after dlopen. */
+#define MCS_ABI_VERSION 3
+
 #define MCS_MAX_POLY 16
 #define MCS_MAX_LEVELS 16
 
@@ -58,6 +63,7 @@ typedef struct {
 typedef enum { MCS_MEM_HOST = 0, MCS_MEM_DEVICE = 1 } mcs_mem_kind;
 
 const char* mcs_last_error(void);              /* thread-local text of the last failure */
+int mcs_abi_version(void);                     /* MCS_ABI_VERSION of the library build */
 int mcs_device_count(int* n);
 
 /* One context per (process, GPU).  stream: a hipStream_t to run on (NULL = the context creates its own). */

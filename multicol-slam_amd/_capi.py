@@ -63,7 +63,7 @@ def make_ocam(cam):
 
 
 EXPORTS = [
-    "mcs_last_error", "mcs_device_count", "mcs_ctx_create", "mcs_ctx_destroy", "mcs_ctx_synchronize", "mcs_extractor_create",
+    "mcs_last_error", "mcs_abi_version", "mcs_device_count", "mcs_ctx_create", "mcs_ctx_destroy", "mcs_ctx_synchronize", "mcs_extractor_create",
     "mcs_extractor_destroy", "mcs_extractor_kp_capacity", "mcs_extractor_levels", "mcs_extract_batch", "mcs_extractor_status",
     "mcs_extractor_tap_level", "mcs_extractor_tap_candidates", "mcs_extractor_tap_selected", "mcs_match_topk",
     "mcs_match_topk_batched", "mcs_descriptor_distance", "mcs_descriptor_distance_masked", "mcs_ctx_enable_timing",

@@ -245,6 +245,7 @@ struct mcs_extractor {
 extern "C" {
 
 const char* mcs_last_error(void) { return mcs_err().c_str(); }
+int mcs_abi_version(void) { return MCS_ABI_VERSION; }
 
 int mcs_device_count(int* n) {
 	if (!n) return fail(MCS_ERR_INVALID, "null");

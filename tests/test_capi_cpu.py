@@ -41,6 +41,12 @@ def test_fails_loudly_without_gpu(pkg):
         pkg.Context(0)
 
 
+def test_abi_version_matches_the_header(pkg):
+    txt = open(os.path.join(ROOT, "include", "mcs_c.h")).read()
+    want = int(re.search(r"#define MCS_ABI_VERSION (\d+)", txt).group(1))
+    assert pkg.lib().mcs_abi_version() == want >= 3
+
+
 def test_struct_layouts(pkg):
     assert C.sizeof(pkg._capi.KeyPoint) == 28 and pkg.KP_DTYPE.itemsize == 28       # cv::KeyPoint
     assert C.sizeof(pkg._capi.ExtractorParams) == 13 * 4

@@ -151,3 +151,28 @@ def test_host_memory_call_with_block_structured_sets(G, scene):
     bad = cap.DescSet(P(Garr, doff), P(Garr, moff), P(val, voff), None, n, stride, 7, bpitch)
     assert lib.mcs_search_kf_kf(ctx.h, 1, C.byref(bad), 0, C.byref(t), 0, 32, 0.9, 8, cap.MEM_HOST, m12.ctypes.data_as(C.c_void_p), nm.ctypes.data_as(C.c_void_p), None) == cap.MCS_ERR_INVALID
     assert rows.shape[0] == lay.images_total * lay.rows_img
+
+
+def test_strided_outputs_are_validated(G, scene):
+    """mcs_extract_batch_strided rejects layouts its 8-byte row stores cannot serve: a row stride that is not a multiple of 8, misaligned row pointers,
+    descriptor and mask rows that overlap for the given pitch / stride"""
+    lay, ex = scene["lay"], scene["ex"]
+    cams = G.cams3()
+    imgs = [G.synth.synth_image(0, c, cams[c]) for c in range(2)]
+    d_img = G.DevBuf(np.stack(imgs))
+    oc = [G.mcs.make_ocam(cams[c]) for c in range(2)]
+    buf = G.DevBuf(np.zeros(2 * (ex.cap + 1) * 128 + 64, np.uint8))
+    nkp = G.DevBuf(np.zeros(2, np.int32)); kps = G.DevBuf(np.zeros((2 * ex.cap, 7), np.float32))
+    g = buf.ptr.value
+
+    def call(desc, mask, pitch_rows, stride):
+        ex.extract_strided(2, d_img.ptr.value, 754 * 480, 754, None, 0, 0, oc, nkp.ptr.value, kps.ptr.value, desc, mask, None, pitch_rows, stride)
+    call(g, g + 32, ex.cap + 1, 64)                       # the exchange layout itself is fine
+    G.ctx().synchronize()
+    for bad in ((g, g + 32, ex.cap + 1, 68),              # stride not a multiple of 8
+                (g + 4, g + 36, ex.cap + 1, 64),          # misaligned rows
+                (g, g + 16, ex.cap + 1, 64),              # mask inside the descriptor bytes
+                (g, g + 40, ex.cap + 1, 64),              # mask row runs into the next descriptor row
+                (g, g + 64 * 5, ex.cap + 1, 64)):         # a separate mask array that starts inside the descriptor array
+        with pytest.raises(G.mcs.McsError):
+            call(*bad)
