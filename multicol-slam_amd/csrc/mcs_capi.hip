@@ -230,7 +230,7 @@ struct mcs_extractor {
 	// descriptor passes (mcs_describe.hip): fallback list of the fast pass, its running total, the guard band
 	int* d_fbCount = nullptr; uint32_t *d_fbList = nullptr, *d_preList = nullptr; unsigned long long* d_fbStats = nullptr; void* d_aux = nullptr;   // d_fbCount: [0] fallback list, [1] pre-list
 	int describeMode = 0; double guardEps = kDefaultGuardEps;
-	// rho tables of the cameras seen so far (a rig has a handful), and the per-image copy the fast pass reads
+	// G(s) tables of the cameras seen so far (a rig has a handful), and the batch's distinct tables as the fast pass reads them
 	struct CamFast { OcamDev key; GTabInfo info; std::vector<double> tab; };
 	std::vector<CamFast> camCache;
 	double* d_gTab = nullptr;
@@ -668,7 +668,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 			for (int k = 0; k < m.p_deg; ++k) o.p[k] = m.p[k];
 			for (int k = 0; k < m.invP_deg; ++k) o.invP[k] = m.invP[k];
 			o.p_deg = m.p_deg; o.invP_deg = m.invP_deg;
-			// the camera's rho table and its tail bound: built once per distinct camera
+			// the camera's G(s) table and its bounds: built once per distinct camera
 			int w = -1;
 			for (size_t k = 0; k < e->camCache.size() && w < 0; ++k) if (memcmp(&e->camCache[k].key, &o, sizeof(o)) == 0) w = (int)k;
 			if (w < 0) {
@@ -688,7 +688,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 			o.tabIdx = (int)up;
 		}
 		if (e->h_cams.size() != hc.size() || memcmp(e->h_cams.data(), hc.data(), sizeof(OcamDev) * hc.size()) != 0) {
-			HIPCHK(hipStreamSynchronize(s));   // the previous batch may still read d_cams / d_rhoTab
+			HIPCHK(hipStreamSynchronize(s));   // the previous batch may still read d_cams / d_gTab
 			HIPCHK(hipMemcpy(e->d_cams, hc.data(), sizeof(OcamDev) * hc.size(), hipMemcpyHostToDevice));
 			std::vector<double> tabs(uniq.size() * (size_t)kGTabDoubles);
 			for (size_t i = 0; i < uniq.size(); ++i) memcpy(&tabs[i * kGTabDoubles], e->camCache[uniq[i]].tab.data(), kGTabDoubles * sizeof(double));

@@ -36,7 +36,7 @@ def _same(G, a, b):
 def test_fast_arithmetic_stays_below_the_assumed_bound(G):
     lib, ctx = G.mcs.lib(), G.ctx()
     cams = G.cams3() + [G.synth.scaled_camera(G.cams3()[1], 1280, 800)]
-    flipped = dict(G.cams3()[0])                                                        # the mirror camera (p0 > 0, invP(-theta)): the other sign branch of the rho table
+    flipped = dict(G.cams3()[0])                                                        # the mirror camera (p0 > 0, invP(-theta)): the other sign of p0 in the G(s) table
     flipped["p"] = [-v for v in flipped["p"]]; flipped["invP"] = [v * (-1) ** i for i, v in enumerate(flipped["invP"])]
     short = dict(G.cams3()[2]); short["invP"] = short["invP"][:6]                       # a low-degree backward polynomial
     cams += [flipped, short]

@@ -1,6 +1,6 @@
-"""-m gpu: an extractor that meets more than 64 distinct camera models (the per-camera rho tables of the fast descriptor pass are cached per model,
+"""-m gpu: an extractor that meets more than 64 distinct camera models (the per-camera G(s) tables of the fast descriptor pass are cached per model,
 csrc/mcs_capi.hip).  The 65th model arrives in the SAME batch as an image of a cached model: the table uploaded for every image must be its own camera's
-(a cache trimmed in the middle of a batch would hand the fast pass another camera's rho(theta) — wrong descriptors without any fallback)."""
+(a cache trimmed in the middle of a batch would hand the fast pass another camera's G(s) — wrong descriptors without any fallback)."""
 import numpy as np
 import pytest
 
