@@ -265,9 +265,21 @@ class Job:
         self.async_search = os.environ.get("MCS_BENCH_ASYNC_SEARCH", "1") != "0"
         mcs.check(e.lib.mcs_ctx_set_async_search(e.ctx.h, 1 if self.async_search else 0))
         if e.exchange:   # prime the pipeline: the first step() matches the multi-frames exchanged here
-            self.extract_and_exchange(self.sets[self.nsets - 1])
+            try:
+                self.extract_and_exchange(self.sets[self.nsets - 1])
+                torch.cuda.synchronize(dev)
+            except (RuntimeError, TypeError, ValueError) as ex:
+                if self.ring is None:
+                    raise
+                # a torch / RCCL build without grouped point-to-point operations (the failure is the same on every rank): the frame ring falls back to the
+                # all-gather, which delivers a superset of what the ring exchange would; said in the output (config.parallelism names the form used)
+                print("bench.py: ring exchange unavailable (%s: %s), using the all-gather" % (type(ex).__name__, str(ex)[:200]), file=sys.stderr)
+                self.ring, self.view = None, lay
+                self.sets = [self._make_set() for _ in range(self.nsets)]
+                self.matched_set = self.sets[0]
+                self.extract_and_exchange(self.sets[self.nsets - 1])
+                torch.cuda.synchronize(dev)
             self.sets[self.nsets - 1].work = "done"
-            torch.cuda.synchronize(dev)
 
     def _make_set(self):
         torch, lay, dev, e = self.e.torch, self.lay, self.e.dev, self.e
