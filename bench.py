@@ -176,6 +176,16 @@ def kernel_times(e, step, reps=5):
     return {k: v / reps for k, v in acc.items()}
 
 
+def pmc_entry_parts(tag, names):
+    """HBM bytes (FETCH_SIZE + WRITE_SIZE) per launch of the named kernels from the committed counter passes, or None"""
+    try:
+        ks = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["workloads"][tag]["kernels"]
+        parts = [ks[n] for n in names if n in ks]
+        return int(sum(k["fetch_kib"] + k["write_kib"] for k in parts) * 1024) if parts else None
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
 def pmc_entry(tag, dom):
     """HBM bytes (FETCH_SIZE + WRITE_SIZE) and VALU wave-instructions per launch of kernel `dom` from the committed counter passes of this workload"""
     try:
@@ -474,6 +484,10 @@ def roofline_block(sp, job, kern, feats_local, pairs_local):
         tf = pairs_local * flop_pair / (kern[dom] * 1e-3) / 1e12
         out.update({"bound": "mfma", "achieved": round(tf, 1), "peak": 10000.0, "unit": "TFLOP/s", "frac": round(tf / 10000.0, 4),
                     "alg_flop_per_launch": int(pairs_local * flop_pair), "hbm_alg_GBps": round(ach, 2)})
+    if dom == "keypoints":   # the descriptor kernels alone (the part of the stage that runs with nothing beside it in the overlapped schedule), on their own bytes
+        dk = kern["describe"]
+        out["descriptor_kernels_only"] = {"alg_bytes_per_launch": int(alg["describe"]), "avg_launch_ms": round(dk, 4), "achieved_GBps": round(alg["describe"] / (dk * 1e-3) / 1e9, 2),
+                                          "frac": round(alg["describe"] / (dk * 1e-3) / 1e9 / 8000.0, 5), "traffic": pmc_entry_parts(sp.tag, ("orient_b", "describe", "describe_list", "describe_exact"))}
     if valu:
         peak = 1024 * 2.4e9 / 4 / 1e9
         a = valu / (kern[dom] * 1e-3) / 1e9
