@@ -15,8 +15,12 @@
 // ds_read_b128, used for both query sets.  An MFMA result puts 16 of a column's 32 rows in lane c and the other 16 in lane c + 32; one
 // v_permlane32_swap per register between the two sets' results leaves lane c with all 32 rows of query c of the first set and lane c + 32 with all 32
 // rows of query c of the second: ONE query per lane, so its K-best list sees every train row (two half lists per query appended 1.7x as many
-// candidates, and merged as often).  A result becomes (total << 20 | index) — ct and the index ride in one word per row — and goes through the same
-// append / bitonic-merge list as mcs_match.hip.
+// candidates, and merged as often).
+// The candidate word is a FLOAT and the matrix core forms it: the accumulators start from a per-row word (ct + 256) + index / 2^14 (exact in f32: 10 +
+// 14 bits), the +-1 products add the dot product, so an MFMA result IS the key "total - cq + 256, then index" — positive floats order like their bit
+// patterns, so the append is one unsigned compare against the limit's bits, a store and an add under the compare's lane mask; no conversion, no shift-
+// or per pair.  (Any order of the additions inside the instruction is exact: every partial sum is a multiple of 2^-14 in [0, 769).)  The exact integer
+// key (total << 20 | index, as in mcs_match.hip) is formed when a column is merged.  Train sets of more than 2^14 rows go to mcs_match.hip.
 #include "mcs_common.h"
 
 namespace mcs {
@@ -26,11 +30,13 @@ typedef float v16f_t __attribute__((ext_vector_type(16)));
 
 constexpr int XT = 128;        // train rows compacted per outer step (64: 4 workgroups per CU by LDS, but only one wave loads rows — measured slower)
 constexpr int XQ = 256;        // queries per workgroup
-// Words in the candidate columns are BIASED: (dot + ct + 256) << 20 | index, i.e. the total minus the query's own cq (<= 256) plus 256 — never negative —
+// Words in the candidate columns are BIASED: dot + ct + 256 (+ index / 2^14), i.e. the total minus the query's own cq (<= 256) plus 256 — never negative —
 // so that cq costs nothing per pair: it is subtracted from the limit once per group and added back when a column is merged.  The f32 dot product of any
-// staged row (real or stale bits, always 0 / +-1 operands) lies in [-512, 512], so a padding row's word (index word kPadWord) has a distance field in
-// [0xA00, 0xE00]: never below a biased limit (<= kLimCap + 256 << 20 = 0xA00 << 20), never wrapping; real totals (<= 512) stay below kLimCap.
-constexpr uint32_t kPadWord = 0xC00FFFFFu, kLimCap = 0x900u << 20, kBias = 256u << 20;
+// staged row (real or stale bits, always 0 / +-1 operands) lies in [-512, 512], so a padding row's word (kPadWord) ends in [2560, 3584]: never below a
+// biased limit (<= kLimCap + 256 = 2560); real totals (<= 512) stay below kLimCap.
+constexpr float kPadWord = 3072.f, kIdxUnit = 1.f / 16384.f;
+constexpr uint32_t kLimCap = 0x900u, kBias = 256u;
+constexpr int kMaxTrainRows = 16384;
 
 // bit k of the byte -> nibble k = 1
 __device__ __forceinline__ uint32_t spread8(uint32_t b) {
@@ -57,6 +63,18 @@ __device__ __forceinline__ uint4 expandpm(const uint32_t* lut, uint32_t m, uint3
 	return o;
 }
 
+// *(uint32_t*)next = w (next: LDS byte address) and next += 1024 in the lanes with w < lim (unsigned compare of float bits): the compare writes the lane
+// mask, the store and the add run under it — one compare + one add on the VALU per pair (compare / select / shift-add / add as plain C++).  All 64
+// lanes are active at every call site (wave-uniform control flow, full workgroups).
+__device__ __forceinline__ void append(uint32_t& next, uint32_t w, uint32_t lim) {
+	asm volatile(
+		"v_cmpx_lt_u32_e32 vcc, %1, %2\n\t"
+		"ds_write_b32 %0, %1\n\t"
+		"v_add_u32_e32 %0, 0x400, %0\n\t"
+		"s_mov_b64 exec, -1"
+		: "+v"(next) : "v"(w), "v"(lim) : "vcc", "memory");
+}
+
 // Three waves per SIMD (168 registers; the LDS allows three workgroups per CU): left alone the compiler takes 228 registers for K = 32 and two waves —
 // with ~30 spilled dwords the three-wave build is 17 % faster on the configs[2] sweep (13.4 -> 11.4 ms).
 template <int K, int DW, bool MASKED>
@@ -67,7 +85,7 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 	constexpr int CB = 16;                           // candidate column depth per lane
 	__shared__ __attribute__((aligned(16))) uint32_t tdT[DW * XT];                 // compacted train rows, transposed [dword][row]
 	__shared__ __attribute__((aligned(16))) uint32_t tmT[MASKED ? DW * XT : 4];
-	__shared__ __attribute__((aligned(16))) uint32_t wrow[XT + 64];               // (ct << 20) | original index;  kPadWord past the staged rows
+	__shared__ __attribute__((aligned(16))) float wrow[XT + 64];                  // (ct + 256) + original index / 2^14;  kPadWord past the staged rows
 	// A operands of a stage (two 32-row tiles).  One buffer and a barrier more per stage: with two (expansion of stage g + 1 beside the arithmetic of
 	// stage g) the workgroup needs 60 KB and only two fit a CU — measured 18.4 ms against 14.2 ms per configs[2] step with three.
 	__shared__ __attribute__((aligned(16))) uint4 ex[2][NS][64];
@@ -85,7 +103,7 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 
 	// the operands of query (set u, column col): step s = segment * HS + j covers dwords 2j (k-half 0) and 2j + 1 (k-half 1) of the segment's bit vector
 	v8i_t bq[2][NS];
-	uint32_t cq20 = 0;   // popc(mq & q) << 20 of the lane's OWN query (k-half = set)
+	uint32_t cq = 0;     // popc(mq & q) of the lane's OWN query (k-half = set)
 	bool qok = false;
 #pragma unroll
 	for (int u = 0; u < 2; ++u) {
@@ -109,7 +127,7 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 		int c = 0;
 #pragma unroll
 		for (int w = 0; w < DW; ++w) c += __popc(MASKED ? (q[w] & qm[w]) : q[w]);
-		if (u == kh) cq20 = (uint32_t)c << 20;
+		if (u == kh) cq = (uint32_t)c;
 #pragma unroll
 		for (int j = 0; j < HS; ++j) {
 			const uint32_t x = kh ? q[2 * j + 1] : q[2 * j], m = MASKED ? (kh ? qm[2 * j + 1] : qm[2 * j]) : 0xFFFFFFFFu;
@@ -125,9 +143,13 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 	uint32_t best[K];
 #pragma unroll
 	for (int p = 0; p < K; ++p) best[p] = 0xFFFFFFFFu;
-	const uint32_t col0 = tid;
+	const uint32_t col0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cand + tid);   // LDS byte address of the lane's column; slot e is 1024 bytes further
 	uint32_t next = col0;
-	auto exact_key = [&](uint32_t wb) { const uint32_t w = wb - kBias + cq20; return MASKED ? (((w >> 21) << 20) | (w & 0xFFFFFu)) : w; };   // un-bias, then as in mcs_match.hip
+	auto exact_key = [&](uint32_t bits) {   // float word -> un-biased integer key as in mcs_match.hip
+		const uint32_t k = (uint32_t)(__uint_as_float(bits) * 16384.f);   // exact: at most 14 fractional bits
+		const uint32_t t = (k >> 14) - kBias + cq, idx = k & 16383u;
+		return ((MASKED ? (t >> 1) : t) << 20) | idx;
+	};
 	auto bitonic_merge_best = [&]() {
 #pragma unroll
 		for (int j = K >> 1; j > 0; j >>= 1)
@@ -138,13 +160,15 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 			}
 	};
 	auto flush = [&]() {   // as in mcs_match.hip
-		const int cnt = (int)((next - col0) >> 8);
+		const int cnt = (int)((next - col0) >> 10);
 		if (K >= CB) {
 			uint32_t c[CB];
 #pragma unroll
+			for (int e = 0; e < CB; ++e) c[e] = cand[e * 256 + tid];
+#pragma unroll
 			for (int e = 0; e < CB; ++e) {
-				const uint32_t raw = cand[e * 256 + tid];
-				c[e] = e < cnt ? exact_key(raw) : 0xFFFFFFFFu;
+				asm volatile("" : "+v"(c[e]));   // the reads stay unconditional and in flight together (a stale slot's bits convert to some key that the select drops)
+				c[e] = e < cnt ? exact_key(c[e]) : 0xFFFFFFFFu;
 			}
 #pragma unroll
 			for (int k = 2; k <= CB; k <<= 1)
@@ -180,16 +204,20 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 	const int per = ((a.nt + a.splits - 1) / a.splits + 63) / 64 * 64;
 	const int t0 = split * per, t1 = min(a.nt, t0 + per);
 	const uint32_t dCap = a.maxDist >= 4095 ? 4095u : (uint32_t)a.maxDist;
-	// The distance threshold, the padding rows and "closer than the K-th best" are ONE unsigned compare of the biased word against rawLim (masked: the raw
-	// total t stands for distance t >> 1, so "distance <= D" is t <= 2D + 1).  The K-th best only changes in a merge: the limit is recomputed there.
+	// The distance threshold, the padding rows and "closer than the K-th best" are ONE unsigned compare of the biased word's bits against rawLim (masked:
+	// the raw total t stands for distance t >> 1, so "distance <= D" is t <= 2D + 1).  The K-th best only changes in a merge: the limit is recomputed there.
 	auto limit = [&]() -> uint32_t {
-		uint32_t lim;
+		uint32_t lim, frac = 0;   // "field < lim, or field == lim and index < frac"
 		const uint32_t kth = best[K - 1];
 		if (MASKED) {
 			const uint32_t dl = min(kth >> 20, dCap);
-			lim = dl >= 1151u ? kLimCap : ((2u * dl + 2u) << 20);
-		} else lim = min(min(kth, dCap >= 4095u ? 0xFFFFFFFFu : ((dCap + 1u) << 20)), kLimCap);
-		return qok ? lim + kBias - cq20 : 0u;   // the biased words carry total - cq + 256
+			lim = dl >= 1151u ? kLimCap : 2u * dl + 2u;
+		} else {
+			lim = min(dCap >= 4095u ? kLimCap : dCap + 1u, kLimCap);
+			if ((kth >> 20) < lim) { lim = kth >> 20; frac = kth & 0xFFFFFu; }
+		}
+		// the biased words carry total - cq + 256: lim + 256 - cq >= 2 (masked) / >= 0
+		return qok ? __float_as_uint((float)(lim + kBias - cq) + (float)frac * kIdxUnit) : 0u;
 	};
 	uint32_t rawLim = limit();
 	for (int base = t0; base < t1; base += XT) {
@@ -199,7 +227,7 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 		uint32_t* park = reinterpret_cast<uint32_t*>(&ex[0][0][0]);   // [2 * DW][XT] dwords
 		const int j = base + tid;
 		bool ok = false;
-		uint32_t word = 0;
+		float word = 0.f;
 		if (tid < XT && j < t1) {
 			const size_t row = TR(j);
 			const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.td + row * a.tstride);
@@ -218,7 +246,7 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 				park[w * XT + tid] = tw[w];
 				if (MASKED) { park[(DW + w) * XT + tid] = mw[w]; ct += __popc(mw[w] & tw[w]); }
 			}
-			word = (((uint32_t)ct << 20) | (uint32_t)j) + kBias;
+			word = (float)(ct + (int)kBias) + (float)j * kIdxUnit;
 		}
 		const unsigned long long bal = __ballot(ok);
 		if (lane == 0) wcnt[wv] = __popcll(bal);
@@ -257,7 +285,14 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 			for (int tile = 0; tile < 2; ++tile) {
 				const int row0 = (g << 6) + (tile << 5);
 				if (row0 < rows) {
-					v16f_t acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+					// accumulator r of a lane is train row (r & 3) + 8 (r >> 2) + 4 * k-half of the tile: both sets start from the rows' words
+					v16f_t acc0, acc1;
+#pragma unroll
+					for (int jp = 0; jp < 4; ++jp) {
+						const float4 w4 = *reinterpret_cast<const float4*>(&wrow[row0 + 8 * jp + 4 * kh]);
+						acc0[4 * jp] = w4.x; acc0[4 * jp + 1] = w4.y; acc0[4 * jp + 2] = w4.z; acc0[4 * jp + 3] = w4.w;
+					}
+					acc1 = acc0;
 #pragma unroll
 					for (int s = 0; s < NS; ++s) {
 						const uint4 av = ex[tile][s][lane];
@@ -265,28 +300,22 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 						acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, bq[0][s], acc0, 4, 4, 0, 0, 0, 0);
 						acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, bq[1][s], acc1, 4, 4, 0, 0, 0, 0);
 					}
-					// result register r of a lane = train row (r & 3) + 8 (r >> 2) + 4 * k-half of the tile, for column (lane & 31) of its set.  The swap
-					// exchanges the upper half of set 0's register with the lower half of set 1's: afterwards lo[r] is row (r & 3) + 8 (r >> 2) and
-					// hi[r] row (r & 3) + 8 (r >> 2) + 4 of the lane's OWN query, in every lane
+					// result register r of a lane = the key of train row (r & 3) + 8 (r >> 2) + 4 * k-half of the tile, for column (lane & 31) of its set.
+					// The swap exchanges the upper half of set 0's register with the lower half of set 1's: afterwards lo[r] is row (r & 3) + 8 (r >> 2)
+					// and hi[r] row (r & 3) + 8 (r >> 2) + 4 of the lane's OWN query, in every lane
 #pragma unroll
 					for (int jp = 0; jp < 4; ++jp) {
-						int lo[4], hi[4];
+						uint32_t lo[4], hi[4];
 #pragma unroll
 						for (int u = 0; u < 4; ++u) {
-							const auto sw = __builtin_amdgcn_permlane32_swap((int)acc0[4 * jp + u], (int)acc1[4 * jp + u], false, false);
+							const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[4 * jp + u]), __float_as_uint(acc1[4 * jp + u]), false, false);
 							lo[u] = sw[0]; hi[u] = sw[1];
 						}
 #pragma unroll
 						for (int h = 0; h < 2; ++h) {   // four rows at a time: a column has room for 16, so a merge is due once a lane holds more than 12
-							const uint4 wv4 = *reinterpret_cast<const uint4*>(&wrow[row0 + 8 * jp + 4 * h]);   // rows 8 jp + 4 h ..+3: the same address in every lane
-							const uint32_t wr[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
 #pragma unroll
-							for (int u = 0; u < 4; ++u) {
-								const uint32_t w = ((uint32_t)(h ? hi[u] : lo[u]) << 20) + wr[u];
-								cand[next] = w;
-								next += w < rawLim ? 256u : 0u;
-							}
-							if (__any(next > col0 + (CB - 4) * 256)) { flush(); rawLim = limit(); }
+							for (int u = 0; u < 4; ++u) append(next, h ? hi[u] : lo[u], rawLim);
+							if (__any(next > col0 + (CB - 4) * 1024)) { flush(); rawLim = limit(); }
 						}
 					}
 				}
@@ -320,7 +349,7 @@ static void launch_mfma_k(const MatchArgs& a, hipStream_t s) {
 
 // the partial-list kernel of launch_match() for the shapes the matrix-core form serves: 16 / 32-byte descriptors, no count_le output, no camera groups
 bool match_mfma_serves(const MatchArgs& a) {
-	return (a.dim == 16 || a.dim == 32) && a.countThresh < 0 && !(a.qgroup && a.tgroup);
+	return (a.dim == 16 || a.dim == 32) && a.countThresh < 0 && !(a.qgroup && a.tgroup) && a.nt <= kMaxTrainRows;
 }
 
 void launch_match_mfma(const MatchArgs& a, hipStream_t s) {
