@@ -267,6 +267,11 @@ int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
 	if (getenv("MCS_NO_OVERLAP") == nullptr) {
 		// (stream priorities — resize chain urgent, deferred matcher least urgent, and every other combination — change nothing measurable: 2.32 ms either way)
 		HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+		if (getenv("MCS_SIDE2_PRIO")) {
+			int least = 0, greatest = 0;
+			HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+			HIPCHK(hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, atoi(getenv("MCS_SIDE2_PRIO")) > 0 ? greatest : least));
+		} else
 		HIPCHK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
 
 		HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
@@ -315,7 +320,7 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 	while (!c->extractors.empty()) (void)mcs_extractor_destroy(c->extractors.back());   // an extractor must not outlive the stream it runs on
 	for (auto& kv : c->timers) { if (kv.second.a) { (void)hipEventDestroy(kv.second.a); (void)hipEventDestroy(kv.second.b); } }
 	(void)hipFree(c->partial); (void)hipFree(c->partialCount); (void)hipFree(c->stage); (void)hipFree(c->dscalar);
-	(void)hipFree(c->topKeys); (void)hipFree(c->topCnt); (void)hipFree(c->stageOut); (void)hipFree(c->arena); if (c->pinned) (void)hipHostFree(c->pinned);
+	(void)hipFree(c->topKeys); (void)hipFree(c->topCnt); (void)hipFree(c->exA); (void)hipFree(c->exW); (void)hipFree(c->exRows); (void)hipFree(c->stageOut); (void)hipFree(c->arena); if (c->pinned) (void)hipHostFree(c->pinned);
 	if (c->side) {
 		(void)hipStreamSynchronize(c->side);
 		(void)hipStreamSynchronize(c->side2);

@@ -109,7 +109,10 @@ static int run_topk(mcs_ctx* c, const DevSets& d, const SetGrid& sg, const mcs_d
 	MatchArgs a{};
 	const int nsets = sg.nsets;
 	a.maxDist = max_dist;
-	const bool deferred = ls != nullptr;   // launched on the greedy stream itself: ordered behind the previous search without any wait
+	// deferred (ls = the greedy stream): the lists run there, ordered behind the previous search by the stream itself and behind the caller's stream by
+	// an event recorded AFTER the train sets' pass, which stays on the caller's stream — 30 us there, and the matcher starts together with whatever the
+	// caller enqueues next (started 40 us later it found the chip full of the next batch's FAST workgroups: 0.72 instead of 0.30 ms)
+	const bool deferred = ls != nullptr;
 	if (!deferred) ls = c->stream;
 	if (!deferred && c->side && c->greedyPending) { HIPCHK(hipStreamWaitEvent(c->stream, c->evGreedy, 0)); c->greedyPending = false; }
 	if (int r = ensure((void**)&c->topKeys, &c->topKeysCap, std::max<size_t>((size_t)nsets * q->n, 1) * K * sizeof(uint32_t))) return r;
@@ -134,7 +137,25 @@ static int run_topk(mcs_ctx* c, const DevSets& d, const SetGrid& sg, const mcs_d
 	}
 	a.partial = c->partial; a.partialCount = c->partialCount;
 	a.outDist = outDist; a.outIdx = outIdx; a.outCount = outCount;
+	if (match_mfma_shape(a) && t->n > 0) {
+		// the matrix-core matcher reads train sets that one pass has compacted and expanded (256 bytes per masked 32-byte row); beyond kExpandCap the v_bcnt kernel serves
+		static const size_t kExpandCap = getenv("MCS_MATCH_EXPAND_MB") ? (size_t)atoll(getenv("MCS_MATCH_EXPAND_MB")) << 20 : (size_t)8 << 30;
+		size_t bA = 0, bW = 0;
+		match_mfma_scratch(a, sg.nt_sets, &bA, &bW, &a.exStages);
+		if (bA <= kExpandCap) {
+			if (int r = ensure((void**)&c->exA, &c->exACap, bA)) return r;
+			if (int r = ensure((void**)&c->exW, &c->exWCap, bW)) return r;
+			if (int r = ensure((void**)&c->exRows, &c->exRowsCap, (size_t)sg.nt_sets * sizeof(int))) return r;
+			a.exA = (uint4*)c->exA; a.exW = (float*)c->exW; a.exRows = c->exRows; a.tsets = sg.nt_sets;
+		}
+	}
 	c->tic("match");
+	static const bool valuOnly = getenv("MCS_MATCH_VALU") != nullptr;
+	if (deferred) {
+		if (!valuOnly && match_mfma_serves(a)) { launch_match_expand(a, c->stream); a.exDone = 1; }
+		HIPCHK(hipEventRecord(c->evMatch, c->stream));
+		HIPCHK(hipStreamWaitEvent(ls, c->evMatch, 0));
+	}
 	launch_match(a, ls);
 	c->toc("match");
 	HIPCHK(hipGetLastError());
@@ -186,8 +207,7 @@ static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc
 	// behind the previous search by the stream itself; the caller's stream goes on at once (the next batch's extraction fills the matcher's stalls).
 	const bool deferred = kind == MCS_MEM_DEVICE && c->overlap() && c->asyncSearch;
 	if (deferred) {
-		HIPCHK(hipEventRecord(c->evMatch, s));
-		HIPCHK(hipStreamWaitEvent(c->side2, c->evMatch, 0));
+		if (q->n == 0) { HIPCHK(hipEventRecord(c->evMatch, s)); HIPCHK(hipStreamWaitEvent(c->side2, c->evMatch, 0)); }   // otherwise in run_topk
 	} else if (c->side && c->greedyPending) {   // the previous search's greedy pass (side stream) still reads the shared list buffers
 		HIPCHK(hipStreamWaitEvent(s, c->evGreedy, 0));
 		c->greedyPending = false;

@@ -170,8 +170,15 @@ struct MatchArgs {
 	uint32_t* keys;            // [nsets][K][nq] final packed lists (0xFFFFFFFF = empty)
 	int* outDist; int* outIdx; // optional public [nsets][nq][K] form
 	int* outCount;
+	// mcs_match_mfma.hip: the train sets, compacted and expanded to matrix-core operands once per call (nullptr: the v_bcnt kernel serves)
+	uint4* exA; float* exW; int* exRows; int exStages; int tsets;   // tsets distinct train sets, exStages 64-row stages reserved per set
+	int exDone;                // the caller has launched launch_match_expand itself
 };
 void launch_match(const MatchArgs& a, hipStream_t s);
+bool match_mfma_serves(const MatchArgs& a);
+void launch_match_expand(const MatchArgs& a, hipStream_t s);
+bool match_mfma_shape(const MatchArgs& a);
+void match_mfma_scratch(const MatchArgs& a, int tsets, size_t* bytesA, size_t* bytesW, int* stages);
 
 // greedy, order-dependent resolution of the reference's brute-force searches on top of the top-K lists
 struct GreedyArgs {

@@ -36,6 +36,9 @@ struct mcs_ctx {
 	int* dscalar = nullptr;
 	uint32_t* topKeys = nullptr; size_t topKeysCap = 0;   // packed [set][K][nq] top-K lists feeding the greedy kernels
 	int* topCnt = nullptr; size_t topCntCap = 0;
+	uint8_t* exA = nullptr; size_t exACap = 0;            // train sets expanded to matrix-core operands (mcs_match_mfma.hip), per call
+	uint8_t* exW = nullptr; size_t exWCap = 0;
+	int* exRows = nullptr; size_t exRowsCap = 0;
 	uint8_t* stageOut = nullptr; size_t stageOutCap = 0;
 	uint8_t* pinned = nullptr; size_t pinnedCap = 0;      // page-locked host mirror of the arena's staged inputs (PinnedUpload)
 	uint8_t* arena = nullptr; size_t arenaCap = 0;        // scratch + host-kind staging of the window / projection / map-point entry points (mcs_capi_window.hip)

@@ -23,12 +23,17 @@
 // key (total << 20 | index, as in mcs_match.hip) is formed when a column is merged.  Train sets of more than 2^14 rows go to mcs_match.hip.
 #include "mcs_common.h"
 
+#ifndef MCS_MM_WAVES
+#define MCS_MM_WAVES 3
+#endif
+#ifndef MCS_MM_NBUF
+#define MCS_MM_NBUF 2
+#endif
 namespace mcs {
 
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 
-constexpr int XT = 128;        // train rows compacted per outer step (64: 4 workgroups per CU by LDS, but only one wave loads rows — measured slower)
 constexpr int XQ = 256;        // queries per workgroup
 // Words in the candidate columns are BIASED: dot + ct + 256 (+ index / 2^14), i.e. the total minus the query's own cq (<= 256) plus 256 — never negative —
 // so that cq costs nothing per pair: it is subtracted from the limit once per group and added back when a column is merged.  The f32 dot product of any
@@ -75,29 +80,116 @@ __device__ __forceinline__ void append(uint32_t& next, uint32_t w, uint32_t lim)
 		: "+v"(next) : "v"(w), "v"(lim) : "vcc", "memory");
 }
 
-// Three waves per SIMD (168 registers; the LDS allows three workgroups per CU): left alone the compiler takes 228 registers for K = 32 and two waves —
-// with ~30 spilled dwords the three-wave build is 17 % faster on the configs[2] sweep (13.4 -> 11.4 ms).
+// ---- train side, once per call: eligible rows compacted in order and expanded bit -> FP4 nibble into the A-operand layout ----------------------------
+// exA[set][stage of 64 rows][tile of 32][K step][lane] (16 bytes: lane = row + 32 * k-half), exW[set][stage * 64 + row] = the row's word
+// (ct + 256) + original index / 2^14, exRows[set] = eligible rows.  Every workgroup of the matcher that meets the set (a database sweep: hundreds) then
+// copies finished operands instead of staging, compacting and expanding the rows itself — that was two thirds of the matcher's time.
+template <int DW, bool MASKED>
+__global__ __launch_bounds__(256) void k_expand_train(MatchArgs a) {
+	constexpr int HS = DW / 2, NS = (MASKED ? 2 : 1) * HS;
+	__shared__ uint32_t lut[256];
+	__shared__ int wcnt[4], wbefore[4];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ts = blockIdx.x, base = blockIdx.y * 256;
+	const RowMap TR{(size_t)ts * a.tpitch, a.tblk, a.tbpitch};
+	lut[tid] = spread8((uint32_t)tid);
+	uint4* dstA = a.exA + (size_t)ts * a.exStages * (2 * NS * 64);
+	float* dstW = a.exW + (size_t)ts * a.exStages * 64;
+	// a workgroup per 256 rows; where its rows go = the eligible rows before them, counted from the flags (at most nt bytes)
+	int mine = 0;
+	if (a.tvalid) for (int j = tid; j < base; j += 256) mine += __popcll(__ballot(a.tvalid[TR(j)] != 0));
+	const int j = base + tid;
+	bool ok = false;
+	uint32_t tw[DW], mw[DW];
+	int ct = 0;
+	if (j < a.nt) {
+		const size_t row = TR(j);
+		const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.td + row * a.tstride);
+#pragma unroll
+		for (int w = 0; w < DW; ++w) tw[w] = tp[w];
+		if (MASKED) {
+			const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.tm + row * a.tstride);
+#pragma unroll
+			for (int w = 0; w < DW; ++w) { mw[w] = mp[w]; ct += __popc(mw[w] & tw[w]); }
+		}
+		ok = a.tvalid ? a.tvalid[row] != 0 : true;
+	}
+	const unsigned long long bal = __ballot(ok);
+	if (lane == 0) { wcnt[wv] = __popcll(bal); wbefore[wv] = mine; }
+	__syncthreads();
+	const int before = a.tvalid ? wbefore[0] + wbefore[1] + wbefore[2] + wbefore[3] : base;
+	int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+	for (int w = 0; w < wv; ++w) pos += wcnt[w];
+	if (ok) {
+		uint4* d = dstA + (size_t)(pos >> 5) * (NS * 64) + (pos & 31);
+#pragma unroll
+		for (int w = 0; w < DW; ++w) {   // step (segment * HS + w / 2), k-half w & 1
+			d[((w >> 1) * 64) + 32 * (w & 1)] = expand01(lut, tw[w]);
+			if (MASKED) d[((HS + (w >> 1)) * 64) + 32 * (w & 1)] = expandpm(lut, mw[w], tw[w]);
+		}
+		dstW[pos] = (float)(ct + (int)kBias) + (float)j * kIdxUnit;
+	}
+	if (base + 256 >= a.nt) {
+		// the set's last workgroup: the rest of the last stage gets zero operands and a word no limit can reach
+		const int rows = before + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3], p2 = rows + tid;
+		if (tid < 64 && p2 < ((rows + 63) & ~63)) {
+			uint4* d = dstA + (size_t)(p2 >> 5) * (NS * 64) + (p2 & 31);
+#pragma unroll
+			for (int st = 0; st < NS; ++st) { d[st * 64] = uint4{0, 0, 0, 0}; d[st * 64 + 32] = uint4{0, 0, 0, 0}; }
+			dstW[p2] = kPadWord;
+		}
+		if (tid == 0) a.exRows[ts] = rows;
+	}
+}
+
+// ---- the lists ---------------------------------------------------------------------------------------------------------------------------------------
+// Three waves per SIMD (168 registers; the LDS allows three workgroups per CU): left alone the compiler takes more registers for K = 32 and two waves.
 template <int K, int DW, bool MASKED>
-__attribute__((amdgpu_waves_per_eu(3, 3)))
+__attribute__((amdgpu_waves_per_eu(MCS_MM_WAVES, MCS_MM_WAVES)))
 __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 	constexpr int HS = DW / 2;                       // K steps per segment (64 bits each)
 	constexpr int NS = (MASKED ? 2 : 1) * HS;        // K steps per pair
 	constexpr int CB = 16;                           // candidate column depth per lane
-	__shared__ __attribute__((aligned(16))) uint32_t tdT[DW * XT];                 // compacted train rows, transposed [dword][row]
-	__shared__ __attribute__((aligned(16))) uint32_t tmT[MASKED ? DW * XT : 4];
-	__shared__ __attribute__((aligned(16))) float wrow[XT + 64];                  // (ct + 256) + original index / 2^14;  kPadWord past the staged rows
-	// A operands of a stage (two 32-row tiles).  One buffer and a barrier more per stage: with two (expansion of stage g + 1 beside the arithmetic of
-	// stage g) the workgroup needs 60 KB and only two fit a CU — measured 18.4 ms against 14.2 ms per configs[2] step with three.
-	__shared__ __attribute__((aligned(16))) uint4 ex[2][NS][64];
+	constexpr int SLABS = 2 * NS;                    // 1-KB operand slabs (tile, K step) per stage of 64 rows
+	// A operands of two stages: stage g + 1 arrives (global_load_lds: global -> LDS without passing registers) while stage g is multiplied
+	__shared__ __attribute__((aligned(16))) uint4 ex[MCS_MM_NBUF][2][NS][64];
+	__shared__ __attribute__((aligned(16))) float wrow[MCS_MM_NBUF][64];
 	__shared__ uint32_t lut[256];
-	__shared__ int wcnt[4];
 	__shared__ uint32_t cand[(CB + 1) * 256];
 
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, kh = lane >> 5;
-	const int set = blockIdx.z, split = blockIdx.y;
-	const int qbase = blockIdx.x * XQ + wv * 64;
+	// Workgroups are dealt to the 8 XCDs round robin; each XCD has its own L2.  Give XCD x the x-th contiguous eighth of the (set, split, query tile) order, so
+	// that the workgroups that read one train set run on one XCD (a set's expanded operands are fetched into one L2, not eight).
+	int bx = blockIdx.x, split = blockIdx.y, set = blockIdx.z;
+	{
+		const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+		if ((total & 7u) == 0) {
+			const unsigned lin = (blockIdx.z * ny + blockIdx.y) * nx + blockIdx.x, m = (lin & 7u) * (total >> 3) + (lin >> 3);
+			bx = (int)(m % nx); split = (int)((m / nx) % ny); set = (int)(m / (nx * ny));
+		}
+	}
+	const int qbase = bx * XQ + wv * 64;
 	const int qi = qbase + lane;   // the query this lane OWNS after the half swap (set 0: lanes 0..31, set 1: lanes 32..63)
-	const RowMap QR{(size_t)(set % a.qmod) * a.qpitch, a.qblk, a.qbpitch}, TR{(size_t)((set / a.tdiv + a.toff) % a.tmod) * a.tpitch, a.tblk, a.tbpitch};
+	const RowMap QR{(size_t)(set % a.qmod) * a.qpitch, a.qblk, a.qbpitch};
+	const int ts = a.tsets > 1 ? (set / a.tdiv + a.toff) % a.tmod : 0;
+	const int rows = a.exRows[ts];
+	const int per = (a.exStages + a.splits - 1) / a.splits;
+	const int g0 = split * per, g1 = min((rows + 63) >> 6, g0 + per);
+	const uint4* srcA = a.exA + (size_t)ts * a.exStages * (SLABS * 64);
+	const float* srcW = a.exW + (size_t)ts * a.exStages * 64;
+	// (lane indices and addresses are re-derived from an opaque copy of the thread index per stage: held across the loop they were spilled, and a spill
+	// reload waits for every load in flight — the next stage's operands included)
+	auto request = [&](int g, int buf, int ln, int wave) {   // this wave's share of stage g: SLABS / 4 slabs (and the words, wave 0)
+#pragma unroll
+		for (int i = 0; i < SLABS / 4; ++i) {
+			const int slab = wave * (SLABS / 4) + i;
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA + ((size_t)g * SLABS + slab) * 64 + ln),
+			                                 (__attribute__((address_space(3))) void*)(&ex[buf][0][0][0] + slab * 64), 16, 0, 0);
+		}
+		if (wave == 0)
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW + (size_t)g * 64 + ln),
+			                                 (__attribute__((address_space(3))) void*)(&wrow[buf][0]), 4, 0, 0);
+	};
+	if (MCS_MM_NBUF == 2 && g0 < g1) request(g0, 0, lane, wv);
 	lut[tid] = spread8((uint32_t)tid);
 	__syncthreads();
 
@@ -201,8 +293,6 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 		next = col0;
 	};
 
-	const int per = ((a.nt + a.splits - 1) / a.splits + 63) / 64 * 64;
-	const int t0 = split * per, t1 = min(a.nt, t0 + per);
 	const uint32_t dCap = a.maxDist >= 4095 ? 4095u : (uint32_t)a.maxDist;
 	// The distance threshold, the padding rows and "closer than the K-th best" are ONE unsigned compare of the biased word's bits against rawLim (masked:
 	// the raw total t stands for distance t >> 1, so "distance <= D" is t <= 2D + 1).  The K-th best only changes in a merge: the limit is recomputed there.
@@ -220,107 +310,65 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 		return qok ? __float_as_uint((float)(lim + kBias - cq) + (float)frac * kIdxUnit) : 0u;
 	};
 	uint32_t rawLim = limit();
-	for (int base = t0; base < t1; base += XT) {
-		// The rows of this step: row and flag are requested together (one memory round trip), parked in LDS as they come (the operand buffer is free between
-		// stages), then the eligible ones are compacted in order (ballot prefix) — holding 16 row dwords in registers across the prefix and its barrier
-		// spilled them.  ct and the original index go into one word per row.
-		uint32_t* park = reinterpret_cast<uint32_t*>(&ex[0][0][0]);   // [2 * DW][XT] dwords
-		const int j = base + tid;
-		bool ok = false;
-		float word = 0.f;
-		if (tid < XT && j < t1) {
-			const size_t row = TR(j);
-			const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.td + row * a.tstride);
-			uint32_t tw[DW], mw[DW];
-#pragma unroll
-			for (int w = 0; w < DW; ++w) tw[w] = tp[w];
-			if (MASKED) {
-				const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.tm + row * a.tstride);
-#pragma unroll
-				for (int w = 0; w < DW; ++w) mw[w] = mp[w];
-			}
-			ok = a.tvalid ? a.tvalid[row] != 0 : true;
-			int ct = 0;
-#pragma unroll
-			for (int w = 0; w < DW; ++w) {
-				park[w * XT + tid] = tw[w];
-				if (MASKED) { park[(DW + w) * XT + tid] = mw[w]; ct += __popc(mw[w] & tw[w]); }
-			}
-			word = (float)(ct + (int)kBias) + (float)j * kIdxUnit;
-		}
-		const unsigned long long bal = __ballot(ok);
-		if (lane == 0) wcnt[wv] = __popcll(bal);
+	for (int g = g0; g < g1; ++g) {
+#if MCS_MM_NBUF == 2
+		const int buf = (g - g0) & 1;
+		// stage g has landed once every wave's own LDS-DMA loads are complete (hipcc does not count them before a barrier: the wait is explicit) and the
+		// waves have met; every wave is then through with stage g - 1 as well
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
-		int pos = __popcll(bal & ((1ull << lane) - 1ull));
-		for (int w = 0; w < wv; ++w) pos += wcnt[w];
-		const int rows = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-		if (ok) {
-#pragma unroll
-			for (int w = 0; w < DW; ++w) { tdT[w * XT + pos] = park[w * XT + tid]; if (MASKED) tmT[w * XT + pos] = park[(DW + w) * XT + tid]; }
-			wrow[pos] = word;
-		}
-		if (tid < 64) wrow[rows + tid] = kPadWord;
+		int t2 = threadIdx.x;
+		asm volatile("" : "+v"(t2));
+		const int ln = t2 & 63, kh2 = (t2 >> 5) & 1;
+		if (g + 1 < g1) request(g + 1, buf ^ 1, ln, t2 >> 6);
+#else
+		const int buf = 0;
+		int t2 = threadIdx.x;
+		asm volatile("" : "+v"(t2));
+		const int ln = t2 & 63, kh2 = (t2 >> 5) & 1;
 		__syncthreads();
-		const int nstage = (rows + 63) >> 6;
-		// expansion of stage g (64 rows) into ex: item = (row of the stage, segment, dword) -> the 16 bytes of lane (row & 31) + 32 * (dword & 1), step
-		// segment * HS + dword / 2, tile row >> 5.  Rows past `rows` expand stale data: their index word is kPadWord.
-		auto expand_stage = [&](int g) {
-			constexpr int items = 64 * (MASKED ? 2 : 1) * DW;
+		request(g, 0, ln, t2 >> 6);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+#endif
 #pragma unroll
-			for (int it = 0; it < items / 256; ++it) {
-				const int e = it * 256 + tid;
-				const int r = e & 63, q = e >> 6, seg = q / DW, dw = q - seg * DW;
-				const int src = (g << 6) + r;
-				const uint32_t x = tdT[dw * XT + src];
-				uint4 o;
-				if (MASKED) { const uint32_t m = tmT[dw * XT + src]; o = seg == 0 ? expand01(lut, x) : expandpm(lut, m, x); }
-				else o = expand01(lut, x);
-				ex[r >> 5][seg * HS + (dw >> 1)][(r & 31) + 32 * (dw & 1)] = o;
-			}
-		};
-		for (int g = 0; g < nstage; ++g) {
-			expand_stage(g);
-			__syncthreads();
+		for (int tile = 0; tile < 2; ++tile) {
+			const int row0 = (g << 6) + (tile << 5);
+			if (row0 < rows) {
+				// accumulator r of a lane is train row (r & 3) + 8 (r >> 2) + 4 * k-half of the tile: both sets start from the rows' words
+				v16f_t acc0, acc1;
 #pragma unroll
-			for (int tile = 0; tile < 2; ++tile) {
-				const int row0 = (g << 6) + (tile << 5);
-				if (row0 < rows) {
-					// accumulator r of a lane is train row (r & 3) + 8 (r >> 2) + 4 * k-half of the tile: both sets start from the rows' words
-					v16f_t acc0, acc1;
+				for (int jp = 0; jp < 4; ++jp) {
+					const float4 w4 = *reinterpret_cast<const float4*>(&wrow[buf][(tile << 5) + 8 * jp + 4 * kh2]);
+					acc0[4 * jp] = w4.x; acc0[4 * jp + 1] = w4.y; acc0[4 * jp + 2] = w4.z; acc0[4 * jp + 3] = w4.w;
+				}
+				acc1 = acc0;
 #pragma unroll
-					for (int jp = 0; jp < 4; ++jp) {
-						const float4 w4 = *reinterpret_cast<const float4*>(&wrow[row0 + 8 * jp + 4 * kh]);
-						acc0[4 * jp] = w4.x; acc0[4 * jp + 1] = w4.y; acc0[4 * jp + 2] = w4.z; acc0[4 * jp + 3] = w4.w;
+				for (int s = 0; s < NS; ++s) {
+					const uint4 av = ex[buf][tile][s][ln];
+					const v8i_t va{(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
+					acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, bq[0][s], acc0, 4, 4, 0, 0, 0, 0);
+					acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, bq[1][s], acc1, 4, 4, 0, 0, 0, 0);
+				}
+				// result register r of a lane = the key of train row (r & 3) + 8 (r >> 2) + 4 * k-half of the tile, for column (lane & 31) of its set.
+				// The swap exchanges the upper half of set 0's register with the lower half of set 1's: afterwards lo[r] is row (r & 3) + 8 (r >> 2)
+				// and hi[r] row (r & 3) + 8 (r >> 2) + 4 of the lane's OWN query, in every lane
+#pragma unroll
+				for (int jp = 0; jp < 4; ++jp) {
+					uint32_t lo[4], hi[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[4 * jp + u]), __float_as_uint(acc1[4 * jp + u]), false, false);
+						lo[u] = sw[0]; hi[u] = sw[1];
 					}
-					acc1 = acc0;
 #pragma unroll
-					for (int s = 0; s < NS; ++s) {
-						const uint4 av = ex[tile][s][lane];
-						const v8i_t va{(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
-						acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, bq[0][s], acc0, 4, 4, 0, 0, 0, 0);
-						acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, bq[1][s], acc1, 4, 4, 0, 0, 0, 0);
-					}
-					// result register r of a lane = the key of train row (r & 3) + 8 (r >> 2) + 4 * k-half of the tile, for column (lane & 31) of its set.
-					// The swap exchanges the upper half of set 0's register with the lower half of set 1's: afterwards lo[r] is row (r & 3) + 8 (r >> 2)
-					// and hi[r] row (r & 3) + 8 (r >> 2) + 4 of the lane's OWN query, in every lane
+					for (int h = 0; h < 2; ++h) {   // four rows at a time: a column has room for 16, so a merge is due once a lane holds more than 12
 #pragma unroll
-					for (int jp = 0; jp < 4; ++jp) {
-						uint32_t lo[4], hi[4];
-#pragma unroll
-						for (int u = 0; u < 4; ++u) {
-							const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[4 * jp + u]), __float_as_uint(acc1[4 * jp + u]), false, false);
-							lo[u] = sw[0]; hi[u] = sw[1];
-						}
-#pragma unroll
-						for (int h = 0; h < 2; ++h) {   // four rows at a time: a column has room for 16, so a merge is due once a lane holds more than 12
-#pragma unroll
-							for (int u = 0; u < 4; ++u) append(next, h ? hi[u] : lo[u], rawLim);
-							if (__any(next > col0 + (CB - 4) * 1024)) { flush(); rawLim = limit(); }
-						}
+						for (int u = 0; u < 4; ++u) append(next, h ? hi[u] : lo[u], rawLim);
+						if (__any(next > col0 + (CB - 4) * 1024)) { flush(); rawLim = limit(); }
 					}
 				}
 			}
-			__syncthreads();
 		}
 	}
 	flush();
@@ -347,12 +395,29 @@ static void launch_mfma_k(const MatchArgs& a, hipStream_t s) {
 	else launch_mfma_kd<K, 8>(a, s);
 }
 
-// the partial-list kernel of launch_match() for the shapes the matrix-core form serves: 16 / 32-byte descriptors, no count_le output, no camera groups
-bool match_mfma_serves(const MatchArgs& a) {
+// the partial-list kernel of launch_match() for the shapes the matrix-core form serves: 16 / 32-byte descriptors, no count_le output, no camera groups,
+// at most 2^14 train rows per set (the index rides in the low 14 bits of a float)
+bool match_mfma_shape(const MatchArgs& a) {
 	return (a.dim == 16 || a.dim == 32) && a.countThresh < 0 && !(a.qgroup && a.tgroup) && a.nt <= kMaxTrainRows;
+}
+// scratch of the expanded train sets (the caller allocates; a.exA == nullptr sends the call to mcs_match.hip)
+void match_mfma_scratch(const MatchArgs& a, int tsets, size_t* bytesA, size_t* bytesW, int* stages) {
+	const int st = (a.nt + 63) / 64, ns = (a.qm && a.tm ? 2 : 1) * (a.dim / 8);
+	*stages = st;
+	*bytesA = (size_t)tsets * st * 2 * ns * 64 * sizeof(uint4);
+	*bytesW = (size_t)tsets * st * 64 * sizeof(float);
+}
+bool match_mfma_serves(const MatchArgs& a) { return match_mfma_shape(a) && a.exA && a.exW && a.exRows && a.tsets >= 1; }
+
+// the train sets' pass; launch_match_mfma runs it itself unless the caller has (a.exDone: on another stream, ordered before s)
+void launch_match_expand(const MatchArgs& a, hipStream_t s) {
+	const bool masked = a.qm && a.tm;
+	if (a.dim == 16) { if (masked) hipLaunchKernelGGL((k_expand_train<4, true>), dim3(a.tsets, (a.nt + 255) / 256), dim3(256), 0, s, a); else hipLaunchKernelGGL((k_expand_train<4, false>), dim3(a.tsets, (a.nt + 255) / 256), dim3(256), 0, s, a); }
+	else { if (masked) hipLaunchKernelGGL((k_expand_train<8, true>), dim3(a.tsets, (a.nt + 255) / 256), dim3(256), 0, s, a); else hipLaunchKernelGGL((k_expand_train<8, false>), dim3(a.tsets, (a.nt + 255) / 256), dim3(256), 0, s, a); }
 }
 
 void launch_match_mfma(const MatchArgs& a, hipStream_t s) {
+	if (!a.exDone) launch_match_expand(a, s);
 	switch (a.K) {
 		case 1: launch_mfma_k<1>(a, s); break;
 		case 2: launch_mfma_k<2>(a, s); break;
