@@ -11,6 +11,9 @@
 // query — exact for any K, K only trades list size against rescans.  Integer + a few FP64 mul/div: bit-exact.
 #include "mcs_common.h"
 
+#ifndef MCS_GREEDY_WAVES
+#define MCS_GREEDY_WAVES 4
+#endif
 namespace mcs {
 
 constexpr int kBitmapWords = 4096;   // nt <= 131072 train rows per set
@@ -213,23 +216,28 @@ constexpr int kClaimRows = 16384;   // train rows per set supported by the specu
 // global-memory latency of every trip over the train rows (~30 us per rescan), eight waves split the rows and overlap it.  Protocol per RESCAN: wave 0
 // posts the query in LDS, block barrier A (where the helper waves wait), every wave scans its slice and posts its two smallest keys, block barrier B, wave 0 merges.
 // Everything else in a round touches LDS from wave 0 only and is ordered by workgroup fences instead of barriers.
-constexpr int kSpecWaves = 8;
+// wave 0 decides, the others scan.  Few set pairs (a frame ring: 64): 8 waves, the rescans are what takes time; a database sweep (thousands): 4 waves, four
+// workgroups per CU — the kernel is a chain of dependent LDS / memory round trips per workgroup, and what speeds it up is workgroups in flight.
+constexpr int kSpecWaves = 8, kSpecWavesMany = 4, kManySets = 512;
 template <int K, int DW, bool MASKED, bool TRI>
+__attribute__((amdgpu_waves_per_eu(MCS_GREEDY_WAVES, MCS_GREEDY_WAVES)))
 __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
-	__shared__ uint32_t matched[kClaimRows / 32];
-	__shared__ uint32_t claim[kClaimRows];
+	extern __shared__ uint32_t greedy_lds[];               // claim[nt], matched[ceil(nt / 32)]: sized by the launch, so that short sets leave room for more workgroups per CU
+	uint32_t* claim = greedy_lds;
+	uint32_t* matched = greedy_lds + g.nt;
 	__shared__ int reqQ;                                   // query to rescan this round, -1 none, -2 the set is finished
-	__shared__ uint32_t partA[kSpecWaves], partB[kSpecWaves];
+	__shared__ uint32_t partA[kSpecWaves - 1], partB[kSpecWaves - 1];
+	const int nscan = (int)(blockDim.x >> 6) - 1;
 	const int set = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const RowMap QR{(size_t)(set % g.qmod) * g.qpitch, g.qblk, g.qbpitch}, TR{(size_t)((set / g.tdiv + g.toff) % g.tmod) * g.tpitch, g.tblk, g.tbpitch};
 	constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-	for (int i = threadIdx.x; i < (g.nt + 31) / 32; i += 64 * kSpecWaves) matched[i] = 0;
-	for (int i = threadIdx.x; i < g.nt; i += 64 * kSpecWaves) claim[i] = 0xFFFFFFFFu;
+	for (int i = threadIdx.x; i < (g.nt + 31) / 32; i += blockDim.x) matched[i] = 0;
+	for (int i = threadIdx.x; i < g.nt; i += blockDim.x) claim[i] = 0xFFFFFFFFu;
 	int* outM = g.outMatch + (size_t)set * (g.mode == 1 ? g.nt : g.nq);
-	if (g.mode == 1) for (int j = threadIdx.x; j < g.nt; j += 64 * kSpecWaves) outM[j] = -1;
+	if (g.mode == 1) for (int j = threadIdx.x; j < g.nt; j += blockDim.x) outM[j] = -1;
 	__syncthreads();
 	const bool grouped = g.qgroup != nullptr && g.tgroup != nullptr;
-	// this wave's share of the exact rescan of query qi: rows wave*256 + lane + 64*u + 256*kSpecWaves*trip.  non-TRI: the slice's two smallest keys of
+	// this wave's share of the exact rescan of query qi: rows (wave-1)*256 + lane + 64*u + 256*nscan*trip.  non-TRI: the slice's two smallest keys of
 	// free eligible rows; TRI: its smallest candidate key and its smallest candidate key that passes the epipolar test.
 	auto scan_slice = [&](int qi) {
 		uint32_t q[DW], qm[DW];
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 			EmLow = g.E + (size_t)set * g.Epitch + (size_t)9 * ((size_t)qgLow * g.nrCams + qgLow);
 		}
 		// branch-free body, 4 rows per lane and trip: all global loads of a trip are issued before the first use
-		for (int j0 = wave * 256 + lane; j0 < g.nt; j0 += 256 * kSpecWaves) {
+		for (int j0 = (wave - 1) * 256 + lane; j0 < g.nt; j0 += 256 * nscan) {
 			uint32_t kk[4];
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 		}
 		const uint32_t m1 = wave_min_u32(a);
 		const uint32_t m2 = TRI ? wave_min_u32(b2) : wave_min_u32(a == m1 ? b2 : a);
-		if (lane == 0) { partA[wave] = m1; partB[wave] = m2; }
+		if (lane == 0) { partA[wave - 1] = m1; partB[wave - 1] = m2; }
 	};
 	if (wave > 0) {   // helper waves
 		for (;;) {
@@ -350,7 +358,8 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 				int aIdx = -1, aDist = 0, bIdx = -1, bDist = 0;
 #pragma unroll
 				for (int e = 0; e < K; ++e) {
-					const uint32_t k = key[e];
+					uint32_t k = key[e];
+					asm volatile("" : "+v"(k));   // as below
 					if (k != EMPTY && (int)(k >> 20) <= g.thLow && bIdx < 0) {
 						const int idx = (int)(k & 0xFFFFFu);
 						if (!((matched[idx >> 5] >> (idx & 31)) & 1u)) {
@@ -368,7 +377,8 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 				int n = 0;
 #pragma unroll
 				for (int e = 0; e < K; ++e) {
-					const uint32_t k = key[e];
+					uint32_t k = key[e];
+					asm volatile("" : "+v"(k));   // (index, bitmap word and bit of every entry hoisted out of the round loop cost 100 registers)
 					if (k != EMPTY && n < 2) {
 						const int idx = (int)(k & 0xFFFFFu);
 						if (!((matched[idx >> 5] >> (idx & 31)) & 1u)) {
@@ -397,11 +407,9 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 			if (needScan) {
 				if (lane == 0) reqQ = i0 + low;
 				__syncthreads();   // A
-				scan_slice(i0 + low);
-				__syncthreads();   // B
+				__syncthreads();   // B  (wave 0 does not scan: with its lists live across the scan the kernel needed 254 registers — one workgroup per CU)
 				uint32_t m1 = EMPTY, m2 = EMPTY;
-#pragma unroll
-				for (int w = 0; w < kSpecWaves; ++w) {
+				for (int w = 0; w < nscan; ++w) {
 					const uint32_t pa = partA[w], pb = partB[w];
 					if (TRI) { m1 = pa < m1 ? pa : m1; m2 = pb < m2 ? pb : m2; }
 					else {   // the two smallest of all slices' two smallest
@@ -460,14 +468,19 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 	__syncthreads();   // A: releases the helper waves
 }
 
+template <int K, int DW, bool MASKED, bool TRI>
+static void launch_spec(const GreedyArgs& g, hipStream_t s) {
+	const size_t lds = (size_t)(g.nt + (g.nt + 31) / 32) * 4;   // claim[nt] + matched bitmap
+	if (lds > 60 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy_spec<K, DW, MASKED, TRI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipLaunchKernelGGL((k_greedy_spec<K, DW, MASKED, TRI>), dim3(g.nsets), dim3(64 * (g.nsets >= kManySets ? kSpecWavesMany : kSpecWaves)), lds, s, g);
+}
+
 template <int K, int DW>
 static void launch_spec_kd(const GreedyArgs& g, hipStream_t s) {
 	const bool masked = g.qm && g.tm;
-	if (g.mode == 2) {
-		if (masked) hipLaunchKernelGGL((k_greedy_spec<K, DW, true, true>), dim3(g.nsets), dim3(64 * kSpecWaves), 0, s, g);
-		else hipLaunchKernelGGL((k_greedy_spec<K, DW, false, true>), dim3(g.nsets), dim3(64 * kSpecWaves), 0, s, g);
-	} else if (masked) hipLaunchKernelGGL((k_greedy_spec<K, DW, true, false>), dim3(g.nsets), dim3(64 * kSpecWaves), 0, s, g);
-	else hipLaunchKernelGGL((k_greedy_spec<K, DW, false, false>), dim3(g.nsets), dim3(64 * kSpecWaves), 0, s, g);
+	if (g.mode == 2) { if (masked) launch_spec<K, DW, true, true>(g, s); else launch_spec<K, DW, false, true>(g, s); }
+	else if (masked) launch_spec<K, DW, true, false>(g, s);
+	else launch_spec<K, DW, false, false>(g, s);
 }
 
 template <int DW>

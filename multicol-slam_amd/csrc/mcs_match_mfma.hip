@@ -23,6 +23,9 @@
 // key (total << 20 | index, as in mcs_match.hip) is formed when a column is merged.  Train sets of more than 2^14 rows go to mcs_match.hip.
 #include "mcs_common.h"
 
+#ifndef MCS_MM_AB
+#define MCS_MM_AB 0
+#endif
 #ifndef MCS_MM_WAVES
 #define MCS_MM_WAVES 3
 #endif
@@ -252,6 +255,9 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 			}
 	};
 	auto flush = [&]() {   // as in mcs_match.hip
+#if MCS_MM_AB == 2
+		next = col0; return;
+#endif
 		const int cnt = (int)((next - col0) >> 10);
 		if (K >= CB) {
 			uint32_t c[CB];
@@ -347,8 +353,12 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 				for (int s = 0; s < NS; ++s) {
 					const uint4 av = ex[buf][tile][s][ln];
 					const v8i_t va{(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
+#if MCS_MM_AB == 3
+					acc0[s] += __int_as_float(va[0]); acc1[s] += __int_as_float(va[1] ^ bq[1][s][0]);
+#else
 					acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, bq[0][s], acc0, 4, 4, 0, 0, 0, 0);
 					acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, bq[1][s], acc1, 4, 4, 0, 0, 0, 0);
+#endif
 				}
 				// result register r of a lane = the key of train row (r & 3) + 8 (r >> 2) + 4 * k-half of the tile, for column (lane & 31) of its set.
 				// The swap exchanges the upper half of set 0's register with the lower half of set 1's: afterwards lo[r] is row (r & 3) + 8 (r >> 2)
@@ -364,7 +374,12 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 #pragma unroll
 					for (int h = 0; h < 2; ++h) {   // four rows at a time: a column has room for 16, so a merge is due once a lane holds more than 12
 #pragma unroll
-						for (int u = 0; u < 4; ++u) append(next, h ? hi[u] : lo[u], rawLim);
+						for (int u = 0; u < 4; ++u)
+#if MCS_MM_AB == 4
+							next += (h ? hi[u] : lo[u]) == 0x12345u ? 1024u : 0u;
+#else
+							append(next, h ? hi[u] : lo[u], rawLim);
+#endif
 						if (__any(next > col0 + (CB - 4) * 1024)) { flush(); rawLim = limit(); }
 					}
 				}
