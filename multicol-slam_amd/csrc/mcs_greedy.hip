@@ -11,9 +11,6 @@
 // query — exact for any K, K only trades list size against rescans.  Integer + a few FP64 mul/div: bit-exact.
 #include "mcs_common.h"
 
-#ifndef MCS_GREEDY_WAVES
-#define MCS_GREEDY_WAVES 4
-#endif
 namespace mcs {
 
 constexpr int kBitmapWords = 4096;   // nt <= 131072 train rows per set
@@ -220,7 +217,8 @@ constexpr int kClaimRows = 16384;   // train rows per set supported by the specu
 // workgroups per CU — the kernel is a chain of dependent LDS / memory round trips per workgroup, and what speeds it up is workgroups in flight.
 constexpr int kSpecWaves = 8, kSpecWavesMany = 4, kManySets = 512;
 template <int K, int DW, bool MASKED, bool TRI>
-__attribute__((amdgpu_waves_per_eu(MCS_GREEDY_WAVES, MCS_GREEDY_WAVES)))
+// registers: 96 (five 4-wave workgroups per CU) where that costs no spills — the SearchByBoW forms on 16 / 32-byte descriptors —, 128 otherwise
+__attribute__((amdgpu_waves_per_eu((DW <= 8 && !TRI) ? 5 : 4, (DW <= 8 && !TRI) ? 5 : 4)))
 __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 	extern __shared__ uint32_t greedy_lds[];               // claim[nt], matched[ceil(nt / 32)]: sized by the launch, so that short sets leave room for more workgroups per CU
 	uint32_t* claim = greedy_lds;
@@ -375,16 +373,23 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 				else state = 2;
 			} else if (!resolved) {
 				int n = 0;
+				bool stop = false;   // wave-uniform: every active lane has its two free entries (the lists are sorted: usually within the first few)
 #pragma unroll
-				for (int e = 0; e < K; ++e) {
-					uint32_t k = key[e];
-					asm volatile("" : "+v"(k));   // (index, bitmap word and bit of every entry hoisted out of the round loop cost 100 registers)
-					if (k != EMPTY && n < 2) {
-						const int idx = (int)(k & 0xFFFFFu);
-						if (!((matched[idx >> 5] >> (idx & 31)) & 1u)) {
-							if (n == 0) { best = (int)(k >> 20); bestIdx = idx; } else { second = (int)(k >> 20); secondIdx = idx; }
-							++n;
+				for (int e0 = 0; e0 < K; e0 += 4) {
+					if (!stop) {
+#pragma unroll
+						for (int e = e0; e < e0 + 4 && e < K; ++e) {
+							uint32_t k = key[e];
+							asm volatile("" : "+v"(k));   // (index, bitmap word and bit of every entry hoisted out of the round loop cost 100 registers)
+							if (k != EMPTY && n < 2) {
+								const int idx = (int)(k & 0xFFFFFu);
+								if (!((matched[idx >> 5] >> (idx & 31)) & 1u)) {
+									if (n == 0) { best = (int)(k >> 20); bestIdx = idx; } else { second = (int)(k >> 20); secondIdx = idx; }
+									++n;
+								}
+							}
 						}
+						if (e0 + 4 < K) stop = __all(n >= 2 || key[e0 + 3 < K ? e0 + 3 : K - 1] == EMPTY);
 					}
 				}
 				if (n >= 2 || !full) {
