@@ -29,6 +29,12 @@
 #ifndef MCS_MM_WAVES
 #define MCS_MM_WAVES 3
 #endif
+#ifndef MCS_MM_WGW
+#define MCS_MM_WGW 4
+#endif
+#ifndef MCS_MM_TPS
+#define MCS_MM_TPS 2
+#endif
 #ifndef MCS_MM_NBUF
 #define MCS_MM_NBUF 2
 #endif
@@ -37,7 +43,10 @@ namespace mcs {
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 
-constexpr int XQ = 256;        // queries per workgroup
+constexpr int WGW = MCS_MM_WGW;   // waves per workgroup: they share the staged train operands and meet at one barrier per stage
+constexpr int TPS = MCS_MM_TPS;   // 32-row tiles per stage
+constexpr int XQ = 64 * WGW;      // queries per workgroup
+constexpr int kColStride = XQ * 4;   // bytes between the slots of a lane's candidate column
 // Words in the candidate columns are BIASED: dot + ct + 256 (+ index / 2^14), i.e. the total minus the query's own cq (<= 256) plus 256 — never negative —
 // so that cq costs nothing per pair: it is subtracted from the limit once per group and added back when a column is merged.  The f32 dot product of any
 // staged row (real or stale bits, always 0 / +-1 operands) lies in [-512, 512], so a padding row's word (kPadWord) ends in [2560, 3584]: never below a
@@ -71,16 +80,16 @@ __device__ __forceinline__ uint4 expandpm(const uint32_t* lut, uint32_t m, uint3
 	return o;
 }
 
-// *(uint32_t*)next = w (next: LDS byte address) and next += 1024 in the lanes with w < lim (unsigned compare of float bits): the compare writes the lane
+// *(uint32_t*)next = w (next: LDS byte address) and next += kColStride in the lanes with w < lim (unsigned compare of float bits): the compare writes the lane
 // mask, the store and the add run under it — one compare + one add on the VALU per pair (compare / select / shift-add / add as plain C++).  All 64
 // lanes are active at every call site (wave-uniform control flow, full workgroups).
 __device__ __forceinline__ void append(uint32_t& next, uint32_t w, uint32_t lim) {
 	asm volatile(
 		"v_cmpx_lt_u32_e32 vcc, %1, %2\n\t"
 		"ds_write_b32 %0, %1\n\t"
-		"v_add_u32_e32 %0, 0x400, %0\n\t"
+		"v_add_u32_e32 %0, %3, %0\n\t"
 		"s_mov_b64 exec, -1"
-		: "+v"(next) : "v"(w), "v"(lim) : "vcc", "memory");
+		: "+v"(next) : "v"(w), "v"(lim), "i"(kColStride) : "vcc", "memory");
 }
 
 // ---- train side, once per call: eligible rows compacted in order and expanded bit -> FP4 nibble into the A-operand layout ----------------------------
@@ -148,16 +157,16 @@ __global__ __launch_bounds__(256) void k_expand_train(MatchArgs a) {
 // Three waves per SIMD (168 registers; the LDS allows three workgroups per CU): left alone the compiler takes more registers for K = 32 and two waves.
 template <int K, int DW, bool MASKED>
 __attribute__((amdgpu_waves_per_eu(MCS_MM_WAVES, MCS_MM_WAVES)))
-__global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
+__global__ __launch_bounds__(XQ) void k_match_mfma(MatchArgs a) {
 	constexpr int HS = DW / 2;                       // K steps per segment (64 bits each)
 	constexpr int NS = (MASKED ? 2 : 1) * HS;        // K steps per pair
 	constexpr int CB = 16;                           // candidate column depth per lane
-	constexpr int SLABS = 2 * NS;                    // 1-KB operand slabs (tile, K step) per stage of 64 rows
+	constexpr int SLABS = TPS * NS;                  // 1-KB operand slabs (tile, K step) per stage
 	// A operands of two stages: stage g + 1 arrives (global_load_lds: global -> LDS without passing registers) while stage g is multiplied
-	__shared__ __attribute__((aligned(16))) uint4 ex[MCS_MM_NBUF][2][NS][64];
+	__shared__ __attribute__((aligned(16))) uint4 ex[MCS_MM_NBUF][TPS][NS][64];
 	__shared__ __attribute__((aligned(16))) float wrow[MCS_MM_NBUF][64];
 	__shared__ uint32_t lut[256];
-	__shared__ uint32_t cand[(CB + 1) * 256];
+	__shared__ uint32_t cand[(CB + 1) * XQ];
 
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, kh = lane >> 5;
 	// Workgroups are dealt to the 8 XCDs round robin; each XCD has its own L2.  Give XCD x the x-th contiguous eighth of the (set, split, query tile) order, so
@@ -175,25 +184,26 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 	const RowMap QR{(size_t)(set % a.qmod) * a.qpitch, a.qblk, a.qbpitch};
 	const int ts = a.tsets > 1 ? (set / a.tdiv + a.toff) % a.tmod : 0;
 	const int rows = a.exRows[ts];
-	const int per = (a.exStages + a.splits - 1) / a.splits;
-	const int g0 = split * per, g1 = min((rows + 63) >> 6, g0 + per);
-	const uint4* srcA = a.exA + (size_t)ts * a.exStages * (SLABS * 64);
+	const int per = (a.exStages * (2 / TPS) + a.splits - 1) / a.splits;   // a.exStages counts 64-row units
+	const int g0 = split * per, g1 = min((rows + 32 * TPS - 1) / (32 * TPS), g0 + per);
+	const uint4* srcA = a.exA + (size_t)ts * a.exStages * (2 * NS * 64);
 	const float* srcW = a.exW + (size_t)ts * a.exStages * 64;
 	// (lane indices and addresses are re-derived from an opaque copy of the thread index per stage: held across the loop they were spilled, and a spill
 	// reload waits for every load in flight — the next stage's operands included)
-	auto request = [&](int g, int buf, int ln, int wave) {   // this wave's share of stage g: SLABS / 4 slabs (and the words, wave 0)
+	auto request = [&](int g, int buf, int ln, int wave) {   // this wave's share of stage g's slabs (and the words, wave 0)
 #pragma unroll
-		for (int i = 0; i < SLABS / 4; ++i) {
-			const int slab = wave * (SLABS / 4) + i;
+		for (int i = 0; i < (SLABS + WGW - 1) / WGW; ++i) {
+			const int slab = wave + i * WGW;
+			if (SLABS % WGW == 0 || slab < SLABS)
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA + ((size_t)g * SLABS + slab) * 64 + ln),
 			                                 (__attribute__((address_space(3))) void*)(&ex[buf][0][0][0] + slab * 64), 16, 0, 0);
 		}
 		if (wave == 0)
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW + (size_t)g * 64 + ln),
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW + (size_t)g * (32 * TPS) + ln),
 			                                 (__attribute__((address_space(3))) void*)(&wrow[buf][0]), 4, 0, 0);
 	};
 	if (MCS_MM_NBUF == 2 && g0 < g1) request(g0, 0, lane, wv);
-	lut[tid] = spread8((uint32_t)tid);
+	for (int i = tid; i < 256; i += XQ) lut[i] = spread8((uint32_t)i);
 	__syncthreads();
 
 	// the operands of query (set u, column col): step s = segment * HS + j covers dwords 2j (k-half 0) and 2j + 1 (k-half 1) of the segment's bit vector
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 	uint32_t best[K];
 #pragma unroll
 	for (int p = 0; p < K; ++p) best[p] = 0xFFFFFFFFu;
-	const uint32_t col0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cand + tid);   // LDS byte address of the lane's column; slot e is 1024 bytes further
+	const uint32_t col0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cand + tid);   // LDS byte address of the lane's column; slot e is kColStride bytes further
 	uint32_t next = col0;
 	auto exact_key = [&](uint32_t bits) {   // float word -> un-biased integer key as in mcs_match.hip
 		const uint32_t k = (uint32_t)(__uint_as_float(bits) * 16384.f);   // exact: at most 14 fractional bits
@@ -258,11 +268,11 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 #if MCS_MM_AB == 2
 		next = col0; return;
 #endif
-		const int cnt = (int)((next - col0) >> 10);
+		const int cnt = (int)((next - col0) / kColStride);
 		if (K >= CB) {
 			uint32_t c[CB];
 #pragma unroll
-			for (int e = 0; e < CB; ++e) c[e] = cand[e * 256 + tid];
+			for (int e = 0; e < CB; ++e) c[e] = cand[e * XQ + tid];
 #pragma unroll
 			for (int e = 0; e < CB; ++e) {
 				asm volatile("" : "+v"(c[e]));   // the reads stay unconditional and in flight together (a stale slot's bits convert to some key that the select drops)
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
 			for (int e = 0; e < m; ++e) {
-				uint32_t key = e < cnt ? exact_key(cand[e * 256 + tid]) : 0xFFFFFFFFu;
+				uint32_t key = e < cnt ? exact_key(cand[e * XQ + tid]) : 0xFFFFFFFFu;
 				if (__any(key < best[K - 1])) {
 #pragma unroll
 					for (int p = 0; p < K; ++p) { const uint32_t lo = min(best[p], key), hi = max(best[p], key); best[p] = lo; key = hi; }
@@ -338,8 +348,8 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 		__syncthreads();
 #endif
 #pragma unroll
-		for (int tile = 0; tile < 2; ++tile) {
-			const int row0 = (g << 6) + (tile << 5);
+		for (int tile = 0; tile < TPS; ++tile) {
+			const int row0 = (g * TPS + tile) << 5;
 			if (row0 < rows) {
 				// accumulator r of a lane is train row (r & 3) + 8 (r >> 2) + 4 * k-half of the tile: both sets start from the rows' words
 				v16f_t acc0, acc1;
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 #else
 							append(next, h ? hi[u] : lo[u], rawLim);
 #endif
-						if (__any(next > col0 + (CB - 4) * 1024)) { flush(); rawLim = limit(); }
+						if (__any(next > col0 + (CB - 4) * kColStride)) { flush(); rawLim = limit(); }
 					}
 				}
 			}
@@ -400,8 +410,8 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchArgs a) {
 template <int K, int DW>
 static void launch_mfma_kd(const MatchArgs& a, hipStream_t s) {
 	dim3 grid((a.nq + XQ - 1) / XQ, a.splits, a.nsets);
-	if (a.qm && a.tm) hipLaunchKernelGGL((k_match_mfma<K, DW, true>), grid, dim3(256), 0, s, a);
-	else hipLaunchKernelGGL((k_match_mfma<K, DW, false>), grid, dim3(256), 0, s, a);
+	if (a.qm && a.tm) hipLaunchKernelGGL((k_match_mfma<K, DW, true>), grid, dim3(XQ), 0, s, a);
+	else hipLaunchKernelGGL((k_match_mfma<K, DW, false>), grid, dim3(XQ), 0, s, a);
 }
 
 template <int K>
@@ -420,7 +430,7 @@ void match_mfma_scratch(const MatchArgs& a, int tsets, size_t* bytesA, size_t* b
 	const int st = (a.nt + 63) / 64, ns = (a.qm && a.tm ? 2 : 1) * (a.dim / 8);
 	*stages = st;
 	*bytesA = (size_t)tsets * st * 2 * ns * 64 * sizeof(uint4);
-	*bytesW = (size_t)tsets * st * 64 * sizeof(float);
+	*bytesW = ((size_t)tsets * st * 64 + 64) * sizeof(float);   // (a stage's words are fetched 64 at a time)
 }
 bool match_mfma_serves(const MatchArgs& a) { return match_mfma_shape(a) && a.exA && a.exW && a.exRows && a.tsets >= 1; }
 
