@@ -520,6 +520,18 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	for (int v = 0; v <= kHalfPatch; ++v) hd.umax[v] = umax[v];
 	upload_describe_tables(kPattern);
 
+	hd.chainFits = 0; hd.chainRegOff = 0;
+	// One launch for the whole resize chain (k_resize_chain, bit-exact, tests/test_gpu_env_paths.py) is opt-in: measured 0.37 ms alone against 0.22 ms for the
+	// seven launches (its 6912 workgroups pay eight barriers and the small levels run at a quarter of the lanes), default step 2.20 against 2.09 ms.
+	// (Also measured without gain on the seven-launch chain: FAST launched per level as soon as the level exists, 2.11 ms.)
+	if (getenv("MCS_PYR_CHAIN") && !taps.empty()) {
+		std::vector<int> table;
+		if (pyramid_chain_table(hd, taps.data(), &table)) {   // regions of the one-launch resize chain, stored behind the taps (8 bytes per entry)
+			hd.chainFits = 1; hd.chainRegOff = (int)taps.size();
+			taps.resize(taps.size() + (table.size() * sizeof(int) + sizeof(ResizeTap) - 1) / sizeof(ResizeTap));
+			memcpy(taps.data() + hd.chainRegOff, table.data(), table.size() * sizeof(int));
+		}
+	}
 	const size_t B = max_batch;
 #define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) { mcs_extractor_destroy(e); return fail(MCS_ERR_HIP, std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(_e)); } } while (0)
 	ALLOC(e->d_desc, sizeof(PyrDesc));
@@ -711,6 +723,16 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		// when the pyramid is there, and runs the oct-tree.  Both chains leave most of the chip idle on their own.
 		HIPCHK(hipEventRecord(c->evFork, s));
 		HIPCHK(hipStreamWaitEvent(c->side, c->evFork, 0));
+		if (hd.chainFits) {
+			// the resize chain is one launch (k_resize_chain): FAST on level 0 beside it, then FAST on all other levels in one launch beside the blur
+			launch_pyramid(b, hd, nimg, c->side);
+			HIPCHK(hipEventRecord(c->evPyr, c->side));
+			launch_blur(b, hd, nimg, c->side);
+			HIPCHK(hipEventRecord(c->evBlur, c->side));
+			launch_fast(b, hd, nimg, s, 0, 1);
+			HIPCHK(hipStreamWaitEvent(s, c->evPyr, 0));
+			launch_fast(b, hd, nimg, s, 1, hd.nlevels);
+		} else {
 		launch_pyramid(b, hd, nimg, c->side, 1, 2);
 		HIPCHK(hipEventRecord(c->evPyr1, c->side));
 		launch_pyramid(b, hd, nimg, c->side, 2, hd.nlevels);
@@ -722,6 +744,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		launch_fast(b, hd, nimg, s, 1, 2);
 		HIPCHK(hipStreamWaitEvent(s, c->evPyr, 0));
 		launch_fast(b, hd, nimg, s, 2, hd.nlevels);
+		}
 		// (holding the previous step's deferred matcher back until here, so that it runs beside the oct-tree / orientation / descriptor kernels instead of
 		// beside FAST and the resize chain: measured, 2.22 -> 2.55 ms per step — the descriptor kernel on the critical path suffers more from the company)
 		launch_octree(b, hd, nimg, s);   // (oct-trees of levels 0 / 1 on a further stream beside FAST of the rest: measured, no gain)

@@ -2,6 +2,7 @@
 // Written for CDNA4 only (wave64, 160 KiB LDS/CU, 8 XCDs); no other target is supported.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdint.h>
 #include "../../include/mcs_c.h"
 
@@ -47,6 +48,8 @@ struct PyrDesc {
 	int fastRing;           // 16 / 12 / 8: FastFeatureDetector TYPE_9_16 / TYPE_7_12 / TYPE_5_8
 	int descSize, npoints;
 	int umax[kHalfPatch + 1];   // half-width of orientation-disc row |v| (reference :187-202)
+	int chainFits;          // the one-launch resize chain (k_resize_chain) serves this geometry
+	int chainRegOff;        // its region table [tile][8 levels][8 ints], appended to the tap array (offset in tap entries)
 	int mode;               // 0 ORB, 1 dBRIEF, 2 mdBRIEF
 	int undistort;          // do_dBrief (reference gates undistortion on it only, Appendix B.1)
 	LevelInfo lv[MCS_MAX_LEVELS];
@@ -138,6 +141,7 @@ __host__ __device__ inline const uint8_t* level_ptr(const ExtractBuffers& b, con
 
 // kernel launchers (each enqueues on `s`)
 void launch_pyramid(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0 = 1, int level1 = MCS_MAX_LEVELS);
+bool pyramid_chain_table(const PyrDesc& d, const ResizeTap* taps, std::vector<int>* table);
 void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0 = 0, int level1 = MCS_MAX_LEVELS);
 void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0 = 0, int level1 = MCS_MAX_LEVELS);
 void launch_blur(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s);

@@ -140,7 +140,193 @@ __global__ __launch_bounds__(256) void k_resize_level(ExtractBuffers b, int leve
 	}
 }
 
+// ---- the whole chain in one launch ------------------------------------------------------------------------------------------------------------------
+// Seven dependent launches, the small levels latency-bound and each waiting for the previous one's last workgroup, were the longest stretch of the
+// overlapped step (0.7 ms beside FAST for 0.22 ms of work).  k_resize_chain gives one workgroup a 64 x 16 tile of the LAST level and lets it compute, level by
+// level, the region of every level below that the tile depends on: the level-0 footprint is staged in LDS once, level l is computed from the LDS copy of level
+// l - 1 into the other LDS buffer, and written to memory for the part the workgroup OWNS.  Ownership is the tile grid of the last level pushed down through the
+// tap tables (boundary of level l - 1 = tap offset of the boundary of level l, columns rounded down to a multiple of 4 so that every stored dword has one
+// owner); the region a workgroup computes is the hull of what its next level needs and what it owns.  Same integer arithmetic per pixel as k_resize_level.
+// Overlap between neighbouring workgroups' regions (about two pixels per level and side) is computed twice: ~25 % more arithmetic, no extra memory traffic.
+constexpr int FT_W = 64, FT_H = 16;              // tile of the last level
+constexpr int FA_PITCH = 288, FA_ROWS = 72;      // LDS buffer of the even levels (level 0 footprint the largest, 267 x 71 at 1920 x 1080): 20 736 B
+constexpr int FB_PITCH = 232, FB_ROWS = 60;      // odd levels (222 x 59): 13 920 B
+constexpr int FUSED_MAX_W = 256;                 // a computed region is at most 64 column groups of 4 pixels wide
+constexpr int kChainLevels = 8;                  // pyramids of up to 8 levels (the level loops are unrolled: the regions stay in scalar registers)
+
+struct ChainRegion { int xa, xb, ya, yb; int oxs, oxe, oys, oye; };   // computed region (inclusive), owned region [oxs, oxe) x [oys, oye)
+
+// regions of levels top .. 0 for tile (tx, ty) of level `top` (host: the table the kernel reads, [tile][kChainLevels]; evaluated on the device this is a chain of
+// ~30 dependent memory round trips per workgroup — measured 0.6 ms for the launch)
+static void chain_regions(const PyrDesc& d, const ResizeTap* taps, int top, int tx, int ty, int tilesX, int tilesY, ChainRegion* R) {
+	const LevelInfo& T = d.lv[top];
+	ChainRegion r;
+	r.xa = tx * FT_W; r.xb = (tx == tilesX - 1 ? T.w : r.xa + FT_W) - 1;
+	r.ya = ty * FT_H; r.yb = (ty == tilesY - 1 ? T.h : r.ya + FT_H) - 1;
+	r.oxs = r.xa; r.oxe = tx == tilesX - 1 ? (T.w + 3) & ~3 : r.xa + FT_W;
+	r.oys = r.ya; r.oye = r.yb + 1;
+	R[top] = r;
+	for (int l = top; l >= 1; --l) {
+		const LevelInfo& L = d.lv[l];
+		const LevelInfo& P = d.lv[l - 1];
+		const ResizeTap* tapX = taps + L.tabX;
+		const ResizeTap* tapY = taps + L.tabY;
+		const ChainRegion& c = R[l];
+		ChainRegion n;
+		auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+		// what level l's region reads
+		n.xa = tapX[c.xa].ofs; n.xb = clampi(tapX[c.xb < L.w ? c.xb : L.w - 1].ofs + 1, 0, P.w - 1);
+		n.ya = clampi(tapY[c.ya].ofs, 0, P.h - 1); n.yb = clampi(tapY[c.yb].ofs + 1, 0, P.h - 1);
+		// what the workgroup owns of level l - 1
+		n.oxs = tx == 0 ? 0 : (tapX[c.oxs].ofs & ~3);
+		n.oxe = tx == tilesX - 1 ? (P.w + 3) & ~3 : (tapX[c.oxe].ofs & ~3);
+		n.oys = ty == 0 ? 0 : clampi(tapY[c.oys].ofs, 0, P.h - 1);
+		n.oye = ty == tilesY - 1 ? P.h : clampi(tapY[c.oye].ofs, 0, P.h - 1);
+		if (l - 1 >= 1) {   // level 0 is the input: nothing to own, and its footprint need not start on a dword
+			if (n.oxs < n.xa) n.xa = n.oxs;
+			if (n.oxe - 1 > n.xb) n.xb = (n.oxe - 1 < P.w - 1) ? n.oxe - 1 : P.w - 1;
+			if (n.oys < n.ya) n.ya = n.oys;
+			if (n.oye - 1 > n.yb) n.yb = n.oye - 1;
+			n.xa &= ~3;
+		}
+		R[l - 1] = n;
+	}
+}
+
+// The kernel's region table, [tile][kChainLevels] x 8 ints; false if the fused kernel cannot serve this geometry (some region of some tile outside the LDS buffers)
+bool pyramid_chain_table(const PyrDesc& d, const ResizeTap* taps, std::vector<int>* table) {
+	const int top = d.nlevels - 1;
+	if (top < 1 || top >= kChainLevels) return false;
+	const int tilesX = (d.lv[top].w + FT_W - 1) / FT_W, tilesY = (d.lv[top].h + FT_H - 1) / FT_H;
+	table->assign((size_t)tilesX * tilesY * kChainLevels * 8, 0);
+	for (int ty = 0; ty < tilesY; ++ty)
+		for (int tx = 0; tx < tilesX; ++tx) {
+			ChainRegion* R = reinterpret_cast<ChainRegion*>(table->data() + (size_t)(ty * tilesX + tx) * kChainLevels * 8);
+			chain_regions(d, taps, top, tx, ty, tilesX, tilesY, R);
+			for (int l = 0; l <= top; ++l) {
+				const int w = R[l].xb - R[l].xa + 1, h = R[l].yb - R[l].ya + 1;
+				const int pitch = (l & 1) ? FB_PITCH : FA_PITCH, rows = (l & 1) ? FB_ROWS : FA_ROWS;
+				if (w < 1 || h < 1 || w + 8 > pitch || h > rows) return false;   // + 8: dword-rounded width and the weight-0 right neighbour
+				if (l >= 1 && (w > FUSED_MAX_W || h > FB_ROWS)) return false;
+				if (l >= 1 && (R[l].oxs < R[l].xa || R[l].oys < R[l].ya || R[l].oye - 1 > R[l].yb || R[l].oxs > R[l].oxe || R[l].oys > R[l].oye)) return false;
+				if (l >= 1 && ((R[l].oxe - 1 < d.lv[l].w - 1 ? R[l].oxe - 1 : d.lv[l].w - 1) > R[l].xb)) return false;
+			}
+		}
+	return true;
+}
+
+__global__ __launch_bounds__(256) void k_resize_chain(ExtractBuffers b, int tilesX, int tilesY) {
+	__shared__ __attribute__((aligned(16))) uint8_t bufA[FA_ROWS * FA_PITCH];
+	__shared__ __attribute__((aligned(16))) uint8_t bufB[FB_ROWS * FB_PITCH];
+	__shared__ ChainRegion R[kChainLevels];
+	__shared__ ResizeTap tyl[kChainLevels - 1][FB_ROWS];   // row taps of the regions of levels 1..: fetched per row they cost a memory round trip per trip of the row loop
+	const PyrDesc& d = *b.desc;
+	const int top = d.nlevels - 1;
+	const int img = blockIdx.x / (tilesX * tilesY);
+	const int t = blockIdx.x - img * (tilesX * tilesY);
+	const int tid = threadIdx.x;
+	if (tid < kChainLevels * 8) reinterpret_cast<int*>(R)[tid] = reinterpret_cast<const int*>(b.taps + d.chainRegOff)[(size_t)t * (kChainLevels * 8) + tid];
+	__syncthreads();
+	for (int l = 1; l <= top; ++l)
+		if (tid <= R[l].yb - R[l].ya) tyl[l - 1][tid] = (b.taps + d.lv[l].tabY)[R[l].ya + tid];
+	// level 0 footprint -> bufA (dword loads, four per thread in flight; row tails byte-wise)
+	{
+		int sstride;
+		const uint8_t* src = level_ptr(b, d, img, 0, &sstride);
+		const LevelInfo& P = d.lv[0];
+		const int sxa = R[0].xa, sya = R[0].ya, nrows = R[0].yb - R[0].ya + 1, ndw = (R[0].xb - R[0].xa + 1 + 3) >> 2;
+		const unsigned rowM = (1048576u + (unsigned)ndw - 1u) / (unsigned)ndw;   // i / ndw by multiplication: i < 72 * 72, ndw <= 72: i * (M * ndw - 2^20) < i * ndw < 2^20
+		const int ndwTile = nrows * ndw;
+		for (int base = 0; base < ndwTile; base += 4 * 256) {
+			uint32_t sv[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int i = base + u * 256 + tid;
+				const int r = (int)(((unsigned long long)(unsigned)i * rowM) >> 20), k = i - r * ndw;
+				const uint8_t* gp = src + ((unsigned)(sya + r) * (unsigned)sstride + (unsigned)(sxa + 4 * k));
+				uint32_t v = 0;
+				if (i < ndwTile) {
+					if (sxa + 4 * k + 3 < P.w) v = load_u32_unaligned(gp);
+					else
+						for (int e = 0; e < 4; ++e) if (sxa + 4 * k + e < P.w) v |= (uint32_t)gp[e] << (8 * e);
+				}
+				sv[u] = v;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int i = base + u * 256 + tid;
+				const int r = (int)(((unsigned long long)(unsigned)i * rowM) >> 20), k = i - r * ndw;
+				if (i < ndwTile) *reinterpret_cast<uint32_t*>(&bufA[r * FA_PITCH + 4 * k]) = sv[u];
+			}
+		}
+	}
+	__syncthreads();
+	const int cg = tid & 63, rs = tid >> 6;   // column group (4 pixels) and row slot of the thread
+	ResizeTap txn[4];   // the thread's column taps of the next level, requested a phase ahead
+#pragma unroll
+	for (int i = 0; i < 4; ++i) txn[i] = (b.taps + d.lv[1].tabX)[min(R[1].xa + 4 * cg + i, d.lv[1].w - 1)];
+	for (int l = 1; l <= top; ++l) {
+		const LevelInfo& L = d.lv[l];
+		const LevelInfo& P = d.lv[l - 1];
+		const ChainRegion c = R[l], sr = R[l - 1];
+		const uint8_t* sbuf = (l & 1) ? bufA : bufB;   // level l - 1
+		uint8_t* dbuf = (l & 1) ? bufB : bufA;
+		const int sp = (l & 1) ? FA_PITCH : FB_PITCH, dp = (l & 1) ? FB_PITCH : FA_PITCH;
+		const int x4 = c.xa + 4 * cg;
+		ResizeTap txv[4];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) txv[i] = txn[i];
+		if (l < top) {
+			const LevelInfo& N = d.lv[l + 1];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) txn[i] = (b.taps + N.tabX)[min(R[l + 1].xa + 4 * cg + i, N.w - 1)];
+		}
+		if (x4 <= c.xb) {
+			int col[4], col1[4];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				col[i] = txv[i].ofs - sr.xa;
+				col1[i] = col[i] + 1;
+				asm volatile("" : "+v"(col1[i]));   // byte-sized LDS reads (k_resize_level)
+			}
+			uint32_t live = 0;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) live |= (x4 + i < L.w) ? 0xffu << (8 * i) : 0u;
+			uint8_t* dst = b.pyr + (size_t)img * d.pyrBytes + L.off;
+			const bool ownX = x4 >= c.oxs && x4 < c.oxe;
+#pragma unroll 1
+			for (int y = c.ya + rs; y <= c.yb; y += 4) {
+				const ResizeTap tyv = tyl[l - 1][y - c.ya];
+				const int sy0 = min(max((int)tyv.ofs, 0), P.h - 1), sy1 = min(max((int)tyv.ofs + 1, 0), P.h - 1);
+				const uint8_t* r0 = &sbuf[(sy0 - sr.ya) * sp];
+				const uint8_t* r1 = &sbuf[(sy1 - sr.ya) * sp];
+				int p00[4], p01[4], p10[4], p11[4];
+#pragma unroll
+				for (int i = 0; i < 4; ++i) { p00[i] = r0[col[i]]; p01[i] = r0[col1[i]]; p10[i] = r1[col[i]]; p11[i] = r1[col1[i]]; }
+				uint32_t packed = 0;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int t0 = p00[i] * txv[i].a0 + p01[i] * txv[i].a1;
+					const int t1 = p10[i] * txv[i].a0 + p11[i] * txv[i].a1;
+					const int v = ((((int)tyv.a0 * (t0 >> 4)) >> 16) + (((int)tyv.a1 * (t1 >> 4)) >> 16) + 2) >> 2;
+					packed |= (uint32_t)(v & 0xff) << (8 * i);
+				}
+				packed &= live;
+				if (l < top) *reinterpret_cast<uint32_t*>(&dbuf[(y - c.ya) * dp + 4 * cg]) = packed;
+				if (ownX && y >= c.oys && y < c.oye) *reinterpret_cast<uint32_t*>(dst + (unsigned)y * (unsigned)L.stride + (unsigned)x4) = packed;
+			}
+		}
+		__syncthreads();
+	}
+}
+
 void launch_pyramid(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0, int level1) {   // levels [level0, level1), level0 >= 1
+	if (level0 <= 1 && level1 >= hd.nlevels && hd.chainFits && hd.nlevels > 1) {
+		const int top = hd.nlevels - 1;
+		const int tilesX = (hd.lv[top].w + FT_W - 1) / FT_W, tilesY = (hd.lv[top].h + FT_H - 1) / FT_H;
+		hipLaunchKernelGGL(k_resize_chain, dim3(nimg * tilesX * tilesY), dim3(256), 0, s, b, tilesX, tilesY);
+		return;
+	}
 	for (int level = level0 < 1 ? 1 : level0; level < hd.nlevels && level < level1; ++level) {
 		const LevelInfo& L = hd.lv[level];
 		const int tilesX = (L.w + PT_W - 1) / PT_W, tilesY = (L.h + PT_H - 1) / PT_H;
