@@ -192,7 +192,8 @@ def pmc_entry(tag, dom):
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         ks = t["workloads"][tag]["kernels"]
         # "keypoints" = the keypoint stage: oct-tree + orientation (its tail), keypoint records / rays, descriptors
-        parts = [ks[n] for n in (("octree", "orient_a", "orient_b", "describe", "describe_list", "describe_exact") if dom == "keypoints" else (dom,)) if n in ks]
+        doms = ("octree", "orient_a", "orient_b", "describe", "describe_list", "describe_exact") if dom == "keypoints" else ("match", "match_expand") if dom == "match" else (dom,)
+        parts = [ks[n] for n in doms if n in ks]
         if not parts:
             return None, None
         return int(sum(k["fetch_kib"] + k["write_kib"] for k in parts) * 1024), sum(k.get("valu_insts", 0) for k in parts)

@@ -265,13 +265,8 @@ int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
 	else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownStream = true; }
 	HIPCHK(hipMalloc(&c->dscalar, 64));
 	if (getenv("MCS_NO_OVERLAP") == nullptr) {
-		// (stream priorities — resize chain urgent, deferred matcher least urgent, and every other combination — change nothing measurable: 2.32 ms either way)
+		// (stream priorities — resize chain urgent, deferred matcher least urgent or most urgent, and every other combination — change nothing measurable)
 		HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-		if (getenv("MCS_SIDE2_PRIO")) {
-			int least = 0, greatest = 0;
-			HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-			HIPCHK(hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, atoi(getenv("MCS_SIDE2_PRIO")) > 0 ? greatest : least));
-		} else
 		HIPCHK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
 
 		HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
