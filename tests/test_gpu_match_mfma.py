@@ -101,3 +101,33 @@ def test_valid_flags_and_ragged_sizes(G):
         _check(G, qd, td, 8, qm, tm, qv, tv)
     tv0 = np.zeros(1500, np.uint8)   # no eligible train row at all
     _check(G, qd, td, 8, qm, tm, None, tv0)
+
+
+def test_train_set_size_at_the_index_range_boundary(G):
+    """the matrix-core form carries the train index in 14 fraction bits of a float: 16 384 rows are its largest set (index 16 383 must survive the round trip
+    through the float key, also as a tie-breaker), 16 385 rows go to the v_bcnt kernel — same lists either way"""
+    rng = np.random.default_rng(23)
+    for nt in (16384, 16385):
+        td = rng.integers(0, 256, (nt, 32)).astype(np.uint8)
+        tm = rng.integers(0, 256, (nt, 32)).astype(np.uint8)
+        td[-3:] = td[0]; tm[-3:] = tm[0]                      # the last rows tie with row 0: order by index decides
+        qd = np.concatenate([td[[0, nt - 1, nt // 2]], rng.integers(0, 256, (67, 32)).astype(np.uint8)])
+        qm = np.concatenate([tm[[0, nt - 1, nt // 2]], rng.integers(0, 256, (67, 32)).astype(np.uint8)])
+        _check(G, qd, td, 32, qm, tm)
+        _check(G, qd, td, 4)
+
+
+def test_eligible_row_counts_around_the_stage_size(G):
+    """the train sets' pass compacts eligible rows into 64-row stages: 0, 1, 63, 64, 65, 128 eligible rows among 300, and all of 256 / 257 (workgroup boundary of the pass)"""
+    rng = np.random.default_rng(29)
+    td = rng.integers(0, 256, (300, 32)).astype(np.uint8)
+    tm = rng.integers(0, 256, (300, 32)).astype(np.uint8)
+    qd = td[rng.integers(0, 300, 90)] ^ (rng.integers(0, 256, (90, 32)) & rng.integers(0, 256, (90, 32)) & 3).astype(np.uint8)
+    qm = rng.integers(0, 256, (90, 32)).astype(np.uint8)
+    for n in (0, 1, 63, 64, 65, 128):
+        tv = np.zeros(300, np.uint8)
+        tv[rng.permutation(300)[:n]] = 1
+        _check(G, qd, td, 8, qm, tm, None, tv)
+    for nt in (256, 257):
+        _check(G, qd, td[:nt], 8, qm, tm[:nt])
+        _check(G, qd, td[:nt], 8, qm, tm[:nt], None, np.ones(nt, np.uint8))
