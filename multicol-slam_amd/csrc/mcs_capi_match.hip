@@ -152,7 +152,11 @@ static int run_topk(mcs_ctx* c, const DevSets& d, const SetGrid& sg, const mcs_d
 	c->tic("match");
 	static const bool valuOnly = getenv("MCS_MATCH_VALU") != nullptr;
 	if (deferred) {
-		if (!valuOnly && match_mfma_serves(a)) { launch_match_expand(a, c->stream); a.exDone = 1; }
+		if (!valuOnly && match_mfma_serves(a)) {
+			// the previous deferred search (other stream) may still read the expanded sets: order the pass behind it (in a pipelined caller it finished long ago)
+			if (c->searchSeq > 0) HIPCHK(hipStreamWaitEvent(c->stream, c->evSearch[(c->searchSeq - 1) & 3], 0));
+			launch_match_expand(a, c->stream); a.exDone = 1;
+		}
 		HIPCHK(hipEventRecord(c->evMatch, c->stream));
 		HIPCHK(hipStreamWaitEvent(ls, c->evMatch, 0));
 	}
