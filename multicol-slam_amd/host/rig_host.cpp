@@ -223,6 +223,7 @@ static void rank_main(const Job& J, int rank, ncclComm_t comm) {
 
 int main(int argc, char** argv) {
 	if (argc < 2) { fprintf(stderr, "usage: rig_host <config>\n"); return 1; }
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);   // before the first HIP call: streams that share a hardware queue run in order (the exchange would stall the extraction stream)
 	auto cfg = read_config(argv[1]);
 	auto geti = [&](const char* k, int def) { return cfg.count(k) ? atoi(cfg[k].c_str()) : def; };
 	Job J;
