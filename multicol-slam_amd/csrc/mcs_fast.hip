@@ -175,6 +175,47 @@ __device__ __forceinline__ int fast_score(const uint8_t* c /* centre in LDS tile
 	return best > t ? best - 1 : 0;
 }
 
+// The same score for TWO survivors at once, one in each half of packed 16-bit lanes (differences fit 9 bits): the min / max network is issued once for the pair
+// (v_pk_min_i16 / v_pk_max_i16 cost what the 32-bit forms cost), so a cell's ~150 survivors take one trip of the workgroup instead of two, the second a sixth full.
+template <int kTilePitch>
+__device__ __forceinline__ uint32_t fast_score2(const uint8_t* ca, const uint8_t* cb, int t) {
+	auto pk = [&](int off) { return as_v2s((uint32_t)ca[off] | ((uint32_t)cb[off] << 16)); };
+	const v2s v = pk(0);
+	v2s d[16];
+	d[0] = v - pk(3 * kTilePitch);
+	d[8] = v - pk(-3 * kTilePitch);
+	d[4] = v - pk(3);
+	d[12] = v - pk(-3);
+	d[1] = v - pk(3 * kTilePitch + 1);
+	d[2] = v - pk(2 * kTilePitch + 2);
+	d[3] = v - pk(1 * kTilePitch + 3);
+	d[5] = v - pk(-1 * kTilePitch + 3);
+	d[6] = v - pk(-2 * kTilePitch + 2);
+	d[7] = v - pk(-3 * kTilePitch + 1);
+	d[9] = v - pk(-3 * kTilePitch - 1);
+	d[10] = v - pk(-2 * kTilePitch - 2);
+	d[11] = v - pk(-1 * kTilePitch - 3);
+	d[13] = v - pk(1 * kTilePitch - 3);
+	d[14] = v - pk(2 * kTilePitch - 2);
+	d[15] = v - pk(3 * kTilePitch - 1);
+	v2s lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+	for (int k = 0; k < 16; ++k) { lo2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]); hi2[k] = __builtin_elementwise_max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+	for (int k = 0; k < 16; ++k) { lo4[k] = __builtin_elementwise_min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = __builtin_elementwise_max(hi2[k], hi2[(k + 2) & 15]); }
+	v2s A = {-256, -256}, Bn = {256, 256};
+#pragma unroll
+	for (int k = 0; k < 16; ++k) {
+		const v2s lo9 = __builtin_elementwise_min(__builtin_elementwise_min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+		const v2s hi9 = __builtin_elementwise_max(__builtin_elementwise_max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+		A = __builtin_elementwise_max(A, lo9);
+		Bn = __builtin_elementwise_min(Bn, hi9);
+	}
+	const v2s best = __builtin_elementwise_max(A, -Bn);
+	const int ba = best.x, bb = best.y;
+	return (uint32_t)(ba > t ? ba - 1 : 0) | ((uint32_t)(bb > t ? bb - 1 : 0) << 8);
+}
+
 template <int CW, int kFastBS, int P>   // P = ring size: 16 (TYPE_9_16), 12 (TYPE_7_12), 8 (TYPE_5_8)
 __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd, int cell0, int ncells) {
 	typedef FastGeom<CW> Geo;
@@ -283,6 +324,15 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	}
 	__syncthreads();
 	const int ns = nSurv;
+	if constexpr (P == 16) {
+		for (int i = 2 * tid; i < ns; i += 2 * kFastBS) {
+			const int pa = surv[i], pb = surv[i + 1 < ns ? i + 1 : i];
+			const int ya = (int)(((unsigned)pa * divM) >> 18), xa = pa - ya * cw, yb = (int)(((unsigned)pb * divM) >> 18), xb = pb - yb * cw;
+			const uint32_t s2 = fast_score2<kTilePitch>(&tile[(ya + 3) * kTilePitch + xa + Geo::kTileX], &tile[(yb + 3) * kTilePitch + xb + Geo::kTileX], t);
+			sc[(ya + 1) * kScPitch + xa + 1] = (uint8_t)s2;
+			if (i + 1 < ns) sc[(yb + 1) * kScPitch + xb + 1] = (uint8_t)(s2 >> 8);
+		}
+	} else
 	for (int i = tid; i < ns; i += kFastBS) {
 		const int p = surv[i];
 		const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
