@@ -30,9 +30,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # HIP streams share a small pool of hardware queues (4 by default), and streams on one queue run in order: with the context's three streams, torch's and RCCL's
-# the exchange kernels of the N > 1 step landed on the main stream's queue and stalled it (2.28 -> 2.16 ms per step at world size 1 with 8 queues; N = 1 unchanged).
-# Read by the HIP runtime at its first call; a host application sets it the same way.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the exchange kernels of the N > 1 step landed on the main stream's queue and stalled it (2.28 -> 2.16 ms per step with 8 queues, measured at world size 1 with
+# --exchange nccl1).  Only for the multi-process runs: which streams share a queue is the runtime's choice, and in the N = 1 default run — more streams: the e2e
+# leg's two copy streams — 8 queues measured WORSE for the e2e leg (3.2 against 2.4 ms) and for the exchange_world1 leg (2.9 against 2.35); the headline is 2.08 ms
+# either way.  Read by the HIP runtime at its first call; a host application sets it the same way.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
