@@ -268,6 +268,9 @@ int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
 		// (stream priorities — resize chain urgent, deferred matcher least urgent or most urgent, and every other combination — change nothing measurable)
 		HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
 		HIPCHK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
+		HIPCHK(hipStreamCreateWithFlags(&c->side3, hipStreamNonBlocking));
+		HIPCHK(hipEventCreateWithFlags(&c->evLists, hipEventDisableTiming));
+		for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&c->evGreedyBuf[i], hipEventDisableTiming));
 
 		HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&c->evPyr1, hipEventDisableTiming));
@@ -294,7 +297,7 @@ int mcs_ctx_join(mcs_ctx* c) {
 int mcs_ctx_set_async_search(mcs_ctx* c, int on) {
 	if (!c) return fail(MCS_ERR_INVALID, "null ctx");
 	HIPCHK(hipStreamSynchronize(c->stream));
-	if (c->side2) HIPCHK(hipStreamSynchronize(c->side2));
+	if (c->side2) { HIPCHK(hipStreamSynchronize(c->side2)); HIPCHK(hipStreamSynchronize(c->side3)); }
 	c->asyncSearch = on != 0 && c->side2 != nullptr;
 	return MCS_OK;
 }
@@ -315,11 +318,13 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 	while (!c->extractors.empty()) (void)mcs_extractor_destroy(c->extractors.back());   // an extractor must not outlive the stream it runs on
 	for (auto& kv : c->timers) { if (kv.second.a) { (void)hipEventDestroy(kv.second.a); (void)hipEventDestroy(kv.second.b); } }
 	(void)hipFree(c->partial); (void)hipFree(c->partialCount); (void)hipFree(c->stage); (void)hipFree(c->dscalar);
-	(void)hipFree(c->topKeys); (void)hipFree(c->topCnt); (void)hipFree(c->exA); (void)hipFree(c->exW); (void)hipFree(c->exRows); (void)hipFree(c->stageOut); (void)hipFree(c->arena); if (c->pinned) (void)hipHostFree(c->pinned);
+	(void)hipFree(c->topKeys); (void)hipFree(c->topKeys2); (void)hipFree(c->topCnt); (void)hipFree(c->exA); (void)hipFree(c->exW); (void)hipFree(c->exRows); (void)hipFree(c->stageOut); (void)hipFree(c->arena); if (c->pinned) (void)hipHostFree(c->pinned);
 	if (c->side) {
 		(void)hipStreamSynchronize(c->side);
 		(void)hipStreamSynchronize(c->side2);
 		(void)hipStreamDestroy(c->side2);
+		(void)hipStreamSynchronize(c->side3); (void)hipStreamDestroy(c->side3);
+		(void)hipEventDestroy(c->evLists); (void)hipEventDestroy(c->evGreedyBuf[0]); (void)hipEventDestroy(c->evGreedyBuf[1]);
 		for (int i = 0; i < 4; ++i) if (c->evSearch[i]) (void)hipEventDestroy(c->evSearch[i]);
 		(void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evPyr1); (void)hipEventDestroy(c->evPyr); (void)hipEventDestroy(c->evBlur); (void)hipEventDestroy(c->evMatch); (void)hipEventDestroy(c->evGreedy);
 		(void)hipEventDestroy(c->evDescFork); (void)hipEventDestroy(c->evDescJoin);
@@ -333,7 +338,7 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 int mcs_ctx_synchronize(mcs_ctx* c) {
 	if (!c) return fail(MCS_ERR_INVALID, "null ctx");
 	HIPCHK(hipStreamSynchronize(c->stream));
-	if (c->side) { HIPCHK(hipStreamSynchronize(c->side)); HIPCHK(hipStreamSynchronize(c->side2)); c->greedyPending = false; }
+	if (c->side) { HIPCHK(hipStreamSynchronize(c->side)); HIPCHK(hipStreamSynchronize(c->side2)); HIPCHK(hipStreamSynchronize(c->side3)); c->greedyPending = false; }
 	return MCS_OK;
 }
 

@@ -105,7 +105,7 @@ static int stage_sets(mcs_ctx* c, const SetGrid& sg, const mcs_desc_set* q, size
 }
 
 static int run_topk(mcs_ctx* c, const DevSets& d, const SetGrid& sg, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, int dim,
-                    int K, int count_thresh, int max_dist, int* outDist, int* outIdx, int* outCount, hipStream_t ls = nullptr) {
+                    int K, int count_thresh, int max_dist, int* outDist, int* outIdx, int* outCount, hipStream_t ls = nullptr, int slot = 0) {
 	MatchArgs a{};
 	const int nsets = sg.nsets;
 	a.maxDist = max_dist;
@@ -115,8 +115,8 @@ static int run_topk(mcs_ctx* c, const DevSets& d, const SetGrid& sg, const mcs_d
 	const bool deferred = ls != nullptr;
 	if (!deferred) ls = c->stream;
 	if (!deferred && c->side && c->greedyPending) { HIPCHK(hipStreamWaitEvent(c->stream, c->evGreedy, 0)); c->greedyPending = false; }
-	if (int r = ensure((void**)&c->topKeys, &c->topKeysCap, std::max<size_t>((size_t)nsets * q->n, 1) * K * sizeof(uint32_t))) return r;
-	a.keys = c->topKeys;
+	if (int r = ensure((void**)(slot ? &c->topKeys2 : &c->topKeys), slot ? &c->topKeys2Cap : &c->topKeysCap, std::max<size_t>((size_t)nsets * q->n, 1) * K * sizeof(uint32_t))) return r;
+	a.keys = slot ? c->topKeys2 : c->topKeys;
 	a.qd = d.qd; a.qm = d.qm; a.qvalid = d.qvalid; a.qgroup = d.qgroup; a.td = d.td; a.tm = d.tm; a.tvalid = d.tvalid; a.tgroup = d.tgroup;
 	a.nq = q->n; a.nt = t->n; a.qstride = q->stride; a.tstride = t->stride; a.qpitch = qpitch; a.tpitch = tpitch;
 	a.nsets = nsets; a.qmod = sg.qmod; a.tdiv = sg.tdiv; a.dim = dim; a.K = K; a.countThresh = count_thresh;
@@ -153,14 +153,16 @@ static int run_topk(mcs_ctx* c, const DevSets& d, const SetGrid& sg, const mcs_d
 	static const bool valuOnly = getenv("MCS_MATCH_VALU") != nullptr;
 	if (deferred) {
 		if (!valuOnly && match_mfma_serves(a)) {
-			// the previous deferred search (other stream) may still read the expanded sets: order the pass behind it (in a pipelined caller it finished long ago)
-			if (c->searchSeq > 0) HIPCHK(hipStreamWaitEvent(c->stream, c->evSearch[(c->searchSeq - 1) & 3], 0));
+			// the previous deferred search's LISTS (other stream) may still read the expanded sets: order the pass behind them (in a pipelined caller they finished long ago)
+			if (c->searchSeq > 0) HIPCHK(hipStreamWaitEvent(c->stream, c->evLists, 0));
 			launch_match_expand(a, c->stream); a.exDone = 1;
 		}
 		HIPCHK(hipEventRecord(c->evMatch, c->stream));
 		HIPCHK(hipStreamWaitEvent(ls, c->evMatch, 0));
+		if (c->searchSeq > 1) HIPCHK(hipStreamWaitEvent(ls, c->evGreedyBuf[slot], 0));   // the greedy pass that read this list buffer (two searches ago)
 	}
 	launch_match(a, ls);
+	if (deferred) HIPCHK(hipEventRecord(c->evLists, ls));
 	c->toc("match");
 	HIPCHK(hipGetLastError());
 	return MCS_OK;
@@ -223,6 +225,9 @@ static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc
 	if (int r = stage_sets(c, sg, q, qpitch, t, tpitch, kind, &d, mode == 2 ? &rays1 : nullptr, mode == 2 ? &rays2 : nullptr,
 	                       mode == 2 ? &E : nullptr, Epitch * (size_t)(nsets - 1) + (size_t)nrCams * nrCams * 9)) return r;
 	const size_t rows = (size_t)nsets * q->n;
+	// deferred: two list buffers in turn, the greedy pass on a stream of its own — it is a chain of dependent round trips with a few waves per CU, the matcher waits
+	// 45 % of its cycles: side by side (greedy pass of search n, lists of search n + 1) the greedy pass disappears from the matcher stream's critical path
+	const int slot = deferred ? (int)(c->searchSeq & 1) : 0;
 	if (int r = ensure((void**)&c->topCnt, &c->topCntCap, std::max<size_t>(rows, 1) * 4)) return r;
 	{
 		// Rows that can never influence a decision stay out of the lists: SearchByBoW needs best <= TH_LOW and, for the ratio
@@ -231,12 +236,12 @@ static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc
 		int maxDist = thLow;
 		if (mode != 2) while (maxDist < 8 * dim && nnratio * static_cast<double>(maxDist + 1) <= static_cast<double>(thLow)) ++maxDist;
 		if (q->n > 0)
-			if (int r = run_topk(c, d, sg, q, qpitch, t, tpitch, dim, K, -1, maxDist, nullptr, nullptr, c->topCnt, deferred ? c->side2 : nullptr)) return r;
+			if (int r = run_topk(c, d, sg, q, qpitch, t, tpitch, dim, K, -1, maxDist, nullptr, nullptr, c->topCnt, deferred ? c->side2 : nullptr, slot)) return r;
 	}
 	GreedyArgs g{};
 	g.qd = d.qd; g.qm = d.qm; g.qvalid = d.qvalid; g.qgroup = d.qgroup; g.td = d.td; g.tm = d.tm; g.tvalid = d.tvalid; g.tgroup = d.tgroup;
 	g.nq = q->n; g.nt = t->n; g.qstride = q->stride; g.tstride = t->stride; g.qpitch = qpitch; g.tpitch = tpitch;
-	g.nsets = nsets; g.qmod = sg.qmod; g.tdiv = sg.tdiv; g.dim = dim; g.K = K; g.keys = c->topKeys;
+	g.nsets = nsets; g.qmod = sg.qmod; g.tdiv = sg.tdiv; g.dim = dim; g.K = K; g.keys = slot ? c->topKeys2 : c->topKeys;
 	g.qblk = q->block_rows; g.qbpitch = (size_t)q->block_pitch_rows; g.tblk = t->block_rows; g.tbpitch = (size_t)t->block_pitch_rows;
 	g.toff = sg.toff; g.tmod = sg.tmod;
 	g.thLow = thLow; g.thInclusive = mode == 1 ? 1 : 0; g.ratio = nnratio; g.mode = mode;
@@ -245,9 +250,12 @@ static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc
 	if (kind == MCS_MEM_DEVICE) {
 		g.outMatch = out_match; g.outCount = out_nmatches; g.outFallbacks = out_fallbacks;
 		if (deferred) {
-			launch_greedy(g, c->side2);
-			HIPCHK(hipEventRecord(c->evGreedy, c->side2));
-			HIPCHK(hipEventRecord(c->evSearch[c->searchSeq & 3], c->side2));
+			if (q->n > 0) HIPCHK(hipStreamWaitEvent(c->side3, c->evLists, 0));
+			else HIPCHK(hipStreamWaitEvent(c->side3, c->evMatch, 0));
+			launch_greedy(g, c->side3);
+			HIPCHK(hipEventRecord(c->evGreedyBuf[slot], c->side3));
+			HIPCHK(hipEventRecord(c->evGreedy, c->side3));
+			HIPCHK(hipEventRecord(c->evSearch[c->searchSeq & 3], c->side3));
 			++c->searchSeq;
 			c->greedyPending = true;
 		} else if (c->overlap()) {

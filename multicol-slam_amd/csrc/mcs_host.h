@@ -35,6 +35,7 @@ struct mcs_ctx {
 	uint8_t* stage = nullptr; size_t stageCap = 0;   // host-kind staging for the matcher
 	int* dscalar = nullptr;
 	uint32_t* topKeys = nullptr; size_t topKeysCap = 0;   // packed [set][K][nq] top-K lists feeding the greedy kernels
+	uint32_t* topKeys2 = nullptr; size_t topKeys2Cap = 0; // second list buffer of the deferred searches: the greedy pass of search n reads one while the matcher of search n + 1 fills the other
 	int* topCnt = nullptr; size_t topCntCap = 0;
 	uint8_t* exA = nullptr; size_t exACap = 0;            // train sets expanded to matrix-core operands (mcs_match_mfma.hip), per call
 	uint8_t* exW = nullptr; size_t exWCap = 0;
@@ -45,6 +46,8 @@ struct mcs_ctx {
 	// Second HIP stream for the latency-bound / independent kernels (blur next to FAST+oct-tree, the greedy resolution next to the
 	// following batch's extraction): they leave most CUs idle, so overlapping them with the VALU-bound kernels is free throughput.
 	hipStream_t side = nullptr;    // extraction fork: resize chain + blur beside FAST + oct-tree
+	hipStream_t side3 = nullptr;   // deferred searches: the greedy pass, beside the next search's lists on side2
+	hipEvent_t evLists = nullptr, evGreedyBuf[2] = {nullptr, nullptr};   // lists of the latest deferred search complete / the greedy pass that read list buffer i complete
 	hipStream_t side2 = nullptr;   // the greedy match resolution (its own stream: it must not hold up the next batch's resize chain)
 	hipEvent_t evFork = nullptr, evPyr1 = nullptr, evPyr = nullptr, evBlur = nullptr, evMatch = nullptr, evGreedy = nullptr;
 	hipEvent_t evDescFork = nullptr, evDescJoin = nullptr;   // the exact descriptor pass over the pre-list on `side`, beside the fast pass
