@@ -10,9 +10,10 @@
 // (tools/mfma_fp4_probe.hip pins the operand and result layout used here on the device.)
 //
 // Workgroup = 4 waves, 64 queries per wave as two 32-column operand sets (B operand lane = column + 32 * k-half; 4 VGPRs per K step and set, in
-// registers for the whole kernel).  Train rows are staged like in mcs_match.hip (eligible rows only, compacted in order), then expanded bit -> nibble
-// through a 256-entry LDS table into the A-operand layout [tile of 32 rows][K step][lane] so that every wave's operand read is one conflict-free
-// ds_read_b128, used for both query sets.  An MFMA result puts 16 of a column's 32 rows in lane c and the other 16 in lane c + 32; one
+// registers for the whole kernel).  The train sets are prepared ONCE per call by k_expand_train (eligible rows only, compacted in order, expanded bit ->
+// nibble through a 256-entry LDS table into the A-operand layout [stage of 64 rows][tile of 32][K step][lane]); the list kernel copies a stage at a time into
+// LDS with global_load_lds, where every wave's operand read is one conflict-free ds_read_b128, used for both query sets (round 2 staged, compacted and expanded
+// the rows in every workgroup: two thirds of its time).  An MFMA result puts 16 of a column's 32 rows in lane c and the other 16 in lane c + 32; one
 // v_permlane32_swap per register between the two sets' results leaves lane c with all 32 rows of query c of the first set and lane c + 32 with all 32
 // rows of query c of the second: ONE query per lane, so its K-best list sees every train row (two half lists per query appended 1.7x as many
 // candidates, and merged as often).
@@ -49,7 +50,7 @@ constexpr int XQ = 64 * WGW;      // queries per workgroup
 constexpr int kColStride = XQ * 4;   // bytes between the slots of a lane's candidate column
 // Words in the candidate columns are BIASED: dot + ct + 256 (+ index / 2^14), i.e. the total minus the query's own cq (<= 256) plus 256 — never negative —
 // so that cq costs nothing per pair: it is subtracted from the limit once per group and added back when a column is merged.  The f32 dot product of any
-// staged row (real or stale bits, always 0 / +-1 operands) lies in [-512, 512], so a padding row's word (kPadWord) ends in [2560, 3584]: never below a
+// staged row (real rows; the rest of a set's last stage holds zero operands) lies in [-512, 512], so a padding row's word (kPadWord) ends in [2560, 3584]: never below a
 // biased limit (<= kLimCap + 256 = 2560); real totals (<= 512) stay below kLimCap.
 constexpr float kPadWord = 3072.f, kIdxUnit = 1.f / 16384.f;
 constexpr uint32_t kLimCap = 0x900u, kBias = 256u;
