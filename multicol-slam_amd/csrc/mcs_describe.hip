@@ -894,7 +894,7 @@ static void launch_fast_passes(const ExtractBuffers& b, int nimg, int wavesPerIm
 	int fblocks = (ngroups + groupsPerBlock - 1) / groupsPerBlock;
 	if (fblocks >= kNumXCD) fblocks = (fblocks + kNumXCD - 1) / kNumXCD * kNumXCD;   // whole XCD rounds: the kernel's block -> group mapping is XCD-contiguous
 	const size_t fLds = (size_t)kFastWaves * kPatchBytes + kGTabDoubles * sizeof(double);
-	(void)hipMemsetAsync(b.fbCount, 0, 2 * sizeof(int), s);   // fbCount and preCount are neighbours
+	// (fbCount and preCount — neighbours — were cleared by k_octree's first workgroup)
 	hipLaunchKernelGGL((k_orient_b<MODE>), dim3((nslots + 255) / 256), dim3(256), 0, s, b, wavesPerImage, nslots);
 	// the pre-list (about one keypoint in a hundred: the ones next to the optical axis) through the exact pass BESIDE the fast pass
 	hipStream_t ps = b.sideStream ? b.sideStream : s;

@@ -77,6 +77,9 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int 
 	const LevelInfo& Lv = d.lv[level];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int N = Lv.nfeat;
+	// the two exact-pass list counters of the descriptor stage start every batch at zero: cleared here (the previous batch's list kernels are done — stream order —,
+	// k_orient_b, their first writer, comes after this kernel) instead of by a memset launch of their own on the critical path
+	if (blockIdx.x == 0 && tid == 0 && b.fbCount) { b.fbCount[0] = 0; b.fbCount[1] = 0; }
 
 	uint32_t* denseG = b.dense + (size_t)img * d.densePerImage + Lv.denseBase;
 	unsigned short* knodeG = b.knode + (size_t)img * d.densePerImage + Lv.denseBase;
