@@ -36,6 +36,8 @@ sys.path.insert(0, ROOT)
 # either way.  Read by the HIP runtime at its first call; a host application sets it the same way.
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# multi-process GPU work on these hosts needs dmabuf IPC (without it RCCL fails with hipIpcGetMemHandle: invalid argument); exported on the boxes, kept here for a bare environment
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 
