@@ -313,7 +313,8 @@ void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStre
 	const int nl = level1 - level0;
 	int need = 0;
 	for (int l = 0; l < hd.nlevels; ++l) need = need > hd.lv[l].nfeat + 3 ? need : hd.lv[l].nfeat + 3, need = need > 4 * hd.lv[l].nIni ? need : 4 * hd.lv[l].nIni;
-	if (need <= 512) hipLaunchKernelGGL((k_octree<512, 3072>), dim3(nimg * nl), dim3(256), 0, s, b, nimg, level0);   // 50 KB LDS: 3 workgroups per CU
+	if (need <= 256) hipLaunchKernelGGL((k_octree<256, 2048>), dim3(nimg * nl), dim3(256), 0, s, b, nimg, level0);   // N = 1000 over 8 levels needs 220 nodes: 29 KB LDS, five workgroups per CU (0.195 -> 0.162 ms; key cache 3072: four per CU, 0.175; 1536: 0.176)
+	else if (need <= 512) hipLaunchKernelGGL((k_octree<512, 3072>), dim3(nimg * nl), dim3(256), 0, s, b, nimg, level0);   // 50 KB LDS: 3 workgroups per CU
 	else hipLaunchKernelGGL((k_octree<1024, 2048>), dim3(nimg * nl), dim3(256), 0, s, b, nimg, level0);
 }
 
