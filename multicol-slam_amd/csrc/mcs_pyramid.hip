@@ -22,6 +22,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
 	return v;
 }
 
+__attribute__((amdgpu_waves_per_eu(8, 8)))   // 64 registers: eight workgroups per CU (the compiler's own choice: 67, seven)
 __global__ __launch_bounds__(256) void k_resize_level(ExtractBuffers b, int level, int tilesX, int tilesY) {
 	__shared__ __attribute__((aligned(16))) uint8_t src_t[PS_ROWS * PS_PITCH];
 	const PyrDesc& d = *b.desc;
