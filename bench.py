@@ -78,6 +78,37 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+def free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks here (one process per GPU, torch.distributed.run on 127.0.0.1 with a free port) and hand
+    back their exit code; rank 0 of the children prints the JSON line on our stdout.  The reference's own split is one worker per camera of a multi-frame
+    (`#pragma omp parallel for num_threads(nrCams)`, /root/reference/src/cMultiFrame.cpp:128-164); here one process per GPU."""
+    import subprocess
+    if os.environ.get("MCS_BENCH_SHARE_GPU") != "1":    # before any rank starts: N ranks need N GPUs (the ranks check again, each for itself)
+        import torch
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible (MCS_BENCH_SHARE_GPU=1 runs the ranks on one GPU over gloo: a functional run, not a "
+                             "measurement)" % (args.gpus, torch.cuda.device_count()))
+    env = dict(os.environ)
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")            # see the note at the top of this file: the exchange needs hardware queues of its own
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["MCS_BENCH_LAUNCHED"] = "1"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -97,7 +128,7 @@ def torch_empty_like_cpu(t):
     return torch.empty(t.shape, dtype=t.dtype)
 
 
-def setup():
+def setup(args):
     import torch
     import torch.distributed as dist
     e = Env()
@@ -109,6 +140,12 @@ def setup():
     e.share = os.environ.get("MCS_BENCH_SHARE_GPU") == "1"
     if e.share:
         e.local = 0
+    # refuse to lie: the line's n_gpus is the number of ranks that ran, and it must be what --gpus asked for, each rank on a GPU of its own
+    if e.world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (launch with --nproc-per-node %d, or let bench.py start the ranks itself)" % (args.gpus, e.world, args.gpus))
+    if not e.share and torch.cuda.device_count() < max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible (MCS_BENCH_SHARE_GPU=1 runs the ranks on one GPU over gloo: a functional run, not a measurement)"
+                         % (args.gpus, torch.cuda.device_count()))
     e.backend = None
     e.exchange = e.world > 1          # the step runs the exchange (send buffer -> all-gather -> late matching); world 1 normally has nothing to exchange
     if e.world > 1:
@@ -527,6 +564,7 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True, check=True):
     rescans = int(b.fb.sum().item())
     elapsed_max, feats_all = e.rig.reduce_timing(elapsed, feats_local, e.red_dev, e.world)
     _, pairs_all = e.rig.reduce_timing(elapsed, pairs_local, e.red_dev, e.world)
+    elapsed_min = -e.rig.reduce_timing(-elapsed, 0, e.red_dev, e.world)[0]   # the fastest rank (max of the negated times)
     checked = check_against_oracle(e, sp, job) if (check and e.rank == 0) else None   # before the per-kernel passes: the output of the timed configuration
     kern = kernel_times(e, job.step) if want_roofline else None   # every rank: step() contains the collective
     roof = roofline_block(sp, job, kern, feats_local, pairs_local) if (want_roofline and e.rank == 0) else None
@@ -540,6 +578,9 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True, check=True):
            "matches_per_step_rank0": matches, "greedy_rescans_rank0": rescans, "topk": sp.topk, "stored_keyframes": sp.D,
            "descriptor_exact_pass_keypoints_per_step_rank0": exact_kp,
            "n_ranks": e.world, "collective_backend": e.backend, "tag": sp.tag,
+           "ms_per_step_slowest_rank": round(elapsed_max / steps * 1e3, 4), "ms_per_step_fastest_rank": round(elapsed_min / steps * 1e3, 4),
+           "exchange_bytes_received_per_rank_per_step": (0 if not e.exchange else job.ring.bytes_received(e.rank) if job.ring else job.lay.send_bytes * (e.world - 1)),
+           "ranks_share_one_gpu": bool(e.share),
            "parallelism": ("single GPU, no collective" if not e.exchange else
                            ("camera-major image slabs x%d + 1 point-to-point exchange per step of the camera blocks of this rank's frames and one predecessor "
                             "(%d KiB received per rank; the all-gather would deliver %d KiB) + frame pairs sharded x%d"
@@ -786,7 +827,9 @@ def secondary_args(args, **kw):
 
 def main():
     args = parse()
-    e = setup()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    e = setup(args)
     if args.exchange == "nccl1":
         force_exchange_world1(e)
     sp = Spec(args, e.world)
@@ -825,8 +868,9 @@ def main():
             j3.close()
             out["exchange_world1"] = {k: o3[k] for k in ("value", "unit", "steps", "ms_per_step", "oracle_check") if k in o3}
             out["exchange_world1"]["parallelism"] = o3["config"]["parallelism"]
-            out["exchange_world1"]["what"] = ("the N > 1 step (send buffer -> asynchronous all_gather_into_tensor on RCCL -> work.wait() -> row flags -> matching one "
-                                              "step late, three buffer sets) at world size 1, backend nccl")
+            out["exchange_world1"]["what"] = ("the N > 1 step of configs[1] (send buffer -> asynchronous point-to-point batch on RCCL, at world size 1 a self send / receive of "
+                                              "this rank's own camera blocks -> wait -> row flags -> matching one step late, three buffer sets) at world size 1, backend "
+                                              "nccl; the sweeps' all_gather_into_tensor form runs at world size 1 in tests/test_gpu_bench_jobs.py")
             checks.append(o3.get("oracle_check"))
         except Exception as ex:   # an environment without a usable RCCL is reported, not hidden; a wrong RESULT is a failed check above
             out["exchange_world1"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}

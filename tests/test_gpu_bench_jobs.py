@@ -73,3 +73,37 @@ def test_default_run_checks_every_leg():
     assert out["cpu_baseline"]["reference_threading"]["cores"] == 3
     for k in ("roofline", "cpu_baseline"):
         assert out[k]
+
+
+@pytest.mark.parametrize("n,args", [(2, []), (3, ["--workload", "db", "--frames", "4"])])
+def test_gpus_n_starts_n_ranks_by_itself(n, args):
+    """`python bench.py --gpus N` with no launcher around it starts N ranks (here on one shared GPU over gloo: a functional run of the N > 1 step) and rank 0
+    prints ONE line with n_gpus = N; the split is the reference's per-camera one (src/cMultiFrame.cpp:128-164) over ranks"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MCS_BENCH_SHARE_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-secondary", *args],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == n and cfg["n_ranks"] == n and cfg["collective_backend"] == "gloo" and cfg["ranks_share_one_gpu"] is True
+    assert out["oracle_check"] is True and cfg["oracle_checked"]["pairs"] >= 1
+    assert cfg["exchange_bytes_received_per_rank_per_step"] > 0
+    assert 0 < cfg["ms_per_step_fastest_rank"] <= cfg["ms_per_step_slowest_rank"] == out["ms_per_step"]
+
+
+def test_gpus_n_without_n_gpus_is_refused():
+    """more ranks asked for than GPUs visible (and no MCS_BENCH_SHARE_GPU): non-zero exit, no JSON line"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MCS_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    n = 9   # no node of this pool has more than 8
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "GPU(s) visible" in p.stderr
