@@ -86,6 +86,82 @@ __global__ __launch_bounds__(256) void k(double* out, int iters) {
 #pragma unroll
 				for (int j = 0; j < 4; ++j) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(f[j]) : "v"(f[(j + 1) & 3]));
 			}
+			if (MODE == 22) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(u[j]) : "v"(u[(j + 1) & 7]), "v"(u[(j + 2) & 7]));
+			}
+			if (MODE == 23) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(u[j]) : "v"(u[(j + 1) & 7]), "v"(u[(j + 2) & 7]));
+			}
+			if (MODE == 24) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[j]) : "v"(u[(j + 1) & 7]), "v"(u[(j + 2) & 7]));
+			}
+			if (MODE == 25) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 26) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_sad_u8 %0, %1, %2, %0" : "+v"(u[j]) : "v"(u[(j + 1) & 7]), "v"(u[(j + 2) & 7]));
+			}
+			if (MODE == 27) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_alignbyte_b32 %0, %0, %1, 1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 28) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[j]) : "v"(u[(j + 1) & 7]), "v"(u[(j + 2) & 7]));
+			}
+			if (MODE == 29) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_lshrrev_b32 %0, 4, %0" : "+v"(u[j]));
+			}
+			if (MODE == 30) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(u[j]));
+			}
+			if (MODE == 31) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 32) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 33) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 34) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_and_b32 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 35) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 36) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[j]) : "v"(u[(j + 1) & 7]) : "vcc");
+			}
+			if (MODE == 37) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_max_u32 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 38) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(u[j]) : "v"(u[(j + 1) & 7]), "v"(u[(j + 2) & 7]));
+			}
+			if (MODE == 39) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+			}
+			if (MODE == 40) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(u[j]) : "v"(u[(j + 1) & 7]), "v"(u[(j + 2) & 7]));
+			}
 			if (MODE == 8) {                                                                                                  // 8 independent FP64 mul
 #pragma unroll
 				for (int j = 0; j < 8; ++j) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(f[j]) : "v"(c));
@@ -140,5 +216,24 @@ int main() {
 	run<19>("8 independent v_pk_min_i16", 8, d);
 	run<20>("8 independent v_min_i32", 8, d);
 	run<21>("4 independent v_lshl_add_u64", 4, d);
+	run<22>("8 independent v_dot4_u32_u8", 8, d);
+	run<23>("8 independent v_dot2_u32_u16", 8, d);
+	run<24>("8 independent v_perm_b32", 8, d);
+	run<25>("8 independent v_mul_hi_u32_u24", 8, d);
+	run<26>("8 independent v_sad_u8", 8, d);
+	run<27>("8 independent v_alignbyte_b32", 8, d);
+	run<28>("8 independent v_add3_u32", 8, d);
+	run<29>("8 independent v_lshrrev_b32", 8, d);
+	run<30>("8 independent v_bfe_u32", 8, d);
+	run<31>("8 independent v_add_u32_sdwa", 8, d);
+	run<32>("8 independent v_sub_u32", 8, d);
+	run<33>("8 independent v_mul_hi_u32", 8, d);
+	run<34>("8 independent v_and_b32", 8, d);
+	run<35>("8 independent v_pk_add_u16", 8, d);
+	run<36>("8 independent v_cmp_gt_u32+v_cndmask", 16, d);
+	run<37>("8 independent v_max_u32", 8, d);
+	run<38>("8 independent v_max3_u32", 8, d);
+	run<39>("8 independent v_pk_max_u16", 8, d);
+	run<40>("8 independent v_med3_i32", 8, d);
 	return 0;
 }
