@@ -475,6 +475,10 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 				ResizeTap t{(short)sx, sat_short((1.f - fx) * 2048), sat_short(fx * 2048), 0};
 				taps.push_back(t);
 			}
+			// k_resize_cols: every group of four adjacent columns must read within 8 adjacent source bytes (any scale factor up to 2), rows per thread <= 64
+			L.colsOk = P.w >= 8 && L.h >= 1;
+			for (int dx = 0; dx < L.w; dx += 4)
+				if (taps[L.tabX + std::min(dx + 3, L.w - 1)].ofs - taps[L.tabX + dx].ofs > 6) L.colsOk = 0;
 			L.tabY = (int)taps.size();
 			for (int dy = 0; dy < L.h; dy++) {
 				float fy = (float)((dy + 0.5) * scale_y - 0.5);
@@ -483,7 +487,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 				ResizeTap t{(short)sy, sat_short((1.f - fy) * 2048), sat_short(fy * 2048), 0};
 				taps.push_back(t);
 			}
-		} else L.tabY = L.tabX;
+		} else { L.tabY = L.tabX; L.colsOk = 0; }
 		L.mapX = (int)maps.size();
 		for (int x = 0; x < L.w; ++x) {
 			if (l == 0) maps.push_back((short)x);

@@ -33,6 +33,7 @@ struct LevelInfo {
 	int rootX[kMaxRoots + 1];
 	double hX;
 	int tabX, tabY;         // offsets of this level's resize tables (from level-1), in entries
+	int colsOk;             // the column-marching resize kernel serves this level (four adjacent columns read <= 8 adjacent source bytes)
 	int mapX, mapY;         // offsets of this level's composed nearest-neighbour maps to level-0 mask coordinates
 	float scale;            // (float)mvScaleFactor[level]
 	float kpSize;           // (float)(int)(PATCH_SIZE*mvScaleFactor[level])

@@ -9,6 +9,7 @@
 // loads (row segments start 4-byte aligned in LDS; global addresses may be unaligned for level 0, which gfx950 global
 // loads support), every thread then emits 4 adjacent destination pixels as one dword store.
 #include "mcs_common.h"
+#include <type_traits>
 
 namespace mcs {
 
@@ -139,6 +140,116 @@ __global__ __launch_bounds__(256) void k_resize_level(ExtractBuffers b, int leve
 			});
 		}
 	}
+}
+
+// ---- round 4: column-marching resize, no LDS, no barrier ------------------------------------------------------------------------------------------
+// A THREAD owns 4 adjacent destination columns of one image and streams down the SOURCE rows its block of destination rows reads: per source row one
+// unaligned 8-byte load (the <= 8 source bytes its four columns touch), per column one v_perm_b32 (the two neighbours as a 16-bit pair) and one
+// v_dot2_u32_u16 against the packed coefficients (a0 | a1 << 16) — the horizontal interpolation is done ONCE per source row (the tile kernel redid both rows for
+// every destination row).  A destination row is emitted when its second source row arrives: two v_mul_hi_u32 per pixel against b << 16 (= (b * (T >> 4)) >> 16
+// exactly), add, shift, pack.  A WAVE holds 64 consecutive (image, column group) items of one block of destination rows, so the row bookkeeping (taps, clipping,
+// which rows to emit) is scalar; the row taps sit one per lane and are read with v_readlane.  Same integer arithmetic as above (reference:
+// src/mdBRIEFextractorOct.cpp:1158-1201 -> cv::resize INTER_LINEAR).  Serves every level whose four-column source span fits 8 bytes
+// (LevelInfo.colsOk: every scale factor up to 2); k_resize_level stays for the rest.
+constexpr int kColsAhead = 3;      // source rows requested ahead of the one being interpolated (ring of 4)
+
+__global__ __launch_bounds__(256) void k_resize_cols(ExtractBuffers b, int level, int wavesX, int rows, int ncg, int nimg, int totalWaves) {
+	const PyrDesc& d = *b.desc;
+	const LevelInfo& L = d.lv[level];
+	const LevelInfo& P = d.lv[level - 1];
+	const int w = L.w, h = L.h, sw = P.w, sh = P.h, dstride = L.stride, pyrBytes = d.pyrBytes, loff = L.off;   // read before the first store
+	const ResizeTap* tapX = b.taps + L.tabX;
+	const ResizeTap* tapY = b.taps + L.tabY;
+	const int blk = (blockIdx.x & (kNumXCD - 1)) * (gridDim.x / kNumXCD) + (blockIdx.x / kNumXCD);   // XCD-contiguous wave order (k_blur)
+	const int wave = __builtin_amdgcn_readfirstlane(blk * 4 + (threadIdx.x >> 6));
+	if (wave >= totalWaves) return;
+	const int rb = wave / wavesX, wx = wave - rb * wavesX;
+	const int y0 = rb * rows;
+	const int nrows = min(rows, h - y0);
+	const int lane = threadIdx.x & 63;
+	const int items = nimg * ncg;
+	const int item0 = wx * 64;
+	const int item = min(item0 + lane, items - 1);   // lanes past the last item repeat it: the same bytes to the same addresses
+	const int img = item / ncg, cg = item - img * ncg;
+	const int img0 = item0 / ncg;
+	const int x = cg * 4;
+	int sstride;
+	const uint8_t* src = level_ptr(b, d, img0, level - 1, &sstride);
+	const size_t simg = level == 1 ? b.img0Pitch : (size_t)pyrBytes;
+	uint8_t* dst = b.pyr + (size_t)img0 * pyrBytes + loff;
+	// column taps: the thread's 8 source bytes start at A; column i reads bytes ofs_i - A and ofs_i + 1 - A of them (the right neighbour past the row has weight 0)
+	ResizeTap tx[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) tx[i] = tapX[min(x + i, w - 1)];
+	const int A = min((int)tx[0].ofs, sw - 8);
+	uint32_t sel[4], wt[4], liveMask = 0;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const uint32_t c0 = (uint32_t)(tx[i].ofs - A) & 7u, c1 = (uint32_t)(min(tx[i].ofs + 1, sw - 1) - A) & 7u;
+		sel[i] = c0 | 0x0c00u | (c1 << 16) | 0x0c000000u;
+		wt[i] = (uint32_t)(unsigned short)tx[i].a0 | ((uint32_t)(unsigned short)tx[i].a1 << 16);
+		liveMask |= (x + i < w) ? 0xffu << (8 * i) : 0u;   // bytes past the level's width are row padding, stored as 0
+	}
+	uint32_t voffS = (uint32_t)((size_t)(img - img0) * simg) + (uint32_t)A;
+	uint32_t voffD = (uint32_t)((size_t)(img - img0) * (size_t)pyrBytes) + (uint32_t)x;
+	// row taps of the block, one per lane
+	uint32_t tyA, tyB;
+	{
+		const uint2 t = *reinterpret_cast<const uint2*>(&tapY[min(y0 + lane, h - 1)]);
+		tyA = t.x; tyB = t.y;   // ofs | a0 << 16,  a1 | pad << 16
+	}
+	auto clipRow = [&](int r) { return min(max(r, 0), sh - 1); };
+	const int rs = clipRow((int)(short)(__builtin_amdgcn_readlane(tyA, 0) & 0xffff));
+	const int re = clipRow((int)(short)(__builtin_amdgcn_readlane(tyA, nrows - 1) & 0xffff) + 1);
+	auto loadRow = [&](int r) -> uint2 {
+		asm volatile("" : "+v"(voffS));   // opaque per call: SGPR row base + 32-bit lane offset (k_blur)
+		uint2 v;
+		__builtin_memcpy(&v, src + (size_t)((unsigned)min(r, re) * (unsigned)sstride) + voffS, 8);
+		return v;
+	};
+	uint2 raw[4];
+#pragma unroll
+	for (int k = 0; k < kColsAhead; ++k) raw[k] = loadRow(rs + k);
+	uint32_t T[2][4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) T[0][i] = T[1][i] = 0;
+	int yi = 0;                      // next destination row of the block
+	int sy = (int)(short)(__builtin_amdgcn_readlane(tyA, 0) & 0xffff);
+	auto emit = [&](const uint32_t* T0, const uint32_t* T1) {
+		const uint32_t b0 = __builtin_amdgcn_readlane(tyA, yi) & 0xffff0000u;          // a0 << 16
+		const uint32_t b1 = __builtin_amdgcn_readlane(tyB, yi) << 16;                  // a1 << 16
+		uint32_t v[4];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) v[i] = (__umulhi(T0[i], b0) + __umulhi(T1[i], b1) + 2u) >> 2;
+		const uint32_t out = (v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24)) & liveMask;
+		asm volatile("" : "+v"(voffD));
+		*reinterpret_cast<uint32_t*>(dst + (size_t)((unsigned)(y0 + yi) * (unsigned)dstride) + voffD) = out;   // row pitch is a multiple of 64: the tail dword stays in-pitch
+	};
+	// one source row: request row r + 3, interpolate row r horizontally into T[K & 1], emit the destination rows whose second source row it is
+	auto body = [&](int r, auto kc) {
+		constexpr int K = decltype(kc)::value;
+		raw[(K + kColsAhead) % 4] = loadRow(r + kColsAhead);
+		uint32_t* cur = T[K & 1];
+		const uint32_t* prev = T[(K & 1) ^ 1];
+		typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			cur[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(raw[K].y, raw[K].x, sel[i])), __builtin_bit_cast(us2, wt[i]), 0u, false) >> 4;
+		while (yi < nrows && clipRow(sy + 1) == r) {
+			if (clipRow(sy) == r) emit(cur, cur);       // both source rows clipped to the same one (first / last row of the level)
+			else emit(prev, cur);
+			++yi;
+			sy = (int)(short)(__builtin_amdgcn_readlane(tyA, min(yi, nrows - 1)) & 0xffff);
+		}
+	};
+	int r = rs;
+	for (; r + 3 <= re; r += 4) {
+		body(r, std::integral_constant<int, 0>()); body(r + 1, std::integral_constant<int, 1>());
+		body(r + 2, std::integral_constant<int, 2>()); body(r + 3, std::integral_constant<int, 3>());
+	}
+	if (r <= re) body(r, std::integral_constant<int, 0>());
+	if (r + 1 <= re) body(r + 1, std::integral_constant<int, 1>());
+	if (r + 2 <= re) body(r + 2, std::integral_constant<int, 2>());
 }
 
 // ---- the whole chain in one launch ------------------------------------------------------------------------------------------------------------------
@@ -328,8 +439,19 @@ void launch_pyramid(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStr
 		hipLaunchKernelGGL(k_resize_chain, dim3(nimg * tilesX * tilesY), dim3(256), 0, s, b, tilesX, tilesY);
 		return;
 	}
+	static const bool tileOnly = getenv("MCS_PYR_TILES") != nullptr;   // A/B: the LDS tile kernel for every level
 	for (int level = level0 < 1 ? 1 : level0; level < hd.nlevels && level < level1; ++level) {
 		const LevelInfo& L = hd.lv[level];
+		if (L.colsOk && !tileOnly) {
+			const int ncg = (L.w + 3) / 4, wavesX = (nimg * ncg + 63) / 64;
+			// rows per thread: 32 where that still gives the chip a few thousand waves, fewer on the small levels (each block re-reads ~2 source rows)
+			int nrb = (L.h + 31) / 32;
+			while (wavesX * nrb < 4096 && (L.h + nrb - 1) / nrb > 8) ++nrb;
+			const int rows = (L.h + nrb - 1) / nrb;
+			const int waves = wavesX * ((L.h + rows - 1) / rows);
+			hipLaunchKernelGGL(k_resize_cols, dim3(((waves + 3) / 4 + kNumXCD - 1) / kNumXCD * kNumXCD), dim3(256), 0, s, b, level, wavesX, rows, ncg, nimg, waves);
+			continue;
+		}
 		const int tilesX = (L.w + PT_W - 1) / PT_W, tilesY = (L.h + PT_H - 1) / PT_H;
 		hipLaunchKernelGGL(k_resize_level, dim3(nimg * tilesX * tilesY), dim3(256), 0, s, b, level, tilesX, tilesY);
 	}
