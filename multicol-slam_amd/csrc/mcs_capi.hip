@@ -442,6 +442,10 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 				c.cw = skip ? 0 : (short)std::max(0, (int)maxX - (int)iniX - 6);
 				c.ch = skip ? 0 : (short)std::max(0, (int)maxY - (int)iniY - 6);
 				c.slot = slotBase + (i * L.nCols + j) * L.capc;
+				{   // k_fast_cells: tile row = cw + 4 + 3 bytes in dwords, 4-pixel groups per row
+					const int ndw = (c.cw + 4 + 3 + 3) >> 2, gpr = std::max((c.cw + 3) >> 2, 1);
+					c.rowM = (65536 + ndw - 1) / ndw; c.grpM = (65536 + gpr - 1) / gpr;
+				}
 				e->cells.push_back(c);
 			}
 		cellBase += L.nCols * L.nRows;

@@ -56,7 +56,8 @@ struct PyrDesc {
 	LevelInfo lv[MCS_MAX_LEVELS];
 };
 
-struct CellInfo { short level; short x0, y0; short cw, ch; short pad; int slot; };  // processed region [x0,x0+cw) x [y0,y0+ch) in level ROI coords
+struct CellInfo { short level; short x0, y0; short cw, ch; short pad; int slot; int rowM, grpM; };  // processed region [x0,x0+cw) x [y0,y0+ch) in level ROI coords;
+// rowM = ceil(2^16 / dwords per staged tile row), grpM = ceil(2^16 / 4-pixel groups per row): the FAST kernel's divisions by multiplication
 
 // bilinear resize tables (Appendix A.1), one entry per destination column / row of a level
 struct ResizeTap { short ofs; short a0; short a1; short pad; };

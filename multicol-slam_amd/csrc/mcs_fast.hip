@@ -15,6 +15,8 @@
 #include "mcs_common.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace mcs {
 
@@ -28,7 +30,6 @@ template <int CW> struct FastGeom {
 	static constexpr int kTileX = 4;   // tile column of the cell's first processed pixel: a 4-byte left margin (3 ring pixels + 1), so that groups of 4 pixels are aligned dwords
 	static constexpr int kTilePitch = (CW + kTileX + 3 + 4 + 3) / 4 * 4, kTileRows = CW + 6;   // + 4: the packed compass test reads one dword past the right ring
 	static constexpr int kScPitch = (CW + 2 + 3) / 4 * 4, kScRows = CW + 2;
-	static constexpr int kBitWords = (CW * CW + 63) / 64 * 2, kGroups = (CW * CW + 63) / 64;
 };
 
 // ---- the two small rings (FastFeatureDetector TYPE_7_12 / TYPE_5_8, reference src/mdBRIEFextractorOct.cpp:869-872) -------------------------------------
@@ -109,33 +110,33 @@ __device__ __forceinline__ bool fast_quick(const uint8_t* c, int t) {
 	return (h0 & h4) | (h4 & h8) | (h8 & h12) | (h12 & h0) | (l0 & l4) | (l4 & l8) | (l8 & l12) | (l12 & l0);
 }
 
-// The same test for 4 horizontally adjacent pixels at once (an aligned group of the tile row): five aligned LDS dwords instead of 20 byte reads, the
-// differences as packed 16-bit pairs (v_pk_sub_i16 / v_pk_min_i16 / v_pk_max_i16).  With d = centre - ring pixel: two adjacent compass points darker
-// <=> min(d_a, d_b) > t, brighter <=> min(-d_a, -d_b) > t, so pass <=> max over the four adjacent pairs of max(min(d_a, d_b), -max(d_a, d_b)) > t.
-// Returns bit j = pixel 4g + j passes.
+// The same test for 4 horizontally adjacent pixels at once (an aligned group of the tile row): five aligned LDS dwords, the bytes spread into packed 16-bit
+// pairs by v_perm_b32 (pixels 0 | 2 and 1 | 3).  Any of {0, 8} is adjacent to any of {4, 12}, so "two adjacent compass points darker" is
+//   max(min(r0, r8), min(r4, r12)) < v - t      (the smaller of each opposite pair must both be dark <=> ... written on the ring values r, no differences)
+// and brighter is  min(max(r0, r8), max(r4, r12)) > v + t:  six packed min / max, two packed subtractions, one min whose SIGN BITS are the verdicts.
+// Returns the verdicts of pixels 0, 1, 2, 3 in bits 0, 1, 16, 17.
 typedef short v2s __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2s as_v2s(uint32_t x) { union { uint32_t u; v2s v; } c; c.u = x; return c.v; }
+__device__ __forceinline__ uint32_t as_u32(v2s x) { union { uint32_t u; v2s v; } c; c.v = x; return c.u; }
 template <int kTilePitch>
-__device__ __forceinline__ int fast_quick4(const uint8_t* rowc /* tile row of the centres, at the group's first pixel (4-aligned) */, int t) {
+__device__ __forceinline__ uint32_t fast_quick4(const uint8_t* rowc /* tile row of the centres, at the group's first pixel (4-aligned) */, v2s tt /* t in both halves */) {
 	const uint32_t A = *reinterpret_cast<const uint32_t*>(rowc - 4), Cc = *reinterpret_cast<const uint32_t*>(rowc), B = *reinterpret_cast<const uint32_t*>(rowc + 4);
 	const uint32_t U = *reinterpret_cast<const uint32_t*>(rowc - 3 * kTilePitch), D = *reinterpret_cast<const uint32_t*>(rowc + 3 * kTilePitch);
-	const uint32_t Lf = __builtin_amdgcn_alignbyte(Cc, A, 1);   // the pixels 3 to the left of each centre:  A[1] A[2] A[3] C[0]
-	const uint32_t Rt = __builtin_amdgcn_alignbyte(B, Cc, 3);   // 3 to the right:                           C[3] B[0] B[1] B[2]
-	int bits = 0;
+	uint32_t sign[2];
 #pragma unroll
-	for (int h = 0; h < 2; ++h) {   // h = 0: bytes 0 and 2 of every dword, h = 1: bytes 1 and 3
-		const uint32_t m = 0x00FF00FFu;
-		const v2s v = as_v2s((Cc >> (8 * h)) & m);
-		const v2s d0 = v - as_v2s((D >> (8 * h)) & m), d8 = v - as_v2s((U >> (8 * h)) & m), d4 = v - as_v2s((Rt >> (8 * h)) & m), d12 = v - as_v2s((Lf >> (8 * h)) & m);
-		const v2s lo = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(d0, d4), __builtin_elementwise_min(d4, d8)),
-		                                         __builtin_elementwise_max(__builtin_elementwise_min(d8, d12), __builtin_elementwise_min(d12, d0)));
-		const v2s hi = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(d0, d4), __builtin_elementwise_max(d4, d8)),
-		                                         __builtin_elementwise_min(__builtin_elementwise_max(d8, d12), __builtin_elementwise_max(d12, d0)));
-		const v2s best = __builtin_elementwise_max(lo, -hi);
-		bits |= (best.x > t ? 1 : 0) << h;
-		bits |= (best.y > t ? 1 : 0) << (2 + h);
+	for (int h = 0; h < 2; ++h) {   // h = 0: pixels 0 and 2, h = 1: pixels 1 and 3.  v_perm_b32(s0, s1, sel): selector 0-3 = byte of s1, 4-7 = byte of s0, 0x0c = zero
+		const uint32_t own = h ? 0x0c030c01u : 0x0c020c00u;
+		const v2s v = as_v2s(__builtin_amdgcn_perm(0u, Cc, own));
+		const v2s r0 = as_v2s(__builtin_amdgcn_perm(0u, D, own)), r8 = as_v2s(__builtin_amdgcn_perm(0u, U, own));
+		const v2s r4 = as_v2s(__builtin_amdgcn_perm(B, Cc, h ? 0x0c060c04u : 0x0c050c03u));    // 3 to the right of pixel j: C[3] B[0] B[1] B[2]
+		const v2s r12 = as_v2s(__builtin_amdgcn_perm(Cc, A, h ? 0x0c040c02u : 0x0c030c01u));   // 3 to the left:            A[1] A[2] A[3] C[0]
+		const v2s m1 = __builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12));
+		const v2s m2 = __builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12));
+		const v2s dark = m1 - (v - tt);      // < 0 <=> two adjacent compass points are darker than v - t
+		const v2s bright = (v + tt) - m2;    // < 0 <=> ... brighter than v + t
+		sign[h] = as_u32(__builtin_elementwise_min(dark, bright));
 	}
-	return bits;
+	return ((sign[0] >> 15) & 0x00010001u) | ((sign[1] >> 14) & 0x00020002u);
 }
 
 template <int kTilePitch>
@@ -175,11 +176,14 @@ __device__ __forceinline__ int fast_score(const uint8_t* c /* centre in LDS tile
 	return best > t ? best - 1 : 0;
 }
 
-// The same score for TWO survivors at once, one in each half of packed 16-bit lanes (differences fit 9 bits): the min / max network is issued once for the pair
-// (v_pk_min_i16 / v_pk_max_i16 cost what the 32-bit forms cost), so a cell's ~150 survivors take one trip of the workgroup instead of two, the second a sixth full.
+// The same score for TWO survivors at once, one in each half of packed 16-bit lanes (differences fit 9 bits; v_pk_min_i16 / v_pk_max_i16 cost what the 32-bit
+// forms cost).  The arcs are taken in pairs like cv::cornerScore does: with a_k = min d[k+1 .. k+8] for EVEN k, the arc from k is min(d[k], a_k) and
+// the arc from k + 1 is min(a_k, d[k+9]), so  A = max over even k of min(a_k, max(d[k], d[k+9]))  — only the eight windows that start on an odd index are needed
+// (three levels of eight packed minima), and the same with min / max exchanged for the brighter side: 110 packed operations per pair where all sixteen
+// windows of both kinds took 176.
 template <int kTilePitch>
 __device__ __forceinline__ uint32_t fast_score2(const uint8_t* ca, const uint8_t* cb, int t) {
-	auto pk = [&](int off) { return as_v2s((uint32_t)ca[off] | ((uint32_t)cb[off] << 16)); };
+	auto pk = [&](int off) { v2s r; r.x = (short)ca[off]; r.y = (short)cb[off]; return r; };
 	const v2s v = pk(0);
 	v2s d[16];
 	d[0] = v - pk(3 * kTilePitch);
@@ -198,42 +202,55 @@ __device__ __forceinline__ uint32_t fast_score2(const uint8_t* ca, const uint8_t
 	d[13] = v - pk(1 * kTilePitch - 3);
 	d[14] = v - pk(2 * kTilePitch - 2);
 	d[15] = v - pk(3 * kTilePitch - 1);
-	v2s lo2[16], hi2[16], lo4[16], hi4[16];
+	v2s lo2[8], hi2[8], lo4[8], hi4[8];   // windows starting at the odd index 2j + 1
 #pragma unroll
-	for (int k = 0; k < 16; ++k) { lo2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]); hi2[k] = __builtin_elementwise_max(d[k], d[(k + 1) & 15]); }
+	for (int j = 0; j < 8; ++j) { lo2[j] = __builtin_elementwise_min(d[2 * j + 1], d[(2 * j + 2) & 15]); hi2[j] = __builtin_elementwise_max(d[2 * j + 1], d[(2 * j + 2) & 15]); }
 #pragma unroll
-	for (int k = 0; k < 16; ++k) { lo4[k] = __builtin_elementwise_min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = __builtin_elementwise_max(hi2[k], hi2[(k + 2) & 15]); }
+	for (int j = 0; j < 8; ++j) { lo4[j] = __builtin_elementwise_min(lo2[j], lo2[(j + 1) & 7]); hi4[j] = __builtin_elementwise_max(hi2[j], hi2[(j + 1) & 7]); }
 	v2s A = {-256, -256}, Bn = {256, 256};
 #pragma unroll
-	for (int k = 0; k < 16; ++k) {
-		const v2s lo9 = __builtin_elementwise_min(__builtin_elementwise_min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-		const v2s hi9 = __builtin_elementwise_max(__builtin_elementwise_max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-		A = __builtin_elementwise_max(A, lo9);
-		Bn = __builtin_elementwise_min(Bn, hi9);
+	for (int j = 0; j < 8; ++j) {   // k = 2j: a_k = min d[k+1 .. k+8] = the 8-window from odd index 2j + 1
+		const v2s a = __builtin_elementwise_min(lo4[j], lo4[(j + 2) & 7]), bb = __builtin_elementwise_max(hi4[j], hi4[(j + 2) & 7]);
+		const v2s e0 = d[2 * j], e9 = d[(2 * j + 9) & 15];
+		A = __builtin_elementwise_max(A, __builtin_elementwise_min(a, __builtin_elementwise_max(e0, e9)));
+		Bn = __builtin_elementwise_min(Bn, __builtin_elementwise_max(bb, __builtin_elementwise_min(e0, e9)));
 	}
 	const v2s best = __builtin_elementwise_max(A, -Bn);
 	const int ba = best.x, bb = best.y;
 	return (uint32_t)(ba > t ? ba - 1 : 0) | ((uint32_t)(bb > t ? bb - 1 : 0) << 8);
 }
 
+// inclusive prefix sum over the 64 lanes of a wave on the VALU data-parallel-primitive path (no LDS round trips): four row_shr steps inside the rows of 16, then
+// row_bcast:15 / row_bcast:31 carry the row totals
+__device__ __forceinline__ int wave_incl_scan(int x) {
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+	return x;
+}
+
+// A pixel of the cell is named by its code  row << 6 | column  (cells are at most 60 wide): row-major order, and the row / column come back with a shift and a mask.
 template <int CW, int kFastBS, int P>   // P = ring size: 16 (TYPE_9_16), 12 (TYPE_7_12), 8 (TYPE_5_8)
-__global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd, int cell0, int ncells) {
+__global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd, int cell0, int ncells, unsigned ncellsM) {
 	typedef FastGeom<CW> Geo;
 	constexpr int kTilePitch = Geo::kTilePitch, kTileRows = Geo::kTileRows, kScPitch = Geo::kScPitch, kScRows = Geo::kScRows;
 	__shared__ __attribute__((aligned(16))) uint8_t tile[kTileRows * kTilePitch];
 	__shared__ __attribute__((aligned(16))) uint8_t sc[kScRows * kScPitch];
-	__shared__ uint32_t keepBits[Geo::kBitWords];   // NMS + mask verdict per pixel of the cell (row-major bit index)
-	__shared__ int groupOff[64];         // exclusive prefix of the kept-pixel counts per 64-pixel group
+	__shared__ uint32_t keepBits[2 * CW];   // NMS + mask verdict per pixel of the cell: two words per row, bit = column
+	__shared__ int rowOff[64];           // exclusive prefix of the kept-pixel counts per row
 	__shared__ int runBase;
 	__shared__ int nSurv;
-	__shared__ unsigned short surv[CW * CW];   // pixel indices that pass the compass test
+	__shared__ unsigned short surv[CW * CW];   // codes of the pixels that pass the compass test
 
 	// XCD-aware mapping: hardware places block i on XCD i%8; give every XCD a contiguous run of cells so that the
 	// overlapping cell rings / shared cache lines of neighbouring cells hit the same L2.
 	const int logical = (blockIdx.x % kNumXCD) * perXcd + blockIdx.x / kNumXCD;
 	if (logical >= nblocks) return;
 	const PyrDesc& d = *b.desc;
-	const int img = logical / ncells;                  // this launch covers cells [cell0, cell0 + ncells) of every image (a range of pyramid levels)
+	const int img = (int)__umulhi((unsigned)logical, ncellsM);   // logical / ncells (launch_fast checks the multiplier's range); this launch covers cells [cell0, cell0 + ncells) of every image
 	const int ci = cell0 + (logical - img * ncells);
 	const CellInfo cell = b.cells[ci];
 	const LevelInfo& L = d.lv[cell.level];
@@ -247,9 +264,9 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	src += (size_t)(cell.y0 - 3) * stride + (cell.x0 - Geo::kTileX);
 	const int tw = cw + Geo::kTileX + 3, th = ch + 6;
 	const int ndw = (tw + 3) >> 2;   // unaligned dword loads; the <= 3 bytes of over-read per row stay inside the image row
-	// i / ndw by multiplication: ndw <= 17 and i < 17 * 66, so with M = ceil(2^16 / ndw) the error term i * (M*ndw - 2^16) < 2^16 and
+	// i / ndw by multiplication (CellInfo.rowM = ceil(2^16 / ndw)): ndw <= 17 and i < 17 * 66, so the error term i * (M*ndw - 2^16) < 2^16 and
 	// (i * M) >> 16 is exact; 32-bit offsets keep the address arithmetic out of 64-bit multiplies.
-	const unsigned rowM = (65536u + (unsigned)ndw - 1u) / (unsigned)ndw;
+	const unsigned rowM = (unsigned)cell.rowM;
 	// two dwords per thread and trip (a ~30x30 cell is 370 dwords: one trip): both loads are in flight before the first LDS store waits
 	const int ndwTile = ndw * th;
 	for (int i = tid; i < ndwTile; i += 2 * kFastBS) {
@@ -263,71 +280,70 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 		*reinterpret_cast<uint32_t*>(&tile[ty * kTilePitch + 4 * kx]) = v;
 		if (has2) *reinterpret_cast<uint32_t*>(&tile[ty2 * kTilePitch + 4 * kx2]) = v2;
 	}
-	const int sw = cw + 2, sh = ch + 2;
+	const int sh = ch + 2;
 	for (int i = tid; i < sh * (kScPitch / 4); i += kFastBS) reinterpret_cast<uint32_t*>(sc)[i] = 0;   // score tile cleared as dwords
-	for (int i = tid; i < Geo::kBitWords; i += kFastBS) keepBits[i] = 0;
+	for (int i = tid; i < 2 * ch; i += kFastBS) keepBits[i] = 0;
 	if (tid == 0) { runBase = 0; nSurv = 0; }
 	__syncthreads();
 
 	const int t = d.fastThreshold;
-	const int npx = cw * ch;
-	// p / cw by multiplication: cw <= 60 and p < 3600, so with M = ceil(2^18 / cw) the error term p * (M*cw - 2^18) < 3600 * 60 < 2^18
-	// and (p * M) >> 18 is exact (a variable integer division is ~20 VALU instructions, and there were three per pixel).
-	const unsigned divM = (262144u + (unsigned)cw - 1u) / (unsigned)cw;
 	const int lane = tid & 63, wave = tid >> 6;
 	// pass 1: cheap compass test on every pixel; survivors are compacted into an LDS list (order is irrelevant here) so that
 	// pass 2 — the full 16-pixel arc score, ~10x the work — runs with all lanes busy instead of diverging inside each wave
 	if constexpr (P == 16) {
-		// pass 1, 16-pixel ring: four adjacent pixels per thread (fast_quick4), one list reservation per wave and trip for the four ballots
-		const int gpr = (cw + 3) >> 2, ngrp = gpr * ch;   // groups per row: gpr <= 15, g < 15 * 60: M = ceil(2^16 / gpr) is exact
-		const unsigned gM = (65536u + (unsigned)gpr - 1u) / (unsigned)gpr;
+		// pass 1, 16-pixel ring: four adjacent pixels per thread (fast_quick4); the wave reserves list space for all of them with one prefix sum over the lanes'
+		// survivor counts (DPP) and one atomic
+		const int gpr = (cw + 3) >> 2, ngrp = gpr * ch;   // groups per row: gpr <= 15, g < 15 * 60: CellInfo.grpM = ceil(2^16 / gpr) is exact
+		const unsigned gM = (unsigned)cell.grpM;
+		const v2s tt = {(short)t, (short)t};
 		for (int base = 0; base < ngrp; base += kFastBS) {
 			const int g = base + tid;
-			int bits = 0, py = 0, gx = 0;
+			uint32_t bits = 0;
+			int code = 0;
 			if (g < ngrp) {
-				py = (int)(((unsigned)g * gM) >> 16); gx = g - py * gpr;
-				bits = fast_quick4<kTilePitch>(&tile[(py + 3) * kTilePitch + 4 * gx + Geo::kTileX], t);
-				const int left = cw - 4 * gx;   // pixels of the group inside the cell (the last group of a row may be partial)
-				if (left < 4) bits &= (1 << left) - 1;
+				const int py = (int)(((unsigned)g * gM) >> 16), gx = g - py * gpr;
+				bits = fast_quick4<kTilePitch>(&tile[(py + 3) * kTilePitch + 4 * gx + Geo::kTileX], tt);
+				const int left = cw - 4 * gx;   // pixels of the group inside the cell (the last group of a row may be partial): pixels 0, 1, 2, 3 are bits 0, 1, 16, 17
+				if (left < 4) bits &= left == 3 ? 0x00010003u : left == 2 ? 0x00000003u : 0x00000001u;
+				code = (py << 6) | (4 * gx);
 			}
-			unsigned long long bal[4];
-			int cnt[4];
-#pragma unroll
-			for (int j = 0; j < 4; ++j) { bal[j] = __ballot((bits >> j) & 1); cnt[j] = __popcll(bal[j]); }
-			const int total = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+			const int cnt = __popc(bits);
+			const int incl = wave_incl_scan(cnt);
+			const int total = __builtin_amdgcn_readlane(incl, 63);
 			int wbase = 0;
 			if (lane == 0 && total) wbase = atomicAdd(&nSurv, total);
-			wbase = __shfl(wbase, 0);
-			const int p0 = py * cw + 4 * gx;
-			const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				if ((bits >> j) & 1) surv[wbase + __popcll(bal[j] & below)] = (unsigned short)(p0 + j);
-				wbase += cnt[j];
+			wbase = __builtin_amdgcn_readfirstlane(wbase) + incl - cnt;
+			if (bits & 0x00000001u) surv[wbase] = (unsigned short)code;
+			if (bits & 0x00000002u) surv[wbase + (int)(bits & 1u)] = (unsigned short)(code + 1);
+			if (bits & 0x00010000u) surv[wbase + __popc(bits & 0x3u)] = (unsigned short)(code + 2);
+			if (bits & 0x00020000u) surv[wbase + __popc(bits & 0x10003u)] = (unsigned short)(code + 3);
+		}
+	} else {
+		// p / cw by multiplication: cw <= 60 and p < 3600, so with M = ceil(2^18 / cw) the error term p * (M*cw - 2^18) < 3600 * 60 < 2^18 and (p * M) >> 18 is exact
+		const int npx = cw * ch;
+		const unsigned divM = (262144u + (unsigned)cw - 1u) / (unsigned)cw;
+		for (int base = 0; base < npx; base += kFastBS) {
+			const int p = base + tid;
+			bool pass = false;
+			int code = 0;
+			if (p < npx) {
+				const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
+				pass = small_ring_quick<P, kTilePitch>(&tile[(py + 3) * kTilePitch + px + Geo::kTileX], t);
+				code = (py << 6) | px;
 			}
+			const unsigned long long bal = __ballot(pass);
+			int wbase = 0;
+			if (lane == 0 && bal) wbase = atomicAdd(&nSurv, __popcll(bal));
+			wbase = __shfl(wbase, 0);
+			if (pass) surv[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)code;
 		}
-	} else
-	for (int base = 0; base < npx; base += kFastBS) {
-		const int p = base + tid;
-		bool pass = false;
-		if (p < npx) {
-			const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
-			const uint8_t* c = &tile[(py + 3) * kTilePitch + px + Geo::kTileX];
-			if constexpr (P == 16) pass = fast_quick<kTilePitch>(c, t);
-			else pass = small_ring_quick<P, kTilePitch>(c, t);
-		}
-		const unsigned long long bal = __ballot(pass);
-		int wbase = 0;
-		if (lane == 0 && bal) wbase = atomicAdd(&nSurv, __popcll(bal));
-		wbase = __shfl(wbase, 0);
-		if (pass) surv[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)p;
 	}
 	__syncthreads();
 	const int ns = nSurv;
 	if constexpr (P == 16) {
 		for (int i = 2 * tid; i < ns; i += 2 * kFastBS) {
 			const int pa = surv[i], pb = surv[i + 1 < ns ? i + 1 : i];
-			const int ya = (int)(((unsigned)pa * divM) >> 18), xa = pa - ya * cw, yb = (int)(((unsigned)pb * divM) >> 18), xb = pb - yb * cw;
+			const int ya = pa >> 6, xa = pa & 63, yb = pb >> 6, xb = pb & 63;
 			const uint32_t s2 = fast_score2<kTilePitch>(&tile[(ya + 3) * kTilePitch + xa + Geo::kTileX], &tile[(yb + 3) * kTilePitch + xb + Geo::kTileX], t);
 			sc[(ya + 1) * kScPitch + xa + 1] = (uint8_t)s2;
 			if (i + 1 < ns) sc[(yb + 1) * kScPitch + xb + 1] = (uint8_t)(s2 >> 8);
@@ -335,12 +351,8 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	} else
 	for (int i = tid; i < ns; i += kFastBS) {
 		const int p = surv[i];
-		const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
-		const uint8_t* c = &tile[(py + 3) * kTilePitch + px + Geo::kTileX];
-		int score;
-		if constexpr (P == 16) score = fast_score<kTilePitch>(c, t);
-		else score = small_ring_score<P, kTilePitch>(c, t);
-		sc[(py + 1) * kScPitch + px + 1] = (uint8_t)score;
+		const int py = p >> 6, px = p & 63;
+		sc[(py + 1) * kScPitch + px + 1] = (uint8_t)small_ring_score<P, kTilePitch>(&tile[(py + 3) * kTilePitch + px + Geo::kTileX], t);
 	}
 	__syncthreads();
 
@@ -349,10 +361,10 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	const short* mapY = b.maskMap + L.mapY;
 	const uint8_t* mask = b.mask0 ? b.mask0 + (size_t)img * b.mask0Pitch : nullptr;
 	// pass 3a: non-max suppression + mirror mask, only for the pixels that have a score at all (the compass survivors); the verdicts go
-	// into a bitmap indexed by the pixel's row-major number inside the cell
+	// into a bitmap indexed by the pixel's code
 	for (int i = tid; i < ns; i += kFastBS) {
 		const int p = surv[i];
-		const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
+		const int py = p >> 6, px = p & 63;
 		const uint8_t* q = &sc[(py + 1) * kScPitch + px + 1];
 		const int s0 = q[0];
 		const int nb = max(max(max((int)q[-1], (int)q[1]), max((int)q[-kScPitch - 1], (int)q[-kScPitch])),
@@ -365,32 +377,27 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 		if (keep) atomicOr(&keepBits[p >> 5], 1u << (p & 31));
 	}
 	__syncthreads();
-	// the emission order (row-major inside the cell, the reference's) is an exclusive prefix sum over the kept-pixel counts of <= 57 groups of
-	// 64 pixels (two bitmap words each; one wave does it) — two barriers for the whole cell instead of three per 256-pixel slab.
-	const int ngroups = (npx + 63) >> 6;
+	// the emission order (row-major inside the cell, the reference's) is an exclusive prefix sum over the kept-pixel counts of the <= 60 rows (two bitmap words
+	// each; one wave does it) — two barriers for the whole cell
 	if (wave == 0) {
-		const int v = lane < ngroups ? __popc(keepBits[2 * lane]) + __popc(keepBits[2 * lane + 1]) : 0;
-		int incl = v;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-		groupOff[lane] = incl - v;
+		const int v = lane < ch ? __popc(keepBits[2 * lane]) + __popc(keepBits[2 * lane + 1]) : 0;
+		const int incl = wave_incl_scan(v);
+		rowOff[lane] = incl - v;
 		if (lane == 63) runBase = incl;
 	}
 	__syncthreads();
-	// every kept survivor writes its record at (kept pixels before it in row-major order): group prefix + kept bits below it in its own 64-pixel group
+	// every kept survivor writes its record at (kept pixels before it in row-major order): row prefix + kept bits below it in its own row
 	for (int i = tid; i < ns; i += kFastBS) {
 		const int p = surv[i];
 		const uint32_t w = keepBits[p >> 5];
 		if ((w >> (p & 31)) & 1u) {
-			const int g = p >> 6;
-			const uint32_t below = (p & 32) ? __popc(keepBits[2 * g]) + __popc(w & ((1u << (p & 31)) - 1u)) : __popc(w & ((1u << (p & 31)) - 1u));
-			const int py = (int)(((unsigned)p * divM) >> 18), px = p - py * cw;
+			const int py = p >> 6, px = p & 63;
+			const uint32_t below = (p & 32) ? __popc(keepBits[2 * py]) + __popc(w & ((1u << (p & 31)) - 1u)) : __popc(w & ((1u << (p & 31)) - 1u));
 			const int s0 = sc[(py + 1) * kScPitch + px + 1];
-			slots[groupOff[g] + (int)below] = (uint32_t)(cell.x0 + px - kMinBorder) | ((uint32_t)(cell.y0 + py - kMinBorder) << 12) | ((uint32_t)s0 << 24);
+			slots[rowOff[py] + (int)below] = (uint32_t)(cell.x0 + px - kMinBorder) | ((uint32_t)(cell.y0 + py - kMinBorder) << 12) | ((uint32_t)s0 << 24);
 		}
 	}
 	if (tid == 0) *countOut = runBase;
-	(void)sw;
 }
 
 // (A strip form — one workgroup per run of 8 cells of a cell row, per-wave survivor queues instead of the list + atomics, the score tile rescanned as dwords
@@ -410,10 +417,13 @@ void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream
 	for (int l = level0; l < level1; ++l) cellMax = std::max(cellMax, std::max(hd.lv[l].wCell, hd.lv[l].hCell));
 	// two waves per cell for the small instance: alone 0.46 ms against 0.52 (one wave) and 0.55 (four waves); in the overlapped step one and two waves are within 1 %
 	const dim3 grid(perXcd * kNumXCD);
+	// block -> image by multiplication: M = ceil(2^32 / ncells) is exact while block * ncells < 2^32 (block * (M * ncells - 2^32) < 2^32)
+	if ((unsigned long long)nblocks * (unsigned long long)ncells >= (1ull << 32)) { fprintf(stderr, "mcs: FAST launch too large (%d blocks)\n", nblocks); abort(); }
+	const unsigned ncellsM = (unsigned)(((1ull << 32) + (unsigned long long)ncells - 1ull) / (unsigned long long)ncells);
 #define MCS_FAST_LAUNCH(P)                                                                                                                      \
 	do {                                                                                                                                        \
-		if (cellMax <= 40) hipLaunchKernelGGL((k_fast_cells<40, MCS_FAST_BS, P>), grid, dim3(MCS_FAST_BS), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);     \
-		else hipLaunchKernelGGL((k_fast_cells<60, 256, P>), grid, dim3(256), 0, s, b, nimg, nblocks, perXcd, cell0, ncells);                   \
+		if (cellMax <= 40) hipLaunchKernelGGL((k_fast_cells<40, MCS_FAST_BS, P>), grid, dim3(MCS_FAST_BS), 0, s, b, nimg, nblocks, perXcd, cell0, ncells, ncellsM);     \
+		else hipLaunchKernelGGL((k_fast_cells<60, 256, P>), grid, dim3(256), 0, s, b, nimg, nblocks, perXcd, cell0, ncells, ncellsM);                   \
 	} while (0)
 	if (hd.fastRing == 16) MCS_FAST_LAUNCH(16);
 	else if (hd.fastRing == 12) MCS_FAST_LAUNCH(12);
