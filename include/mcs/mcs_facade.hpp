@@ -2,6 +2,7 @@
 // that cTracking / cLocalMapping / cLoopClosing compile against it unchanged in spirit:
 //
 //   MultiColSLAM::mdBRIEFextractorOct   include/mdBRIEFextractorOct.h:335-421 (13-argument ctor, operator(), getters)
+//   MultiColSLAM::ORBextractor          include/cORBextractor.h:48-67 (the ORB-mode extractor behind its own constructor / operator())
 //   MultiColSLAM::cORBmatcher           include/cORBmatcher.h:43-133 (brute-force and grid-window searches on flat views)
 //   MultiColSLAM::cMultiCamSys_ / LoadMCS / cORBVocabulary / ComputeDistinctiveDescriptors   the callers either side of the path
 //   MultiColSLAM::DescriptorDistance64[_Masked]   src/cORBmatcher.cpp:2438-2474
@@ -75,12 +76,16 @@ public:
 	// operator()(image, mask, keypoints, camModel, descriptors, descriptorMasks)  (src/mdBRIEFextractorOct.cpp:1244-1337)
 	void operator()(const Mat8u& image, const Mat8u& mask, std::vector<KeyPoint>& keypoints, cCamModelGeneral_& camModel, Mat8u& descriptors,
 	                Mat8u& descriptorMasks) {
+		extract(image, mask, keypoints, &camModel.ocam, descriptors, descriptorMasks);
+	}
+	// the same with an optional camera model (ORB mode reads none: ORBextractor below)
+	void extract(const Mat8u& image, const Mat8u& mask, std::vector<KeyPoint>& keypoints, const mcs_ocam* ocam, Mat8u& descriptors, Mat8u& descriptorMasks) {
 		if (image.empty()) return;   // :1252-1253
 		ensure(image.cols, image.rows, 1);
 		std::vector<mcs_keypoint> kps(cap_);
 		std::vector<uint8_t> d((size_t)cap_ * p_.descSize), m((size_t)cap_ * p_.descSize);
 		int32_t n = 0;
-		mcs_throw(mcs_extract_batch(ex_, 1, image.data, 0, image.step, mask.empty() ? nullptr : mask.data, 0, mask.step, &camModel.ocam,
+		mcs_throw(mcs_extract_batch(ex_, 1, image.data, 0, image.step, mask.empty() ? nullptr : mask.data, 0, mask.step, ocam,
 		                            MCS_MEM_HOST, &n, kps.data(), d.data(), m.data(), nullptr));
 		keypoints.resize(n);
 		if (n) std::memcpy(keypoints.data(), kps.data(), (size_t)n * sizeof(KeyPoint));
@@ -202,6 +207,28 @@ inline Matx44d Cayley2Hom(const double c[6]) {   // include/misc.h:132-160, 211-
 	M[15] = 1.0;
 	return M;
 }
+
+// ORBextractor (include/cORBextractor.h:48-67; the reference declares the class and never compiles an implementation): the extractor in ORB mode behind the
+// five-argument constructor and the four-argument operator() — no camera model, no descriptor masks.  scaleFactor is a double in this header (a float in
+// mdBRIEFextractorOct's): it is narrowed to the float the extraction tables are built from, and GetScaleFactor() returns what was passed.
+class ORBextractor {
+public:
+	enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+	ORBextractor(Context& ctx, int nfeatures = 1000, double scaleFactor = 1.2, int nlevels = 8, int scoreType = FAST_SCORE, int fastTh = 20)
+	    : impl_(ctx, nfeatures, (float)scaleFactor, nlevels, 25, 0, scoreType, 32, fastTh, false, 2, false, false, 32), nlevels_(nlevels), scaleFactor_(scaleFactor) {}
+	// operator()(image, mask, keypoints, descriptors)   (include/cORBextractor.h:61-63)
+	void operator()(const Mat8u& image, const Mat8u& mask, std::vector<KeyPoint>& keypoints, Mat8u& descriptors) {
+		Mat8u unusedMasks;
+		impl_.extract(image, mask, keypoints, nullptr, descriptors, unusedMasks);   // ORB mode reads no camera model
+	}
+	int GetLevels() { return nlevels_; }
+	double GetScaleFactor() { return scaleFactor_; }
+
+private:
+	mdBRIEFextractorOct impl_;
+	int nlevels_;
+	double scaleFactor_;
+};
 
 // cMultiCamSys_ (include/cam_system_omni.h): calibrations + poses; the projection of many points runs on the GPU in one call
 class cMultiCamSys_ {

@@ -81,7 +81,10 @@ int mcs_ctx_join(mcs_ctx*);
  * previous search): the caller's stream continues at once, so the next batch's extraction overlaps the matcher.  The caller then owes the ordering a
  * plain stream would have given it: the search's INPUT buffers must not be overwritten, and its outputs not read, before
  *   mcs_ctx_search_fence(ctx, lag)   the context's stream waits for the search issued `lag` calls before the latest one (0 = the latest = mcs_ctx_join)
- * (a stream-side wait, no host block).  bench.py alternates two buffer sets and fences with lag 1 before it reuses a set. */
+ * (a stream-side wait, no host block).  bench.py alternates two buffer sets and fences with lag 1 before it reuses a set.
+ * The same holds, to a lesser degree, WITHOUT deferred searches: the greedy pass of a search runs on the library's side stream and rescans the search's input
+ * rows and valid flags, so they must stay intact until mcs_ctx_join / the next mcs_search_* call / mcs_ctx_synchronize — a caller that refills them on its own
+ * stream in between (the native rig host's exchange) joins first or rotates buffer sets. */
 int mcs_ctx_set_async_search(mcs_ctx*, int on);
 int mcs_ctx_search_fence(mcs_ctx*, int lag);
 
@@ -102,7 +105,9 @@ int mcs_extractor_levels(const mcs_extractor*, int* nlevels, int* widths, int* h
  * outputs (row i*cap + k is keypoint k of image i, cap = mcs_extractor_kp_capacity):
  *   nkp[nimg]  keypoints[nimg*cap]  desc[nimg*cap*descSize]  descmask[nimg*cap*descSize] (zeros unless learnMasks)
  *   rays[nimg*cap*3] (ImgToWorld of every keypoint, optional)
- * With kind == DEVICE the call only enqueues work on the context's stream (no host synchronisation).              */
+ * With kind == DEVICE the call only enqueues work on the context's stream (no host synchronisation).
+ * DEVICE-kind desc / descmask pointers (and out_row_stride of the strided form) must be 8-byte aligned: a descriptor leaves the kernel as 64-bit words
+ * (the reference's matcher reads its rows as const uint64_t* too, src/cMultiKeyFrame.cpp:356-364); MCS_ERR_INVALID otherwise.                          */
 int mcs_extract_batch(mcs_extractor*, int nimg, const uint8_t* images, size_t image_pitch, int image_stride,
                       const uint8_t* masks, size_t mask_pitch, int mask_stride, const mcs_ocam* cams, mcs_mem_kind kind,
                       int32_t* nkp, mcs_keypoint* keypoints, uint8_t* desc, uint8_t* descmask, double* rays);

@@ -457,9 +457,9 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 		selBase += L.selCap;
 		// oct-tree roots (:641-661)
 		L.nIni = cvRound_(wd / ht);
-		if (L.nIni < 1 || L.nIni > kMaxRoots || L.nfeat + 3 > 1024) {
+		if (L.nIni < 1 || L.nIni > kMaxRoots || L.nfeat + 3 > kMaxNodes) {
 			delete e;
-			return fail(MCS_ERR_UNSUPPORTED, "aspect ratio / features per level outside the oct-tree kernel's capacity (nIni in [1,32], nfeatures_level+3 <= 1024)");
+			return fail(MCS_ERR_UNSUPPORTED, "aspect ratio / features per level outside the oct-tree kernel's capacity (nIni in [1,32], nfeatures_level+3 <= 2048)");
 		}
 		L.hX = wd / L.nIni;
 		for (int i = 0; i <= L.nIni; ++i) L.rootX[i] = (int)(L.hX * static_cast<double>(i));

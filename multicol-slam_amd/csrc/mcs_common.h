@@ -14,7 +14,7 @@ constexpr int kPatchSize = 32;     // PATCH_SIZE       (:84)
 constexpr int kMinBorder = kEdge - 3;  // 22 (:876)
 constexpr int kCellW = 30;         // W (:868)
 constexpr int kMaxRoots = 32;
-constexpr int kMaxNodes = 2560;    // oct-tree node capacity per (image, level): nfeatures_level + 3 must fit
+constexpr int kMaxNodes = 2048;    // oct-tree node capacity per (image, level): nfeatures_level + 3 must fit (k_octree<2048, ...>: 140 of the CU's 160 KB of LDS)
 constexpr int kNumXCD = 8;
 
 // One pyramid level of one image (identical for every image of the batch).

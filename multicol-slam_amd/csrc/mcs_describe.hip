@@ -894,15 +894,18 @@ static void launch_fast_passes(const ExtractBuffers& b, int nimg, int wavesPerIm
 	int fblocks = (ngroups + groupsPerBlock - 1) / groupsPerBlock;
 	if (fblocks >= kNumXCD) fblocks = (fblocks + kNumXCD - 1) / kNumXCD * kNumXCD;   // whole XCD rounds: the kernel's block -> group mapping is XCD-contiguous
 	const size_t fLds = (size_t)kFastWaves * kPatchBytes + kGTabDoubles * sizeof(double);
-	// (fbCount and preCount — neighbours — were cleared by k_octree's first workgroup)
+	// PRECONDITION: fbCount and preCount — neighbours — were cleared by k_octree's first workgroup, i.e. every launch_describe follows a launch_octree of the same
+	// batch on the same stream, and the previous batch's side-stream pre-list kernel has been joined (the evDescJoin wait below); extract_impl in mcs_capi.hip is
+	// the only caller and keeps that order
 	hipLaunchKernelGGL((k_orient_b<MODE>), dim3((nslots + 255) / 256), dim3(256), 0, s, b, wavesPerImage, nslots);
 	// the pre-list (about one keypoint in a hundred: the ones next to the optical axis) through the exact pass BESIDE the fast pass
 	hipStream_t ps = b.sideStream ? b.sideStream : s;
 	if (b.sideStream) { (void)hipEventRecord(b.evDescFork, s); (void)hipStreamWaitEvent(ps, b.evDescFork, 0); }
 	hipLaunchKernelGGL((k_describe_list<MODE, NB>), dim3(lblocks), dim3(64), listLds, ps, b, wavesPerImage, b.preCount, b.preList);
 	if (b.sideStream) (void)hipEventRecord(b.evDescJoin, ps);
-	static bool ldsAttr = false;   // more than the default 64 KB of dynamic LDS per workgroup
-	if (!ldsAttr && fLds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_describe_fast<MODE, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fLds); ldsAttr = true; }
+	// more than the default 64 KB of dynamic LDS per workgroup: the attribute belongs to the function ON THE CURRENT DEVICE, and one process may drive several
+	// devices from several threads (host/rig_host.cpp), so it is set before every launch (as launch_spec in mcs_greedy.hip does), not once per process
+	if (fLds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_describe_fast<MODE, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fLds);
 	hipLaunchKernelGGL((k_describe_fast<MODE, NB>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage, nslots, groupsPerBlock);
 	hipLaunchKernelGGL((k_describe_list<MODE, NB>), dim3(lblocks), dim3(64), listLds, s, b, wavesPerImage, b.fbCount, b.fbList);
 	if (b.sideStream) (void)hipStreamWaitEvent(s, b.evDescJoin, 0);

@@ -29,13 +29,15 @@ struct NodeBuf {
 	short cre[MAXN];   // creation index inside the pass that made the node if cnt > 1, else -1
 };
 
-// exclusive scan of a[0..n) (n <= MAXN) by the whole 256-thread block; returns the total.  Caller must have synced.
+// exclusive scan of a[0..n) (n <= 256 * IPT) by the whole 256-thread block, IPT consecutive entries per thread; returns the total.  Caller must have synced.
+template <int IPT>
 __device__ int block_exscan(int* a, int n, int* wsum) {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int base = tid * 4;
-	int v0 = base < n ? a[base] : 0, v1 = base + 1 < n ? a[base + 1] : 0, v2 = base + 2 < n ? a[base + 2] : 0,
-	    v3 = base + 3 < n ? a[base + 3] : 0;
-	const int s = v0 + v1 + v2 + v3;
+	const int base = tid * IPT;
+	int v[IPT];
+	int s = 0;
+#pragma unroll
+	for (int j = 0; j < IPT; ++j) { v[j] = base + j < n ? a[base + j] : 0; s += v[j]; }
 	int x = s;
 #pragma unroll
 	for (int o = 1; o < 64; o <<= 1) {
@@ -48,10 +50,8 @@ __device__ int block_exscan(int* a, int n, int* wsum) {
 	for (int w = 0; w < wave; ++w) woff += wsum[w];
 	const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 	int ex = woff + x - s;
-	if (base < n) a[base] = ex;
-	if (base + 1 < n) a[base + 1] = ex + v0;
-	if (base + 2 < n) a[base + 2] = ex + v0 + v1;
-	if (base + 3 < n) a[base + 3] = ex + v0 + v1 + v2;
+#pragma unroll
+	for (int j = 0; j < IPT; ++j) { if (base + j < n) a[base + j] = ex; ex += v[j]; }
 	__syncthreads();
 	return total;
 }
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int 
 	__shared__ int wsum[4];
 	__shared__ int shR;
 
+	constexpr int IPT = MAXN / 256 < 4 ? 4 : MAXN / 256;   // scan entries per thread: every scan below is over at most MAXN entries
 	const PyrDesc& d = *b.desc;
 	// level-major over the launch's level range: the big levels (most candidates, most passes) start first and the small ones fill the tail
 	const int level = level0 + blockIdx.x / nimg;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int 
 		__syncthreads();
 		for (int i = tid; i < m; i += 256) scanA[i] = cellCount[c0 + i];
 		__syncthreads();
-		const int tot = block_exscan(scanA, m, wsum);
+		const int tot = block_exscan<IPT>(scanA, m, wsum);
 		for (int c = wave; c < m; c += 4) {
 			const int cnt = cellCount[c0 + c];
 			const int off = n + scanA[c];
@@ -159,12 +160,12 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int 
 		if (!phaseB) {
 			for (int i = tid; i < L; i += 256) scanA[i] = A.cnt[i] > 1 ? 1 : 0;
 			__syncthreads();
-			M = block_exscan(scanA, L, wsum);
+			M = block_exscan<IPT>(scanA, L, wsum);
 			for (int i = tid; i < L; i += 256) crank[i] = A.cnt[i] > 1 ? (short)scanA[i] : (short)-1;
 		} else {
 			for (int i = tid; i < L; i += 256) scanA[i] = A.cre[i] >= 0 ? 1 : 0;
 			__syncthreads();
-			M = block_exscan(scanA, L, wsum);
+			M = block_exscan<IPT>(scanA, L, wsum);
 			for (int i = tid; i < L; i += 256) {   // rank = number of candidates with a larger (cnt, cre) key
 				short r = -1;
 				if (A.cre[i] >= 0) {
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int 
 			}
 			if (tid == 0) shR = M - 1;
 			__syncthreads();
-			block_exscan(scanB, M, wsum);
+			block_exscan<IPT>(scanB, M, wsum);
 			for (int r = tid; r < M; r += 256) {
 				const int i = byRank[r];
 				const int nch = (cc[i * 4] > 0) + (cc[i * 4 + 1] > 0) + (cc[i * 4 + 2] > 0) + (cc[i * 4 + 3] > 0);
@@ -225,8 +226,8 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int 
 			scanB[r] = (cc[i * 4] > 1) + (cc[i * 4 + 1] > 1) + (cc[i * 4 + 2] > 1) + (cc[i * 4 + 3] > 1);
 		}
 		__syncthreads();
-		const int T = block_exscan(scanA, P, wsum);
-		const int nToExpand = block_exscan(scanB, P, wsum);
+		const int T = block_exscan<IPT>(scanA, P, wsum);
+		const int nToExpand = block_exscan<IPT>(scanB, P, wsum);
 		const int newL = T + L - P;
 		if (newL > MAXN) { if (tid == 0) atomicExch(b.status, MCS_ERR_CAPACITY); L = 0; break; }
 		// children of processed nodes
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int 
 		// untouched nodes keep their relative order behind the new children
 		for (int i = tid; i < L; i += 256) scanA[i] = (crank[i] >= 0 && crank[i] < P) ? 0 : 1;
 		__syncthreads();
-		block_exscan(scanA, L, wsum);
+		block_exscan<IPT>(scanA, L, wsum);
 		for (int i = tid; i < L; i += 256) {
 			if (!(crank[i] >= 0 && crank[i] < P)) {
 				const int p = T + scanA[i];
@@ -315,7 +316,8 @@ void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStre
 	for (int l = 0; l < hd.nlevels; ++l) need = need > hd.lv[l].nfeat + 3 ? need : hd.lv[l].nfeat + 3, need = need > 4 * hd.lv[l].nIni ? need : 4 * hd.lv[l].nIni;
 	if (need <= 256) hipLaunchKernelGGL((k_octree<256, 2048>), dim3(nimg * nl), dim3(256), 0, s, b, nimg, level0);   // N = 1000 over 8 levels needs 220 nodes: 29 KB LDS, five workgroups per CU (0.195 -> 0.162 ms; key cache 3072: four per CU, 0.175; 1536: 0.176)
 	else if (need <= 512) hipLaunchKernelGGL((k_octree<512, 3072>), dim3(nimg * nl), dim3(256), 0, s, b, nimg, level0);   // 50 KB LDS: 3 workgroups per CU
-	else hipLaunchKernelGGL((k_octree<1024, 2048>), dim3(nimg * nl), dim3(256), 0, s, b, nimg, level0);
+	else if (need <= 1024) hipLaunchKernelGGL((k_octree<1024, 2048>), dim3(nimg * nl), dim3(256), 0, s, b, nimg, level0);
+	else hipLaunchKernelGGL((k_octree<2048, 2048>), dim3(nimg * nl), dim3(256), 0, s, b, nimg, level0);   // nFeatures up to ~9400 (the reference has no limit, :167-179): 140 KB of LDS, one workgroup per CU
 }
 
 }  // namespace mcs

@@ -14,7 +14,9 @@
 //
 // Input: a key / value text file (see tests/test_gpu_rig_host.py) naming raw binary inputs — images [camera][frame][H][W] u8 for the whole job, one mask per
 // camera, one mcs_ocam per camera.  Output: per rank its received array, keypoints, counts and match arrays as raw files + one JSON line on stdout
-// (steps, ms per step = max over ranks between two barriers).  No Python, no torch.
+// (steps, ms per step = max over ranks between two barriers, and each rank's own).  No Python, no torch.
+// The step is pipelined like bench.py's: three buffer sets, the exchange of step n on a second stream beside the extraction of step n + 1, the searches deferred
+// (mcs_ctx_set_async_search) and fenced before their inputs are reused.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -95,7 +97,7 @@ struct Job {
 };
 
 static pthread_barrier_t g_barrier;
-static std::vector<double> g_ms;
+static std::vector<double> g_ms, g_msAll;   // per rank: its own step time, and the time to the barrier behind the slowest rank
 
 static void rank_main(const Job& J, int rank, ncclComm_t comm) {
 	HIPOK(hipSetDevice(rank));
@@ -128,72 +130,122 @@ static void rank_main(const Job& J, int rank, ncclComm_t comm) {
 		HIPOK(hipMemcpy(d_msk + i * px, J.masks.data() + c * px, px, hipMemcpyHostToDevice));
 		memcpy(&cam[i], J.cams.data() + (size_t)c * sizeof(mcs_ocam), sizeof(mcs_ocam));
 	}
-	uint8_t* d_send = dalloc<uint8_t>(lay.send_bytes);
-	uint8_t* d_G = dalloc<uint8_t>(view.images_total * view.block_bytes);
-	uint8_t* d_valid = dalloc<uint8_t>((size_t)view.images_total * view.rows_img);
-	int32_t* d_nkp = dalloc<int32_t>(lay.L);
-	int32_t* d_nkpAll = dalloc<int32_t>(view.images_total);
-	mcs_keypoint* d_kps = dalloc<mcs_keypoint>((size_t)lay.L * cap);
-	double* d_rays = dalloc<double>((size_t)lay.L * cap * 3);
-
+	// ---- three buffer sets in rotation (the schedule of bench.py's Job.step): step n extracts set n % 3 and STARTS its exchange on a second stream; the exchange
+	// of step n - 1 had a whole step of kernels to hide behind and is finished (an event wait) before its rows are flagged and matched — as a deferred search
+	// (mcs_ctx_set_async_search: lists + greedy pass on the library's own stream beside the next extraction), so results are one step late.  The search that last
+	// read a set is fenced (mcs_ctx_search_fence) before the set is extracted into again: nothing of a search's inputs is overwritten while it runs.
+	constexpr int NS = 3;
+	struct Set {
+		uint8_t *send, *G, *valid; int32_t *nkp, *nkpAll; mcs_keypoint* kps; double* rays; int32_t *match, *nmatch, *fb;
+		hipEvent_t evExtracted, evExchanged;
+	};
 	std::vector<int> kfs;
 	for (int k = 0; k < J.D; ++k) if (k % J.world == rank) kfs.push_back(k);
 	const int nkf = (int)kfs.size(), npairs = ring ? J.F : FT * std::max(nkf, 1);
+	Set sets[NS];
+	for (Set& b : sets) {
+		b.send = dalloc<uint8_t>(lay.send_bytes);
+		b.G = dalloc<uint8_t>(view.images_total * view.block_bytes);
+		b.valid = dalloc<uint8_t>((size_t)view.images_total * view.rows_img);
+		b.nkp = dalloc<int32_t>(lay.L);
+		b.nkpAll = dalloc<int32_t>(view.images_total);
+		b.kps = dalloc<mcs_keypoint>((size_t)lay.L * cap);
+		b.rays = dalloc<double>((size_t)lay.L * cap * 3);
+		b.match = dalloc<int32_t>((size_t)npairs * lay.rows_frame);
+		b.nmatch = dalloc<int32_t>(npairs);
+		b.fb = dalloc<int32_t>(npairs);
+		HIPOK(hipEventCreateWithFlags(&b.evExtracted, hipEventDisableTiming));
+		HIPOK(hipEventCreateWithFlags(&b.evExchanged, hipEventDisableTiming));
+	}
+	hipStream_t xstream;   // the exchange's own stream: the collective of step n runs beside the extraction kernels of step n + 1
+	HIPOK(hipStreamCreateWithFlags(&xstream, hipStreamNonBlocking));
 	uint8_t* d_db = dalloc<uint8_t>((size_t)std::max(nkf, 1) * lay.rows_frame * lay.row_stride);
 	uint8_t* d_dbValid = dalloc<uint8_t>((size_t)std::max(nkf, 1) * lay.rows_frame);
-	int32_t* d_match = dalloc<int32_t>((size_t)npairs * lay.rows_frame);
-	int32_t* d_nmatch = dalloc<int32_t>(npairs);
-	int32_t* d_fb = dalloc<int32_t>(npairs);
 
 	const std::vector<Run> mine = ring ? ring_runs(lay, rank) : std::vector<Run>();
 	std::vector<std::vector<Run> > theirs(J.world);   // what every destination needs (to find my sends, in the receiver's order)
 	if (ring) for (int r = 0; r < J.world; ++r) theirs[r] = ring_runs(lay, r);
 
-	auto extract_and_exchange = [&]() {
-		MCSOK(mcs_extract_batch_strided(ex, lay.L, d_img, px, J.W, d_msk, px, J.W, cam.data(), d_nkp, d_kps, d_send, d_send + lay.ds, d_rays, lay.rows_img, lay.row_stride));
-		MCSOK(mcs_rig_pack_headers(ctx, d_nkp, lay.L, cap, d_send, lay.row_stride));
-		if (!ring) NCCLOK(ncclAllGather(d_send, d_G, lay.send_bytes, ncclUint8, comm, stream));
+	auto extract = [&](Set& b) {
+		MCSOK(mcs_extract_batch_strided(ex, lay.L, d_img, px, J.W, d_msk, px, J.W, cam.data(), b.nkp, b.kps, b.send, b.send + lay.ds, b.rays, lay.rows_img, lay.row_stride));
+		MCSOK(mcs_rig_pack_headers(ctx, b.nkp, lay.L, cap, b.send, lay.row_stride));
+		HIPOK(hipEventRecord(b.evExtracted, stream));
+	};
+	auto exchange_begin = [&](Set& b) {   // on the exchange stream, behind this set's extraction
+		HIPOK(hipStreamWaitEvent(xstream, b.evExtracted, 0));
+		if (!ring) NCCLOK(ncclAllGather(b.send, b.G, lay.send_bytes, ncclUint8, comm, xstream));
 		else {
 			NCCLOK(ncclGroupStart());
-			for (const Run& r : mine) NCCLOK(ncclRecv(d_G + (size_t)r.dst * lay.block_bytes, (size_t)r.n * lay.block_bytes, ncclUint8, r.owner, comm, stream));
+			for (const Run& r : mine) NCCLOK(ncclRecv(b.G + (size_t)r.dst * lay.block_bytes, (size_t)r.n * lay.block_bytes, ncclUint8, r.owner, comm, xstream));
 			for (int dest = 0; dest < J.world; ++dest)
 				for (const Run& r : theirs[dest])
-					if (r.owner == rank) NCCLOK(ncclSend(d_send + (size_t)r.src * lay.block_bytes, (size_t)r.n * lay.block_bytes, ncclUint8, dest, comm, stream));
+					if (r.owner == rank) NCCLOK(ncclSend(b.send + (size_t)r.src * lay.block_bytes, (size_t)r.n * lay.block_bytes, ncclUint8, dest, comm, xstream));
 			NCCLOK(ncclGroupEnd());
 		}
-		MCSOK(mcs_rig_rows_valid(ctx, d_G, view.images_total, cap, lay.row_stride, d_valid, d_nkpAll));
+		HIPOK(hipEventRecord(b.evExchanged, xstream));
 	};
-	auto match = [&]() {
-		const mcs_desc_set fr = view.frame_set(d_G, d_valid, 0, masksOn);
-		if (ring) MCSOK(mcs_search_kf_kf_ring(ctx, J.F + 1, 1, J.F, &fr, view.rows_img, 32, 0.9, J.topk, MCS_MEM_DEVICE, d_match, d_nmatch, d_fb));
+	auto exchange_end = [&](Set& b) {     // the context's stream continues behind the exchange: flags from the received headers
+		HIPOK(hipStreamWaitEvent(stream, b.evExchanged, 0));
+		MCSOK(mcs_rig_rows_valid(ctx, b.G, view.images_total, cap, lay.row_stride, b.valid, b.nkpAll));
+	};
+	auto match = [&](Set& b) {
+		const mcs_desc_set fr = view.frame_set(b.G, b.valid, 0, masksOn);
+		if (ring) MCSOK(mcs_search_kf_kf_ring(ctx, J.F + 1, 1, J.F, &fr, view.rows_img, 32, 0.9, J.topk, MCS_MEM_DEVICE, b.match, b.nmatch, b.fb));
 		else if (nkf) {
 			mcs_desc_set kf;
 			memset(&kf, 0, sizeof(kf));
 			kf.desc = d_db; kf.mask = masksOn ? d_db + lay.ds : nullptr; kf.valid = d_dbValid; kf.n = lay.rows_frame; kf.stride = lay.row_stride;
-			MCSOK(mcs_search_kf_f_sweep(ctx, nkf, &kf, lay.rows_frame, FT, &fr, lay.rows_img, 32, 0.9, J.topk, MCS_MEM_DEVICE, d_match, d_nmatch, d_fb));
+			MCSOK(mcs_search_kf_f_sweep(ctx, nkf, &kf, lay.rows_frame, FT, &fr, lay.rows_img, 32, 0.9, J.topk, MCS_MEM_DEVICE, b.match, b.nmatch, b.fb));
 		}
 	};
 
 	if (!ring) {   // untimed: stored keyframe k = multi-frame k % FT of one pass (as bench.py fills its database)
-		extract_and_exchange();
+		Set& b = sets[0];
+		extract(b); exchange_begin(b); exchange_end(b);
 		for (int j = 0; j < nkf; ++j)
 			for (int c = 0; c < J.ncam; ++c) {
 				const size_t x = lay.image_index(c, kfs[j] % FT);
-				HIPOK(hipMemcpyAsync(d_db + ((size_t)j * lay.rows_frame + (size_t)c * cap) * lay.row_stride, d_G + x * lay.block_bytes, (size_t)cap * lay.row_stride, hipMemcpyDeviceToDevice, stream));
-				HIPOK(hipMemcpyAsync(d_dbValid + (size_t)j * lay.rows_frame + (size_t)c * cap, d_valid + x * lay.rows_img, cap, hipMemcpyDeviceToDevice, stream));
+				HIPOK(hipMemcpyAsync(d_db + ((size_t)j * lay.rows_frame + (size_t)c * cap) * lay.row_stride, b.G + x * lay.block_bytes, (size_t)cap * lay.row_stride, hipMemcpyDeviceToDevice, stream));
+				HIPOK(hipMemcpyAsync(d_dbValid + (size_t)j * lay.rows_frame + (size_t)c * cap, b.valid + x * lay.rows_img, cap, hipMemcpyDeviceToDevice, stream));
 			}
 		HIPOK(hipStreamSynchronize(stream));
 	}
-	auto step = [&]() { extract_and_exchange(); match(); };
+	MCSOK(mcs_ctx_set_async_search(ctx, 1));
+	int cur = 0;
+	bool pending = false;   // the set before `cur` has an exchange in flight that nobody has matched yet
+	auto step = [&]() {
+		Set& b = sets[cur];
+		Set& p = sets[(cur + NS - 1) % NS];
+		cur = (cur + 1) % NS;
+		MCSOK(mcs_ctx_search_fence(ctx, 1));   // the search issued before the latest one read the set about to be overwritten (three sets, matching one step late)
+		extract(b);
+		exchange_begin(b);                     // in flight until the NEXT step needs it
+		if (pending) { exchange_end(p); match(p); }
+		pending = true;
+	};
+	auto drain = [&]() -> Set& {              // finish the step in flight: its exchange, flags and search; returns the set whose results are complete
+		Set& p = sets[(cur + NS - 1) % NS];
+		if (pending) { exchange_end(p); match(p); pending = false; }
+		MCSOK(mcs_ctx_join(ctx));
+		MCSOK(mcs_ctx_synchronize(ctx));
+		HIPOK(hipStreamSynchronize(xstream));
+		return p;
+	};
+	step();                                    // prime the pipeline: the first timed step matches what is exchanged here
 	for (int i = 0; i < J.warmup; ++i) step();
 	MCSOK(mcs_ctx_synchronize(ctx));
+	HIPOK(hipStreamSynchronize(xstream));
 	pthread_barrier_wait(&g_barrier);
 	const auto t0 = std::chrono::steady_clock::now();
-	for (int i = 0; i < J.steps; ++i) step();
+	for (int i = 0; i < J.steps; ++i) step();   // each: one extraction, one exchange, one matching pass
 	MCSOK(mcs_ctx_synchronize(ctx));
-	pthread_barrier_wait(&g_barrier);
+	HIPOK(hipStreamSynchronize(xstream));
 	g_ms[rank] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / std::max(J.steps, 1);
+	pthread_barrier_wait(&g_barrier);
+	g_msAll[rank] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / std::max(J.steps, 1);
+	Set& R = drain();                          // untimed: the last extracted set through its exchange and search
 	MCSOK(mcs_extractor_status(ex));
+	uint8_t *d_G = R.G, *d_valid = R.valid; int32_t *d_nkp = R.nkp, *d_match = R.match, *d_nmatch = R.nmatch; mcs_keypoint* d_kps = R.kps;
 
 	// ---- results of the last step, as this rank holds them
 	auto dump = [&](const char* name, const void* dptr, size_t bytes) {
@@ -215,9 +267,12 @@ static void rank_main(const Job& J, int rank, ncclComm_t comm) {
 	}
 	MCSOK(mcs_extractor_destroy(ex));
 	MCSOK(mcs_ctx_destroy(ctx));
-	for (void* p : {(void*)d_img, (void*)d_msk, (void*)d_send, (void*)d_G, (void*)d_valid, (void*)d_nkp, (void*)d_nkpAll, (void*)d_kps, (void*)d_rays, (void*)d_db, (void*)d_dbValid,
-	                (void*)d_match, (void*)d_nmatch, (void*)d_fb})
-		(void)hipFree(p);
+	for (Set& b : sets) {
+		for (void* p : {(void*)b.send, (void*)b.G, (void*)b.valid, (void*)b.nkp, (void*)b.nkpAll, (void*)b.kps, (void*)b.rays, (void*)b.match, (void*)b.nmatch, (void*)b.fb}) (void)hipFree(p);
+		(void)hipEventDestroy(b.evExtracted); (void)hipEventDestroy(b.evExchanged);
+	}
+	for (void* p : {(void*)d_img, (void*)d_msk, (void*)d_db, (void*)d_dbValid}) (void)hipFree(p);
+	HIPOK(hipStreamDestroy(xstream));
 	HIPOK(hipStreamDestroy(stream));
 }
 
@@ -233,7 +288,7 @@ int main(int argc, char** argv) {
 	HIPOK(hipGetDeviceCount(&ndev));
 	J.world = std::min(geti("gpus", ndev), ndev);
 	if (J.world < 1) { fprintf(stderr, "no HIP device\n"); return 1; }
-	if ((J.ncam * J.F * J.world) % J.world) { fprintf(stderr, "bad split\n"); return 1; }
+	if (J.ncam < 1 || J.F < 1 || J.steps < 0 || J.warmup < 0 || J.D < 0 || J.topk < 1) { fprintf(stderr, "bad configuration: ncam >= 1, frames >= 1, keyframes >= 0, topk >= 1\n"); return 1; }
 	J.images = read_file(cfg["images"]); J.masks = read_file(cfg["masks"]); J.cams = read_file(cfg["cams"]); J.out = cfg["out"];
 	const size_t need = (size_t)J.ncam * J.F * J.world * J.W * J.H;
 	if (J.images.size() != need || J.masks.size() != (size_t)J.ncam * J.W * J.H || J.cams.size() != (size_t)J.ncam * sizeof(mcs_ocam)) {
@@ -245,14 +300,18 @@ int main(int argc, char** argv) {
 	for (int i = 0; i < J.world; ++i) devs[i] = i;
 	NCCLOK(ncclCommInitAll(comms.data(), J.world, devs.data()));
 	pthread_barrier_init(&g_barrier, nullptr, J.world);
-	g_ms.assign(J.world, 0.0);
+	g_ms.assign(J.world, 0.0); g_msAll.assign(J.world, 0.0);
 	std::vector<std::thread> th;
 	for (int r = 0; r < J.world; ++r) th.emplace_back(rank_main, std::cref(J), r, comms[r]);
 	for (auto& t : th) t.join();
 	for (auto c : comms) NCCLOK(ncclCommDestroy(c));
-	const double ms = *std::max_element(g_ms.begin(), g_ms.end());
-	printf("{\"host\": \"rig_host (C++, one process, one thread per GPU, RCCL from ncclCommInitAll)\", \"n_gpus\": %d, \"steps\": %d, \"ms_per_step\": %.4f, "
+	const double ms = *std::max_element(g_msAll.begin(), g_msAll.end());   // between the two barriers: the slowest rank
+	std::string per = "[";
+	for (int r = 0; r < J.world; ++r) { char t[32]; snprintf(t, sizeof t, "%s%.4f", r ? ", " : "", g_ms[r]); per += t; }
+	per += "]";
+	printf("{\"host\": \"rig_host (C++, one process, one thread per GPU, RCCL from ncclCommInitAll; three buffer sets, exchange on its own stream, matching one step late)\", "
+	       "\"n_gpus\": %d, \"steps\": %d, \"ms_per_step\": %.4f, \"ms_per_step_ranks\": %s, "
 	       "\"exchange\": \"%s\", \"multi_frames_per_step_per_gpu\": %d, \"stored_keyframes\": %d}\n",
-	       J.world, J.steps, ms, J.D == 0 ? "ncclSend/ncclRecv group (frame ring)" : "ncclAllGather", J.F, J.D);
+	       J.world, J.steps, ms, per.c_str(), J.D == 0 ? "ncclSend/ncclRecv group (frame ring)" : "ncclAllGather", J.F, J.D);
 	return 0;
 }

@@ -1,0 +1,35 @@
+// facade_driver_orb.cpp — MultiColSLAM::ORBextractor of include/mcs/mcs_facade.hpp (reference include/cORBextractor.h:48-67) on one image:
+//   in : int32 w, h, nfeatures | image (w*h) | mask (w*h)          out: int32 n, levels | double scaleFactor | keypoints (28 B) | descriptors (32 B)
+#include <cstdio>
+#include <cstdlib>
+#include "mcs/mcs_facade.hpp"
+
+using namespace MultiColSLAM;
+
+int main(int argc, char** argv) {
+	if (argc != 3) return 1;
+	try {
+		FILE* fi = std::fopen(argv[1], "rb");
+		FILE* fo = std::fopen(argv[2], "wb");
+		if (!fi || !fo) return 1;
+		int32_t hdr[3];
+		if (fread(hdr, 4, 3, fi) != 3) return 2;
+		const int w = hdr[0], h = hdr[1];
+		Mat8u img, mask, desc;
+		img.create(h, w); mask.create(h, w);
+		if (fread(img.data, 1, (size_t)w * h, fi) != (size_t)w * h || fread(mask.data, 1, (size_t)w * h, fi) != (size_t)w * h) return 2;
+		Context ctx(0);
+		ORBextractor ex(ctx, hdr[2], 1.2, 8, ORBextractor::FAST_SCORE, 20);
+		std::vector<KeyPoint> keys;
+		ex(img, mask, keys, desc);
+		const int32_t out[2] = {(int32_t)keys.size(), ex.GetLevels()};
+		const double sf = ex.GetScaleFactor();
+		fwrite(out, 4, 2, fo); fwrite(&sf, 8, 1, fo);
+		if (!keys.empty()) { fwrite(keys.data(), sizeof(KeyPoint), keys.size(), fo); fwrite(desc.data, 32, keys.size(), fo); }
+		std::fclose(fo);
+		return 0;
+	} catch (const std::exception& e) {
+		std::fprintf(stderr, "facade_driver_orb: %s\n", e.what());
+		return 3;
+	}
+}

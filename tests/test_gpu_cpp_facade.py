@@ -191,3 +191,32 @@ def test_cpp_facade_callers_and_mapping_side(tmp_path):
     en, em = O.search_kf_f_bow(fr[0][2], fr[0][3], valid, node[0], fr[1][2], fr[1][3], node[1], True, 0.8)
     assert nm == en and np.array_equal(mF, em) and nm > 30
     assert off[0] == len(buf)
+
+
+def test_cpp_orbextractor_facade(tmp_path):
+    """MultiColSLAM::ORBextractor (reference include/cORBextractor.h:48-67: five-argument constructor, four-argument operator()) compiled with g++:
+    keypoints and descriptors of the ORB mode, bit for bit against the oracle"""
+    import gpu_common as G
+    O = G.O
+    cam = G.cams3()[0]
+    w, h, nfeat = 754, 480, 700
+    exe = tmp_path / "facade_driver_orb"
+    lib_dir = os.path.join(ROOT, "multicol-slam_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "facade_driver_orb.cpp"),
+                           "-o", str(exe), "-L" + lib_dir, "-lmcs_hip", "-Wl,-rpath," + lib_dir])
+    img, mask = G.synth.synth_image(3, 0, cam), G.synth.mirror_mask(cam)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(np.array([w, h, nfeat], np.int32).tobytes())
+        f.write(np.ascontiguousarray(img, np.uint8).tobytes())
+        f.write(np.ascontiguousarray(mask, np.uint8).tobytes())
+    subprocess.check_call([str(exe), str(fin), str(fout)])
+    buf = open(fout, "rb").read()
+    n, levels = np.frombuffer(buf, np.int32, 2, 0)
+    assert levels == 8 and np.frombuffer(buf, np.float64, 1, 8)[0] == 1.2
+    keys = np.frombuffer(buf, O.KP_DTYPE, n, 16)
+    d = np.frombuffer(buf, np.uint8, n * 32, 16 + n * 28).reshape(n, 32)
+    _, ek, ed, _, _ = G.oracle_extract(img, mask, cam, nfeatures=nfeat, do_dBrief=0, learnMasks=0)
+    assert n == len(ek) and n > 500
+    assert G.first_diff(keys, ek) is None and G.first_diff(d, ed) is None
+    assert 16 + n * 60 == len(buf)

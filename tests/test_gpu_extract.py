@@ -176,6 +176,8 @@ def test_unsupported_parameters_fail_loudly(G):
         G.mcs.Extractor(G.ctx(), 754, 480, descSize=24)
     with pytest.raises(G.mcs.McsError):
         G.mcs.Extractor(G.ctx(), 120, 90)            # too small: a level has no 30-px FAST cell
+    with pytest.raises(G.mcs.McsError):
+        G.mcs.Extractor(G.ctx(), 754, 480, nfeatures=12000)      # level 0 would get 2604 + 3 oct-tree nodes: beyond the largest kernel instance (2048)
 
 
 def test_host_images_with_padded_rows_and_gaps(G):
@@ -213,6 +215,10 @@ def test_host_images_with_padded_rows_and_gaps(G):
     dict(scaleFactor=1.2, nlevels=8, nfeatures=700, descSize=64, do_dBrief=1, learnMasks=1),
     dict(scaleFactor=1.2, nlevels=8, nfeatures=300, descSize=64, do_dBrief=1, learnMasks=0),
     dict(scaleFactor=1.3, nlevels=3, nfeatures=2000, descSize=32, do_dBrief=1, learnMasks=1, fastThreshold=9),
+    # the reference sets no limit on nFeatures (src/mdBRIEFextractorOct.cpp:167-179): 5000 puts 1085 on level 0 (the 2048-node oct-tree instance), and the
+    # low threshold gives every level more candidates than its quota, so the largest-first phase runs with > 1024 nodes
+    dict(scaleFactor=1.2, nlevels=8, nfeatures=5000, descSize=32, do_dBrief=1, learnMasks=1, fastThreshold=7),
+    dict(scaleFactor=1.2, nlevels=8, nfeatures=9000, descSize=32, do_dBrief=0, learnMasks=0, fastThreshold=5),
 ])
 def test_parameter_space_matches_oracle(G, case):
     """the cases of tests/test_oracle_vs_ref.py::test_oracle_equals_reference_code_over_the_parameter_space (there: oracle == the reference's own code),
@@ -221,8 +227,6 @@ def test_parameter_space_matches_oracle(G, case):
     big = G.synth.scaled_camera(cams[1], 1280, 800)
     for f, cam in ((3, cams[2]), (1, big)):
         img, mask = G.synth.synth_image(f, 1, cam), G.synth.mirror_mask(cam)
-        if case["nfeatures"] / case["nlevels"] > 900:   # features per level + 3 must stay <= 1024
-            pytest.skip("feature budget per level beyond the library's limit")
         ex = G.mcs.Extractor(G.ctx(), cam["width"], cam["height"], max_batch=1, **case)
         gk, gd, gm, gr = ex.extract_host([img], [mask], [G.mcs.make_ocam(cam)])[0]
         _, kps, d, dm, rays = G.oracle_extract(img, mask, cam, **case)
