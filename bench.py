@@ -557,6 +557,7 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True, check=True):
     x0 = job.ex.describe_stats()[0]
     job.step()
     exact_kp = job.ex.describe_stats()[0] - x0   # keypoints the guarded fast descriptor pass handed to the exact pass in one (untimed) step
+    tie = job.ex.tie_stats()                     # the run's closest approach of an exact-arithmetic cvRound argument to a rounding tie (pixels)
     feats_local = job.local_features()
     pairs_local = job.pairs_per_step_local()
     b = job.last()
@@ -577,6 +578,9 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True, check=True):
            "pair_distances_per_step": pairs_all, "Gpairs_per_s": round(pairs_all * steps / elapsed_max / 1e9, 1),
            "matches_per_step_rank0": matches, "greedy_rescans_rank0": rescans, "topk": sp.topk, "stored_keyframes": sp.D,
            "descriptor_exact_pass_keypoints_per_step_rank0": exact_kp,
+           # device libm vs the reference's can only round a coordinate differently within ~1e-13 px of a tie: this run's margin, measured over every cvRound
+           # argument of the exact arithmetic (all warm-up and timed steps); null if no exact-arithmetic coordinate occurred
+           "min_distance_to_a_rounding_tie_px_rank0": (tie if tie != float("inf") else None),
            "n_ranks": e.world, "collective_backend": e.backend, "tag": sp.tag,
            "ms_per_step_slowest_rank": round(elapsed_max / steps * 1e3, 4), "ms_per_step_fastest_rank": round(elapsed_min / steps * 1e3, 4),
            "exchange_bytes_received_per_rank_per_step": (0 if not e.exchange else job.ring.bytes_received(e.rank) if job.ring else job.lay.send_bytes * (e.world - 1)),

@@ -34,7 +34,7 @@ extern "C" {
 /* ABI revision of this header: bumped whenever a struct layout or an entry point's signature changes (3: mcs_desc_set carries block_rows / block_pitch_rows
  * since round 2 — callers built against an older header must be recompiled; mcs_describe_fast_table, FAST types 0 / 1 in round 3).  mcs_abi_version() returns
  * the value the LIBRARY was built with: compare it with MCS_ABI_VERSION after dlopen. */
-#define MCS_ABI_VERSION 3
+#define MCS_ABI_VERSION 4
 
 #define MCS_MAX_POLY 16
 #define MCS_MAX_LEVELS 16
@@ -119,6 +119,11 @@ int mcs_extract_batch(mcs_extractor*, int nimg, const uint8_t* images, size_t im
  *   mcs_extractor_set_describe     exact_only != 0: every keypoint through the exact pass.  guard_eps: half-width of the band (0 = default 2^-24 px);
  *                                  a camera whose bound exceeds guard_eps / 2 runs exact-only by itself.
  *   mcs_extractor_describe_stats   keypoints the exact pass has handled since the extractor was created (fast-pass mode), and the band in use
+ *   mcs_extractor_tie_stats        the checked invariant behind "bit-identical": the smallest distance to a rounding tie (|frac| = 1/2), in pixels, among ALL
+ *                                  cvRound arguments the extractor has computed with the reference's exact arithmetic since creation / the last reset (ORB
+ *                                  rotation :295-296; rotateAndDistortPattern :280-281 in the exact pass) — device libm (ocml) and the reference's (glibc) can
+ *                                  only round such a coordinate differently within ~1e-13 px of a tie.  +inf before the first one.  Fast-pass coordinates are
+ *                                  not listed: they are at least guard_eps from a tie by construction.
  *   mcs_describe_fast_bound        the worst-case coordinate difference the library assumes for a camera and descriptor size
  *   mcs_selftest_describe_fast     n pseudo-random pattern points of camera `cam` through both arithmetics on the device: the largest difference seen
  *                                  (must stay below mcs_describe_fast_bound)
@@ -128,6 +133,7 @@ int mcs_extract_batch(mcs_extractor*, int nimg, const uint8_t* images, size_t im
  *                                  (x G, y G), largest row error the builder itself measured, max Lipschitz bound x (sqrt(s) + 44)}; any output may be NULL                                */
 int mcs_extractor_set_describe(mcs_extractor*, int exact_only, double guard_eps);
 int mcs_extractor_describe_stats(mcs_extractor*, uint64_t* exact_pass_keypoints, double* guard_eps);
+int mcs_extractor_tie_stats(mcs_extractor*, double* min_tie_distance, int reset);
 int mcs_describe_fast_bound(const mcs_ocam* cam, int desc_size, double* bound);
 int mcs_selftest_describe_fast(mcs_ctx*, const mcs_ocam* cam, uint64_t seed, int n, double* max_abs_diff);
 int mcs_describe_fast_table(const mcs_ocam* cam, double* table, int* rows, int* row_len, int* e0, int* bins_per_octave, double* info6);

@@ -161,6 +161,12 @@ class Extractor:
         check(lib().mcs_extractor_describe_stats(self.h, C.byref(n), C.byref(eps)))
         return n.value, eps.value
 
+    def tie_stats(self, reset=False):
+        """smallest distance (pixels) of a cvRound argument of the exact arithmetic to a rounding tie since creation / the last reset (inf: none yet)"""
+        v = C.c_double()
+        check(lib().mcs_extractor_tie_stats(self.h, C.byref(v), int(reset)))
+        return v.value
+
     # ---- stage taps (parity tests)
     def tap_level(self, img, level, blurred=False):
         w, h = self.level_sizes[level]

@@ -228,7 +228,7 @@ struct mcs_extractor {
 	OcamDev* d_cams = nullptr;
 	std::vector<OcamDev> h_cams;
 	// descriptor passes (mcs_describe.hip): fallback list of the fast pass, its running total, the guard band
-	int* d_fbCount = nullptr; uint32_t *d_fbList = nullptr, *d_preList = nullptr; unsigned long long* d_fbStats = nullptr; void* d_aux = nullptr;   // d_fbCount: [0] fallback list, [1] pre-list
+	int* d_fbCount = nullptr; uint32_t *d_fbList = nullptr, *d_preList = nullptr; unsigned long long* d_fbStats = nullptr; unsigned long long* d_tieMin = nullptr; void* d_aux = nullptr;   // d_fbCount: [0] fallback list, [1] pre-list
 	int describeMode = 0; double guardEps = kDefaultGuardEps;
 	// G(s) tables of the cameras seen so far (a rig has a handful), and the batch's distinct tables as the fast pass reads them
 	struct CamFast { OcamDev key; GTabInfo info; std::vector<double> tab; };
@@ -563,6 +563,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	ALLOC(e->d_fbList, B * slotsPerImage * sizeof(uint32_t));
 	ALLOC(e->d_preList, B * slotsPerImage * sizeof(uint32_t));
 	ALLOC(e->d_fbStats, sizeof(unsigned long long));
+	ALLOC(e->d_tieMin, sizeof(unsigned long long));
 	ALLOC(e->d_aux, B * slotsPerImage * describe_aux_bytes());
 	ALLOC(e->d_gTab, B * (size_t)kGTabDoubles * sizeof(double));
 	ALLOC(e->d_nkp, B * sizeof(int));
@@ -578,6 +579,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
 	HIPCHK(hipMemset(e->d_fbCount, 0, 2 * sizeof(int)));
 	HIPCHK(hipMemset(e->d_fbStats, 0, sizeof(unsigned long long)));
+	{ const unsigned long long inf = 0x7FF0000000000000ull; HIPCHK(hipMemcpy(e->d_tieMin, &inf, sizeof(inf), hipMemcpyHostToDevice)); }   // +inf: no coordinate seen yet
 	if (getenv("MCS_DESCRIBE_EXACT")) e->describeMode = 1;   // A/B and debugging: the exact pass for every keypoint
 	HIPCHK(hipMemset(e->d_pyr, 0, B * hd.pyrBytes));
 	HIPCHK(hipMemset(e->d_blur, 0, B * hd.pyrBytes));
@@ -596,7 +598,7 @@ int mcs_extractor_destroy(mcs_extractor* e) {
 	}
 	void* ptrs[] = {e->d_desc, e->d_cells, e->d_taps, e->d_maskMap, e->d_pyr, e->d_blur, e->d_slots, e->d_dense, e->d_knode,
 	                e->d_sel, e->d_cellCount, e->d_denseCount, e->d_selCount, e->d_status, e->d_cams, e->d_nkp, e->d_kps, e->d_odesc,
-	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_preList, e->d_fbStats, e->d_aux, e->d_gTab, e->d_selAngle};
+	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_preList, e->d_fbStats, e->d_tieMin, e->d_aux, e->d_gTab, e->d_selAngle};
 	for (void* p : ptrs) (void)hipFree(p);
 	delete e;
 	return MCS_OK;
@@ -646,7 +648,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 	b.pyr = e->d_pyr; b.blur = e->d_blur; b.slots = e->d_slots; b.cellCount = e->d_cellCount; b.dense = e->d_dense; b.knode = e->d_knode;
 	b.denseCount = e->d_denseCount; b.sel = e->d_sel; b.selCount = e->d_selCount; b.selAngle = e->d_selAngle; b.status = e->d_status;
 	b.gTab = e->d_gTab; b.aux = e->d_aux; b.fbCount = e->d_fbCount; b.fbList = e->d_fbList; b.preCount = e->d_fbCount + 1; b.preList = e->d_preList;
-	b.fbStats = e->d_fbStats; b.guardEps = e->guardEps; b.describeMode = e->describeMode;
+	b.fbStats = e->d_fbStats; b.tieMin = e->d_tieMin; b.guardEps = e->guardEps; b.describeMode = e->describeMode;
 	b.sideStream = nullptr; b.evDescFork = nullptr; b.evDescJoin = nullptr;
 	b.outImgPitch = out_image_pitch_rows ? out_image_pitch_rows : (size_t)hd.kpCap;
 	b.outRowStride = out_row_stride ? out_row_stride : hd.descSize;
@@ -821,6 +823,16 @@ int mcs_extractor_describe_stats(mcs_extractor* e, uint64_t* exact_pass_keypoint
 	HIPCHK(hipMemcpy(&v, e->d_fbStats, sizeof(v), hipMemcpyDeviceToHost));
 	if (exact_pass_keypoints) *exact_pass_keypoints = v;
 	if (guard_eps) *guard_eps = e->guardEps;
+	return MCS_OK;
+}
+
+int mcs_extractor_tie_stats(mcs_extractor* e, double* min_tie_distance, int reset) {
+	if (!e) return fail(MCS_ERR_INVALID, "null");
+	HIPCHK(hipStreamSynchronize(e->ctx->stream));
+	unsigned long long v = 0;
+	HIPCHK(hipMemcpy(&v, e->d_tieMin, sizeof(v), hipMemcpyDeviceToHost));
+	if (min_tie_distance) memcpy(min_tie_distance, &v, sizeof(double));
+	if (reset) { const unsigned long long inf = 0x7FF0000000000000ull; HIPCHK(hipMemcpy(e->d_tieMin, &inf, sizeof(inf), hipMemcpyHostToDevice)); }
 	return MCS_OK;
 }
 

@@ -127,6 +127,7 @@ struct ExtractBuffers {
 	int* fbCount; uint32_t* fbList;      // keypoint slots (image * wavesPerImage + slot) the fast pass handed to the exact pass, this batch
 	int* preCount; uint32_t* preList;    // ... and the ones k_orient_b sent there before the fast pass ran (camera not served, keypoint next to the optical axis)
 	unsigned long long* fbStats;         // running total of both (all batches of the extractor)
+	unsigned long long* tieMin;          // bits of the smallest distance to a rounding tie (| |frac| - 1/2 |, pixels) seen among the cvRound arguments of the EXACT arithmetic
 	hipStream_t sideStream; hipEvent_t evDescFork, evDescJoin;   // optional: the exact pass over preList runs here, beside the fast pass
 	double guardEps;                     // half-width of the guard band around the rounding ties
 	int describeMode;                    // 0 fast + exact fallback, 1 exact pass for every keypoint

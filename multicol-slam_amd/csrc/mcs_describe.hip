@@ -284,6 +284,23 @@ __device__ __forceinline__ bool kp_prologue(const ExtractBuffers& b, int wavesPe
 	return true;
 }
 
+// ---- how close did a cvRound argument of the exact arithmetic come to a tie? -------------------------------------------------------------------------
+// The exact passes (ORB rotation; rotateAndDistortPattern for dBRIEF / mdBRIEF) call ocml's sincos / atan where the reference calls glibc's: results that differ in
+// the last place can only change cvRound(v) if v lies within ~1e-13 px of k + 1/2.  Rather than argue that this is improbable, every such argument is measured:
+// the largest |v - rint(v)| of a wave's coordinates is reduced over the wave and 1/2 minus it — the distance to the nearest tie — lowers a per-extractor minimum
+// (mcs_extractor_tie_stats), which bench.py prints and the -m gpu suite asserts to stay above 1e-10 px.  (Fast-pass coordinates need no entry: the guard band
+// keeps them at least guard_eps from a tie by construction.)  Reference: src/mdBRIEFextractorOct.cpp:280-281, 295-296.
+__device__ __forceinline__ double tie_frac(double v) { return fabs(v - rint(v)); }
+__device__ __forceinline__ void tie_commit(unsigned long long* tieMin, double maxFrac) {
+	if (!tieMin) return;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) maxFrac = fmax(maxFrac, __shfl_xor(maxFrac, o));
+	const double dist = 0.5 - maxFrac;   // >= 0: |v - rint(v)| <= 1/2; exact (both within a binade of 1/2 or smaller)
+	const unsigned long long bits = (unsigned long long)__double_as_longlong(dist);   // non-negative doubles order like their bit patterns
+	// the stored minimum only ever falls: a (possibly stale) plain read that is already smaller spares the atomic — after the first few keypoints almost every wave
+	if ((threadIdx.x & 63) == 0 && bits < *reinterpret_cast<volatile unsigned long long*>(tieMin)) atomicMin(tieMin, bits);
+}
+
 template <int MODE, int NB>   // MODE 0 ORB, 1 dBRIEF, 2 mdBRIEF; NB = descSize/8 ballots.  lds: MODE > 0: [waves][x|y][npoints] coordinates + patch
 __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int wavesPerImage, double* lds, int gw) {   // gw = image * wavesPerImage + slot
 	const PyrDesc& d = *b.desc;
@@ -304,11 +321,14 @@ __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int waves
 		const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
 		const double ang = (double)(angle * DEG2RADf);
 		const double ax = cos(ang), ay = sin(ang);
+		double tie = 0.0;
 		for (int j = 0; j < nballots; ++j) {
 			const int k = j * 64 + lane;
 			const double x0 = c_pattern[4 * k], y0 = c_pattern[4 * k + 1], x1 = c_pattern[4 * k + 2], y1 = c_pattern[4 * k + 3];
-			const int ix0 = __double2int_rn(x0 * ax - y0 * ay), iy0 = __double2int_rn(x0 * ay + y0 * ax);
-			const int ix1 = __double2int_rn(x1 * ax - y1 * ay), iy1 = __double2int_rn(x1 * ay + y1 * ax);
+			const double fx0 = x0 * ax - y0 * ay, fy0 = x0 * ay + y0 * ax, fx1 = x1 * ax - y1 * ay, fy1 = x1 * ay + y1 * ax;
+			const int ix0 = __double2int_rn(fx0), iy0 = __double2int_rn(fy0);
+			const int ix1 = __double2int_rn(fx1), iy1 = __double2int_rn(fy1);
+			tie = fmax(fmax(tie, fmax(tie_frac(fx0), tie_frac(fy0))), fmax(tie_frac(fx1), tie_frac(fy1)));
 			int t0, t1;
 			sm.pair(row, col, iy0, ix0, iy1, ix1, t0, t1);
 			const unsigned long long bits = __ballot(t0 < t1);
@@ -317,6 +337,7 @@ __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int waves
 				*reinterpret_cast<unsigned long long*>(mout + 8 * j) = 0ull;   // descriptorMasks = zeros (:1216)
 			}
 		}
+		tie_commit(b.tieMin, tie);
 		return;
 	}
 
@@ -421,7 +442,7 @@ __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int waves
 	for (int j = 0; j < NB; ++j) { bitsMain[j] = 0ull; agree[j] = ~0ull; }
 	constexpr int npat = MODE == 2 ? 3 : 1;
 	constexpr bool merged = MODE == 2 && MCS_MERGE_CHAINS;
-	double sumAll = 0.0;
+	double sumAll = 0.0, tie = 0.0;
 	if (merged) {
 		// all three patterns first, then ONE dependent add chain: lane 2*pat + c accumulates coordinate c of pattern pat (each of the
 		// six sums still runs p = 0..NP-1 in the reference's order; the other lanes repeat lane 0's work)
@@ -447,8 +468,10 @@ __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int waves
 #pragma unroll
 		for (int j = 0; j < NB; ++j) {
 			const int k = j * 64 + lane;
-			const int ix0 = __double2int_rn(cur[2 * k] - meanX), iy0 = __double2int_rn(cur[YO + 2 * k] - meanY);
-			const int ix1 = __double2int_rn(cur[2 * k + 1] - meanX), iy1 = __double2int_rn(cur[YO + 2 * k + 1] - meanY);
+			const double fx0 = cur[2 * k] - meanX, fy0 = cur[YO + 2 * k] - meanY, fx1 = cur[2 * k + 1] - meanX, fy1 = cur[YO + 2 * k + 1] - meanY;
+			const int ix0 = __double2int_rn(fx0), iy0 = __double2int_rn(fy0);
+			const int ix1 = __double2int_rn(fx1), iy1 = __double2int_rn(fy1);
+			tie = fmax(fmax(tie, fmax(tie_frac(fx0), tie_frac(fy0))), fmax(tie_frac(fx1), tie_frac(fy1)));
 			int t0 = ix0, t1 = iy1;
 			if (!(MCS_ABLATE & 4)) sm.pair(row, col, iy0, ix0, iy1, ix1, t0, t1);
 			const unsigned long long bits = __ballot(t0 < t1);
@@ -463,6 +486,7 @@ __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int waves
 			*reinterpret_cast<unsigned long long*>(mout + 8 * j) = MODE == 2 ? agree[j] : 0ull;
 		}
 	}
+	tie_commit(b.tieMin, tie);
 }
 
 // Two entry points over the same body: the 128-register cap (4 waves per SIMD) pays off wherever the LDS slice of a wave lets 16 waves share a CU;

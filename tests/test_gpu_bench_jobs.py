@@ -47,6 +47,8 @@ def test_full_size_workloads_against_the_oracle(name, args, min_pairs):
     assert cfg["oracle_checked"]["pairs"] >= min_pairs and cfg["oracle_checked"]["images"] >= 6
     assert cfg["matches_per_step_rank0"] > 0 and cfg["pair_distances_per_step"] > 1e9
     assert out["roofline"]["matcher"]["kernel"] == "k_match_mfma"
+    tie = cfg["min_distance_to_a_rounding_tie_px_rank0"]   # the libm assumption as a checked invariant (None: the batch had no exact-pass keypoint)
+    assert tie is None or tie > 1e-10
 
 
 @pytest.mark.parametrize("args", [[], ["--workload", "db", "--frames", "8"]])
@@ -71,6 +73,10 @@ def test_default_run_checks_every_leg():
     assert all(s["oracle_check"] is True for s in out["secondary"]) and out["secondary"][0]["e2e"]["oracle_check"] is True
     assert out["exchange_world1"].get("oracle_check") is True, out["exchange_world1"]
     assert out["cpu_baseline"]["reference_threading"]["cores"] == 3
+    # bit-identical as a per-run statement: no cvRound argument of the exact arithmetic (mdBRIEF fallbacks; every ORB coordinate of the shipped-settings leg)
+    # came within 1e-10 px of a tie — ocml and glibc could only disagree within ~1e-13
+    ties = [out["config"]["min_distance_to_a_rounding_tie_px_rank0"]] + [s["config"]["min_distance_to_a_rounding_tie_px_rank0"] for s in out["secondary"]]
+    assert all(t is None or t > 1e-10 for t in ties) and ties[2] is not None, ties
     for k in ("roofline", "cpu_baseline"):
         assert out[k]
 

@@ -124,3 +124,39 @@ def test_set_describe_argument_checks(G):
     assert G.mcs.lib().mcs_extractor_set_describe(ex.h, 0, 0.6) == G.mcs._capi.MCS_ERR_INVALID
     assert G.mcs.lib().mcs_extractor_set_describe(ex.h, 0, -1.0) == G.mcs._capi.MCS_ERR_INVALID
     ex.close()
+
+
+def test_tie_distance_is_measured_for_the_exact_arithmetic(G):
+    """mcs_extractor_tie_stats: the smallest | |frac(v)| - 1/2 | over the cvRound arguments of the exact arithmetic.  Checked against numpy on the ORB rotation
+    (reference src/mdBRIEFextractorOct.cpp:285-301), on all three modes' real images it must stay far above the ~1e-13 px where device and host libm could
+    round differently, and the fast pass must not feed it (its coordinates are guarded instead)."""
+    import oracle_lib as O
+    cams = G.cams3()
+    img, mask = G.synth.synth_image(2, 0, cams[0]), G.synth.mirror_mask(cams[0])
+    # ORB: every coordinate is measured.  The same minimum from numpy (cos / sin of glibc: the margin is 1e-10, their difference to ocml 1e-16)
+    ex = G.mcs.Extractor(G.ctx(), 754, 480, max_batch=1, nfeatures=300)
+    assert ex.tie_stats() == float("inf")
+    kps = ex.extract_host([img], [mask], [G.mcs.make_ocam(cams[0])])[0][0]
+    got = ex.tie_stats()
+    xy = np.zeros(2 * 16 * 32, np.int32)
+    assert O.lib().orc_pattern(32, O.ptr(xy)) == 512
+    pat = xy.astype(np.float64).reshape(-1, 2)
+    ang = (kps["angle"].astype(np.float32) * np.float32(np.float32(np.pi) / np.float32(180.0))).astype(np.float64)
+    c, s = np.cos(ang)[:, None], np.sin(ang)[:, None]
+    x, y = pat[None, :, 0] * c - pat[None, :, 1] * s, pat[None, :, 0] * s + pat[None, :, 1] * c
+    frac = np.maximum(np.abs(x - np.rint(x)), np.abs(y - np.rint(y)))
+    want = 0.5 - frac.max()
+    assert abs(got - want) < 1e-12 and got > 1e-10, (got, want)
+    assert ex.tie_stats(reset=True) == got and ex.tie_stats() == float("inf")
+    ex.close()
+    # mdBRIEF, default mode: only the keypoints the guard band hands to the exact pass are measured (few or none); exact-only mode: all of them
+    ex = G.mcs.Extractor(G.ctx(), 754, 480, max_batch=1, nfeatures=500, do_dBrief=1, learnMasks=1)
+    ex.extract_host([img], [mask], [G.mcs.make_ocam(cams[0])])
+    n_exact, eps = ex.describe_stats()
+    t_fast = ex.tie_stats(reset=True)
+    assert (t_fast == float("inf")) == (n_exact == 0)
+    ex.set_describe(exact_only=True)
+    ex.extract_host([img], [mask], [G.mcs.make_ocam(cams[0])])
+    t_all = ex.tie_stats()
+    assert 1e-10 < t_all < 1e-3 and t_all <= t_fast   # ~1.5 million coordinates: the closest lies ~1e-7 from a tie
+    ex.close()
