@@ -743,17 +743,32 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 			HIPCHK(hipStreamWaitEvent(s, c->evPyr, 0));
 			launch_fast(b, hd, nimg, s, 1, hd.nlevels);
 		} else {
+		static const int sched = getenv("MCS_SCHED") ? atoi(getenv("MCS_SCHED")) : 3;   // launch order; 3 (default) since round 4, the others for A/B
 		launch_pyramid(b, hd, nimg, c->side, 1, 2);
 		HIPCHK(hipEventRecord(c->evPyr1, c->side));
 		launch_pyramid(b, hd, nimg, c->side, 2, hd.nlevels);
 		HIPCHK(hipEventRecord(c->evPyr, c->side));
 		launch_blur(b, hd, nimg, c->side);
 		HIPCHK(hipEventRecord(c->evBlur, c->side));
+		if (sched == 1) {          // FAST level 0, then every other level in one launch behind the whole chain
+			launch_fast(b, hd, nimg, s, 0, 1);
+			HIPCHK(hipStreamWaitEvent(s, c->evPyr, 0));
+			launch_fast(b, hd, nimg, s, 1, hd.nlevels);
+		} else if (sched == 2) {   // head start for the chain: levels 0 + 1 in one launch once level 1 exists, the rest behind the chain
+			HIPCHK(hipStreamWaitEvent(s, c->evPyr1, 0));
+			launch_fast(b, hd, nimg, s, 0, 2);
+			HIPCHK(hipStreamWaitEvent(s, c->evPyr, 0));
+			launch_fast(b, hd, nimg, s, 2, hd.nlevels);
+		} else if (sched == 3) {   // the whole chain first, then FAST on all levels in one launch (the blur beside it)
+			HIPCHK(hipStreamWaitEvent(s, c->evPyr, 0));
+			launch_fast(b, hd, nimg, s, 0, hd.nlevels);
+		} else {
 		launch_fast(b, hd, nimg, s, 0, 1);           // levels 0 and 1 carry more than half of the FAST work: the rest of the resize chain finishes behind them
 		HIPCHK(hipStreamWaitEvent(s, c->evPyr1, 0));
 		launch_fast(b, hd, nimg, s, 1, 2);
 		HIPCHK(hipStreamWaitEvent(s, c->evPyr, 0));
 		launch_fast(b, hd, nimg, s, 2, hd.nlevels);
+		}
 		}
 		// (holding the previous step's deferred matcher back until here, so that it runs beside the oct-tree / orientation / descriptor kernels instead of
 		// beside FAST and the resize chain: measured, 2.22 -> 2.55 ms per step — the descriptor kernel on the critical path suffers more from the company)
