@@ -761,8 +761,12 @@ __device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const Fas
 		wave_sum2_f64(sumx, sumy, totx, toty);
 		const double meanX = totx * (1.0 / (double)NP), meanY = toty * (1.0 / (double)NP);
 		bad |= !(fabs(meanX) < 16384.0) || !(fabs(meanY) < 16384.0);
-		const double cmx = kFix - meanX, cmy = kFix - meanY;
-		unsigned reach = 0;
+		// the guard's half-width is folded into the addend: the low word of y then reads (fraction + g) mod 2^32, and "within the band of a tie" is low word < 2g —
+		// no integer add per coordinate.  (Where the fraction + g wraps, the carry lands in the high word: such a coordinate is in the band, its keypoint leaves
+		// for the exact pass and the offset is never used.)  The smallest low word of the pattern is kept (v_min3_u32) and compared once.
+		const double gAdd = (double)guardUnits * (1.0 / 4294967296.0);
+		const double cmx = (kFix - meanX) + gAdd, cmy = (kFix - meanY) + gAdd;   // exact: one unit of the last place of kFix - mean is 2^-32 (or more)
+		unsigned reach = 0, minlo = 0xFFFFFFFFu;
 		// rounding, guard and the pair's test in one sweep (the samples of a keypoint that turns out to need the exact pass are wasted, nothing else: its
 		// bits are not written)
 #pragma unroll
@@ -772,7 +776,7 @@ __device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const Fas
 			for (int e = 0; e < 2; ++e) {
 				const double yx = u[2 * j + e] + cmx, yy = v[2 * j + e] + cmy;
 				const unsigned hx = (unsigned)__double2hiint(yx) - kHiBase, hy = (unsigned)__double2hiint(yy) - kHiBase;
-				if (!(MCS_FAST_ABLATE & 4)) bad |= ((unsigned)__double2loint(yx) + guardUnits < 2u * guardUnits) || ((unsigned)__double2loint(yy) + guardUnits < 2u * guardUnits);
+				if (!(MCS_FAST_ABLATE & 4)) minlo = min(minlo, min((unsigned)__double2loint(yx), (unsigned)__double2loint(yy)));
 				reach |= hx | hy;
 				ix[e] = (int)hx - 4096; iy[e] = (int)hy - 4096;
 			}
@@ -782,6 +786,7 @@ __device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const Fas
 			if (pat == 0) bitsMain[j] = bits;
 			else agree[j] &= ~(bits ^ bitsMain[j]);
 		}
+		if (!(MCS_FAST_ABLATE & 4)) bad |= minlo < 2u * guardUnits;
 		if (!(MCS_FAST_ABLATE & 4)) bad |= reach >= 8192u;
 		if (__any(bad)) return false;
 	}
