@@ -43,6 +43,7 @@ import numpy as np  # noqa: E402
 
 MODES = {"orb": (0, 0), "dbrief": (1, 0), "mdbrief": (1, 1)}
 KERNELS = ("pyramid", "fast", "octree", "blur", "describe", "match", "greedy")
+E2E_COPY_WG = "runtime"   # how the e2e leg moves its page-locked buffers unless MCS_E2E_H2D / MCS_E2E_D2H say otherwise (run_e2e)
 POOL = 64   # distinct synthetic multi-frames the stream cycles through: 8 scenes of 8 frames each ((3,1)-px shifts), synth.stream_image
 WORKLOADS = {
     #          ncam  W     H    nfeat  F/GPU  keyframes  name in BASELINE.json
@@ -72,6 +73,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-frames", type=int, default=0, help="multi-frames in the bounded CPU-baseline sample (default: 3 x cpu quota, >= 48)")
     ap.add_argument("--check", action="store_true", help="(default; kept for old command lines) verify the timed output against the oracle")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the timed output (profiling runs)")
+    ap.add_argument("--e2e-sweep", default="", help="A/B of the e2e leg's copy mechanism: comma list of H2D:D2H settings, each 'runtime' or a workgroup count "
+                                                    "(e.g. runtime:runtime,16:16,16:runtime); runs only the headline job and those e2e legs")
     ap.add_argument("--exchange", default="auto", choices=["auto", "nccl1"],
                     help="nccl1: run the N > 1 code path (separate send buffers, asynchronous all_gather_into_tensor on RCCL, work.wait(), three buffer sets, "
                          "matching one step late) at world size 1 over the nccl backend")
@@ -620,10 +623,20 @@ def run_e2e(e, sp, steps, warmup, check=True):
     ev_out = [torch.cuda.Event() for _ in range(NS)]      # outputs of buffer set k copied out
     state = {"i": 0}
 
+    # How the page-locked buffers travel: the library's narrow copy kernel (mcs_copy_narrow: a few workgroups, the CUs stay with the step's kernels) or the
+    # runtime's own copy (torch copy_ -> hipMemcpyAsync, which this runtime executes as chip-wide blit kernels).  MCS_E2E_H2D / MCS_E2E_D2H = "runtime" | "<workgroups>"
+    wg_in, wg_out = (0 if v == "runtime" else int(v) for v in (os.environ.get("MCS_E2E_H2D", E2E_COPY_WG), os.environ.get("MCS_E2E_D2H", E2E_COPY_WG)))
+
+    def travel(dst, src, wg, stream):
+        if wg > 0:
+            e.mcs.check(e.lib.mcs_copy_narrow(e.ctx.h, dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size(), wg, stream.cuda_stream))
+        else:
+            dst.copy_(src, non_blocking=True)
+
     def upload(i):   # images of buffer i: page-locked host memory -> device, on the copy stream, once the kernels no longer read the buffer
         with torch.cuda.stream(cin):
             cin.wait_event(ev_free[i])
-            job.d_imgs[i].copy_(h_img[i], non_blocking=True)
+            travel(job.d_imgs[i], h_img[i], wg_in, cin)
             ev_in[i].record(cin)
 
     def download(k):   # outputs of buffer set k -> page-locked host memory on the second copy stream
@@ -631,7 +644,7 @@ def run_e2e(e, sp, steps, warmup, check=True):
         with torch.cuda.stream(cout):
             cout.wait_event(ev_done[k])
             for src, dst in outs[k]:
-                dst.copy_(src, non_blocking=True)
+                travel(dst, src, wg_out, cout)
             ev_out[k].record(cout)
 
     def step():
@@ -676,12 +689,15 @@ def run_e2e(e, sp, steps, warmup, check=True):
             fn()
         torch.cuda.synchronize(e.dev)
         return round(nbytes * reps / (time.perf_counter() - t0) / 1e9, 1)
-    h2d_rate = rate(lambda: job.d_imgs[0].copy_(h_img[0], non_blocking=True), h2d)
-    d2h_rate = rate(lambda: [dst.copy_(src, non_blocking=True) for src, dst in outs[0]], d2h)
+    with torch.cuda.stream(cin):
+        h2d_rate = rate(lambda: travel(job.d_imgs[0], h_img[0], wg_in, cin), h2d)
+    with torch.cuda.stream(cout):
+        d2h_rate = rate(lambda: [travel(dst, src, wg_out, cout) for src, dst in outs[0]], d2h)
     job.close()
     return {"value": round(feats * steps / elapsed / 1e6, 3), "unit": "Mfeatures/s", "ms_per_step": round(elapsed / steps * 1e3, 4), "oracle_check": checked,
             "oracle_checked": "the page-locked HOST copies of the last step's outputs: %s" % getattr(job, "checked", None),
             "h2d_bytes_per_step": int(h2d), "d2h_bytes_per_step": int(d2h), "h2d_GBps_alone": h2d_rate, "d2h_GBps_alone": d2h_rate,
+            "copy_workgroups": {"h2d": wg_in or "runtime", "d2h": wg_out or "runtime"},
             "what": "host buffers at the boundary: images H2D from page-locked memory (double-buffered, copy stream), keypoints + descriptor|mask blocks + counts + "
                     "match arrays D2H to page-locked memory (second copy stream), overlapped with the neighbouring steps' kernels"}
 
@@ -850,7 +866,14 @@ def main():
         out["speedup_vs_cpu_reference_threading"] = round(out["value"] / cpu["reference_threading"]["value"], 2)
     job.close()
     checks = [out.get("oracle_check")]
-    if e.world == 1 and headline and not args.no_secondary:
+    if e.world == 1 and args.e2e_sweep:
+        out["e2e_sweep"] = {}
+        for item in args.e2e_sweep.split(","):
+            os.environ["MCS_E2E_H2D"], os.environ["MCS_E2E_D2H"] = item.split(":")
+            r = run_e2e(e, sp, args.steps, args.warmup, check)
+            checks.append(r["oracle_check"])
+            out["e2e_sweep"][item] = {k: r[k] for k in ("value", "ms_per_step", "oracle_check", "h2d_GBps_alone", "d2h_GBps_alone")}
+    elif e.world == 1 and headline and not args.no_secondary:
         # further legs of the default run, each bounded: host buffers at the boundary (configs[1] and [2]); the matcher-dominated BASELINE configs[2]; the
         # reference's shipped settings; the N > 1 code path at world size 1 over RCCL
         s2 = min(args.steps, 10)

@@ -34,7 +34,7 @@ extern "C" {
 /* ABI revision of this header: bumped whenever a struct layout or an entry point's signature changes (3: mcs_desc_set carries block_rows / block_pitch_rows
  * since round 2 — callers built against an older header must be recompiled; mcs_describe_fast_table, FAST types 0 / 1 in round 3).  mcs_abi_version() returns
  * the value the LIBRARY was built with: compare it with MCS_ABI_VERSION after dlopen. */
-#define MCS_ABI_VERSION 4
+#define MCS_ABI_VERSION 5
 
 #define MCS_MAX_POLY 16
 #define MCS_MAX_LEVELS 16
@@ -343,6 +343,13 @@ int mcs_rows_valid(mcs_ctx*, const int32_t* nkp_dev, int nimg, int cap, uint8_t*
  * All pointers on the context's GPU; both only enqueue on the context's stream. */
 int mcs_rig_pack_headers(mcs_ctx*, const int32_t* nkp_dev, int nimg, int cap, uint8_t* blocks_dev, int row_stride);
 int mcs_rig_rows_valid(mcs_ctx*, const uint8_t* blocks_dev, int nimg, int cap, int row_stride, uint8_t* valid_dev, int32_t* nkp_out_dev);
+
+/* A copy between page-locked host memory and the device (either direction, or device to device) that occupies at most `workgroups` workgroups of 256
+ * threads instead of the runtime's chip-wide blit kernel: for the images that arrive from the host (the cv::Mat of src/cMultiFrame.cpp:92-216) and the
+ * keypoints / descriptors / matches that leave for it, travelling BESIDE the kernels of the neighbouring steps.  Both pointers must be addressable from the
+ * context's GPU (device memory; hipHostMalloc / hipHostRegister'ed host memory).  16 workgroups saturate PCIe 5 x16.  Enqueues on `hip_stream` (NULL: the
+ * context's stream) and returns; buffers that are not 16-byte aligned relative to each other go through hipMemcpyAsync. */
+int mcs_copy_narrow(mcs_ctx*, void* dst, const void* src, size_t bytes, int workgroups, void* hip_stream);
 
 /* single-pair distances on the device (known-answer / spot checks) */
 int mcs_descriptor_distance(mcs_ctx*, const uint8_t* a, const uint8_t* b, int dim, int* out);

@@ -81,25 +81,33 @@ struct OcamDev {
 #define MCS_G_M 5     // 32 bins per octave, degree 6: 56-byte rows, 54 KB (64 bins, degree 5: 48-byte rows, 0.675 against 0.696 ms, but 92 KB for the same range; 16 bins, degree 8: 0.753 ms)
 #define MCS_G_DEG 6
 #endif
-constexpr int kGM = MCS_G_M, kGDeg = MCS_G_DEG, kGE0 = -10, kGE1 = 24, kGRows = (kGE1 - kGE0) << kGM, kGRow = kGDeg + 1, kGTabDoubles = kGRows * kGRow;
+#ifndef MCS_G_E0
+#define MCS_G_E0 (-10)
+#define MCS_G_E1 24
+#endif
+constexpr int kGM = MCS_G_M, kGDeg = MCS_G_DEG, kGE0 = MCS_G_E0, kGE1 = MCS_G_E1, kGRows = (kGE1 - kGE0) << kGM, kGRow = kGDeg + 1, kGTabDoubles = kGRows * kGRow;
 // The table starts at s = 2^kGE0, i.e. 1/32 pixel from the optical axis: G has a sqrt-type branch point at s = 0 (rho(theta) of a fitted backward polynomial
 // does not vanish exactly on the axis), so only log-spaced bins reach down there.  One keypoint in 200 has the axis inside its pattern's footprint, and of
 // those one in 300 a point within 1/32 px of it: that keypoint takes the exact pass.  (Starting the table at s = 16 sent 1 % of all keypoints there, at
 // s = 2^-6 still 60 per 193 000.)
-constexpr int kSlotAlign = 8;       // keypoint slots per image are a multiple of this (the fast pass walks groups of 8 keypoints of ONE image, a wave each)
+#ifndef MCS_FAST_WAVES
+#define MCS_FAST_WAVES 16   // waves per workgroup of the fast descriptor pass (mcs_describe.hip): they share the camera's table in LDS
+#endif
+constexpr int kSlotAlign = MCS_FAST_WAVES > 8 ? MCS_FAST_WAVES : 8;       // keypoint slots per image are a multiple of this (the fast pass walks groups of 8 keypoints of ONE image, a wave each)
 
 // Per-keypoint scratch of the descriptor passes (mcs_describe.hip), one array per field over all keypoint slots of the batch (thread-per-keypoint kernels
 // write full cache lines).  lvl: -1 no keypoint, else level | kAuxExact if the keypoint is on the exact pass's list already.
 constexpr int kAuxExact = 0x100;
 struct KpAuxSoA {
-	int* lvl; int* rc;                  // level / flags;  row | col << 16
+	int* lvl; int* rc;                  // level (bits 0..7) | flags | row stride of the blurred level << 16;  row | col << 16
+	unsigned* poff;                     // byte offset of the patch origin (row - R, col - R) inside the image's blurred pyramid
 	double* d8;                         // [8][slots]: undistorted keypoint x, y; cos, sin of the (up to) three pattern angles
 	int slots;
-	__host__ __device__ static size_t bytes_per_slot() { return 2 * sizeof(int) + 8 * sizeof(double); }
+	__host__ __device__ static size_t bytes_per_slot() { return 3 * sizeof(int) + 8 * sizeof(double); }
 	__host__ __device__ void carve(void* base, int nslots) {   // nslots is a multiple of kSlotAlign
 		slots = nslots;
 		d8 = reinterpret_cast<double*>(base);
-		lvl = reinterpret_cast<int*>(d8 + (size_t)8 * nslots); rc = lvl + nslots;
+		lvl = reinterpret_cast<int*>(d8 + (size_t)8 * nslots); rc = lvl + nslots; poff = reinterpret_cast<unsigned*>(rc + nslots);
 	}
 };
 struct ExtractBuffers {

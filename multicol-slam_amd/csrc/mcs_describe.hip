@@ -534,9 +534,6 @@ __global__ __launch_bounds__(64) void k_describe_list(ExtractBuffers b, int wave
 #ifndef MCS_FAST_ABLATE
 #define MCS_FAST_ABLATE 0   // A/B experiments only (tools/ab_describe.sh): 1 no sampling, 2 no omni model, 4 no guard / rounding checks
 #endif
-#ifndef MCS_FAST_WAVES
-#define MCS_FAST_WAVES 8
-#endif
 constexpr int kFastWaves = MCS_FAST_WAVES;   // waves per workgroup of the fast pass (each with its own keypoints, all of one image): they share the camera's table in LDS
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -631,6 +628,8 @@ __global__ __launch_bounds__(256) void k_orient_b(ExtractBuffers b, int wavesPer
 	kp.x = pxf; kp.y = pyf; kp.size = L.kpSize; kp.angle = angle; kp.response = (float)(rec >> 24); kp.octave = level; kp.class_id = -1;
 	b.kps[(size_t)img * d.kpCap + s] = kp;
 	A.rc[gw] = row | (col << 16);
+	A.poff[gw] = (unsigned)(L.off + (size_t)(row - kPatchR) * L.stride + (col - kPatchR));   // the fast pass requests the next keypoint's patch from this alone
+	const int lvlWord = level | (L.stride << 16);                                            // (level coordinates < 4096: the stride fits 15 bits)
 	const OcamDev& cam = b.cams[img];
 	double rayx, rayy, rayz;
 	img2world(cam, (double)pxf, (double)pyf, rayx, rayy, rayz);
@@ -650,11 +649,11 @@ __global__ __launch_bounds__(256) void k_orient_b(ExtractBuffers b, int wavesPer
 	// a camera beyond the guard band, or a keypoint whose undistorted position is not finite (a ray in the image plane): not for the fast pass
 	const double n2 = ukx * ukx + uky * uky;
 	if (cam.fastOk == 0 || !(n2 < 1.0e300)) {
-		A.lvl[gw] = level | kAuxExact;
+		A.lvl[gw] = lvlWord | kAuxExact;
 		b.preList[atomicAdd(b.preCount, 1)] = (uint32_t)gw;
 		return;   // the exact pass computes its own angles
 	}
-	A.lvl[gw] = level;
+	A.lvl[gw] = lvlWord;
 	double ang[3] = {0.0, 0.0, 0.0};
 	if (MODE == 1) {
 		const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
@@ -678,7 +677,7 @@ __global__ __launch_bounds__(256) void k_orient_b(ExtractBuffers b, int wavesPer
 #define MCS_FAST_WAVES_PER_EU 4
 #endif
 #ifndef MCS_FAST_BLOCKS
-#define MCS_FAST_BLOCKS 512   // 256 CUs x 2 resident workgroups
+#define MCS_FAST_BLOCKS (4096 / MCS_FAST_WAVES)   // 256 CUs x 16 resident waves (registers: 4 waves per SIMD)
 #endif
 constexpr int kFastBlocks = MCS_FAST_BLOCKS;
 static_assert(kSlotAlign % kFastWaves == 0, "a group's keypoint slots must belong to one image");
@@ -797,13 +796,80 @@ __device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const Fas
 // wave).  The camera's table is loaded into LDS when the camera changes — once per workgroup for a camera-major batch — and there is no barrier inside the
 // walk, so the waves drift apart and one wave's memory round trips (slot record -> patch) hide behind the others' arithmetic.  (One workgroup per 8
 // keypoints spent half its life in the load -> LDS -> barrier prologue: the kernel without model, sampling and guard took 0.36 of 0.71 ms.)
+// ---- the walk, software-pipelined through LDS-DMA --------------------------------------------------------------------------------------------------
+// A wave alone pays three dependent memory round trips per keypoint (slot record -> patch -> LDS: ~4.5 us against ~10 us of arithmetic), and the waves of a
+// SIMD do NOT hide them for each other: every keypoint costs the same, so waves that start together stay in step — they wait together, then compete for the
+// issue slots together (measured: the walk alone 0.24 ms + the arithmetic 0.48 ms = the 0.70 ms of the whole kernel).  So every wave requests AHEAD, with
+// global_load_lds (global memory -> LDS without passing registers: nothing to hold, nothing to spill): at the top of trip k
+//   * the RECORD of keypoint k + 2 — level / stride, row | col, patch offset, undistorted position, the pattern angles' cos / sin (k_orient_b's field arrays)
+//     and the camera's affine terms and table index — into a 32-dword mailbox of the wave (two mailboxes in turn), one request: lane L fetches dword L;
+//   * the PATCH of keypoint k + 1, whose record arrived a trip ago, into the wave's other patch buffer: dword i = 64 t + lane of the patch (row i / kPatchDw,
+//     dword i % kPatchDw) lands at byte 4 i — the layout patch_store writes.
+// Both have a whole trip to arrive; one s_waitcnt vmcnt(0) at the top of a trip covers them (the compiler does not count LDS-DMA requests: the wait is
+// explicit, and every register load of the trip is consumed before the next requests go out, so that no compiler-placed vmcnt(0) waits for them).
+#ifndef MCS_FAST_DMA
+#define MCS_FAST_DMA 1   // 0: the round-3 walk (slot record by loads, patch through registers), for A/B
+#endif
+constexpr int kFastPatchBufs = MCS_FAST_DMA ? 2 : 1;
+constexpr int kMailDwords = 32, kMailBytes = MCS_FAST_DMA ? 2 * kMailDwords * 4 : 0;   // per wave
+constexpr int kMailCam = 19, kMailUsed = 26;   // dwords 0..2 lvl, rc, poff; 3..18 the eight doubles of KpAuxSoA::d8; 19 tabIdx; 20..25 cam.c, cam.d, cam.e
+constexpr size_t kFastWaveLds = (size_t)kFastPatchBufs * kPatchBytes + kMailBytes;
+
+__device__ __forceinline__ void patch_request(const uint8_t* origin, int bstride, uint8_t* patch) {
+	int lane = threadIdx.x & 63;
+	asm volatile("" : "+v"(lane));
+#pragma unroll
+	for (int t = 0; t < kPatchTrips; ++t) {
+		const int i = lane + 64 * t;
+		const int r = i / kPatchDw, k = i - r * kPatchDw;
+		if (64 * (t + 1) <= kPatchRows * kPatchDw || i < kPatchRows * kPatchDw)
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(origin + (size_t)r * bstride + 4 * k),
+			                                 (__attribute__((address_space(3))) void*)(patch + 256 * t), 4, 0, 0);
+	}
+}
+// the record of slot gw (a keypoint of image img) -> mailbox
+__device__ __forceinline__ void record_request(const KpAuxSoA& A, const OcamDev* cams, int gw, int img, uint32_t* mail) {
+	int lane = threadIdx.x & 63;
+	asm volatile("" : "+v"(lane));
+	const size_t S = (size_t)A.slots;
+	const uint32_t* src;
+	if (lane < 3) src = reinterpret_cast<const uint32_t*>(A.lvl) + (size_t)lane * S + gw;            // lvl, rc, poff: three arrays of S words one after the other
+	else if (lane < kMailCam) src = reinterpret_cast<const uint32_t*>(A.d8 + (size_t)((lane - 3) >> 1) * S + gw) + ((lane - 3) & 1);
+	else if (lane == kMailCam) src = reinterpret_cast<const uint32_t*>(&cams[img].tabIdx);
+	else src = reinterpret_cast<const uint32_t*>(&cams[img].c) + (lane - kMailCam - 1);              // c, d, e: the first three doubles of OcamDev
+	if (lane < kMailUsed)
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)mail, 4, 0, 0);
+}
+static_assert(offsetof(OcamDev, c) == 0 && offsetof(OcamDev, d) == 8 && offsetof(OcamDev, e) == 16, "record_request reads c, d, e as six consecutive words");
+
+struct FastKp {   // a mailbox read back: wave-uniform, in SGPRs
+	int lvl, rc; unsigned poff; int tabIdx;
+	double d8[8]; FastCam C;
+	__device__ __forceinline__ bool usable() const { return lvl >= 0 && !(lvl & kAuxExact); }   // a keypoint, and not already on the exact pass's pre-list
+};
+__device__ __forceinline__ int rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ double rfl2(uint32_t lo, uint32_t hi) { return __hiloint2double(rfl(hi), rfl(lo)); }
+__device__ __forceinline__ FastKp mail_read(const uint32_t* mail) {
+	uint4 q[7];
+#pragma unroll
+	for (int i = 0; i < 7; ++i) q[i] = reinterpret_cast<const uint4*>(mail)[i];   // every lane reads the same words (LDS broadcast)
+	const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
+	FastKp r;
+	r.lvl = rfl(w[0]); r.rc = rfl(w[1]); r.poff = (unsigned)rfl(w[2]); r.tabIdx = rfl(w[kMailCam]);
+#pragma unroll
+	for (int i = 0; i < 8; ++i) r.d8[i] = rfl2(w[3 + 2 * i], w[4 + 2 * i]);
+	r.C.c = rfl2(w[20], w[21]); r.C.d = rfl2(w[22], w[23]); r.C.e = rfl2(w[24], w[25]);
+	return r;
+}
+
 template <int MODE, int NB>
 __attribute__((amdgpu_waves_per_eu(MCS_FAST_WAVES_PER_EU, MCS_FAST_WAVES_PER_EU)))
 __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffers b, int wavesPerImage, int nslots, int groupsPerBlock) {
-	extern __shared__ __attribute__((aligned(16))) double lds[];   // the camera's G table (shared, at offset 0: its reads then need no address arithmetic), then the blurred patch of each wave's keypoint
+	extern __shared__ __attribute__((aligned(16))) double lds[];   // the camera's G table (shared, at offset 0: its reads then need no address arithmetic), then per wave: patch buffer(s), mailboxes
 	static_assert(MODE == 1 || MODE == 2, "the fast pass is for the distorted patterns");
-	const int wave = threadIdx.x >> 6;
-	uint8_t* const patchLds = reinterpret_cast<uint8_t*>(lds) + kGTabDoubles * sizeof(double) + (size_t)wave * kPatchBytes;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	uint8_t* const waveLds = reinterpret_cast<uint8_t*>(lds) + kGTabDoubles * sizeof(double) + (size_t)wave * kFastWaveLds;
+	uint32_t* const mailBase = reinterpret_cast<uint32_t*>(waveLds + kFastPatchBufs * kPatchBytes);
 	double* const tabLds = lds;
 	const PyrDesc& d = *b.desc;
 	KpAuxSoA A; A.carve(b.aux, nslots);
@@ -814,15 +880,54 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 	const int nb = (int)gridDim.x, perXcd = (nb + kNumXCD - 1) / kNumXCD;
 	const int logical = nb % kNumXCD == 0 ? ((int)blockIdx.x % kNumXCD) * perXcd + (int)blockIdx.x / kNumXCD : (int)blockIdx.x;   // a bijection on [0, nb) either way
 	const size_t S = (size_t)nslots;
+	const size_t pyrBytes = d.pyrBytes;
 	int curTab = -1;
+#if MCS_FAST_DMA
+	auto slot_of = [&](int kk) { const int g = kk * nb + logical; return kk < groupsPerBlock && g < ngroups ? g * kFastWaves + wave : -1; };
+	auto ask_record = [&](int kk) { const int gw = slot_of(kk); if (gw >= 0) record_request(A, b.cams, gw, gw / wavesPerImage, mailBase + (kk & 1) * kMailDwords); };
+	auto ask_patch = [&](const FastKp& r, int kk) {
+		const int gw = slot_of(kk);
+		if (gw < 0 || !r.usable()) return;
+		patch_request(b.blur + (size_t)(gw / wavesPerImage) * pyrBytes + r.poff, (int)((unsigned)r.lvl >> 16), waveLds + (kk & 1) * kPatchBytes);
+	};
+	// prologue: records 0 and 1, patch 0
+	ask_record(0);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	FastKp nxt = mail_read(mailBase);
+	if (slot_of(0) < 0) nxt.lvl = -1;
+	ask_patch(nxt, 0);
+	ask_record(1);
+#endif
 #pragma unroll 1
 	for (int k = 0; k < groupsPerBlock; ++k) {
 		const int g = k * nb + logical;
 		if (g >= ngroups) break;   // uniform over the workgroup
 		const int base = g * kFastWaves;
 		const int bimg = base / wavesPerImage;   // every slot of a group is a keypoint of the same image
+		const int gwu = base + wave;
+		int lane = threadIdx.x & 63;
+		asm volatile("" : "+v"(lane));   // opaque per trip: nothing derived from the lane id is worth holding in registers across the walk
+		uint32_t ppk[NB];
+#pragma unroll
+		for (int j = 0; j < NB; ++j) ppk[j] = reinterpret_cast<const uint32_t*>(c_pattern)[j * 64 + lane];
+#if MCS_FAST_DMA
+		const FastKp me = nxt;
+		// this keypoint's patch and the next one's record have landed — and so have the pattern words, which are "used" here so that the compiler's own wait for
+		// them cannot fall behind the requests below (a vmcnt(0) there would wait for what was just requested)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+		for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(ppk[j]));
+		nxt = mail_read(mailBase + ((k + 1) & 1) * kMailDwords);
+		if (slot_of(k + 1) < 0) nxt.lvl = -1;
+		ask_patch(nxt, k + 1);   // the other patch buffer: its keypoint (k - 1) is finished
+		ask_record(k + 2);       // the mailbox record k was read from a trip ago
+		const int tabIdx = me.tabIdx;
+		uint8_t* const patchLds = waveLds + (k & 1) * kPatchBytes;
+#else
 		const OcamDev& cam = b.cams[bimg];
 		const int tabIdx = cam.tabIdx;
+		uint8_t* const patchLds = waveLds;
+#endif
 		if (tabIdx != curTab) {   // uniform over the workgroup: every wave walks the same groups
 			if (curTab >= 0) __syncthreads();   // nobody reads the old table any more
 			if (!(MCS_FAST_ABLATE & 8)) {
@@ -837,33 +942,39 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 			__syncthreads();
 			curTab = tabIdx;
 		}
+#if MCS_FAST_DMA
+		if (!me.usable()) continue;   // nothing here, or already on the exact pass's pre-list
+		const int level = me.lvl & 0xFF;
+		const int row = me.rc & 0xFFFF, col = (int)((unsigned)me.rc >> 16);
+		const FastCam C = me.C;
+		const double ukx = me.d8[0], uky = me.d8[1];
+		double axc[3], ays[3];
+#pragma unroll
+		for (int q = 0; q < 3; ++q) { axc[q] = me.d8[2 + 2 * q]; ays[q] = me.d8[3 + 2 * q]; }
+#else
 		// this wave's keypoint as the orientation kernels left it (wave-uniform: scalar loads)
-		const int gwu = __builtin_amdgcn_readfirstlane(base + wave);
-		const int lvlRaw = A.lvl[gwu];
+		const int gws = __builtin_amdgcn_readfirstlane(gwu);
+		const int lvlRaw = A.lvl[gws];
 		if (lvlRaw < 0 || (lvlRaw & kAuxExact)) continue;   // nothing here, or already on the exact pass's pre-list
-		const int level = lvlRaw;
-		const int rc = A.rc[gwu];
+		const int level = lvlRaw & 0xFF;
+		const int rc = A.rc[gws];
 		const int row = rc & 0xFFFF, col = (int)((unsigned)rc >> 16);
 		{
 			const LevelInfo& L = d.lv[level];
 			uint32_t pv[kPatchTrips];
-			patch_load(b.blur + (size_t)bimg * d.pyrBytes + L.off, L.stride, row, col, pv);
+			patch_load(b.blur + (size_t)bimg * pyrBytes + L.off, L.stride, row, col, pv);
 			patch_store(patchLds, pv);   // the previous keypoint's samples are done: same wave, LDS operations stay in order
 		}
-		int lane = threadIdx.x & 63;
-		asm volatile("" : "+v"(lane));   // opaque per trip: nothing derived from the lane id is worth holding in registers across the walk
 		FastCam C;
 		C.c = cam.c; C.d = cam.d; C.e = cam.e;
-		uint32_t ppk[NB];
-#pragma unroll
-		for (int j = 0; j < NB; ++j) ppk[j] = reinterpret_cast<const uint32_t*>(c_pattern)[j * 64 + lane];
-		LazySampler sm;
-		sm.b = &b; sm.img = bimg; sm.level = level; sm.patch = patchLds;
-		const double* D8 = A.d8 + gwu;
+		const double* D8 = A.d8 + gws;
 		const double ukx = D8[0], uky = D8[S];
 		double axc[3], ays[3];
 #pragma unroll
-		for (int k = 0; k < 3; ++k) { axc[k] = D8[(2 + 2 * k) * S]; ays[k] = D8[(3 + 2 * k) * S]; }
+		for (int q = 0; q < 3; ++q) { axc[q] = D8[(2 + 2 * q) * S]; ays[q] = D8[(3 + 2 * q) * S]; }
+#endif
+		LazySampler sm;
+		sm.b = &b; sm.img = bimg; sm.level = level; sm.patch = patchLds;
 		unsigned long long bitsMain[NB], agree[NB];
 		const bool ok = fast_keypoint<MODE, NB>(b, C, tabLds, sm, row, col, ukx, uky, axc, ays, ppk, bitsMain, agree);
 		if (lane == 0) {
@@ -880,6 +991,7 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 			}
 		}
 	}
+	(void)S; (void)d;
 }
 
 // self-test of the fast arithmetic: n pseudo-random pattern points around random keypoints of camera `cam` through fast_w2i and through the exact
@@ -922,7 +1034,7 @@ static void launch_fast_passes(const ExtractBuffers& b, int nimg, int wavesPerIm
 	const int groupsPerBlock = std::max(1, (ngroups + kFastBlocks - 1) / kFastBlocks);
 	int fblocks = (ngroups + groupsPerBlock - 1) / groupsPerBlock;
 	if (fblocks >= kNumXCD) fblocks = (fblocks + kNumXCD - 1) / kNumXCD * kNumXCD;   // whole XCD rounds: the kernel's block -> group mapping is XCD-contiguous
-	const size_t fLds = (size_t)kFastWaves * kPatchBytes + kGTabDoubles * sizeof(double);
+	const size_t fLds = (size_t)kFastWaves * kFastWaveLds + kGTabDoubles * sizeof(double);
 	// PRECONDITION: fbCount and preCount — neighbours — were cleared by k_octree's first workgroup, i.e. every launch_describe follows a launch_octree of the same
 	// batch on the same stream, and the previous batch's side-stream pre-list kernel has been joined (the evDescJoin wait below); extract_impl in mcs_capi.hip is
 	// the only caller and keeps that order

@@ -1,0 +1,57 @@
+"""mcs_copy_narrow: the few-workgroup copy between page-locked host memory and the device (the way images arrive from and results leave for the host
+beside the step's kernels, src/cMultiFrame.cpp:92-216) moves exactly the bytes it is given — every alignment, head / body / tail split and direction."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gpu_common as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _pinned(nbytes):
+    hip = G.hip()
+    hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipHostFree.argtypes = [C.c_void_p]
+    p = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(p), nbytes, 0) == 0
+    arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+    return p, arr
+
+
+@pytest.mark.parametrize("nbytes,off,wg", [(1 << 20, 0, 16), (1 << 20, 16, 1), (1000003, 5, 8), (4097, 15, 16), (17, 3, 4), (15, 1, 2), (3 * 754 * 480, 0, 32)])
+def test_host_to_device_and_back(nbytes, off, wg):
+    ctx = G.ctx()
+    L = G.mcs.lib()
+    rng = np.random.default_rng(nbytes + off)
+    p_in, h_in = _pinned(nbytes + 64)
+    p_out, h_out = _pinned(nbytes + 64)
+    h_in[:] = rng.integers(0, 256, nbytes + 64, dtype=np.uint8)
+    h_out[:] = 0
+    dev = G.DevBuf(np.zeros(nbytes + 64, np.uint8))
+    # host -> device (same offset on both sides: mutually aligned), device -> host
+    G.mcs.check(L.mcs_copy_narrow(ctx.h, dev.ptr.value + off, p_in.value + off, nbytes, wg, None))
+    G.mcs.check(L.mcs_copy_narrow(ctx.h, p_out.value + off, dev.ptr.value + off, nbytes, wg, None))
+    G.mcs.check(L.mcs_ctx_synchronize(ctx.h))
+    got = dev.read()
+    assert (got[off:off + nbytes] == h_in[off:off + nbytes]).all()
+    assert not got[:off].any() and not got[off + nbytes:].any()          # nothing outside the range was touched
+    assert (h_out[off:off + nbytes] == h_in[off:off + nbytes]).all()
+    assert not h_out[:off].any() and not h_out[off + nbytes:].any()
+    # mutually misaligned buffers take the runtime's copy: same bytes
+    h_out[:] = 0
+    G.mcs.check(L.mcs_copy_narrow(ctx.h, p_out.value + off + 1, dev.ptr.value + off, nbytes, wg, None))
+    G.mcs.check(L.mcs_ctx_synchronize(ctx.h))
+    assert (h_out[off + 1:off + 1 + nbytes] == h_in[off:off + nbytes]).all()
+    G.hip().hipHostFree(p_in)
+    G.hip().hipHostFree(p_out)
+
+
+def test_bad_arguments():
+    ctx = G.ctx()
+    L = G.mcs.lib()
+    dev = G.DevBuf(np.zeros(64, np.uint8))
+    assert L.mcs_copy_narrow(ctx.h, None, dev.ptr, 64, 4, None) != 0
+    assert L.mcs_copy_narrow(ctx.h, dev.ptr, dev.ptr, 64, 0, None) != 0
+    assert L.mcs_copy_narrow(ctx.h, dev.ptr, dev.ptr, 0, 4, None) == 0
