@@ -38,12 +38,14 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # multi-process GPU work on these hosts needs dmabuf IPC (without it RCCL fails with hipIpcGetMemHandle: invalid argument); exported on the boxes, kept here for a bare environment
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# the oracle (checks, CPU baseline) is OpenMP code: its idle worker threads must not spin on the CPUs the host thread enqueues from (libgomp reads this when it loads)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 import numpy as np  # noqa: E402
 
 MODES = {"orb": (0, 0), "dbrief": (1, 0), "mdbrief": (1, 1)}
 KERNELS = ("pyramid", "fast", "octree", "blur", "describe", "match", "greedy")
-E2E_COPY_WG = "runtime"   # how the e2e leg moves its page-locked buffers unless MCS_E2E_H2D / MCS_E2E_D2H say otherwise (run_e2e)
+E2E_H2D, E2E_D2H = "runtime", "2"   # how the e2e leg moves its page-locked buffers unless MCS_E2E_H2D / MCS_E2E_D2H say otherwise (run_e2e): the runtime's SDMA copy in, mcs_copy_narrow with TWO workgroups out (they saturate the link's write direction; more of them stall every other kernel's memory traffic)
 POOL = 64   # distinct synthetic multi-frames the stream cycles through: 8 scenes of 8 frames each ((3,1)-px shifts), synth.stream_image
 WORKLOADS = {
     #          ncam  W     H    nfeat  F/GPU  keyframes  name in BASELINE.json
@@ -606,28 +608,53 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True, check=True):
 
 # ------------------------------------------------------------------------------------------------ end-to-end (host buffers in and out)
 def run_e2e(e, sp, steps, warmup, check=True):
-    """The same step with the boundary's host buffers: images start in page-locked host memory (double-buffered H2D on a copy stream), keypoints,
-    descriptor | mask blocks, counts and match arrays end in page-locked host memory (D2H on a second copy stream), both overlapped with the compute of
-    the neighbouring steps.  N = 1 only."""
+    """The same step with the boundary's host buffers: images start in page-locked host memory (three device buffers in turn, hipMemcpyAsync = the SDMA engine, on a copy
+    stream), keypoints, descriptor | mask blocks, counts and match arrays end in page-locked host memory (mcs_copy_narrow, two workgroups, on the context's result
+    stream right behind the search that completes them), both overlapped with the compute of the neighbouring steps.  N = 1 only."""
     torch = e.torch
-    job = Job(e, sp, n_image_buffers=2, n_sets=3)
+    NI = int(os.environ.get("MCS_E2E_IMAGE_BUFFERS", "3"))   # image buffers on the device: the upload runs up to two steps ahead
+    job = Job(e, sp, n_image_buffers=NI, n_sets=3)
     NS = job.nsets
-    cin, cout = torch.cuda.Stream(device=e.dev), torch.cuda.Stream(device=e.dev)
-    h_img = [torch.from_numpy(job.imgs_np.copy()).pin_memory() for _ in range(2)]
+    upload_conflicts = None
+    if os.environ.get("MCS_E2E_STREAMS", "probed").startswith("prio:"):   # A/B: explicit priorities (-1 high, 0 normal, 1 low), e.g. prio:0:1
+        hip = C.CDLL("libamdhip64.so")
+        hs = []
+        for pr in os.environ["MCS_E2E_STREAMS"].split(":")[1:3]:
+            h = C.c_void_p()
+            assert hip.hipStreamCreateWithPriority(C.byref(h), 1, int(pr)) == 0
+            hs.append(h)
+        cin, cout = (torch.cuda.ExternalStream(h.value, device=e.dev) for h in hs)
+    elif os.environ.get("MCS_E2E_STREAMS", "probed") == "probed":   # the upload stream the library picked by probing the hardware queues (mcs_ctx_upload_stream)
+        h, m = C.c_void_p(), C.c_uint()
+        e.mcs.check(e.lib.mcs_ctx_upload_stream(e.ctx.h, C.byref(h), C.byref(m)))
+        upload_conflicts = m.value
+        cin, cout = torch.cuda.ExternalStream(h.value, device=e.dev), torch.cuda.Stream(device=e.dev)
+    elif os.environ.get("MCS_E2E_STREAMS", "plain") == "null":   # the uploads on the device's null stream (no new stream, no new pairing with a hardware queue)
+        cin, cout = torch.cuda.default_stream(e.dev), torch.cuda.Stream(device=e.dev)
+    else:                                                   # two plain streams (cout only serves MCS_E2E_OUT=stream)
+        cin, cout = torch.cuda.Stream(device=e.dev), torch.cuda.Stream(device=e.dev)
+    if os.environ.get("MCS_E2E_DIAG"):
+        m = C.c_uint()
+        e.mcs.check(e.lib.mcs_ctx_stream_conflicts(e.ctx.h, cin.cuda_stream, C.byref(m)))
+        sys.stderr.write("e2e diag: upload stream shares a hardware queue with context streams (bit 0 main, 1 side, 2 matcher, 3 greedy): 0x%x\n" % m.value)
+    h_img = [torch.from_numpy(job.imgs_np.copy()).pin_memory() for _ in range(NI)]
     outs = []
     for b in job.sets:
         outs.append([(t, torch.empty(t.shape, dtype=t.dtype).pin_memory()) for t in (b.send, b.nkp, b.kps, b.match, b.nmatch)])
-    ev_in = [torch.cuda.Event() for _ in range(2)]
-    ev_free = [torch.cuda.Event() for _ in range(2)]      # compute no longer reads image buffer i
+    ev_in = [torch.cuda.Event() for _ in range(NI)]
+    ev_free = [torch.cuda.Event() for _ in range(NI)]     # compute no longer reads image buffer i
     ev_done = [torch.cuda.Event() for _ in range(NS)]     # outputs of buffer set k complete
     ev_out = [torch.cuda.Event() for _ in range(NS)]      # outputs of buffer set k copied out
-    state = {"i": 0}
+    state = {"i": 0, "worst": [0.0] * 4}
 
-    # How the page-locked buffers travel: the library's narrow copy kernel (mcs_copy_narrow: a few workgroups, the CUs stay with the step's kernels) or the
-    # runtime's own copy (torch copy_ -> hipMemcpyAsync, which this runtime executes as chip-wide blit kernels).  MCS_E2E_H2D / MCS_E2E_D2H = "runtime" | "<workgroups>"
-    wg_in, wg_out = (0 if v == "runtime" else int(v) for v in (os.environ.get("MCS_E2E_H2D", E2E_COPY_WG), os.environ.get("MCS_E2E_D2H", E2E_COPY_WG)))
+    # How the page-locked buffers travel: the runtime's own copy (torch copy_ -> hipMemcpyAsync: host -> device goes through the SDMA engine and occupies no CU;
+    # device -> host runs as chip-wide blit kernels beside the step's kernels) or the library's narrow copy kernel (mcs_copy_narrow: a few workgroups).  Measured
+    # (profiles/r04): H2D runtime + D2H narrow is the fast pairing; a narrow kernel reading host memory is the slow one.  MCS_E2E_H2D / MCS_E2E_D2H = "runtime" | "<workgroups>"
+    wg_in, wg_out = (0 if v == "runtime" else -1 if v == "off" else int(v) for v in (os.environ.get("MCS_E2E_H2D", E2E_H2D), os.environ.get("MCS_E2E_D2H", E2E_D2H)))
 
     def travel(dst, src, wg, stream):
+        if wg < 0:      # "off": A/B of the leg's event structure without the copy (run with --no-check)
+            return
         if wg > 0:
             e.mcs.check(e.lib.mcs_copy_narrow(e.ctx.h, dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size(), wg, stream.cuda_stream))
         else:
@@ -647,32 +674,94 @@ def run_e2e(e, sp, steps, warmup, check=True):
                 travel(dst, src, wg_out, cout)
             ev_out[k].record(cout)
 
+    # Results leave on the RESULT stream (mcs_ctx_result_stream: the greedy pass's), right behind the search that completes them — no event in front, no further
+    # stream — unless MCS_E2E_OUT=stream asks for the round-3 form (a copy stream of its own, ordered by an event, two steps late).
+    on_result = os.environ.get("MCS_E2E_OUT", "result") == "result"
+    if on_result:
+        h = C.c_void_p()
+        e.mcs.check(e.lib.mcs_ctx_result_stream(e.ctx.h, C.byref(h)))
+        rstream = torch.cuda.ExternalStream(h.value, device=e.dev)
+
+    def download_behind_search(k):
+        with torch.cuda.stream(rstream):
+            for src, dst in outs[k]:
+                travel(dst, src, wg_out, rstream)
+            ev_out[k].record(rstream)
+
+    # The host stays at most AHEAD steps in front of the GPU (it waits for the results of step n - AHEAD to have reached host memory — which a live caller does
+    # anyway, it consumes them): run far ahead, the runtime's H2D copy call blocks the host for 7-14 ms at a time every few dozen steps and the GPU runs dry behind it
+    AHEAD = int(os.environ.get("MCS_E2E_AHEAD", "3"))
+
+    MARK = int(os.environ.get("MCS_E2E_MARK", "1"))
+    marks = [torch.cuda.Event(enable_timing=MARK == 1) for _ in range(8)]
+
     def step():
         n = state["i"]
-        i = n & 1
+        i = n % NI
         state["i"] += 1
         k = n % NS
+        if AHEAD and n >= AHEAD and on_result and AHEAD <= NS:
+            ev_out[(n - AHEAD) % NS].synchronize()
         e.stream.wait_event(ev_in[i])                     # this step's images (uploaded while the previous step computed)
         e.stream.wait_event(ev_out[k])                    # the output set about to be overwritten has been copied out
         e.mcs.check(e.lib.mcs_ctx_search_fence(e.ctx.h, 1))   # the deferred search of step n - 2 is complete (it ran beside the extraction of step n - 1)
-        if n >= 2:
+        if n >= 2 and not on_result:
             download((n - 2) % NS)                        # ... so its match arrays (and the rest of that set) leave now, two steps late
         b = job.sets[k]
         job.cur = (k + 1) % NS
+        t1 = time.perf_counter()
         job.extract_and_exchange(b, i)
         ev_free[i].record(e.stream)
-        upload(i ^ 1)                                     # the next step's images travel while this step computes
+        t2 = time.perf_counter()
+        upload((n + NI - 1) % NI)                         # the images of step n + NI - 1 travel while this and the following steps compute (NI = 2: the next step's)
+        t3 = time.perf_counter()
         job.match(b)
         job.matched_set = b
+        t4 = time.perf_counter()
+        if on_result:
+            download_behind_search(k)                     # behind this step's greedy pass: the set leaves during the next step
+        if MARK:
+            marks[n % len(marks)].record(e.stream)
+        t5 = time.perf_counter()
+        for j, dt in enumerate((t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+            state["worst"][j] = max(state["worst"][j], dt * 1e3)
+        state.setdefault("log", []).append((round((t1 - state.setdefault("t00", t1)) * 1e3, 2), round((t3 - t2) * 1e3, 2), round((t5 - t1) * 1e3, 2)))
 
     for ev in ev_free + ev_out:
         ev.record(e.stream)
-    upload(0)
+    for i0 in range(NI - 1):
+        upload(i0)
+    # This leg is timed in its steady state.  Per process the runtime's H2D path goes through two settling phases, each ended by a 7-10 ms block of the host inside the
+    # copy call four uploads after a device-wide synchronisation; until both are through, a step takes 1.93 instead of 1.60 ms (per-step log: MCS_E2E_DIAG=1).  Two
+    # untimed rounds of steps, each closed by a synchronisation, put them in front of the clock.
+    for _ in range(2):
+        for _ in range(8):
+            step()
+        sync_all(e)
     elapsed = timed(e, step, warmup, steps, job.status)
+    if os.environ.get("MCS_E2E_DIAG"):                    # where do slow steps come from: the spread of the per-step intervals on the GPU and of the host's enqueue time
+        evs, host = [], []
+        for _ in range(60):
+            t0 = time.perf_counter()
+            step()
+            host.append((time.perf_counter() - t0) * 1e3)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(e.stream)
+            evs.append(ev)
+        torch.cuda.synchronize(e.dev)
+        gaps = sorted(a.elapsed_time(b) for a, b in zip(evs, evs[1:]))
+        sys.stderr.write("e2e diag: GPU step interval min %.3f median %.3f p90 %.3f max %.3f ms; host step() median %.3f max %.3f ms\n"
+                         % (gaps[0], gaps[len(gaps) // 2], gaps[int(len(gaps) * 0.9)], gaps[-1], sorted(host)[len(host) // 2], max(host)))
+        sys.stderr.write("e2e diag: host %s\n" % " ".join("%.2f" % h for h in host))
+        sys.stderr.write("e2e diag: (index: start ms, upload ms, step ms) of every step over 2.3 ms or with a slow upload call: %s\n"
+                         % " ".join("%d:%s/%s/%s" % ((j,) + x) for j, x in enumerate(state["log"]) if x[1] > 1.0 or x[2] > 2.3))
+        lg = state["log"]
+        sys.stderr.write("e2e diag: step starts (ms): %s\n" % " ".join("%.1f" % x[0] for x in lg))
+        sys.stderr.write("e2e diag: slowest host call of a step (ms): extract %.2f upload %.2f match %.2f download %.2f\n" % tuple(state["worst"]))
     e.mcs.check(e.lib.mcs_ctx_join(e.ctx.h))
     n = state["i"]
     for m in (n - 2, n - 1):                              # the last two steps' outputs
-        if m >= 0:
+        if m >= 0 and not on_result:
             download(m % NS)
     torch.cuda.synchronize(e.dev)
     feats = job.local_features()
@@ -697,9 +786,10 @@ def run_e2e(e, sp, steps, warmup, check=True):
     return {"value": round(feats * steps / elapsed / 1e6, 3), "unit": "Mfeatures/s", "ms_per_step": round(elapsed / steps * 1e3, 4), "oracle_check": checked,
             "oracle_checked": "the page-locked HOST copies of the last step's outputs: %s" % getattr(job, "checked", None),
             "h2d_bytes_per_step": int(h2d), "d2h_bytes_per_step": int(d2h), "h2d_GBps_alone": h2d_rate, "d2h_GBps_alone": d2h_rate,
-            "copy_workgroups": {"h2d": wg_in or "runtime", "d2h": wg_out or "runtime"},
-            "what": "host buffers at the boundary: images H2D from page-locked memory (double-buffered, copy stream), keypoints + descriptor|mask blocks + counts + "
-                    "match arrays D2H to page-locked memory (second copy stream), overlapped with the neighbouring steps' kernels"}
+            "copy_workgroups": {"h2d": wg_in or "runtime", "d2h": wg_out or "runtime"}, "upload_stream_queue_conflicts": upload_conflicts,
+            "what": "host buffers at the boundary: images H2D from page-locked memory (three device buffers in turn, the runtime's SDMA copy on a copy stream), keypoints + "
+                    "descriptor|mask blocks + counts + match arrays D2H to page-locked memory (mcs_copy_narrow on the context's result stream, behind the step's greedy "
+                    "pass), overlapped with the neighbouring steps' kernels; outputs leave one step late"}
 
 
 # ------------------------------------------------------------------------------------------------ oracle legs
@@ -857,13 +947,8 @@ def main():
     job, out = run_job(e, sp, args, args.steps, args.warmup, check=check)
     headline = args.workload == "stream" and args.mode == "mdbrief" and not (args.ncam or args.width or args.height or args.nfeatures or args.keyframes >= 0
                                                                                or args.frames or args.exchange != "auto")
-    cpu = None
-    if e.rank == 0 and e.world == 1 and headline and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, e, sp, job)
-    out["cpu_baseline"] = cpu
-    if cpu:
-        out["speedup_vs_cpu_all_cores"] = round(out["value"] / cpu["value"], 2)
-        out["speedup_vs_cpu_reference_threading"] = round(out["value"] / cpu["reference_threading"]["value"], 2)
+    out["cpu_baseline"] = None   # filled in LAST (below): the oracle's OpenMP threads keep spinning for a while after their last parallel region, on the same 16 CPUs
+                                 # the host thread needs for the legs that follow (measured: the e2e leg right behind the baseline 2.36 instead of 1.66 ms per step)
     job.close()
     checks = [out.get("oracle_check")]
     if e.world == 1 and args.e2e_sweep:
@@ -902,6 +987,11 @@ def main():
         except Exception as ex:   # an environment without a usable RCCL is reported, not hidden; a wrong RESULT is a failed check above
             out["exchange_world1"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
         e.exchange = False
+    if e.rank == 0 and e.world == 1 and headline and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, e, sp, job)
+        out["cpu_baseline"] = cpu
+        out["speedup_vs_cpu_all_cores"] = round(out["value"] / cpu["value"], 2)
+        out["speedup_vs_cpu_reference_threading"] = round(out["value"] / cpu["reference_threading"]["value"], 2)
     failed = check and e.rank == 0 and any(c is False for c in checks)
     if e.dist.is_initialized():
         e.dist.barrier()

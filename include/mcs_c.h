@@ -345,11 +345,25 @@ int mcs_rig_pack_headers(mcs_ctx*, const int32_t* nkp_dev, int nimg, int cap, ui
 int mcs_rig_rows_valid(mcs_ctx*, const uint8_t* blocks_dev, int nimg, int cap, int row_stride, uint8_t* valid_dev, int32_t* nkp_out_dev);
 
 /* A copy between page-locked host memory and the device (either direction, or device to device) that occupies at most `workgroups` workgroups of 256
- * threads instead of the runtime's chip-wide blit kernel: for the images that arrive from the host (the cv::Mat of src/cMultiFrame.cpp:92-216) and the
- * keypoints / descriptors / matches that leave for it, travelling BESIDE the kernels of the neighbouring steps.  Both pointers must be addressable from the
- * context's GPU (device memory; hipHostMalloc / hipHostRegister'ed host memory).  16 workgroups saturate PCIe 5 x16.  Enqueues on `hip_stream` (NULL: the
- * context's stream) and returns; buffers that are not 16-byte aligned relative to each other go through hipMemcpyAsync. */
+ * threads instead of the runtime's chip-wide blit kernel: for the keypoints / descriptors / matches that leave for the host (the cv::KeyPoint vectors and
+ * cv::Mat descriptors of src/cMultiFrame.cpp:92-216) BESIDE the kernels of the neighbouring steps.  Both pointers must be addressable from the context's GPU
+ * (device memory; hipHostMalloc / hipHostRegister'ed host memory).  Towards the host TWO workgroups saturate PCIe 5 x16 (48 GB/s) — more of them stall the
+ * memory traffic of every kernel running beside the copy.  Images coming FROM the host are better served by hipMemcpyAsync (SDMA engine).  Enqueues on
+ * `hip_stream` (NULL: the context's stream) and returns; buffers that are not 16-byte aligned relative to each other go through hipMemcpyAsync. */
 int mcs_copy_narrow(mcs_ctx*, void* dst, const void* src, size_t bytes, int workgroups, void* hip_stream);
+/* The stream on which the outputs of the latest mcs_search_* call on device memory become complete IN STREAM ORDER (the greedy pass's stream; the context's own
+ * stream when nothing is overlapped).  Results leave for the host from here without an event in front and without another stream: enqueue mcs_copy_narrow on it
+ * right after the search call, record an event behind the copies, and wait for that event before the buffers are written again. */
+int mcs_ctx_result_stream(mcs_ctx*, void** hip_stream);
+/* Images arrive from the host by hipMemcpyAsync on a stream of the caller's — and which HARDWARE QUEUE that stream gets is the runtime's choice: HIP streams
+ * are dealt onto four queues, a queue runs its packets in order, and an upload holds its queue for its whole duration (1.3 ms for the 69.5 MB of a default step): on
+ * the queue of the context's main stream it adds that to every step (measured: 1.6 against 3.0 ms per step, alternating from one stream to the next).
+ *   mcs_ctx_stream_conflicts   bit i of *mask: `hip_stream` shares a queue with the context's stream i (0 main, 1 extraction side stream, 2 deferred matcher,
+ *                              3 greedy pass = result stream); probes with a held kernel and a marker, ~2 ms, synchronises the streams involved
+ *   mcs_ctx_upload_stream      a stream created and probed by the library until one shares a queue with none of the context's streams or only with the
+ *                              deferred matcher's, which has a step of slack (owned by the context; *conflicts = its mask, may be NULL) */
+int mcs_ctx_stream_conflicts(mcs_ctx*, void* hip_stream, unsigned* mask);
+int mcs_ctx_upload_stream(mcs_ctx*, void** hip_stream, unsigned* conflicts);
 
 /* single-pair distances on the device (known-answer / spot checks) */
 int mcs_descriptor_distance(mcs_ctx*, const uint8_t* a, const uint8_t* b, int dim, int* out);

@@ -267,8 +267,19 @@ int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
 	if (getenv("MCS_NO_OVERLAP") == nullptr) {
 		// (stream priorities — resize chain urgent, deferred matcher least urgent or most urgent, and every other combination — change nothing measurable)
 		HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-		HIPCHK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
-		HIPCHK(hipStreamCreateWithFlags(&c->side3, hipStreamNonBlocking));
+		// A/B: MCS_MATCH_CU_MASK=<hex word> confines the deferred matcher's stream (MCS_GREEDY_CU_MASK: the greedy pass's) to the CUs whose bit is set in the word,
+		// repeated over the chip's CUs — its workgroups (3 waves per SIMD at 168 registers) otherwise leave no room for anybody else on the CUs they hold
+		auto masked = [&](hipStream_t* st, const char* var) -> hipError_t {
+			const char* m = getenv(var);
+			if (!m || !*m) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+			uint32_t words[16];
+			for (auto& w : words) w = (uint32_t)strtoul(m, nullptr, 16);
+			hipDeviceProp_t prop;
+			if (hipGetDeviceProperties(&prop, device) != hipSuccess) return hipErrorInvalidValue;
+			return hipExtStreamCreateWithCUMask(st, (uint32_t)((prop.multiProcessorCount + 31) / 32), words);
+		};
+		HIPCHK(masked(&c->side2, "MCS_MATCH_CU_MASK"));
+		HIPCHK(masked(&c->side3, "MCS_GREEDY_CU_MASK"));
 		HIPCHK(hipEventCreateWithFlags(&c->evLists, hipEventDisableTiming));
 		for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&c->evGreedyBuf[i], hipEventDisableTiming));
 
@@ -330,6 +341,7 @@ int mcs_ctx_destroy(mcs_ctx* c) {
 		(void)hipEventDestroy(c->evDescFork); (void)hipEventDestroy(c->evDescJoin);
 		(void)hipStreamDestroy(c->side);
 	}
+	for (hipStream_t ps : c->probed) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
 	if (c->ownStream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return MCS_OK;

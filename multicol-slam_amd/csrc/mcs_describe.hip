@@ -136,15 +136,18 @@ __device__ __forceinline__ void img2world(const OcamDev& cam, double u, double v
 #endif
 constexpr int kPatchR = MCS_PATCH_R, kPatchRows = 2 * kPatchR + 1, kPatchDw = (kPatchRows + 3) / 4, kPatchPitch = 4 * kPatchDw;
 constexpr int kPatchBytes = (kPatchRows * kPatchPitch + 15) / 16 * 16;
+// the fast pass's patch rows are 16-byte multiples: a row is requested by (kFPitch / 16) lanes of one global_load_lds_dwordx4
+constexpr int kFPitch = (kPatchRows + 15) / 16 * 16, kFPatchBytes = kPatchRows * kFPitch;
 
 struct Sampler {
 	const uint8_t* blur; int bstride;
 	const uint8_t* raw; int rstride;
 	int w, h;
 	const uint8_t* patch; int prow, pcol;   // LDS patch and the level coordinates of its origin
+	template <int PITCH = kPatchPitch>
 	__device__ __forceinline__ int at(int r, int c) const {
 		const unsigned pr = (unsigned)(r - prow), pc = (unsigned)(c - pcol);
-		if (pr < (unsigned)kPatchRows && pc < (unsigned)kPatchRows) return patch[pr * kPatchPitch + pc];
+		if (pr < (unsigned)kPatchRows && pc < (unsigned)kPatchRows) return patch[pr * PITCH + pc];
 		if ((unsigned)r < (unsigned)h && (unsigned)c < (unsigned)w) return blur[(size_t)r * bstride + c];
 		r = r < -kEdge ? -kEdge : (r > h + kEdge - 1 ? h + kEdge - 1 : r);   // clamp to the bordered buffer
 		c = c < -kEdge ? -kEdge : (c > w + kEdge - 1 ? w + kEdge - 1 : c);
@@ -548,8 +551,9 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // sum, like the shuffle form (describe_fast_bound counts its roundings, not its order).
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
-	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+	const int vl = __double2loint(v), vh = __double2hiint(v);   // old = the source itself: every lane is written (full row / bank masks), no zero to set up
+	const int lo = __builtin_amdgcn_update_dpp(vl, vl, CTRL, 0xF, 0xF, false);
+	const int hi = __builtin_amdgcn_update_dpp(vh, vh, CTRL, 0xF, 0xF, false);
 	return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ void wave_sum2_f64(double sx, double sy, double& totx, double& toty) {
@@ -572,13 +576,18 @@ __device__ __forceinline__ void wave_sum2_f64(double sx, double sy, double& totx
 // one pattern point through the fast arithmetic; `bad` collects points the table does not cover.  (Requesting the row of point t + 1 before the Horner
 // chain of point t — a hand-made software pipeline — was built and measured: 0.712 against 0.705 ms, not kept.)
 struct FastCam { double c, d, e; };
-template <class Tab>
-__device__ __forceinline__ void fast_w2i(const FastCam& C, Tab tab, double xr, double yr, double& u, double& v, bool& bad) {
+#ifndef MCS_FAST_CLAMP
+#define MCS_FAST_CLAMP 1   // clamp the row index before the LDS gather (0, A/B: an unclamped gather measured the same, 0.594 against 0.602 ms)
+#endif
+// `top` collects the largest row index seen (unsigned: below the table, negative, NaN and Inf all come out huge): one compare per pattern instead of one per
+// point; the gather itself reads the clamped row, its value is never used for such a point (the keypoint goes to the exact pass).
+template <bool CLAMP, class Tab>
+__device__ __forceinline__ void fast_w2i(const FastCam& C, Tab tab, double xr, double yr, double& u, double& v, unsigned& top) {
 	const double s = __builtin_fma(xr, xr, yr * yr);
 	const unsigned hi = (unsigned)__double2hiint(s), lo = (unsigned)__double2loint(s);
 	const unsigned idx = (hi >> (20 - kGM)) - (unsigned)((1023 + kGE0) << kGM);            // (exponent - kGE0) * 2^kGM + top kGM mantissa bits
-	bad |= idx >= (unsigned)kGRows;                                                       // below / above the table, negative, NaN, Inf
-	unsigned row = idx < (unsigned)kGRows ? idx : (unsigned)(kGRows - 1);
+	top = max(top, idx);
+	unsigned row = CLAMP || MCS_FAST_CLAMP ? (idx < (unsigned)kGRows ? idx : (unsigned)(kGRows - 1)) : (idx & 0xFFFFFFu);   // 24 bits: v_mad_u32_u24 forms the byte offset
 	if (MCS_FAST_ABLATE & 16) row = 0;   // A/B: every lane reads the same row (LDS broadcast: no bank conflicts, no gather)
 	const double frac = __hiloint2double((int)((hi & ((1u << (20 - kGM)) - 1u)) | 0x3FF00000u), (int)lo);   // 1 + the mantissa bits below the bin index
 	const double tau = frac - (1.0 + 1.0 / (double)(2 << kGM));                           // exact
@@ -687,13 +696,20 @@ static_assert(kSlotAlign % kFastWaves == 0, "a group's keypoint slots must belon
 struct LazySampler {
 	const ExtractBuffers* b; int img, level;
 	const uint8_t* patch;
-	__device__ __forceinline__ void pair(int row, int col, int dy0, int dx0, int dy1, int dx1, int& t0, int& t1) const {
+	// `reach` collects offset + 4096 of every sample that takes the general path: the caller sends the keypoint to the exact pass unless all stay below 8192.
+	// (A sample inside the patch is within +-21: nothing to collect on the fast path — and an offset outside [-4096, 4096), NaN included, can never pass for inside.)
+	__device__ __forceinline__ void pair(int row, int col, int dy0, int dx0, int dy1, int dx1, int& t0, int& t1, unsigned& reach) const {
 		const unsigned r0 = (unsigned)(dy0 + kPatchR), c0 = (unsigned)(dx0 + kPatchR), r1 = (unsigned)(dy1 + kPatchR), c1 = (unsigned)(dx1 + kPatchR);
 		const bool inside = max(max(r0, c0), max(r1, c1)) < (unsigned)kPatchRows;
 		if (!__any(!inside)) {
-			t0 = patch[r0 * kPatchPitch + c0];
-			t1 = patch[r1 * kPatchPitch + c1];
+			// explicitly LDS: left as loads through the generic `patch` pointer, the compiler merges this load with the general path's (below) into ONE flat load
+			// behind the branch — slower than ds_read_u8, and every flat load waits on vmcnt(0), i.e. for the patch requested for the NEXT keypoint
+			typedef const __attribute__((address_space(3))) uint8_t lds_byte;
+			lds_byte* const pl = (lds_byte*)patch;
+			t0 = pl[r0 * kFPitch + c0];
+			t1 = pl[r1 * kFPitch + c1];
 		} else {
+			reach |= (unsigned)(dy0 + 4096) | (unsigned)(dx0 + 4096) | (unsigned)(dy1 + 4096) | (unsigned)(dx1 + 4096);
 			const PyrDesc& d = *b->desc;
 			const LevelInfo& L = d.lv[level];
 			Sampler sm;
@@ -703,18 +719,22 @@ struct LazySampler {
 			sm.blur = b->blur + (size_t)img * d.pyrBytes + L.off; sm.bstride = L.stride;
 			sm.w = L.w; sm.h = L.h;
 			sm.patch = patch; sm.prow = row - kPatchR; sm.pcol = col - kPatchR;
-			t0 = sm.at(row + dy0, col + dx0);
-			t1 = sm.at(row + dy1, col + dx1);
+			t0 = sm.at<kFPitch>(row + dy0, col + dx0);
+			t1 = sm.at<kFPitch>(row + dy1, col + dx1);
+			asm volatile("" : "+v"(t0), "+v"(t1));   // (keeps the two paths' loads apart, see above)
 		}
 	}
 };
 
 // One keypoint of the fast pass by one wave: the patch is in LDS, (ukx, uky) and the pattern angles' cos / sin come from k_orient_b.  Returns false if the
 // keypoint has to take the exact pass (a coordinate in the guard band, a point outside the table, out of range).
-template <int MODE, int NB>
+// patD: this lane's pattern points as doubles in LDS — point t at patD[64 t] = (x, y): one ds_read_b128 where unpacking the packed bytes took four VALU instructions
+// per point and pattern (hoisted out of the loops the 4 NB doubles would cost 8 NB registers)
+// ahead(): the walk's requests for the keypoints to come, issued right behind this keypoint's first LDS read (k_describe_fast says why there).
+template <int MODE, int NB, class Ahead>
 __device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const FastCam& C, const double* tabLds, const LazySampler& sm, int row, int col,
-                                              double ukx, double uky, const double (&axc)[3], const double (&ays)[3], const uint32_t (&ppk_)[NB],
-                                              unsigned long long (&bitsMain)[NB], unsigned long long (&agree)[NB]) {
+                                              double ukx, double uky, const double (&axc)[3], const double (&ays)[3], const double2* patD,
+                                              unsigned long long (&bitsMain)[NB], unsigned long long (&agree)[NB], Ahead&& ahead) {
 	constexpr int NP = 128 * NB;
 	// The rounding and its guard in fixed point: y = coordinate - mean + 1.5 * 2^20 + 0.5 lies in [2^20, 2^21) where one unit of the high word is one pixel and
 	// the low word is the fraction in units of 2^-32.  floor(y) is the rounded offset (ties are excluded by the guard), the fraction within guardUnits of 0 /
@@ -732,16 +752,19 @@ __device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const Fas
 		double u[2 * NB], v[2 * NB];
 		double sumx = 0.0, sumy = 0.0;
 		bool bad = false;
-		// the packed pattern bytes are widened to double at the point of use, for every pattern and keypoint again: hoisted out of the loops the 4 NB doubles
-		// would cost 8 NB registers (the compiler does hoist them unless the packed words are opaque here, and then spills)
-		uint32_t ppk[NB];
-#pragma unroll
-		for (int j = 0; j < NB; ++j) { ppk[j] = ppk_[j]; asm volatile("" : "+v"(ppk[j])); }
+		unsigned top = 0;
+		// opaque per pattern — the points are read again for every pattern, not held across them — as an LDS byte offset: an opaque generic pointer would make
+		// these flat loads, which count on vmcnt too and would wait for the patch just requested
+		typedef double f64x2 __attribute__((ext_vector_type(2)));
+		typedef const __attribute__((address_space(3))) f64x2 lds_f64x2;
+		unsigned pdo = (unsigned)(uintptr_t)(lds_f64x2*)patD;
+		asm volatile("" : "+v"(pdo));
+		lds_f64x2* const pd = (lds_f64x2*)(uintptr_t)pdo;
 		auto rotate = [&](int t, double& xr, double& yr) {
-			const int e = t & 1;
-			const double ptx = (double)(int)(signed char)(ppk[t >> 1] >> (16 * e)), pty = (double)(int)(signed char)(ppk[t >> 1] >> (16 * e + 8));
-			xr = __builtin_fma(ptx, ax, __builtin_fma(-pty, ay, ukx));
-			yr = __builtin_fma(ptx, ay, __builtin_fma(pty, ax, uky));
+			const f64x2 p = pd[64 * t];
+			if (pat == 0 && t == 0) ahead();
+			xr = __builtin_fma(p.x, ax, __builtin_fma(-p.y, ay, ukx));
+			yr = __builtin_fma(p.x, ay, __builtin_fma(p.y, ax, uky));
 		};
 		if (MCS_FAST_ABLATE & 2) {
 #pragma unroll
@@ -751,7 +774,7 @@ __device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const Fas
 			for (int t = 0; t < 2 * NB; ++t) {
 				double xr, yr;
 				rotate(t, xr, yr);
-				fast_w2i(C, tabLds, xr, yr, u[t], v[t], bad);
+				fast_w2i<false>(C, tabLds, xr, yr, u[t], v[t], top);
 				sumx += u[t]; sumy += v[t];
 				if ((t & (MCS_FAST_FENCE - 1)) == MCS_FAST_FENCE - 1) __builtin_amdgcn_sched_barrier(0);   // at most MCS_FAST_FENCE point evaluations in flight (registers)
 			}
@@ -759,6 +782,7 @@ __device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const Fas
 		double totx, toty;
 		wave_sum2_f64(sumx, sumy, totx, toty);
 		const double meanX = totx * (1.0 / (double)NP), meanY = toty * (1.0 / (double)NP);
+		bad |= top >= (unsigned)kGRows;   // a point below / above the table, NaN, Inf
 		bad |= !(fabs(meanX) < 16384.0) || !(fabs(meanY) < 16384.0);
 		// the guard's half-width is folded into the addend: the low word of y then reads (fraction + g) mod 2^32, and "within the band of a tie" is low word < 2g —
 		// no integer add per coordinate.  (Where the fraction + g wraps, the carry lands in the high word: such a coordinate is in the band, its keypoint leaves
@@ -776,11 +800,10 @@ __device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const Fas
 				const double yx = u[2 * j + e] + cmx, yy = v[2 * j + e] + cmy;
 				const unsigned hx = (unsigned)__double2hiint(yx) - kHiBase, hy = (unsigned)__double2hiint(yy) - kHiBase;
 				if (!(MCS_FAST_ABLATE & 4)) minlo = min(minlo, min((unsigned)__double2loint(yx), (unsigned)__double2loint(yy)));
-				reach |= hx | hy;
 				ix[e] = (int)hx - 4096; iy[e] = (int)hy - 4096;
 			}
 			int t0 = ix[0], t1 = iy[1];
-			if (!(MCS_FAST_ABLATE & 1)) sm.pair(row, col, iy[0], ix[0], iy[1], ix[1], t0, t1);
+			if (!(MCS_FAST_ABLATE & 1)) sm.pair(row, col, iy[0], ix[0], iy[1], ix[1], t0, t1, reach);
 			const unsigned long long bits = __ballot(t0 < t1);
 			if (pat == 0) bitsMain[j] = bits;
 			else agree[j] &= ~(bits ^ bitsMain[j]);
@@ -813,18 +836,31 @@ __device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const Fas
 constexpr int kFastPatchBufs = MCS_FAST_DMA ? 2 : 1;
 constexpr int kMailDwords = 32, kMailBytes = MCS_FAST_DMA ? 2 * kMailDwords * 4 : 0;   // per wave
 constexpr int kMailCam = 19, kMailUsed = 26;   // dwords 0..2 lvl, rc, poff; 3..18 the eight doubles of KpAuxSoA::d8; 19 tabIdx; 20..25 cam.c, cam.d, cam.e
-constexpr size_t kFastWaveLds = (size_t)kFastPatchBufs * kPatchBytes + kMailBytes;
+constexpr size_t kFastWaveLds = (size_t)kFastPatchBufs * kFPatchBytes + kMailBytes;
+__host__ __device__ constexpr size_t fast_pat_bytes(int nb) { return (size_t)2 * nb * 64 * sizeof(double2); }   // the pattern points as doubles, [point][lane]
 
+// The requests are written as inline assembly, not __builtin_amdgcn_global_load_lds: knowing an LDS-DMA write is in flight, the compiler puts an
+// s_waitcnt vmcnt(0) in front of the first LDS read it cannot prove disjoint from the destination — here every table, pattern and patch read of the keypoint
+// being described, i.e. it would wait for the request right after issuing it.  The ordering that is needed is the explicit wait at the top of a trip.  (Requests the
+// compiler does not know about can only make ITS vmcnt waits wait longer, never shorter: loads complete in order and it counts too few outstanding.)
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+__device__ __forceinline__ void dma16(const void* g, unsigned ldsBase) {   // lane l: 16 bytes at g -> LDS byte ldsBase + 16 l
+	asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(ldsBase) : "memory", "m0");
+}
+__device__ __forceinline__ void dma4(const void* g, unsigned ldsBase) {    // lane l: 4 bytes at g -> LDS byte ldsBase + 4 l
+	asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(ldsBase) : "memory", "m0");
+}
+// 16 bytes per lane: kFPitch / 16 lanes fetch a row.  The bytes past the 43rd column are never sampled; they stay inside the level's pitch or are the first
+// bytes of the next row, which exists: a keypoint sits >= 25 px inside its level, the patch's last row is at least 4 rows above the level's last.
 __device__ __forceinline__ void patch_request(const uint8_t* origin, int bstride, uint8_t* patch) {
 	int lane = threadIdx.x & 63;
 	asm volatile("" : "+v"(lane));
+	constexpr int perRow = kFPitch / 16, total = kPatchRows * perRow;
 #pragma unroll
-	for (int t = 0; t < kPatchTrips; ++t) {
+	for (int t = 0; t * 64 < total; ++t) {
 		const int i = lane + 64 * t;
-		const int r = i / kPatchDw, k = i - r * kPatchDw;
-		if (64 * (t + 1) <= kPatchRows * kPatchDw || i < kPatchRows * kPatchDw)
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(origin + (size_t)r * bstride + 4 * k),
-			                                 (__attribute__((address_space(3))) void*)(patch + 256 * t), 4, 0, 0);
+		const int r = i / perRow, k = i - r * perRow;
+		if (64 * (t + 1) <= total || i < total) dma16(origin + (size_t)r * bstride + 16 * k, __builtin_amdgcn_readfirstlane(lds_addr(patch) + 1024 * t));
 	}
 }
 // the record of slot gw (a keypoint of image img) -> mailbox
@@ -837,8 +873,7 @@ __device__ __forceinline__ void record_request(const KpAuxSoA& A, const OcamDev*
 	else if (lane < kMailCam) src = reinterpret_cast<const uint32_t*>(A.d8 + (size_t)((lane - 3) >> 1) * S + gw) + ((lane - 3) & 1);
 	else if (lane == kMailCam) src = reinterpret_cast<const uint32_t*>(&cams[img].tabIdx);
 	else src = reinterpret_cast<const uint32_t*>(&cams[img].c) + (lane - kMailCam - 1);              // c, d, e: the first three doubles of OcamDev
-	if (lane < kMailUsed)
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)mail, 4, 0, 0);
+	if (lane < kMailUsed) dma4(src, __builtin_amdgcn_readfirstlane(lds_addr(mail)));
 }
 static_assert(offsetof(OcamDev, c) == 0 && offsetof(OcamDev, d) == 8 && offsetof(OcamDev, e) == 16, "record_request reads c, d, e as six consecutive words");
 
@@ -868,8 +903,15 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 	extern __shared__ __attribute__((aligned(16))) double lds[];   // the camera's G table (shared, at offset 0: its reads then need no address arithmetic), then per wave: patch buffer(s), mailboxes
 	static_assert(MODE == 1 || MODE == 2, "the fast pass is for the distorted patterns");
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint8_t* const waveLds = reinterpret_cast<uint8_t*>(lds) + kGTabDoubles * sizeof(double) + (size_t)wave * kFastWaveLds;
-	uint32_t* const mailBase = reinterpret_cast<uint32_t*>(waveLds + kFastPatchBufs * kPatchBytes);
+	double2* const patLds = reinterpret_cast<double2*>(reinterpret_cast<uint8_t*>(lds) + kGTabDoubles * sizeof(double));
+	uint8_t* const waveLds = reinterpret_cast<uint8_t*>(patLds) + fast_pat_bytes(NB) + (size_t)wave * kFastWaveLds;
+	uint32_t* const mailBase = reinterpret_cast<uint32_t*>(waveLds + kFastPatchBufs * kFPatchBytes);
+	// the pattern points as doubles (visible after the barrier behind the first table load)
+	for (int i = threadIdx.x; i < 2 * NB * 64; i += 64 * kFastWaves) {
+		const int t = i >> 6, ln = i & 63;
+		const signed char* pp = c_pattern + ((t >> 1) * 64 + ln) * 4 + 2 * (t & 1);
+		patLds[i] = double2{(double)pp[0], (double)pp[1]};
+	}
 	double* const tabLds = lds;
 	const PyrDesc& d = *b.desc;
 	KpAuxSoA A; A.carve(b.aux, nslots);
@@ -888,7 +930,7 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 	auto ask_patch = [&](const FastKp& r, int kk) {
 		const int gw = slot_of(kk);
 		if (gw < 0 || !r.usable()) return;
-		patch_request(b.blur + (size_t)(gw / wavesPerImage) * pyrBytes + r.poff, (int)((unsigned)r.lvl >> 16), waveLds + (kk & 1) * kPatchBytes);
+		patch_request(b.blur + (size_t)(gw / wavesPerImage) * pyrBytes + r.poff, (int)((unsigned)r.lvl >> 16), waveLds + (kk & 1) * kFPatchBytes);
 	};
 	// prologue: records 0 and 1, patch 0
 	ask_record(0);
@@ -907,22 +949,19 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 		const int gwu = base + wave;
 		int lane = threadIdx.x & 63;
 		asm volatile("" : "+v"(lane));   // opaque per trip: nothing derived from the lane id is worth holding in registers across the walk
-		uint32_t ppk[NB];
-#pragma unroll
-		for (int j = 0; j < NB; ++j) ppk[j] = reinterpret_cast<const uint32_t*>(c_pattern)[j * 64 + lane];
 #if MCS_FAST_DMA
 		const FastKp me = nxt;
-		// this keypoint's patch and the next one's record have landed — and so have the pattern words, which are "used" here so that the compiler's own wait for
-		// them cannot fall behind the requests below (a vmcnt(0) there would wait for what was just requested)
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-		for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(ppk[j]));
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this keypoint's patch and the next one's record have landed
 		nxt = mail_read(mailBase + ((k + 1) & 1) * kMailDwords);
 		if (slot_of(k + 1) < 0) nxt.lvl = -1;
-		ask_patch(nxt, k + 1);   // the other patch buffer: its keypoint (k - 1) is finished
-		ask_record(k + 2);       // the mailbox record k was read from a trip ago
+		// The requests go out behind this keypoint's first LDS read (inside fast_keypoint), not here: the compiler keeps an s_waitcnt vmcnt(0) in front of that
+		// read (pending flat accesses of the sampler's general path, as its bookkeeping sees the loop) — issued before it, they would be waited for at once.
+		auto ahead = [&]() {
+			ask_patch(nxt, k + 1);   // the other patch buffer: its keypoint (k - 1) is finished
+			ask_record(k + 2);       // the mailbox record k was read from a trip ago
+		};
 		const int tabIdx = me.tabIdx;
-		uint8_t* const patchLds = waveLds + (k & 1) * kPatchBytes;
+		uint8_t* const patchLds = waveLds + (k & 1) * kFPatchBytes;
 #else
 		const OcamDev& cam = b.cams[bimg];
 		const int tabIdx = cam.tabIdx;
@@ -943,7 +982,7 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 			curTab = tabIdx;
 		}
 #if MCS_FAST_DMA
-		if (!me.usable()) continue;   // nothing here, or already on the exact pass's pre-list
+		if (!me.usable()) { ahead(); continue; }   // nothing here, or already on the exact pass's pre-list
 		const int level = me.lvl & 0xFF;
 		const int row = me.rc & 0xFFFF, col = (int)((unsigned)me.rc >> 16);
 		const FastCam C = me.C;
@@ -961,9 +1000,13 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 		const int row = rc & 0xFFFF, col = (int)((unsigned)rc >> 16);
 		{
 			const LevelInfo& L = d.lv[level];
+			int ln = threadIdx.x & 63;
+			const uint8_t* bp = b.blur + (size_t)bimg * pyrBytes + L.off + (size_t)(row - kPatchR) * L.stride + (col - kPatchR);
 			uint32_t pv[kPatchTrips];
-			patch_load(b.blur + (size_t)bimg * pyrBytes + L.off, L.stride, row, col, pv);
-			patch_store(patchLds, pv);   // the previous keypoint's samples are done: same wave, LDS operations stay in order
+#pragma unroll
+			for (int t = 0; t < kPatchTrips; ++t) { const int i = min(ln + 64 * t, kPatchRows * kPatchDw - 1); const int r = i / kPatchDw; __builtin_memcpy(&pv[t], bp + (size_t)r * L.stride + 4 * (i - r * kPatchDw), 4); }
+#pragma unroll
+			for (int t = 0; t < kPatchTrips; ++t) { const int i = min(ln + 64 * t, kPatchRows * kPatchDw - 1); const int r = i / kPatchDw; *reinterpret_cast<uint32_t*>(&patchLds[r * kFPitch + 4 * (i - r * kPatchDw)]) = pv[t]; }
 		}
 		FastCam C;
 		C.c = cam.c; C.d = cam.d; C.e = cam.e;
@@ -976,7 +1019,11 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 		LazySampler sm;
 		sm.b = &b; sm.img = bimg; sm.level = level; sm.patch = patchLds;
 		unsigned long long bitsMain[NB], agree[NB];
-		const bool ok = fast_keypoint<MODE, NB>(b, C, tabLds, sm, row, col, ukx, uky, axc, ays, ppk, bitsMain, agree);
+#if MCS_FAST_DMA
+		const bool ok = fast_keypoint<MODE, NB>(b, C, tabLds, sm, row, col, ukx, uky, axc, ays, patLds + lane, bitsMain, agree, ahead);
+#else
+		const bool ok = fast_keypoint<MODE, NB>(b, C, tabLds, sm, row, col, ukx, uky, axc, ays, patLds + lane, bitsMain, agree, [] {});
+#endif
 		if (lane == 0) {
 			if (!ok) { const int at = atomicAdd(b.fbCount, 1); b.fbList[at] = (uint32_t)gwu; }
 			else {
@@ -1015,9 +1062,9 @@ __global__ void k_selftest_fast_model(const OcamDev* camp, const double* tab, un
 	FastCam C;
 	C.c = cam.c; C.d = cam.d; C.e = cam.e;
 	double uf, vf;
-	bool bad = false;
-	fast_w2i(C, tab, xr, yr, uf, vf, bad);
-	if (bad) return;
+	unsigned top = 0;
+	fast_w2i<true>(C, tab, xr, yr, uf, vf, top);
+	if (top >= (unsigned)kGRows) return;
 	double diff = fmax(fabs(uf + cam.u0 - ue), fabs(vf + cam.v0 - ve));   // one extra rounding here (the kernel never adds the principal point)
 	if (!(diff == diff)) diff = 1e300;   // NaN on either side counts as a failure
 	atomicMax(maxDiff, (unsigned long long)__double_as_longlong(diff));
@@ -1034,7 +1081,7 @@ static void launch_fast_passes(const ExtractBuffers& b, int nimg, int wavesPerIm
 	const int groupsPerBlock = std::max(1, (ngroups + kFastBlocks - 1) / kFastBlocks);
 	int fblocks = (ngroups + groupsPerBlock - 1) / groupsPerBlock;
 	if (fblocks >= kNumXCD) fblocks = (fblocks + kNumXCD - 1) / kNumXCD * kNumXCD;   // whole XCD rounds: the kernel's block -> group mapping is XCD-contiguous
-	const size_t fLds = (size_t)kFastWaves * kFastWaveLds + kGTabDoubles * sizeof(double);
+	const size_t fLds = (size_t)kFastWaves * kFastWaveLds + kGTabDoubles * sizeof(double) + fast_pat_bytes(NB);
 	// PRECONDITION: fbCount and preCount — neighbours — were cleared by k_octree's first workgroup, i.e. every launch_describe follows a launch_octree of the same
 	// batch on the same stream, and the previous batch's side-stream pre-list kernel has been joined (the evDescJoin wait below); extract_impl in mcs_capi.hip is
 	// the only caller and keeps that order

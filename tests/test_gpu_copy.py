@@ -55,3 +55,40 @@ def test_bad_arguments():
     assert L.mcs_copy_narrow(ctx.h, None, dev.ptr, 64, 4, None) != 0
     assert L.mcs_copy_narrow(ctx.h, dev.ptr, dev.ptr, 64, 0, None) != 0
     assert L.mcs_copy_narrow(ctx.h, dev.ptr, dev.ptr, 0, 4, None) == 0
+
+
+def test_result_stream():
+    """the stream on which a search's outputs complete: a stream handle with overlap on; a copy enqueued on it arrives"""
+    ctx = G.ctx()
+    L = G.mcs.lib()
+    h = C.c_void_p()
+    G.mcs.check(L.mcs_ctx_result_stream(ctx.h, C.byref(h)))
+    assert L.mcs_ctx_result_stream(ctx.h, None) != 0
+    p_out, h_out = _pinned(4096)
+    h_out[:] = 0
+    src = np.arange(4096, dtype=np.uint8)
+    dev = G.DevBuf(src)
+    G.mcs.check(L.mcs_copy_narrow(ctx.h, p_out.value, dev.ptr.value, 4096, 2, h))
+    G.mcs.check(L.mcs_ctx_synchronize(ctx.h))
+    assert G.hip().hipDeviceSynchronize() == 0
+    assert (h_out == src).all()
+    G.hip().hipHostFree(p_out)
+
+
+def test_stream_conflicts_and_upload_stream():
+    """the hardware-queue probe: a context stream conflicts with itself; the upload stream the library picks keeps clear of the streams the extraction runs on"""
+    ctx = G.ctx()
+    L = G.mcs.lib()
+    h, m = C.c_void_p(), C.c_uint()
+    G.mcs.check(L.mcs_ctx_result_stream(ctx.h, C.byref(h)))
+    G.mcs.check(L.mcs_ctx_stream_conflicts(ctx.h, h, C.byref(m)))
+    assert m.value & 0x8 or m.value & 0x4          # the result stream is the greedy pass's (or the matcher's without deferred searches)
+    up, um = C.c_void_p(), C.c_uint()
+    G.mcs.check(L.mcs_ctx_upload_stream(ctx.h, C.byref(up), C.byref(um)))
+    assert up.value and (um.value & 0x3) == 0      # not on the main stream's nor on the extraction side stream's queue
+    up2 = C.c_void_p()
+    G.mcs.check(L.mcs_ctx_upload_stream(ctx.h, C.byref(up2), None))
+    assert up2.value == up.value                   # one per context
+    G.mcs.check(L.mcs_ctx_stream_conflicts(ctx.h, up, C.byref(m)))
+    assert m.value == um.value
+    assert L.mcs_ctx_stream_conflicts(ctx.h, up, None) != 0
