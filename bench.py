@@ -624,9 +624,9 @@ def run_e2e(e, sp, steps, warmup, check=True):
             assert hip.hipStreamCreateWithPriority(C.byref(h), 1, int(pr)) == 0
             hs.append(h)
         cin, cout = (torch.cuda.ExternalStream(h.value, device=e.dev) for h in hs)
-    elif os.environ.get("MCS_E2E_STREAMS", "probed") == "probed":   # the upload stream the library picked by probing the hardware queues (mcs_ctx_upload_stream)
+    elif os.environ.get("MCS_E2E_STREAMS", "probed") == "probed":   # the upload stream the library picked by probing the hardware queues (mcs_ctx_transfer_stream)
         h, m = C.c_void_p(), C.c_uint()
-        e.mcs.check(e.lib.mcs_ctx_upload_stream(e.ctx.h, C.byref(h), C.byref(m)))
+        e.mcs.check(e.lib.mcs_ctx_transfer_stream(e.ctx.h, C.byref(h), C.byref(m)))
         upload_conflicts = m.value
         cin, cout = torch.cuda.ExternalStream(h.value, device=e.dev), torch.cuda.Stream(device=e.dev)
     elif os.environ.get("MCS_E2E_STREAMS", "plain") == "null":   # the uploads on the device's null stream (no new stream, no new pairing with a hardware queue)

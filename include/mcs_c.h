@@ -355,15 +355,16 @@ int mcs_copy_narrow(mcs_ctx*, void* dst, const void* src, size_t bytes, int work
  * stream when nothing is overlapped).  Results leave for the host from here without an event in front and without another stream: enqueue mcs_copy_narrow on it
  * right after the search call, record an event behind the copies, and wait for that event before the buffers are written again. */
 int mcs_ctx_result_stream(mcs_ctx*, void** hip_stream);
-/* Images arrive from the host by hipMemcpyAsync on a stream of the caller's — and which HARDWARE QUEUE that stream gets is the runtime's choice: HIP streams
- * are dealt onto four queues, a queue runs its packets in order, and an upload holds its queue for its whole duration (1.3 ms for the 69.5 MB of a default step): on
- * the queue of the context's main stream it adds that to every step (measured: 1.6 against 3.0 ms per step, alternating from one stream to the next).
+/* Long transfers beside the step — the image upload (hipMemcpyAsync from page-locked memory), the descriptor exchange of a multi-GPU rig (RCCL) — run on a
+ * stream of the caller's, and which HARDWARE QUEUE that stream gets is the runtime's choice: HIP streams are dealt onto four queues, a queue runs its packets in
+ * order, and an upload holds its queue for its whole duration (1.3 ms for the 69.5 MB of a default step).  Measured per step, by the context stream the upload
+ * shared a queue with: deferred matcher 1.60 ms, greedy pass 2.17 ms, main stream 2.89 ms (alternating from one freshly created stream to the next).
  *   mcs_ctx_stream_conflicts   bit i of *mask: `hip_stream` shares a queue with the context's stream i (0 main, 1 extraction side stream, 2 deferred matcher,
  *                              3 greedy pass = result stream); probes with a held kernel and a marker, ~2 ms, synchronises the streams involved
- *   mcs_ctx_upload_stream      a stream created and probed by the library until one shares a queue with none of the context's streams or only with the
+ *   mcs_ctx_transfer_stream    a stream created and probed by the library until one shares a queue with none of the context's streams or only with the
  *                              deferred matcher's, which has a step of slack (owned by the context; *conflicts = its mask, may be NULL) */
 int mcs_ctx_stream_conflicts(mcs_ctx*, void* hip_stream, unsigned* mask);
-int mcs_ctx_upload_stream(mcs_ctx*, void** hip_stream, unsigned* conflicts);
+int mcs_ctx_transfer_stream(mcs_ctx*, void** hip_stream, unsigned* conflicts);
 
 /* single-pair distances on the device (known-answer / spot checks) */
 int mcs_descriptor_distance(mcs_ctx*, const uint8_t* a, const uint8_t* b, int dim, int* out);

@@ -70,7 +70,7 @@ EXPORTS = [
     "mcs_ctx_kernel_ms", "mcs_ctx_join", "mcs_ctx_set_async_search", "mcs_ctx_search_fence", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_search_kf_f_sweep",
     "mcs_search_triangulation_sweep", "mcs_search_kf_kf_ring", "mcs_rows_valid", "mcs_extractor_set_describe", "mcs_extractor_describe_stats", "mcs_extractor_tie_stats", "mcs_describe_fast_bound",
     "mcs_selftest_describe_fast", "mcs_describe_fast_table", "mcs_extract_batch_strided", "mcs_rig_pack_headers", "mcs_rig_rows_valid",
-    "mcs_search_by_projection", "mcs_window_match", "mcs_window_best", "mcs_rotation_consistency", "mcs_world_to_cam", "mcs_distinctive_descriptors", "mcs_selftest_shared_reciprocal", "mcs_vocabulary_create", "mcs_vocabulary_destroy", "mcs_bow_transform", "mcs_copy_narrow", "mcs_ctx_result_stream", "mcs_ctx_stream_conflicts", "mcs_ctx_upload_stream",
+    "mcs_search_by_projection", "mcs_window_match", "mcs_window_best", "mcs_rotation_consistency", "mcs_world_to_cam", "mcs_distinctive_descriptors", "mcs_selftest_shared_reciprocal", "mcs_vocabulary_create", "mcs_vocabulary_destroy", "mcs_bow_transform", "mcs_copy_narrow", "mcs_ctx_result_stream", "mcs_ctx_stream_conflicts", "mcs_ctx_transfer_stream",
 ]
 
 WINDOW_RATIO, WINDOW_BEST, WINDOW_INITIALIZE = 1, 2, 3
@@ -160,7 +160,7 @@ def lib():
     L.mcs_copy_narrow.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
     L.mcs_ctx_result_stream.argtypes = [vp, C.POINTER(vp)]
     L.mcs_ctx_stream_conflicts.argtypes = [vp, vp, C.POINTER(C.c_uint)]
-    L.mcs_ctx_upload_stream.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint)]
+    L.mcs_ctx_transfer_stream.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint)]
     L.mcs_descriptor_distance.argtypes = [vp, vp, vp, C.c_int, i32p]
     L.mcs_descriptor_distance_masked.argtypes = [vp, vp, vp, vp, vp, C.c_int, i32p]
     _lib = L

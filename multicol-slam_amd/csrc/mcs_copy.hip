@@ -84,7 +84,7 @@ extern "C" int mcs_ctx_stream_conflicts(mcs_ctx* c, void* hip_stream, unsigned* 
 // A stream for the image uploads (hipMemcpyAsync from page-locked memory): created here, probed, and kept if it shares a hardware queue with none of the context's
 // streams or only with the deferred matcher's (four queues, four streams of the context: SOME stream has to be shared with; the matcher has a step of slack).
 // Owned by the context.
-extern "C" int mcs_ctx_upload_stream(mcs_ctx* c, void** hip_stream, unsigned* conflicts) {
+extern "C" int mcs_ctx_transfer_stream(mcs_ctx* c, void** hip_stream, unsigned* conflicts) {
 	if (!c || !hip_stream) return fail(MCS_ERR_INVALID, "bad argument");
 	HIPCHK(hipSetDevice(c->device));
 	if (!c->upload) {

@@ -84,10 +84,10 @@ def test_stream_conflicts_and_upload_stream():
     G.mcs.check(L.mcs_ctx_stream_conflicts(ctx.h, h, C.byref(m)))
     assert m.value & 0x8 or m.value & 0x4          # the result stream is the greedy pass's (or the matcher's without deferred searches)
     up, um = C.c_void_p(), C.c_uint()
-    G.mcs.check(L.mcs_ctx_upload_stream(ctx.h, C.byref(up), C.byref(um)))
+    G.mcs.check(L.mcs_ctx_transfer_stream(ctx.h, C.byref(up), C.byref(um)))
     assert up.value and (um.value & 0x3) == 0      # not on the main stream's nor on the extraction side stream's queue
     up2 = C.c_void_p()
-    G.mcs.check(L.mcs_ctx_upload_stream(ctx.h, C.byref(up2), None))
+    G.mcs.check(L.mcs_ctx_transfer_stream(ctx.h, C.byref(up2), None))
     assert up2.value == up.value                   # one per context
     G.mcs.check(L.mcs_ctx_stream_conflicts(ctx.h, up, C.byref(m)))
     assert m.value == um.value
