@@ -9,7 +9,7 @@ import re
 import sys
 
 NAMES = {"k_describe_fast": "describe", "k_match_partial": "match", "k_match_mfma": "match", "k_fast_cells": "fast", "k_blur": "blur", "k_resize_level": "pyramid", "k_octree": "octree",
-         "k_greedy_spec": "greedy", "k_orient_a": "orient_a", "k_orient_b": "orient_b", "k_describe_list": "describe_list", "k_describe": "describe_exact", "k_expand_train": "match_expand", "k_resize_chain": "pyramid"}
+         "k_greedy_spec": "greedy", "k_orient_a": "orient_a", "k_orient_b": "orient_b", "k_describe_list": "describe_list", "k_describe": "describe_exact", "k_expand_train": "match_expand", "k_resize_chain": "pyramid", "k_resize_cols": "pyramid"}
 out = {"_comment": "HBM traffic and VALU instructions per launch from separate rocprofv3 --pmc passes (tools/profile_round.sh; FETCH_SIZE / WRITE_SIZE in KiB per "
                    "dispatch, SQ_INSTS_VALU in wave instructions per dispatch).  The loads of these kernels are dword-granular, for which FETCH_SIZE matched a "
                    "known byte count within 14 % (k_blur, round 1), so the guide's x2 correction for 16-byte-per-lane streams is not applied.  "
