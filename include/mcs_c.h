@@ -32,7 +32,8 @@ extern "C" {
 #define MCS_ERR_UNSUPPORTED (-4)
 
 /* ABI revision of this header: bumped whenever a struct layout or an entry point's signature changes (3: mcs_desc_set carries block_rows / block_pitch_rows
- * since round 2 — callers built against an older header must be recompiled; mcs_describe_fast_table, FAST types 0 / 1 in round 3).  mcs_abi_version() returns
+ * since round 2 — callers built against an older header must be recompiled; mcs_describe_fast_table, FAST types 0 / 1 in round 3; 4: mcs_extractor_tie_stats; 5: mcs_copy_narrow,
+ * mcs_ctx_result_stream, mcs_ctx_stream_conflicts, mcs_ctx_transfer_stream in round 4).  mcs_abi_version() returns
  * the value the LIBRARY was built with: compare it with MCS_ABI_VERSION after dlopen. */
 #define MCS_ABI_VERSION 5
 
