@@ -60,13 +60,14 @@ extern "C" int mcs_ctx_stream_conflicts(mcs_ctx* c, void* hip_stream, unsigned* 
 	*mask = 0;
 	if (!c->side) return MCS_OK;   // nothing overlapped: one stream
 	volatile int* pin = nullptr;
-	HIPCHK(hipHostMalloc((void**)&pin, 64, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void**)&pin, 128, hipHostMallocDefault));
 	hipStream_t cand = (hipStream_t)hip_stream;
 	hipStream_t own[4] = {c->stream, c->side, c->side2, c->side3};
-	int rc = MCS_OK;
-	for (int i = 0; i < 4 && rc == MCS_OK; ++i) {
+	bool ok = true;
+	for (int i = 0; i < 4 && ok; ++i) {
 		if (own[i] == cand) { *mask |= 1u << i; continue; }
-		(void)hipStreamSynchronize(own[i]); (void)hipStreamSynchronize(cand);
+		ok = hipStreamSynchronize(own[i]) == hipSuccess && hipStreamSynchronize(cand) == hipSuccess;
+		if (!ok) break;
 		pin[0] = 0; pin[16] = 0;
 		hipLaunchKernelGGL(mcs::k_hold, dim3(1), dim3(1), 0, own[i], pin);
 		hipLaunchKernelGGL(mcs::k_mark, dim3(1), dim3(1), 0, cand, pin + 16);
@@ -75,10 +76,10 @@ extern "C" int mcs_ctx_stream_conflicts(mcs_ctx* c, void* hip_stream, unsigned* 
 		while (!(seen = pin[16] != 0) && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1500)) {}
 		if (!seen) *mask |= 1u << i;
 		pin[0] = 1;   // release the hold
-		if (hipStreamSynchronize(own[i]) != hipSuccess || hipStreamSynchronize(cand) != hipSuccess) rc = fail(MCS_ERR_HIP, "stream probe failed");
+		ok = hipStreamSynchronize(own[i]) == hipSuccess && hipStreamSynchronize(cand) == hipSuccess;
 	}
-	(void)hipHostFree((void*)pin);
-	return rc;
+	(void)hipHostFree((void*)pin);   // on every path
+	return ok ? MCS_OK : fail(MCS_ERR_HIP, "stream probe failed");
 }
 
 // A stream for the image uploads (hipMemcpyAsync from page-locked memory): created here, probed, and kept if it shares a hardware queue with none of the context's
