@@ -17,6 +17,12 @@ images of a step are sharded camera-major over the ranks, ONE all-gather of desc
 place, the (frame, keyframe) pairs are sharded.  Per-GPU work is fixed (F multi-frames and F x keyframes pairs per GPU): weak scaling.  N = 1 runs the
 same code without the collective.  Barrier + max-over-ranks timing.
 
+Legs of the default run besides the headline (each checked against the oracle): `e2e` — the same step with host buffers at the boundary (images up through the SDMA
+engine on a stream picked by the library's hardware-queue probe, results down through mcs_copy_narrow on the context's result stream; --e2e-sweep "h2d:d2h,..."
+and the MCS_E2E_* variables are its A/B switches, tools/ab_e2e.sh) —, configs[2] at 16 multi-frames per step with its own e2e leg, the reference's
+shipped ORB settings, the N > 1 exchange path at world size 1 over RCCL, and last the CPU baseline.  Every leg runs `settle_steps` untimed steps in front of its
+warm-up (GPU clocks), reported in the line.  `python bench.py --gpus N` outside a launcher starts its N ranks itself.
+
 torch is plumbing only (device memory, stream handle, process group); all compute is libmcs_hip.so through its C ABI.
 """
 import argparse
