@@ -93,7 +93,7 @@ constexpr int kGM = MCS_G_M, kGDeg = MCS_G_DEG, kGE0 = MCS_G_E0, kGE1 = MCS_G_E1
 #ifndef MCS_FAST_WAVES
 #define MCS_FAST_WAVES 16   // waves per workgroup of the fast descriptor pass (mcs_describe.hip): they share the camera's table in LDS
 #endif
-constexpr int kSlotAlign = MCS_FAST_WAVES > 8 ? MCS_FAST_WAVES : 8;       // keypoint slots per image are a multiple of this (the fast pass walks groups of 8 keypoints of ONE image, a wave each)
+constexpr int kSlotAlign = MCS_FAST_WAVES > 8 ? MCS_FAST_WAVES : 8;       // keypoint slots per image are a multiple of this (the fast pass walks groups of kFastWaves keypoints of ONE image, a wave each)
 
 // Per-keypoint scratch of the descriptor passes (mcs_describe.hip), one array per field over all keypoint slots of the batch (thread-per-keypoint kernels
 // write full cache lines).  lvl: -1 no keypoint, else level | kAuxExact if the keypoint is on the exact pass's list already.

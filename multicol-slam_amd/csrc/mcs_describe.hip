@@ -20,13 +20,14 @@
 // Compiled with -ffp-contract=off: no FMA contraction anywhere, like the oracle.
 //
 // dBRIEF / mdBRIEF run in TWO passes:
-//   k_describe_fast   every keypoint.  The 2*8*descSize*npat omni-model evaluations use a cheaper arithmetic (explicit FMAs, rsqrt + one cubic refinement
-//                     instead of sqrt + three divisions, a 17-term odd polynomial for atan) and the pattern mean is a wave tree sum instead of the
-//                     reference's sequential chain.  The results differ from the reference's by at most a bound delta known per camera (host,
-//                     mcs_capi.hip: describe_fast_bound) — far below half a pixel, but cvRound(coordinate - mean) only agrees for sure when no
-//                     coordinate lies within delta of a rounding tie.  Every coordinate is therefore checked against a guard band eps >= delta around
-//                     the ties (|frac - 0.5| < eps); a keypoint with ANY coordinate inside the band (or out of range / NaN) is not written, its slot
-//                     goes onto the fallback list.
+//   k_describe_fast   every keypoint.  The 2*8*descSize*npat omni-model evaluations use a cheaper arithmetic (explicit FMAs; G(s) = rho(atan(p0 / sqrt(s))) / sqrt(s)
+//                     from a per-camera table indexed by the bit pattern of s = x^2 + y^2: no square root, no division, no atan, no backward polynomial) and the
+//                     pattern mean is a wave tree sum instead of the reference's sequential chain.  The results differ from the reference's by at most a bound
+//                     delta known per camera (host, mcs_capi.hip: describe_fast_bound) — far below half a pixel, but cvRound(coordinate - mean) only agrees for
+//                     sure when no coordinate lies within delta of a rounding tie.  Every coordinate is therefore checked against a guard band eps >= delta
+//                     around the ties (|frac - 0.5| < eps); a keypoint with ANY coordinate inside the band (or out of range / NaN) is not written, its slot goes
+//                     onto the fallback list.  Persistent 16-wave workgroups (table and pattern in LDS once per CU) walk the batch; the walk is software-pipelined
+//                     through LDS-DMA (round 4): the next keypoint's patch and the record after it travel global -> LDS while this keypoint is described.
 //   k_describe_list   the keypoints of the fallback list through describe_wave — the reference's exact arithmetic (below, unchanged), a few per 10^4.
 // Integer pixel offsets that pass the guard are PROVABLY the reference's, so the descriptors stay bit-identical; mcs_extractor_set_describe() can force
 // the exact pass for everything or widen the band (tests/test_gpu_describe_guard.py runs both against the oracle).
@@ -817,8 +818,8 @@ __device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const Fas
 
 // Persistent workgroups: a workgroup of kFastWaves waves walks a contiguous range of keypoint GROUPS (kFastWaves consecutive slots of one image, one per
 // wave).  The camera's table is loaded into LDS when the camera changes — once per workgroup for a camera-major batch — and there is no barrier inside the
-// walk, so the waves drift apart and one wave's memory round trips (slot record -> patch) hide behind the others' arithmetic.  (One workgroup per 8
-// keypoints spent half its life in the load -> LDS -> barrier prologue: the kernel without model, sampling and guard took 0.36 of 0.71 ms.)
+// walk.  (One workgroup per 8 keypoints spent half its life in the load -> LDS -> barrier prologue: the kernel without model, sampling and guard took 0.36 of
+// 0.71 ms.  Round 3 hoped the waves of a persistent workgroup would drift apart and hide each other's memory round trips; they do not — next paragraph.)
 // ---- the walk, software-pipelined through LDS-DMA --------------------------------------------------------------------------------------------------
 // A wave alone pays three dependent memory round trips per keypoint (slot record -> patch -> LDS: ~4.5 us against ~10 us of arithmetic), and the waves of a
 // SIMD do NOT hide them for each other: every keypoint costs the same, so waves that start together stay in step — they wait together, then compete for the
@@ -1077,7 +1078,8 @@ void launch_selftest_fast_model(const OcamDev* cam, const double* tab, unsigned 
 template <int MODE, int NB>
 static void launch_fast_passes(const ExtractBuffers& b, int nimg, int wavesPerImage, size_t listLds, hipStream_t s) {
 	const int nslots = nimg * wavesPerImage, ngroups = nslots / kFastWaves, lblocks = std::min(nslots, 2048);
-	// two workgroups of 8 waves fit a CU (registers: 4 waves per SIMD): one resident generation of workgroups walks the whole batch
+	// one workgroup of kFastWaves = 16 waves per CU (registers: 4 waves per SIMD; LDS: table + pattern + 16 x (two patch buffers + mailboxes) = 139 KB): one resident
+	// generation of workgroups walks the whole batch
 	const int groupsPerBlock = std::max(1, (ngroups + kFastBlocks - 1) / kFastBlocks);
 	int fblocks = (ngroups + groupsPerBlock - 1) / groupsPerBlock;
 	if (fblocks >= kNumXCD) fblocks = (fblocks + kNumXCD - 1) / kNumXCD * kNumXCD;   // whole XCD rounds: the kernel's block -> group mapping is XCD-contiguous
