@@ -51,6 +51,13 @@ public:
 	~Context() { mcs_ctx_destroy(h); }
 	Context(const Context&) = delete;
 	Context& operator=(const Context&) = delete;
+	// A pipelined host (include/mcs_c.h: "Long transfers beside the step"): results leave on resultStream() through copyNarrow(), images arrive by hipMemcpyAsync on
+	// transferStream(), a stream the library has probed to share a hardware queue with none of the streams the extraction runs on.
+	void* resultStream() const { void* s = nullptr; mcs_throw(mcs_ctx_result_stream(h, &s)); return s; }
+	void* transferStream(unsigned* conflicts = nullptr) const { void* s = nullptr; mcs_throw(mcs_ctx_transfer_stream(h, &s, conflicts)); return s; }
+	unsigned streamConflicts(void* hipStream) const { unsigned m = 0; mcs_throw(mcs_ctx_stream_conflicts(h, hipStream, &m)); return m; }
+	void copyNarrow(void* dst, const void* src, size_t bytes, void* hipStream, int workgroups = 2) const { mcs_throw(mcs_copy_narrow(h, dst, src, bytes, workgroups, hipStream)); }
+	void synchronize() const { mcs_throw(mcs_ctx_synchronize(h)); }
 	mcs_ctx* h = nullptr;
 };
 

@@ -27,6 +27,11 @@ int main(int argc, char** argv) {
 		fwrite(out, 4, 2, fo); fwrite(&sf, 8, 1, fo);
 		if (!keys.empty()) { fwrite(keys.data(), sizeof(KeyPoint), keys.size(), fo); fwrite(desc.data, 32, keys.size(), fo); }
 		std::fclose(fo);
+		// the pipelined host's helpers of Context: the result stream exists, the transfer stream keeps clear of the extraction's queues, the probe agrees with itself
+		unsigned conf = 0;
+		void* ts = ctx.transferStream(&conf);
+		if (!ctx.resultStream() || !ts || (conf & 3u) != 0 || ctx.streamConflicts(ts) != conf) return 4;
+		ctx.synchronize();
 		return 0;
 	} catch (const std::exception& e) {
 		std::fprintf(stderr, "facade_driver_orb: %s\n", e.what());
