@@ -161,7 +161,10 @@ __attribute__((amdgpu_waves_per_eu(MCS_MM_WAVES, MCS_MM_WAVES)))
 __global__ __launch_bounds__(XQ) void k_match_mfma(MatchArgs a) {
 	constexpr int HS = DW / 2;                       // K steps per segment (64 bits each)
 	constexpr int NS = (MASKED ? 2 : 1) * HS;        // K steps per pair
-	constexpr int CB = 16;                           // candidate column depth per lane
+#ifndef MCS_MM_CB
+#define MCS_MM_CB 16
+#endif
+	constexpr int CB = MCS_MM_CB;                    // candidate column depth per lane, a power of two (A/B, round 4: 32 with one-tile stages — the same LDS — 10.6 against 7.07 ms on configs[2]: 30 spilled registers, sort network of 32)
 	constexpr int SLABS = TPS * NS;                  // 1-KB operand slabs (tile, K step) per stage
 	// A operands of two stages: stage g + 1 arrives (global_load_lds: global -> LDS without passing registers) while stage g is multiplied
 	__shared__ __attribute__((aligned(16))) uint4 ex[MCS_MM_NBUF][TPS][NS][64];
