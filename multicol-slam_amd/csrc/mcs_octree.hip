@@ -57,6 +57,7 @@ __device__ int block_exscan(int* a, int n, int* wsum) {
 }
 
 template <int MAXN, int KCACHE>
+__attribute__((amdgpu_waves_per_eu(5, 5)))   // 102 registers: five workgroups per CU stay possible (the orientation tail in its round-4 form would take 113)
 __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int level0) {
 	__shared__ NodeBuf<MAXN> nb[2];
 	__shared__ uint32_t kd[KCACHE];          // LDS copy of the level's candidate records ...
@@ -302,10 +303,14 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int 
 	// ---------------------------------------------------------------- E5: orientation of the selected keys (IC_Angle, :221-248)
 	// Here rather than in a kernel of its own: a separate launch ran 0.115 ms with nothing beside it, three dependent memory round trips per key; in this
 	// tail they hide behind the other (image, level) workgroups' passes.
-	__syncthreads();
+	__shared__ __attribute__((aligned(16))) uint32_t otab[kOrientTabWords];
+	orient_table(d.umax, otab);
+	__syncthreads();   // the selection and the table are complete
 	int rstride;
 	const uint8_t* raw = level_ptr(b, d, img, level, &rstride);
-	orient_selected(raw, rstride, d.umax, sel, L, b.selAngle + (size_t)img * d.selPerImage + Lv.selBase);
+#ifndef MCS_OCT_AB   // A/B (timing only): the kernel without its orientation tail (101 against 157 us before the tail's byte dot products)
+	orient_selected(raw, rstride, otab, sel, L, b.selAngle + (size_t)img * d.selPerImage + Lv.selBase);
+#endif
 }
 
 void launch_octree(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream_t s, int level0, int level1) {   // levels [level0, level1)

@@ -26,43 +26,51 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 	return a;
 }
 
-// The orientation of `count` selected keys of one (image, level) by a whole workgroup: 16 lanes per key (lane j of a group owns disc rows j - 16, j and —
-// lane 0 — 16: nine unaligned dwords per row), int32 moments reduced inside the group (exact, order-free), then the float polynomial of cv::fastAtan2.
-// sel[k] = x | y << 12 | score << 24 relative to kMinBorder; out[k] = angle in degrees.  umax = half-width of disc row |v| (PyrDesc.umax).
-__device__ __forceinline__ void orient_selected(const uint8_t* raw, int rstride, const int* umax, const uint32_t* sel, int count, float* out) {
+// Per disc row |v| the orientation needs  sum(val)  and  sum(u * val)  over the columns |u| <= umax[|v|]: as byte dot products against two words per dword of the
+// row — mask bytes 1 inside the disc / 0 outside, and weight bytes (u + 16) inside / 0 outside (u * val = (u + 16) * val - 16 * val) — v_dot4_u32_u8 does four
+// pixels per instruction.  Table in LDS, built once per workgroup: [|v| = 0 .. 16][10 mask words | 10 weight words] (words 9: past the disc, zero).
+constexpr int kOrientTabRow = 20, kOrientTabWords = (kHalfPatch + 1) * kOrientTabRow;
+__device__ __forceinline__ void orient_table(const int* umax, uint32_t* tab) {   // all threads of the workgroup; the caller synchronises
+	for (int i = threadIdx.x; i < (kHalfPatch + 1) * 10; i += blockDim.x) {
+		const int a = i / 10, q = i - 10 * a, um = umax[a];
+		uint32_t mask = 0, wt = 0;
+#pragma unroll
+		for (int e = 0; e < 4; ++e) {
+			const int jj = 4 * q + e, u = jj - kHalfPatch;
+			if (jj <= 2 * kHalfPatch && u >= -um && u <= um) { mask |= 1u << (8 * e); wt |= (uint32_t)jj << (8 * e); }
+		}
+		tab[a * kOrientTabRow + q] = mask;
+		tab[a * kOrientTabRow + 10 + q] = wt;
+	}
+}
+
+// The orientation of `count` selected keys of one (image, level) by a whole workgroup: 16 lanes per key.  Round 4: the lanes of a group read CONTIGUOUS bytes —
+// lane j = 5 sub + c takes the 8 bytes 8c .. 8c + 7 of disc row 3 i + sub in step i = 0 .. 10 (11 steps x 3 rows = the 33 rows; lane 15 idles), so a wave's load
+// touches a dozen cache lines where the row-per-lane form (27 dwords of three whole rows per lane) touched 64: the tail of k_octree was bound by those line
+// requests (55 of the kernel's 157 us; the byte dot products alone changed nothing).  int32 moments reduced inside the group (exact, order-free), then the float
+// polynomial of cv::fastAtan2.  sel[k] = x | y << 12 | score << 24 relative to kMinBorder; out[k] = angle in degrees.  tab = orient_table's words (LDS).
+// (The 4 bytes a row's fifth chunk reads past the disc's 36 lie inside the level's pitch or are the next row's first bytes: a key sits >= 22 px inside.)
+__device__ __forceinline__ void orient_selected(const uint8_t* raw, int rstride, const uint32_t* tab, const uint32_t* sel, int count, float* out) {
 	const int tid = threadIdx.x, j = tid & 15, groups = blockDim.x >> 4;
-	// the disc rows of ONE key owned by this lane: 27 unaligned dwords, all requested before the first is used
+	const int sub = j / 5, c = j - 5 * sub;   // j = 15: sub = 3, no row
 	auto moments = [&](int k, int& m10, int& m01) {
 		m10 = 0; m01 = 0;
-		if (k >= count) return;
+		if (k >= count || sub > 2) return;
 		const uint32_t rec = sel[k];
 		const int col = (int)(rec & 0xFFF) + kMinBorder, row = (int)((rec >> 12) & 0xFFF) + kMinBorder;
-		uint32_t w[3][9];
+		const uint8_t* p0 = raw + (size_t)(row - kHalfPatch + sub) * rstride + (col - kHalfPatch + 8 * c);
+		uint2 w[11];
 #pragma unroll
-		for (int t = 0; t < 3; ++t) {
-			const int r = min(j + 16 * t, 2 * kHalfPatch);   // disc row index 0..32 (the surplus lanes of the third trip re-read row 32, unused)
-			const uint8_t* rp = raw + (size_t)(row + r - kHalfPatch) * rstride + (col - kHalfPatch);
+		for (int i = 0; i < 11; ++i) __builtin_memcpy(&w[i], p0 + (size_t)(3 * i) * rstride, 8);   // all requested before the first is used
 #pragma unroll
-			for (int q = 0; q < 9; ++q) __builtin_memcpy(&w[t][q], rp + 4 * q, 4);
-		}
-#pragma unroll
-		for (int t = 0; t < 3; ++t) {
-			const int r = j + 16 * t;
-			if (r <= 2 * kHalfPatch) {
-				const int v = r - kHalfPatch;
-				const int um = umax[v < 0 ? -v : v];
-				int rowSum = 0, rowMom = 0;
-#pragma unroll
-				for (int jj = 0; jj <= 2 * kHalfPatch; ++jj) {
-					const int u = jj - kHalfPatch;
-					int val = (int)((w[t][jj >> 2] >> (8 * (jj & 3))) & 0xffu);
-					val = (u >= -um && u <= um) ? val : 0;
-					rowSum += val;
-					rowMom += u * val;
-				}
-				m10 += rowMom;
-				m01 += v * rowSum;
-			}
+		for (int i = 0; i < 11; ++i) {
+			const int v = 3 * i + sub - kHalfPatch;
+			const uint32_t* tw = tab + (v < 0 ? -v : v) * kOrientTabRow + 2 * c;
+			const uint2 mk = *reinterpret_cast<const uint2*>(tw), wt = *reinterpret_cast<const uint2*>(tw + 10);
+			const uint32_t rowSum = __builtin_amdgcn_udot4(w[i].y, mk.y, __builtin_amdgcn_udot4(w[i].x, mk.x, 0u, false), false);
+			const uint32_t rowW = __builtin_amdgcn_udot4(w[i].y, wt.y, __builtin_amdgcn_udot4(w[i].x, wt.x, 0u, false), false);
+			m10 += (int)rowW - kHalfPatch * (int)rowSum;   // this chunk's share of sum(u * val)
+			m01 += v * (int)rowSum;
 		}
 	};
 	for (int k0 = 0; k0 < count; k0 += 2 * groups) {   // two keys per 16-lane group and trip: their loads overlap
