@@ -100,12 +100,28 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int 
 		for (int i = tid; i < m; i += 256) scanA[i] = cellCount[c0 + i];
 		__syncthreads();
 		const int tot = block_exscan<IPT>(scanA, m, wsum);
+#ifdef MCS_OCT_WAVE_CELLS   // A/B: round 3's form, a wave per cell — a hundred dependent trips per wave (count -> records -> store) with a handful of lanes each
 		for (int c = wave; c < m; c += 4) {
 			const int cnt = cellCount[c0 + c];
 			const int off = n + scanA[c];
 			const uint32_t* sp = slots + (size_t)(c0 + c) * Lv.capc;
 			for (int j = lane; j < cnt; j += 64) denseG[off + j] = sp[j];
 		}
+#else
+		// a THREAD per cell (a cell holds a handful of records): every thread's loads are independent of everybody else's, four records in flight per thread
+		for (int c = tid; c < m; c += 256) {
+			const int cnt = cellCount[c0 + c];
+			const int off = n + scanA[c];
+			const uint32_t* sp = slots + (size_t)(c0 + c) * Lv.capc;
+			for (int j = 0; j < cnt; j += 4) {
+				uint32_t v[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) v[u] = j + u < cnt ? sp[j + u] : 0u;
+#pragma unroll
+				for (int u = 0; u < 4; ++u) if (j + u < cnt) denseG[off + j + u] = v[u];
+			}
+		}
+#endif
 		n += tot;
 	}
 	__syncthreads();
