@@ -73,19 +73,24 @@ __device__ __forceinline__ void orient_selected(const uint8_t* raw, int rstride,
 			m01 += v * (int)rowSum;
 		}
 	};
-	for (int k0 = 0; k0 < count; k0 += 2 * groups) {   // two keys per 16-lane group and trip: their loads overlap
-		const int ka = k0 + (tid >> 4), kb = ka + groups;
-		int a10, a01, b10, b01;
-		moments(ka, a10, a01);
-		moments(kb, b10, b01);
+#ifndef MCS_ORIENT_KEYS
+#define MCS_ORIENT_KEYS 3   // keys per 16-lane group and trip: their loads overlap (11 eight-byte loads per key and lane in flight)
+#endif
+	constexpr int KPT = MCS_ORIENT_KEYS;
+	for (int k0 = 0; k0 < count; k0 += KPT * groups) {
+		int m10[KPT], m01[KPT];
 #pragma unroll
-		for (int o = 8; o > 0; o >>= 1) {   // within the 16-lane group (exact integer sums: order-free)
-			a10 += __shfl_xor(a10, o); a01 += __shfl_xor(a01, o);
-			b10 += __shfl_xor(b10, o); b01 += __shfl_xor(b01, o);
-		}
+		for (int q = 0; q < KPT; ++q) moments(k0 + (tid >> 4) + q * groups, m10[q], m01[q]);
+#pragma unroll
+		for (int o = 8; o > 0; o >>= 1)   // within the 16-lane group (exact integer sums: order-free)
+#pragma unroll
+			for (int q = 0; q < KPT; ++q) { m10[q] += __shfl_xor(m10[q], o); m01[q] += __shfl_xor(m01[q], o); }
 		if (j == 0) {
-			if (ka < count) out[ka] = fast_atan2_deg((float)a01, (float)a10);
-			if (kb < count) out[kb] = fast_atan2_deg((float)b01, (float)b10);
+#pragma unroll
+			for (int q = 0; q < KPT; ++q) {
+				const int k = k0 + (tid >> 4) + q * groups;
+				if (k < count) out[k] = fast_atan2_deg((float)m01[q], (float)m10[q]);
+			}
 		}
 	}
 }
