@@ -898,46 +898,188 @@ def cpu_baseline(args, e, sp, job):
     L.orc_extract_match_many.restype = C.c_long
     L.orc_extract_match_many.argtypes = [C.POINTER(O.Params), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_double, C.c_void_p, C.c_void_p]
-    best = None
-    for threads in sorted({quota, min(nproc, 2 * quota)}):   # the quota, and 2x for SMT/oversubscription; keep the faster
-        for _ in range(2):                                   # second pass: warm thread pool / page cache
-            tot = L.orc_extract_match_many(C.byref(prm), nf, NCAM, iptr, W, H, W, mptr, ocs, threads, 0.9, nmatch, secs)
-            wall = secs[0] + secs[1]
-            if best is None or wall < best[0]:
-                best = (wall, secs[0], secs[1], tot, threads)
-    wall, se, sm, tot, threads = best
+    def one_pass(n_frames, threads):
+        tot = L.orc_extract_match_many(C.byref(prm), n_frames, NCAM, iptr, W, H, W, mptr, ocs, threads, 0.9, nmatch, secs)
+        return secs[0] + secs[1], secs[0], secs[1], tot
+    # median of >= 20 repetitions after 3 warm-ups.  The warm-ups also pick the thread count (the quota, and 2x for SMT / oversubscription).
+    cand = sorted({quota, min(nproc, 2 * quota)})
+    warm = {t: one_pass(nf, t)[0] for t in cand}
+    threads = min(warm, key=warm.get)
+    one_pass(nf, threads)
+    if len(cand) < 2:
+        one_pass(nf, threads)
+    reps = [one_pass(nf, threads) for _ in range(20)]
+    walls = sorted(r[0] for r in reps)
+    wall, se, sm, tot = sorted(reps, key=lambda r: r[0])[len(reps) // 2]
     per_frame = tot / nf
     # the reference's own threading: one thread per camera of a multi-frame (#pragma omp parallel for num_threads(nrCams), src/cMultiFrame.cpp:128), the
-    # multi-frames one after the other, the matcher single-threaded — NCAM images in flight at any time
+    # multi-frames one after the other, the matcher single-threaded — NCAM images in flight at any time.  One warm-up, median of 5.
     nf_f = max(4, min(nf, 12))
-    tot_f = L.orc_extract_match_many(C.byref(prm), nf_f, NCAM, iptr, W, H, W, mptr, ocs, NCAM, 0.9, nmatch, secs)
-    faithful = {"value": round(tot_f / nf_f * (nf_f - 1) / (secs[0] + secs[1]) / 1e6, 4), "unit": "Mfeatures/s", "cores": NCAM,
+    one_pass(nf_f, NCAM)
+    rf = sorted((one_pass(nf_f, NCAM) for _ in range(5)), key=lambda r: r[0])[2]
+    faithful = {"value": round(rf[3] / nf_f * (nf_f - 1) / rf[0] / 1e6, 4), "unit": "Mfeatures/s", "cores": NCAM,
+                "ms_per_multi_frame": round(rf[0] / nf_f * 1e3, 2),
                 "sample": "%d multi-frames one after the other on %d threads (extraction: one thread per camera, the reference's threading; the frame pairs of the "
-                          "matcher share the same threads): extract %.2fs + match %.2fs" % (nf_f, NCAM, secs[0], secs[1])}
-    # the same extractor as the REFERENCE's own sources (oracle/_ref = src/mdBRIEFextractorOct.cpp compiled unmodified against oracle/cvshim, its image
-    # primitives are the oracle's), single thread, next to the oracle single thread: the port is not slower than the code it restates
-    side = None
+                          "matcher share the same threads): extract %.2fs + match %.2fs, median of 5 passes after a warm-up" % (nf_f, NCAM, rf[1], rf[2])}
+    # The REFERENCE-COMPILED figure: oracle/_ref = the reference's own src/mdBRIEFextractorOct.cpp, src/cMultiFrame.cpp, src/cORBmatcher.cpp ... built here,
+    # unmodified, against oracle/cvshim (OpenCV's image primitives are the oracle's restatements: OpenCV itself is not in the image).  Single thread (that build
+    # has no OpenMP): cMultiFrame's constructor per multi-frame + cORBmatcher::SearchByBoW(KF,KF) against the previous keyframe; and with the reference's
+    # threading for the extraction — one thread per camera, each running the reference's extractor — the matcher single-threaded as in the reference.
+    refc = None
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libmcs_ref.so")
-    if os.path.exists(ref_so):
+    if os.path.exists(ref_so) and NCAM == 3:
         try:
+            import threading
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import ref_compare as R
-            t0 = time.perf_counter()
-            for i in range(6):
-                R.run_ref(flat[i], mk[i % NCAM], job.cams[i % NCAM], nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)
-            t1 = time.perf_counter()
-            exo = [O.Extractor(nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on) for _ in range(NCAM)]
-            for i in range(6):
-                exo[i % NCAM](flat[i], mk[i % NCAM], O.make_ocam(job.cams[i % NCAM]))
-            t2 = time.perf_counter()
-            side = {"reference_sources_ms_per_image_1thread": round((t1 - t0) / 6 * 1e3, 1), "port_ms_per_image_1thread": round((t2 - t1) / 6 * 1e3, 1)}
-        except Exception as ex:   # the side measurement is optional
-            side = {"error": str(ex)[:120]}
-    return {"extract_1thread": side, "reference_threading": faithful, "value": round(per_frame * (nf - 1) / wall / 1e6, 4), "unit": "Mfeatures/s", "cores": threads, "kind": "port",
+            import ref_scene
+            import test_io_formats as T
+            io = importlib.import_module("multicol-slam_amd.io")
+            S = ref_scene.RefScene(job.cams[:NCAM], mk, [io.cayley2hom(c) for c in T.CAYLEY], None, so_path=ref_so, nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)
+            nr = 4
+            t_ext, feats = [], []
+            for f in range(nr):
+                t0 = time.perf_counter()
+                fid = S.add_frame([flat[f * NCAM + c] for c in range(NCAM)], 0.04 * f, np.eye(4))
+                t_ext.append(time.perf_counter() - t0)
+                feats.append(S.L.rs_frame_total(S.h, fid))
+            kfs = [S.make_keyframe(f) for f in range(nr)]
+            for f in range(nr):
+                S.set_mappoints(True, kfs[f], np.ones(feats[f], np.uint8), base=100000 * f, ref_kf=kfs[f])
+            t_m = []
+            for f in range(1, nr):
+                t0 = time.perf_counter()
+                S._ids(S.L.rs_bow_kf_kf, feats[f], kfs[f], kfs[f - 1], 0.9)
+                t_m.append(time.perf_counter() - t0)
+            S.close()
+            t3 = []
+            for f in range(nr):
+                th = [threading.Thread(target=R.run_ref, args=(flat[f * NCAM + c], mk[c], job.cams[c]), kwargs=dict(nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)) for c in range(NCAM)]
+                t0 = time.perf_counter()
+                for t_ in th:
+                    t_.start()
+                for t_ in th:
+                    t_.join()
+                t3.append(time.perf_counter() - t0)
+            ext1, ext3, mt, fpm = float(np.median(t_ext)), float(np.median(t3)), float(np.median(t_m)), float(np.mean(feats))
+            refc = {"kind": "reference", "single_thread": {"value": round(fpm / (ext1 + mt) / 1e6, 5), "unit": "Mfeatures/s", "cores": 1, "extract_ms_per_multi_frame": round(ext1 * 1e3, 1),
+                                                            "match_ms_per_pair": round(mt * 1e3, 1)},
+                    "one_thread_per_camera": {"value": round(fpm / (ext3 + mt) / 1e6, 5), "unit": "Mfeatures/s", "cores": NCAM, "extract_ms_per_multi_frame": round(ext3 * 1e3, 1),
+                                              "match_ms_per_pair": round(mt * 1e3, 1)},
+                    "sample": "%d multi-frames: cMultiFrame::cMultiFrame (src/cMultiFrame.cpp:92-216) and cORBmatcher::SearchByBoW(KF,KF) (src/cORBmatcher.cpp:885-966) of the "
+                              "reference's own sources compiled here (oracle/_ref), medians; threads = Python threads around the reference's extractor (the GIL is released)" % nr}
+        except Exception as ex:   # this side measurement is optional; the error is reported, not hidden
+            refc = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+    return {"reference_compiled": refc, "reference_threading": faithful, "value": round(per_frame * (nf - 1) / wall / 1e6, 4), "unit": "Mfeatures/s", "cores": threads, "kind": "port",
+            "repetitions": len(reps), "warmups": 3, "wall_s_min_median_max": [round(walls[0], 3), round(wall, 3), round(walls[-1], 3)],
             "sample": "%d multi-frames (%d images) of the same synthetic stream: oracle extract (%s) %.2fs + SearchByBoW(KF,KF) vs previous frame %.2fs wall, "
-                      "OpenMP over images/frames on %d threads (cgroup CPU quota of this box: %d of %d hardware threads; best of quota and 2x quota, 2 passes each)"
+                      "OpenMP over images/frames on %d threads (cgroup CPU quota of this box: %d of %d hardware threads; thread count picked by the warm-ups from quota and "
+                      "2x quota); MEDIAN of 20 passes after 3 warm-ups"
                       % (nf, nf * NCAM, sp.mode, se, sm, threads, quota, nproc),
             "cpu_model": cpu_model(), "cpu_quota": quota, "nproc": nproc}
+
+
+def run_latency(e, sp, calls=300, py_calls=200):
+    """ONE multi-frame per call — the reference's own unit of work (cTracking builds one cMultiFrame per grabbed image set and tracks it, src/cTracking.cpp:206-235).
+    Per call: mcs_extract_batch of the rig's images with HOST buffers in and out (synchronous), then SearchByBoW(KF,KF) of that multi-frame against the one before it
+    (mcs_search_kf_kf, host buffers, synchronous).  Measured twice: by the native C++ program (multicol-slam_amd/host/frame_latency: page-locked buffers, no Python in
+    the loop — the figure a C++ tracker sees) and by a Python / ctypes loop over the same entry points (numpy buffers).  The last native call is checked against the
+    oracle: keypoints, descriptors, masks, counts, match indices."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    mcs, synth = e.mcs, e.synth
+    do_db, masks_on = MODES[sp.mode]
+    NCAM, W, H, nfeat = sp.ncam, sp.W, sp.H, sp.nfeat
+    cams = [synth.lafida_cameras()[c % 3] if (W, H) == (754, 480) else synth.scaled_camera(synth.lafida_cameras()[c % 3], W, H) for c in range(NCAM)]
+    frames = 8
+    imgs = [[np.ascontiguousarray(synth.stream_image(f, c, cams[c], POOL)) for f in range(frames)] for c in range(NCAM)]
+    masks = [np.ascontiguousarray(synth.mirror_mask(cams[c])) for c in range(NCAM)]
+    out = {"unit_of_work": "one %d-camera %dx%d multi-frame per call: %s extraction (N = %d) with host buffers in and out + SearchByBoW(KF,KF) against the previous multi-frame, both synchronous"
+                           % (NCAM, W, H, sp.mode, nfeat)}
+    host = os.path.join(ROOT, "multicol-slam_amd", "host", "frame_latency")
+    ok = None
+    if os.path.exists(host):
+        d = tempfile.mkdtemp(prefix="mcs_latency_")
+        np.stack([imgs[c][f] for c in range(NCAM) for f in range(frames)]).tofile(d + "/images.bin")
+        np.stack(masks).tofile(d + "/masks.bin")
+        open(d + "/cams.bin", "wb").write(bytes((mcs.Ocam * NCAM)(*[mcs.make_ocam(cams[c]) for c in range(NCAM)])))
+        open(d + "/cfg.txt", "w").write("ncam %d\nwidth %d\nheight %d\nnfeatures %d\nmode %d\nframes %d\ncalls %d\nwarmup 20\ntopk 32\ndevice %d\nimages %s/images.bin\nmasks %s/masks.bin\n"
+                                        "cams %s/cams.bin\nout %s/out\n" % (NCAM, W, H, nfeat, do_db + masks_on, frames, calls, e.local, d, d, d, d))
+        r = subprocess.run([host, d + "/cfg.txt"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            out["native"] = {"error": r.stderr[-300:]}
+            ok = False
+        else:
+            nat = json.loads(r.stdout.strip().splitlines()[-1])
+            cap, fl = nat["cap"], nat["last_frame"]
+            rows = NCAM * cap
+            nkp = np.fromfile(d + "/out.nkp", np.int32)
+            kps = np.fromfile(d + "/out.kps", np.uint8).reshape(rows, 28)
+            dsc, msk = np.fromfile(d + "/out.desc", np.uint8).reshape(rows, 32), np.fromfile(d + "/out.mask", np.uint8).reshape(rows, 32)
+            match = np.fromfile(d + "/out.match", np.int32)
+            # the oracle on the same two multi-frames, laid out like the native program's sets (camera blocks of `cap` rows, rows past a camera's count invalid)
+            want = {}
+            for f in (fl, (fl - 1) % frames):
+                D, M, V = np.zeros((rows, 32), np.uint8), np.zeros((rows, 32), np.uint8), np.zeros(rows, np.uint8)
+                K = []
+                for c in range(NCAM):
+                    k_, d_, m_ = O.Extractor(nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)(imgs[c][f], masks[c], O.make_ocam(cams[c]))
+                    D[c * cap:c * cap + len(d_)], M[c * cap:c * cap + len(d_)], V[c * cap:c * cap + len(d_)] = d_, m_, 1
+                    K.append(k_)
+                want[f] = (D, M, V, K)
+            D1, M1, V1, K1 = want[fl]
+            D0, M0, V0, _ = want[(fl - 1) % frames]
+            ones = np.full_like(D1, 255)
+            n, m12 = O.search_kf_kf(D1, M1 if masks_on else ones, V1, D0, M0 if masks_on else ones, V0, bool(masks_on), 0.9)
+            ok = (all(int(nkp[c]) == len(K1[c]) for c in range(NCAM)) and all(np.array_equal(kps[c * cap:c * cap + len(K1[c])].reshape(-1), np.ascontiguousarray(K1[c]).view(np.uint8).reshape(-1)) for c in range(NCAM))
+                  and all(np.array_equal(dsc[c * cap:c * cap + nkp[c]], D1[c * cap:c * cap + nkp[c]]) and np.array_equal(msk[c * cap:c * cap + nkp[c]], M1[c * cap:c * cap + nkp[c]]) for c in range(NCAM))
+                  and n == nat["matches_last"] and np.array_equal(match, m12))
+            nat["oracle_check"] = bool(ok)
+            nat["what"] = "native C++ host (multicol-slam_amd/host/frame_latency.cpp): page-locked staging, %d timed calls after 20 warm-up calls, steady clock around each call" % calls
+            out["native"] = nat
+            out["median_ms"], out["p99_ms"] = nat["total_ms"]["median"], nat["total_ms"]["p99"]
+            out["features_per_call"] = nat["features_last"]
+            out["Mfeatures_per_s_at_batch_1"] = round(nat["features_last"] / nat["total_ms"]["median"] / 1e3, 3)
+    else:
+        out["native"] = {"error": "multicol-slam_amd/host/frame_latency not built (__graft_entry__.build())"}
+    # the same two entry points from Python (ctypes, numpy buffers — what the -m gpu tests and frontend.py do)
+    ctx = mcs.Context(e.local)
+    ex = mcs.Extractor(ctx, W, H, max_batch=NCAM, nfeatures=nfeat, do_dBrief=do_db, learnMasks=masks_on)
+    oc = [mcs.make_ocam(c) for c in cams]
+    cap = ex.cap
+    rows = NCAM * cap
+    bufs = []
+    for _ in range(2):
+        bufs.append(dict(desc=np.zeros((rows, 32), np.uint8), mask=np.zeros((rows, 32), np.uint8), valid=np.zeros(rows, np.uint8)))
+    m12, nm, fb = np.full(rows, -1, np.int32), np.zeros(1, np.int32), np.zeros(1, np.int32)
+    te, tm = [], []
+    for it in range(20 + py_calls):
+        f = it % frames
+        cur, prev = bufs[it & 1], bufs[(it & 1) ^ 1]
+        t0 = time.perf_counter()
+        res = ex.extract_host([imgs[c][f] for c in range(NCAM)], masks, oc, want_rays=True)
+        for c in range(NCAM):
+            k = len(res[c][0])
+            cur["desc"][c * cap:c * cap + k], cur["mask"][c * cap:c * cap + k] = res[c][1], res[c][2]
+            cur["valid"][c * cap:c * cap + k], cur["valid"][c * cap + k:(c + 1) * cap] = 1, 0
+        t1 = time.perf_counter()
+        if it > 0:
+            q = mcs.DescSet(mcs.np_ptr(cur["desc"]), mcs.np_ptr(cur["mask"]) if masks_on else None, mcs.np_ptr(cur["valid"]), None, rows, 32)
+            t = mcs.DescSet(mcs.np_ptr(prev["desc"]), mcs.np_ptr(prev["mask"]) if masks_on else None, mcs.np_ptr(prev["valid"]), None, rows, 32)
+            mcs.check(e.lib.mcs_search_kf_kf(ctx.h, 1, C.byref(q), 0, C.byref(t), 0, 32, 0.9, 32, 0, mcs.np_ptr(m12), mcs.np_ptr(nm), mcs.np_ptr(fb)))
+        t2 = time.perf_counter()
+        if it >= 20:
+            te.append(1e3 * (t1 - t0)); tm.append(1e3 * (t2 - t1))
+    tot = np.array(te) + np.array(tm)
+    out["python_ctypes"] = {"calls": py_calls, "extract_ms_median": round(float(np.median(te)), 4), "match_ms_median": round(float(np.median(tm)), 4),
+                            "total_ms": {"median": round(float(np.median(tot)), 4), "p99": round(float(np.percentile(tot, 99)), 4)},
+                            "what": "the same two calls from Python (numpy buffers allocated per call by Extractor.extract_host, ctypes)"}
+    ex.close()
+    ctx.close()
+    out["oracle_check"] = ok
+    return out
 
 
 def secondary_args(args, **kw):
@@ -986,6 +1128,8 @@ def main():
         sec[0]["e2e"] = run_e2e(e, Spec(a, e.world), s2, 2, check)
         checks.append(sec[0]["e2e"]["oracle_check"])
         out["secondary"] = sec
+        out["latency"] = run_latency(e, sp)
+        checks.append(out["latency"]["oracle_check"])
         try:   # a one-rank RCCL group: the code path of the N > 1 runs (the driver's SCALE run) on this box's own RCCL
             force_exchange_world1(e)
             j3, o3 = run_job(e, sp, args, s2, 2, want_roofline=False, check=check)
@@ -1004,6 +1148,11 @@ def main():
         out["cpu_baseline"] = cpu
         out["speedup_vs_cpu_all_cores"] = round(out["value"] / cpu["value"], 2)
         out["speedup_vs_cpu_reference_threading"] = round(out["value"] / cpu["reference_threading"]["value"], 2)
+        if isinstance(out.get("latency"), dict):   # the same unit of work on the host: one multi-frame at a time with the reference's threading
+            out["latency"]["cpu_reference_threading_ms_per_multi_frame"] = cpu["reference_threading"]["ms_per_multi_frame"]
+            if isinstance(cpu.get("reference_compiled"), dict) and "one_thread_per_camera" in cpu["reference_compiled"]:
+                rc = cpu["reference_compiled"]["one_thread_per_camera"]
+                out["latency"]["reference_compiled_ms_per_multi_frame"] = round(rc["extract_ms_per_multi_frame"] + rc["match_ms_per_pair"], 1)
     failed = check and e.rank == 0 and any(c is False for c in checks)
     if e.dist.is_initialized():
         e.dist.barrier()

@@ -35,7 +35,7 @@ extern "C" {
  * since round 2 — callers built against an older header must be recompiled; mcs_describe_fast_table, FAST types 0 / 1 in round 3; 4: mcs_extractor_tie_stats; 5: mcs_copy_narrow,
  * mcs_ctx_result_stream, mcs_ctx_stream_conflicts, mcs_ctx_transfer_stream in round 4).  mcs_abi_version() returns
  * the value the LIBRARY was built with: compare it with MCS_ABI_VERSION after dlopen. */
-#define MCS_ABI_VERSION 5
+#define MCS_ABI_VERSION 6
 
 #define MCS_MAX_POLY 16
 #define MCS_MAX_LEVELS 16
@@ -135,6 +135,19 @@ int mcs_extract_batch(mcs_extractor*, int nimg, const uint8_t* images, size_t im
 int mcs_extractor_set_describe(mcs_extractor*, int exact_only, double guard_eps);
 int mcs_extractor_describe_stats(mcs_extractor*, uint64_t* exact_pass_keypoints, double* guard_eps);
 int mcs_extractor_tie_stats(mcs_extractor*, double* min_tie_distance, int reset);
+/* Rounding ties are ENFORCED, not only watched (round 5; csrc/mcs_tiefix.hip; reference src/mdBRIEFextractorOct.cpp:280-281, 295-296).  Every keypoint whose
+ * exact arithmetic (ORB rotation; rotateAndDistortPattern in the exact pass) produced a cvRound argument within `band` pixels of a tie is listed by the device,
+ * and its descriptor (+ mask) is recomputed ON THE HOST with the host's libm — the one the reference links — before the results are final:
+ *   - host-kind mcs_extract_batch does it by itself before it returns (it synchronises anyway);
+ *   - device-kind calls only enqueue work: the caller runs mcs_extractor_fix_ties once the batch may be synchronised and BEFORE the extractor's next batch (the
+ *     list belongs to the last batch); it waits for the context's stream, patches the device rows in place and reports how many it recomputed.  A caller that
+ *     consumes the rows on-stream without it accepts the device libm's rounding for the listed keypoints (counted: mcs_extractor_tie_counts).
+ *   mcs_extractor_set_tie_band   band in pixels; 0 = default (1e-9 for dBRIEF / mdBRIEF, 1e-12 for ORB — csrc/mcs_tiefix.hip derives both from a two-ulp libm
+ *                                difference), < 0 = list nothing (round 4's behaviour), at most 0.5 (= every exact-pass keypoint: the test suite's setting)
+ *   mcs_extractor_tie_counts     keypoints listed / recomputed since the extractor was created, and the band in use; any output may be NULL                        */
+int mcs_extractor_set_tie_band(mcs_extractor*, double band_px);
+int mcs_extractor_fix_ties(mcs_extractor*, int* recomputed);
+int mcs_extractor_tie_counts(mcs_extractor*, uint64_t* listed, uint64_t* recomputed, double* band_px);
 int mcs_describe_fast_bound(const mcs_ocam* cam, int desc_size, double* bound);
 int mcs_selftest_describe_fast(mcs_ctx*, const mcs_ocam* cam, uint64_t seed, int n, double* max_abs_diff);
 int mcs_describe_fast_table(const mcs_ocam* cam, double* table, int* rows, int* row_len, int* e0, int* bins_per_octave, double* info6);
@@ -354,7 +367,10 @@ int mcs_rig_rows_valid(mcs_ctx*, const uint8_t* blocks_dev, int nimg, int cap, i
 int mcs_copy_narrow(mcs_ctx*, void* dst, const void* src, size_t bytes, int workgroups, void* hip_stream);
 /* The stream on which the outputs of the latest mcs_search_* call on device memory become complete IN STREAM ORDER (the greedy pass's stream; the context's own
  * stream when nothing is overlapped).  Results leave for the host from here without an event in front and without another stream: enqueue mcs_copy_narrow on it
- * right after the search call, record an event behind the copies, and wait for that event before the buffers are written again. */
+ * right after the search call, record an event behind the copies, and wait for that event before the buffers are written again.
+ * The answer belongs to the LATEST search (each search records the stream it used); before the first search it is the stream the next one would use in the
+ * context's current mode — so query it AFTER the search whose results are to be copied, or at least after mcs_ctx_set_async_search / mcs_ctx_enable_timing:
+ * both change which stream completes a search (in-order: the greedy pass's stream; deferred: a further one behind it). */
 int mcs_ctx_result_stream(mcs_ctx*, void** hip_stream);
 /* Long transfers beside the step — the image upload (hipMemcpyAsync from page-locked memory), the descriptor exchange of a multi-GPU rig (RCCL) — run on a
  * stream of the caller's, and which HARDWARE QUEUE that stream gets is the runtime's choice: HIP streams are dealt onto four queues, a queue runs its packets in
@@ -366,6 +382,12 @@ int mcs_ctx_result_stream(mcs_ctx*, void** hip_stream);
  *                              deferred matcher's, which has a step of slack (owned by the context; *conflicts = its mask, may be NULL) */
 int mcs_ctx_stream_conflicts(mcs_ctx*, void* hip_stream, unsigned* mask);
 int mcs_ctx_transfer_stream(mcs_ctx*, void** hip_stream, unsigned* conflicts);
+
+/* Page-locked host memory (hipHostMalloc) for callers that only see this header: images staged in it are uploaded by DMA without the runtime's pageable-memory
+ * bounce buffer, results copied into it arrive at PCIe rate.  integration/cMultiFrame_mcs.cpp stages the rig's images and receives keypoints / descriptors /
+ * rays through it (the cv::Mat / std::vector side of src/cMultiFrame.cpp:92-216).  Free before mcs_ctx_destroy. */
+int mcs_host_alloc(mcs_ctx*, size_t bytes, void** out);
+int mcs_host_free(mcs_ctx*, void* p);
 
 /* single-pair distances on the device (known-answer / spot checks) */
 int mcs_descriptor_distance(mcs_ctx*, const uint8_t* a, const uint8_t* b, int dim, int* out);

@@ -16,6 +16,7 @@
 
 #include "mdBRIEFextractorOct.h"
 #include "mcs_c.h"
+#include "mcs_dropin.h"
 
 namespace MultiColSLAM
 {
@@ -31,9 +32,19 @@ namespace
 	mcs_ctx* g_ctx = nullptr;                                   // one context (device 0, its own stream) for all extractors of the process
 	std::map<Key, Device> g_devices;
 
+	void check(int rc, const char* what) { mcs_dropin::check(rc, what); }
+}
+namespace mcs_dropin
+{
 	void check(int rc, const char* what)
 	{
 		if (rc != MCS_OK) throw std::runtime_error(std::string(what) + ": " + mcs_last_error());
+	}
+	std::mutex& mutex() { return g_mutex; }
+	mcs_ctx* context()   // call with mutex() held
+	{
+		if (!g_ctx) check(mcs_ctx_create(0, nullptr, &g_ctx), "mcs_ctx_create");
+		return g_ctx;
 	}
 }
 
@@ -59,7 +70,7 @@ void mdBRIEFextractorOct::operator()(cv::InputArray _image, cv::InputArray _mask
 	Device dev;
 	{
 		std::lock_guard<std::mutex> lock(g_mutex);
-		if (!g_ctx) check(mcs_ctx_create(0, nullptr, &g_ctx), "mcs_ctx_create");
+		mcs_dropin::context();
 		Key key;
 		std::memset(&key, 0, sizeof(key));   // padding bytes take part in the comparison
 		const mcs_extractor_params p = { nfeatures, (float)scaleFactor, numlevels, edgeThreshold, firstLevel, scoreType, patchSize, fastThreshold,

@@ -167,6 +167,22 @@ class Extractor:
         check(lib().mcs_extractor_tie_stats(self.h, C.byref(v), int(reset)))
         return v.value
 
+    def set_tie_band(self, band_px=0.0):
+        """band (px) around the cvRound ties inside which an exact-arithmetic keypoint is recomputed on the host with the host's libm; 0 = default, < 0 = off"""
+        check(lib().mcs_extractor_set_tie_band(self.h, float(band_px)))
+
+    def fix_ties(self):
+        """device-kind batches: recompute the last batch's listed keypoints on the host and patch the device rows; returns how many"""
+        n = C.c_int()
+        check(lib().mcs_extractor_fix_ties(self.h, C.byref(n)))
+        return n.value
+
+    def tie_counts(self):
+        """(keypoints listed, keypoints recomputed on the host, band in px) since creation"""
+        a, b_, band = C.c_uint64(), C.c_uint64(), C.c_double()
+        check(lib().mcs_extractor_tie_counts(self.h, C.byref(a), C.byref(b_), C.byref(band)))
+        return a.value, b_.value, band.value
+
     # ---- stage taps (parity tests)
     def tap_level(self, img, level, blurred=False):
         w, h = self.level_sizes[level]

@@ -13,8 +13,11 @@
 #include <vector>
 
 namespace mcs {
-void upload_describe_tables(const signed char* pattern);
+bool upload_describe_tables(const signed char* pattern);
 void launch_single_distance(const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out, hipStream_t s);
+struct HostLevel { const uint8_t* blur; const uint8_t* raw; int w, h; };
+void describe_host(int mode, int descSize, const signed char* pattern, const OcamDev* cam, int undistort, int level, float levelScale, int row, int col, float angle,
+                   const HostLevel& L, uint8_t* desc, uint8_t* mask);   // mcs_tiefix.hip
 void launch_selftest_fast_model(const OcamDev* cam, const double* tab, unsigned long long seed, int n, int width, int height, unsigned long long* maxDiff, hipStream_t s);
 static const signed char kPattern[2048] = {
 #include "learned_pattern_64_orb.inc"
@@ -26,6 +29,8 @@ using namespace mcs;
 // Guard band of the fast descriptor pass: a coordinate closer than this to a rounding tie sends its keypoint to the exact pass.  2^-24 px: ~4 of
 // 10 000 keypoints, and 30-40x above describe_fast_bound() for the Lafida cameras.
 static constexpr double kDefaultGuardEps = 5.9604644775390625e-08;
+// Default bands around the cvRound ties inside which an exact-arithmetic keypoint is recomputed on the host with the host's libm (mcs_tiefix.hip says why these)
+static constexpr double kTieBandOrb = 1e-12, kTieBandDistorted = 1e-9;
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 // The fast pass's table of G(s) = rho(theta) / sqrt(s), theta = atan(p0 / sqrt(s)), for one camera (layout: mcs_common.h kG*), built in long double, with
@@ -230,6 +235,8 @@ struct mcs_extractor {
 	// descriptor passes (mcs_describe.hip): fallback list of the fast pass, its running total, the guard band
 	int* d_fbCount = nullptr; uint32_t *d_fbList = nullptr, *d_preList = nullptr; unsigned long long* d_fbStats = nullptr; unsigned long long* d_tieMin = nullptr; void* d_aux = nullptr;   // d_fbCount: [0] fallback list, [1] pre-list
 	int describeMode = 0; double guardEps = kDefaultGuardEps;
+	// rounding ties of the exact arithmetic (mcs_tiefix.hip): the batch's listed keypoints, the band (0 = the mode's default, < 0 = list nothing), totals
+	uint32_t* d_tieList = nullptr; double tieBand = 0.0; unsigned long long tieFixed = 0;
 	// G(s) tables of the cameras seen so far (a rig has a handful), and the batch's distinct tables as the fast pass reads them
 	struct CamFast { OcamDev key; GTabInfo info; std::vector<double> tab; };
 	std::vector<CamFast> camCache;
@@ -272,8 +279,13 @@ int mcs_ctx_create(int device, void* hip_stream, mcs_ctx** out) {
 		auto masked = [&](hipStream_t* st, const char* var) -> hipError_t {
 			const char* m = getenv(var);
 			if (!m || !*m) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+			char* end = nullptr;
+			const unsigned long v = strtoul(m, &end, 16);
+			if (end == m || *end != '\0' || v == 0 || v > 0xFFFFFFFFul) { fprintf(stderr, "mcs: %s=\"%s\" is not a non-zero 32-bit hex word\n", var, m); return hipErrorInvalidValue; }
+			// NOTE: hipExtStreamCreateWithCUMask makes a BLOCKING stream (it synchronises implicitly with the null stream), unlike the hipStreamNonBlocking ones of
+			// the default path: an A/B through these switches changes more than CU placement
 			uint32_t words[16];
-			for (auto& w : words) w = (uint32_t)strtoul(m, nullptr, 16);
+			for (auto& w : words) w = (uint32_t)v;
 			hipDeviceProp_t prop;
 			if (hipGetDeviceProperties(&prop, device) != hipSuccess) return hipErrorInvalidValue;
 			return hipExtStreamCreateWithCUMask(st, (uint32_t)((prop.multiProcessorCount + 31) / 32), words);
@@ -309,7 +321,9 @@ int mcs_ctx_set_async_search(mcs_ctx* c, int on) {
 	if (!c) return fail(MCS_ERR_INVALID, "null ctx");
 	HIPCHK(hipStreamSynchronize(c->stream));
 	if (c->side2) { HIPCHK(hipStreamSynchronize(c->side2)); HIPCHK(hipStreamSynchronize(c->side3)); }
+	const bool was = c->asyncSearch;
 	c->asyncSearch = on != 0 && c->side2 != nullptr;
+	if (was != c->asyncSearch) { c->upload = nullptr; c->lastResultStream = nullptr; }   // the transfer stream is re-scored for the new mode (mcs_copy.hip); the result stream follows the next search
 	return MCS_OK;
 }
 
@@ -538,7 +552,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 		for (int u = -umax[std::abs(v)]; u <= umax[std::abs(v)]; ++u) { disc.push_back((signed char)u); disc.push_back((signed char)v); }
 	if (disc.size() != 845 * 2) { delete e; return fail(MCS_ERR_INVALID, "internal: disc size"); }
 	for (int v = 0; v <= kHalfPatch; ++v) hd.umax[v] = umax[v];
-	upload_describe_tables(kPattern);
+	if (!upload_describe_tables(kPattern)) { delete e; return fail(MCS_ERR_HIP, "pattern tables: upload failed (or the distinct-point rounds of mcs_describe.hip do not fit this pattern)"); }
 
 	hd.chainFits = 0; hd.chainRegOff = 0;
 	// One launch for the whole resize chain (k_resize_chain, bit-exact, tests/test_gpu_env_paths.py) is opt-in: measured 0.37 ms alone against 0.22 ms for the
@@ -571,10 +585,11 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	ALLOC(e->d_status, sizeof(int));
 	ALLOC(e->d_cams, B * sizeof(OcamDev));
 	const size_t slotsPerImage = (size_t)(hd.kpCap + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
-	ALLOC(e->d_fbCount, 2 * sizeof(int));
+	ALLOC(e->d_fbCount, 3 * sizeof(int));   // [0] fallback list, [1] pre-list, [2] tie list
+	ALLOC(e->d_tieList, B * slotsPerImage * sizeof(uint32_t));
 	ALLOC(e->d_fbList, B * slotsPerImage * sizeof(uint32_t));
 	ALLOC(e->d_preList, B * slotsPerImage * sizeof(uint32_t));
-	ALLOC(e->d_fbStats, sizeof(unsigned long long));
+	ALLOC(e->d_fbStats, 2 * sizeof(unsigned long long));   // [0] exact-pass keypoints, [1] tie-listed keypoints
 	ALLOC(e->d_tieMin, sizeof(unsigned long long));
 	ALLOC(e->d_aux, B * slotsPerImage * describe_aux_bytes());
 	ALLOC(e->d_gTab, B * (size_t)kGTabDoubles * sizeof(double));
@@ -589,8 +604,8 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	if (!taps.empty()) HIPCHK(hipMemcpy(e->d_taps, taps.data(), sizeof(ResizeTap) * taps.size(), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(e->d_maskMap, maps.data(), sizeof(short) * maps.size(), hipMemcpyHostToDevice));
 	HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
-	HIPCHK(hipMemset(e->d_fbCount, 0, 2 * sizeof(int)));
-	HIPCHK(hipMemset(e->d_fbStats, 0, sizeof(unsigned long long)));
+	HIPCHK(hipMemset(e->d_fbCount, 0, 3 * sizeof(int)));
+	HIPCHK(hipMemset(e->d_fbStats, 0, 2 * sizeof(unsigned long long)));
 	{ const unsigned long long inf = 0x7FF0000000000000ull; HIPCHK(hipMemcpy(e->d_tieMin, &inf, sizeof(inf), hipMemcpyHostToDevice)); }   // +inf: no coordinate seen yet
 	if (getenv("MCS_DESCRIBE_EXACT")) e->describeMode = 1;   // A/B and debugging: the exact pass for every keypoint
 	HIPCHK(hipMemset(e->d_pyr, 0, B * hd.pyrBytes));
@@ -610,7 +625,7 @@ int mcs_extractor_destroy(mcs_extractor* e) {
 	}
 	void* ptrs[] = {e->d_desc, e->d_cells, e->d_taps, e->d_maskMap, e->d_pyr, e->d_blur, e->d_slots, e->d_dense, e->d_knode,
 	                e->d_sel, e->d_cellCount, e->d_denseCount, e->d_selCount, e->d_status, e->d_cams, e->d_nkp, e->d_kps, e->d_odesc,
-	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_preList, e->d_fbStats, e->d_tieMin, e->d_aux, e->d_gTab, e->d_selAngle};
+	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_preList, e->d_fbStats, e->d_tieMin, e->d_aux, e->d_gTab, e->d_selAngle, e->d_tieList};
 	for (void* p : ptrs) (void)hipFree(p);
 	delete e;
 	return MCS_OK;
@@ -642,6 +657,58 @@ static int grow(uint8_t** p, size_t* cap, size_t need) {   // device buffer of a
 	return MCS_OK;
 }
 
+// The listed keypoints of the extractor's LAST batch (ExtractBuffers.tieList) through describe_host; the stream must be idle.  The recomputed rows replace the
+// device outputs in place and, when given, the host copies (tight [image][kpCap][descSize] arrays).
+static int fix_ties(mcs_extractor* e, int nties, uint8_t* h_desc, uint8_t* h_mask) {
+	const PyrDesc& hd = e->hd;
+	const ExtractBuffers& b = e->last;
+	const int wavesPerImage = (hd.kpCap + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
+	const int cap = e->maxBatch * wavesPerImage;
+	if (nties > cap) nties = cap;
+	std::vector<uint32_t> list(nties);
+	HIPCHK(hipMemcpy(list.data(), e->d_tieList, sizeof(uint32_t) * nties, hipMemcpyDeviceToHost));
+	std::sort(list.begin(), list.end());   // by image, then slot: one download per (image, level)
+	struct Lv { std::vector<uint8_t> blur, raw; };
+	std::map<std::pair<int, int>, Lv> levels;
+	std::vector<int> selCount(hd.nlevels);
+	int curImg = -1;
+	std::vector<uint8_t> dsc(hd.descSize), msk(hd.descSize);
+	for (uint32_t gw : list) {
+		const int img = (int)(gw / (uint32_t)wavesPerImage), sl = (int)(gw - (uint32_t)img * wavesPerImage);
+		if (img >= e->lastN || sl >= hd.kpCap) continue;
+		if (img != curImg) { HIPCHK(hipMemcpy(selCount.data(), e->d_selCount + (size_t)img * hd.nlevels, sizeof(int) * hd.nlevels, hipMemcpyDeviceToHost)); curImg = img; levels.clear(); }
+		int level = -1, pos = 0, total = 0;
+		for (int l = 0; l < hd.nlevels; ++l) { if (sl >= total && sl < total + selCount[l]) { level = l; pos = sl - total; } total += selCount[l]; }
+		if (level < 0) continue;
+		const LevelInfo& L = hd.lv[level];
+		uint32_t rec = 0; float angle = 0.f;
+		HIPCHK(hipMemcpy(&rec, e->d_sel + (size_t)img * hd.selPerImage + L.selBase + pos, sizeof(rec), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(&angle, e->d_selAngle + (size_t)img * hd.selPerImage + L.selBase + pos, sizeof(angle), hipMemcpyDeviceToHost));
+		Lv& lv = levels[std::make_pair(img, level)];
+		if (lv.blur.empty()) {
+			lv.blur.resize((size_t)L.w * L.h); lv.raw.resize((size_t)L.w * L.h);
+			int rstride = 0;
+			const uint8_t* raw = level_ptr(b, hd, img, level, &rstride);
+			HIPCHK(hipMemcpy2D(lv.blur.data(), L.w, e->d_blur + (size_t)img * hd.pyrBytes + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost));
+			HIPCHK(hipMemcpy2D(lv.raw.data(), L.w, raw, rstride, L.w, L.h, hipMemcpyDeviceToHost));
+		}
+		HostLevel hl{lv.blur.data(), lv.raw.data(), L.w, L.h};
+		const int col = (int)(rec & 0xFFF) + kMinBorder, row = (int)((rec >> 12) & 0xFFF) + kMinBorder;
+		const OcamDev* cam = hd.mode != 0 && (size_t)img < e->h_cams.size() ? &e->h_cams[img] : nullptr;
+		if (hd.mode != 0 && !cam) return fail(MCS_ERR_INVALID, "internal: tie list without camera models");
+		describe_host(hd.mode, hd.descSize, kPattern, cam, hd.undistort, level, L.scale, row, col, angle, hl, dsc.data(), msk.data());
+		const size_t drow = ((size_t)img * b.outImgPitch + sl) * b.outRowStride;
+		HIPCHK(hipMemcpy(b.out_desc + drow, dsc.data(), hd.descSize, hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(b.out_mask + drow, msk.data(), hd.descSize, hipMemcpyHostToDevice));
+		if (h_desc) memcpy(h_desc + ((size_t)img * hd.kpCap + sl) * hd.descSize, dsc.data(), hd.descSize);
+		if (h_mask) memcpy(h_mask + ((size_t)img * hd.kpCap + sl) * hd.descSize, msk.data(), hd.descSize);
+		e->tieFixed++;
+	}
+	const int zero = 0;
+	HIPCHK(hipMemcpy(e->d_fbCount + 2, &zero, sizeof(int), hipMemcpyHostToDevice));   // done: a second call finds nothing
+	return MCS_OK;
+}
+
 static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_t image_pitch, int image_stride, const uint8_t* masks,
                         size_t mask_pitch, int mask_stride, const mcs_ocam* cams, mcs_mem_kind kind, int32_t* nkp, mcs_keypoint* keypoints,
                         uint8_t* desc, uint8_t* descmask, double* rays, size_t out_image_pitch_rows, int out_row_stride) {
@@ -661,6 +728,8 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 	b.denseCount = e->d_denseCount; b.sel = e->d_sel; b.selCount = e->d_selCount; b.selAngle = e->d_selAngle; b.status = e->d_status;
 	b.gTab = e->d_gTab; b.aux = e->d_aux; b.fbCount = e->d_fbCount; b.fbList = e->d_fbList; b.preCount = e->d_fbCount + 1; b.preList = e->d_preList;
 	b.fbStats = e->d_fbStats; b.tieMin = e->d_tieMin; b.guardEps = e->guardEps; b.describeMode = e->describeMode;
+	b.tieCount = e->d_fbCount + 2; b.tieList = e->d_tieList; b.tieTotal = e->d_fbStats + 1;
+	b.tieBand = e->tieBand > 0.0 ? e->tieBand : (e->tieBand < 0.0 ? -1.0 : (hd.mode == 0 ? kTieBandOrb : kTieBandDistorted));
 	b.sideStream = nullptr; b.evDescFork = nullptr; b.evDescJoin = nullptr;
 	b.outImgPitch = out_image_pitch_rows ? out_image_pitch_rows : (size_t)hd.kpCap;
 	b.outRowStride = out_row_stride ? out_row_stride : hd.descSize;
@@ -676,6 +745,12 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		if (!interleaved && hi - lo < span) return fail(MCS_ERR_INVALID, "descriptor and mask rows overlap for this pitch / stride");
 	}
 	if (kind == MCS_MEM_HOST && (b.outImgPitch != (size_t)hd.kpCap || b.outRowStride != hd.descSize)) return fail(MCS_ERR_UNSUPPORTED, "strided descriptor outputs need device memory");
+	{
+		// k_blur / k_resize_cols form a lane's level-0 source offset as (image - first image of the wave) * image_pitch in 32 bits; a wave spans 64 / (column groups
+		// per image) + 2 images at most
+		const unsigned long long ncg = (unsigned long long)((hd.width + 3) / 4), span = 64ull / (ncg ? ncg : 1ull) + 2ull;
+		if ((unsigned long long)image_pitch * span >= (1ull << 32)) return fail(MCS_ERR_UNSUPPORTED, "image_pitch too large for the level-0 readers (pitch * images per wave must stay below 4 GiB)");
+	}
 	if (kind == MCS_MEM_HOST) {
 		// ONE linear copy per block, in the caller's own layout; the kernels take any pitch / stride for level 0.  (A pitched hipMemcpy2D from pageable
 		// host memory is carried out row by row by the runtime: 2 x 480 small transfers per image, ~9 ms per image.)
@@ -803,10 +878,13 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		HIPCHK(hipMemcpyAsync(desc, e->d_odesc, rows * hd.descSize, hipMemcpyDeviceToHost, s));
 		HIPCHK(hipMemcpyAsync(descmask, e->d_omask, rows * hd.descSize, hipMemcpyDeviceToHost, s));
 		if (rays) HIPCHK(hipMemcpyAsync(rays, e->d_rays, rows * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-		int st = 0;
+		int st = 0, nties = 0;
 		HIPCHK(hipMemcpyAsync(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+		HIPCHK(hipMemcpyAsync(&nties, e->d_fbCount + 2, sizeof(int), hipMemcpyDeviceToHost, s));
 		HIPCHK(hipStreamSynchronize(s));
 		if (st != 0) { (void)hipMemset(e->d_status, 0, sizeof(int)); return fail(st, "device capacity exceeded during extraction"); }
+		// keypoints whose exact arithmetic came within the band of a rounding tie: recomputed here with the host's libm before the results are final
+		if (nties > 0) { if (int r = fix_ties(e, nties, desc, descmask)) return r; }
 	}
 	return MCS_OK;
 }
@@ -860,6 +938,40 @@ int mcs_extractor_tie_stats(mcs_extractor* e, double* min_tie_distance, int rese
 	HIPCHK(hipMemcpy(&v, e->d_tieMin, sizeof(v), hipMemcpyDeviceToHost));
 	if (min_tie_distance) memcpy(min_tie_distance, &v, sizeof(double));
 	if (reset) { const unsigned long long inf = 0x7FF0000000000000ull; HIPCHK(hipMemcpy(e->d_tieMin, &inf, sizeof(inf), hipMemcpyHostToDevice)); }
+	return MCS_OK;
+}
+
+int mcs_extractor_set_tie_band(mcs_extractor* e, double band_px) {
+	if (!e) return fail(MCS_ERR_INVALID, "null");
+	if (!(band_px <= 0.5)) return fail(MCS_ERR_INVALID, "tie band must be <= 0.5 pixels (0 = default, < 0 = list nothing)");
+	HIPCHK(hipStreamSynchronize(e->ctx->stream));
+	e->tieBand = band_px;
+	return MCS_OK;
+}
+
+int mcs_extractor_fix_ties(mcs_extractor* e, int* recomputed) {
+	if (!e) return fail(MCS_ERR_INVALID, "null");
+	if (recomputed) *recomputed = 0;
+	if (e->lastN <= 0) return MCS_OK;
+	HIPCHK(hipSetDevice(e->ctx->device));
+	HIPCHK(hipStreamSynchronize(e->ctx->stream));
+	int nties = 0;
+	HIPCHK(hipMemcpy(&nties, e->d_fbCount + 2, sizeof(int), hipMemcpyDeviceToHost));
+	if (nties <= 0) return MCS_OK;
+	const unsigned long long before = e->tieFixed;
+	if (int r = fix_ties(e, nties, nullptr, nullptr)) return r;
+	if (recomputed) *recomputed = (int)(e->tieFixed - before);
+	return MCS_OK;
+}
+
+int mcs_extractor_tie_counts(mcs_extractor* e, uint64_t* listed, uint64_t* recomputed, double* band_px) {
+	if (!e) return fail(MCS_ERR_INVALID, "null");
+	HIPCHK(hipStreamSynchronize(e->ctx->stream));
+	unsigned long long v = 0;
+	HIPCHK(hipMemcpy(&v, e->d_fbStats + 1, sizeof(v), hipMemcpyDeviceToHost));
+	if (listed) *listed = v;
+	if (recomputed) *recomputed = e->tieFixed;
+	if (band_px) *band_px = e->tieBand > 0.0 ? e->tieBand : (e->tieBand < 0.0 ? -1.0 : (e->hd.mode == 0 ? kTieBandOrb : kTieBandDistorted));
 	return MCS_OK;
 }
 

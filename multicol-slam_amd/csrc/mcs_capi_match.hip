@@ -258,6 +258,7 @@ static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc
 			HIPCHK(hipEventRecord(c->evSearch[c->searchSeq & 3], c->side3));
 			++c->searchSeq;
 			c->greedyPending = true;
+			c->lastResultStream = c->side3;
 		} else if (c->overlap()) {
 			// the greedy resolution is one wave per set pair (latency-bound): run it on the side stream so that whatever the caller
 			// enqueues next on the main stream (the next batch's extraction) fills the idle CUs.  mcs_ctx_join / the next search /
@@ -267,7 +268,8 @@ static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc
 			launch_greedy(g, c->side2);
 			HIPCHK(hipEventRecord(c->evGreedy, c->side2));
 			c->greedyPending = true;
-		} else { c->tic("greedy"); launch_greedy(g, s); c->toc("greedy"); }
+			c->lastResultStream = c->side2;
+		} else { c->tic("greedy"); launch_greedy(g, s); c->toc("greedy"); c->lastResultStream = s; }
 		HIPCHK(hipGetLastError());
 		return MCS_OK;
 	}

@@ -136,6 +136,10 @@ struct ExtractBuffers {
 	int* preCount; uint32_t* preList;    // ... and the ones k_orient_b sent there before the fast pass ran (camera not served, keypoint next to the optical axis)
 	unsigned long long* fbStats;         // running total of both (all batches of the extractor)
 	unsigned long long* tieMin;          // bits of the smallest distance to a rounding tie (| |frac| - 1/2 |, pixels) seen among the cvRound arguments of the EXACT arithmetic
+	// keypoints of this batch whose EXACT arithmetic had a cvRound argument within tieBand of a tie: the host recomputes them with its own libm (mcs_tiefix.hip)
+	int* tieCount; uint32_t* tieList;    // slots (image * wavesPerImage + slot); tieCount = fbCount + 2, cleared with its neighbours by k_octree
+	unsigned long long* tieTotal;        // running total (all batches of the extractor)
+	double tieBand;                      // pixels; < 0: nothing is listed
 	hipStream_t sideStream; hipEvent_t evDescFork, evDescJoin;   // optional: the exact pass over preList runs here, beside the fast pass
 	double guardEps;                     // half-width of the guard band around the rounding ties
 	int describeMode;                    // 0 fast + exact fallback, 1 exact pass for every keypoint

@@ -64,19 +64,32 @@ extern "C" int mcs_ctx_stream_conflicts(mcs_ctx* c, void* hip_stream, unsigned* 
 	hipStream_t cand = (hipStream_t)hip_stream;
 	hipStream_t own[4] = {c->stream, c->side, c->side2, c->side3};
 	bool ok = true;
-	for (int i = 0; i < 4 && ok; ++i) {
-		if (own[i] == cand) { *mask |= 1u << i; continue; }
-		ok = hipStreamSynchronize(own[i]) == hipSuccess && hipStreamSynchronize(cand) == hipSuccess;
-		if (!ok) break;
+	// one probe: hold own[i], launch the marker on the candidate, watch for it while the hold spins.  The verdict rests on wall-clock time, so everything else is
+	// quiesced first (work in flight on ANY of the context's streams could delay the marker: a false conflict), the launches are checked, and a "conflict" is only
+	// believed when a second probe agrees (a host thread descheduled between the two launches looks the same as a shared queue).  What remains undecidable from
+	// here — a host stall longer than the 3 ms hold reads as "no conflict" — costs performance, not correctness: the streams are ordered by events either way.
+	auto probe = [&](int i, bool* conflict) -> bool {
+		for (hipStream_t st : own) if (st && hipStreamSynchronize(st) != hipSuccess) return false;
+		if (hipStreamSynchronize(cand) != hipSuccess) return false;
 		pin[0] = 0; pin[16] = 0;
 		hipLaunchKernelGGL(mcs::k_hold, dim3(1), dim3(1), 0, own[i], pin);
+		const hipError_t e1 = hipGetLastError();
 		hipLaunchKernelGGL(mcs::k_mark, dim3(1), dim3(1), 0, cand, pin + 16);
+		const hipError_t e2 = hipGetLastError();
 		const auto t0 = std::chrono::steady_clock::now();
 		bool seen = false;
-		while (!(seen = pin[16] != 0) && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1500)) {}
-		if (!seen) *mask |= 1u << i;
+		while (e1 == hipSuccess && e2 == hipSuccess && !(seen = pin[16] != 0) && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1500)) {}
 		pin[0] = 1;   // release the hold
-		ok = hipStreamSynchronize(own[i]) == hipSuccess && hipStreamSynchronize(cand) == hipSuccess;
+		const bool synced = hipStreamSynchronize(own[i]) == hipSuccess && hipStreamSynchronize(cand) == hipSuccess;
+		*conflict = !seen;
+		return e1 == hipSuccess && e2 == hipSuccess && synced;
+	};
+	for (int i = 0; i < 4 && ok; ++i) {
+		if (own[i] == cand) { *mask |= 1u << i; continue; }
+		bool conflict = false;
+		ok = probe(i, &conflict);
+		if (ok && conflict) ok = probe(i, &conflict);   // believe a conflict only twice in a row
+		if (ok && conflict) *mask |= 1u << i;
 	}
 	(void)hipHostFree((void*)pin);   // on every path
 	return ok ? MCS_OK : fail(MCS_ERR_HIP, "stream probe failed");
@@ -89,16 +102,25 @@ extern "C" int mcs_ctx_transfer_stream(mcs_ctx* c, void** hip_stream, unsigned* 
 	if (!c || !hip_stream) return fail(MCS_ERR_INVALID, "bad argument");
 	HIPCHK(hipSetDevice(c->device));
 	if (!c->upload) {
+		// measured (default step, 1.54 ms device-resident, deferred searches): sharing with the deferred matcher's stream 1.60 ms, with the greedy pass's (the results'
+		// way out) 2.17 ms, with the main stream 2.89 ms.  What bits 2 and 3 MEAN depends on the search mode: deferred — side2 carries the lists (a step of slack),
+		// side3 the greedy pass and the results; in order — side2 is the greedy pass and the result stream, side3 is idle.  The choice is re-scored (not re-probed)
+		// when mcs_ctx_set_async_search changes the mode.
+		const bool deferred = c->asyncSearch;
+		auto cost = [deferred](unsigned x) {
+			const int c2 = deferred ? 1 : 4, c3 = deferred ? 4 : 0;
+			return (x & 1u ? 8 : 0) + (x & 2u ? 8 : 0) + (x & 4u ? c2 : 0) + (x & 8u ? c3 : 0);
+		};
 		hipStream_t best = nullptr; unsigned bestMask = ~0u;
-		// measured (default step, 1.54 ms device-resident): sharing with the deferred matcher's stream 1.60 ms, with the greedy pass's (the results' way out) 2.17 ms,
-		// with the main stream 2.89 ms
-		for (int t = 0; t < 8 && (bestMask & ~0x4u) != 0; ++t) {
+		for (size_t i = 0; i < c->probed.size(); ++i)
+			if (!best || cost(c->probedMask[i]) < cost(bestMask)) { best = c->probed[i]; bestMask = c->probedMask[i]; }
+		for (int t = (int)c->probed.size(); t < 8 && (!best || cost(bestMask) > 1); ++t) {
 			hipStream_t s = nullptr;
 			HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-			c->probed.push_back(s);   // kept alive until the context goes: a destroyed stream would hand its queue slot to the next candidate
 			unsigned m = 0;
-			if (int r = mcs_ctx_stream_conflicts(c, s, &m)) return r;
-			auto cost = [](unsigned x) { return (x & 1u ? 8 : 0) + (x & 2u ? 8 : 0) + (x & 4u ? 1 : 0) + (x & 8u ? 4 : 0); };
+			if (int r = mcs_ctx_stream_conflicts(c, s, &m)) { (void)hipStreamDestroy(s); return r; }
+			c->probed.push_back(s);   // kept alive until the context goes: a destroyed stream would hand its queue slot to the next candidate
+			c->probedMask.push_back(m);
 			if (!best || cost(m) < cost(bestMask)) { best = s; bestMask = m; }
 		}
 		c->upload = best; c->uploadMask = bestMask;
@@ -140,6 +162,25 @@ extern "C" int mcs_copy_narrow(mcs_ctx* c, void* dst, const void* src, size_t by
 // with them, and a queue runs in order), and waits in nobody's way: the only later work on this stream is the next step's greedy pass, which has a step of slack.
 extern "C" int mcs_ctx_result_stream(mcs_ctx* c, void** hip_stream) {
 	if (!c || !hip_stream) return fail(MCS_ERR_INVALID, "bad argument");
-	*hip_stream = (void*)(c->overlap() ? (c->asyncSearch ? c->side3 : c->side2) : c->stream);
+	// the stream the latest search actually used (recorded by the search itself: the answer cannot go stale when mcs_ctx_set_async_search or
+	// mcs_ctx_enable_timing is toggled between the search and this query); before the first search, the stream the NEXT one would use in the current mode
+	*hip_stream = (void*)(c->lastResultStream ? c->lastResultStream : (c->overlap() ? (c->asyncSearch ? c->side3 : c->side2) : c->stream));
+	return MCS_OK;
+}
+
+// Page-locked host memory through the C ABI, so that a host translation unit that only sees include/mcs_c.h (integration/cMultiFrame_mcs.cpp inside the
+// reference's build: no HIP headers there) can stage its images and receive its results without the runtime's pageable-memory detour.
+extern "C" int mcs_host_alloc(mcs_ctx* c, size_t bytes, void** out) {
+	if (!c || !out || bytes == 0) return fail(MCS_ERR_INVALID, "bad argument");
+	HIPCHK(hipSetDevice(c->device));
+	*out = nullptr;
+	HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+	return MCS_OK;
+}
+extern "C" int mcs_host_free(mcs_ctx* c, void* p) {
+	if (!c) return fail(MCS_ERR_INVALID, "bad argument");
+	if (!p) return MCS_OK;
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipHostFree(p));
 	return MCS_OK;
 }

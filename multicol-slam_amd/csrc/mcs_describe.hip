@@ -35,13 +35,73 @@
 #include "mcs_orient.h"
 
 #include <algorithm>
+#include <vector>
 
 namespace mcs {
 
 __constant__ __attribute__((aligned(16))) signed char c_pattern[2048];
 
-void upload_describe_tables(const signed char* pattern) {
-	if (pattern) (void)hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), pattern, 2048);
+// ---- the pattern's DISTINCT points (fast pass, round 5) ---------------------------------------------------------------------------------------------
+// The learned pattern repeats itself: the first 2*8*descSize points of learned_pattern_64_ORB hold 224 / 384 / 567 distinct (x, y) for descSize 16 / 32 / 64
+// (multiplicities up to 3 / 4 / 7).  The omni model is a function of the point, so the fast pass evaluates every DISTINCT point once — UPat<NB>::R rounds of
+// 64 lanes: 4 / 6 / 9 instead of 4 / 8 / 16 —, forms the pattern mean as the multiplicity-weighted sum, samples the patch once per distinct point and
+// leaves the sampled byte in a per-wave LDS array; a lane then gathers the bytes of its own pairs' points by index.  Layout (host: build_unique_pattern):
+//   upat[t * 64 + l]   point of round t, lane l (doubles).  Order: multiplicity >= 2 first, then the padding slots (copies of point 0 with weight 0 — a real
+//                      point's coordinates, so that range and guard checks see nothing new), then multiplicity 1; the first RW rounds carry explicit weights
+//   uw[t * 64 + l]     multiplicity of that point as a double, rounds 0..RW-1 (beyond them every weight is 1: a plain add)
+//   gidx[l * 2NB + i]  index into upat (= into the wave's vals[]) of point (i & 1) of pair (i >> 1) * 64 + l, the pairs lane l ballots on
+// (Measured and dropped: every lane publishing its R bytes as ONE packed store into a per-lane slot — the packing cost registers, the kernel began to spill, and a
+// spill is a vector memory access that waits for the patch prefetch in flight: 470 -> 521 us.)
+template <int NB> struct UPat;
+template <> struct UPat<2> { static constexpr int R = 4, RW = 1; };
+template <> struct UPat<4> { static constexpr int R = 6, RW = 2; };
+template <> struct UPat<8> { static constexpr int R = 9, RW = 5; };
+constexpr int kUPatMax = 9 * 64, kUWMax = 5 * 64;
+__device__ double2 g_upat[3][kUPatMax];
+__device__ double g_uw[3][kUWMax];
+__device__ unsigned short g_gidx[3][64 * 16];
+
+template <int NB>
+static bool build_unique_pattern(const signed char* pattern, int slot) {
+	constexpr int R = UPat<NB>::R, RW = UPat<NB>::RW, NP = 128 * NB;
+	std::vector<int> first, mult, ofPoint(NP);
+	for (int i = 0; i < NP; ++i) {
+		int f = -1;
+		for (size_t k = 0; k < first.size(); ++k)
+			if (pattern[2 * first[k]] == pattern[2 * i] && pattern[2 * first[k] + 1] == pattern[2 * i + 1]) { f = (int)k; break; }
+		if (f < 0) { f = (int)first.size(); first.push_back(i); mult.push_back(0); }
+		mult[f]++; ofPoint[i] = f;
+	}
+	const int nu = (int)first.size(), pad = R * 64 - nu;
+	int heavy = 0;
+	for (int m : mult) heavy += m >= 2;
+	if (pad < 0 || heavy + pad > RW * 64) return false;   // the round counts above belong to the shipped pattern
+	std::vector<int> order;   // distinct point per slot, -1 = padding
+	for (int k = 0; k < nu; ++k) if (mult[k] >= 2) order.push_back(k);
+	for (int k = 0; k < pad; ++k) order.push_back(-1);
+	for (int k = 0; k < nu; ++k) if (mult[k] < 2) order.push_back(k);
+	std::vector<int> slotOf(nu);
+	std::vector<double2> up(kUPatMax, double2{0.0, 0.0});
+	std::vector<double> uw(kUWMax, 0.0);
+	for (int sidx = 0; sidx < R * 64; ++sidx) {
+		const int k = order[sidx], src = first[k < 0 ? 0 : k];
+		up[sidx] = double2{(double)pattern[2 * src], (double)pattern[2 * src + 1]};
+		if (k >= 0) slotOf[k] = sidx;
+		if (sidx < RW * 64) uw[sidx] = k < 0 ? 0.0 : (double)mult[k];
+		else if (k < 0 || mult[k] != 1) return false;
+	}
+	std::vector<unsigned short> gi(64 * 16, 0);
+	for (int l = 0; l < 64; ++l)
+		for (int i = 0; i < 2 * NB; ++i) gi[l * 2 * NB + i] = (unsigned short)slotOf[ofPoint[2 * ((i >> 1) * 64 + l) + (i & 1)]];
+	return hipMemcpyToSymbol(HIP_SYMBOL(g_upat), up.data(), sizeof(double2) * kUPatMax, sizeof(double2) * kUPatMax * slot) == hipSuccess &&
+	       hipMemcpyToSymbol(HIP_SYMBOL(g_uw), uw.data(), sizeof(double) * kUWMax, sizeof(double) * kUWMax * slot) == hipSuccess &&
+	       hipMemcpyToSymbol(HIP_SYMBOL(g_gidx), gi.data(), sizeof(unsigned short) * 64 * 16, sizeof(unsigned short) * 64 * 16 * slot) == hipSuccess;
+}
+
+bool upload_describe_tables(const signed char* pattern) {
+	if (!pattern) return false;
+	if (hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), pattern, 2048) != hipSuccess) return false;
+	return build_unique_pattern<2>(pattern, 0) && build_unique_pattern<4>(pattern, 1) && build_unique_pattern<8>(pattern, 2);
 }
 
 // Division by a shared denominator: the compiler's own f64 division expansion (rcp, two Newton steps, q0 = n*r,
@@ -295,14 +355,22 @@ __device__ __forceinline__ bool kp_prologue(const ExtractBuffers& b, int wavesPe
 // (mcs_extractor_tie_stats), which bench.py prints and the -m gpu suite asserts to stay above 1e-10 px.  (Fast-pass coordinates need no entry: the guard band
 // keeps them at least guard_eps from a tie by construction.)  Reference: src/mdBRIEFextractorOct.cpp:280-281, 295-296.
 __device__ __forceinline__ double tie_frac(double v) { return fabs(v - rint(v)); }
-__device__ __forceinline__ void tie_commit(unsigned long long* tieMin, double maxFrac) {
+// Round 5: watching is not enforcing.  A keypoint whose closest approach is inside b.tieBand is LISTED (tieList), and the host recomputes its descriptor with the
+// libm the reference links before the results count as final (mcs_tiefix.hip: automatically for host outputs, mcs_extractor_fix_ties for device outputs).
+__device__ __forceinline__ void tie_commit(const ExtractBuffers& b, int gw, double maxFrac) {
+	unsigned long long* const tieMin = b.tieMin;
 	if (!tieMin) return;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) maxFrac = fmax(maxFrac, __shfl_xor(maxFrac, o));
 	const double dist = 0.5 - maxFrac;   // >= 0: |v - rint(v)| <= 1/2; exact (both within a binade of 1/2 or smaller)
 	const unsigned long long bits = (unsigned long long)__double_as_longlong(dist);   // non-negative doubles order like their bit patterns
+	if ((threadIdx.x & 63) != 0) return;
 	// the stored minimum only ever falls: a (possibly stale) plain read that is already smaller spares the atomic — after the first few keypoints almost every wave
-	if ((threadIdx.x & 63) == 0 && bits < *reinterpret_cast<volatile unsigned long long*>(tieMin)) atomicMin(tieMin, bits);
+	if (bits < *reinterpret_cast<volatile unsigned long long*>(tieMin)) atomicMin(tieMin, bits);
+	if (dist < b.tieBand && b.tieList) {   // NaN coordinates (dist = NaN) are not ties: they round the same way everywhere
+		b.tieList[atomicAdd(b.tieCount, 1)] = (uint32_t)gw;
+		if (b.tieTotal) atomicAdd(b.tieTotal, 1ull);
+	}
 }
 
 template <int MODE, int NB>   // MODE 0 ORB, 1 dBRIEF, 2 mdBRIEF; NB = descSize/8 ballots.  lds: MODE > 0: [waves][x|y][npoints] coordinates + patch
@@ -341,7 +409,7 @@ __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int waves
 				*reinterpret_cast<unsigned long long*>(mout + 8 * j) = 0ull;   // descriptorMasks = zeros (:1216)
 			}
 		}
-		tie_commit(b.tieMin, tie);
+		tie_commit(b, gw, tie);
 		return;
 	}
 
@@ -490,7 +558,7 @@ __device__ __forceinline__ void describe_wave(const ExtractBuffers& b, int waves
 			*reinterpret_cast<unsigned long long*>(mout + 8 * j) = MODE == 2 ? agree[j] : 0ull;
 		}
 	}
-	tie_commit(b.tieMin, tie);
+	tie_commit(b, gw, tie);
 }
 
 // Two entry points over the same body: the 128-register cap (4 waves per SIMD) pays off wherever the LDS slice of a wave lets 16 waves share a CU;
@@ -699,6 +767,19 @@ struct LazySampler {
 	const uint8_t* patch;
 	// `reach` collects offset + 4096 of every sample that takes the general path: the caller sends the keypoint to the exact pass unless all stay below 8192.
 	// (A sample inside the patch is within +-21: nothing to collect on the fast path — and an offset outside [-4096, 4096), NaN included, can never pass for inside.)
+	// one sample at offset (dy, dx) from the keypoint through the general path (blurred level / bordered raw level; the patch too, for a lane whose own point is inside)
+	__device__ __forceinline__ int sample(int dy, int dx, int row, int col) const {
+		const PyrDesc& d = *b->desc;
+		const LevelInfo& L = d.lv[level];
+		Sampler sm;
+		int rstride;
+		sm.raw = level_ptr(*b, d, img, level, &rstride);
+		sm.rstride = rstride;
+		sm.blur = b->blur + (size_t)img * d.pyrBytes + L.off; sm.bstride = L.stride;
+		sm.w = L.w; sm.h = L.h;
+		sm.patch = patch; sm.prow = row - kPatchR; sm.pcol = col - kPatchR;
+		return sm.at<kFPitch>(row + dy, col + dx);
+	}
 	__device__ __forceinline__ void pair(int row, int col, int dy0, int dx0, int dy1, int dx1, int& t0, int& t1, unsigned& reach) const {
 		const unsigned r0 = (unsigned)(dy0 + kPatchR), c0 = (unsigned)(dx0 + kPatchR), r1 = (unsigned)(dy1 + kPatchR), c1 = (unsigned)(dx1 + kPatchR);
 		const bool inside = max(max(r0, c0), max(r1, c1)) < (unsigned)kPatchRows;
@@ -816,6 +897,265 @@ __device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const Fas
 	return true;
 }
 
+#ifndef MCS_FAST_UNIQ
+#define MCS_FAST_UNIQ 1   // 1: the pattern's distinct points (round 5, UPat above); 0: every point of the pattern (round 4's fast_keypoint), kept for A/B
+#endif
+// The LDS tables of the distinct-point form as one workgroup sees them, and this wave's byte array
+struct UTabs {
+	const double2* upat; const double* uw; const uint32_t* gidx;   // already offset by the lane (upat + lane, uw + lane, gidx + lane * NB)
+	uint8_t* vals;                                                 // this wave's R * 64 sampled bytes
+};
+__host__ __device__ constexpr size_t upat_bytes(int nb) { return (size_t)(nb == 2 ? 4 : nb == 4 ? 6 : 9) * 64 * sizeof(double2); }
+__host__ __device__ constexpr size_t uw_bytes(int nb) { return (size_t)(nb == 2 ? 1 : nb == 4 ? 2 : 5) * 64 * sizeof(double); }
+__host__ __device__ constexpr size_t gidx_bytes(int nb) { return (size_t)64 * 2 * nb * sizeof(unsigned short); }
+__host__ __device__ constexpr size_t uvals_bytes(int nb) { return (size_t)(nb == 2 ? 4 : nb == 4 ? 6 : 9) * 64; }
+
+// One keypoint of the fast pass by one wave, distinct-point form.  Per pattern: R rounds of the omni model (lane l, round t: distinct point t * 64 + l), the
+// weighted wave sum for the mean, rounding + guard per DISTINCT point in the fixed-point form of fast_keypoint, ONE patch byte per distinct point written to
+// vals[], then every lane gathers the 2 NB bytes of its own pairs.  LDS operations of one wave execute in order, so the gather sees the bytes written just
+// before it by the other lanes (and the next pattern's bytes land behind this pattern's gather); nothing here needs a barrier.
+// The whole keypoint is ONE basic block: the measured bound of this kernel is not instruction issue but the dependent chains of a pattern (the wave sum's 22
+// cross-lane steps, then rounding -> patch byte -> vals -> gather -> ballot: four LDS round trips) with only four waves per SIMD to cover them — round 4's form
+// (and the first distinct-point build: 520 us either way) left the kernel after every pattern (`bad`) and branched on "a sample outside the patch", so nothing of
+// pattern p + 1 could be issued under pattern p's chains.  Now every verdict is collected and taken ONCE at the end; a keypoint with a sample outside the staged
+// 43 x 43 patch (the reads are clamped into it, the bits discarded) goes to the exact pass like one in the guard band — the sampler's general path is gone from
+// this kernel.
+template <int MODE, int NB, class Ahead>
+__device__ __forceinline__ bool fast_keypoint_u(const ExtractBuffers& b, const FastCam& C, const double* tabLds, const uint8_t* patch,
+                                                double ukx, double uky, const double (&axc)[3], const double (&ays)[3], const UTabs& T,
+                                                unsigned long long (&bitsMain)[NB], unsigned long long (&agree)[NB], Ahead&& ahead) {
+	constexpr int NP = 128 * NB, R = UPat<NB>::R, RW = UPat<NB>::RW;
+	const double kFix = 1572864.5;                                       // 1.5 * 2^20 + 0.5 (fast_keypoint)
+	const unsigned kHiPatch = 0x4137F000u + 4096u - (unsigned)kPatchR;   // high word of y minus this = offset + kPatchR: the patch row / column
+	const unsigned guardUnits = (unsigned)__builtin_ceil(b.guardEps * 4294967296.0);
+	const double gAdd = (double)guardUnits * (1.0 / 4294967296.0);       // the guard's half-width folded into the addend (fast_keypoint)
+#pragma unroll
+	for (int j = 0; j < NB; ++j) { bitsMain[j] = 0ull; agree[j] = ~0ull; }
+	constexpr int npat = MODE == 2 ? 3 : 1;
+	typedef double f64x2 __attribute__((ext_vector_type(2)));
+	typedef const __attribute__((address_space(3))) f64x2 lds_f64x2;
+	typedef const __attribute__((address_space(3))) double lds_f64;
+	typedef const __attribute__((address_space(3))) uint32_t lds_u32;
+	typedef __attribute__((address_space(3))) uint8_t lds_u8;
+	typedef const __attribute__((address_space(3))) uint8_t lds_cu8;
+	// opaque (as LDS byte offsets: see fast_keypoint): the tables are read again for every keypoint, nothing derived from them is held across the walk
+	unsigned pdo = (unsigned)(uintptr_t)(lds_f64x2*)T.upat, pwo = (unsigned)(uintptr_t)(lds_f64*)T.uw, pgo = (unsigned)(uintptr_t)(lds_u32*)T.gidx;
+	unsigned pvo = (unsigned)(uintptr_t)(lds_u8*)T.vals, plo = (unsigned)(uintptr_t)(lds_cu8*)patch;
+	int lane = threadIdx.x & 63;
+	asm volatile("" : "+v"(pdo), "+v"(pwo), "+v"(pgo), "+s"(pvo), "+s"(plo), "+v"(lane));
+	lds_f64x2* const pd = (lds_f64x2*)(uintptr_t)pdo;
+	lds_f64* const pw = (lds_f64*)(uintptr_t)pwo;
+	lds_u32* const pg = (lds_u32*)(uintptr_t)pgo;
+	lds_u8* const pv = (lds_u8*)(uintptr_t)pvo;
+	lds_cu8* const pvr = (lds_cu8*)(uintptr_t)pvo;
+	lds_cu8* const pl = (lds_cu8*)(uintptr_t)plo;
+	unsigned top = 0, minlo = 0xFFFFFFFFu, maxrc = 0;   // largest table row, smallest guard word, largest patch row / column over ALL patterns of the keypoint
+	bool bad = false;
+#pragma unroll
+	for (int pat = 0; pat < npat; ++pat) {
+		const double ax = axc[pat], ay = ays[pat];
+		double u[R], v[R];
+		double sumx = 0.0, sumy = 0.0;
+#pragma unroll
+		for (int t = 0; t < R; ++t) {
+			const f64x2 p = pd[64 * t];
+			if (pat == 0 && t == 0) ahead();
+			const double xr = __builtin_fma(p.x, ax, __builtin_fma(-p.y, ay, ukx));
+			const double yr = __builtin_fma(p.x, ay, __builtin_fma(p.y, ax, uky));
+			if (MCS_FAST_ABLATE & 2) { u[t] = xr; v[t] = yr; } else fast_w2i<false>(C, tabLds, xr, yr, u[t], v[t], top);
+			if (t < RW) { const double w = pw[64 * t]; sumx = __builtin_fma(w, u[t], sumx); sumy = __builtin_fma(w, v[t], sumy); }
+			else { sumx += u[t]; sumy += v[t]; }
+			constexpr int kFence = R > 6 ? 2 : MCS_FAST_FENCE;   // at most kFence point evaluations in flight (registers; nine rounds hold 36 for u, v alone)
+			if ((t & (kFence - 1)) == kFence - 1) __builtin_amdgcn_sched_barrier(0);
+		}
+		double totx, toty;
+		wave_sum2_f64(sumx, sumy, totx, toty);
+		const double meanX = totx * (1.0 / (double)NP), meanY = toty * (1.0 / (double)NP);
+		bad |= !(fabs(meanX) < 16384.0) || !(fabs(meanY) < 16384.0);
+		const double cmx = (kFix - meanX) + gAdd, cmy = (kFix - meanY) + gAdd;
+		if (R > 6) __builtin_amdgcn_sched_barrier(0);
+		int val[R];
+#pragma unroll
+		for (int t = 0; t < R; ++t) {
+			const double yx = u[t] + cmx, yy = v[t] + cmy;
+			const unsigned pc = (unsigned)__double2hiint(yx) - kHiPatch, pr = (unsigned)__double2hiint(yy) - kHiPatch;   // unsigned: left of / above the patch, NaN: huge
+			if (!(MCS_FAST_ABLATE & 4)) minlo = min(minlo, min((unsigned)__double2loint(yx), (unsigned)__double2loint(yy)));
+			maxrc = max(maxrc, max(pr, pc));
+			const unsigned off = min(pr * (unsigned)kFPitch + pc, (unsigned)(kFPatchBytes - 1));   // (a sample outside the patch: any byte of it, the keypoint leaves below)
+			val[t] = (MCS_FAST_ABLATE & 1) ? (int)off : (int)pl[off];
+		}
+#pragma unroll
+		for (int t = 0; t < R; ++t) pv[64 * t + lane] = (uint8_t)val[t];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler ordering only: the bytes above are written before the reads below are issued)
+#pragma unroll
+		for (int j = 0; j < NB; ++j) {   // the lane's own pairs: the two bytes of each by the points' indices
+			const uint32_t g = pg[j];
+			const int t0 = pvr[g & 0xFFFFu], t1 = pvr[g >> 16];
+			const unsigned long long bits = __ballot(t0 < t1);
+			if (pat == 0) bitsMain[j] = bits;
+			else agree[j] &= ~(bits ^ bitsMain[j]);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		// 64-byte descriptors (nine rounds): the one-block form spills (36 registers for u, v alone), and a spill is a vector memory access that waits for the
+		// patch prefetch in flight — so there the kernel is left after every pattern as in round 4, which splits the block and bounds what is live
+		if (R > 6) { if (__any(bad | (top >= (unsigned)kGRows) | (minlo < 2u * guardUnits) | (maxrc >= (unsigned)kPatchRows))) return false; }
+	}
+	bad |= top >= (unsigned)kGRows;                              // a point below / above the table, NaN, Inf
+	if (!(MCS_FAST_ABLATE & 4)) bad |= minlo < 2u * guardUnits;  // a coordinate in the guard band of a rounding tie
+	bad |= maxrc >= (unsigned)kPatchRows;                        // a sample outside the staged patch
+	return !__any(bad);
+}
+
+#ifndef MCS_FAST_PIPE
+#define MCS_FAST_PIPE 0   // 1: mdBRIEF keypoints with R <= 6 rounds run the hand-pipelined form below (measured: 492 against 470 us); 0: fast_keypoint_u for everything
+#endif
+// The same keypoint, software-pipelined by hand (mdBRIEF, R <= 6: descriptor sizes 16 and 32).  What bounds the fast pass is neither VALU issue (~0.65 busy) nor
+// the LDS pipe (~0.6): it is the dependent chains of one wave — table-row gather -> Horner, and per pattern wave sum -> rounding -> patch byte -> vals -> gather
+// -> ballot — which the three other waves of the SIMD, all in the same phase, do not cover; the compiler's schedule runs them strictly one after the other.
+// Here the work is cut into chunks that are laid out in the wanted order and separated by scheduling barriers:
+//     chunk (pat, t):   A(pat, t + 1)   rotation, s, row index, tau and the REQUEST of the table row of the next point (row registers double-buffered)
+//                       B(pat, t)       Horner + affine + sums of this point, whose row was requested a chunk ago
+//                       stage k of the TAIL of pattern pat - 1  (k = 0..5: wave sum 1 / wave sum 2 + mean / rounding + patch bytes (two halves) / vals + gather / ballots)
+// so every chain of pattern pat - 1 is issued under the arithmetic of pattern pat (u, v double-buffered); only the last pattern's tail runs bare.
+template <int MODE, int NB, class Ahead>
+__device__ __forceinline__ bool fast_keypoint_p(const ExtractBuffers& b, const FastCam& C, const double* tabLds, const uint8_t* patch,
+                                                double ukx, double uky, const double (&axc)[3], const double (&ays)[3], const UTabs& T,
+                                                unsigned long long (&bitsMain)[NB], unsigned long long (&agree)[NB], Ahead&& ahead) {
+	constexpr int NP = 128 * NB, R = UPat<NB>::R, RW = UPat<NB>::RW, npat = 3;
+	static_assert(MODE == 2 && R <= 6, "the pipelined form is for mdBRIEF with at most six rounds");
+	const double kFix = 1572864.5;
+	const unsigned kHiPatch = 0x4137F000u + 4096u - (unsigned)kPatchR;
+	const unsigned guardUnits = (unsigned)__builtin_ceil(b.guardEps * 4294967296.0);
+	const double gAdd = (double)guardUnits * (1.0 / 4294967296.0);
+#pragma unroll
+	for (int j = 0; j < NB; ++j) { bitsMain[j] = 0ull; agree[j] = ~0ull; }
+	typedef double f64x2 __attribute__((ext_vector_type(2)));
+	typedef const __attribute__((address_space(3))) f64x2 lds_f64x2;
+	typedef const __attribute__((address_space(3))) double lds_f64;
+	typedef const __attribute__((address_space(3))) uint32_t lds_u32;
+	typedef __attribute__((address_space(3))) uint8_t lds_u8;
+	typedef const __attribute__((address_space(3))) uint8_t lds_cu8;
+	unsigned pdo = (unsigned)(uintptr_t)(lds_f64x2*)T.upat, pwo = (unsigned)(uintptr_t)(lds_f64*)T.uw, pgo = (unsigned)(uintptr_t)(lds_u32*)T.gidx;
+	unsigned pvo = (unsigned)(uintptr_t)(lds_u8*)T.vals, plo = (unsigned)(uintptr_t)(lds_cu8*)patch, tbo = (unsigned)(uintptr_t)(lds_f64*)tabLds;
+	int lane = threadIdx.x & 63;
+	asm volatile("" : "+v"(pdo), "+v"(pwo), "+v"(pgo), "+s"(pvo), "+s"(plo), "+s"(tbo), "+v"(lane));
+	lds_f64x2* const pd = (lds_f64x2*)(uintptr_t)pdo;
+	lds_f64* const pw = (lds_f64*)(uintptr_t)pwo;
+	lds_u32* const pg = (lds_u32*)(uintptr_t)pgo;
+	lds_u8* const pv = (lds_u8*)(uintptr_t)pvo;
+	lds_cu8* const pvr = (lds_cu8*)(uintptr_t)pvo;
+	lds_cu8* const pl = (lds_cu8*)(uintptr_t)plo;
+	lds_f64* const tab = (lds_f64*)(uintptr_t)tbo;
+	unsigned top = 0, minlo = 0xFFFFFFFFu, maxrc = 0;
+	bool bad = false;
+	// double-buffered state: the point being evaluated (slot t & 1), the pattern's coordinates (pat & 1)
+	double xr_[2], yr_[2], tau_[2], gc_[2][kGRow], w_[2];
+	double u_[2][R], v_[2][R], sumx = 0.0, sumy = 0.0;
+	// the tail's state
+	double z_ = 0.0, cmx = 0.0, cmy = 0.0;
+	int val[R];
+	int t0_[NB], t1_[NB];
+	auto A = [&](int pat, int t) {   // the request half of fast_w2i
+		const int sl = t & 1;
+		const f64x2 p = pd[64 * t];
+		if (pat == 0 && t == 0) ahead();
+		const double ax = axc[pat], ay = ays[pat];
+		const double xr = __builtin_fma(p.x, ax, __builtin_fma(-p.y, ay, ukx));
+		const double yr = __builtin_fma(p.x, ay, __builtin_fma(p.y, ax, uky));
+		const double s = __builtin_fma(xr, xr, yr * yr);
+		const unsigned hi = (unsigned)__double2hiint(s), lo = (unsigned)__double2loint(s);
+		const unsigned idx = (hi >> (20 - kGM)) - (unsigned)((1023 + kGE0) << kGM);
+		top = max(top, idx);
+		const unsigned row = idx < (unsigned)kGRows ? idx : (unsigned)(kGRows - 1);
+		const double frac = __hiloint2double((int)((hi & ((1u << (20 - kGM)) - 1u)) | 0x3FF00000u), (int)lo);
+		xr_[sl] = xr; yr_[sl] = yr; tau_[sl] = frac - (1.0 + 1.0 / (double)(2 << kGM));
+		lds_f64* const g = tab + row * kGRow;
+#pragma unroll
+		for (int i = 0; i < kGRow; ++i) gc_[sl][i] = g[i];
+		if (t < RW) w_[sl] = pw[64 * t];
+	};
+	auto B = [&](int pat, int t) {   // the arithmetic half
+		const int sl = t & 1, pb = pat & 1;
+		double G = gc_[sl][kGDeg];
+#pragma unroll
+		for (int i = kGDeg - 1; i >= 0; --i) G = __builtin_fma(G, tau_[sl], gc_[sl][i]);
+		const double uu = xr_[sl] * G, vv = yr_[sl] * G;
+		const double u = __builtin_fma(uu, C.c, vv * C.d), v = __builtin_fma(uu, C.e, vv);
+		u_[pb][t] = u; v_[pb][t] = v;
+		if (t < RW) { sumx = __builtin_fma(w_[sl], u, sumx); sumy = __builtin_fma(w_[sl], v, sumy); }
+		else { sumx += u; sumy += v; }
+	};
+	auto round_pt = [&](int q, int t) {
+		const double yx = u_[q & 1][t] + cmx, yy = v_[q & 1][t] + cmy;
+		const unsigned pc = (unsigned)__double2hiint(yx) - kHiPatch, pr = (unsigned)__double2hiint(yy) - kHiPatch;
+		minlo = min(minlo, min((unsigned)__double2loint(yx), (unsigned)__double2loint(yy)));
+		maxrc = max(maxrc, max(pr, pc));
+		const unsigned off = min(pr * (unsigned)kFPitch + pc, (unsigned)(kFPatchBytes - 1));
+		val[t] = (int)pl[off];
+	};
+	double sx_ = 0.0, sy_ = 0.0;   // the finished pattern's lane sums, handed to its tail
+	auto tail = [&](int q, int k) {   // stage k of pattern q's tail
+		if (k == 0) {   // wave sum, first half (wave_sum2_f64): halves, then row pairs
+			const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(sx_), __double2loint(sy_), false, false);
+			const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(sx_), __double2hiint(sy_), false, false);
+			double z = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+			const auto l2 = __builtin_amdgcn_permlane16_swap(__double2loint(z), __double2loint(z), false, false);
+			const auto h2 = __builtin_amdgcn_permlane16_swap(__double2hiint(z), __double2hiint(z), false, false);
+			z_ = __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+		} else if (k == 1) {   // second half: the 16 lanes of a row, the totals as scalars, the mean folded into the rounding addends
+			double z = z_;
+			z += dpp_f64<0x128>(z); z += dpp_f64<0x124>(z); z += dpp_f64<0x122>(z); z += dpp_f64<0x121>(z);
+			const double totx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(z), 0), __builtin_amdgcn_readlane(__double2loint(z), 0));
+			const double toty = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(z), 32), __builtin_amdgcn_readlane(__double2loint(z), 32));
+			const double meanX = totx * (1.0 / (double)NP), meanY = toty * (1.0 / (double)NP);
+			bad |= !(fabs(meanX) < 16384.0) || !(fabs(meanY) < 16384.0);
+			cmx = (kFix - meanX) + gAdd; cmy = (kFix - meanY) + gAdd;
+		} else if (k == 2) {
+#pragma unroll
+			for (int t = 0; t < (R + 1) / 2; ++t) round_pt(q, t);
+		} else if (k == 3) {
+#pragma unroll
+			for (int t = (R + 1) / 2; t < R; ++t) round_pt(q, t);
+		} else if (k == 4) {
+	#pragma unroll
+		for (int t = 0; t < R; ++t) pv[64 * t + lane] = (uint8_t)val[t];
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+			for (int j = 0; j < NB; ++j) { const uint32_t g = pg[j]; t0_[j] = pvr[g & 0xFFFFu]; t1_[j] = pvr[g >> 16]; }
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		} else {
+#pragma unroll
+			for (int j = 0; j < NB; ++j) {
+				const unsigned long long bits = __ballot(t0_[j] < t1_[j]);
+				if (q == 0) bitsMain[j] = bits;
+				else agree[j] &= ~(bits ^ bitsMain[j]);
+			}
+		}
+	};
+	constexpr int kStages = 6;
+#pragma unroll
+	for (int pat = 0; pat <= npat; ++pat) {
+		if (pat < npat) A(pat, 0);
+#pragma unroll
+		for (int t = 0; t < R; ++t) {
+			if (pat < npat) {
+				if (t + 1 < R) A(pat, t + 1);
+				B(pat, t);
+			}
+			if (pat > 0) {   // stages [t * kStages / R, (t + 1) * kStages / R) of the previous pattern's tail
+#pragma unroll
+				for (int k = t * kStages / R; k < (t + 1) * kStages / R; ++k) tail(pat - 1, k);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		if (pat < npat) { sx_ = sumx; sy_ = sumy; sumx = 0.0; sumy = 0.0; }
+	}
+	bad |= top >= (unsigned)kGRows;
+	bad |= minlo < 2u * guardUnits;
+	bad |= maxrc >= (unsigned)kPatchRows;
+	return !__any(bad);
+}
+
 // Persistent workgroups: a workgroup of kFastWaves waves walks a contiguous range of keypoint GROUPS (kFastWaves consecutive slots of one image, one per
 // wave).  The camera's table is loaded into LDS when the camera changes — once per workgroup for a camera-major batch — and there is no barrier inside the
 // walk.  (One workgroup per 8 keypoints spent half its life in the load -> LDS -> barrier prologue: the kernel without model, sampling and guard took 0.36 of
@@ -837,8 +1177,13 @@ __device__ __forceinline__ bool fast_keypoint(const ExtractBuffers& b, const Fas
 constexpr int kFastPatchBufs = MCS_FAST_DMA ? 2 : 1;
 constexpr int kMailDwords = 32, kMailBytes = MCS_FAST_DMA ? 2 * kMailDwords * 4 : 0;   // per wave
 constexpr int kMailCam = 19, kMailUsed = 26;   // dwords 0..2 lvl, rc, poff; 3..18 the eight doubles of KpAuxSoA::d8; 19 tabIdx; 20..25 cam.c, cam.d, cam.e
-constexpr size_t kFastWaveLds = (size_t)kFastPatchBufs * kFPatchBytes + kMailBytes;
+#if MCS_FAST_UNIQ
+__host__ __device__ constexpr size_t fast_wave_lds(int nb) { return (size_t)kFastPatchBufs * kFPatchBytes + kMailBytes + uvals_bytes(nb); }   // patch buffer(s), mailboxes, the sampled bytes
+__host__ __device__ constexpr size_t fast_pat_bytes(int nb) { return upat_bytes(nb) + uw_bytes(nb) + gidx_bytes(nb); }   // distinct points, weights, gather indices
+#else
+__host__ __device__ constexpr size_t fast_wave_lds(int) { return (size_t)kFastPatchBufs * kFPatchBytes + kMailBytes; }
 __host__ __device__ constexpr size_t fast_pat_bytes(int nb) { return (size_t)2 * nb * 64 * sizeof(double2); }   // the pattern points as doubles, [point][lane]
+#endif
 
 // The requests are written as inline assembly, not __builtin_amdgcn_global_load_lds: knowing an LDS-DMA write is in flight, the compiler puts an
 // s_waitcnt vmcnt(0) in front of the first LDS read it cannot prove disjoint from the destination — here every table, pattern and patch read of the keypoint
@@ -904,15 +1249,26 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 	extern __shared__ __attribute__((aligned(16))) double lds[];   // the camera's G table (shared, at offset 0: its reads then need no address arithmetic), then per wave: patch buffer(s), mailboxes
 	static_assert(MODE == 1 || MODE == 2, "the fast pass is for the distorted patterns");
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	constexpr size_t kFastWaveLds = fast_wave_lds(NB);
 	double2* const patLds = reinterpret_cast<double2*>(reinterpret_cast<uint8_t*>(lds) + kGTabDoubles * sizeof(double));
 	uint8_t* const waveLds = reinterpret_cast<uint8_t*>(patLds) + fast_pat_bytes(NB) + (size_t)wave * kFastWaveLds;
 	uint32_t* const mailBase = reinterpret_cast<uint32_t*>(waveLds + kFastPatchBufs * kFPatchBytes);
+#if MCS_FAST_UNIQ
+	// the pattern's distinct points, their weights and the lanes' gather indices (host-built, upload_describe_tables; visible after the barrier behind the first table load)
+	constexpr int kSlot = NB == 2 ? 0 : NB == 4 ? 1 : 2;
+	double* const uwLds = reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(patLds) + upat_bytes(NB));
+	uint32_t* const gidxLds = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(uwLds) + uw_bytes(NB));
+	for (int i = threadIdx.x; i < UPat<NB>::R * 64; i += 64 * kFastWaves) patLds[i] = g_upat[kSlot][i];
+	for (int i = threadIdx.x; i < UPat<NB>::RW * 64; i += 64 * kFastWaves) uwLds[i] = g_uw[kSlot][i];
+	for (int i = threadIdx.x; i < 64 * NB; i += 64 * kFastWaves) gidxLds[i] = reinterpret_cast<const uint32_t*>(g_gidx[kSlot])[i];
+#else
 	// the pattern points as doubles (visible after the barrier behind the first table load)
 	for (int i = threadIdx.x; i < 2 * NB * 64; i += 64 * kFastWaves) {
 		const int t = i >> 6, ln = i & 63;
 		const signed char* pp = c_pattern + ((t >> 1) * 64 + ln) * 4 + 2 * (t & 1);
 		patLds[i] = double2{(double)pp[0], (double)pp[1]};
 	}
+#endif
 	double* const tabLds = lds;
 	const PyrDesc& d = *b.desc;
 	KpAuxSoA A; A.carve(b.aux, nslots);
@@ -1019,8 +1375,19 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 #endif
 		LazySampler sm;
 		sm.b = &b; sm.img = bimg; sm.level = level; sm.patch = patchLds;
+		(void)sm; (void)row; (void)col;
 		unsigned long long bitsMain[NB], agree[NB];
+#if MCS_FAST_UNIQ
+		UTabs T;
+		T.upat = patLds + lane; T.uw = uwLds + lane; T.gidx = gidxLds + lane * NB; T.vals = waveLds + kFastPatchBufs * kFPatchBytes + kMailBytes;
 #if MCS_FAST_DMA
+		bool ok;
+		if constexpr (MCS_FAST_PIPE && MODE == 2 && UPat<NB>::R <= 6) ok = fast_keypoint_p<MODE, NB>(b, C, tabLds, patchLds, ukx, uky, axc, ays, T, bitsMain, agree, ahead);
+		else ok = fast_keypoint_u<MODE, NB>(b, C, tabLds, patchLds, ukx, uky, axc, ays, T, bitsMain, agree, ahead);
+#else
+		const bool ok = fast_keypoint_u<MODE, NB>(b, C, tabLds, patchLds, ukx, uky, axc, ays, T, bitsMain, agree, [] {});
+#endif
+#elif MCS_FAST_DMA
 		const bool ok = fast_keypoint<MODE, NB>(b, C, tabLds, sm, row, col, ukx, uky, axc, ays, patLds + lane, bitsMain, agree, ahead);
 #else
 		const bool ok = fast_keypoint<MODE, NB>(b, C, tabLds, sm, row, col, ukx, uky, axc, ays, patLds + lane, bitsMain, agree, [] {});
@@ -1083,7 +1450,7 @@ static void launch_fast_passes(const ExtractBuffers& b, int nimg, int wavesPerIm
 	const int groupsPerBlock = std::max(1, (ngroups + kFastBlocks - 1) / kFastBlocks);
 	int fblocks = (ngroups + groupsPerBlock - 1) / groupsPerBlock;
 	if (fblocks >= kNumXCD) fblocks = (fblocks + kNumXCD - 1) / kNumXCD * kNumXCD;   // whole XCD rounds: the kernel's block -> group mapping is XCD-contiguous
-	const size_t fLds = (size_t)kFastWaves * kFastWaveLds + kGTabDoubles * sizeof(double) + fast_pat_bytes(NB);
+	const size_t fLds = (size_t)kFastWaves * fast_wave_lds(NB) + kGTabDoubles * sizeof(double) + fast_pat_bytes(NB);
 	// PRECONDITION: fbCount and preCount — neighbours — were cleared by k_octree's first workgroup, i.e. every launch_describe follows a launch_octree of the same
 	// batch on the same stream, and the previous batch's side-stream pre-list kernel has been joined (the evDescJoin wait below); extract_impl in mcs_capi.hip is
 	// the only caller and keeps that order

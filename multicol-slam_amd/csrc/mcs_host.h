@@ -48,7 +48,7 @@ struct mcs_ctx {
 	hipStream_t side = nullptr;    // extraction fork: resize chain + blur beside FAST + oct-tree
 	hipStream_t side3 = nullptr;   // deferred searches: the greedy pass, beside the next search's lists on side2
 	hipEvent_t evLists = nullptr, evGreedyBuf[2] = {nullptr, nullptr};   // lists of the latest deferred search complete / the greedy pass that read list buffer i complete
-	hipStream_t upload = nullptr; unsigned uploadMask = 0; std::vector<hipStream_t> probed;   // mcs_ctx_transfer_stream (mcs_copy.hip)
+	hipStream_t upload = nullptr; unsigned uploadMask = 0; std::vector<hipStream_t> probed; std::vector<unsigned> probedMask;   // mcs_ctx_transfer_stream (mcs_copy.hip)
 	hipStream_t side2 = nullptr;   // the greedy match resolution (its own stream: it must not hold up the next batch's resize chain)
 	hipEvent_t evFork = nullptr, evPyr1 = nullptr, evPyr = nullptr, evBlur = nullptr, evMatch = nullptr, evGreedy = nullptr;
 	hipEvent_t evDescFork = nullptr, evDescJoin = nullptr;   // the exact descriptor pass over the pre-list on `side`, beside the fast pass
@@ -57,6 +57,7 @@ struct mcs_ctx {
 	bool asyncSearch = false;
 	hipEvent_t evSearch[4] = {nullptr, nullptr, nullptr, nullptr};
 	long long searchSeq = 0;
+	hipStream_t lastResultStream = nullptr;   // the stream the LATEST device-memory search completed its outputs on (search_common records it); nullptr: none yet
 	bool overlap() const { return side != nullptr && !timing; }   // per-kernel timing runs everything in order on the main stream
 
 	void tic(const char* name) {

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int 
 	const int N = Lv.nfeat;
 	// the two exact-pass list counters of the descriptor stage start every batch at zero: cleared here (the previous batch's list kernels are done — stream order —,
 	// k_orient_b, their first writer, comes after this kernel) instead of by a memset launch of their own on the critical path
-	if (blockIdx.x == 0 && tid == 0 && b.fbCount) { b.fbCount[0] = 0; b.fbCount[1] = 0; }
+	if (blockIdx.x == 0 && tid == 0 && b.fbCount) { b.fbCount[0] = 0; b.fbCount[1] = 0; b.fbCount[2] = 0; }   // fallback list, pre-list, tie list (mcs_describe.hip)
 
 	uint32_t* denseG = b.dense + (size_t)img * d.densePerImage + Lv.denseBase;
 	unsigned short* knodeG = b.knode + (size_t)img * d.densePerImage + Lv.denseBase;

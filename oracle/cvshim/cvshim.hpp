@@ -192,6 +192,7 @@ public:
 	size_t elemSize1() const { return esz(flags_type); }
 	size_t step1() const { return (size_t)step / elemSize1(); }
 	bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+	bool isContinuous() const { return (size_t)step == (size_t)cols * elemSize(); }
 	Size size() const { return Size(cols, rows); }
 	void release() { *this = Mat(); }
 	Mat clone() const { Mat m; if (empty()) return m; m.create(rows, cols, flags_type); for (int i = 0; i < rows; ++i) std::memcpy(m.data + (size_t)i * m.step, data + (size_t)i * step, (size_t)cols * elemSize()); return m; }

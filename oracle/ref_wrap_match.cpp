@@ -102,6 +102,29 @@ extern "C" void rs_frame_get(void* h, int f, orc_keypoint* keys, uint8_t* desc, 
 	for (auto& e : F->mFeatVec) for (unsigned i : e.second) node[i] = (int)e.first;
 	for (int c = 0; c < s->rig.GetNrCams(); ++c) { gridInv[2 * c] = F->mfGridElementWidthInv[c]; gridInv[2 * c + 1] = F->mfGridElementHeightInv[c]; }
 }
+// the remaining fields the trackers read (include/cMultiFrame.h:69-162): per-camera counts, local indices, image bounds, scale tables, flags.
+// ints: [N[c] x nrCams][minX maxX minY maxY x nrCams][cont_idx_to_local_cam_idx x totalN][mnScaleLevels masksLearned descDimension mdBRIEF(1) imgCnt nOutliers nMapPoints sizes-consistent]
+// doubles: [mfScaleFactor][mvScaleFactors][mvLevelSigma2][mvInvLevelSigma2]   (levels = mnScaleLevels)
+extern "C" void rs_frame_extra(void* h, int f, int* ints, double* dbl) {
+	Scene* s = (Scene*)h; cMultiFrame* F = s->frames[f];
+	const int nr = s->rig.GetNrCams();
+	int* o = ints;
+	for (int c = 0; c < nr; ++c) *o++ = F->N[c];
+	for (int c = 0; c < nr; ++c) { *o++ = F->mnMinX[c]; *o++ = F->mnMaxX[c]; *o++ = F->mnMinY[c]; *o++ = F->mnMaxY[c]; }
+	for (size_t i = 0; i < F->totalN; ++i) *o++ = F->cont_idx_to_local_cam_idx.find(i)->second;
+	*o++ = F->mnScaleLevels; *o++ = F->HavingMasks() ? 1 : 0; *o++ = F->DescDims(); *o++ = 1; *o++ = F->GetImgCnt();
+	int nout = 0, nmp = 0;
+	for (size_t i = 0; i < F->mvbOutlier.size(); ++i) nout += F->mvbOutlier[i] ? 1 : 0;
+	for (size_t i = 0; i < F->mvpMapPoints.size(); ++i) nmp += F->mvpMapPoints[i] ? 1 : 0;
+	*o++ = nout; *o++ = nmp;
+	*o++ = (F->mvKeys.size() == F->totalN && F->mvKeysRays.size() == F->totalN && F->mvbOutlier.size() == F->totalN && F->mvpMapPoints.size() == F->totalN &&
+	        F->keypoint_to_cam.size() == F->totalN && F->cont_idx_to_local_cam_idx.size() == F->totalN && (int)F->mDescriptors.size() == nr && (int)F->mGrids.size() == nr) ? 1 : 0;
+	double* d = dbl;
+	*d++ = F->mfScaleFactor;
+	for (int i = 0; i < F->mnScaleLevels; ++i) *d++ = F->mvScaleFactors[i];
+	for (int i = 0; i < F->mnScaleLevels; ++i) *d++ = F->mvLevelSigma2[i];
+	for (int i = 0; i < F->mnScaleLevels; ++i) *d++ = F->mvInvLevelSigma2[i];
+}
 // the 64x48 grid: cell of feature i (or -1) as the reference filled mGrids
 extern "C" void rs_frame_grid(void* h, int f, int* cellOf) {
 	Scene* s = (Scene*)h; cMultiFrame* F = s->frames[f];

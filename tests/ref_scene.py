@@ -27,6 +27,7 @@ class RefScene:
             getattr(L, name).argtypes = [vp, C.c_int]
         L.rs_frame_get.argtypes = [vp, C.c_int] + [vp] * 7
         L.rs_frame_grid.argtypes = [vp, C.c_int, vp]
+        L.rs_frame_extra.argtypes = [vp, C.c_int, vp, vp]
         L.rs_set_mappoints.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int]
         L.rs_set_outliers.argtypes = [vp, C.c_int, vp]
         L.rs_frame_mappoint_ids.argtypes = [vp, C.c_int, vp]
@@ -76,6 +77,13 @@ class RefScene:
         self.L.rs_frame_get(self.h, f, P(keys), P(d), P(m), P(cam), P(rays), P(node), P(ginv))
         self.L.rs_frame_grid(self.h, f, P(cell))
         return dict(n=n, keys=keys, desc=d, mask=m, cam=cam, rays=rays, node=node, grid_inv=ginv, cell=cell)
+
+    def frame_extra(self, f, levels=8):
+        """every other field of the cMultiFrame the trackers read (rs_frame_extra): per-camera counts, image bounds, local indices, flags; the scale tables"""
+        n = self.L.rs_frame_total(self.h, f)
+        ints, dbl = np.zeros(5 * self.nr + n + 8, np.int32), np.zeros(1 + 3 * 16)
+        self.L.rs_frame_extra(self.h, f, P(ints), P(dbl))
+        return ints, dbl[:1 + 3 * levels]
 
     def make_keyframe(self, f):
         return self.L.rs_make_keyframe(self.h, f)

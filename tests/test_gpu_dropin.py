@@ -58,6 +58,57 @@ def test_reference_multiframe_over_the_gpu_extractor(mode, tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------------
+# The frame binding (integration/cMultiFrame_mcs.cpp): cMultiFrame's extraction constructor replaced by ONE batched mcs_extract_batch over the rig's images
+# (page-locked staging, device rays); every other member of the class is the reference's own object code (oracle/Makefile: dropin_frame).
+FRAME_SO = os.path.join(ROOT, "oracle", "_ref", "libmcs_dropin_frame.so")
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_SO) and os.path.exists(FRAME_SO)), reason="oracle/_ref libraries not built (need the reference checkout at build time)")
+@pytest.mark.parametrize("mode", ["mdbrief", "orb"])
+def test_reference_multiframe_constructor_over_one_batched_call(mode, tmp_path, capfd):
+    import ctypes as C
+    import ref_scene
+    import test_io_formats as T
+    import vocab_synth
+    synth = importlib.import_module("multicol-slam_amd.synth")
+    io = importlib.import_module("multicol-slam_amd.io")
+    cams = synth.lafida_cameras()
+    masks = [np.ascontiguousarray(synth.mirror_mask(c)) for c in cams]
+    M_c = [io.cayley2hom(c) for c in T.CAYLEY]
+    voc = str(tmp_path / "voc.yml")
+    vocab_synth.write_vocabulary(voc, k=9, L=5, seed=3)
+    params = dict(nfeatures=1000, do_dBrief=int(mode == "mdbrief"), learnMasks=int(mode == "mdbrief"))
+    nfr = 6
+    imgs = [synth.synth_multiframe(f, cams) for f in range(nfr)]
+    out = {}
+    for name, so in (("ref", REF_SO), ("gpu", FRAME_SO)):
+        S = ref_scene.RefScene(cams, masks, M_c, voc, so_path=so, **params)
+        ids = [S.add_frame(imgs[f], 0.04 * f, np.eye(4)) for f in range(nfr)]
+        out[name] = [(S.frame(i), S.frame_extra(i)) for i in ids]
+        if name == "gpu":
+            last, mean, calls = C.c_double(), C.c_double(), C.c_long()
+            S.L.mcs_dropin_frame_stats(C.byref(last), C.byref(mean), C.byref(calls))
+            assert calls.value >= nfr
+            S.L.mcs_dropin_frame_stats_reset()
+            for f in range(nfr):   # steady state: the device extractor and its staging exist, the mirror masks are resident in the staging block
+                S.add_frame(imgs[f], 1.0 + 0.04 * f, np.eye(4))
+            S.L.mcs_dropin_frame_stats(C.byref(last), C.byref(mean), C.byref(calls))
+            out["ms"] = mean.value
+        S.close()
+    for f in range(nfr):
+        (a, (ai, ad)), (b, (bi, bd)) = out["ref"][f], out["gpu"][f]
+        assert a["n"] == b["n"] and a["n"] > 2500
+        for key in ("keys", "desc", "mask", "cam", "node", "grid_inv", "cell"):
+            assert np.array_equal(a[key], b[key]), (f, key)
+        assert np.array_equal(a["rays"].view(np.uint64), b["rays"].view(np.uint64)), (f, "mvKeysRays bits")
+        assert np.array_equal(ai, bi) and ai[-1] == 1, (f, "counts / bounds / local indices / flags")
+        assert np.array_equal(ad.view(np.uint64), bd.view(np.uint64)), (f, "scale tables")
+    # the constructor's own clock (what the reference prints as "---Feature Extraction (.. ms)"): one batched call for the three cameras
+    print("cMultiFrame constructor over libmcs_hip, %s: %.3f ms per 3-camera multi-frame (steady state)" % (mode, out["ms"]))
+    assert out["ms"] < 3.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
 # Both translation units exchanged: src/mdBRIEFextractorOct.cpp AND src/cORBmatcher.cpp (integration/cORBmatcher_mcs.cpp).  The script below drives
 # every search the replacement implements through the reference's own cMultiFrame / cMultiKeyFrame / cMapPoint objects, once in the all-reference
 # library and once in the drop-in library, and compares the raw results.
