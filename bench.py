@@ -83,6 +83,8 @@ def parse(argv=None):
     ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the timed output (profiling runs)")
     ap.add_argument("--e2e-sweep", default="", help="A/B of the e2e leg's copy mechanism: comma list of H2D:D2H settings, each 'runtime' or a workgroup count "
                                                     "(e.g. runtime:runtime,16:16,16:runtime); runs only the headline job and those e2e legs")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: build the multi-GPU plan (slabs, exchange runs, pair ownership, buffer sizes) of every workload for "
+                                                          "--gpus N (N = 1: for 2, 4 and 8) and check it; non-zero exit on the first violated property")
     ap.add_argument("--exchange", default="auto", choices=["auto", "nccl1"],
                     help="nccl1: run the N > 1 code path (separate send buffers, asynchronous all_gather_into_tensor on RCCL, work.wait(), three buffer sets, "
                          "matching one step late) at world size 1 over the nccl backend")
@@ -118,6 +120,53 @@ def launch_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """The plan of every workload at the world sizes the driver's SCALE run uses, checked without a GPU (multicol-slam_amd/rig.py plan_check): what the first
+    multi-GPU execution relies on is index arithmetic, and a wrong plan must fail HERE, loudly, not as a silent wrong buffer on eight GPUs."""
+    rig = importlib.import_module("multicol-slam_amd.rig")
+    worlds = [args.gpus] if args.gpus > 1 else [2, 4, 8]
+    report, failed = [], False
+    for name, (ncam, W, H, nfeat, F, D, cfg) in WORKLOADS.items():
+        if args.workload != "stream" and name != args.workload:
+            continue
+        F, D = args.frames or F, (D if args.keyframes < 0 else args.keyframes)
+        cap = (args.nfeatures or nfeat) + 3 * 8   # keypoint rows per image of the usual configurations (nfeatures + 3 per level, 8 levels)
+        for world in worlds:
+            row = {"workload": name, "config": cfg, "world": world}
+            try:
+                row.update(rig.plan_check(args.ncam or ncam, F, world, cap, D, 32, args.topk))
+                row["image_bytes_per_rank"] = row["images_per_rank"] * W * H
+                row["ok"] = True
+            except ValueError as ex:
+                row["ok"], row["error"] = False, str(ex)
+                failed = True
+            report.append(row)
+    print(json.dumps({"dry_run": report, "ok": not failed}))
+    return 1 if failed else 0
+
+
+_WATCHDOGS = []
+
+
+def watchdog(seconds, what):
+    """A hang in the first multi-rank RCCL calls (rendezvous, the first collective) must end loudly: after `seconds` the rank prints its distributed / RCCL environment
+    and leaves with exit code 3.  Returns a function that retires the watchdog."""
+    import threading
+
+    def fire():
+        keys = ["RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY", "GPU_MAX_HW_QUEUES", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES",
+                "NCCL_DEBUG", "NCCL_SOCKET_IFNAME", "NCCL_P2P_DISABLE", "NCCL_SHM_DISABLE", "NCCL_IB_DISABLE", "RCCL_MSCCL_ENABLE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "MCS_BENCH_SHARE_GPU"]
+        sys.stderr.write("bench.py: WATCHDOG — %s did not finish within %d s on rank %s; environment:\n%s\n"
+                         % (what, seconds, os.environ.get("RANK", "0"), "\n".join("  %s=%s" % (k, os.environ.get(k, "(unset)")) for k in keys)))
+        sys.stderr.flush()
+        os._exit(3)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    _WATCHDOGS.append(t)
+    return t.cancel
 
 
 def cpu_model():
@@ -162,7 +211,14 @@ def setup(args):
     if e.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         e.backend = "gloo" if e.share else "nccl"
+        done = watchdog(int(os.environ.get("MCS_BENCH_INIT_TIMEOUT", "420")), "the rendezvous + first barrier (init_process_group, %s)" % e.backend)   # ranks of a fresh box import torch for up to two minutes each
         dist.init_process_group(e.backend, rank=e.rank, world_size=e.world)
+        if e.backend == "nccl":
+            torch.cuda.set_device(e.local)
+            dist.barrier(device_ids=[e.local])   # the communicator is created HERE (lazily, by the first collective), not in the first timed step
+        else:
+            dist.barrier()
+        done()
     torch.cuda.set_device(e.local)
     e.dev = torch.device("cuda", e.local)
     e.red_dev = torch.device("cpu") if e.share else e.dev
@@ -339,9 +395,11 @@ class Job:
         self.async_search = os.environ.get("MCS_BENCH_ASYNC_SEARCH", "1") != "0"
         mcs.check(e.lib.mcs_ctx_set_async_search(e.ctx.h, 1 if self.async_search else 0))
         if e.exchange:   # prime the pipeline: the first step() matches the multi-frames exchanged here
+            done = watchdog(int(os.environ.get("MCS_BENCH_EXCHANGE_TIMEOUT", "60")), "the first descriptor exchange (%s)" % ("point-to-point ring" if self.ring else "all-gather"))
             try:
                 self.extract_and_exchange(self.sets[self.nsets - 1])
                 torch.cuda.synchronize(dev)
+                done()
             except (RuntimeError, TypeError, ValueError) as ex:
                 if self.ring is None:
                     raise
@@ -353,6 +411,7 @@ class Job:
                 self.matched_set = self.sets[0]
                 self.extract_and_exchange(self.sets[self.nsets - 1])
                 torch.cuda.synchronize(dev)
+                done()
             self.sets[self.nsets - 1].work = "done"
 
     def _make_set(self):
@@ -540,7 +599,10 @@ def roofline_block(sp, job, kern, feats_local, pairs_local):
            "frac": round(ach / 8000.0, 5), "traffic": traffic, "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kern[dom], 4),
            "per_kernel_ms": {k: round(v, 4) for k, v in kern.items() if k != "keypoints"},
            "per_kernel_alg_GBps": {k: round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) for k in alg if k in kern and kern[k] > 0},
-           "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" if traffic else None,
+           "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the builder's GPU box, committed; fetch = 2 x FETCH_SIZE: "
+                             "every read request of this chip's L2 is 128 bytes and is tallied as 64, profiles/r05/pmc_calibration.txt; Infinity-Cache hits are counted)" if traffic else None,
+           "traffic_measured_in_this_run": False,
+           "traffic_over_algorithmic": round(traffic / alg[dom], 3) if traffic and alg[dom] else None,
            "note": "no kernel of this path is HBM-bound (descriptor kernel: LDS gather of the camera table + FP64 at 16 lanes/clk; matcher: FP4 MFMA dot products + a VALU-bound K-best selection); "
                    "the bounds that apply are VALU issue and, for the matcher, the matrix cores: DESIGN.md §6"}
     flop_pair = 2 * 8 * job.lay.desc_size * (2 if job.masks_on else 1)   # a pair distance = one dot product over K = 8 * bytes (x2 with masks), DESIGN.md §4c
@@ -575,6 +637,11 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True, check=True):
     job.step()
     exact_kp = job.ex.describe_stats()[0] - x0   # keypoints the guarded fast descriptor pass handed to the exact pass in one (untimed) step
     tie = job.ex.tie_stats()                     # the run's closest approach of an exact-arithmetic cvRound argument to a rounding tie (pixels)
+    # ties are ENFORCED at the host boundary (mcs_extract_batch with host buffers recomputes the listed keypoints with the host's libm before it returns); this leg keeps
+    # its outputs on the device and consumes them on-stream, so it COUNTS the keypoints the device listed over all its steps (expected ~3e-4 per step at the default band)
+    # and patches the last step's rows — the ones the oracle check reads — through mcs_extractor_fix_ties
+    tie_fixed = job.ex.fix_ties()
+    tie_listed, _, tie_band = job.ex.tie_counts()
     feats_local = job.local_features()
     pairs_local = job.pairs_per_step_local()
     b = job.last()
@@ -598,6 +665,7 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True, check=True):
            # device libm vs the reference's can only round a coordinate differently within ~1e-13 px of a tie: this run's margin, measured over every cvRound
            # argument of the exact arithmetic (all warm-up and timed steps); null if no exact-arithmetic coordinate occurred
            "min_distance_to_a_rounding_tie_px_rank0": (tie if tie != float("inf") else None),
+           "rounding_tie_band_px": tie_band, "keypoints_listed_within_the_band_all_steps_rank0": int(tie_listed), "recomputed_on_the_host_last_step_rank0": int(tie_fixed),
            "n_ranks": e.world, "collective_backend": e.backend, "tag": sp.tag,
            "ms_per_step_slowest_rank": round(elapsed_max / steps * 1e3, 4), "ms_per_step_fastest_rank": round(elapsed_min / steps * 1e3, 4),
            "exchange_bytes_received_per_rank_per_step": (0 if not e.exchange else job.ring.bytes_received(e.rank) if job.ring else job.lay.send_bytes * (e.world - 1)),
@@ -1091,6 +1159,8 @@ def secondary_args(args, **kw):
 
 def main():
     args = parse()
+    if args.dry_run:
+        sys.exit(dry_run(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     e = setup(args)

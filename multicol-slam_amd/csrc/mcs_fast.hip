@@ -26,6 +26,9 @@ namespace mcs {
 #ifndef MCS_FAST_BS
 #define MCS_FAST_BS 128
 #endif
+#ifndef MCS_FAST_SEG16
+#define MCS_FAST_SEG16 1   // pass 1 of the 16-pixel ring on sixteen pixels per thread (round 5); 0: four pixels per thread (round 4), for A/B
+#endif
 template <int CW> struct FastGeom {
 	static constexpr int kTileX = 4;   // tile column of the cell's first processed pixel: a 4-byte left margin (3 ring pixels + 1), so that groups of 4 pixels are aligned dwords
 	static constexpr int kTilePitch = (CW + kTileX + 3 + 4 + 3) / 4 * 4, kTileRows = CW + 6;   // + 4: the packed compass test reads one dword past the right ring
@@ -290,7 +293,45 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	const int lane = tid & 63, wave = tid >> 6;
 	// pass 1: cheap compass test on every pixel; survivors are compacted into an LDS list (order is irrelevant here) so that
 	// pass 2 — the full 16-pixel arc score, ~10x the work — runs with all lanes busy instead of diverging inside each wave
-	if constexpr (P == 16) {
+	if constexpr (P == 16 && MCS_FAST_SEG16) {
+		// pass 1, 16-pixel ring, round 5: SIXTEEN adjacent pixels per thread (four fast_quick4 groups whose row dwords overlap: 14 LDS dwords instead of 20), so a
+		// 31 x 31 cell is 62 lanes — ONE trip of ONE wave where four-pixel lanes took two trips of both waves —, and the per-trip overhead (index arithmetic, prefix sum
+		// over the lanes' survivor counts, the atomic, the list writes) is paid once per 16 pixels: ~236 instead of ~470 wave-instructions per cell for this pass.
+		// The survivors of a lane go out in a loop over its set bits (as many trips as the fullest lane has survivors: ~6 of 16).
+		const int segs = (cw + 15) >> 4, nseg = segs * ch;   // segs <= 4 (cells up to 60 wide)
+		const unsigned sM = segs == 1 ? 65536u : segs == 2 ? 32768u : segs == 3 ? 21846u : 16384u;   // s / segs = (s * sM) >> 16, exact for s < 4 * 60
+		const v2s tt = {(short)t, (short)t};
+		for (int base = 0; base < nseg; base += kFastBS) {
+			const int sg = base + tid;
+			uint32_t bits = 0;
+			int code = 0;
+			if (sg < nseg) {
+				const int py = (int)(((unsigned)sg * sM) >> 16), sx = sg - py * segs;
+				const uint8_t* rowc = &tile[(py + 3) * kTilePitch + 16 * sx + Geo::kTileX];
+				const int valid = cw - 16 * sx;   // pixels of the segment inside the cell: >= 1
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					if (4 * g < valid) {   // (a group wholly outside the cell is not read: the tile's right margin holds only one dword past the ring)
+						const uint32_t q = fast_quick4<kTilePitch>(rowc + 4 * g, tt);   // verdicts of pixels 0, 1, 2, 3 in bits 0, 1, 16, 17
+						bits |= ((q | (q >> 14)) & 0xFu) << (4 * g);
+					}
+				}
+				if (valid < 16) bits &= (1u << valid) - 1u;
+				code = (py << 6) | (16 * sx);
+			}
+			const int cnt = __popc(bits);
+			const int incl = wave_incl_scan(cnt);
+			const int total = __builtin_amdgcn_readlane(incl, 63);
+			int wbase = 0;
+			if (lane == 0 && total) wbase = atomicAdd(&nSurv, total);
+			int pos = __builtin_amdgcn_readfirstlane(wbase) + incl - cnt;
+			while (bits) {
+				const int j = __builtin_ctz(bits);
+				surv[pos++] = (unsigned short)(code + j);
+				bits &= bits - 1u;
+			}
+		}
+	} else if constexpr (P == 16) {
 		// pass 1, 16-pixel ring: four adjacent pixels per thread (fast_quick4); the wave reserves list space for all of them with one prefix sum over the lanes'
 		// survivor counts (DPP) and one atomic
 		const int gpr = (cw + 3) >> 2, ngrp = gpr * ch;   // groups per row: gpr <= 15, g < 15 * 60: CellInfo.grpM = ceil(2^16 / gpr) is exact

@@ -21,8 +21,10 @@
 #include <rccl/rccl.h>
 
 #include <pthread.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -97,6 +99,7 @@ struct Job {
 };
 
 static pthread_barrier_t g_barrier;
+static std::atomic<int> g_firstExchange{0};   // ranks whose first exchange has completed (the start-up watchdog in main waits for all of them)
 static std::vector<unsigned> g_xconf;   // per rank: which of the context's streams the exchange stream shares a hardware queue with (mcs_ctx_stream_conflicts)
 static std::vector<double> g_ms, g_msAll;   // per rank: its own step time, and the time to the barrier behind the slowest rank
 
@@ -240,6 +243,7 @@ static void rank_main(const Job& J, int rank, ncclComm_t comm) {
 	for (int i = 0; i < J.warmup; ++i) step();
 	MCSOK(mcs_ctx_synchronize(ctx));
 	HIPOK(hipStreamSynchronize(xstream));
+	g_firstExchange.fetch_add(1);               // this rank's first exchanges have completed: the start-up watchdog (main) retires once every rank is here
 	pthread_barrier_wait(&g_barrier);
 	const auto t0 = std::chrono::steady_clock::now();
 	for (int i = 0; i < J.steps; ++i) step();   // each: one extraction, one exchange, one matching pass
@@ -281,7 +285,7 @@ static void rank_main(const Job& J, int rank, ncclComm_t comm) {
 }
 
 int main(int argc, char** argv) {
-	if (argc < 2) { fprintf(stderr, "usage: rig_host <config>\n"); return 1; }
+	if (argc < 2) { fprintf(stderr, "usage: rig_host <config> [--gpus N]\n"); return 1; }
 	// (round 3 asked the runtime for 8 hardware queues here so that the exchange stream would not share one with the extraction; the exchange stream is now CHOSEN by
 	// probing the default four queues — mcs_ctx_transfer_stream — which is faster: 1.59 against 1.98 ms per step at world size 1, the extra queues slow the step itself)
 	auto cfg = read_config(argv[1]);
@@ -291,8 +295,13 @@ int main(int argc, char** argv) {
 	J.F = geti("frames", 2); J.D = geti("keyframes", 0); J.steps = geti("steps", 2); J.warmup = geti("warmup", 1); J.topk = geti("topk", 32);
 	int ndev = 0;
 	HIPOK(hipGetDeviceCount(&ndev));
-	J.world = std::min(geti("gpus", ndev), ndev);
-	if (J.world < 1) { fprintf(stderr, "no HIP device\n"); return 1; }
+	// `gpus N` in the configuration or `--gpus N` on the command line (the command line wins): the job runs on exactly N GPUs or not at all — a run that quietly
+	// used fewer would report a scaling point nobody measured
+	int want = geti("gpus", ndev);
+	for (int i = 2; i + 1 < argc; ++i) if (!strcmp(argv[i], "--gpus")) want = atoi(argv[i + 1]);
+	if (want < 1) { fprintf(stderr, "rig_host: --gpus must be >= 1\n"); return 1; }
+	if (want > ndev) { fprintf(stderr, "rig_host: %d GPUs requested but only %d visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)\n", want, ndev); return 5; }
+	J.world = want;
 	if (J.ncam < 1 || J.F < 1 || J.steps < 0 || J.warmup < 0 || J.D < 0 || J.topk < 1) { fprintf(stderr, "bad configuration: ncam >= 1, frames >= 1, keyframes >= 0, topk >= 1\n"); return 1; }
 	J.images = read_file(cfg["images"]); J.masks = read_file(cfg["masks"]); J.cams = read_file(cfg["cams"]); J.out = cfg["out"];
 	const size_t need = (size_t)J.ncam * J.F * J.world * J.W * J.H;
@@ -303,12 +312,26 @@ int main(int argc, char** argv) {
 	std::vector<ncclComm_t> comms(J.world);
 	std::vector<int> devs(J.world);
 	for (int i = 0; i < J.world; ++i) devs[i] = i;
+	// The first multi-rank RCCL calls of a deployment are where an environment problem shows (IPC mode, visible devices, a peer that cannot be mapped): a hang there
+	// must end loudly.  The watchdog covers communicator creation and every rank's first exchange (g_firstExchange counts them); after that it retires.
+	std::thread dog([&] {
+		for (int i = 0; i < 600 && g_firstExchange.load() < J.world; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+		if (g_firstExchange.load() >= J.world) return;
+		fprintf(stderr, "rig_host: WATCHDOG — %d of %d ranks finished their first exchange within 60 s; environment:\n", g_firstExchange.load(), J.world);
+		for (const char* k : {"HSA_ENABLE_IPC_MODE_LEGACY", "GPU_MAX_HW_QUEUES", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "NCCL_DEBUG", "NCCL_SOCKET_IFNAME", "NCCL_P2P_DISABLE",
+		                      "NCCL_SHM_DISABLE", "NCCL_IB_DISABLE", "RCCL_MSCCL_ENABLE", "HSA_FORCE_FINE_GRAIN_PCIE"})
+			fprintf(stderr, "  %s=%s\n", k, getenv(k) ? getenv(k) : "(unset)");
+		fflush(stderr);
+		_exit(6);
+	});
 	NCCLOK(ncclCommInitAll(comms.data(), J.world, devs.data()));
 	pthread_barrier_init(&g_barrier, nullptr, J.world);
 	g_ms.assign(J.world, 0.0); g_msAll.assign(J.world, 0.0); g_xconf.assign(J.world, 0u);
 	std::vector<std::thread> th;
 	for (int r = 0; r < J.world; ++r) th.emplace_back(rank_main, std::cref(J), r, comms[r]);
 	for (auto& t : th) t.join();
+	g_firstExchange.store(J.world);
+	dog.join();
 	for (auto c : comms) NCCLOK(ncclCommDestroy(c));
 	const double ms = *std::max_element(g_msAll.begin(), g_msAll.end());   // between the two barriers: the slowest rank
 	std::string per = "[";

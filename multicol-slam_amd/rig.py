@@ -111,6 +111,64 @@ class RingExchange:
         return sum(n for owner, _, n in self.recvs(rank) if owner != rank) * self.lay.block_bytes
 
 
+def plan_check(ncam, frames_per_rank, world, cap, keyframes, desc_size=32, topk=32):
+    """Everything a multi-GPU run of a workload relies on, checked WITHOUT a GPU (bench.py --dry-run, tests/test_rig_gloo.py): the slabs partition the images;
+    every transfer of the exchange stays inside the sender's send buffer and the receiver's array, arrives exactly once and pairs up with a send of the same
+    size in the same order; every (frame, keyframe) / (frame, predecessor) pair has exactly one owner.  Returns the plan's sizes (bytes per rank); raises
+    ValueError naming the first violated property."""
+    FT = frames_per_rank * world
+    lay = RigLayout(ncam, FT, world, cap, desc_size)
+
+    def need(cond, what):
+        if not cond:
+            raise ValueError("rig plan (ncam %d, frames/rank %d, world %d, keyframes %d): %s" % (ncam, frames_per_rank, world, keyframes, what))
+    slabs = [lay.slab(r) for r in range(world)]
+    need(all(len(sl) == lay.L for sl in slabs), "unequal slabs")
+    need(sum(slabs, []) == [(c, f) for c in range(ncam) for f in range(FT)], "the slabs are not the contiguous camera-major partition of the images")
+    out = {"world": world, "images_per_rank": lay.L, "send_bytes_per_rank": lay.send_bytes, "block_bytes": lay.block_bytes}
+    if keyframes == 0:
+        ex = RingExchange(lay)
+        view_blocks = ncam * (ex.F + 1)
+        for r in range(world):
+            seen = {}
+            for owner, src, dst, n in ex._runs(r):
+                need(0 <= owner < world and n >= 1, "bad run")
+                need(0 <= src and src + n <= lay.L, "a send run leaves rank %d's send buffer" % owner)
+                need(0 <= dst and dst + n <= view_blocks, "a receive run leaves rank %d's local array" % r)
+                for i in range(n):
+                    need(dst + i not in seen, "block %d of rank %d's array is written twice" % (dst + i, r))
+                    seen[dst + i] = owner * lay.L + src + i
+            need(sorted(seen) == list(range(view_blocks)), "rank %d's array is not covered" % r)
+            need(all(seen[c * (ex.F + 1) + j] == lay.image_index(c, ex.global_frame(r, j)) for c in range(ncam) for j in range(ex.F + 1)), "rank %d receives the wrong image somewhere" % r)
+        for a in range(world):
+            for b in range(world):
+                need([n for d, _, n in ex.sends(a) if d == b] == [n for o, _, n in ex.recvs(b) if o == a], "sends of rank %d and receives of rank %d do not pair up" % (a, b))
+        pairs = sum((lay.frame_pairs(r) for r in range(world)), [])
+        need(sorted(f for f, _ in pairs) == list(range(FT)) and all(p == (f - 1) % FT for f, p in pairs), "a (frame, predecessor) pair is owned twice or by nobody")
+        for r in range(world):   # the pairs a rank owns only read frames its local array holds
+            have = {ex.global_frame(r, j) for j in range(ex.F + 1)}
+            need(all(f in have and pp in have for f, pp in lay.frame_pairs(r)), "rank %d matches a frame it did not receive" % r)
+        out.update(exchange="point-to-point frame ring", recv_bytes_per_rank=[ex.bytes_received(r) for r in range(world)], array_bytes_per_rank=view_blocks * lay.block_bytes,
+                   pairs_per_rank=[len(lay.frame_pairs(r)) for r in range(world)], match_rows_per_rank=ex.F * lay.rows_frame,
+                   topk_list_bytes_per_rank=ex.F * lay.rows_frame * topk * 4)
+    else:
+        shards = [lay.keyframe_shard(keyframes, r) for r in range(world)]
+        need(sorted(sum(shards, [])) == list(range(keyframes)), "a stored keyframe is owned twice or by nobody")
+        owned = {}
+        for r in range(world):
+            for k in shards[r]:
+                for f in range(FT):
+                    need((f, k) not in owned, "pair (frame %d, keyframe %d) is owned twice" % (f, k))
+                    owned[(f, k)] = r
+        need(len(owned) == FT * keyframes, "a (frame, keyframe) pair has no owner")
+        need(world * lay.send_bytes == lay.images_total * lay.block_bytes, "the all-gather's output is not the global array")
+        out.update(exchange="all-gather", recv_bytes_per_rank=[(world - 1) * lay.send_bytes] * world, array_bytes_per_rank=lay.images_total * lay.block_bytes,
+                   pairs_per_rank=[FT * len(sh) for sh in shards], match_rows_per_rank=max(FT * len(sh) for sh in shards) * lay.rows_frame,
+                   topk_list_bytes_per_rank=max(FT * len(sh) for sh in shards) * lay.rows_frame * topk * 4)
+    need(out["array_bytes_per_rank"] < 2 ** 40 and out["topk_list_bytes_per_rank"] < 200 * 2 ** 30, "a buffer exceeds what a 288 GB GPU can hold")
+    return out
+
+
 def ring_exchange_begin(ex, rank, send, recv, group=None, self_via_p2p=False):
     """start the ring exchange of one step: send / recv are flat uint8 torch tensors (the rank's send blocks, its local [camera][F + 1] array).  Local runs
     are copied at once (self_via_p2p: sent through the backend like the others — a one-rank RCCL run then exercises the transport); returns the list of

@@ -37,6 +37,29 @@ def _truth(ncam, FT, seed=5):
     return desc, mask, nkp
 
 
+def _truth_images(ncam, FT, seed=5):
+    """the same arrays, but every image REALLY extracted: tiny synthetic fisheye images (256 x 192, ORB-sized budget) through the oracle's mdBRIEF extractor —
+    pyramid, FAST, oct-tree, masks and all — so the rows the ranks exchange are what the device would produce, ragged counts included"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_lib as O
+    synth = importlib.import_module("multicol-slam_amd.synth")
+    cams = [synth.scaled_camera(synth.lafida_cameras()[c % 3], 256, 192) for c in range(ncam)]
+    desc, mask = np.zeros((ncam, FT, CAP, DS), np.uint8), np.zeros((ncam, FT, CAP, DS), np.uint8)
+    nkp = np.zeros((ncam, FT), np.int32)
+    ex = O.Extractor(nfeatures=CAP - 8, nlevels=2, do_dBrief=1, learnMasks=1)
+    for c in range(ncam):
+        mk = synth.mirror_mask(cams[c])
+        for f in range(FT):
+            k, d, m = ex(synth.synth_image(f % 4, c % 3, cams[c], nshapes=60, scene=c // 3), mk, O.make_ocam(cams[c]))
+            n = min(len(d), CAP)
+            desc[c, f, :n], mask[c, f, :n], nkp[c, f] = d[:n], m[:n], n
+    return desc, mask, nkp
+
+
+_TRUTH = {False: _truth, True: _truth_images}
+
+
 def _frame(desc, mask, nkp, f):
     """multi-frame f as the reference sees it: cameras concatenated, CAP rows per camera, rows beyond a camera's count invalid"""
     ncam = desc.shape[0]
@@ -46,7 +69,7 @@ def _frame(desc, mask, nkp, f):
     return np.ascontiguousarray(d), np.ascontiguousarray(m), v
 
 
-def _worker(rank, world, port, ncam, F, nkf, q):
+def _worker(rank, world, port, ncam, F, nkf, q, images=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -56,7 +79,9 @@ def _worker(rank, world, port, ncam, F, nkf, q):
     rig = importlib.import_module("multicol-slam_amd.rig")
     FT = F * world
     lay = rig.RigLayout(ncam, FT, world, CAP, DS)
-    desc, mask, nkp = _truth(ncam, FT)
+    rig.plan_check(ncam, F, world, CAP, 0, DS)
+    rig.plan_check(ncam, F, world, CAP, nkf, DS)
+    desc, mask, nkp = _TRUTH[images](ncam, FT)
     # ---- this rank's slab -> send blocks -> ONE all-gather
     slab = lay.slab(rank)
     send = rig.pack_blocks(lay, np.stack([desc[c, f] for c, f in slab]), np.stack([mask[c, f] for c, f in slab]), np.array([nkp[c, f] for c, f in slab]))
@@ -102,12 +127,14 @@ def _worker(rank, world, port, ncam, F, nkf, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,ncam,F,nkf", [(2, 3, 2, 5), (2, 6, 1, 4), (3, 8, 1, 4)])
-def test_rig_matched_output_equals_single_process_oracle(oracle, world, ncam, F, nkf):
+# world 4 and 8 — the sizes of the driver's scaling run — on rows the oracle extracted from tiny images (`images`): every rank regenerates the stream, extracts only
+# through the oracle, and the exchange / in-place consumption / pair sharding must reproduce the single-process result match for match
+@pytest.mark.parametrize("world,ncam,F,nkf,images", [(2, 3, 2, 5, False), (2, 6, 1, 4, False), (3, 8, 1, 4, False), (4, 3, 1, 5, True), (8, 3, 1, 9, True), (4, 6, 2, 3, False)])
+def test_rig_matched_output_equals_single_process_oracle(oracle, world, ncam, F, nkf, images):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ncam, F, nkf, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ncam, F, nkf, q, images)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -122,7 +149,7 @@ def test_rig_matched_output_equals_single_process_oracle(oracle, world, ncam, F,
     # single process, no sharding, no exchange: the same searches straight on the stream
     import oracle_lib as O
     FT = F * world
-    desc, mask, nkp = _truth(ncam, FT)
+    desc, mask, nkp = _TRUTH[images](ncam, FT)
     n_ring = n_db = 0
     for f in range(FT):
         d1, m1, v1 = _frame(desc, mask, nkp, f)
@@ -140,7 +167,47 @@ def test_rig_matched_output_equals_single_process_oracle(oracle, world, ncam, F,
             full[keep] = m
             assert merged[("db", k, f)] == (n, full.tolist())
             n_db += n
-    assert len(merged) == FT + nkf * FT and n_ring > 10 * FT and n_db > 10 * nkf * FT
+    assert len(merged) == FT + nkf * FT and n_ring > (2 if images else 10) * FT and n_db > (2 if images else 10) * nkf * FT
+
+
+def test_plan_check_covers_every_bench_workload_and_names_violations():
+    """bench.py --dry-run: the plans of all workloads at world 2 / 4 / 8 hold; what cannot be sharded is named, not swallowed"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["ok"] and len(rep["dry_run"]) == 12 and all(x["ok"] for x in rep["dry_run"])
+    for x in rep["dry_run"]:
+        if x["workload"] == "stream":   # frame ring: every frame of the step has one owner, and a rank receives an order of magnitude less than an all-gather would deliver
+            assert x["exchange"].startswith("point-to-point") and sum(x["pairs_per_rank"]) == 64 * x["world"]
+            assert max(x["recv_bytes_per_rank"]) < x["send_bytes_per_rank"] * (x["world"] - 1) or x["world"] == 2
+        else:
+            assert x["exchange"] == "all-gather" and x["recv_bytes_per_rank"][0] == (x["world"] - 1) * x["send_bytes_per_rank"]
+    # a world size the frames do not divide into: refused with a message and a non-zero exit, as the real run would
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--gpus", "3", "--workload", "rig8", "--ncam", "8", "--frames", "1", "--keyframes", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0 and rep["ok"]            # 8 cameras x 3 frames over 3 ranks: equal slabs of 8 images
+    rig = importlib.import_module("multicol-slam_amd.rig")
+    with pytest.raises(ValueError):
+        rig.plan_check(4, 1, 3, 1024, 0)              # 4 cameras x 3 frames = 12 images over 3 ranks is fine ...
+        rig.RigLayout(4, 2, 3, 1024)                  # ... 2 frames in total over 3 ranks is not
+    # a tampered plan is caught: shift one receive run of rank 1 by a block
+    lay = rig.RigLayout(3, 8, 4, 1024)
+    ex = rig.RingExchange(lay)
+    good = ex._runs
+    ex_bad = rig.RingExchange(lay)
+    orig = rig.RingExchange._runs
+    try:
+        rig.RingExchange._runs = lambda self, rank: [(o, s_, d + (1 if rank == 1 and i == 0 else 0), n) for i, (o, s_, d, n) in enumerate(orig(self, rank))]
+        with pytest.raises(ValueError):
+            rig.plan_check(3, 2, 4, 1024, 0)
+    finally:
+        rig.RingExchange._runs = orig
+    assert good(1) == ex_bad._runs(1)
 
 
 def test_ring_exchange_plan():

@@ -10,15 +10,17 @@ import sys
 
 NAMES = {"k_describe_fast": "describe", "k_match_partial": "match", "k_match_mfma": "match", "k_fast_cells": "fast", "k_blur": "blur", "k_resize_level": "pyramid", "k_octree": "octree",
          "k_greedy_spec": "greedy", "k_orient_a": "orient_a", "k_orient_b": "orient_b", "k_describe_list": "describe_list", "k_describe": "describe_exact", "k_expand_train": "match_expand", "k_resize_chain": "pyramid", "k_resize_cols": "pyramid", "k_copy_narrow": "copy"}
-# FETCH_SIZE reads HALF the bytes of a 16-byte-per-lane coalesced stream on gfx950 (the guide; calibrated here on a copy of known size, tools/pmc_calibrate.sh ->
-# profiles/r04/pmc_calibration.txt: 262 158 KiB read for 524 288 KiB copied, WRITE_SIZE 524 331 KiB for the same bytes): the kernels whose reads ARE such streams
-# (the matcher's global_load_lds operand stream, the copy kernel) are doubled; dword-granular readers matched a known byte count within 14 % (k_blur, round 1).
-WIDE_READERS = {"match": 2.0, "copy": 2.0}
-out = {"_comment": "HBM traffic and VALU instructions per launch from separate rocprofv3 --pmc passes (tools/profile_round.sh; FETCH_SIZE / WRITE_SIZE in KiB per "
-                   "dispatch, SQ_INSTS_VALU in wave instructions per dispatch).  FETCH_SIZE of the kernels that read 16 bytes per lane in whole-wave streams (match: "
-                   "global_load_lds of the expanded operands) is DOUBLED (gfx950 tallies their 128-byte requests at 64 bytes: profiles/r04/pmc_calibration.txt, a copy of "
-                   "known size reads 0.50 of its bytes, writes 1.00); fetch_kib_raw keeps the counter's own reading.  k_describe_fast requests its patches as 48-byte row "
-                   "segments (three 16-byte lanes): not calibrated, left as read.  Kernels launched several times per step (the 7 k_resize_cols launches) are summed per step.", "workloads": {}}
+# FETCH_SIZE = TCC_EA0_RDREQ x 64 B, and EVERY read request the L2 sends to the memory side of this chip is a 128-byte request (round 5, tools/pmc_patterns.hip under
+# rocprofv3 -> profiles/r05/pmc_calibration.txt: TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ for 16 / 8 / 4-byte-per-lane streams AND for scattered 48-byte / 36-byte row
+# segments; the streams read exactly 0.500 of their bytes, the segment patterns exactly (line touches) x 64 B).  So the bytes that really cross the L2's memory side
+# are 2 x FETCH_SIZE for every kernel — round 4 doubled only the 16-byte-per-lane readers and so reported the keypoint stage at 0.81x its algorithmic bytes; it is
+# ~1.6x.  WRITE_SIZE reads 1.00 of a copy's bytes.  What is counted is the L2's miss traffic: lines served by the 256 MiB Infinity Cache are included.
+FETCH_FACTOR = 2.0
+out = {"_comment": "Memory-side traffic of the L2 and VALU instructions per launch from separate rocprofv3 --pmc passes (tools/profile_round.sh; KiB per dispatch, wave instructions "
+                   "per dispatch).  fetch_kib = 2 x FETCH_SIZE for EVERY kernel: the counter tallies each 128-byte read request as 64 bytes, and all requests are 128-byte "
+                   "ones (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ on streams and on scattered 36 / 48-byte segments alike: profiles/r05/pmc_calibration.txt); fetch_kib_raw keeps "
+                   "the counter's own reading.  WRITE_SIZE is used as read (1.00 on a copy of known size).  Infinity-Cache hits are part of the count (it is the L2's miss "
+                   "traffic, an upper bound of the HBM traffic).  Kernels launched several times per step (the 7 k_resize_cols launches) are summed per step.", "workloads": {}}
 for arg in sys.argv[2:]:
     label, rest = arg.split("=", 1)
     summary, benchjson = rest.split(":")
@@ -36,9 +38,8 @@ for arg in sys.argv[2:]:
         mult = disp / ref[0] if ref else 1.0
         k = kern.setdefault(name, {})
         if "FETCH_SIZE" in vals:
-            k["fetch_kib"] = round(vals["FETCH_SIZE"] * mult * WIDE_READERS.get(name, 1.0), 1)
-            if name in WIDE_READERS:
-                k["fetch_kib_raw"] = round(vals["FETCH_SIZE"] * mult, 1)
+            k["fetch_kib"] = round(vals["FETCH_SIZE"] * mult * FETCH_FACTOR, 1)
+            k["fetch_kib_raw"] = round(vals["FETCH_SIZE"] * mult, 1)
         if "WRITE_SIZE" in vals:
             k["write_kib"] = round(vals["WRITE_SIZE"] * mult, 1)
         if "SQ_INSTS_VALU" in vals:
