@@ -370,6 +370,7 @@ int mcs_ctx_synchronize(mcs_ctx* c) {
 
 int mcs_ctx_enable_timing(mcs_ctx* c, int on) {
 	if (!c) return fail(MCS_ERR_INVALID, "null ctx");
+	if (c->timing != (on != 0)) c->lastResultStream = nullptr;   // per-kernel timing runs the searches in order on the main stream: what the last search recorded belongs to the other mode
 	c->timing = on != 0;
 	return MCS_OK;
 }

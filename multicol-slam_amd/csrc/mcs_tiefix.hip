@@ -6,7 +6,9 @@
 // brought a cvRound argument within `tieBand` of a tie (ExtractBuffers.tieList; default band 1e-9 px for the distorted modes — ~300x the worst chain of two-ulp
 // libm differences through atan, the 12-term backward polynomial and the mean —, 1e-12 px for the plain ORB rotation, whose coordinates are |x|,|y| <= 15 times a
 // cosine / sine: 2 * 15 * 2 ulp = 1.3e-14 px), and the host recomputes exactly those descriptors here, calling the libm the reference itself would call.
-// The blurred / unblurred level of the keypoint is fetched from the device for it; the events are rare (mdBRIEF: ~3e-4 per 64-multi-frame batch).
+// The blurred / unblurred level of the keypoint is fetched from the device for it.  How often: in the default mdBRIEF mode only the fast pass's fallbacks run the exact
+// arithmetic, and those are by construction the keypoints with a coordinate within the guard band (6e-8 px) of a tie — 1e-9 / 6e-8 = 1.7 % of them land in this band: about
+// one keypoint per 64-multi-frame batch (measured on the bench stream: one per step).
 // Reference: src/mdBRIEFextractorOct.cpp:250-283 (rotateAndDistortPattern), :285-301 (rotatePattern), :303-554 (compute_ORB / _dBRIEF / _mdBRIEF),
 // src/cam_model_omni.cpp:49-67, 146-161, include/cam_model_omni.h:127-145.  This is product code (the C ABI's own host side), not the test oracle: nothing here
 // includes, links or calls oracle/.

@@ -27,10 +27,13 @@ int main(int argc, char** argv) {
 		fwrite(out, 4, 2, fo); fwrite(&sf, 8, 1, fo);
 		if (!keys.empty()) { fwrite(keys.data(), sizeof(KeyPoint), keys.size(), fo); fwrite(desc.data, 32, keys.size(), fo); }
 		std::fclose(fo);
-		// the pipelined host's helpers of Context: the result stream exists, the transfer stream keeps clear of the extraction's queues, the probe agrees with itself
+		// the pipelined host's helpers of Context: the result stream exists and conflicts with itself, the transfer stream is one stable handle whose mask names
+		// context streams only (WHICH queue it shares is a wall-clock probe's verdict: not asserted, a loaded box can read a conflict where there is none)
 		unsigned conf = 0;
 		void* ts = ctx.transferStream(&conf);
-		if (!ctx.resultStream() || !ts || (conf & 3u) != 0 || ctx.streamConflicts(ts) != conf) return 4;
+		unsigned conf2 = 0;
+		void* ts2 = ctx.transferStream(&conf2);
+		if (!ctx.resultStream() || !ts || ts2 != ts || (conf & ~0xFu) != 0 || (ctx.streamConflicts(ts) & ~0xFu) != 0 || ctx.streamConflicts(ctx.resultStream()) == 0) return 4;
 		ctx.synchronize();
 		return 0;
 	} catch (const std::exception& e) {
