@@ -815,7 +815,10 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 	}
 	// (Other launch orders measured in round 3: the whole resize chain first on the main stream, then FAST on all levels in one launch with the blur beside it:
 	// 2.55 instead of 2.21 ms per step; level 1 first, then FAST on levels 0 and 1 beside the rest of the chain: 2.51.)
-	if (c->overlap()) {
+	// Small batches run IN ORDER on the context's stream (round 5): the forks pay for themselves only when the kernels are long — for ONE 3-camera multi-frame the
+	// kernels take 5-50 us each, and every cross-stream event costs about as much as one of them (extraction of 3 images: 0.33 -> 0.29 ms).
+	const bool forked = c->overlap() && (long long)nimg * hd.width * hd.height >= 4000000ll;
+	if (forked) {
 		// Two chains until the descriptors: the side stream runs the resize chain (7 dependent, latency-bound launches) and then the blur, which needs
 		// nothing else; the main stream starts FAST on level 0 — the input image itself, a third of all FAST work — at once, picks up the other levels
 		// when the pyramid is there, and runs the oct-tree.  Both chains leave most of the chip idle on their own.
@@ -868,7 +871,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		c->tic("octree"); launch_octree(b, hd, nimg, s); c->toc("octree");
 		c->tic("blur"); launch_blur(b, hd, nimg, s); c->toc("blur");
 	}
-	if (c->overlap()) { b.sideStream = c->side; b.evDescFork = c->evDescFork; b.evDescJoin = c->evDescJoin; }   // the side stream is idle again: the main stream has waited for the blur
+	if (forked) { b.sideStream = c->side; b.evDescFork = c->evDescFork; b.evDescJoin = c->evDescJoin; }   // the side stream is idle again: the main stream has waited for the blur
 	c->tic("describe"); launch_describe(b, hd, nimg, s); c->toc("describe");
 	HIPCHK(hipGetLastError());
 	e->last = b; e->lastN = nimg;

@@ -312,7 +312,14 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 			for (int e = 0; e < K; ++e) key[e] = src[(size_t)e * g.nq];
 		}
 		bool resolved = !qok;
-		if (inRange && !qok && g.mode != 1) outM[i] = -1;
+		// The lane's result is written after the rounds (round 5: a workgroup-scope fence waits for every vector-memory operation of the wave on this chip, so a store
+		// inside a round sits in front of the next fence).  Traced with the cycle counter on ONE keyframe pair (48 chunks one after the other, 245 us, the largest
+		// piece of one multi-frame's matching latency): 107 rounds, 59 % of the cycles in the walk over the list entries below (≈ 3000 cycles per round: a chain of
+		// dependent LDS bitmap reads as long as the unluckiest lane's prefix of taken rows), 15 % claims, 13 % list loads, 3 % commits.  Measured against it without
+		// gain: the next chunk's lists requested a chunk ahead (245 us), these deferred stores (244), all K bitmap bits read at once and the two free entries picked
+		// with bit arithmetic (317 with per-entry branches, 300 branch-free: 64 lanes x K entries of VALU work cost more than the chain they replace).
+		int myOut = -1;            // modes 0 / 2: the row this query takes; mode 1: the row whose slot receives this query's index
+
 		// TRI: a list that ends with an empty slot or an entry beyond TH_LOW holds every candidate; otherwise rows of distance >= dK may be hidden
 		const bool full = TRI ? (key[K - 1] != EMPTY && (int)(key[K - 1] >> 20) <= g.thLow) : key[K - 1] != EMPTY;
 		const int dK = full ? (int)(key[K - 1] >> 20) : 0x7FFFFFFF;
@@ -457,13 +464,15 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 			if (commit) {
 				if (state == 1) {
 					atomicOr(&matched[bestIdx >> 5], 1u << (bestIdx & 31));
-					if (g.mode != 1) outM[i] = bestIdx; else outM[bestIdx] = i;
-				} else if (g.mode != 1) outM[i] = -1;
+					myOut = bestIdx;
+				}
 				resolved = true;
 			}
 			nmatches += __popcll(__ballot(commit && state == 1));
 			__threadfence_block();
 		}
+		if (g.mode != 1) { if (inRange) outM[i] = myOut; }   // (a query without a good map point: -1)
+		else if (myOut >= 0) outM[myOut] = i;
 	}
 	if (lane == 0) {
 		g.outCount[set] = nmatches;

@@ -279,16 +279,32 @@ __global__ __launch_bounds__(256) void k_match_merge(MatchArgs a) {
 #pragma unroll
 	for (int p = 0; p < K; ++p) best[p] = 0xFFFFFFFFu;
 	int countLe = 0;
-	for (int s = 0; s < a.splits; ++s) {
-		const size_t o = (size_t)set * a.splits + s;
-		countLe += a.partialCount[o * a.nq + qi];
-		const uint32_t* src = a.partial + o * K * a.nq;
-		for (int e = 0; e < K; ++e) {
-			uint32_t key = src[(size_t)e * a.nq + qi];
-			if (key >= best[K - 1]) break;   // lists are ascending
+	// A split's K entries are requested TOGETHER, and the next split's while this one is merged (round 5): entry by entry behind the `break` every thread paid a
+	// dependent global round trip per entry — 77 us for the 12 splits of a single keyframe pair, the second largest piece of one multi-frame's matching latency.
+	static_assert((K & (K - 1)) == 0, "the merge network needs a power of two");
+	uint32_t cur[K], nxt[K];
+	auto request = [&](int s, uint32_t (&dstv)[K]) {
+		const uint32_t* src = a.partial + ((size_t)set * a.splits + s) * K * a.nq + qi;
 #pragma unroll
-			for (int p = 0; p < K; ++p) { const uint32_t lo = min(best[p], key), hi = max(best[p], key); best[p] = lo; key = hi; }
-		}
+		for (int e = 0; e < K; ++e) dstv[e] = src[(size_t)e * a.nq];
+	};
+	request(0, cur);
+	for (int s = 0; s < a.splits; ++s) {
+		countLe += a.partialCount[((size_t)set * a.splits + s) * a.nq + qi];
+		if (s + 1 < a.splits) request(s + 1, nxt);
+		// both lists ascend: the K smallest of their union are min(best[i], cur[K - 1 - i]) — a bitonic sequence —, sorted by one bitonic merge (log2 K stages of K / 2
+		// compare-exchanges; K is a power of two).  Branch-free: 32 + 160 operations per split for K = 32 where insertion took up to 2048.
+#pragma unroll
+		for (int e = 0; e < K; ++e) best[K - 1 - e] = min(best[K - 1 - e], cur[e]);
+#pragma unroll
+		for (int j = K >> 1; j > 0; j >>= 1)
+#pragma unroll
+			for (int i = 0; i < K; ++i) {
+				const int l = i ^ j;
+				if (l > i) { const uint32_t lo = min(best[i], best[l]), hi = max(best[i], best[l]); best[i] = lo; best[l] = hi; }
+			}
+#pragma unroll
+		for (int e = 0; e < K; ++e) cur[e] = nxt[e];
 	}
 	uint32_t* dst = a.keys + (size_t)set * K * a.nq;
 #pragma unroll
