@@ -54,7 +54,9 @@ typedef struct {
 	int32_t width, height;
 } mcs_ocam;
 
-/* the 13 constructor arguments of mdBRIEFextractorOct, same order and meaning (h:339-351) */
+/* the 13 constructor arguments of mdBRIEFextractorOct, same order and meaning (h:339-351).  useAgast 0: cv::FastFeatureDetector, fastAgastType 0 / 1 / 2 =
+   TYPE_5_8 / TYPE_7_12 / TYPE_9_16; useAgast 1: cv::AgastFeatureDetector, fastAgastType 0 / 1 / 2 / 3 = AGAST_5_8 / AGAST_7_12d / AGAST_7_12s / OAST_9_16
+   (src/mdBRIEFextractorOct.cpp:869-872, 912-917), 1 <= fastThreshold <= 254 */
 typedef struct {
 	int32_t nfeatures; float scaleFactor; int32_t nlevels; int32_t edgeThreshold; int32_t firstLevel; int32_t scoreType;
 	int32_t patchSize; int32_t fastThreshold; int32_t useAgast; int32_t fastAgastType; int32_t do_dBrief; int32_t learnMasks;

@@ -402,8 +402,11 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	if (!ctx || !p || !out) return fail(MCS_ERR_INVALID, "null argument");
 	if (p->nlevels < 1 || p->nlevels > MCS_MAX_LEVELS) return fail(MCS_ERR_INVALID, "nlevels out of range");
 	if (p->descSize != 16 && p->descSize != 32 && p->descSize != 64) return fail(MCS_ERR_INVALID, "descSize must be 16, 32 or 64");
-	if (p->useAgast) return fail(MCS_ERR_UNSUPPORTED, "AGAST is not implemented (OpenCV's generated decision trees are not part of the reference tree); use FAST (useAgast 0)");
-	if (p->fastAgastType < 0 || p->fastAgastType > 2) return fail(MCS_ERR_INVALID, "fastAgastType must be 0 (TYPE_5_8), 1 (TYPE_7_12) or 2 (TYPE_9_16)");
+	if (p->useAgast) {
+		if (p->fastAgastType < 0 || p->fastAgastType > 3) return fail(MCS_ERR_INVALID, "fastAgastType must be 0 (AGAST_5_8), 1 (AGAST_7_12d), 2 (AGAST_7_12s) or 3 (OAST_9_16) with useAgast");
+		// the device stores "no corner" as score 0 and a corner's score is >= the threshold; cv::AGAST's bisection never returns more than 254
+		if (p->fastThreshold < 1 || p->fastThreshold > 254) return fail(MCS_ERR_UNSUPPORTED, "useAgast needs 1 <= fastThreshold <= 254");
+	} else if (p->fastAgastType < 0 || p->fastAgastType > 2) return fail(MCS_ERR_INVALID, "fastAgastType must be 0 (TYPE_5_8), 1 (TYPE_7_12) or 2 (TYPE_9_16)");
 	if (!(p->scaleFactor > 1.0f)) return fail(MCS_ERR_INVALID, "scaleFactor must be > 1");
 	if (max_batch < 1 || width < 1 || height < 1 || p->nfeatures < 1) return fail(MCS_ERR_INVALID, "bad size");
 	HIPCHK(hipSetDevice(ctx->device));
@@ -415,6 +418,9 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	hd.nlevels = nl; hd.width = width; hd.height = height;
 	hd.fastThreshold = std::min(std::max(p->fastThreshold, 0), 255);
 	hd.fastRing = p->fastAgastType == 2 ? 16 : (p->fastAgastType == 1 ? 12 : 8);
+	hd.agast = p->useAgast ? p->fastAgastType : -1;
+	// border of the detector inside a cell view: cv::FAST keeps 3 pixels for every ring, cv::AGAST the ring's radius (1 / 3 / 2 / 3)
+	const int detB = !p->useAgast ? 3 : (p->fastAgastType == 0 ? 1 : (p->fastAgastType == 2 ? 2 : 3));
 	hd.descSize = p->descSize; hd.npoints = 2 * 8 * p->descSize;
 	hd.mode = p->learnMasks ? 2 : (p->do_dBrief ? 1 : 0);
 	hd.undistort = p->do_dBrief ? 1 : 0;
@@ -454,7 +460,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 		}
 		L.wCell = (int)ceil(wd / L.nCols);
 		L.hCell = (int)ceil(ht / L.nRows);
-		L.capc = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
+		L.capc = p->useAgast ? ((L.wCell + 6 - 2 * detB) * (L.hCell + 6 - 2 * detB) + 1) / 2 : ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
 		L.cellBase = cellBase; L.slotBase = slotBase;
 		for (int i = 0; i < L.nRows; i++)
 			for (int j = 0; j < L.nCols; j++) {
@@ -465,9 +471,9 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 				bool skip = (iniY >= maxBY - 3) || (iniX >= maxBX - 6);   // :897,906
 				if (maxY > maxBY) maxY = maxBY;
 				if (maxX > maxBX) maxX = maxBX;
-				c.x0 = (short)(iniX + 3); c.y0 = (short)(iniY + 3);
-				c.cw = skip ? 0 : (short)std::max(0, (int)maxX - (int)iniX - 6);
-				c.ch = skip ? 0 : (short)std::max(0, (int)maxY - (int)iniY - 6);
+				c.x0 = (short)(iniX + detB); c.y0 = (short)(iniY + detB);
+				c.cw = skip ? 0 : (short)std::max(0, (int)maxX - (int)iniX - 2 * detB);
+				c.ch = skip ? 0 : (short)std::max(0, (int)maxY - (int)iniY - 2 * detB);
 				c.slot = slotBase + (i * L.nCols + j) * L.capc;
 				{   // k_fast_cells: tile row = cw + 4 + 3 bytes in dwords, 4-pixel groups per row
 					const int ndw = (c.cw + 4 + 3 + 3) >> 2, gpr = std::max((c.cw + 3) >> 2, 1);

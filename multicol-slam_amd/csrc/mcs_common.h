@@ -24,7 +24,7 @@ struct LevelInfo {
 	// FAST cell grid (reference :884-890)
 	int nCols, nRows, wCell, hCell;
 	int cellBase;           // first cell of this level in the per-image cell list
-	int capc;               // candidate slots per cell  = ceil(wCell/2)*ceil(hCell/2)  (strict local maxima cannot be 8-adjacent)
+	int capc;               // candidate slots per cell  = ceil(wCell/2)*ceil(hCell/2)  (strict local maxima cannot be 8-adjacent); AGAST: half the cell's pixels (survivors are not 4-adjacent)
 	int slotBase;           // first candidate slot of this level in the per-image slot array
 	int denseBase, denseCap;// dense (compacted, ordered) candidate list of this level
 	int nfeat;              // mnFeaturesPerLevel[level]
@@ -47,6 +47,7 @@ struct PyrDesc {
 	int kpCap;              // output rows per image
 	int fastThreshold;
 	int fastRing;           // 16 / 12 / 8: FastFeatureDetector TYPE_9_16 / TYPE_7_12 / TYPE_5_8
+	int agast;              // -1: FAST; 0 / 1 / 2 / 3: AgastFeatureDetector AGAST_5_8 / AGAST_7_12d / AGAST_7_12s / OAST_9_16 (useAgast)
 	int descSize, npoints;
 	int umax[kHalfPatch + 1];   // half-width of orientation-disc row |v| (reference :187-202)
 	int chainFits;          // the one-launch resize chain (k_resize_chain) serves this geometry

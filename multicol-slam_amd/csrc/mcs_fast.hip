@@ -12,6 +12,13 @@
 // Survivors are emitted in the reference's order (row-major inside the cell) with wave64 ballots + prefix counts into
 // the cell's private slot range, so the later compaction is a pure prefix sum over cells (cell row-major order).
 // Candidate record: x | y<<12 | score<<24 with x,y relative to minBorder (22), like vToDistributeKeys.
+//
+// AGAST (useAgast, reference :869-870, 912-914; cv::AgastFeatureDetector AGAST_5_8 / AGAST_7_12d / AGAST_7_12s / OAST_9_16) runs in the same kernel (template
+// parameter AG): the detector's decision trees decide the plain segment test "N contiguous of the P ring pixels all brighter than v + t or all darker than v - t",
+// so the closed form above on the type's ring IS the detector and its bisection score (tests/test_oracle_agast.py); what differs from FAST is the border (the
+// ring's radius: 1 / 3 / 2 / 3, so the processed regions of neighbouring cells overlap and a corner can be reported by two cells, as in the reference) and the
+// suppression: corners are merged into 4-connected regions by a forest of "dominated by" links, in raster order — one wave walks the corners that have a
+// neighbour above or to the left, exactly the statements of cv::AGAST's loop (the indices of those neighbours come from a bitmap, in parallel).
 #include "mcs_common.h"
 
 #include <algorithm>
@@ -101,6 +108,40 @@ __device__ __forceinline__ int small_ring_score(const uint8_t* c, int t) {
 	return corner ? max(A, -Bn) - 1 : 0;
 }
 
+// ---- AGAST: the plain segment test on the type's ring (cv::AgastFeatureDetector; the restatement is oracle/mcs_oracle.cpp orc_agast_type) ----------------
+// type 0 AGAST_5_8: the 8 neighbours, 5 contiguous; 1 AGAST_7_12d: the 12-pixel diamond of radius 3, 7 contiguous; 2 AGAST_7_12s: the 12-pixel square of radius 2
+// (= FAST's 12 ring), 7 contiguous; 3 OAST_9_16: the 16-pixel circle, 9 contiguous (scored by fast_score2).  Border of the scan = the radius.
+template <int AG> struct AgastGeom { static constexpr int P = AG == 0 ? 8 : (AG == 3 ? 16 : 12), N = P / 2 + 1, R = AG == 0 ? 1 : (AG == 2 ? 2 : 3); };
+template <int AG, int kTilePitch>
+__device__ __forceinline__ int agast_score(const uint8_t* c, int t) {
+	constexpr int P = AgastGeom<AG>::P, N = AgastGeom<AG>::N;
+	int d[P];
+	if constexpr (AG == 1) {   // makeAgastOffsets AGAST_7_12d, in ring order
+		const int v = c[0];
+		d[0] = v - c[-3]; d[1] = v - c[kTilePitch - 2]; d[2] = v - c[2 * kTilePitch - 1]; d[3] = v - c[3 * kTilePitch];
+		d[4] = v - c[2 * kTilePitch + 1]; d[5] = v - c[kTilePitch + 2]; d[6] = v - c[3]; d[7] = v - c[-kTilePitch + 2];
+		d[8] = v - c[-2 * kTilePitch + 1]; d[9] = v - c[-3 * kTilePitch]; d[10] = v - c[-2 * kTilePitch - 1]; d[11] = v - c[-kTilePitch - 2];
+	} else Ring<P, kTilePitch>::diffs(c, d);   // the same pixels in a circular order (the direction and the start do not matter for "contiguous")
+	int A = -256, Bn = 256;
+#pragma unroll
+	for (int k = 0; k < P; ++k) {
+		int lo = d[k], hi = d[k];
+#pragma unroll
+		for (int j = 1; j < N; ++j) { lo = min(lo, d[(k + j) % P]); hi = max(hi, d[(k + j) % P]); }
+		A = max(A, lo);
+		Bn = min(Bn, hi);
+	}
+	const int best = max(A, -Bn);
+	return best > t ? best - 1 : 0;   // = the bisection of agast_cornerScore: the largest b for which the pixel is still a corner (t >= 1: a corner's score is >= 1)
+}
+// LDS of the region suppression (only in the AGAST instances): per corner, in raster order
+template <bool ON, int CW> struct AgastLds { };
+template <int CW> struct AgastLds<true, CW> {
+	uint32_t info[CW * CW];          // code | score << 12 | has-left << 20 | has-above << 21
+	unsigned short above[CW * CW];   // index of the corner directly above
+	short flags[CW * CW];            // nmsFlags: -1 = a maximum, else the corner that dominates it
+};
+
 // Necessary condition for a 9-of-16 arc: it covers at least two ADJACENT compass points (k = 0, 4, 8, 12), so two
 // adjacent compass pixels must both be darker (d > t) or both be brighter (d < -t) than the centre.  Stricter than
 // cv::FAST's opposite-pair test and never rejects a corner.
@@ -121,18 +162,24 @@ __device__ __forceinline__ bool fast_quick(const uint8_t* c, int t) {
 typedef short v2s __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2s as_v2s(uint32_t x) { union { uint32_t u; v2s v; } c; c.u = x; return c.v; }
 __device__ __forceinline__ uint32_t as_u32(v2s x) { union { uint32_t u; v2s v; } c; c.v = x; return c.u; }
-template <int kTilePitch>
+// R = the ring's radius (3: the 16-pixel ring and AGAST's 12-pixel diamond; 2 / 1: AGAST's 12-pixel square and 8-pixel ring, whose arcs of 7 of 12 / 5 of 8 also cover two
+// adjacent compass points): the selectors pick the pixels R to the right / left out of the three row dwords.
+template <int kTilePitch, int R = 3>
 __device__ __forceinline__ uint32_t fast_quick4(const uint8_t* rowc /* tile row of the centres, at the group's first pixel (4-aligned) */, v2s tt /* t in both halves */) {
 	const uint32_t A = *reinterpret_cast<const uint32_t*>(rowc - 4), Cc = *reinterpret_cast<const uint32_t*>(rowc), B = *reinterpret_cast<const uint32_t*>(rowc + 4);
-	const uint32_t U = *reinterpret_cast<const uint32_t*>(rowc - 3 * kTilePitch), D = *reinterpret_cast<const uint32_t*>(rowc + 3 * kTilePitch);
+	const uint32_t U = *reinterpret_cast<const uint32_t*>(rowc - R * kTilePitch), D = *reinterpret_cast<const uint32_t*>(rowc + R * kTilePitch);
+	// byte k of the concatenation Cc | B is pixel k of the group's row: pixel j + R for j = 0, 2 (h = 0) and j = 1, 3 (h = 1); byte k of A | Cc is pixel k - 4: pixel j - R
+	constexpr uint32_t selR0 = 0x0c000c00u | (uint32_t)(R + 2) << 16 | (uint32_t)R, selR1 = 0x0c000c00u | (uint32_t)(R + 3) << 16 | (uint32_t)(R + 1);
+	constexpr uint32_t selL0 = 0x0c000c00u | (uint32_t)(6 - R) << 16 | (uint32_t)(4 - R), selL1 = 0x0c000c00u | (uint32_t)(7 - R) << 16 | (uint32_t)(5 - R);
+	static_assert(R != 3 || (selR0 == 0x0c050c03u && selR1 == 0x0c060c04u && selL0 == 0x0c030c01u && selL1 == 0x0c040c02u), "selectors of the 16-pixel ring");
 	uint32_t sign[2];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {   // h = 0: pixels 0 and 2, h = 1: pixels 1 and 3.  v_perm_b32(s0, s1, sel): selector 0-3 = byte of s1, 4-7 = byte of s0, 0x0c = zero
 		const uint32_t own = h ? 0x0c030c01u : 0x0c020c00u;
 		const v2s v = as_v2s(__builtin_amdgcn_perm(0u, Cc, own));
 		const v2s r0 = as_v2s(__builtin_amdgcn_perm(0u, D, own)), r8 = as_v2s(__builtin_amdgcn_perm(0u, U, own));
-		const v2s r4 = as_v2s(__builtin_amdgcn_perm(B, Cc, h ? 0x0c060c04u : 0x0c050c03u));    // 3 to the right of pixel j: C[3] B[0] B[1] B[2]
-		const v2s r12 = as_v2s(__builtin_amdgcn_perm(Cc, A, h ? 0x0c040c02u : 0x0c030c01u));   // 3 to the left:            A[1] A[2] A[3] C[0]
+		const v2s r4 = as_v2s(__builtin_amdgcn_perm(B, Cc, h ? selR1 : selR0));    // R = 3: 3 to the right of pixel j: C[3] B[0] B[1] B[2]
+		const v2s r12 = as_v2s(__builtin_amdgcn_perm(Cc, A, h ? selL1 : selL0));   //        3 to the left:             A[1] A[2] A[3] C[0]
 		const v2s m1 = __builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12));
 		const v2s m2 = __builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12));
 		const v2s dark = m1 - (v - tt);      // < 0 <=> two adjacent compass points are darker than v - t
@@ -236,7 +283,7 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
 }
 
 // A pixel of the cell is named by its code  row << 6 | column  (cells are at most 60 wide): row-major order, and the row / column come back with a shift and a mask.
-template <int CW, int kFastBS, int P>   // P = ring size: 16 (TYPE_9_16), 12 (TYPE_7_12), 8 (TYPE_5_8)
+template <int CW, int kFastBS, int P, int AG = -1>   // P = ring size: 16 (TYPE_9_16), 12 (TYPE_7_12), 8 (TYPE_5_8); AG >= 0: AGAST type AG (P = its ring size)
 __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd, int cell0, int ncells, unsigned ncellsM) {
 	typedef FastGeom<CW> Geo;
 	constexpr int kTilePitch = Geo::kTilePitch, kTileRows = Geo::kTileRows, kScPitch = Geo::kScPitch, kScRows = Geo::kScRows;
@@ -247,6 +294,8 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	__shared__ int runBase;
 	__shared__ int nSurv;
 	__shared__ unsigned short surv[CW * CW];   // codes of the pixels that pass the compass test
+	__shared__ AgastLds<(AG >= 0), CW> ag;
+	constexpr int QR = AG >= 0 ? AgastGeom<AG < 0 ? 3 : AG>::R : 3;   // radius of the compass test
 
 	// XCD-aware mapping: hardware places block i on XCD i%8; give every XCD a contiguous run of cells so that the
 	// overlapping cell rings / shared cache lines of neighbouring cells hit the same L2.
@@ -293,7 +342,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	const int lane = tid & 63, wave = tid >> 6;
 	// pass 1: cheap compass test on every pixel; survivors are compacted into an LDS list (order is irrelevant here) so that
 	// pass 2 — the full 16-pixel arc score, ~10x the work — runs with all lanes busy instead of diverging inside each wave
-	if constexpr (P == 16 && MCS_FAST_SEG16) {
+	if constexpr ((P == 16 && MCS_FAST_SEG16) || AG >= 0) {
 		// pass 1, 16-pixel ring, round 5: SIXTEEN adjacent pixels per thread (four fast_quick4 groups whose row dwords overlap: 14 LDS dwords instead of 20), so a
 		// 31 x 31 cell is 62 lanes — ONE trip of ONE wave where four-pixel lanes took two trips of both waves —, and the per-trip overhead (index arithmetic, prefix sum
 		// over the lanes' survivor counts, the atomic, the list writes) is paid once per 16 pixels: ~236 instead of ~470 wave-instructions per cell for this pass.
@@ -312,7 +361,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 #pragma unroll
 				for (int g = 0; g < 4; ++g) {
 					if (4 * g < valid) {   // (a group wholly outside the cell is not read: the tile's right margin holds only one dword past the ring)
-						const uint32_t q = fast_quick4<kTilePitch>(rowc + 4 * g, tt);   // verdicts of pixels 0, 1, 2, 3 in bits 0, 1, 16, 17
+						const uint32_t q = fast_quick4<kTilePitch, QR>(rowc + 4 * g, tt);   // verdicts of pixels 0, 1, 2, 3 in bits 0, 1, 16, 17
 						bits |= ((q | (q >> 14)) & 0xFu) << (4 * g);
 					}
 				}
@@ -393,7 +442,9 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	for (int i = tid; i < ns; i += kFastBS) {
 		const int p = surv[i];
 		const int py = p >> 6, px = p & 63;
-		sc[(py + 1) * kScPitch + px + 1] = (uint8_t)small_ring_score<P, kTilePitch>(&tile[(py + 3) * kTilePitch + px + Geo::kTileX], t);
+		const uint8_t* c = &tile[(py + 3) * kTilePitch + px + Geo::kTileX];
+		if constexpr (AG >= 0) sc[(py + 1) * kScPitch + px + 1] = (uint8_t)agast_score<(AG < 0 ? 0 : AG), kTilePitch>(c, t);
+		else sc[(py + 1) * kScPitch + px + 1] = (uint8_t)small_ring_score<P, kTilePitch>(c, t);
 	}
 	__syncthreads();
 
@@ -401,6 +452,95 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	const short* mapX = b.maskMap + L.mapX;
 	const short* mapY = b.maskMap + L.mapY;
 	const uint8_t* mask = b.mask0 ? b.mask0 + (size_t)img * b.mask0Pitch : nullptr;
+	if constexpr (AG >= 0) {
+		// ---- AGAST: region suppression (cv::AGAST's nmsFlags loop) -------------------------------------------------------------------------------------------
+		// corners = survivors with a score; their raster order (the order of cv::AGAST's keypoint list) from a bitmap + row prefix
+		for (int i = tid; i < ns; i += kFastBS) {
+			const int p = surv[i];
+			if (sc[((p >> 6) + 1) * kScPitch + (p & 63) + 1]) atomicOr(&keepBits[p >> 5], 1u << (p & 31));
+		}
+		__syncthreads();
+		if (wave == 0) {
+			const int v = lane < ch ? __popc(keepBits[2 * lane]) + __popc(keepBits[2 * lane + 1]) : 0;
+			const int incl = wave_incl_scan(v);
+			rowOff[lane] = incl - v;
+			if (lane == 63) runBase = incl;
+		}
+		__syncthreads();
+		auto bit = [&](int code) { return (keepBits[code >> 5] >> (code & 31)) & 1u; };
+		auto index = [&](int code) {   // corners before `code` in raster order
+			const uint32_t w = keepBits[code >> 5], lowm = (1u << (code & 31)) - 1u;
+			return rowOff[code >> 6] + (int)((code & 32) ? __popc(keepBits[(code >> 5) - 1]) + __popc(w & lowm) : __popc(w & lowm));
+		};
+		for (int i = tid; i < ns; i += kFastBS) {
+			const int p = surv[i];
+			const int py = p >> 6, px = p & 63;
+			const uint32_t s0 = sc[(py + 1) * kScPitch + px + 1];
+			if (!s0) continue;
+			const int idx = index(p);
+			const uint32_t left = px > 0 ? bit(p - 1) : 0u, up = py > 0 ? bit(p - 64) : 0u;
+			ag.info[idx] = (uint32_t)p | (s0 << 12) | (left << 20) | (up << 21);
+			ag.above[idx] = (unsigned short)(up ? index(p - 64) : 0);
+			ag.flags[idx] = -1;
+		}
+		__syncthreads();
+		if (wave != 0) return;
+		const int n = runBase;
+		auto resp = [&](int k) { return (int)((ag.info[k] >> 12) & 0xffu); };
+		// the walk: wave-uniform (every lane executes the same statements on the same LDS words); only corners with a neighbour above or to the left do anything
+		for (int base = 0; base < n; base += 64) {
+			const uint32_t inf = base + lane < n ? ag.info[base + lane] : 0u;
+			unsigned long long act = __ballot(((inf >> 20) & 3u) != 0u);
+			while (act) {
+				const int l = __builtin_ctzll(act);
+				act &= act - 1ull;
+				const int cur = base + l;
+				const uint32_t ci = __builtin_amdgcn_readlane(inf, l);
+				const int cr = (int)((ci >> 12) & 0xffu);
+				if (ci & (1u << 21)) {   // check above: the maximum of the block the corner above belongs to
+					int w = ag.above[cur];
+					while (ag.flags[w] != -1) w = ag.flags[w];
+					if (cr < resp(w)) ag.flags[cur] = (short)w;
+					else ag.flags[w] = (short)cur;
+				}
+				if (ci & (1u << 20)) {   // check left
+					int tl = cur - 1;
+					const int maxAbove = ag.flags[cur];
+					while (ag.flags[tl] != -1) tl = ag.flags[tl];
+					if (maxAbove == -1) {   // no maximum above
+						if (tl != cur) {
+							if (cr < resp(tl)) ag.flags[cur] = (short)tl;
+							else ag.flags[tl] = (short)cur;
+						}
+					} else if (tl != maxAbove) {   // maximum above
+						if (resp(maxAbove) < resp(tl)) { ag.flags[maxAbove] = (short)tl; ag.flags[cur] = (short)tl; }
+						else { ag.flags[tl] = (short)maxAbove; ag.flags[cur] = (short)maxAbove; }
+					}
+				}
+			}
+		}
+		// the maxima, in raster order, through the mirror mask (AgastFeatureDetector::detect: KeyPointsFilter::runByPixelsMask after the suppression)
+		uint32_t* slotsA = b.slots + (size_t)img * d.slotsPerImage + cell.slot;
+		const uint8_t* maskA = b.mask0 ? b.mask0 + (size_t)img * b.mask0Pitch : nullptr;
+		int run = 0;
+		for (int base = 0; base < n; base += 64) {
+			const int i = base + lane;
+			bool keep = false;
+			uint32_t rec = 0;
+			if (i < n) {
+				const uint32_t inf = ag.info[i];
+				const int px = inf & 63, py = (inf >> 6) & 63;
+				keep = ag.flags[i] == -1;
+				if (keep && maskA) keep = maskA[(size_t)(b.maskMap + L.mapY)[cell.y0 + py] * b.mask0Stride + (b.maskMap + L.mapX)[cell.x0 + px]] != 0;
+				rec = (uint32_t)(cell.x0 + px - kMinBorder) | ((uint32_t)(cell.y0 + py - kMinBorder) << 12) | (((inf >> 12) & 0xffu) << 24);
+			}
+			const unsigned long long bal = __ballot(keep);
+			if (keep) slotsA[run + __popcll(bal & ((1ull << lane) - 1ull))] = rec;
+			run += __popcll(bal);
+		}
+		if (lane == 0) *countOut = run;
+		return;
+	}
 	// pass 3a: non-max suppression + mirror mask, only for the pixels that have a score at all (the compass survivors); the verdicts go
 	// into a bitmap indexed by the pixel's code
 	for (int i = tid; i < ns; i += kFastBS) {
@@ -466,6 +606,22 @@ void launch_fast(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hipStream
 		if (cellMax <= 40) hipLaunchKernelGGL((k_fast_cells<40, MCS_FAST_BS, P>), grid, dim3(MCS_FAST_BS), 0, s, b, nimg, nblocks, perXcd, cell0, ncells, ncellsM);     \
 		else hipLaunchKernelGGL((k_fast_cells<60, 256, P>), grid, dim3(256), 0, s, b, nimg, nblocks, perXcd, cell0, ncells, ncellsM);                   \
 	} while (0)
+	if (hd.agast >= 0) {
+		// AGAST: the processed region of a cell is its view minus the ring's radius on every side (FAST: minus 3), so cells are up to 4 pixels larger
+		const int B = hd.agast == 0 ? 1 : (hd.agast == 2 ? 2 : 3);
+		const int cellMaxA = cellMax + 6 - 2 * B;
+#define MCS_AGAST_LAUNCH(T)                                                                                                                                              \
+		do {                                                                                                                                                                 \
+			if (cellMaxA <= 44) hipLaunchKernelGGL((k_fast_cells<44, 128, AgastGeom<T>::P, T>), grid, dim3(128), 0, s, b, nimg, nblocks, perXcd, cell0, ncells, ncellsM);   \
+			else hipLaunchKernelGGL((k_fast_cells<64, 256, AgastGeom<T>::P, T>), grid, dim3(256), 0, s, b, nimg, nblocks, perXcd, cell0, ncells, ncellsM);                    \
+		} while (0)
+		if (hd.agast == 0) MCS_AGAST_LAUNCH(0);
+		else if (hd.agast == 1) MCS_AGAST_LAUNCH(1);
+		else if (hd.agast == 2) MCS_AGAST_LAUNCH(2);
+		else MCS_AGAST_LAUNCH(3);
+#undef MCS_AGAST_LAUNCH
+		return;
+	}
 	if (hd.fastRing == 16) MCS_FAST_LAUNCH(16);
 	else if (hd.fastRing == 12) MCS_FAST_LAUNCH(12);
 	else MCS_FAST_LAUNCH(8);

@@ -315,9 +315,19 @@ public:
 };
 class AgastFeatureDetector {
 public:
-	static Ptr<AgastFeatureDetector> create(int = 10, bool = true, int = 3) { return std::make_shared<AgastFeatureDetector>(); }
-	void setThreshold(int) {}
-	void detect(const Mat&, std::vector<KeyPoint>&, const Mat& = Mat()) { throw std::runtime_error("cvshim: AGAST is not restated"); }
+	enum { AGAST_5_8 = 0, AGAST_7_12d = 1, AGAST_7_12s = 2, OAST_9_16 = 3 };
+	int threshold; bool nonmax; int type;
+	static Ptr<AgastFeatureDetector> create(int threshold = 10, bool nonmaxSuppression = true, int type = OAST_9_16) {
+		auto p = std::make_shared<AgastFeatureDetector>(); p->threshold = threshold; p->nonmax = nonmaxSuppression; p->type = type; return p; }
+	void setThreshold(int t) { threshold = t; }
+	void detect(const Mat& image, std::vector<KeyPoint>& keypoints, const Mat& mask = Mat()) {
+		if (type < AGAST_5_8 || type > OAST_9_16 || !nonmax) throw std::runtime_error("cvshim: AGAST is restated with non-max suppression only");
+		std::vector<orc_keypoint> out((size_t)image.rows * image.cols + 1);
+		const int n = orc_agast_type(type, image.data, image.cols, image.rows, (int)image.step, mask.empty() ? nullptr : mask.data, mask.empty() ? 0 : (int)mask.step, threshold,
+		                             out.data(), (int)out.size());
+		keypoints.clear();
+		for (int i = 0; i < n; ++i) keypoints.push_back(KeyPoint(out[i].x, out[i].y, out[i].size, out[i].angle, out[i].response, out[i].octave, out[i].class_id));
+	}
 };
 inline void FAST(const Mat& image, std::vector<KeyPoint>& keypoints, int threshold, bool nonmax = true) { FastFeatureDetector::create(threshold, nonmax)->detect(image, keypoints); }
 struct KeyPointsFilter {

@@ -439,6 +439,124 @@ int orc_fast_type(int type, const uint8_t* img, int w, int h, int stride, const 
 	return fast_t(type == 2 ? 16 : type == 1 ? 12 : 8, img, w, h, stride, mask, mstride, threshold, out, cap);
 }
 
+// ---------------------------------------------------------------- AGAST (AgastFeatureDetector, reference src/mdBRIEFextractorOct.cpp:869-870, 912-914)
+// OpenCV 3.x modules/features2d/src/agast.cpp + agast_score.cpp (NOT in the reference tree: "parity unpinned" against a real OpenCV; pinned by hand-derived
+// known answers and an independent literal Python transcription, tests/test_oracle_agast.py).  What OpenCV's AGAST(img, kps, threshold, true, type) does:
+//   1. detection: AGAST_5_8 / AGAST_7_12d / AGAST_7_12s / OAST_9_16 walk machine-generated binary decision trees (Mair et al., ECCV 2010) that DECIDE the
+//      accelerated segment test — "N contiguous pixels of the P-pixel ring are all brighter than v + t, or all darker than v - t" (strict), N / P = 5 / 8,
+//      7 / 12 (diamond, radius 3), 7 / 12 (square, radius 2), 9 / 16 — in as few pixel reads as possible; the trees are an evaluation order of the
+//      predicate, not a different predicate, so the predicate is what is stated here.  Scan: rows y = B .. rows - 1 - B, columns x = B .. cols - 1 - B in
+//      raster order with B = 1 / 3 / 2 / 3 (the trees' xsizeB / ysizeB bounds = the ring radius); a non-continuous view is cloned first (img.isContinuous()),
+//      so a cell view of a pyramid level behaves like an image of its own;
+//   2. response = agast_cornerScore<type>: bisection of the threshold b in [t, 255] with the same predicate ("bmin = b_test if it is still a corner, else
+//      bmax = b_test, until bmin >= bmax - 1; return bmin") = the largest b <= 254 for which the pixel is still a corner (agast_score_bisect below; the
+//      closed form max(A, B) - 1 with A = max over arcs of min(v - I), B = max over arcs of min(I - v) is checked against it by the tests);
+//   3. non-maximum suppression: NOT the 3x3 test of FAST — corners are merged into 4-connected regions (the corner directly above, the corner directly to
+//      the left) with a forest of "is dominated by" links (nmsFlags), one survivor per region: the first-seen maximum, except that a later corner with an
+//      EQUAL response takes over (`response < response` is the only comparison);
+//   4. AgastFeatureDetector::detect then applies KeyPointsFilter::runByPixelsMask.  KeyPoint(x, y, size 7, angle -1, response, octave 0, class_id -1).
+struct AgastRing { int P, N, B; int dx[16], dy[16]; };
+static const AgastRing& agast_ring(int type) {   // makeAgastOffsets, in ring order
+	static const AgastRing rings[4] = {
+		{8, 5, 1, {-1, -1, 0, 1, 1, 1, 0, -1}, {0, 1, 1, 1, 0, -1, -1, -1}},
+		{12, 7, 3, {-3, -2, -1, 0, 1, 2, 3, 2, 1, 0, -1, -2}, {0, 1, 2, 3, 2, 1, 0, -1, -2, -3, -2, -1}},
+		{12, 7, 2, {-2, -2, -1, 0, 1, 2, 2, 2, 1, 0, -1, -2}, {0, 1, 2, 2, 2, 1, 0, -1, -2, -2, -2, -1}},
+		{16, 9, 3, {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3}, {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1}},
+	};
+	return rings[type];
+}
+static bool agast_is_corner(const AgastRing& R, const uint8_t* c, int stride, int b) {
+	const int cb = c[0] + b, c_b = c[0] - b;
+	for (int k = 0; k < R.P; ++k) {
+		bool br = true, dk = true;
+		for (int j = 0; j < R.N && (br || dk); ++j) {
+			const int I = c[(ptrdiff_t)R.dy[(k + j) % R.P] * stride + R.dx[(k + j) % R.P]];
+			br = br && I > cb;
+			dk = dk && I < c_b;
+		}
+		if (br || dk) return true;
+	}
+	return false;
+}
+static int agast_score_bisect(const AgastRing& R, const uint8_t* c, int stride, int threshold) {
+	int bmin = threshold, bmax = 255, b_test = (bmax + bmin) / 2;
+	while (true) {
+		if (agast_is_corner(R, c, stride, b_test)) bmin = b_test; else bmax = b_test;
+		if (bmin == bmax - 1 || bmin == bmax) return bmin;
+		b_test = (bmin + bmax) / 2;
+	}
+}
+int orc_agast_score_type(int type, const uint8_t* center, int stride, int threshold) {
+	if (type < 0 || type > 3) return -1;
+	return agast_score_bisect(agast_ring(type), center, stride, threshold);
+}
+struct AgastK { float x, y, response; };
+static std::vector<AgastK> agast_corners(const AgastRing& R, const uint8_t* img, int w, int h, int stride, int threshold) {
+	std::vector<AgastK> kpts;
+	for (int y = R.B; y < h - R.B; ++y)
+		for (int x = R.B; x < w - R.B; ++x) {
+			const uint8_t* c = img + (size_t)y * stride + x;
+			if (agast_is_corner(R, c, stride, threshold)) kpts.push_back(AgastK{(float)x, (float)y, (float)agast_score_bisect(R, c, stride, threshold)});
+		}
+	return kpts;
+}
+// steps 1 + 2 only (AGAST(..., nonmax_suppression = false) with the responses filled in): every corner in raster order — for the tests
+int orc_agast_corners(int type, const uint8_t* img, int w, int h, int stride, int threshold, orc_keypoint* out, int cap) {
+	if (type < 0 || type > 3) return -1;
+	const std::vector<AgastK> kpts = agast_corners(agast_ring(type), img, w, h, stride, threshold);
+	for (size_t i = 0; i < kpts.size() && (int)i < cap; ++i) { orc_keypoint kp = {kpts[i].x, kpts[i].y, 7.f, -1.f, kpts[i].response, 0, -1}; out[i] = kp; }
+	return (int)kpts.size();
+}
+// AgastFeatureDetector::create(threshold, true, type)->detect(img, kps, mask): type 0 = AGAST_5_8, 1 = AGAST_7_12d, 2 = AGAST_7_12s, 3 = OAST_9_16
+int orc_agast_type(int type, const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride, int threshold, orc_keypoint* out, int cap) {
+	if (type < 0 || type > 3) return -1;
+	typedef AgastK K;
+	const std::vector<K> kpts = agast_corners(agast_ring(type), img, w, h, stride, threshold);
+	// the suppression loop of AGAST(), statement by statement
+	const size_t num_Corners = kpts.size();
+	size_t lastRow = 0, next_lastRow = 0, lastRowCorner_ind = 0, next_lastRowCorner_ind = 0;
+	std::vector<int> nmsFlags(num_Corners, -1);
+	for (size_t curr_idx = 0; curr_idx < num_Corners; curr_idx++) {
+		const K& cur = kpts[curr_idx];
+		// check above
+		if ((float)(lastRow + 1) < cur.y) { lastRow = next_lastRow; lastRowCorner_ind = next_lastRowCorner_ind; }
+		if ((float)next_lastRow != cur.y) { next_lastRow = (size_t)cur.y; next_lastRowCorner_ind = curr_idx; }
+		if ((float)(lastRow + 1) == cur.y) {
+			while ((kpts[lastRowCorner_ind].x < cur.x) && (kpts[lastRowCorner_ind].y == (float)lastRow)) lastRowCorner_ind++;   // the corner above the current one
+			if ((kpts[lastRowCorner_ind].x == cur.x) && (lastRowCorner_ind != curr_idx)) {
+				size_t wi = lastRowCorner_ind;
+				while (nmsFlags[wi] != -1) wi = (size_t)nmsFlags[wi];   // the maximum of that block
+				if (kpts[curr_idx].response < kpts[wi].response) nmsFlags[curr_idx] = (int)wi;
+				else nmsFlags[wi] = (int)curr_idx;
+			}
+		}
+		// check left
+		int t = (int)curr_idx - 1;
+		if ((curr_idx != 0) && (kpts[t].y == cur.y) && (kpts[t].x + 1 == cur.x)) {
+			const int currCornerMaxAbove_ind = nmsFlags[curr_idx];
+			while (nmsFlags[t] != -1) t = nmsFlags[t];   // the maximum of that area
+			if (currCornerMaxAbove_ind == -1) {   // no maximum above
+				if ((size_t)t != curr_idx) {
+					if (kpts[curr_idx].response < kpts[t].response) nmsFlags[curr_idx] = t;
+					else nmsFlags[t] = (int)curr_idx;
+				}
+			} else if (t != currCornerMaxAbove_ind) {   // maximum above
+				if (kpts[currCornerMaxAbove_ind].response < kpts[t].response) { nmsFlags[currCornerMaxAbove_ind] = t; nmsFlags[curr_idx] = t; }
+				else { nmsFlags[t] = currCornerMaxAbove_ind; nmsFlags[curr_idx] = currCornerMaxAbove_ind; }
+			}
+		}
+	}
+	int nout = 0;
+	for (size_t i = 0; i < num_Corners; ++i) {
+		if (nmsFlags[i] != -1) continue;
+		const float fx = kpts[i].x, fy = kpts[i].y;
+		if (mask && mask[(size_t)(int)(fy + 0.5f) * mstride + (int)(fx + 0.5f)] == 0) continue;  // runByPixelsMask
+		if (nout < cap) { orc_keypoint kp = {fx, fy, 7.f, -1.f, kpts[i].response, 0, -1}; out[nout] = kp; }
+		nout++;
+	}
+	return nout;
+}
+
 // ---------------------------------------------------------------- A.4 5x5 normalised box filter, in place on a ROI
 void orc_box5_inplace(uint8_t* roi, int w, int h, int stride) {
 	std::vector<uint8_t> out((size_t)w * h);
@@ -725,7 +843,7 @@ struct orc_extractor {
 
 orc_extractor* orc_extractor_create(const orc_params* p) {
 	if (p->nlevels < 1 || p->descSize < 1 || 2 * 2 * 8 * p->descSize > 2048) return nullptr;
-	if (p->useAgast || p->fastAgastType < 0 || p->fastAgastType > 2) return nullptr;  // AGAST (OpenCV's generated decision trees) is not restated
+	if (p->fastAgastType < 0 || p->fastAgastType > (p->useAgast ? 3 : 2)) return nullptr;  // FAST: TYPE_5_8 / 7_12 / 9_16; AGAST: AGAST_5_8 / 7_12d / 7_12s / OAST_9_16
 	orc_extractor* e = new orc_extractor;
 	e->p = *p;
 	scale_tables(p->scaleFactor, p->nlevels, e->mvScaleFactor, e->mvInvScaleFactor);
@@ -800,8 +918,8 @@ static void ComputeKeyPointsOctTree(orc_extractor* e, std::vector<std::vector<or
 				int y0 = (int)iniY, y1 = (int)maxY, x0 = (int)iniX, x1 = (int)maxX;
 				const uint8_t* view = L.roi() + (ptrdiff_t)y0 * L.stride + x0;
 				const uint8_t* mview = e->has_mask ? M.roi() + (ptrdiff_t)y0 * M.stride + x0 : nullptr;
-				int n = orc_fast_type(e->p.fastAgastType, view, x1 - x0, y1 - y0, L.stride, mview, M.stride, e->p.fastThreshold, cell.data(),
-				                      (int)cell.size());
+				int n = e->p.useAgast ? orc_agast_type(e->p.fastAgastType, view, x1 - x0, y1 - y0, L.stride, mview, M.stride, e->p.fastThreshold, cell.data(), (int)cell.size())
+				                      : orc_fast_type(e->p.fastAgastType, view, x1 - x0, y1 - y0, L.stride, mview, M.stride, e->p.fastThreshold, cell.data(), (int)cell.size());
 				for (int k = 0; k < n; ++k) {
 					orc_keypoint kp = cell[k];
 					kp.x += j * wCell;

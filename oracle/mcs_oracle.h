@@ -64,6 +64,10 @@ int   orc_fast_score(const uint8_t* center, int stride, int threshold);
 int   orc_fast_score_type(int type, const uint8_t* center, int stride, int threshold);   /* cornerScore<8 / 12 / 16> for type 0 / 1 / 2 */
 int   orc_fast_type(int type, const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride,
                     int threshold, orc_keypoint* out, int cap);                          /* FastFeatureDetector TYPE_5_8 / 7_12 / 9_16 */
+int   orc_agast_type(int type, const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mstride,
+                     int threshold, orc_keypoint* out, int cap);                         /* AgastFeatureDetector AGAST_5_8 / 7_12d / 7_12s / OAST_9_16, nonmax = true */
+int   orc_agast_corners(int type, const uint8_t* img, int w, int h, int stride, int threshold, orc_keypoint* out, int cap); /* before the suppression */
+int   orc_agast_score_type(int type, const uint8_t* center, int stride, int threshold);  /* agast_cornerScore<type> (bisection) */
 void  orc_box5_inplace(uint8_t* roi, int w, int h, int stride); /* roi sits inside a >=2px frame */
 float orc_fastAtan2(float y, float x);
 int   orc_cvRound(double v);

@@ -35,8 +35,8 @@ class Params(C.Structure):
                 ("descSize", C.c_int)]
 
 
-def make_params(nfeatures=1000, scaleFactor=1.2, nlevels=8, fastThreshold=20, do_dBrief=0, learnMasks=0, descSize=32, fastAgastType=2):
-    return Params(nfeatures, scaleFactor, nlevels, 25, 0, 0, 32, fastThreshold, 0, fastAgastType, do_dBrief, learnMasks, descSize)
+def make_params(nfeatures=1000, scaleFactor=1.2, nlevels=8, fastThreshold=20, do_dBrief=0, learnMasks=0, descSize=32, fastAgastType=2, useAgast=0):
+    return Params(nfeatures, scaleFactor, nlevels, 25, 0, 0, 32, fastThreshold, useAgast, fastAgastType, do_dBrief, learnMasks, descSize)
 
 
 def make_ocam(cam):
@@ -102,6 +102,9 @@ def lib():
         L.orc_fast_score.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_fast_type.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_fast_score_type.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc_agast_type.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_agast_corners.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_agast_score_type.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_box5_inplace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_resize_nearest.argtypes = L.orc_resize_linear.argtypes

@@ -169,9 +169,9 @@ def test_other_pyramid_parameters(G):
 
 def test_unsupported_parameters_fail_loudly(G):
     with pytest.raises(G.mcs.McsError):
-        G.mcs.Extractor(G.ctx(), 754, 480, useAgast=1)
+        G.mcs.Extractor(G.ctx(), 754, 480, useAgast=1, fastAgastType=4)   # AGAST: 0 .. 3 (tests/test_gpu_agast.py)
     with pytest.raises(G.mcs.McsError):
-        G.mcs.Extractor(G.ctx(), 754, 480, fastAgastType=3)      # 0 / 1 / 2 = TYPE_5_8 / 7_12 / 9_16 (tests/test_gpu_fast_types.py)
+        G.mcs.Extractor(G.ctx(), 754, 480, fastAgastType=3)      # FAST: 0 / 1 / 2 = TYPE_5_8 / 7_12 / 9_16 (tests/test_gpu_fast_types.py)
     with pytest.raises(G.mcs.McsError):
         G.mcs.Extractor(G.ctx(), 754, 480, descSize=24)
     with pytest.raises(G.mcs.McsError):

@@ -1,6 +1,6 @@
 """-m gpu: FAST TYPE_7_12 / TYPE_5_8 (`extractor.fastAgastType` 1 / 0; reference src/mdBRIEFextractorOct.cpp:869-872, 912-914) on the device: the ring is a
 template parameter of k_fast_cells (csrc/mcs_fast.hip), with OpenCV 3.x's wrapped quick test and 3-pixel border kept (tests/test_oracle_fast_types.py
-states both).  Candidates per level and the end-to-end outputs against the oracle, bit for bit; AGAST stays rejected."""
+states both).  Candidates per level and the end-to-end outputs against the oracle, bit for bit (AGAST: tests/test_gpu_agast.py)."""
 import ctypes as C
 
 import numpy as np
@@ -42,8 +42,8 @@ def test_small_rings_bit_exact(G, ftype, th, mode):
     ex.close()
 
 
-def test_large_cells_instance_and_agast_rejected(G):
-    """a small image (cells larger than 40 px: the 60 x 60 kernel instance) with the 12-pixel ring; AGAST and unknown types are refused loudly"""
+def test_large_cells_instance_and_unknown_type_rejected(G):
+    """a small image (cells larger than 40 px: the 60 x 60 kernel instance) with the 12-pixel ring; unknown types are refused loudly"""
     rng = np.random.default_rng(3)
     img = np.clip(rng.normal(110, 30, (200, 260)), 0, 255).astype(np.uint8)
     ex = G.mcs.Extractor(G.ctx(), 260, 200, max_batch=1, nfeatures=300, nlevels=3, fastThreshold=12, fastAgastType=1)
@@ -52,6 +52,4 @@ def test_large_cells_instance_and_agast_rejected(G):
     assert len(ok) > 30 and G.first_diff(kps, ok) is None and G.first_diff(d, od) is None
     ex.close()
     with pytest.raises(G.mcs.McsError):
-        G.mcs.Extractor(G.ctx(), 754, 480, useAgast=1)
-    with pytest.raises(G.mcs.McsError):
-        G.mcs.Extractor(G.ctx(), 754, 480, fastAgastType=3)
+        G.mcs.Extractor(G.ctx(), 754, 480, fastAgastType=3)            # FAST has three types (AGAST's four: tests/test_gpu_agast.py)

@@ -166,13 +166,12 @@ def test_restatement_equals_literal_python_transcription(oracle, synth, ftype):
     assert total > 50
 
 
-def test_extractor_accepts_the_small_rings_and_agast_stays_out(oracle, synth):
+def test_extractor_accepts_the_small_rings(oracle, synth):
     cams = synth.lafida_cameras()
     img, mask = synth.synth_image(0, 0, cams[0]), synth.mirror_mask(cams[0])
     n16 = len(oracle.Extractor(nfeatures=500)(img, mask, oracle.make_ocam(cams[0]))[0])
     n12 = len(oracle.Extractor(nfeatures=500, fastAgastType=1, fastThreshold=8)(img, mask, oracle.make_ocam(cams[0]))[0])
     n8 = len(oracle.Extractor(nfeatures=500, fastAgastType=0, fastThreshold=4)(img, mask, oracle.make_ocam(cams[0]))[0])
     assert n16 > 400 and n12 > 20 and n8 > 20
-    p = oracle.make_params()
-    p.useAgast = 1
+    p = oracle.make_params(fastAgastType=3)                                          # FAST has three types (AGAST's four: tests/test_oracle_agast.py)
     assert not oracle.lib().orc_extractor_create(__import__("ctypes").byref(p))

@@ -69,6 +69,12 @@ def test_oracle_equals_reference_code_full_size(mode):
     # oracle's restatement on both sides (oracle/cvshim), what the reference's own code adds is the cell loop, the oct-tree and everything downstream
     dict(scaleFactor=1.2, nlevels=8, nfeatures=400, descSize=32, do_dBrief=1, learnMasks=1, fastThreshold=8, fastAgastType=1),
     dict(scaleFactor=1.2, nlevels=8, nfeatures=300, descSize=32, do_dBrief=0, learnMasks=0, fastThreshold=4, fastAgastType=0),
+    # the AGAST branch of the reference's cell loop (useAgast, :869-870, 912-914), every type: again the detector is the oracle's restatement on both sides;
+    # the reference's code adds the views, the offsets, the corners reported twice by overlapping views, the oct-tree over them and everything downstream
+    dict(scaleFactor=1.2, nlevels=8, nfeatures=500, descSize=32, do_dBrief=1, learnMasks=1, fastThreshold=20, fastAgastType=0, useAgast=1),
+    dict(scaleFactor=1.2, nlevels=8, nfeatures=500, descSize=32, do_dBrief=0, learnMasks=0, fastThreshold=20, fastAgastType=1, useAgast=1),
+    dict(scaleFactor=1.2, nlevels=8, nfeatures=400, descSize=32, do_dBrief=1, learnMasks=1, fastThreshold=20, fastAgastType=2, useAgast=1),   # the type the shipped settings name
+    dict(scaleFactor=1.3, nlevels=5, nfeatures=700, descSize=32, do_dBrief=1, learnMasks=0, fastThreshold=9, fastAgastType=3, useAgast=1),
 ])
 def test_oracle_equals_reference_code_over_the_parameter_space(case):
     """pyramid geometry (scale factor, level count), feature budget, descriptor size and mode away from the shipped settings, on the Lafida sensor
@@ -81,7 +87,7 @@ def test_oracle_equals_reference_code_over_the_parameter_space(case):
         mask = np.ascontiguousarray(synth.mirror_mask(cam))
         k, d, m = R.run_ref(img, mask, cam, **case)
         ok, od, om = O.Extractor(**case)(img, mask, O.make_ocam(cam))
-        assert len(k) == len(ok) and len(k) > (100 if case.get("fastAgastType", 2) == 2 else 20) and all(np.array_equal(k[x], ok[x]) for x in k.dtype.names), (case, cam["width"], len(k))
+        assert len(k) == len(ok) and len(k) > (100 if case.get("fastAgastType", 2) == 2 or case.get("useAgast") else 20) and all(np.array_equal(k[x], ok[x]) for x in k.dtype.names), (case, cam["width"], len(k))
         assert np.array_equal(d, od) and np.array_equal(m, om), (case, cam["width"])
 
 
