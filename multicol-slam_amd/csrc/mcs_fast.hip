@@ -134,14 +134,6 @@ __device__ __forceinline__ int agast_score(const uint8_t* c, int t) {
 	const int best = max(A, -Bn);
 	return best > t ? best - 1 : 0;   // = the bisection of agast_cornerScore: the largest b for which the pixel is still a corner (t >= 1: a corner's score is >= 1)
 }
-// LDS of the region suppression (only in the AGAST instances): per corner, in raster order
-template <bool ON, int CW> struct AgastLds { };
-template <int CW> struct AgastLds<true, CW> {
-	uint32_t info[CW * CW];          // code | score << 12 | has-left << 20 | has-above << 21
-	unsigned short above[CW * CW];   // index of the corner directly above
-	short flags[CW * CW];            // nmsFlags: -1 = a maximum, else the corner that dominates it
-};
-
 // Necessary condition for a 9-of-16 arc: it covers at least two ADJACENT compass points (k = 0, 4, 8, 12), so two
 // adjacent compass pixels must both be darker (d > t) or both be brighter (d < -t) than the centre.  Stricter than
 // cv::FAST's opposite-pair test and never rejects a corner.
@@ -287,14 +279,16 @@ template <int CW, int kFastBS, int P, int AG = -1>   // P = ring size: 16 (TYPE_
 __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int nimg, int nblocks, int perXcd, int cell0, int ncells, unsigned ncellsM) {
 	typedef FastGeom<CW> Geo;
 	constexpr int kTilePitch = Geo::kTilePitch, kTileRows = Geo::kTileRows, kScPitch = Geo::kScPitch, kScRows = Geo::kScRows;
-	__shared__ __attribute__((aligned(16))) uint8_t tile[kTileRows * kTilePitch];
+	// (AGAST: after the scores are in `sc` the tile is dead and holds the corners' codes in raster order, two bytes per pixel of the cell at most; the links of the
+	// suppression walk, when they do not fit registers, take the place of `surv`)
+	constexpr int kTileBytes = (AG >= 0 && 2 * CW * CW > kTileRows * kTilePitch) ? 2 * CW * CW : kTileRows * kTilePitch;
+	__shared__ __attribute__((aligned(16))) uint8_t tile[kTileBytes];
 	__shared__ __attribute__((aligned(16))) uint8_t sc[kScRows * kScPitch];
 	__shared__ uint32_t keepBits[2 * CW];   // NMS + mask verdict per pixel of the cell: two words per row, bit = column
 	__shared__ int rowOff[64];           // exclusive prefix of the kept-pixel counts per row
 	__shared__ int runBase;
 	__shared__ int nSurv;
 	__shared__ unsigned short surv[CW * CW];   // codes of the pixels that pass the compass test
-	__shared__ AgastLds<(AG >= 0), CW> ag;
 	constexpr int QR = AG >= 0 ? AgastGeom<AG < 0 ? 3 : AG>::R : 3;   // radius of the compass test
 
 	// XCD-aware mapping: hardware places block i on XCD i%8; give every XCD a contiguous run of cells so that the
@@ -472,24 +466,51 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 			const uint32_t w = keepBits[code >> 5], lowm = (1u << (code & 31)) - 1u;
 			return rowOff[code >> 6] + (int)((code & 32) ? __popc(keepBits[(code >> 5) - 1]) + __popc(w & lowm) : __popc(w & lowm));
 		};
+		unsigned short* codes = reinterpret_cast<unsigned short*>(tile);   // the corners in raster order = cv::AGAST's keypoint list
+		short* flags = reinterpret_cast<short*>(surv);                     // nmsFlags: -1 = a maximum, else the corner that dominates it
 		for (int i = tid; i < ns; i += kFastBS) {
 			const int p = surv[i];
-			const int py = p >> 6, px = p & 63;
-			const uint32_t s0 = sc[(py + 1) * kScPitch + px + 1];
-			if (!s0) continue;
-			const int idx = index(p);
-			const uint32_t left = px > 0 ? bit(p - 1) : 0u, up = py > 0 ? bit(p - 64) : 0u;
-			ag.info[idx] = (uint32_t)p | (s0 << 12) | (left << 20) | (up << 21);
-			ag.above[idx] = (unsigned short)(up ? index(p - 64) : 0);
-			ag.flags[idx] = -1;
+			if (sc[((p >> 6) + 1) * kScPitch + (p & 63) + 1]) codes[index(p)] = (unsigned short)p;
 		}
 		__syncthreads();
-		if (wave != 0) return;
 		const int n = runBase;
-		auto resp = [&](int k) { return (int)((ag.info[k] >> 12) & 0xffu); };
-		// the walk: wave-uniform (every lane executes the same statements on the same LDS words); only corners with a neighbour above or to the left do anything
+		for (int i = tid; i < n; i += kFastBS) flags[i] = -1;
+		__syncthreads();
+		if (wave != 0) return;
+		uint32_t* slotsA = b.slots + (size_t)img * d.slotsPerImage + cell.slot;
+		const uint8_t* maskA = b.mask0 ? b.mask0 + (size_t)img * b.mask0Pitch : nullptr;
+		// a maximum leaves through the mirror mask (AgastFeatureDetector::detect: KeyPointsFilter::runByPixelsMask after the suppression), in raster order
+		int run = 0;
+		auto emit = [&](bool keep, uint32_t inf) {
+			const int px = inf & 63, py = (inf >> 6) & 63;
+			if (keep && maskA) keep = maskA[(size_t)(b.maskMap + L.mapY)[cell.y0 + py] * b.mask0Stride + (b.maskMap + L.mapX)[cell.x0 + px]] != 0;
+			const unsigned long long bal = __ballot(keep);
+			if (keep) slotsA[run + __popcll(bal & ((1ull << lane) - 1ull))] =
+				(uint32_t)(cell.x0 + px - kMinBorder) | ((uint32_t)(cell.y0 + py - kMinBorder) << 12) | (((inf >> 12) & 0xffu) << 24);
+			run += __popcll(bal);
+		};
+		// corner i as one word: code | score << 12 | has-left << 20 | has-above << 21
+		auto word = [&](int i) -> uint32_t {
+			if (i >= n) return 0u;
+			const int p = codes[i], py = p >> 6, px = p & 63;
+			const uint32_t s0 = sc[(py + 1) * kScPitch + px + 1];
+			return (uint32_t)p | (s0 << 12) | ((px > 0 ? bit(p - 1) : 0u) << 20) | ((py > 0 ? bit(p - 64) : 0u) << 21);
+		};
+		// The walk is wave-uniform (every lane executes the same statements on the same LDS words); only corners with a neighbour above or to the left do anything.
+		// A step is a chain of dependent LDS round trips, so it is kept short: the index of the corner above is worked out by the corner's own lane beforehand, a hop of
+		// the root chase fetches the link and the code of the same corner together (the code leads to the response if the hop was the last), and what the step itself
+		// has just written is carried in registers instead of being read back.  (Held in registers altogether — readlane / compare-select on uniform indices, for
+		// cells of up to 256 corners — the walk was slower: 1.05 against 0.94 ms for OAST_9_16 on the bench stream's images; the links as extra LDS arrays cost
+		// occupancy: 1.79 ms.)
+		auto respOf = [&](int q) { return (int)sc[((q >> 6) + 1) * kScPitch + (q & 63) + 1]; };
+		auto root = [&](int& w) {   // follows the links from w to its maximum; returns that corner's response
+			int f = flags[w], q = codes[w];
+			while (f != -1) { w = f; f = flags[w]; q = codes[w]; }
+			return respOf(q);
+		};
 		for (int base = 0; base < n; base += 64) {
-			const uint32_t inf = base + lane < n ? ag.info[base + lane] : 0u;
+			const uint32_t inf = word(base + lane);
+			const int ab = (inf >> 21) & 1u ? index((int)(inf & 0xfffu) - 64) : 0;
 			unsigned long long act = __ballot(((inf >> 20) & 3u) != 0u);
 			while (act) {
 				const int l = __builtin_ctzll(act);
@@ -497,46 +518,31 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 				const int cur = base + l;
 				const uint32_t ci = __builtin_amdgcn_readlane(inf, l);
 				const int cr = (int)((ci >> 12) & 0xffu);
+				int maxAbove = -1, respAbove = 0;   // nmsFlags[cur] after the check above, and that corner's response
 				if (ci & (1u << 21)) {   // check above: the maximum of the block the corner above belongs to
-					int w = ag.above[cur];
-					while (ag.flags[w] != -1) w = ag.flags[w];
-					if (cr < resp(w)) ag.flags[cur] = (short)w;
-					else ag.flags[w] = (short)cur;
+					int w = __builtin_amdgcn_readlane(ab, l);
+					const int rw = root(w);
+					if (cr < rw) { flags[cur] = (short)w; maxAbove = w; respAbove = rw; }
+					else flags[w] = (short)cur;
 				}
 				if (ci & (1u << 20)) {   // check left
 					int tl = cur - 1;
-					const int maxAbove = ag.flags[cur];
-					while (ag.flags[tl] != -1) tl = ag.flags[tl];
+					const int rt = root(tl);
 					if (maxAbove == -1) {   // no maximum above
 						if (tl != cur) {
-							if (cr < resp(tl)) ag.flags[cur] = (short)tl;
-							else ag.flags[tl] = (short)cur;
+							if (cr < rt) flags[cur] = (short)tl;
+							else flags[tl] = (short)cur;
 						}
 					} else if (tl != maxAbove) {   // maximum above
-						if (resp(maxAbove) < resp(tl)) { ag.flags[maxAbove] = (short)tl; ag.flags[cur] = (short)tl; }
-						else { ag.flags[tl] = (short)maxAbove; ag.flags[cur] = (short)maxAbove; }
+						if (respAbove < rt) { flags[maxAbove] = (short)tl; flags[cur] = (short)tl; }
+						else { flags[tl] = (short)maxAbove; flags[cur] = (short)maxAbove; }
 					}
 				}
 			}
 		}
-		// the maxima, in raster order, through the mirror mask (AgastFeatureDetector::detect: KeyPointsFilter::runByPixelsMask after the suppression)
-		uint32_t* slotsA = b.slots + (size_t)img * d.slotsPerImage + cell.slot;
-		const uint8_t* maskA = b.mask0 ? b.mask0 + (size_t)img * b.mask0Pitch : nullptr;
-		int run = 0;
 		for (int base = 0; base < n; base += 64) {
 			const int i = base + lane;
-			bool keep = false;
-			uint32_t rec = 0;
-			if (i < n) {
-				const uint32_t inf = ag.info[i];
-				const int px = inf & 63, py = (inf >> 6) & 63;
-				keep = ag.flags[i] == -1;
-				if (keep && maskA) keep = maskA[(size_t)(b.maskMap + L.mapY)[cell.y0 + py] * b.mask0Stride + (b.maskMap + L.mapX)[cell.x0 + px]] != 0;
-				rec = (uint32_t)(cell.x0 + px - kMinBorder) | ((uint32_t)(cell.y0 + py - kMinBorder) << 12) | (((inf >> 12) & 0xffu) << 24);
-			}
-			const unsigned long long bal = __ballot(keep);
-			if (keep) slotsA[run + __popcll(bal & ((1ull << lane) - 1ull))] = rec;
-			run += __popcll(bal);
+			emit(i < n && flags[i] == -1, word(i));
 		}
 		if (lane == 0) *countOut = run;
 		return;
