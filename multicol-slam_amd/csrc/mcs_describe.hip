@@ -35,6 +35,7 @@
 #include "mcs_orient.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace mcs {
@@ -586,6 +587,145 @@ __global__ __launch_bounds__(64) void k_describe_list(ExtractBuffers b, int wave
 	const int n = *count;
 	if (blockIdx.x == 0 && threadIdx.x == 0 && b.fbStats) atomicAdd(b.fbStats, (unsigned long long)n);
 	for (int i = blockIdx.x; i < n; i += gridDim.x) describe_wave<MODE, NB>(b, wavesPerImage, lds, (int)list[i]);
+}
+
+// The exact pass over a SHORT list, split for latency (round 5).  The fallback list holds a few keypoints per batch (one or two per multi-frame), and the pass
+// sits on the critical path between the fast pass and the matcher: one wave per keypoint is a chain of 2 * NB * npat = 24 evaluations of the omni model per
+// lane (38 us for ONE keypoint, whatever the list's length).  Here a WORKGROUP takes the keypoint: wave (pattern, part) evaluates 2 * NB / PARTS of its pattern's
+// point iterations into a coordinate buffer the workgroup shares, every wave then runs its pattern's sequential coordinate sum (the reference's order, redundantly in
+// the PARTS waves of a pattern), compares its own share of the pairs, and wave 0 joins the three patterns' bits.  Statement for statement the arithmetic of
+// describe_wave — same sincos, same shared reciprocal, same Horner, same sum order — so the bits are the same.
+template <int MODE, int NB> struct SplitGeom {
+	static constexpr int NPAT = MODE == 2 ? 3 : 1, PARTS = NB >= 4 ? 4 : 2, WAVES = NPAT * PARTS, TP = 2 * NB / PARTS, JP = NB / PARTS;
+	static constexpr int NP = 128 * NB, PD = pat_doubles(NP);
+	static constexpr size_t lds_bytes() { return (size_t)NPAT * PD * 8 + kPatchBytes + (size_t)NPAT * NB * 8 + (size_t)WAVES * 8; }
+};
+template <int MODE, int NB>
+__global__ __launch_bounds__((64 * SplitGeom<MODE, NB>::WAVES)) void k_describe_list_split(ExtractBuffers b, int wavesPerImage, const int* count, const uint32_t* list) {
+	typedef SplitGeom<MODE, NB> G;
+	constexpr int NP = G::NP, YO = NP + 2, PD = G::PD;
+	extern __shared__ __attribute__((aligned(16))) double lds[];
+	double* coords = lds;                                                                   // [pattern][x | y][NP]
+	uint8_t* patch = reinterpret_cast<uint8_t*>(lds) + (size_t)G::NPAT * PD * 8;          // one blurred patch, written (identically) by every wave
+	unsigned long long* xbits = reinterpret_cast<unsigned long long*>(patch + kPatchBytes); // [pattern][NB] the compare bits
+	double* xtie = reinterpret_cast<double*>(xbits + G::NPAT * NB);                        // [wave] closest approach to a rounding tie
+	__builtin_amdgcn_s_setprio(3);
+	const PyrDesc& d = *b.desc;
+	const int n = *count;
+	if (blockIdx.x == 0 && threadIdx.x == 0 && b.fbStats) atomicAdd(b.fbStats, (unsigned long long)n);
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int pat = wave / G::PARTS, part = wave - pat * G::PARTS;
+	for (int i = blockIdx.x; i < n; i += gridDim.x) {
+		const int gw = (int)list[i];
+		KeyPt kp_;
+		const bool ok = kp_prologue<true>(b, wavesPerImage, gw, patch, kp_);   // the same for every wave of the workgroup
+		double* cur = coords + pat * PD;
+		if (ok) {
+			const OcamDev& cam = b.cams[kp_.img];
+			double cP[MCS_MAX_POLY];
+#pragma unroll
+			for (int k = 0; k < MCS_MAX_POLY; ++k) cP[k] = uniform_f64(&cam.invP[k]);
+			const int cDeg = __builtin_amdgcn_readfirstlane(cam.invP_deg);
+			const double cC = uniform_f64(&cam.c), cD = uniform_f64(&cam.d), cE = uniform_f64(&cam.e), cU0 = uniform_f64(&cam.u0), cV0 = uniform_f64(&cam.v0);
+			auto w2i = [&](double x, double y, double z, double& u, double& v) {   // describe_wave's, verbatim
+				double norm = sqrt(x * x + y * y);
+				if (norm == 0.0) norm = 1e-14;
+				const double rn = recip_refined(norm);
+				auto over_norm = [&](double a) { return div_shared(a, norm, rn); };
+				const double theta = atan(over_norm(-z));
+				double rho = 0.0;
+				if (cDeg == 12) {
+#pragma unroll
+					for (int k = 11; k >= 0; --k) rho = rho * theta + cP[k];
+				} else {
+#pragma unroll
+					for (int k = MCS_MAX_POLY - 1; k >= 0; --k) rho = rho * theta + cP[k];
+				}
+				const double uu = over_norm(x) * rho;
+				const double vv = over_norm(y) * rho;
+				u = uu * cC + vv * cD + cU0;
+				v = uu * cE + vv + cV0;
+			};
+			const double zc = -cam.p[0];
+			double ukx = 0.0, uky = 0.0;
+			if (d.undistort) {
+				const double p0 = uniform_f64(&cam.p[0]);
+				ukx = -kp_.rayx / kp_.rayz * p0;
+				uky = -kp_.rayy / kp_.rayz * p0;
+			}
+			double ang;
+			if (MODE == 1) {
+				const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
+				ang = (double)(kp_.angle * DEG2RADf);
+			} else {
+				const float RHOf = 180.0f / 3.1415926535897932384626f;
+				const double RHOd = 180.0 / 3.1415926535897932384626433832795028841971693993;
+				const double rot = 20.0 / RHOd;
+				const double ang0 = (double)(kp_.angle / RHOf);
+				ang = pat == 0 ? ang0 : (pat == 1 ? ang0 + rot : ang0 - rot);
+			}
+			double ax, ay;
+			sincos(ang, &ay, &ax);
+#pragma unroll
+			for (int tt = 0; tt < G::TP; ++tt) {
+				const int t = part * G::TP + tt;
+				const int k = (t >> 1) * 64 + lane, e = t & 1;
+				const uint32_t pp = reinterpret_cast<const uint32_t*>(c_pattern)[k];
+				const double ptx = (double)(int)(signed char)(pp >> (16 * e)), pty = (double)(int)(signed char)(pp >> (16 * e + 8));
+				const double xr = ptx * ax - pty * ay + ukx;
+				const double yr = ptx * ay + pty * ax + uky;
+				double u, v;
+				w2i(xr, yr, zc, u, v);
+				cur[2 * k + e] = u; cur[YO + 2 * k + e] = v;
+			}
+		}
+		__syncthreads();
+		if (ok) {
+			double sum = 0.0;
+			const double* arr = cur + (lane & 1) * YO;   // even lanes sum(x), odd lanes sum(y), p = 0 .. NP-1 in the reference's order (:264-276)
+#pragma unroll 16
+			for (int p = 0; p < NP; ++p) sum += arr[p];
+			const double mean = sum / (double)NP;
+			const double meanX = __shfl(mean, 0), meanY = __shfl(mean, 1);
+			double tie = 0.0;
+#pragma unroll
+			for (int jj = 0; jj < G::JP; ++jj) {
+				const int j = part * G::JP + jj;
+				const int k = j * 64 + lane;
+				const double fx0 = cur[2 * k] - meanX, fy0 = cur[YO + 2 * k] - meanY, fx1 = cur[2 * k + 1] - meanX, fy1 = cur[YO + 2 * k + 1] - meanY;
+				const int ix0 = __double2int_rn(fx0), iy0 = __double2int_rn(fy0);
+				const int ix1 = __double2int_rn(fx1), iy1 = __double2int_rn(fy1);
+				tie = fmax(fmax(tie, fmax(tie_frac(fx0), tie_frac(fy0))), fmax(tie_frac(fx1), tie_frac(fy1)));
+				int t0, t1;
+				kp_.sm.pair(kp_.row, kp_.col, iy0, ix0, iy1, ix1, t0, t1);
+				const unsigned long long bits = __ballot(t0 < t1);
+				if (lane == 0) xbits[pat * NB + j] = bits;
+			}
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) tie = fmax(tie, __shfl_xor(tie, o));
+			if (lane == 0) xtie[wave] = tie;
+		}
+		__syncthreads();
+		if (ok && wave == 0) {
+			if (lane == 0) {
+				uint8_t* dout = b.out_desc + ((size_t)kp_.img * b.outImgPitch + kp_.out) * b.outRowStride;
+				uint8_t* mout = b.out_mask + ((size_t)kp_.img * b.outImgPitch + kp_.out) * b.outRowStride;
+#pragma unroll
+				for (int j = 0; j < NB; ++j) {
+					const unsigned long long m = xbits[j];
+					unsigned long long agree = 0ull;
+					if (MODE == 2) agree = ~((xbits[NB + j] ^ m) | (xbits[2 * NB + j] ^ m));   // both +-20 degree tests agree with the main test (:468-475)
+					*reinterpret_cast<unsigned long long*>(dout + 8 * j) = m;
+					*reinterpret_cast<unsigned long long*>(mout + 8 * j) = agree;
+				}
+			}
+			double tie = 0.0;
+#pragma unroll
+			for (int w = 0; w < G::WAVES; ++w) tie = fmax(tie, xtie[w]);
+			tie_commit(b, gw, tie);
+		}
+		__syncthreads();   // the next keypoint's prologue rewrites the patch and the coordinates
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
@@ -1464,7 +1604,11 @@ static void launch_fast_passes(const ExtractBuffers& b, int nimg, int wavesPerIm
 	// devices from several threads (host/rig_host.cpp), so it is set before every launch (as launch_spec in mcs_greedy.hip does), not once per process
 	if (fLds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_describe_fast<MODE, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fLds);
 	hipLaunchKernelGGL((k_describe_fast<MODE, NB>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage, nslots, groupsPerBlock);
-	hipLaunchKernelGGL((k_describe_list<MODE, NB>), dim3(lblocks), dim3(64), listLds, s, b, wavesPerImage, b.fbCount, b.fbList);
+	// the fallbacks — a few keypoints on the critical path — by a workgroup each (k_describe_list_split); MCS_LIST_SPLIT=0: one wave each, for A/B
+	static const bool split = !(getenv("MCS_LIST_SPLIT") && atoi(getenv("MCS_LIST_SPLIT")) == 0);
+	typedef SplitGeom<MODE, NB> SG;
+	if (split) hipLaunchKernelGGL((k_describe_list_split<MODE, NB>), dim3(std::min(nslots, 512)), dim3(64 * SG::WAVES), SG::lds_bytes(), s, b, wavesPerImage, b.fbCount, b.fbList);
+	else hipLaunchKernelGGL((k_describe_list<MODE, NB>), dim3(lblocks), dim3(64), listLds, s, b, wavesPerImage, b.fbCount, b.fbList);
 	if (b.sideStream) (void)hipStreamWaitEvent(s, b.evDescJoin, 0);
 }
 
