@@ -454,13 +454,19 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 		const double wd = (maxBX - minB), ht = (maxBY - minB);
 		L.nCols = (int)(wd / (double)kCellW);
 		L.nRows = (int)(ht / (double)kCellW);
-		if (L.nCols < 1 || L.nRows < 1 || L.w - 2 * kMinBorder >= 4096 || L.h - 2 * kMinBorder >= 4096) {
+		if (wd < 1 || ht < 1 || (l == 0 && (L.nCols < 1 || L.nRows < 1)) || L.w - 2 * kMinBorder >= 4096 || L.h - 2 * kMinBorder >= 4096) {
 			delete e;
-			return fail(MCS_ERR_UNSUPPORTED, "image too small for the requested number of levels (a level has no 30-px FAST cell) or too large");
+			return fail(MCS_ERR_UNSUPPORTED, "image too small for the requested number of levels (a level is narrower than its 44-px border, or level 0 has no 30-px FAST cell) or too large");
 		}
-		L.wCell = (int)ceil(wd / L.nCols);
-		L.hCell = (int)ceil(ht / L.nRows);
-		L.capc = p->useAgast ? ((L.wCell + 6 - 2 * detB) * (L.hCell + 6 - 2 * detB) + 1) / 2 : ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
+		// A level whose inner region is less than one 30-px cell high or wide: the reference's cell loops do not run (nRows or nCols = 0, :886-887), the oct-tree gets no
+		// keys and the level contributes nothing — an EMPTY level here (no cells, no slots); everything else about it (resize, blur, the feature budget) stays
+		const bool emptyLevel = L.nCols < 1 || L.nRows < 1;
+		if (emptyLevel) { L.nCols = L.nRows = 0; L.wCell = L.hCell = 0; L.capc = 0; }
+		else {
+			L.wCell = (int)ceil(wd / L.nCols);
+			L.hCell = (int)ceil(ht / L.nRows);
+			L.capc = p->useAgast ? ((L.wCell + 6 - 2 * detB) * (L.hCell + 6 - 2 * detB) + 1) / 2 : ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
+		}
 		L.cellBase = cellBase; L.slotBase = slotBase;
 		for (int i = 0; i < L.nRows; i++)
 			for (int j = 0; j < L.nCols; j++) {

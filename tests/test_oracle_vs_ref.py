@@ -21,21 +21,21 @@ REF_SO = os.path.join(ROOT, "oracle", "_ref", "libmcs_ref.so")
 have_ref = pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (needs the reference checkout)")
 
 
-def oracle_case(frame, ci, w, h, nf, sf, nl, th, db, lm, ds, um):
+def oracle_case(frame, ci, w, h, nf, sf, nl, th, db, lm, ds, um, ft=2, ag=0):
     import gen_golden_ref as GG
     cam, img, mask = GG.case_inputs(frame, ci, w, h, um)
-    k, d, m = O.Extractor(nfeatures=nf, scaleFactor=sf, nlevels=nl, fastThreshold=th, do_dBrief=db, learnMasks=lm, descSize=ds)(img, mask, O.make_ocam(cam))
+    k, d, m = O.Extractor(nfeatures=nf, scaleFactor=sf, nlevels=nl, fastThreshold=th, do_dBrief=db, learnMasks=lm, descSize=ds, fastAgastType=ft, useAgast=ag)(img, mask, O.make_ocam(cam))
     return k, d, m
 
 
 def test_oracle_reproduces_reference_golden_vectors():
     import gen_golden_ref as GG
     g = np.load(os.path.join(ROOT, "tests", "golden", "ref_extract.npz"))
-    for case in GG.CASES:
+    for case in GG.CASES + GG.CASES_DET:   # CASES_DET: the small FAST rings and the four AGAST types
         name = case[0]
         k, d, m = oracle_case(*case[1:])
         gk, gd, gm = g[name + "_kps"], g[name + "_desc"], g[name + "_mask"]
-        assert len(k) == len(gk) and len(gk) > 100, name
+        assert len(k) == len(gk) and len(gk) > (30 if name.startswith("fast5_8") else 100), name   # (the 8-pixel FAST ring needs the whole ring darker or brighter: few corners)
         for f in k.dtype.names:
             assert np.array_equal(k[f], gk[f]), (name, f)
         assert np.array_equal(d, gd) and np.array_equal(m, gm), name
@@ -236,3 +236,14 @@ def test_epipolar_check_and_median_equal_reference_code():
         dist = np.unpackbits(d[:, None, :] ^ d[None, :, :], axis=2).sum(2)
         med = [sorted(dist[i, i + 1:].tolist())[(n - 1 - i) // 2] for i in range(n - 1)]
         assert O.distinctive_descriptor(d, None) == int(np.argmin(med))
+
+
+@have_ref
+def test_gpu_golden_test_restates_the_generators_case_tables():
+    """tests/test_gpu_golden.py cannot import the generator on the GPU box (it loads the reference library): its copy of the case tables must be the generator's"""
+    import gen_golden_ref as GG
+    src = open(os.path.join(ROOT, "tests", "test_gpu_golden.py")).read()
+    ns = {}
+    exec("cases =" + src[src.index("cases = [") + 7:src.index("    assert sorted")], ns)
+    want = [tuple(t[:12]) + (2, 0) for t in GG.CASES] + [tuple(t[:12]) + tuple(t[13:]) for t in GG.CASES_DET]
+    assert ns["cases"] == want

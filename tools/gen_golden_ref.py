@@ -19,6 +19,17 @@ CASES = [  # (name, frame, cam, width, height, nfeatures, scale, nlevels, fastTh
     ("mdbrief16_fast12_333x251", 3, 0, 333, 251, 250, 1.2, 6, 12, 1, 1, 16, 1),
     ("mdbrief64_scale11_400x300", 4, 1, 400, 300, 400, 1.1, 10, 20, 1, 1, 64, 1),
 ]
+# detector options (extractor.useAgast / extractor.fastAgastType, reference src/mdBRIEFextractorOct.cpp:869-872, 912-917): the same tuple + (fastAgastType, useAgast).
+# The detectors themselves are OpenCV's (restated in oracle/, forwarded by oracle/cvshim); what the reference's code contributes to these vectors is the cell loop
+# with its overlapping views, the oct-tree over corners reported twice, and everything downstream.
+CASES_DET = [
+    ("fast7_12_376x240", 0, 1, 376, 240, 300, 1.2, 8, 8, 1, 1, 32, 1, 1, 0),
+    ("fast5_8_376x240", 1, 2, 376, 240, 300, 1.2, 8, 4, 0, 0, 32, 1, 0, 0),
+    ("agast5_8_376x240", 2, 0, 376, 240, 300, 1.2, 8, 20, 1, 1, 32, 1, 0, 1),
+    ("agast7_12d_376x240", 3, 1, 376, 240, 300, 1.2, 8, 20, 0, 0, 32, 1, 1, 1),
+    ("agast7_12s_376x240", 4, 2, 376, 240, 300, 1.2, 8, 20, 1, 1, 32, 1, 2, 1),
+    ("oast9_16_333x251", 5, 0, 333, 251, 250, 1.2, 6, 12, 1, 0, 32, 1, 3, 1),
+]
 
 
 def case_inputs(frame, cam_idx, w, h, use_mask):
@@ -33,6 +44,11 @@ if __name__ == "__main__":
     for name, frame, ci, w, h, nf, sf, nl, th, db, lm, ds, um in CASES:
         cam, img, mask = case_inputs(frame, ci, w, h, um)
         k, d, m = R.run_ref(img, mask, cam, nfeatures=nf, scaleFactor=sf, nlevels=nl, fastThreshold=th, do_dBrief=db, learnMasks=lm, descSize=ds)
+        out[name + "_kps"], out[name + "_desc"], out[name + "_mask"] = k, d, m
+        print(name, len(k), "keypoints")
+    for name, frame, ci, w, h, nf, sf, nl, th, db, lm, ds, um, ft, ag in CASES_DET:
+        cam, img, mask = case_inputs(frame, ci, w, h, um)
+        k, d, m = R.run_ref(img, mask, cam, nfeatures=nf, scaleFactor=sf, nlevels=nl, fastThreshold=th, do_dBrief=db, learnMasks=lm, descSize=ds, fastAgastType=ft, useAgast=ag)
         out[name + "_kps"], out[name + "_desc"], out[name + "_mask"] = k, d, m
         print(name, len(k), "keypoints")
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_extract.npz"), **out)
