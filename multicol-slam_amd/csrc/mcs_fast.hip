@@ -108,7 +108,7 @@ __device__ __forceinline__ int small_ring_score(const uint8_t* c, int t) {
 	return corner ? max(A, -Bn) - 1 : 0;
 }
 
-// ---- AGAST: the plain segment test on the type's ring (cv::AgastFeatureDetector; the restatement is oracle/mcs_oracle.cpp orc_agast_type) ----------------
+// ---- AGAST: the plain segment test on the type's ring (cv::AgastFeatureDetector; what OpenCV 3.x computes is written out in DESIGN.md section 7) ----------------
 // type 0 AGAST_5_8: the 8 neighbours, 5 contiguous; 1 AGAST_7_12d: the 12-pixel diamond of radius 3, 7 contiguous; 2 AGAST_7_12s: the 12-pixel square of radius 2
 // (= FAST's 12 ring), 7 contiguous; 3 OAST_9_16: the 16-pixel circle, 9 contiguous (scored by fast_score2).  Border of the scan = the radius.
 template <int AG> struct AgastGeom { static constexpr int P = AG == 0 ? 8 : (AG == 3 ? 16 : 12), N = P / 2 + 1, R = AG == 0 ? 1 : (AG == 2 ? 2 : 3); };
