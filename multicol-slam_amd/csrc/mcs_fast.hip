@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	typedef FastGeom<CW> Geo;
 	constexpr int kTilePitch = Geo::kTilePitch, kTileRows = Geo::kTileRows, kScPitch = Geo::kScPitch, kScRows = Geo::kScRows;
 	// (AGAST: after the scores are in `sc` the tile is dead and holds the corners' codes in raster order, two bytes per pixel of the cell at most; the links of the
-	// suppression walk, when they do not fit registers, take the place of `surv`)
+	// suppression walk take the place of `surv`)
 	constexpr int kTileBytes = (AG >= 0 && 2 * CW * CW > kTileRows * kTilePitch) ? 2 * CW * CW : kTileRows * kTilePitch;
 	__shared__ __attribute__((aligned(16))) uint8_t tile[kTileBytes];
 	__shared__ __attribute__((aligned(16))) uint8_t sc[kScRows * kScPitch];
