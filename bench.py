@@ -1069,7 +1069,8 @@ def run_latency(e, sp, calls=300, py_calls=200):
     host = os.path.join(ROOT, "multicol-slam_amd", "host", "frame_latency")
     ok = None
     if os.path.exists(host):
-        d = tempfile.mkdtemp(prefix="mcs_latency_")
+        d = os.environ.get("MCS_KEEP_LATENCY_DIR") or tempfile.mkdtemp(prefix="mcs_latency_")   # (kept when named: tools/latency_trace.sh reruns the program under the profiler)
+        os.makedirs(d, exist_ok=True)
         np.stack([imgs[c][f] for c in range(NCAM) for f in range(frames)]).tofile(d + "/images.bin")
         np.stack(masks).tofile(d + "/masks.bin")
         open(d + "/cams.bin", "wb").write(bytes((mcs.Ocam * NCAM)(*[mcs.make_ocam(cams[c]) for c in range(NCAM)])))
@@ -1105,7 +1106,8 @@ def run_latency(e, sp, calls=300, py_calls=200):
                   and all(np.array_equal(dsc[c * cap:c * cap + nkp[c]], D1[c * cap:c * cap + nkp[c]]) and np.array_equal(msk[c * cap:c * cap + nkp[c]], M1[c * cap:c * cap + nkp[c]]) for c in range(NCAM))
                   and n == nat["matches_last"] and np.array_equal(match, m12))
             nat["oracle_check"] = bool(ok)
-            nat["what"] = "native C++ host (multicol-slam_amd/host/frame_latency.cpp): page-locked staging, %d timed calls after 20 warm-up calls, steady clock around each call" % calls
+            nat["what"] = ("native C++ host (multicol-slam_amd/host/frame_latency.cpp): page-locked staging and result arrays (the library writes the valid rows into them with one launch), the rig's mirror "
+                           "masks resident on the device (mcs_extractor_set_masks), the launch sequence replayed from a hipGraph; %d timed calls after 20 warm-up calls, steady clock around each call" % calls)
             out["native"] = nat
             out["median_ms"], out["p99_ms"] = nat["total_ms"]["median"], nat["total_ms"]["p99"]
             out["features_per_call"] = nat["features_last"]

@@ -35,7 +35,7 @@ extern "C" {
  * since round 2 — callers built against an older header must be recompiled; mcs_describe_fast_table, FAST types 0 / 1 in round 3; 4: mcs_extractor_tie_stats; 5: mcs_copy_narrow,
  * mcs_ctx_result_stream, mcs_ctx_stream_conflicts, mcs_ctx_transfer_stream in round 4).  mcs_abi_version() returns
  * the value the LIBRARY was built with: compare it with MCS_ABI_VERSION after dlopen. */
-#define MCS_ABI_VERSION 6
+#define MCS_ABI_VERSION 7
 
 #define MCS_MAX_POLY 16
 #define MCS_MAX_LEVELS 16
@@ -111,6 +111,13 @@ int mcs_extractor_levels(const mcs_extractor*, int* nlevels, int* widths, int* h
  * With kind == DEVICE the call only enqueues work on the context's stream (no host synchronisation).
  * DEVICE-kind desc / descmask pointers (and out_row_stride of the strided form) must be 8-byte aligned: a descriptor leaves the kernel as 64-bit words
  * (the reference's matcher reads its rows as const uint64_t* too, src/cMultiKeyFrame.cpp:356-364); MCS_ERR_INVALID otherwise.                          */
+/* Mirror masks that do not change from frame to frame (the reference builds them once per camera: cCamModelGeneral_::CreateMirrorMask, src/cam_model_omni.cpp) can be
+ * left on the device: mcs_extractor_set_masks copies nimg masks (same layout rules as above; synchronous), after which MCS_MASKS_RESIDENT as the `masks` argument of
+ * mcs_extract_batch / _strided means "mask i of that set for image i" — for ONE multi-frame per call the mask upload is a tenth of the extraction's latency.
+ * Host-kind outputs: when nkp / keypoints / desc / descmask (/ rays) are page-locked (mcs_host_alloc), the call writes the VALID rows (k < nkp[i]) straight into
+ * them with one launch instead of five copies; rows past an image's count are then left as they were.                                                      */
+#define MCS_MASKS_RESIDENT ((const uint8_t*)(uintptr_t)1)
+int mcs_extractor_set_masks(mcs_extractor*, int nimg, const uint8_t* masks, size_t mask_pitch, int mask_stride, mcs_mem_kind kind);
 int mcs_extract_batch(mcs_extractor*, int nimg, const uint8_t* images, size_t image_pitch, int image_stride,
                       const uint8_t* masks, size_t mask_pitch, int mask_stride, const mcs_ocam* cams, mcs_mem_kind kind,
                       int32_t* nkp, mcs_keypoint* keypoints, uint8_t* desc, uint8_t* descmask, double* rays);

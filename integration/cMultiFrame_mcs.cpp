@@ -177,6 +177,7 @@ cMultiFrame::cMultiFrame(const std::vector<cv::Mat>& images_, const double& time
 			r.maskSeen.assign(nrCams, nullptr);
 		}
 		const size_t plane = (size_t)w * h;
+		bool masksChanged = false;
 		for (int c = 0; c < nrCams; ++c)   // rows of a cv::Mat may be padded (step): copy row by row unless it is continuous
 		{
 			uint8_t* dst = r.pin + c * plane;
@@ -188,13 +189,16 @@ cMultiFrame::cMultiFrame(const std::vector<cv::Mat>& images_, const double& time
 				if (masks[c].isContinuous()) std::memcpy(md, masks[c].data, plane);
 				else for (int y = 0; y < h; ++y) std::memcpy(md + (size_t)y * w, masks[c].ptr<uchar>(y), w);
 				r.maskSeen[c] = masks[c].data;
+				masksChanged = true;
 			}
 		}
+		// the mirror masks are per-camera constants: they stay on the device and travel again only when one of them changes
+		if (masksChanged) mcs_dropin::check(mcs_extractor_set_masks(r.ex, nrCams, r.pin + r.offMask, plane, w, MCS_MEM_HOST), "mcs_extractor_set_masks");
 		int32_t* n = (int32_t*)(r.pin + r.offN);
 		mcs_keypoint* kps = (mcs_keypoint*)(r.pin + r.offKp);
 		uint8_t* desc = r.pin + r.offDesc; uint8_t* dmask = r.pin + r.offDmask;
 		double* rays = (double*)(r.pin + r.offRays);
-		mcs_dropin::check(mcs_extract_batch(r.ex, nrCams, r.pin, plane, w, r.pin + r.offMask, plane, w, cams.data(), MCS_MEM_HOST, n, kps, desc, dmask, rays),
+		mcs_dropin::check(mcs_extract_batch(r.ex, nrCams, r.pin, plane, w, MCS_MASKS_RESIDENT, plane, w, cams.data(), MCS_MEM_HOST, n, kps, desc, dmask, rays),
 			"mcs_extract_batch");
 		for (int c = 0; c < nrCams; ++c)
 		{

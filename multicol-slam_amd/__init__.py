@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (KP_DTYPE, MEM_DEVICE, MEM_HOST, DescSet, ExtractorParams, McsError, Ocam, check, lib, make_ocam, np_ptr)
+from ._capi import (KP_DTYPE, MASKS_RESIDENT, MEM_DEVICE, MEM_HOST, DescSet, ExtractorParams, McsError, Ocam, check, lib, make_ocam, np_ptr)
 
 __all__ = ["Context", "Extractor", "McsError", "KP_DTYPE", "make_ocam", "ExtractorParams", "MEM_HOST", "MEM_DEVICE"]
 
@@ -105,12 +105,23 @@ class Extractor:
         except Exception:
             pass
 
+    def set_masks(self, masks):
+        """keep the (mirror) masks on the device: afterwards masks="resident" in extract_host means mask i of this set for image i (mcs_extractor_set_masks)"""
+        m = np.ascontiguousarray(np.stack(masks), np.uint8)
+        n, h, w = m.shape
+        assert (w, h) == (self.width, self.height)
+        check(lib().mcs_extractor_set_masks(self.h, n, np_ptr(m), w * h, w, MEM_HOST))
+
     def extract_host(self, images, masks, cams, want_rays=True):
-        """images: list/array of HxW uint8; masks: same or None; cams: list of Ocam or None.  Returns per-image tuples."""
+        """images: list/array of HxW uint8; masks: same, None, or "resident" (set_masks); cams: list of Ocam or None.  Returns per-image tuples."""
         imgs = np.ascontiguousarray(np.stack(images), np.uint8)
         n, h, w = imgs.shape
         assert (w, h) == (self.width, self.height)
-        m = None if masks is None else np.ascontiguousarray(np.stack(masks), np.uint8)
+        if isinstance(masks, str):
+            assert masks == "resident"
+            m = MASKS_RESIDENT
+        else:
+            m = None if masks is None else np.ascontiguousarray(np.stack(masks), np.uint8)
         camarr = None
         if cams is not None:
             camarr = (Ocam * n)(*cams)
@@ -119,7 +130,7 @@ class Extractor:
         desc = np.zeros((n, self.cap, self.descSize), np.uint8)
         dmask = np.zeros((n, self.cap, self.descSize), np.uint8)
         rays = np.zeros((n, self.cap, 3), np.float64) if (want_rays and cams is not None) else None
-        check(lib().mcs_extract_batch(self.h, n, np_ptr(imgs), w * h, w, np_ptr(m), w * h, w, camarr, MEM_HOST, np_ptr(nkp), np_ptr(kps),
+        check(lib().mcs_extract_batch(self.h, n, np_ptr(imgs), w * h, w, m if isinstance(m, C.c_void_p) else np_ptr(m), w * h, w, camarr, MEM_HOST, np_ptr(nkp), np_ptr(kps),
                                       np_ptr(desc), np_ptr(dmask), np_ptr(rays)))
         out = []
         for i in range(n):

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("MCS_HIP_LIB", os.path.join(_HERE, "libmcs_hip.so"))  
 
 MCS_OK, MCS_ERR_INVALID, MCS_ERR_HIP, MCS_ERR_CAPACITY, MCS_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 MEM_HOST, MEM_DEVICE = 0, 1
+MASKS_RESIDENT = C.c_void_p(1)   # MCS_MASKS_RESIDENT of include/mcs_c.h
 MAX_POLY = 16
 
 
@@ -64,7 +65,7 @@ def make_ocam(cam):
 
 EXPORTS = [
     "mcs_last_error", "mcs_abi_version", "mcs_device_count", "mcs_ctx_create", "mcs_ctx_destroy", "mcs_ctx_synchronize", "mcs_extractor_create",
-    "mcs_extractor_destroy", "mcs_extractor_kp_capacity", "mcs_extractor_levels", "mcs_extract_batch", "mcs_extractor_status",
+    "mcs_extractor_destroy", "mcs_extractor_set_masks", "mcs_extractor_kp_capacity", "mcs_extractor_levels", "mcs_extract_batch", "mcs_extractor_status",
     "mcs_extractor_tap_level", "mcs_extractor_tap_candidates", "mcs_extractor_tap_selected", "mcs_match_topk",
     "mcs_match_topk_batched", "mcs_descriptor_distance", "mcs_descriptor_distance_masked", "mcs_ctx_enable_timing",
     "mcs_ctx_kernel_ms", "mcs_ctx_join", "mcs_ctx_set_async_search", "mcs_ctx_search_fence", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_search_kf_f_sweep",
@@ -123,6 +124,7 @@ def lib():
     L.mcs_extractor_describe_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     L.mcs_extractor_tie_stats.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
     L.mcs_extractor_set_tie_band.argtypes = [vp, C.c_double]
+    L.mcs_extractor_set_masks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     L.mcs_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.mcs_host_free.argtypes = [vp, vp]
     L.mcs_extractor_fix_ties.argtypes = [vp, C.POINTER(C.c_int)]

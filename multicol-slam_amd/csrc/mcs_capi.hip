@@ -247,6 +247,12 @@ struct mcs_extractor {
 	int* d_nkp = nullptr; mcs_keypoint* d_kps = nullptr; uint8_t *d_odesc = nullptr, *d_omask = nullptr; double* d_rays = nullptr;
 	ExtractBuffers last{};
 	int lastN = 0;
+	// mirror masks kept on the device (mcs_extractor_set_masks): tight rows, one after the other
+	uint8_t* d_resMask = nullptr; int resMaskN = 0;
+	int* h_status = nullptr;   // page-locked: device status + tie count of a host-kind batch, written by k_extract_out
+	// hipGraphs of the in-order launch sequence (small batches, extract_impl): keyed by the kernels' arguments
+	struct Graph { ExtractBuffers key; int nimg; hipGraphExec_t exec; };
+	std::vector<Graph> graphs;
 };
 
 extern "C" {
@@ -599,6 +605,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	ALLOC(e->d_cams, B * sizeof(OcamDev));
 	const size_t slotsPerImage = (size_t)(hd.kpCap + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
 	ALLOC(e->d_fbCount, 3 * sizeof(int));   // [0] fallback list, [1] pre-list, [2] tie list
+	if (hipHostMalloc((void**)&e->h_status, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); e->h_status = nullptr; }   // (without it host-kind outputs take the runtime's copies)
 	ALLOC(e->d_tieList, B * slotsPerImage * sizeof(uint32_t));
 	ALLOC(e->d_fbList, B * slotsPerImage * sizeof(uint32_t));
 	ALLOC(e->d_preList, B * slotsPerImage * sizeof(uint32_t));
@@ -640,6 +647,9 @@ int mcs_extractor_destroy(mcs_extractor* e) {
 	                e->d_sel, e->d_cellCount, e->d_denseCount, e->d_selCount, e->d_status, e->d_cams, e->d_nkp, e->d_kps, e->d_odesc,
 	                e->d_omask, e->d_rays, e->d_inImg, e->d_inMask, e->d_fbCount, e->d_fbList, e->d_preList, e->d_fbStats, e->d_tieMin, e->d_aux, e->d_gTab, e->d_selAngle, e->d_tieList};
 	for (void* p : ptrs) (void)hipFree(p);
+	for (mcs_extractor::Graph& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
+	(void)hipFree(e->d_resMask);
+	if (e->h_status) (void)hipHostFree(e->h_status);
 	delete e;
 	return MCS_OK;
 }
@@ -722,12 +732,46 @@ static int fix_ties(mcs_extractor* e, int nties, uint8_t* h_desc, uint8_t* h_mas
 	return MCS_OK;
 }
 
+namespace mcs {
+// Host-kind outputs in ONE launch: when the caller's output arrays are page-locked (mcs_host_alloc / hipHostMalloc: visible to the device), the valid rows of the
+// five staging arrays, the counts and the batch's status words are written straight into them.  The five hipMemcpyAsync calls this replaces cost ~15 us each for
+// ONE multi-frame (7 us of transfer, 8 of runtime per call), plus two more for the status words: a third of the extraction's latency.
+struct ExtractOut { int32_t* nkp; uint32_t* kps; uint32_t* desc; uint32_t* mask; uint32_t* rays; int* status; };
+__global__ __launch_bounds__(256) void k_extract_out(const int* __restrict__ d_nkp, const uint32_t* __restrict__ kps, const uint32_t* __restrict__ desc, const uint32_t* __restrict__ mask,
+                                                     const uint32_t* __restrict__ rays, const int* __restrict__ d_status, const int* __restrict__ d_ties, ExtractOut o, int kpCap, int descDw) {
+	const int img = blockIdx.y, n = d_nkp[img], part = blockIdx.x, parts = gridDim.x;
+	auto copy = [&](uint32_t* dst, const uint32_t* src, int rowDw) {   // rows [0, n) of image img: one contiguous run of dwords
+		const size_t base = (size_t)img * kpCap * rowDw;
+		const int total = n * rowDw;
+		for (int i = part * 256 + threadIdx.x; i < total; i += parts * 256) dst[base + i] = src[base + i];
+	};
+	copy(o.kps, kps, (int)(sizeof(mcs_keypoint) / 4));
+	copy(o.desc, desc, descDw);
+	copy(o.mask, mask, descDw);
+	if (o.rays) copy(o.rays, rays, 6);
+	if (part == 0 && threadIdx.x == 0) {
+		o.nkp[img] = n;
+		if (img == 0) { o.status[0] = *d_status; o.status[1] = *d_ties; }
+	}
+}
+}  // namespace mcs
+
+static bool use_graphs() {   // MCS_GRAPHS=0: every launch of a small batch enqueued one by one (A/B, tests)
+	static const bool on = !(getenv("MCS_GRAPHS") && atoi(getenv("MCS_GRAPHS")) == 0);
+	return on;
+}
+
 static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_t image_pitch, int image_stride, const uint8_t* masks,
                         size_t mask_pitch, int mask_stride, const mcs_ocam* cams, mcs_mem_kind kind, int32_t* nkp, mcs_keypoint* keypoints,
                         uint8_t* desc, uint8_t* descmask, double* rays, size_t out_image_pitch_rows, int out_row_stride) {
 	if (!e || !images || !nkp || !keypoints || !desc || !descmask) return fail(MCS_ERR_INVALID, "null argument");
 	if (nimg < 1 || nimg > e->maxBatch) return fail(MCS_ERR_INVALID, "nimg exceeds the extractor's max_batch");
 	const PyrDesc& hd = e->hd;
+	const bool resMask = masks == MCS_MASKS_RESIDENT;
+	if (resMask) {
+		if (!e->d_resMask || nimg > e->resMaskN) return fail(MCS_ERR_INVALID, "MCS_MASKS_RESIDENT: mcs_extractor_set_masks has not been called for this many images");
+		masks = e->d_resMask; mask_pitch = (size_t)hd.width * hd.height; mask_stride = hd.width;
+	}
 	if (image_stride < hd.width || (masks && mask_stride < hd.width)) return fail(MCS_ERR_INVALID, "stride smaller than the image width");
 	if (hd.mode != 0 && !cams) return fail(MCS_ERR_INVALID, "dBRIEF/mdBRIEF need camera models");
 	if (rays && !cams) return fail(MCS_ERR_INVALID, "rays need camera models");
@@ -771,7 +815,8 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		if (int r = grow(&e->d_inImg, &e->inImgCap, imgSpan)) return r;
 		HIPCHK(hipMemcpyAsync(e->d_inImg, images, imgSpan, hipMemcpyHostToDevice, s));
 		b.img0 = e->d_inImg; b.img0Pitch = image_pitch; b.img0Stride = image_stride;
-		if (masks) {
+		if (resMask) { b.mask0 = masks; b.mask0Pitch = mask_pitch; b.mask0Stride = mask_stride; }
+		else if (masks) {
 			const size_t maskSpan = (size_t)(nimg - 1) * mask_pitch + (size_t)(hd.height - 1) * mask_stride + hd.width;
 			if (int r = grow(&e->d_inMask, &e->inMaskCap, maskSpan)) return r;
 			HIPCHK(hipMemcpyAsync(e->d_inMask, masks, maskSpan, hipMemcpyHostToDevice, s));
@@ -877,6 +922,27 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		// beside FAST and the resize chain: measured, 2.22 -> 2.55 ms per step — the descriptor kernel on the critical path suffers more from the company)
 		launch_octree(b, hd, nimg, s);   // (oct-trees of levels 0 / 1 on a further stream beside FAST of the rest: measured, no gain)
 		HIPCHK(hipStreamWaitEvent(s, c->evBlur, 0));
+	} else if (!c->timing && use_graphs()) {
+		// ONE multi-frame per call is launch-bound: a dozen dependent kernels of 4 - 50 us each, most of them shorter than the host takes to enqueue the next.  The
+		// sequence is captured once per argument set into a hipGraph and replayed (the copies in and out stay ordinary stream operations around it).
+		hipGraphExec_t exec = nullptr;
+		for (mcs_extractor::Graph& g : e->graphs)
+			if (g.nimg == nimg && memcmp(&g.key, &b, sizeof(b)) == 0) exec = g.exec;
+		if (!exec) {
+			hipGraph_t graph = nullptr;
+			HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+			launch_pyramid(b, hd, nimg, s);
+			launch_fast(b, hd, nimg, s);
+			launch_octree(b, hd, nimg, s);
+			launch_blur(b, hd, nimg, s);
+			launch_describe(b, hd, nimg, s);
+			HIPCHK(hipStreamEndCapture(s, &graph));
+			HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+			(void)hipGraphDestroy(graph);
+			if (e->graphs.size() >= 4) { (void)hipStreamSynchronize(s); (void)hipGraphExecDestroy(e->graphs.front().exec); e->graphs.erase(e->graphs.begin()); }   // a caller that rotates output buffers: a few sets
+			e->graphs.push_back(mcs_extractor::Graph{b, nimg, exec});
+		}
+		HIPCHK(hipGraphLaunch(exec, s));
 	} else {
 		c->tic("pyramid"); launch_pyramid(b, hd, nimg, s); c->toc("pyramid");
 		c->tic("fast"); launch_fast(b, hd, nimg, s); c->toc("fast");
@@ -884,17 +950,31 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		c->tic("blur"); launch_blur(b, hd, nimg, s); c->toc("blur");
 	}
 	if (forked) { b.sideStream = c->side; b.evDescFork = c->evDescFork; b.evDescJoin = c->evDescJoin; }   // the side stream is idle again: the main stream has waited for the blur
-	c->tic("describe"); launch_describe(b, hd, nimg, s); c->toc("describe");
+	if (forked || c->timing || !use_graphs()) { c->tic("describe"); launch_describe(b, hd, nimg, s); c->toc("describe"); }
 	HIPCHK(hipGetLastError());
 	e->last = b; e->lastN = nimg;
 	if (kind == MCS_MEM_HOST) {
 		const size_t rows = (size_t)nimg * hd.kpCap;
+		int st = 0, nties = 0;
+		mcs::ExtractOut o{(int32_t*)device_view(nkp), (uint32_t*)device_view(keypoints), (uint32_t*)device_view(desc), (uint32_t*)device_view(descmask),
+		                  (uint32_t*)device_view(rays), e->h_status ? (int*)device_view(e->h_status) : nullptr};
+		static const bool outKernel = !(getenv("MCS_OUT_KERNEL") && atoi(getenv("MCS_OUT_KERNEL")) == 0);   // A/B, tests: 0 = always the runtime's copies
+		if (outKernel && o.nkp && o.kps && o.desc && o.mask && o.status && (o.rays || !rays)) {
+			// page-locked outputs: one launch writes the valid rows (rows past an image's count are left as they are), the counts and the status words
+			hipLaunchKernelGGL(mcs::k_extract_out, dim3(4, nimg), dim3(256), 0, s, e->d_nkp, (const uint32_t*)e->d_kps, (const uint32_t*)e->d_odesc, (const uint32_t*)e->d_omask,
+			                   (const uint32_t*)e->d_rays, e->d_status, e->d_fbCount + 2, o, hd.kpCap, hd.descSize / 4);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipStreamSynchronize(s));
+			st = e->h_status[0]; nties = e->h_status[1];
+			if (st != 0) { (void)hipMemset(e->d_status, 0, sizeof(int)); return fail(st, "device capacity exceeded during extraction"); }
+			if (nties > 0) { if (int r = fix_ties(e, nties, desc, descmask)) return r; }
+			return MCS_OK;
+		}
 		HIPCHK(hipMemcpyAsync(nkp, e->d_nkp, nimg * sizeof(int), hipMemcpyDeviceToHost, s));
 		HIPCHK(hipMemcpyAsync(keypoints, e->d_kps, rows * sizeof(mcs_keypoint), hipMemcpyDeviceToHost, s));
 		HIPCHK(hipMemcpyAsync(desc, e->d_odesc, rows * hd.descSize, hipMemcpyDeviceToHost, s));
 		HIPCHK(hipMemcpyAsync(descmask, e->d_omask, rows * hd.descSize, hipMemcpyDeviceToHost, s));
 		if (rays) HIPCHK(hipMemcpyAsync(rays, e->d_rays, rows * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-		int st = 0, nties = 0;
 		HIPCHK(hipMemcpyAsync(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
 		HIPCHK(hipMemcpyAsync(&nties, e->d_fbCount + 2, sizeof(int), hipMemcpyDeviceToHost, s));
 		HIPCHK(hipStreamSynchronize(s));
@@ -902,6 +982,21 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		// keypoints whose exact arithmetic came within the band of a rounding tie: recomputed here with the host's libm before the results are final
 		if (nties > 0) { if (int r = fix_ties(e, nties, desc, descmask)) return r; }
 	}
+	return MCS_OK;
+}
+
+int mcs_extractor_set_masks(mcs_extractor* e, int nimg, const uint8_t* masks, size_t mask_pitch, int mask_stride, mcs_mem_kind kind) {
+	if (!e || !masks || nimg < 1 || nimg > e->maxBatch) return fail(MCS_ERR_INVALID, "bad argument");
+	const PyrDesc& hd = e->hd;
+	if (mask_stride < hd.width) return fail(MCS_ERR_INVALID, "stride smaller than the image width");
+	HIPCHK(hipSetDevice(e->ctx->device));
+	HIPCHK(hipStreamSynchronize(e->ctx->stream));   // an earlier batch may still read the previous masks
+	const size_t plane = (size_t)hd.width * hd.height;
+	if (nimg > e->resMaskN) { (void)hipFree(e->d_resMask); e->d_resMask = nullptr; e->resMaskN = 0; HIPCHK(hipMalloc((void**)&e->d_resMask, plane * nimg)); }
+	for (int i = 0; i < nimg; ++i)
+		HIPCHK(hipMemcpy2D(e->d_resMask + (size_t)i * plane, hd.width, masks + (size_t)i * mask_pitch, mask_stride, hd.width, hd.height,
+		                   kind == MCS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
+	e->resMaskN = nimg;
 	return MCS_OK;
 }
 

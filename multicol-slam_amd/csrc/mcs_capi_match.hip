@@ -56,6 +56,19 @@ static int validate_sets(mcs_ctx* c, int nsets, const mcs_desc_set* q, const mcs
 	return MCS_OK;
 }
 
+namespace mcs {
+__global__ __launch_bounds__(256) void k_search_out(int* __restrict__ dm, const int* __restrict__ sm, size_t n, int* __restrict__ dn, const int* __restrict__ sn, int* __restrict__ df,
+                                                    const int* __restrict__ sf, int nsets) {
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dm[i] = sm[i];
+	if (blockIdx.x == 0)
+		for (int i = threadIdx.x; i < nsets; i += 256) { dn[i] = sn[i]; if (df) df[i] = sf[i]; }
+}
+}  // namespace mcs
+static void launch_search_out(int* dm, const int* sm, size_t n, int* dn, const int* sn, int* df, const int* sf, int nsets, hipStream_t s) {
+	const int blocks = (int)std::min<size_t>(std::max<size_t>((n + 1023) / 1024, 1), 64);
+	hipLaunchKernelGGL(mcs::k_search_out, dim3(blocks), dim3(256), 0, s, dm, sm, n, dn, sn, df, sf, nsets);
+}
+
 // host pointers -> staged device copies (on the context's stream); device pointers pass through
 static int stage_sets(mcs_ctx* c, const SetGrid& sg, const mcs_desc_set* q, size_t qpitch, const mcs_desc_set* t, size_t tpitch, mcs_mem_kind kind,
                       DevSets* out, const double** rays1, const double** rays2, const double** E, size_t nE) {
@@ -279,6 +292,17 @@ static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc
 	g.outMatch = (int*)(so + oM); g.outCount = (int*)(so + oN); g.outFallbacks = (int*)(so + oF);
 	c->tic("greedy"); launch_greedy(g, s); c->toc("greedy");
 	HIPCHK(hipGetLastError());
+	{
+		// page-locked outputs: one launch instead of three copies (mcs_host.h device_view)
+		static const bool outKernel = !(getenv("MCS_OUT_KERNEL") && atoi(getenv("MCS_OUT_KERNEL")) == 0);
+		int* dm = (int*)device_view(out_match); int* dn = (int*)device_view(out_nmatches); int* df = (int*)device_view(out_fallbacks);
+		if (outKernel && dm && dn && (df || !out_fallbacks)) {
+			launch_search_out(dm, (const int*)(so + oM), outN, dn, (const int*)(so + oN), df, (const int*)(so + oF), nsets, s);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipStreamSynchronize(s));
+			return MCS_OK;
+		}
+	}
 	if (outN) HIPCHK(hipMemcpyAsync(out_match, so + oM, outN * 4, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipMemcpyAsync(out_nmatches, so + oN, (size_t)nsets * 4, hipMemcpyDeviceToHost, s));
 	if (out_fallbacks) HIPCHK(hipMemcpyAsync(out_fallbacks, so + oF, (size_t)nsets * 4, hipMemcpyDeviceToHost, s));

@@ -202,6 +202,9 @@ __global__ __launch_bounds__(64) void k_greedy(GreedyArgs g) {
 // have had, because every lower lane either committed earlier or commits in the same step without touching its rows).
 // A lane whose list cannot decide (its K entries are used up) is rescanned cooperatively by the wave when it becomes the
 // lowest unresolved lane, and blocks the lanes above it until then.
+#ifndef MCS_GREEDY_GROUP
+#define MCS_GREEDY_GROUP 1   // the walk over a list's entries four at a time (0: entry by entry, for A/B)
+#endif
 constexpr int kClaimRows = 16384;   // train rows per set supported by the speculative kernel (LDS claim table)
 
 // SearchForTriangulationRaw (TRI) in the same scheme: a query's outcome needs two rows of its sorted candidate list — a = the first FREE candidate
@@ -384,6 +387,28 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 #pragma unroll
 				for (int e0 = 0; e0 < K; e0 += 4) {
 					if (!stop) {
+#if MCS_GREEDY_GROUP
+						// the bitmap words of the group's four entries are requested TOGETHER (their addresses come from registers), then the first free ones are
+						// picked branch-free: one LDS round trip per four entries where the entry-by-entry walk paid one per entry
+						uint32_t kk[4], ww[4];
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {
+							uint32_t k = key[e0 + u < K ? e0 + u : K - 1];
+							asm volatile("" : "+v"(k));   // (index, bitmap word and bit of every entry hoisted out of the round loop cost 100 registers)
+							kk[u] = e0 + u < K ? k : EMPTY;
+							ww[u] = matched[kk[u] != EMPTY ? (kk[u] & 0xFFFFFu) >> 5 : 0u];
+						}
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {
+							const uint32_t k = kk[u];
+							const int idx = (int)(k & 0xFFFFFu);
+							const bool fr = k != EMPTY && !((ww[u] >> (idx & 31)) & 1u);
+							const bool t0 = fr && n == 0, t1 = fr && n == 1;
+							best = t0 ? (int)(k >> 20) : best; bestIdx = t0 ? idx : bestIdx;
+							second = t1 ? (int)(k >> 20) : second; secondIdx = t1 ? idx : secondIdx;
+							n += (fr && n < 2) ? 1 : 0;
+						}
+#else
 #pragma unroll
 						for (int e = e0; e < e0 + 4 && e < K; ++e) {
 							uint32_t k = key[e];
@@ -396,6 +421,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 								}
 							}
 						}
+#endif
 						if (e0 + 4 < K) stop = __all(n >= 2 || key[e0 + 3 < K ? e0 + 3 : K - 1] == EMPTY);
 					}
 				}

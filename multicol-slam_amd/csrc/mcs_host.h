@@ -22,6 +22,17 @@ static inline short sat_short(float v) { int iv = cvRoundf_(v); return (short)(i
 
 struct Timer { hipEvent_t a = nullptr, b = nullptr; bool used = false; };
 
+// the device's view of a page-locked host pointer, or nullptr (pageable memory, another device's allocation): host-kind calls write their outputs straight
+// into page-locked arrays with one launch instead of one runtime copy per array (~15 us each for the small arrays of ONE multi-frame)
+inline void* device_view(const void* host) {
+	if (!host) return nullptr;
+	hipPointerAttribute_t a;
+	memset(&a, 0, sizeof(a));
+	if (hipPointerGetAttributes(&a, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+	return a.devicePointer;
+}
+
 struct mcs_ctx {
 	int device = 0;
 	std::vector<mcs_extractor*> extractors;   // live extractors built on this context: mcs_ctx_destroy releases them (their buffers and stream are the context's)

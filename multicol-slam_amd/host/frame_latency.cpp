@@ -70,6 +70,9 @@ int main(int argc, char** argv) {
 	MCSOK(mcs_host_alloc(ctx, ncam * plane, (void**)&inImg));
 	MCSOK(mcs_host_alloc(ctx, ncam * plane, (void**)&inMask));
 	memcpy(inMask, masks.data(), ncam * plane);
+	// the rig's mirror masks never change: they stay on the device ("resident 0" in the config: uploaded with every call, as the reference's call shape would)
+	const bool resident = geti("resident", 1) != 0;
+	if (resident) MCSOK(mcs_extractor_set_masks(ex, ncam, inMask, plane, W, MCS_MEM_HOST));
 	struct Out { int32_t* nkp; mcs_keypoint* kps; uint8_t *desc, *mask, *valid; double* rays; int32_t* match; };
 	Out o[2];
 	for (Out& s : o) {
@@ -90,7 +93,7 @@ int main(int argc, char** argv) {
 		Out& prev = o[(it & 1) ^ 1];
 		const auto t0 = std::chrono::steady_clock::now();
 		for (int c = 0; c < ncam; ++c) memcpy(inImg + c * plane, images.data() + ((size_t)c * frames + f) * plane, plane);   // what a grabber's cv::Mat -> staging copy costs
-		MCSOK(mcs_extract_batch(ex, ncam, inImg, plane, W, inMask, plane, W, cams, MCS_MEM_HOST, cur.nkp, cur.kps, cur.desc, cur.mask, cur.rays));
+		MCSOK(mcs_extract_batch(ex, ncam, inImg, plane, W, resident ? MCS_MASKS_RESIDENT : inMask, plane, W, cams, MCS_MEM_HOST, cur.nkp, cur.kps, cur.desc, cur.mask, cur.rays));
 		// the multi-frame as ONE descriptor set: camera blocks of `cap` rows, the rows past a camera's count flagged invalid (every keypoint "has a map point")
 		for (int c = 0; c < ncam; ++c) {
 			memset(cur.valid + (size_t)c * cap, 1, (size_t)cur.nkp[c]);
@@ -124,11 +127,11 @@ int main(int argc, char** argv) {
 	int feats = 0;
 	for (int c = 0; c < ncam; ++c) feats += o[last].nkp[c];
 	const Stats e = stats(tE), m = stats(tM), s = stats(tS);
-	printf("{\"calls\": %d, \"warmup\": %d, \"cap\": %d, \"features_last\": %d, \"matches_last\": %d, \"rescans_last\": %d, \"last_frame\": %d, "
+	printf("{\"masks_resident\": %s, \"calls\": %d, \"warmup\": %d, \"cap\": %d, \"features_last\": %d, \"matches_last\": %d, \"rescans_last\": %d, \"last_frame\": %d, "
 	       "\"extract_ms\": {\"median\": %.4f, \"p90\": %.4f, \"p99\": %.4f, \"mean\": %.4f, \"min\": %.4f}, "
 	       "\"match_ms\": {\"median\": %.4f, \"p90\": %.4f, \"p99\": %.4f, \"mean\": %.4f, \"min\": %.4f}, "
 	       "\"total_ms\": {\"median\": %.4f, \"p90\": %.4f, \"p99\": %.4f, \"mean\": %.4f, \"min\": %.4f}}\n",
-	       calls, warm, cap, feats, nmatch, nfb, lastFrame, e.med, e.p90, e.p99, e.mean, e.mn, m.med, m.p90, m.p99, m.mean, m.mn, s.med, s.p90, s.p99, s.mean, s.mn);
+	       resident ? "true" : "false", calls, warm, cap, feats, nmatch, nfb, lastFrame, e.med, e.p90, e.p99, e.mean, e.mn, m.med, m.p90, m.p99, m.mean, m.mn, s.med, s.p90, s.p99, s.mean, s.mn);
 	for (Out& s2 : o) { mcs_host_free(ctx, s2.nkp); mcs_host_free(ctx, s2.kps); mcs_host_free(ctx, s2.desc); mcs_host_free(ctx, s2.mask); mcs_host_free(ctx, s2.valid); mcs_host_free(ctx, s2.rays); mcs_host_free(ctx, s2.match); }
 	mcs_host_free(ctx, inImg); mcs_host_free(ctx, inMask);
 	MCSOK(mcs_extractor_destroy(ex));

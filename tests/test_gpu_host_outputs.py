@@ -1,0 +1,88 @@
+"""-m gpu: the two host-side shortcuts of the one-multi-frame-per-call shape (mcs_c.h): mirror masks kept on the device (mcs_extractor_set_masks +
+MCS_MASKS_RESIDENT) and page-locked output arrays written by one launch (k_extract_out) instead of five copies.  Both must return exactly what the plain host-kind
+call returns; rows past an image's count stay untouched in the page-locked form."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_common
+    return gpu_common
+
+
+def pinned(G, dtype, shape):
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    G.mcs.check(G.mcs.lib().mcs_host_alloc(G.ctx().h, n, C.byref(p)))
+    buf = (C.c_uint8 * n).from_address(p.value)
+    a = np.frombuffer(buf, np.uint8)
+    a[:] = 0xAB
+    return p, a.view(dtype).reshape(shape)
+
+
+@pytest.mark.parametrize("mode", [dict(do_dBrief=1, learnMasks=1), dict(do_dBrief=0, learnMasks=0)])
+def test_resident_masks_and_page_locked_outputs(G, mode):
+    imgs, masks, cams = G.frame_inputs(1)
+    ocams = [G.mcs.make_ocam(c) for c in cams]
+    ex = G.mcs.Extractor(G.ctx(), 754, 480, max_batch=3, nfeatures=700, **mode)
+    want = ex.extract_host(imgs, masks, ocams)                       # pageable arrays, masks uploaded with the call
+    ex.set_masks(masks)
+    got = ex.extract_host(imgs, "resident", ocams)
+    for (k, d, m, r), (wk, wd, wm, wr) in zip(got, want):
+        assert G.first_diff(k, wk) is None and G.first_diff(d, wd) is None and G.first_diff(m, wm) is None and G.first_diff(r, wr) is None
+    with pytest.raises(G.mcs.McsError):
+        G.mcs.Extractor(G.ctx(), 754, 480, max_batch=3).extract_host(imgs, "resident", None)      # no masks set on that extractor
+    # page-locked outputs through the raw entry point
+    cap, ds = ex.cap, ex.descSize
+    hs = []
+    p_nkp, nkp = pinned(G, np.int32, (3,)); hs.append(p_nkp)
+    p_kps, kps = pinned(G, G.mcs.KP_DTYPE, (3, cap)); hs.append(p_kps)
+    p_d, desc = pinned(G, np.uint8, (3, cap, ds)); hs.append(p_d)
+    p_m, dmask = pinned(G, np.uint8, (3, cap, ds)); hs.append(p_m)
+    p_r, rays = pinned(G, np.float64, (3, cap, 3)); hs.append(p_r)
+    im = np.ascontiguousarray(np.stack(imgs))
+    camarr = (G.mcs.Ocam * 3)(*ocams)
+    for rep in range(3):                                             # the second and third call replay the captured launch sequence
+        G.mcs.check(G.mcs.lib().mcs_extract_batch(ex.h, 3, G.mcs.np_ptr(im), 754 * 480, 754, G.mcs.MASKS_RESIDENT, 754 * 480, 754, camarr, G.mcs.MEM_HOST,
+                                                  p_nkp, p_kps, p_d, p_m, p_r))
+        for i, (wk, wd, wm, wr) in enumerate(want):
+            n = int(nkp[i])
+            assert n == len(wk) and G.first_diff(kps[i, :n], wk) is None and G.first_diff(desc[i, :n], wd) is None and G.first_diff(dmask[i, :n], wm) is None
+            assert G.first_diff(rays[i, :n], wr) is None
+            assert n < cap and (desc[i, n:] == 0xAB).all() and (dmask[i, n:] == 0xAB).all() and (kps[i, n:].view(np.uint8) == 0xAB).all()
+    for p in hs:
+        G.mcs.check(G.mcs.lib().mcs_host_free(G.ctx().h, p))
+    ex.close()
+
+
+def test_search_outputs_in_page_locked_arrays(G):
+    """mcs_search_kf_kf with host buffers: page-locked match / count / rescan arrays are filled by one launch; same numbers as the pageable call"""
+    cap = __import__("importlib").import_module("multicol-slam_amd._capi")
+    res = []
+    ex = G.mcs.Extractor(G.ctx(), 754, 480, max_batch=3, nfeatures=600, do_dBrief=1, learnMasks=1)
+    for f in (0, 1):
+        imgs, masks, cams = G.frame_inputs(f)
+        res.append(ex.extract_host(imgs, masks, [G.mcs.make_ocam(c) for c in cams]))
+    ex.close()
+    rows = max(len(r[0]) for fr in res for r in fr)
+    def stack(fr):
+        D = np.zeros((3 * rows, 32), np.uint8); M = np.zeros_like(D); V = np.zeros(3 * rows, np.uint8)
+        for c, (k, d, m, _) in enumerate(fr):
+            D[c * rows:c * rows + len(d)], M[c * rows:c * rows + len(d)], V[c * rows:c * rows + len(d)] = d, m, 1
+        return D, M, V
+    (D0, M0, V0), (D1, M1, V1) = stack(res[0]), stack(res[1])
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    q = cap.DescSet(P(D1), P(M1), P(V1), None, 3 * rows, 32)
+    t = cap.DescSet(P(D0), P(M0), P(V0), None, 3 * rows, 32)
+    m_ref = np.full(3 * rows, -7, np.int32); n_ref = np.zeros(1, np.int32); f_ref = np.zeros(1, np.int32)
+    cap.check(G.mcs.lib().mcs_search_kf_kf(G.ctx().h, 1, C.byref(q), 0, C.byref(t), 0, 32, 0.9, 32, cap.MEM_HOST, P(m_ref), P(n_ref), P(f_ref)))
+    p_m, m_pin = pinned(G, np.int32, (3 * rows,)); p_n, n_pin = pinned(G, np.int32, (1,)); p_f, f_pin = pinned(G, np.int32, (1,))
+    cap.check(G.mcs.lib().mcs_search_kf_kf(G.ctx().h, 1, C.byref(q), 0, C.byref(t), 0, 32, 0.9, 32, cap.MEM_HOST, p_m, p_n, p_f))
+    assert int(n_ref[0]) > 300 and np.array_equal(m_pin, m_ref) and int(n_pin[0]) == int(n_ref[0]) and int(f_pin[0]) == int(f_ref[0])
+    for p in (p_m, p_n, p_f):
+        G.mcs.check(G.mcs.lib().mcs_host_free(G.ctx().h, p))
