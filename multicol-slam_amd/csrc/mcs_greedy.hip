@@ -11,6 +11,9 @@
 // query — exact for any K, K only trades list size against rescans.  Integer + a few FP64 mul/div: bit-exact.
 #include "mcs_common.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace mcs {
 
 constexpr int kBitmapWords = 4096;   // nt <= 131072 train rows per set
@@ -508,6 +511,228 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 	__syncthreads();   // A: releases the helper waves
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same greedy as a FIXPOINT, for FEW set pairs (one multi-frame against one keyframe: the latency of a live tracker's call).  The sequential loop is a
+// lower-triangular system: query i's outcome A_i (the row it takes, or none) is a function f_i of { A_j : j < i } — a row is "taken" for i iff some earlier
+// query takes it.  Iterating  A_i <- f_i({A_j : j < i})  for ALL queries at once converges to the unique solution of that system (after t sweeps the first t
+// queries are final), which is the sequential result; dependencies are short chains (a query depends on the few earlier queries that compete for its two
+// nearest free rows), so a handful of sweeps suffices where k_greedy_spec walks 48 chunks of 64 queries one after the other (0.25 ms for ONE pair).
+//   sweep:  owner[r] = the lowest query that currently takes row r (LDS, atomicMin);  then every query re-derives its decision from its sorted list with
+//           "taken" = owner[r] < i — the same best / second / threshold / ratio rules as above;  queries whose list cannot decide (its K entries used up) keep
+//           their previous outcome during the sweeps and are rescanned EXACTLY (all waves, the whole train set, free = owner >= i) once the sweeps are stable;
+//           a rescan that changes an outcome restarts the sweeps.  The loop ends only after a pass in which nothing changed and every such query was rescanned
+//           against the final owners: every equation of the system holds.
+// One workgroup of 1024 threads per set pair; a thread owns queries tid, tid + 1024, ...; the first kJacCache entries of every list sit in LDS.
+constexpr int kJacThreads = 1024, kJacCache = 8;   // list entries per query kept in LDS (a walk beyond them reads the list in memory: a dependent round trip per entry)
+__host__ __device__ constexpr size_t jacobi_lds_words(int nq, int nt, int K) { return (size_t)2 * nt + nq + (size_t)(K < kJacCache ? K : kJacCache) * nq + nq; }
+template <int K, int DW, bool MASKED>
+__global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
+	// LDS: owner[2][nt] — the lowest query that takes a row, as  (0xFFFF - sweep tag) << 16 | query  under atomicMin: entries of older sweeps compare larger and are
+	// simply ignored, so nothing is cleared, and the claims of sweep t + 1 go into the other buffer while sweep t is still being read: ONE barrier per sweep —,
+	// A[nq] the outcomes, head[C][nq] the first C list entries, last[nq] the K-th entry
+	extern __shared__ uint32_t greedy_lds[];
+	constexpr int C = K < kJacCache ? K : kJacCache;
+	uint32_t* owner = greedy_lds;
+	int* A = reinterpret_cast<int*>(greedy_lds + 2 * (size_t)g.nt);
+	uint32_t* head = greedy_lds + 2 * (size_t)g.nt + g.nq;
+	uint32_t* lastK = head + (size_t)C * g.nq;
+	__shared__ int changed[3], nRescan[3], rescanQ[3][64];   // per sweep, slot = sweep % 3: a slot is cleared two sweeps before it is used (one barrier per sweep)
+	__shared__ uint32_t partA[kJacThreads / 64], partB[kJacThreads / 64];
+	const int set = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const RowMap QR{(size_t)(set % g.qmod) * g.qpitch, g.qblk, g.qbpitch}, TR{(size_t)((set / g.tdiv + g.toff) % g.tmod) * g.tpitch, g.tblk, g.tbpitch};
+	constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+	const bool grouped = g.qgroup != nullptr && g.tgroup != nullptr;
+	const uint32_t* keys = g.keys + (size_t)set * K * g.nq;   // [K][nq]
+	int* outM = g.outMatch + (size_t)set * (g.mode == 1 ? g.nt : g.nq);
+	for (int j = tid; j < 2 * g.nt; j += kJacThreads) owner[j] = EMPTY;
+	if (g.mode == 1) for (int j = tid; j < g.nt; j += kJacThreads) outM[j] = -1;
+	for (int i = tid; i < g.nq; i += kJacThreads) {
+		const bool ok = !g.qvalid || g.qvalid[QR(i)] != 0;   // a query without a map point never takes a row: an empty list
+		A[i] = -1;
+#pragma unroll
+		for (int e = 0; e < C; ++e) head[(size_t)e * g.nq + i] = ok ? keys[(size_t)e * g.nq + i] : EMPTY;
+		lastK[i] = ok ? keys[(size_t)(K - 1) * g.nq + i] : EMPTY;
+	}
+	if (tid < 3) { changed[tid] = 0; nRescan[tid] = 0; }
+	__syncthreads();
+	// decision of query i from its list under "taken = a lower query claims the row in buffer `own` with tag `tag`": 0 none, 1 takes *row, 2 the list cannot decide
+	auto taken = [&](const uint32_t* own, uint32_t tag, int row, int i) { const uint32_t v = own[row]; return (v >> 16) == tag && (v & 0xFFFFu) < (uint32_t)i; };
+	auto decide = [&](const uint32_t* own, uint32_t tag, int i, int* row) {
+		int n = 0, best = 0x7FFFFFFF, second = 0x7FFFFFFF, bestIdx = -1;
+		// the cached head in two halves: a half's entries and their claim words are requested together (two LDS round trips per half), then picked in registers;
+		// the second half only if the first did not yield two free rows (the lists are sorted and most rows are free: seldom)
+		constexpr int H = C >= 8 ? C / 2 : C;
+		uint32_t kk[C];
+		auto half = [&](auto e0c) {
+			constexpr int e0 = decltype(e0c)::value;
+			uint32_t vv[H];
+#pragma unroll
+			for (int e = 0; e < H; ++e) kk[e0 + e] = head[(size_t)(e0 + e) * g.nq + i];
+#pragma unroll
+			for (int e = 0; e < H; ++e) vv[e] = own[kk[e0 + e] != EMPTY ? (kk[e0 + e] & 0xFFFFFu) : 0u];
+#pragma unroll
+			for (int e = 0; e < H; ++e) {
+				const uint32_t k = kk[e0 + e], v = vv[e];
+				const bool fr = k != EMPTY && !((v >> 16) == tag && (v & 0xFFFFu) < (uint32_t)i);
+				const bool t0 = fr && n == 0, t1 = fr && n == 1;
+				best = t0 ? (int)(k >> 20) : best; bestIdx = t0 ? (int)(k & 0xFFFFFu) : bestIdx;
+				second = t1 ? (int)(k >> 20) : second;
+				n += (fr && n < 2) ? 1 : 0;
+			}
+		};
+		half(std::integral_constant<int, 0>());
+		if (H < C) { if (n < 2 && kk[H - 1] != EMPTY) half(std::integral_constant<int, H>()); else kk[C - 1] = EMPTY; }
+		if (n < 2 && kk[C - 1] != EMPTY) {   // beyond the cached head (rare): the list in memory, entry by entry
+			for (int e = C; e < K && n < 2; ++e) {
+				const uint32_t k = keys[(size_t)e * g.nq + i];
+				if (k == EMPTY) break;
+				const int idx = (int)(k & 0xFFFFFu);
+				if (!taken(own, tag, idx, i)) { if (n == 0) { best = (int)(k >> 20); bestIdx = idx; } else second = (int)(k >> 20); ++n; }
+			}
+		}
+		const uint32_t last = lastK[i];
+		const bool full = last != EMPTY;
+		const int dK = full ? (int)(last >> 20) : 0x7FFFFFFF;
+		*row = bestIdx;
+		if (n >= 2 || !full) {
+			const bool pass = bestIdx >= 0 && (g.thInclusive ? best <= g.thLow : best < g.thLow);
+			return (pass && static_cast<double>(best) < g.ratio * static_cast<double>(second)) ? 1 : 0;
+		}
+		if (n == 1) {   // hidden rows beyond the list all have distance >= dK
+			const bool pass = g.thInclusive ? best <= g.thLow : best < g.thLow;
+			if (!pass) return 0;
+			return static_cast<double>(best) < g.ratio * static_cast<double>(dK) ? 1 : 2;
+		}
+		return (g.thInclusive ? dK <= g.thLow : dK < g.thLow) ? 2 : 0;
+	};
+	// exact rescan of query qi by the whole workgroup: the two smallest keys among the eligible rows no lower query takes -> the query's outcome
+	auto rescan = [&](const uint32_t* own, uint32_t tag, int qi) -> int {
+		uint32_t q[DW], qm[DW];
+		const uint32_t* qp = reinterpret_cast<const uint32_t*>(g.qd + QR(qi) * g.qstride);
+#pragma unroll
+		for (int w = 0; w < DW; ++w) q[w] = qp[w];
+		if (MASKED) {
+			const uint32_t* mp = reinterpret_cast<const uint32_t*>(g.qm + QR(qi) * g.qstride);
+#pragma unroll
+			for (int w = 0; w < DW; ++w) qm[w] = mp[w];
+		}
+		const int qg = grouped ? g.qgroup[QR(qi)] : 0;
+		uint32_t a = EMPTY, b2 = EMPTY;
+		// rows as 16-byte words where the layout allows it (a 32-byte row is two loads instead of eight)
+		const bool wide = DW % 4 == 0 && ((((uintptr_t)g.td | (uintptr_t)(MASKED ? g.tm : g.td)) | (uintptr_t)g.tstride) & 15u) == 0;
+		for (int j = tid; j < g.nt; j += kJacThreads) {
+			const uint8_t* tb = g.td + TR(j) * g.tstride;
+			const uint8_t* mb = MASKED ? g.tm + TR(j) * g.tstride : tb;
+			uint32_t tw[DW], mw[DW];
+			if (wide) {
+#pragma unroll
+				for (int w = 0; w < DW / 4; ++w) {
+					const uint4 v = reinterpret_cast<const uint4*>(tb)[w];
+					tw[4 * w] = v.x; tw[4 * w + 1] = v.y; tw[4 * w + 2] = v.z; tw[4 * w + 3] = v.w;
+					if (MASKED) { const uint4 u = reinterpret_cast<const uint4*>(mb)[w]; mw[4 * w] = u.x; mw[4 * w + 1] = u.y; mw[4 * w + 2] = u.z; mw[4 * w + 3] = u.w; }
+				}
+			} else {
+#pragma unroll
+				for (int w = 0; w < DW; ++w) { tw[w] = reinterpret_cast<const uint32_t*>(tb)[w]; if (MASKED) mw[w] = reinterpret_cast<const uint32_t*>(mb)[w]; }
+			}
+			const bool ok = !taken(own, tag, j, qi) && (g.tvalid ? g.tvalid[TR(j)] != 0 : true) && (!grouped || g.tgroup[TR(j)] == qg);
+			const uint32_t k = ok ? (((uint32_t)hamming_g<DW, MASKED>(q, qm, tw, MASKED ? mw : tw) << 20) | (uint32_t)j) : EMPTY;
+			if (k < a) { b2 = a; a = k; } else if (k < b2) b2 = k;
+		}
+		const uint32_t m1 = wave_min_u32(a);
+		const uint32_t m2 = wave_min_u32(a == m1 ? b2 : a);
+		if (lane == 0) { partA[wave] = m1; partB[wave] = m2; }
+		__syncthreads();
+		uint32_t r1 = EMPTY, r2 = EMPTY;
+		for (int w = 0; w < kJacThreads / 64; ++w) {
+			const uint32_t pa = partA[w], pb = partB[w];
+			if (pa < r1) { r2 = r1; r1 = pa; } else if (pa < r2) r2 = pa;
+			if (pb < r2) r2 = pb;
+		}
+		__syncthreads();
+		const int best = r1 == EMPTY ? 0x7FFFFFFF : (int)(r1 >> 20), second = r2 == EMPTY ? 0x7FFFFFFF : (int)(r2 >> 20);
+		const bool pass = r1 != EMPTY && (g.thInclusive ? best <= g.thLow : best < g.thLow);
+		return (pass && static_cast<double>(best) < g.ratio * static_cast<double>(second)) ? (int)(r1 & 0xFFFFFu) : -1;
+	};
+	// sweep t reads the claims of buffer t & 1 made with tag t (none for t = 0: every row free) and writes the claims of the new outcomes into the other buffer
+	int nfallback = 0;
+	uint32_t t = 0;
+	for (int guard = 0; guard < 2 * g.nq + 4; ++guard) {
+		const uint32_t* own = owner + (size_t)(t & 1u) * g.nt;
+		uint32_t* nxt = owner + (size_t)((t + 1u) & 1u) * g.nt;
+		const uint32_t tag = 0xFFFFu - (t & 0xFFFFu), ntag = 0xFFFFu - ((t + 1u) & 0xFFFFu);   // (tags repeat after 65536 sweeps; a sweep count is bounded by nq + passes, far below)
+		const int slot = (int)(t % 3u);
+		bool ch = false;
+		for (int i = tid; i < g.nq; i += kJacThreads) {
+			int row, na = A[i];
+			const int st = decide(own, tag, i, &row);
+			if (st == 2) { const int at = atomicAdd(&nRescan[slot], 1); if (at < 64) rescanQ[slot][at] = i; }   // keeps its outcome until the exact rescan below
+			else { na = st == 1 ? row : -1; if (na != A[i]) { A[i] = na; ch = true; } }
+			if (na >= 0) atomicMin(&nxt[na], (ntag << 16) | (uint32_t)i);
+		}
+		if (ch) changed[slot] = 1;
+		__syncthreads();
+		const bool again = changed[slot] != 0;
+		const int nr = nRescan[slot];
+		if (tid == 0) { const int s2 = (int)((t + 2u) % 3u); changed[s2] = 0; nRescan[s2] = 0; }   // the flags of the sweep after the next (last read before this barrier, next written after the next one)
+		++t;
+		if (again) continue;
+		// ---- stable: the queries whose lists could not decide, exactly, against the claims of the stable state (= the next buffer: every outcome re-claimed there)
+		if (nr == 0) break;
+		bool any = false;
+		auto settle = [&](int qi) {   // (uniform: every thread sees the same old and new outcome)
+			const int na = rescan(nxt, ntag, qi);
+			const int old = A[qi];
+			__syncthreads();
+			if (na != old) { any = true; if (tid == 0) A[qi] = na; }
+		};
+		nfallback = 0;
+		if (nr > 64) {   // (more than the queue holds: found again one by one)
+			for (int i = 0; i < g.nq; ++i) {
+				if (tid == 0) { int row = -1; rescanQ[slot][0] = decide(nxt, ntag, i, &row); }
+				__syncthreads();
+				const int st = rescanQ[slot][0];
+				__syncthreads();
+				if (st != 2) continue;
+				++nfallback;
+				settle(i);
+			}
+		} else {
+			for (int k = 0; k < nr; ++k) settle(rescanQ[slot][k]);
+			nfallback = nr;
+		}
+		__syncthreads();
+		if (!any) break;
+		// a rescan changed an outcome: the claims of buffer `nxt` are stale for that query — rebuild them under a fresh tag by one more pass over the outcomes
+		++t;   // (skip a tag: buffer (t & 1) is `own` again, written with the tag of sweep t)
+		{
+			uint32_t* cur = owner + (size_t)(t & 1u) * g.nt;
+			const uint32_t ctag = 0xFFFFu - (t & 0xFFFFu);
+			for (int i = tid; i < g.nq; i += kJacThreads) { const int r = A[i]; if (r >= 0) atomicMin(&cur[r], (ctag << 16) | (uint32_t)i); }
+			if (tid < 3) { changed[tid] = 0; nRescan[tid] = 0; }
+			__syncthreads();
+		}
+	}
+	// ---- results
+	int nm = 0;
+	for (int i = tid; i < g.nq; i += kJacThreads) {
+		const int r = A[i];
+		if (g.mode != 1) outM[i] = r;
+		else if (r >= 0) outM[r] = i;
+		nm += r >= 0 ? 1 : 0;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) nm += __shfl_xor(nm, o);
+	if (lane == 0) partA[wave] = (uint32_t)nm;
+	__syncthreads();
+	if (tid == 0) {
+		int tot = 0;
+		for (int w = 0; w < kJacThreads / 64; ++w) tot += (int)partA[w];
+		g.outCount[set] = tot;
+		if (g.outFallbacks) g.outFallbacks[set] = nfallback;
+	}
+}
+
 template <int K, int DW, bool MASKED, bool TRI>
 static void launch_spec(const GreedyArgs& g, hipStream_t s) {
 	const size_t lds = (size_t)(g.nt + (g.nt + 31) / 32) * 4;   // claim[nt] + matched bitmap
@@ -515,9 +740,23 @@ static void launch_spec(const GreedyArgs& g, hipStream_t s) {
 	hipLaunchKernelGGL((k_greedy_spec<K, DW, MASKED, TRI>), dim3(g.nsets), dim3(64 * (g.nsets >= kManySets ? kSpecWavesMany : kSpecWaves)), lds, s, g);
 }
 
+template <int K, int DW, bool MASKED>
+static void launch_jacobi(const GreedyArgs& g, hipStream_t s) {
+	const size_t lds = jacobi_lds_words(g.nq, g.nt, K) * 4;
+	if (lds > 60 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy_jacobi<K, DW, MASKED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipLaunchKernelGGL((k_greedy_jacobi<K, DW, MASKED>), dim3(g.nsets), dim3(kJacThreads), lds, s, g);
+}
+
 template <int K, int DW>
 static void launch_spec_kd(const GreedyArgs& g, hipStream_t s) {
 	const bool masked = g.qm && g.tm;
+	// few set pairs (a tracker's one multi-frame against one keyframe): the fixpoint form, a whole workgroup per pair; MCS_GREEDY_JACOBI = the largest number of
+	// pairs that takes it (0: never, for A/B and tests)
+	static const int jacSets = getenv("MCS_GREEDY_JACOBI") ? atoi(getenv("MCS_GREEDY_JACOBI")) : 8;
+	if (g.mode != 2 && g.nsets <= jacSets && g.nq < 65536 && jacobi_lds_words(g.nq, g.nt, K) * 4 <= 150 * 1024) {
+		if (masked) launch_jacobi<K, DW, true>(g, s); else launch_jacobi<K, DW, false>(g, s);
+		return;
+	}
 	if (g.mode == 2) { if (masked) launch_spec<K, DW, true, true>(g, s); else launch_spec<K, DW, false, true>(g, s); }
 	else if (masked) launch_spec<K, DW, true, false>(g, s);
 	else launch_spec<K, DW, false, false>(g, s);

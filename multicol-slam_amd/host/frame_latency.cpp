@@ -86,7 +86,10 @@ int main(int argc, char** argv) {
 		memset(s.valid, 0, rows);
 	}
 	std::vector<double> tE, tM, tS;
-	int32_t nmatch = 0, nfb = 0;
+	int32_t* counts = nullptr;   // [0] matches, [1] rescans: page-locked like the match array, so that the search writes all three with one launch
+	MCSOK(mcs_host_alloc(ctx, 2 * sizeof(int32_t), (void**)&counts));
+	counts[0] = counts[1] = 0;
+	int32_t &nmatch = counts[0], &nfb = counts[1];
 	for (int it = 0; it < warm + calls; ++it) {
 		const int f = it % frames;
 		Out& cur = o[it & 1];
@@ -133,7 +136,7 @@ int main(int argc, char** argv) {
 	       "\"total_ms\": {\"median\": %.4f, \"p90\": %.4f, \"p99\": %.4f, \"mean\": %.4f, \"min\": %.4f}}\n",
 	       resident ? "true" : "false", calls, warm, cap, feats, nmatch, nfb, lastFrame, e.med, e.p90, e.p99, e.mean, e.mn, m.med, m.p90, m.p99, m.mean, m.mn, s.med, s.p90, s.p99, s.mean, s.mn);
 	for (Out& s2 : o) { mcs_host_free(ctx, s2.nkp); mcs_host_free(ctx, s2.kps); mcs_host_free(ctx, s2.desc); mcs_host_free(ctx, s2.mask); mcs_host_free(ctx, s2.valid); mcs_host_free(ctx, s2.rays); mcs_host_free(ctx, s2.match); }
-	mcs_host_free(ctx, inImg); mcs_host_free(ctx, inMask);
+	mcs_host_free(ctx, inImg); mcs_host_free(ctx, inMask); mcs_host_free(ctx, counts);
 	MCSOK(mcs_extractor_destroy(ex));
 	MCSOK(mcs_ctx_destroy(ctx));
 	return 0;
