@@ -523,6 +523,10 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 //           a rescan that changes an outcome restarts the sweeps.  The loop ends only after a pass in which nothing changed and every such query was rescanned
 //           against the final owners: every equation of the system holds.
 // One workgroup of 1024 threads per set pair; a thread owns queries tid, tid + 1024, ...; the first kJacCache entries of every list sit in LDS.
+#ifndef MCS_JAC_EXT
+#define MCS_JAC_EXT 4
+#endif
+constexpr int kJacOwn = 3, kJacExt = MCS_JAC_EXT;   // queries per thread whose list entries 8 .. 8 + kJacExt - 1 sit in registers (sets of up to 3072 queries: all of them)
 constexpr int kJacThreads = 1024, kJacCache = 8;   // list entries per query kept in LDS (a walk beyond them reads the list in memory: a dependent round trip per entry)
 __host__ __device__ constexpr size_t jacobi_lds_words(int nq, int nt, int K) { return (size_t)2 * nt + nq + (size_t)(K < kJacCache ? K : kJacCache) * nq + nq; }
 template <int K, int DW, bool MASKED>
@@ -554,10 +558,33 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 		lastK[i] = ok ? keys[(size_t)(K - 1) * g.nq + i] : EMPTY;
 	}
 	if (tid < 3) { changed[tid] = 0; nRescan[tid] = 0; }
+	uint32_t extq[kJacOwn][kJacExt];   // entries C .. C + kJacExt - 1 of the thread's first kJacOwn queries
+#pragma unroll
+	for (int u = 0; u < kJacOwn; ++u) {
+		const int i = tid + u * kJacThreads;
+		const bool ok = i < g.nq && (!g.qvalid || g.qvalid[QR(i)] != 0);
+#pragma unroll
+		for (int e = 0; e < kJacExt; ++e) extq[u][e] = (ok && C + e < K) ? keys[(size_t)(C + e) * g.nq + i] : EMPTY;
+	}
 	__syncthreads();
 	// decision of query i from its list under "taken = a lower query claims the row in buffer `own` with tag `tag`": 0 none, 1 takes *row, 2 the list cannot decide
 	auto taken = [&](const uint32_t* own, uint32_t tag, int row, int i) { const uint32_t v = own[row]; return (v >> 16) == tag && (v & 0xFFFFu) < (uint32_t)i; };
-	auto decide = [&](const uint32_t* own, uint32_t tag, int i, int* row) {
+	// the rules on (free rows found, best, second, the list's K-th entry): 0 none, 1 take the best row, 2 the list cannot decide
+	auto verdict = [&](int n, int best, int bestIdx, int second, uint32_t last) {
+		const bool full = last != EMPTY;
+		const int dK = full ? (int)(last >> 20) : 0x7FFFFFFF;
+		if (n >= 2 || !full) {
+			const bool pass = bestIdx >= 0 && (g.thInclusive ? best <= g.thLow : best < g.thLow);
+			return (pass && static_cast<double>(best) < g.ratio * static_cast<double>(second)) ? 1 : 0;
+		}
+		if (n == 1) {   // hidden rows beyond the list all have distance >= dK
+			const bool pass = g.thInclusive ? best <= g.thLow : best < g.thLow;
+			if (!pass) return 0;
+			return static_cast<double>(best) < g.ratio * static_cast<double>(dK) ? 1 : 2;
+		}
+		return (g.thInclusive ? dK <= g.thLow : dK < g.thLow) ? 2 : 0;
+	};
+	auto decide = [&](const uint32_t* own, uint32_t tag, int i, int* row, const uint32_t* ext = nullptr) {   // ext: entries C .. C + kJacExt - 1 of the list, held by the caller
 		int n = 0, best = 0x7FFFFFFF, second = 0x7FFFFFFF, bestIdx = -1;
 		// the cached head in two halves: a half's entries and their claim words are requested together (two LDS round trips per half), then picked in registers;
 		// the second half only if the first did not yield two free rows (the lists are sorted and most rows are free: seldom)
@@ -582,28 +609,37 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 		};
 		half(std::integral_constant<int, 0>());
 		if (H < C) { if (n < 2 && kk[H - 1] != EMPTY) half(std::integral_constant<int, H>()); else kk[C - 1] = EMPTY; }
-		if (n < 2 && kk[C - 1] != EMPTY) {   // beyond the cached head (rare): the list in memory, entry by entry
-			for (int e = C; e < K && n < 2; ++e) {
-				const uint32_t k = keys[(size_t)e * g.nq + i];
-				if (k == EMPTY) break;
-				const int idx = (int)(k & 0xFFFFFu);
-				if (!taken(own, tag, idx, i)) { if (n == 0) { best = (int)(k >> 20); bestIdx = idx; } else second = (int)(k >> 20); ++n; }
+		if (n < 2 && kk[C - 1] != EMPTY) {   // beyond the cached head (a query whose nearest rows are mostly taken by lower queries: the late ones)
+			// several entries per round trip (entry by entry this was a dependent memory round trip each, and the slowest lane of the workgroup sets the pace of every
+			// sweep: 13 us per sweep): first the caller's register copy of entries C .. C + kJacExt - 1, then the list in memory, eight at a time
+			bool ended = false;
+			auto batch = [&](const uint32_t* kb, auto wc) {
+				constexpr int W = decltype(wc)::value;
+				uint32_t vb[W];
+#pragma unroll
+				for (int u = 0; u < W; ++u) vb[u] = own[kb[u] != EMPTY ? (kb[u] & 0xFFFFFu) : 0u];
+#pragma unroll
+				for (int u = 0; u < W; ++u) {
+					const uint32_t k = kb[u], v = vb[u];
+					ended = ended || k == EMPTY;
+					const bool fr = !ended && !((v >> 16) == tag && (v & 0xFFFFu) < (uint32_t)i);
+					const bool t0 = fr && n == 0, t1 = fr && n == 1;
+					best = t0 ? (int)(k >> 20) : best; bestIdx = t0 ? (int)(k & 0xFFFFFu) : bestIdx;
+					second = t1 ? (int)(k >> 20) : second;
+					n += (fr && n < 2) ? 1 : 0;
+				}
+			};
+			int e0 = C;
+			if (ext) { batch(ext, std::integral_constant<int, kJacExt>()); e0 = C + kJacExt; }
+			for (; e0 < K && n < 2 && !ended; e0 += 8) {
+				uint32_t k8[8];
+#pragma unroll
+				for (int u = 0; u < 8; ++u) k8[u] = e0 + u < K ? keys[(size_t)(e0 + u) * g.nq + i] : EMPTY;
+				batch(k8, std::integral_constant<int, 8>());
 			}
 		}
-		const uint32_t last = lastK[i];
-		const bool full = last != EMPTY;
-		const int dK = full ? (int)(last >> 20) : 0x7FFFFFFF;
 		*row = bestIdx;
-		if (n >= 2 || !full) {
-			const bool pass = bestIdx >= 0 && (g.thInclusive ? best <= g.thLow : best < g.thLow);
-			return (pass && static_cast<double>(best) < g.ratio * static_cast<double>(second)) ? 1 : 0;
-		}
-		if (n == 1) {   // hidden rows beyond the list all have distance >= dK
-			const bool pass = g.thInclusive ? best <= g.thLow : best < g.thLow;
-			if (!pass) return 0;
-			return static_cast<double>(best) < g.ratio * static_cast<double>(dK) ? 1 : 2;
-		}
-		return (g.thInclusive ? dK <= g.thLow : dK < g.thLow) ? 2 : 0;
+		return verdict(n, best, bestIdx, second, lastK[i]);
 	};
 	// exact rescan of query qi by the whole workgroup: the two smallest keys among the eligible rows no lower query takes -> the query's outcome
 	auto rescan = [&](const uint32_t* own, uint32_t tag, int qi) -> int {
@@ -663,13 +699,19 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 		const uint32_t tag = 0xFFFFu - (t & 0xFFFFu), ntag = 0xFFFFu - ((t + 1u) & 0xFFFFu);   // (tags repeat after 65536 sweeps; a sweep count is bounded by nq + passes, far below)
 		const int slot = (int)(t % 3u);
 		bool ch = false;
-		for (int i = tid; i < g.nq; i += kJacThreads) {
+		// a thread's queries; the first kJacOwn of them with entries C .. C + 7 of their lists in registers (loaded once): late queries find most of their nearest rows
+		// taken by lower queries and walk a dozen entries — from memory that was a round trip per eight entries in every sweep, and the slowest wave sets the sweep's pace
+		auto one = [&](int i, const uint32_t* ext) {
 			int row, na = A[i];
-			const int st = decide(own, tag, i, &row);
+			const int old = na;
+			const int st = decide(own, tag, i, &row, ext);
 			if (st == 2) { const int at = atomicAdd(&nRescan[slot], 1); if (at < 64) rescanQ[slot][at] = i; }   // keeps its outcome until the exact rescan below
-			else { na = st == 1 ? row : -1; if (na != A[i]) { A[i] = na; ch = true; } }
+			else { na = st == 1 ? row : -1; if (na != old) { A[i] = na; ch = true; } }
 			if (na >= 0) atomicMin(&nxt[na], (ntag << 16) | (uint32_t)i);
-		}
+		};
+#pragma unroll
+		for (int u = 0; u < kJacOwn; ++u) { const int i = tid + u * kJacThreads; if (i < g.nq) one(i, K > C ? extq[u] : nullptr); }
+		for (int i = tid + kJacOwn * kJacThreads; i < g.nq; i += kJacThreads) one(i, nullptr);
 		if (ch) changed[slot] = 1;
 		__syncthreads();
 		const bool again = changed[slot] != 0;
