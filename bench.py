@@ -793,10 +793,17 @@ def run_e2e(e, sp, steps, warmup, check=True):
         job.extract_and_exchange(b, i)
         ev_free[i].record(e.stream)
         t2 = time.perf_counter()
-        upload((n + NI - 1) % NI)                         # the images of step n + NI - 1 travel while this and the following steps compute (NI = 2: the next step's)
+        # The search is enqueued BEFORE the upload: the probed upload stream shares a hardware queue with the deferred matcher's stream (the least harmful pairing),
+        # and a queue starts its packets in order — with the 1.3 ms upload in front, this step's lists started 1.3 ms late and finished right around the fence of step
+        # n + 2: 1.60 ms per step in two runs of three, 1.8 - 2.1 in the third.  The upload has two steps of slack (MCS_E2E_ORDER=upload-first: the former order).
+        upload_first = os.environ.get("MCS_E2E_ORDER", "") == "upload-first"
+        if upload_first:
+            upload((n + NI - 1) % NI)
         t3 = time.perf_counter()
         job.match(b)
         job.matched_set = b
+        if not upload_first:
+            upload((n + NI - 1) % NI)                     # the images of step n + NI - 1 travel while this and the following steps compute (NI = 2: the next step's)
         t4 = time.perf_counter()
         if on_result:
             download_behind_search(k)                     # behind this step's greedy pass: the set leaves during the next step
