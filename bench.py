@@ -1152,7 +1152,7 @@ def run_latency(e, sp, calls=300, py_calls=200):
     tot = np.array(te) + np.array(tm)
     out["python_ctypes"] = {"calls": py_calls, "extract_ms_median": round(float(np.median(te)), 4), "match_ms_median": round(float(np.median(tm)), 4),
                             "total_ms": {"median": round(float(np.median(tot)), 4), "p99": round(float(np.percentile(tot, 99)), 4)},
-                            "what": "the same two calls from Python (numpy buffers allocated per call by Extractor.extract_host, ctypes)"}
+                            "what": "the same two calls from Python (Extractor.extract_host over the extractor's page-locked buffers, the per-image results copied out into numpy arrays; ctypes)"}
     ex.close()
     ctx.close()
     out["oracle_check"] = ok

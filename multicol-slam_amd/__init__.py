@@ -96,8 +96,26 @@ class Extractor:
     def close(self):
         if getattr(self, "h", None):
             if getattr(self.ctx, "h", None):   # mcs_ctx_destroy releases the extractors still alive on it: after that this handle is already gone
+                for p in getattr(self, "_pins", {}).values():
+                    lib().mcs_host_free(self.ctx.h, p[0])
                 lib().mcs_extractor_destroy(self.h)
+            self._pins = {}
             self.h = None
+
+    def _pinned(self, name, dtype, shape):
+        """a page-locked array owned by this extractor (allocated once per name and size, mcs_host_alloc): host-kind calls then upload with one DMA and get
+        their outputs written by one launch instead of one runtime copy per array"""
+        pins = self.__dict__.setdefault("_pins", {})
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ent = pins.get(name)
+        if ent is None or ent[1] < nbytes:
+            if ent is not None:
+                check(lib().mcs_host_free(self.ctx.h, ent[0]))
+            p = C.c_void_p()
+            check(lib().mcs_host_alloc(self.ctx.h, max(nbytes, 64), C.byref(p)))
+            ent = pins[name] = (p, max(nbytes, 64))
+        buf = (C.c_uint8 * nbytes).from_address(ent[0].value)
+        return ent[0], np.frombuffer(buf, np.uint8).view(dtype).reshape(shape)
 
     def __del__(self):
         try:
@@ -114,24 +132,30 @@ class Extractor:
 
     def extract_host(self, images, masks, cams, want_rays=True):
         """images: list/array of HxW uint8; masks: same, None, or "resident" (set_masks); cams: list of Ocam or None.  Returns per-image tuples."""
-        imgs = np.ascontiguousarray(np.stack(images), np.uint8)
-        n, h, w = imgs.shape
-        assert (w, h) == (self.width, self.height)
+        n = len(images)
+        h, w = self.height, self.width
+        p_img, imgs = self._pinned("img", np.uint8, (n, h, w))
+        for i, im in enumerate(images):
+            assert im.shape == (h, w)
+            imgs[i] = im
         if isinstance(masks, str):
             assert masks == "resident"
             m = MASKS_RESIDENT
+        elif masks is None:
+            m = None
         else:
-            m = None if masks is None else np.ascontiguousarray(np.stack(masks), np.uint8)
+            m, mv = self._pinned("mask", np.uint8, (n, h, w))
+            for i, mk in enumerate(masks):
+                mv[i] = mk
         camarr = None
         if cams is not None:
             camarr = (Ocam * n)(*cams)
-        nkp = np.zeros(n, np.int32)
-        kps = np.zeros((n, self.cap), KP_DTYPE)
-        desc = np.zeros((n, self.cap, self.descSize), np.uint8)
-        dmask = np.zeros((n, self.cap, self.descSize), np.uint8)
-        rays = np.zeros((n, self.cap, 3), np.float64) if (want_rays and cams is not None) else None
-        check(lib().mcs_extract_batch(self.h, n, np_ptr(imgs), w * h, w, m if isinstance(m, C.c_void_p) else np_ptr(m), w * h, w, camarr, MEM_HOST, np_ptr(nkp), np_ptr(kps),
-                                      np_ptr(desc), np_ptr(dmask), np_ptr(rays)))
+        p_n, nkp = self._pinned("nkp", np.int32, (n,))
+        p_k, kps = self._pinned("kps", KP_DTYPE, (n, self.cap))
+        p_d, desc = self._pinned("desc", np.uint8, (n, self.cap, self.descSize))
+        p_m, dmask = self._pinned("dmask", np.uint8, (n, self.cap, self.descSize))
+        p_r, rays = self._pinned("rays", np.float64, (n, self.cap, 3)) if (want_rays and cams is not None) else (None, None)
+        check(lib().mcs_extract_batch(self.h, n, p_img, w * h, w, m, w * h, w, camarr, MEM_HOST, p_n, p_k, p_d, p_m, p_r))
         out = []
         for i in range(n):
             k = int(nkp[i])

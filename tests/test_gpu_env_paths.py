@@ -2,7 +2,7 @@
 path per-kernel timing uses), MCS_MATCH_FILL / MCS_MATCH_BLOCKS (train-range splits + k_match_merge even for a deep batch), MCS_DESCRIBE_EXACT=1 (the
 exact descriptor pass for every keypoint), MCS_MATCH_VALU=1 (the v_bcnt matcher instead of the matrix-core one), MCS_MATCH_EXPAND_MB=0 (no room for the
 expanded train sets: the v_bcnt matcher again, chosen by the size check), MCS_PYR_CHAIN=1 (the whole resize chain in one launch, alone and with MCS_NO_OVERLAP), MCS_PYR_TILES=1 (the LDS tile resize kernel that serves
-scale factors above 2 instead of the column-marching one), MCS_LIST_SPLIT=0 (the fast pass's fallbacks by one wave each instead of a workgroup each), MCS_GRAPHS=0 (the launches of a small batch enqueued one by one instead of replayed from a hipGraph), MCS_GREEDY_JACOBI=0 (the chunk-by-chunk greedy pass also for few set pairs, instead of the fixpoint form).  Each is run in a fresh process (the switches are read once) on the same inputs; every output must equal the
+scale factors above 2 instead of the column-marching one), MCS_LIST_SPLIT=0 (the fast pass's fallbacks by one wave each instead of a workgroup each), MCS_GRAPHS=0 (the launches of a small batch enqueued one by one instead of replayed from a hipGraph), MCS_GREEDY_JACOBI=0 (the chunk-by-chunk greedy pass also for few set pairs, instead of the fixpoint form), MCS_OUT_KERNEL=0 (page-locked host outputs — what Extractor.extract_host uses — by the runtime's copies instead of one launch).  Each is run in a fresh process (the switches are read once) on the same inputs; every output must equal the
 default run's, bit for bit."""
 import hashlib
 import os
@@ -60,6 +60,6 @@ def test_run_time_switches_do_not_change_any_output():
     assert nmatch > 1000
     for env in ({"MCS_NO_OVERLAP": "1"}, {"MCS_MATCH_FILL": "100000000", "MCS_MATCH_BLOCKS": "4096"}, {"MCS_DESCRIBE_EXACT": "1"}, {"MCS_MATCH_VALU": "1"},
                 {"MCS_MATCH_VALU": "1", "MCS_MATCH_FILL": "100000000", "MCS_MATCH_BLOCKS": "4096"}, {"MCS_MATCH_EXPAND_MB": "0"}, {"MCS_PYR_CHAIN": "1"},
-                {"MCS_PYR_CHAIN": "1", "MCS_NO_OVERLAP": "1"}, {"MCS_PYR_TILES": "1"}, {"MCS_LIST_SPLIT": "0"}, {"MCS_GRAPHS": "0"}, {"MCS_GREEDY_JACOBI": "0"}):
+                {"MCS_PYR_CHAIN": "1", "MCS_NO_OVERLAP": "1"}, {"MCS_PYR_TILES": "1"}, {"MCS_LIST_SPLIT": "0"}, {"MCS_GRAPHS": "0"}, {"MCS_GREEDY_JACOBI": "0"}, {"MCS_OUT_KERNEL": "0"}):
         got, n = _run(env)
         assert (got, n) == (ref, nmatch), env
