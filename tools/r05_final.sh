@@ -20,6 +20,7 @@ bash tools/ktrace.sh stream > /dev/null 2>&1; cp gpurun_out/ktrace_stream.csv $o
 bash tools/pmc_calibrate.sh > /dev/null 2>&1; cp gpurun_out/pmc_calibration.txt $o/
 python tools/rig_host_bench.py 64 0 40 16 32 10 > $o/rig_host.txt 2>&1
 timeout 200 python tools/agast_time.py 2>/dev/null | tail -1 > $o/agast_time.json
+bash tools/latency_trace.sh > /dev/null 2>&1; cp gpurun_out/latency_trace.txt $o/
 timeout 300 python -m pytest tests/test_gpu_dropin.py -m gpu -q -s -k constructor 2>&1 | grep "cMultiFrame constructor\|passed\|failed" > $o/frame_binding.txt
 python - <<'P'
 import json
