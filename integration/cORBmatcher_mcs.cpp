@@ -9,8 +9,8 @@
 //                   Fuse (pKF, curKF, points) / (pKF, points) / (pKF, Scw, points), and the mbCheckOrientation pass of each search that has one
 //                   SearchByProjection(pKF, Scw, ...) (loop closing): GPU projection + window search, bounds-safe where the reference reads past
 //                   its descriptor matrices (see that function)
-//   not replaced    SearchByProjection(CurrentFrame, pKF, sAlreadyFound, ...): no caller in the reference, and it indexes the keyframe's descriptors
-//                   with the frame's feature indices; it throws.
+//                   SearchByProjection(CurrentFrame, pKF, sAlreadyFound, ...): no caller in the reference; it indexes the keyframe's descriptors
+//                   with the frame's feature indices — reproduced where that is defined (see that function)
 //                   SearchForTriangulation and Fuse(curKF, neighKFs, map) are declared in the header but defined nowhere in the reference.
 // tests/test_gpu_dropin.py builds the reference's cMultiFrame.cpp, cMultiKeyFrame.cpp, cMapPoint.cpp ... around this file and
 // mdBRIEFextractorOct_mcs.cpp and compares every search with the all-reference build.
@@ -786,9 +786,84 @@ int cORBmatcher::SearchByProjection(cMultiKeyFrame* pKF, cv::Matx44d Scw, const 
 	return nmatches;
 }
 
-// ---- not replaced: no caller and no defined behaviour to reproduce -------------------------------------------------------------------------------
-// SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:2120-2263) has NO caller in the reference (cTracking::Relocalisation's calls are
-// commented out) and indexes the KEYFRAME's descriptor rows with the current frame's feature indices (:2196-2197).  Its search loop is
-// mcs_window_best (skip_taken = 1); the entry point itself is left to the reference's own body.
-int cORBmatcher::SearchByProjection(cMultiFrame&, cMultiKeyFrame*, const std::set<cMapPoint*>&, double, int) { not_replaced("SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)"); }
+// ---- SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:2120-2263): no caller in the reference (cTracking::Relocalisation's calls are commented out) ----
+// Every good map point of the keyframe that is not in sAlreadyFound is projected into EVERY camera of the current frame's rig (pose of the frame); inside the mirror
+// mask it gets a window of radius th * scale(predicted level) over the levels predicted - 1 .. predicted + 1, features that already hold a map point are skipped, the
+// nearest one wins if its distance is <= ORBdist and is taken at once: mcs_window_best with skip_taken = 1, probes in the reference's order (point, then camera).
+// One peculiarity of the reference body is kept: the descriptor compared for feature i2 of the CURRENT FRAME is the KEYFRAME's row
+// pKF->GetDescriptorRowPtr(cam, pKF->cont_idx_to_local_cam_idx[i2]) (:2196-2197) — the frame's feature index looked up in the keyframe's index map, the row taken from the
+// probe camera's matrix.  Where that is defined (i2 is a feature index of the keyframe and the local index is a row of that camera's matrix) it is reproduced literally; where
+// the reference dereferences end() or reads past the matrix, the frame feature's own row is used (the evident intent).  mbCheckOrientation through mcs_rotation_consistency.
+int cORBmatcher::SearchByProjection(cMultiFrame& CurrentFrame, cMultiKeyFrame* pKF, const std::set<cMapPoint*>& sAlreadyFound, double th, int ORBdist)
+{
+	cMultiCamSys_& camSys = CurrentFrame.camSystem;
+	cv::Matx44d Tcurr = CurrentFrame.GetPose();
+	const cv::Matx33d Rcw = Tcurr.get_minor<3, 3>(0, 0);
+	const cv::Vec3d tcw(Tcurr(0, 3), Tcurr(1, 3), Tcurr(2, 3));
+	const cv::Vec3d Ow = -Rcw.t() * tcw;
+	const int dim = mbFeatDim, nr = camSys.GetNrCams();
+	const bool masks = havingMasks;
+	Flat b = flatten(CurrentFrame, dim, masks);
+	vector<cMapPoint*> vpMPs = pKF->GetMapPointMatches();
+	std::vector<double> pts; std::vector<int32_t> pc, owner;
+	for (int i = 0, iend = (int)vpMPs.size(); i < iend; ++i)
+	{
+		cMapPoint* pMP = vpMPs[i];
+		if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+		cv::Vec3d X = pMP->GetWorldPos();
+		for (int cam = 0; cam < nr; ++cam) { pts.push_back(X(0)); pts.push_back(X(1)); pts.push_back(X(2)); pc.push_back(cam); owner.push_back(i); }
+	}
+	if (owner.empty() || b.n == 0) return 0;
+	std::vector<double> uv; std::vector<uint8_t> fl;
+	project(camSys, pts, pc, uv, fl);
+	Probes p;
+	for (size_t k = 0; k < owner.size(); ++k)
+	{
+		if (!(fl[k] & 1)) continue;
+		cMapPoint* pMP = vpMPs[owner[k]];
+		const double minDistance = pMP->GetMinDistanceInvariance();
+		cv::Vec3d PO = pMP->GetWorldPos() - Ow;
+		const double dist3D = cv::norm(PO);
+		const double ratio = dist3D / minDistance;
+		vector<double>::iterator it = std::lower_bound(CurrentFrame.mvScaleFactors.begin(), CurrentFrame.mvScaleFactors.end(), ratio);
+		const int nPredictedLevel = std::min(static_cast<int>(it - CurrentFrame.mvScaleFactors.begin()), CurrentFrame.mnScaleLevels - 1);
+		p.add(uv[2 * k], uv[2 * k + 1], th * CurrentFrame.mvScaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel + 1, pc[k], owner[k]);
+		const uchar* dp = (const uchar*)pMP->GetDescriptorPtr();
+		p.d.insert(p.d.end(), dp, dp + dim);
+		if (masks) { const uchar* mp = (const uchar*)pMP->GetDescriptorMaskPtr(); p.m.insert(p.m.end(), mp, mp + dim); }
+	}
+	if (p.x.empty()) return 0;
+	// the frame's features with the row the reference compares for each of them (see above)
+	{
+		Flat kf = flatten(pKF, dim, masks);
+		std::vector<int> rowsOfCam(nr, 0);
+		for (int i = 0; i < kf.n; ++i) ++rowsOfCam[kf.cam[i]];
+		for (int i2 = 0; i2 < b.n; ++i2)
+		{
+			std::unordered_map<size_t, int>::const_iterator it = pKF->cont_idx_to_local_cam_idx.find(i2);
+			const int c = b.cam[i2];
+			if (it == pKF->cont_idx_to_local_cam_idx.end() || it->second < 0 || it->second >= rowsOfCam[c]) continue;   // undefined in the reference: the feature's own row stays
+			std::memcpy(&b.d[(size_t)i2 * dim], pKF->GetDescriptorRowPtr(c, it->second), dim);
+			if (masks) std::memcpy(&b.m[(size_t)i2 * dim], pKF->GetDescriptorMaskRowPtr(c, it->second), dim);
+		}
+	}
+	std::vector<uint8_t> taken(b.n);
+	for (int i2 = 0; i2 < b.n; ++i2) taken[i2] = CurrentFrame.mvpMapPoints[i2] != NULL;
+	mcs_window_probes pr = p.c(dim, masks);
+	mcs_frame_view fv = view(b, taken.data(), dim, masks);
+	std::vector<int32_t> match(p.x.size(), -1), mcur(b.n, -1);
+	int32_t n = 0;
+	check(mcs_window_best(ctx(), &pr, &fv, ORBdist, 1, dim, MCS_MEM_HOST, match.data(), nullptr, &n), "mcs_window_best");
+	for (size_t k = 0; k < match.size(); ++k) if (match[k] >= 0) mcur[match[k]] = p.src[k];
+	if (mbCheckOrientation)
+	{
+		Flat kf = flatten(pKF, dim, false);
+		int32_t removed = 0;
+		check(mcs_rotation_consistency(ctx(), 0, &b.keys[0].angle, sizeof(mcs_keypoint), &kf.keys[0].angle, sizeof(mcs_keypoint), nullptr, mcur.data(), b.n, kf.n, 1,
+			MCS_MEM_HOST, &removed), "mcs_rotation_consistency");
+		n -= removed;
+	}
+	for (int i2 = 0; i2 < b.n; ++i2) if (mcur[i2] >= 0) CurrentFrame.mvpMapPoints[i2] = vpMPs[mcur[i2]];
+	return n;
+}
 }

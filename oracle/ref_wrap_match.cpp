@@ -362,6 +362,22 @@ extern "C" int rs_proj_scw(void* h, int kTarget, int kSource, int nList, const d
 		return n;
 	} catch (const std::exception& e) { std::cerr << "rs_proj_scw: " << e.what() << std::endl; return -1; }
 }
+// SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (src/cORBmatcher.cpp:2120-2263, no caller in the reference).  sAlreadyFound = the map points of
+// keyframe k at the feature indices found[0..nFound).  curIds[i] = id of the frame's mvpMapPoints[i] afterwards.  The caller keeps the scene inside what the reference
+// defines (it looks every candidate feature index of the FRAME up in the KEYFRAME's index map and reads that row of the probe camera's matrix, :2196-2197).
+extern "C" int rs_proj_kf(void* h, int f, int k, double th, int orbDist, int checkOri, const int* found, int nFound, int* curIds) {
+	Scene* s = (Scene*)h;
+	try {
+		cORBmatcher m(0.8, checkOri != 0, s->dim, s->masks);
+		std::vector<cMapPoint*> mps = s->kfs[k]->GetMapPointMatches();
+		std::set<cMapPoint*> already;
+		for (int i = 0; i < nFound; ++i) if (found[i] >= 0 && found[i] < (int)mps.size() && mps[found[i]]) already.insert(mps[found[i]]);
+		const int n = m.SearchByProjection(*s->frames[f], s->kfs[k], already, th, orbDist);
+		cMultiFrame* F = s->frames[f];
+		for (size_t i = 0; i < F->totalN; ++i) curIds[i] = id_or_minus1(s, F->mvpMapPoints[i]);
+		return n;
+	} catch (const std::exception& e) { std::cerr << "rs_proj_kf: " << e.what() << std::endl; return -1; }
+}
 // SearchForTriangulationBetweenCameras(pKF, cam1, cam2, ...) (:1158-1263, no caller in the reference): match12[idx1] = idx2 or -1
 extern "C" int rs_tri_between(void* h, int k, int cam1, int cam2, int* match12) {
 	Scene* s = (Scene*)h;

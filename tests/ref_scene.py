@@ -46,6 +46,8 @@ class RefScene:
             L.rs_sim3.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp, vp, C.c_double, vp, vp]
             L.rs_tri_between.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
             L.rs_proj_scw.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp]
+            if hasattr(L, "rs_proj_kf"):
+                L.rs_proj_kf.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, vp, C.c_int, vp]
         L.rs_destroy.argtypes = [vp]
         self.nr = len(cams)
         self.prm = O.make_params(**params)

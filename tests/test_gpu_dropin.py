@@ -228,6 +228,23 @@ def _script(so, cams, masks, M_c, voc, params, imgs, poses):
         for th in (10, 4):
             cnt = S.L.rs_proj_scw(S.h, k1, k0, n_list, Scw.ctypes.data, th, pre.ctypes.data, ids.ctypes.data)
             R["proj_scw_%s_%d" % (name, th)] = (cnt, ids.copy())
+    # SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (no caller in the reference): keyframe 0's map points into frame 1.  The reference looks every
+    # candidate FRAME feature index up in the KEYFRAME's index map and reads that row of the probe camera's matrix; the check below keeps the scene where that is
+    # defined: the few frame features it is not defined for are given a map point beforehand (the search skips such features)
+    cnt0 = np.bincount(fr[0]["cam"].astype(np.int64), minlength=NC)
+    first0 = np.concatenate([[0], np.cumsum(cnt0)[:-1]])
+    idx = np.arange(n1)
+    kfcam = np.minimum(np.searchsorted(np.cumsum(cnt0), idx, side="right"), NC - 1)
+    undefined = (idx >= n0) | (idx - first0[kfcam] >= cnt0[fr[1]["cam"].astype(np.int64)])      # frame features whose keyframe row the reference reads out of bounds
+    R["proj_kf_undefined"] = (int(undefined.sum()), np.zeros(1, np.int32))
+    if hasattr(S.L, "rs_proj_kf"):
+        for ori, th, od in ((0, 15.0, 100), (1, 15.0, 100), (0, 6.0, 50)):
+            pre = ((rng.random(n1) < 0.1) | undefined).astype(np.uint8)                       # ... hold a map point already: the search skips them before it reads their rows
+            S.set_mappoints(False, 1, pre, base=800000, ref_kf=k0)
+            found = np.sort(rng.choice(n0, 60, replace=False)).astype(np.int32)
+            ids = np.zeros(n1, np.int32)
+            cnt = S.L.rs_proj_kf(S.h, 1, k0, th, od, ori, found.ctypes.data, len(found), ids.ctypes.data)
+            R["proj_kf_%d_%g" % (ori, th)] = (cnt, ids.copy())
     # the three Fuse overloads with whole lists: keyframe 0's map points into keyframe 1 (Replace / AddObservation surgery), each on the state the one before left
     for variant, th in ((0, 2.5), (1, 2.5), (2, 4.0), (0, 10.0)):
         idsT, idsS, bad = np.zeros(n1, np.int32), np.zeros(n0, np.int32), np.zeros(n0, np.uint8)
@@ -264,7 +281,7 @@ def test_reference_objects_over_the_gpu_matcher(mode, tmp_path):
         for key in ("keys", "desc", "mask", "cam", "rays", "node", "grid_inv", "cell"):
             assert np.array_equal(ref["frames"][f][key], gpu["frames"][f][key]), (f, key)
     floor = dict(kfkf=50, kff0=30, tri0=5, win_60_0_0=20, init_100_0=20, proj_mp=30, proj_last0=20, proj_frames=10, fuse_probes=15)
-    floor.update({"fuse0_2.5": 50, "fuse1_2.5": 5, "fuse2_4": 5, "sim3_1": 5, "tri_between_01": 3, "proj_scw_taken0_10": 30, "proj_scw_free0_10": 30})
+    floor.update({"fuse0_2.5": 50, "fuse1_2.5": 5, "fuse2_4": 5, "sim3_1": 5, "tri_between_01": 3, "proj_scw_taken0_10": 30, "proj_scw_free0_10": 30, "proj_kf_0_15": 30})
     for key in ref:
         if key == "frames":
             continue
