@@ -253,6 +253,7 @@ struct mcs_extractor {
 	// hipGraphs of the in-order launch sequence (small batches, extract_impl): keyed by the kernels' arguments
 	struct Graph { ExtractBuffers key; int nimg; hipGraphExec_t exec; };
 	std::vector<Graph> graphs;
+	long graphHits = 0, graphMisses = 0;   // a caller that rotates through more argument sets than the cache holds would re-capture on every call: replay is given up then
 };
 
 extern "C" {
@@ -875,6 +876,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 	// Small batches run IN ORDER on the context's stream (round 5): the forks pay for themselves only when the kernels are long — for ONE 3-camera multi-frame the
 	// kernels take 5-50 us each, and every cross-stream event costs about as much as one of them (extraction of 3 images: 0.33 -> 0.29 ms).
 	const bool forked = c->overlap() && (long long)nimg * hd.width * hd.height >= 4000000ll;
+	bool replayed = false;   // the whole launch sequence, descriptor stage included, came from a graph
 	if (forked) {
 		// Two chains until the descriptors: the side stream runs the resize chain (7 dependent, latency-bound launches) and then the blur, which needs
 		// nothing else; the main stream starts FAST on level 0 — the input image itself, a third of all FAST work — at once, picks up the other levels
@@ -922,12 +924,13 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		// beside FAST and the resize chain: measured, 2.22 -> 2.55 ms per step — the descriptor kernel on the critical path suffers more from the company)
 		launch_octree(b, hd, nimg, s);   // (oct-trees of levels 0 / 1 on a further stream beside FAST of the rest: measured, no gain)
 		HIPCHK(hipStreamWaitEvent(s, c->evBlur, 0));
-	} else if (!c->timing && use_graphs()) {
+	} else if (!c->timing && use_graphs() && !(e->graphMisses > 8 && e->graphMisses > e->graphHits)) {
 		// ONE multi-frame per call is launch-bound: a dozen dependent kernels of 4 - 50 us each, most of them shorter than the host takes to enqueue the next.  The
 		// sequence is captured once per argument set into a hipGraph and replayed (the copies in and out stay ordinary stream operations around it).
 		hipGraphExec_t exec = nullptr;
 		for (mcs_extractor::Graph& g : e->graphs)
 			if (g.nimg == nimg && memcmp(&g.key, &b, sizeof(b)) == 0) exec = g.exec;
+		if (exec) ++e->graphHits; else ++e->graphMisses;
 		if (!exec) {
 			hipGraph_t graph = nullptr;
 			HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
@@ -943,6 +946,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 			e->graphs.push_back(mcs_extractor::Graph{b, nimg, exec});
 		}
 		HIPCHK(hipGraphLaunch(exec, s));
+		replayed = true;
 	} else {
 		c->tic("pyramid"); launch_pyramid(b, hd, nimg, s); c->toc("pyramid");
 		c->tic("fast"); launch_fast(b, hd, nimg, s); c->toc("fast");
@@ -950,7 +954,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		c->tic("blur"); launch_blur(b, hd, nimg, s); c->toc("blur");
 	}
 	if (forked) { b.sideStream = c->side; b.evDescFork = c->evDescFork; b.evDescJoin = c->evDescJoin; }   // the side stream is idle again: the main stream has waited for the blur
-	if (forked || c->timing || !use_graphs()) { c->tic("describe"); launch_describe(b, hd, nimg, s); c->toc("describe"); }
+	if (!replayed) { c->tic("describe"); launch_describe(b, hd, nimg, s); c->toc("describe"); }
 	HIPCHK(hipGetLastError());
 	e->last = b; e->lastN = nimg;
 	if (kind == MCS_MEM_HOST) {
