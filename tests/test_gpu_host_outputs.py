@@ -60,6 +60,22 @@ def test_resident_masks_and_page_locked_outputs(G, mode):
     ex.close()
 
 
+def test_orb_without_cameras_and_too_few_resident_masks(G):
+    """ORB needs no camera model: no rays array, the page-locked outputs still leave by one launch; MCS_MASKS_RESIDENT for more images than masks were set is refused"""
+    imgs, masks, cams = G.frame_inputs(3)
+    ex = G.mcs.Extractor(G.ctx(), 754, 480, max_batch=3, nfeatures=500)
+    want = ex.extract_host(imgs, masks, [G.mcs.make_ocam(c) for c in cams])
+    got = ex.extract_host(imgs, masks, None)
+    for (k, d, m, r), (wk, wd, wm, wr) in zip(got, want):
+        assert r is None and G.first_diff(k, wk) is None and G.first_diff(d, wd) is None and G.first_diff(m, wm) is None
+    ex.set_masks(masks[:2])
+    two = ex.extract_host(imgs[:2], "resident", None)
+    assert all(G.first_diff(a[0], b[0]) is None and G.first_diff(a[1], b[1]) is None for a, b in zip(two, want[:2]))
+    with pytest.raises(G.mcs.McsError):
+        ex.extract_host(imgs, "resident", None)                      # three images, two resident masks
+    ex.close()
+
+
 def test_search_outputs_in_page_locked_arrays(G):
     """mcs_search_kf_kf with host buffers: page-locked match / count / rescan arrays are filled by one launch; same numbers as the pageable call"""
     cap = __import__("importlib").import_module("multicol-slam_amd._capi")
