@@ -526,6 +526,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 #ifndef MCS_JAC_EXT
 #define MCS_JAC_EXT 4
 #endif
+constexpr int kJacBatch = 4;   // undecidable queries rescanned per pass over the train rows
 constexpr int kJacOwn = 3, kJacExt = MCS_JAC_EXT;   // queries per thread whose list entries 8 .. 8 + kJacExt - 1 sit in registers (sets of up to 3072 queries: all of them)
 constexpr int kJacThreads = 1024, kJacCache = 8;   // list entries per query kept in LDS (a walk beyond them reads the list in memory: a dependent round trip per entry)
 __host__ __device__ constexpr size_t jacobi_lds_words(int nq, int nt, int K) { return (size_t)2 * nt + nq + (size_t)(K < kJacCache ? K : kJacCache) * nq + nq; }
@@ -690,6 +691,72 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 		const bool pass = r1 != EMPTY && (g.thInclusive ? best <= g.thLow : best < g.thLow);
 		return (pass && static_cast<double>(best) < g.ratio * static_cast<double>(second)) ? (int)(r1 & 0xFFFFFu) : -1;
 	};
+	// the same for up to kJacBatch undecidable queries in ONE pass over the train rows (a row is loaded once and compared with every query of the batch; one pair of
+	// barriers for all of them): calls with a handful of such queries paid 9 us for each
+	__shared__ uint32_t bq[kJacBatch][2 * DW];
+	__shared__ int bqi[kJacBatch], bgrp[kJacBatch], bres[kJacBatch];
+	__shared__ uint32_t bpart[kJacBatch][kJacThreads / 64][2];
+	auto rescan_batch = [&](const uint32_t* own, uint32_t tag, const int* ql, int nb) {   // results in bres[0 .. nb)
+		for (int x = tid; x < nb * 2 * DW; x += kJacThreads) {
+			const int bb = x / (2 * DW), w = x - bb * 2 * DW, qi = ql[bb];
+			bq[bb][w] = w < DW ? reinterpret_cast<const uint32_t*>(g.qd + QR(qi) * g.qstride)[w]
+			                   : (MASKED ? reinterpret_cast<const uint32_t*>(g.qm + QR(qi) * g.qstride)[w - DW] : 0u);
+		}
+		if (tid < nb) { bqi[tid] = ql[tid]; bgrp[tid] = grouped ? g.qgroup[QR(ql[tid])] : 0; }
+		__syncthreads();
+		uint32_t a[kJacBatch], b2[kJacBatch];
+#pragma unroll
+		for (int bb = 0; bb < kJacBatch; ++bb) { a[bb] = EMPTY; b2[bb] = EMPTY; }
+		const bool wide = DW % 4 == 0 && ((((uintptr_t)g.td | (uintptr_t)(MASKED ? g.tm : g.td)) | (uintptr_t)g.tstride) & 15u) == 0;
+		for (int j = tid; j < g.nt; j += kJacThreads) {
+			const uint8_t* tb = g.td + TR(j) * g.tstride;
+			const uint8_t* mb = MASKED ? g.tm + TR(j) * g.tstride : tb;
+			uint32_t tw[DW], mw[DW];
+			if (wide) {
+#pragma unroll
+				for (int w = 0; w < DW / 4; ++w) {
+					const uint4 v = reinterpret_cast<const uint4*>(tb)[w];
+					tw[4 * w] = v.x; tw[4 * w + 1] = v.y; tw[4 * w + 2] = v.z; tw[4 * w + 3] = v.w;
+					if (MASKED) { const uint4 u = reinterpret_cast<const uint4*>(mb)[w]; mw[4 * w] = u.x; mw[4 * w + 1] = u.y; mw[4 * w + 2] = u.z; mw[4 * w + 3] = u.w; }
+				}
+			} else {
+#pragma unroll
+				for (int w = 0; w < DW; ++w) { tw[w] = reinterpret_cast<const uint32_t*>(tb)[w]; if (MASKED) mw[w] = reinterpret_cast<const uint32_t*>(mb)[w]; }
+			}
+			const uint32_t v = own[j];
+			const bool valid = g.tvalid ? g.tvalid[TR(j)] != 0 : true;
+			const int tg = grouped ? g.tgroup[TR(j)] : 0;
+#pragma unroll
+			for (int bb = 0; bb < kJacBatch; ++bb) {
+				if (bb < nb) {
+					const bool ok = valid && !((v >> 16) == tag && (v & 0xFFFFu) < (uint32_t)bqi[bb]) && (!grouped || tg == bgrp[bb]);
+					const uint32_t k = ok ? (((uint32_t)hamming_g<DW, MASKED>(bq[bb], bq[bb] + DW, tw, MASKED ? mw : tw) << 20) | (uint32_t)j) : EMPTY;
+					if (k < a[bb]) { b2[bb] = a[bb]; a[bb] = k; } else if (k < b2[bb]) b2[bb] = k;
+				}
+			}
+		}
+#pragma unroll
+		for (int bb = 0; bb < kJacBatch; ++bb) {
+			if (bb < nb) {
+				const uint32_t m1 = wave_min_u32(a[bb]);
+				const uint32_t m2 = wave_min_u32(a[bb] == m1 ? b2[bb] : a[bb]);
+				if (lane == 0) { bpart[bb][wave][0] = m1; bpart[bb][wave][1] = m2; }
+			}
+		}
+		__syncthreads();
+		if (tid < nb) {
+			uint32_t r1 = EMPTY, r2 = EMPTY;
+			for (int w = 0; w < kJacThreads / 64; ++w) {
+				const uint32_t pa = bpart[tid][w][0], pb = bpart[tid][w][1];
+				if (pa < r1) { r2 = r1; r1 = pa; } else if (pa < r2) r2 = pa;
+				if (pb < r2) r2 = pb;
+			}
+			const int best = r1 == EMPTY ? 0x7FFFFFFF : (int)(r1 >> 20), second = r2 == EMPTY ? 0x7FFFFFFF : (int)(r2 >> 20);
+			const bool pass = r1 != EMPTY && (g.thInclusive ? best <= g.thLow : best < g.thLow);
+			bres[tid] = (pass && static_cast<double>(best) < g.ratio * static_cast<double>(second)) ? (int)(r1 & 0xFFFFFu) : -1;
+		}
+		__syncthreads();
+	};
 	// sweep t reads the claims of buffer t & 1 made with tag t (none for t = 0: every row free) and writes the claims of the new outcomes into the other buffer
 	int nfallback = 0;
 	uint32_t t = 0;
@@ -740,7 +807,16 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 				settle(i);
 			}
 		} else {
-			for (int k = 0; k < nr; ++k) settle(rescanQ[slot][k]);
+			for (int k0 = 0; k0 < nr; k0 += kJacBatch) {
+				const int nb = min(kJacBatch, nr - k0);
+				rescan_batch(nxt, ntag, &rescanQ[slot][k0], nb);
+				for (int k = 0; k < nb; ++k) {   // (uniform: every thread sees the same old and new outcome)
+					const int qi = rescanQ[slot][k0 + k], na = bres[k], old = A[qi];
+					__syncthreads();
+					if (na != old) { any = true; if (tid == 0) A[qi] = na; }
+				}
+				__syncthreads();   // (bres and the queue entries are read before the next batch overwrites them)
+			}
 			nfallback = nr;
 		}
 		__syncthreads();
