@@ -52,6 +52,7 @@ import numpy as np  # noqa: E402
 MODES = {"orb": (0, 0), "dbrief": (1, 0), "mdbrief": (1, 1)}
 KERNELS = ("pyramid", "fast", "octree", "blur", "describe", "match", "greedy")
 E2E_H2D, E2E_D2H = "runtime", "2"   # how the e2e leg moves its page-locked buffers unless MCS_E2E_H2D / MCS_E2E_D2H say otherwise (run_e2e): the runtime's SDMA copy in, mcs_copy_narrow with TWO workgroups out (they saturate the link's write direction; more of them stall every other kernel's memory traffic)
+TIE_SLOTS = 256   # entries per capture slot of the in-loop tie enforcement (the default band lists about one keypoint per 64-multi-frame step)
 POOL = 64   # distinct synthetic multi-frames the stream cycles through: 8 scenes of 8 frames each ((3,1)-px shifts), synth.stream_image
 WORKLOADS = {
     #          ncam  W     H    nfeat  F/GPU  keyframes  name in BASELINE.json
@@ -376,9 +377,11 @@ class Job:
         self.d_imgs = [torch.from_numpy(self.imgs_np).to(dev) for _ in range(n_image_buffers)]
         self.d_masks = torch.from_numpy(self.masks_np).to(dev)
         self.camarr = (mcs.Ocam * lay.L)(*[mcs.make_ocam(self.cams[c]) for c, _ in slab])
-        # Buffer sets in rotation: the matcher of step n (library side stream) runs beside the extraction of step n + 1.  Two sets when a step extracts
-        # and matches the same set (N = 1); three when the matcher runs one step late (N > 1: behind the exchange; the host-buffer leg: outputs leave late).
-        self.nsets = n_sets or (3 if e.exchange else 2)
+        # Buffer sets in rotation.  Every leg runs the same pipelined order (round 6): a call extracts set n, then — on the host — waits for the capture event of
+        # set n - 1 only, recomputes that batch's rounding-tie keypoints with the host's libm and patches its device rows (mcs_extractor_patch_ties), and only
+        # then enqueues the exchange and the (deferred) search of set n - 1, which run beside the extraction of set n.  Three sets: being extracted, being
+        # exchanged / matched, still read by the search issued one call earlier.
+        self.nsets = n_sets or 3
         self.sets = [self._make_set() for _ in range(self.nsets)]
         self.cur = 0
         # stored keyframes of this rank (database sweeps): contiguous sets of ncam*cap rows, filled once from an untimed pass
@@ -394,10 +397,19 @@ class Job:
         # set is reused gives back the ordering a single stream would have had (include/mcs_c.h: mcs_ctx_set_async_search)
         self.async_search = os.environ.get("MCS_BENCH_ASYNC_SEARCH", "1") != "0"
         mcs.check(e.lib.mcs_ctx_set_async_search(e.ctx.h, 1 if self.async_search else 0))
-        if e.exchange:   # prime the pipeline: the first step() matches the multi-frames exchanged here
+        # rounding ties are enforced INSIDE the loop: a capture slot per buffer set; MCS_BENCH_TIE_BAND widens the band (tests: 2e-4 px lists every fallback)
+        self.ties_in_loop = os.environ.get("MCS_BENCH_TIES_IN_LOOP", "1") != "0"
+        self.ties_listed = self.ties_patched = 0
+        if os.environ.get("MCS_BENCH_TIE_BAND"):
+            self.ex.set_tie_band(float(os.environ["MCS_BENCH_TIE_BAND"]))
+        if self.ties_in_loop:
+            self.ex.set_tie_capture(self.nsets, TIE_SLOTS)
+        # prime the pipeline: the first step() patches, exchanges and matches the multi-frames extracted here
+        self.extract(self.sets[self.nsets - 1])
+        if e.exchange:
             done = watchdog(int(os.environ.get("MCS_BENCH_EXCHANGE_TIMEOUT", "60")), "the first descriptor exchange (%s)" % ("point-to-point ring" if self.ring else "all-gather"))
             try:
-                self.extract_and_exchange(self.sets[self.nsets - 1])
+                self.step()
                 torch.cuda.synchronize(dev)
                 done()
             except (RuntimeError, TypeError, ValueError) as ex:
@@ -407,12 +419,14 @@ class Job:
                 # all-gather, which delivers a superset of what the ring exchange would; said in the output (config.parallelism names the form used)
                 print("bench.py: ring exchange unavailable (%s: %s), using the all-gather" % (type(ex).__name__, str(ex)[:200]), file=sys.stderr)
                 self.ring, self.view = None, lay
+                torch.cuda.synchronize(dev)
                 self.sets = [self._make_set() for _ in range(self.nsets)]
                 self.matched_set = self.sets[0]
-                self.extract_and_exchange(self.sets[self.nsets - 1])
+                self.cur = 0
+                self.extract(self.sets[self.nsets - 1])
+                self.step()
                 torch.cuda.synchronize(dev)
                 done()
-            self.sets[self.nsets - 1].work = "done"
 
     def _make_set(self):
         torch, lay, dev, e = self.e.torch, self.lay, self.e.dev, self.e
@@ -494,7 +508,10 @@ class Job:
         """untimed: the stored keyframes are earlier multi-frames of the same synthetic stream (keyframe k = multi-frame k % frames_total of one pass)"""
         torch, lay = self.e.torch, self.lay
         b = self.sets[0]
-        self.extract_and_exchange(b)
+        self.extract(b)
+        torch.cuda.synchronize(self.e.dev)
+        self.ex.fix_ties()               # the stored keyframes' rows are the host libm's too (synchronous form: this pass is untimed)
+        self.exchange_end(b, self.exchange_begin(b))
         torch.cuda.synchronize(self.e.dev)
         rows = b.G.view(lay.images_total, lay.rows_img, lay.row_stride)
         val = b.valid.view(lay.images_total, lay.rows_img)
@@ -519,27 +536,26 @@ class Job:
             mcs.check(lib.mcs_search_kf_f_sweep(e.ctx.h, self.nkf, C.byref(kf), lay.rows_frame, self.FT, C.byref(fr), lay.rows_img, 32, 0.9, sp.topk,
                                                 mcs.MEM_DEVICE, C.c_void_p(b.match.data_ptr()), C.c_void_p(b.nmatch.data_ptr()), C.c_void_p(b.fb.data_ptr())))
 
+    def patch(self, back=1):
+        """the rounding-tie keypoints of the batch extracted `back` calls ago: recomputed on the host, the device rows patched (waits for that batch only)"""
+        if self.ties_in_loop:
+            listed, fixed = self.ex.patch_ties(back)
+            self.ties_listed += listed
+            self.ties_patched += fixed
+
     def step(self, img_buf=0):
-        """One step.  N = 1: extract, match.  N > 1: extract this step's slab, START its all-gather, then finish the exchange of the PREVIOUS step's slab
-        (its collective had a whole step to complete) and match those multi-frames — one extraction, one exchange and one matching pass per call, the
-        all-gather hidden behind a step's worth of kernels (results one step late)."""
+        """One step = one extraction, one exchange, one matching pass per call, pipelined: enqueue the extraction of this step's slab; wait (host) for the
+        PREVIOUS step's capture event and patch its rounding-tie rows; start that slab's exchange (N > 1; the collective runs beside this step's kernels) and,
+        stream-ordered behind it, match those multi-frames on the deferred streams.  The device never waits for the host: when the previous extraction ends,
+        this one is already queued.  Results one step late."""
         b = self.sets[self.cur]
-        prev = self.sets[(self.cur - 1) % self.nsets]
+        p = self.sets[(self.cur - 1) % self.nsets]   # the set extracted in the previous call
         self.cur = (self.cur + 1) % self.nsets
-        # the search that last read b is the one issued before the latest (two sets, N = 1: step n - 2; three sets, N > 1: the matcher of step n - 2,
-        # which read the set extracted in step n - 3)
+        # the search that last read b is the one issued before the latest (the matcher of call n - 2 read the set extracted in call n - 3)
         self.e.mcs.check(self.e.lib.mcs_ctx_search_fence(self.e.ctx.h, 1))
-        if not self.e.exchange:
-            self.extract_and_exchange(b, img_buf)
-            self.match(b)
-            self.matched_set = b
-            return b
         self.extract(b, img_buf)
-        b.work = self.exchange_begin(b)  # in flight until the NEXT call needs it
-        p = prev                         # the set extracted in the previous call: finish its exchange, then match it
-        if getattr(p, "work", "done") != "done":
-            self.exchange_end(p, p.work)
-            p.work = "done"
+        self.patch(1)
+        self.exchange_end(p, self.exchange_begin(p))
         self.match(p)
         self.matched_set = p
         return b
@@ -637,10 +653,8 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True, check=True):
     job.step()
     exact_kp = job.ex.describe_stats()[0] - x0   # keypoints the guarded fast descriptor pass handed to the exact pass in one (untimed) step
     tie = job.ex.tie_stats()                     # the run's closest approach of an exact-arithmetic cvRound argument to a rounding tie (pixels)
-    # ties are ENFORCED at the host boundary (mcs_extract_batch with host buffers recomputes the listed keypoints with the host's libm before it returns); this leg keeps
-    # its outputs on the device and consumes them on-stream, so it COUNTS the keypoints the device listed over all its steps (expected ~3e-4 per step at the default band)
-    # and patches the last step's rows — the ones the oracle check reads — through mcs_extractor_fix_ties
-    tie_fixed = job.ex.fix_ties()
+    # ties are ENFORCED inside the loop (round 6): every step patched the previous step's listed rows on the host before that set's exchange and search were
+    # enqueued (Job.step), so every row any timed search consumed is the host libm's — listed == patched over all steps is the statement
     tie_listed, _, tie_band = job.ex.tie_counts()
     feats_local = job.local_features()
     pairs_local = job.pairs_per_step_local()
@@ -651,6 +665,10 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True, check=True):
     _, pairs_all = e.rig.reduce_timing(elapsed, pairs_local, e.red_dev, e.world)
     elapsed_min = -e.rig.reduce_timing(-elapsed, 0, e.red_dev, e.world)[0]   # the fastest rank (max of the negated times)
     checked = check_against_oracle(e, sp, job) if (check and e.rank == 0) else None   # before the per-kernel passes: the output of the timed configuration
+    if check and e.rank == 0 and not e.exchange and sp.D == 0:
+        # host copies of the set the loop matched last: main() compares ALL multi-frames and pairs of the CPU-baseline sample with it (check_full)
+        lb = job.last()
+        job.snapshot = {k: getattr(lb, k).cpu().numpy() for k in ("G", "kps", "match", "nmatch")}
     kern = kernel_times(e, job.step) if want_roofline else None   # every rank: step() contains the collective
     roof = roofline_block(sp, job, kern, feats_local, pairs_local) if (want_roofline and e.rank == 0) else None
     value = feats_all * steps / elapsed_max / 1e6
@@ -665,7 +683,8 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True, check=True):
            # device libm vs the reference's can only round a coordinate differently within ~1e-13 px of a tie: this run's margin, measured over every cvRound
            # argument of the exact arithmetic (all warm-up and timed steps); null if no exact-arithmetic coordinate occurred
            "min_distance_to_a_rounding_tie_px_rank0": (tie if tie != float("inf") else None),
-           "rounding_tie_band_px": tie_band, "keypoints_listed_within_the_band_all_steps_rank0": int(tie_listed), "recomputed_on_the_host_last_step_rank0": int(tie_fixed),
+           "rounding_tie_band_px": tie_band, "keypoints_listed_within_the_band_all_steps_rank0": int(tie_listed),
+           "ties_patched_in_loop": bool(job.ties_in_loop), "ties_listed_at_patch_time_rank0": int(job.ties_listed), "ties_recomputed_on_the_host_in_loop_rank0": int(job.ties_patched),
            "n_ranks": e.world, "collective_backend": e.backend, "tag": sp.tag,
            "ms_per_step_slowest_rank": round(elapsed_max / steps * 1e3, 4), "ms_per_step_fastest_rank": round(elapsed_min / steps * 1e3, 4),
            "exchange_bytes_received_per_rank_per_step": (0 if not e.exchange else job.ring.bytes_received(e.rank) if job.ring else job.lay.send_bytes * (e.world - 1)),
@@ -746,21 +765,11 @@ def run_e2e(e, sp, steps, warmup, check=True):
             travel(job.d_imgs[i], h_img[i], wg_in, cin)
             ev_in[i].record(cin)
 
-    def download(k):   # outputs of buffer set k -> page-locked host memory on the second copy stream
-        ev_done[k].record(e.stream)
-        with torch.cuda.stream(cout):
-            cout.wait_event(ev_done[k])
-            for src, dst in outs[k]:
-                travel(dst, src, wg_out, cout)
-            ev_out[k].record(cout)
-
     # Results leave on the RESULT stream (mcs_ctx_result_stream: the greedy pass's), right behind the search that completes them — no event in front, no further
-    # stream — unless MCS_E2E_OUT=stream asks for the round-3 form (a copy stream of its own, ordered by an event, two steps late).
-    on_result = os.environ.get("MCS_E2E_OUT", "result") == "result"
-    if on_result:
-        h = C.c_void_p()
-        e.mcs.check(e.lib.mcs_ctx_result_stream(e.ctx.h, C.byref(h)))
-        rstream = torch.cuda.ExternalStream(h.value, device=e.dev)
+    # stream.  (Round 3's form — a copy stream of its own, ordered by an event, two steps late — went with the pipelined order of round 6.)
+    h = C.c_void_p()
+    e.mcs.check(e.lib.mcs_ctx_result_stream(e.ctx.h, C.byref(h)))
+    rstream = torch.cuda.ExternalStream(h.value, device=e.dev)
 
     def download_behind_search(k):
         with torch.cuda.stream(rstream):
@@ -780,18 +789,19 @@ def run_e2e(e, sp, steps, warmup, check=True):
         i = n % NI
         state["i"] += 1
         k = n % NS
-        if AHEAD and n >= AHEAD and on_result and AHEAD <= NS:
+        if AHEAD and n >= AHEAD and AHEAD <= NS:
             ev_out[(n - AHEAD) % NS].synchronize()
         e.stream.wait_event(ev_in[i])                     # this step's images (uploaded while the previous step computed)
         e.stream.wait_event(ev_out[k])                    # the output set about to be overwritten has been copied out
-        e.mcs.check(e.lib.mcs_ctx_search_fence(e.ctx.h, 1))   # the deferred search of step n - 2 is complete (it ran beside the extraction of step n - 1)
-        if n >= 2 and not on_result:
-            download((n - 2) % NS)                        # ... so its match arrays (and the rest of that set) leave now, two steps late
+        e.mcs.check(e.lib.mcs_ctx_search_fence(e.ctx.h, 1))   # the search issued two calls ago (it read the set extracted three calls ago = this one) is complete
         b = job.sets[k]
+        p = job.sets[(k - 1) % NS]                        # the set extracted in the previous call: patched, matched and sent home in this one
         job.cur = (k + 1) % NS
         t1 = time.perf_counter()
-        job.extract_and_exchange(b, i)
+        job.extract(b, i)
         ev_free[i].record(e.stream)
+        job.patch(1)                                      # host: wait for the previous batch's capture event only, recompute its rounding-tie rows, patch them
+        job.exchange_end(p, job.exchange_begin(p))
         t2 = time.perf_counter()
         # The search is enqueued BEFORE the upload: the probed upload stream shares a hardware queue with the deferred matcher's stream (the least harmful pairing),
         # and a queue starts its packets in order — with the 1.3 ms upload in front, this step's lists started 1.3 ms late and finished right around the fence of step
@@ -800,13 +810,12 @@ def run_e2e(e, sp, steps, warmup, check=True):
         if upload_first:
             upload((n + NI - 1) % NI)
         t3 = time.perf_counter()
-        job.match(b)
-        job.matched_set = b
+        job.match(p)
+        job.matched_set = p
         if not upload_first:
             upload((n + NI - 1) % NI)                     # the images of step n + NI - 1 travel while this and the following steps compute (NI = 2: the next step's)
         t4 = time.perf_counter()
-        if on_result:
-            download_behind_search(k)                     # behind this step's greedy pass: the set leaves during the next step
+        download_behind_search((k - 1) % NS)              # behind this call's greedy pass: the set leaves during the next step
         if MARK:
             marks[n % len(marks)].record(e.stream)
         t5 = time.perf_counter()
@@ -847,13 +856,10 @@ def run_e2e(e, sp, steps, warmup, check=True):
         sys.stderr.write("e2e diag: slowest host call of a step (ms): extract %.2f upload %.2f match %.2f download %.2f\n" % tuple(state["worst"]))
     e.mcs.check(e.lib.mcs_ctx_join(e.ctx.h))
     n = state["i"]
-    for m in (n - 2, n - 1):                              # the last two steps' outputs
-        if m >= 0 and not on_result:
-            download(m % NS)
     torch.cuda.synchronize(e.dev)
     feats = job.local_features()
-    last = outs[(n - 1) % NS]                             # page-locked host copies of the last step's buffer set: (send = gathered array, nkp, kps, match, nmatch)
-    job.matched_set = job.sets[(n - 1) % NS]
+    last = outs[(n - 2) % NS]                             # page-locked host copies of the set matched in the last call: (send = gathered array, nkp, kps, match, nmatch)
+    job.matched_set = job.sets[(n - 2) % NS]
     checked = check_against_oracle(e, sp, job, host={"G": last[0][1], "kps": last[2][1], "match": last[3][1], "nmatch": last[4][1]}) if check else None
     h2d = job.imgs_np.nbytes
     d2h = sum(dst.numel() * dst.element_size() for _, dst in outs[0])
@@ -876,7 +882,8 @@ def run_e2e(e, sp, steps, warmup, check=True):
             "copy_workgroups": {"h2d": wg_in or "runtime", "d2h": wg_out or "runtime"}, "upload_stream_queue_conflicts": upload_conflicts,
             "what": "host buffers at the boundary: images H2D from page-locked memory (three device buffers in turn, the runtime's SDMA copy on a copy stream), keypoints + "
                     "descriptor|mask blocks + counts + match arrays D2H to page-locked memory (mcs_copy_narrow on the context's result stream, behind the step's greedy "
-                    "pass), overlapped with the neighbouring steps' kernels; outputs leave one step late"}
+                    "pass), overlapped with the neighbouring steps' kernels; rounding-tie rows patched on the host before the set's search is enqueued (in the loop); outputs leave one step late",
+            "ties_patched_in_loop": bool(job.ties_in_loop), "ties_recomputed_on_the_host_in_loop": int(job.ties_patched)}
 
 
 # ------------------------------------------------------------------------------------------------ oracle legs
@@ -943,6 +950,44 @@ def check_against_oracle(e, sp, job, host=None):
     return not bad
 
 
+def check_full(e, sp, job, orc):
+    """Every multi-frame and every (frame, predecessor) pair the CPU-baseline pass computed (orc: its outputs, orc_extract_match_many_out) against the host copies of
+    the set the headline loop matched last (job.snapshot): keypoint records, descriptors, masks, counts, match indices and match counts, bit for bit."""
+    lay, rig, snap = job.lay, e.rig, job.snapshot
+    nf, ocap, ncam, cap = orc["nf"], orc["cap"], sp.ncam, lay.cap
+    G = snap["G"].reshape(lay.images_total, lay.rows_img, lay.row_stride)
+    kps = snap["kps"].view(np.uint8).reshape(lay.L, lay.cap, 28)
+    match, nmatch = snap["match"].reshape(sp.F, lay.rows_frame), snap["nmatch"]
+    mine = {cf: i for i, cf in enumerate(job.slab)}
+    okps = orc["kps"].view(np.uint8).reshape(nf * ncam, ocap, 28)
+    bad = []
+    pos = {}
+    nf = min(nf, job.FT)
+    for f in range(nf):
+        d, m, v = rig.unpack_frame(lay, G, f)
+        p_ = []
+        for c in range(ncam):
+            i, lo = f * ncam + c, c * cap
+            n = int(orc["nkp"][i])
+            p_.append(lo + np.arange(n))
+            if not (int(v[lo:lo + cap].sum()) == n and np.array_equal(d[lo:lo + n], orc["desc"][i, :n]) and np.array_equal(m[lo:lo + n], orc["mask"][i, :n])):
+                bad.append("descriptors/masks/count of frame %d camera %d" % (f, c))
+            if (c, f) in mine and not np.array_equal(kps[mine[(c, f)], :n], okps[i, :n]):
+                bad.append("keypoint records of frame %d camera %d" % (f, c))
+        pos[f] = np.concatenate(p_)
+    pairs = 0
+    for f in range(1, nf):
+        m12 = orc["match"][f, :len(pos[f])]
+        full = np.full(lay.rows_frame, -1, np.int32)
+        full[pos[f]] = np.where(m12 >= 0, pos[f - 1][np.maximum(m12, 0)], -1)
+        pairs += 1
+        if not (int(orc["nmatch"][f]) == int(nmatch[f]) and np.array_equal(match[f], full)):
+            bad.append("match indices of the pair (frame %d, frame %d)" % (f, f - 1))
+    for msg in bad[:20]:
+        print("oracle check (full) FAILED [%s]: %s" % (sp.tag, msg), file=sys.stderr)
+    return not bad, {"multi_frames": nf, "images": nf * ncam, "pairs": pairs}
+
+
 def cpu_baseline(args, e, sp, job):
     """The oracle (kind 'port') timed on this box's host cores on a bounded sample of the same stream."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -989,6 +1034,17 @@ def cpu_baseline(args, e, sp, job):
     per_frame = tot / nf
     # the reference's own threading: one thread per camera of a multi-frame (#pragma omp parallel for num_threads(nrCams), src/cMultiFrame.cpp:128), the
     # multi-frames one after the other, the matcher single-threaded — NCAM images in flight at any time.  One warm-up, median of 5.
+    # one more pass, untimed, whose outputs leave: the in-run check compares every multi-frame and pair of this sample with the device's (check_full)
+    ocap = nfeat + 4 * prm.nlevels
+    orc = {"nf": nf, "cap": ocap, "nkp": np.zeros(nf * NCAM, np.int32), "kps": np.zeros((nf * NCAM, ocap, 7), np.float32), "desc": np.zeros((nf * NCAM, ocap, prm.descSize), np.uint8),
+           "mask": np.zeros((nf * NCAM, ocap, prm.descSize), np.uint8), "match": np.full((nf, NCAM * ocap), -1, np.int32), "nmatch": np.zeros(nf, np.int32)}
+    if prm.nlevels == 8 and prm.descSize == 32:
+        L.orc_extract_match_many_out.restype = C.c_long
+        L.orc_extract_match_many_out.argtypes = L.orc_extract_match_many.argtypes + [C.c_void_p] * 5
+        L.orc_extract_match_many_out(C.byref(prm), nf, NCAM, iptr, W, H, W, mptr, ocs, threads, 0.9, orc["nmatch"].ctypes.data, secs, orc["nkp"].ctypes.data, orc["kps"].ctypes.data,
+                                     orc["desc"].ctypes.data, orc["mask"].ctypes.data, orc["match"].ctypes.data)
+    else:
+        orc = None
     nf_f = max(4, min(nf, 12))
     one_pass(nf_f, NCAM)
     rf = sorted((one_pass(nf_f, NCAM) for _ in range(5)), key=lambda r: r[0])[2]
@@ -1045,7 +1101,7 @@ def cpu_baseline(args, e, sp, job):
                               "reference's own sources compiled here (oracle/_ref), medians; threads = Python threads around the reference's extractor (the GIL is released)" % nr}
         except Exception as ex:   # this side measurement is optional; the error is reported, not hidden
             refc = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
-    return {"reference_compiled": refc, "reference_threading": faithful, "value": round(per_frame * (nf - 1) / wall / 1e6, 4), "unit": "Mfeatures/s", "cores": threads, "kind": "port",
+    return {"_oracle_outputs": orc, "reference_compiled": refc, "reference_threading": faithful, "value": round(per_frame * (nf - 1) / wall / 1e6, 4), "unit": "Mfeatures/s", "cores": threads, "kind": "port",
             "repetitions": len(reps), "warmups": 3, "wall_s_min_median_max": [round(walls[0], 3), round(wall, 3), round(walls[-1], 3)],
             "sample": "%d multi-frames (%d images) of the same synthetic stream: oracle extract (%s) %.2fs + SearchByBoW(KF,KF) vs previous frame %.2fs wall, "
                       "OpenMP over images/frames on %d threads (cgroup CPU quota of this box: %d of %d hardware threads; thread count picked by the warm-ups from quota and "
@@ -1224,6 +1280,15 @@ def main():
         e.exchange = False
     if e.rank == 0 and e.world == 1 and headline and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, e, sp, job)
+        orc = cpu.pop("_oracle_outputs", None)
+        if check and orc is not None and getattr(job, "snapshot", None) is not None:
+            # the widened check: every multi-frame and pair of the CPU sample against the set the headline's timed loop matched last
+            ok_full, counts = check_full(e, sp, job, orc)
+            out["oracle_check_full"] = bool(ok_full)
+            out["oracle_check"] = bool(out.get("oracle_check")) and bool(ok_full)
+            out["config"]["oracle_checked"] = dict(counts, first_pass=out["config"].get("oracle_checked"),
+                                                   what="all multi-frames and (frame, predecessor) pairs of the CPU-baseline sample against the set the timed loop matched last")
+            checks.append(bool(ok_full))
         out["cpu_baseline"] = cpu
         out["speedup_vs_cpu_all_cores"] = round(out["value"] / cpu["value"], 2)
         out["speedup_vs_cpu_reference_threading"] = round(out["value"] / cpu["reference_threading"]["value"], 2)

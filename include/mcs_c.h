@@ -33,9 +33,9 @@ extern "C" {
 
 /* ABI revision of this header: bumped whenever a struct layout or an entry point's signature changes (3: mcs_desc_set carries block_rows / block_pitch_rows
  * since round 2 — callers built against an older header must be recompiled; mcs_describe_fast_table, FAST types 0 / 1 in round 3; 4: mcs_extractor_tie_stats; 5: mcs_copy_narrow,
- * mcs_ctx_result_stream, mcs_ctx_stream_conflicts, mcs_ctx_transfer_stream in round 4).  mcs_abi_version() returns
+ * mcs_ctx_result_stream, mcs_ctx_stream_conflicts, mcs_ctx_transfer_stream in round 4; 8: mcs_extractor_set_tie_capture / _patch_ties in round 6).  mcs_abi_version() returns
  * the value the LIBRARY was built with: compare it with MCS_ABI_VERSION after dlopen. */
-#define MCS_ABI_VERSION 7
+#define MCS_ABI_VERSION 8
 
 #define MCS_MAX_POLY 16
 #define MCS_MAX_LEVELS 16
@@ -157,6 +157,20 @@ int mcs_extractor_tie_stats(mcs_extractor*, double* min_tie_distance, int reset)
 int mcs_extractor_set_tie_band(mcs_extractor*, double band_px);
 int mcs_extractor_fix_ties(mcs_extractor*, int* recomputed);
 int mcs_extractor_tie_counts(mcs_extractor*, uint64_t* listed, uint64_t* recomputed, double* band_px);
+/* Pipelined enforcement (round 6): a caller that keeps its outputs on the device and consumes them on-stream — the batched front end whose matcher runs one
+ * step behind the extraction, the multi-GPU rig whose descriptor blocks leave for the other ranks — cannot stop for mcs_extractor_fix_ties, and by the time it
+ * could, the extractor's pyramid buffers hold the next batch.  With a capture ring every DEVICE-kind batch ends with one small launch that writes, for each
+ * listed keypoint, its slot, level, position, angle and the 81 x 81 window of blurred / reflected samples around it (the values the reference's
+ * `img.at<uchar>(…)` reads, src/mdBRIEFextractorOct.cpp:340-352, 437-470) into page-locked memory, and records an event.
+ *   mcs_extractor_set_tie_capture(e, depth, max_ties)   depth = batches in flight (ring slots; 0 = off), max_ties = entries per slot (0 = 64); synchronous
+ *   mcs_extractor_patch_ties(e, back, &listed, &recomputed)   batch `back` calls before the latest one (0 = the latest): waits ON THE HOST for that batch's
+ *        event only — later batches keep running —, recomputes the listed descriptors with the host's libm (the same code path as mcs_extractor_fix_ties) and
+ *        writes them over the batch's device rows; the rows are in place when it returns, so whatever is enqueued afterwards (search, exchange, download) reads
+ *        them.  MCS_ERR_CAPACITY: more listed keypoints than max_ties (nothing patched; widen the slots or use mcs_extractor_fix_ties).
+ * The pipelined order of bench.py / host/rig_host.cpp: enqueue extract(n); patch_ties(back = 1) — batch n - 1 has finished or is about to, the device already
+ * holds batch n's work —; then enqueue search / exchange of batch n - 1.  One step of result latency, no device idle time, every consumed row the host's. */
+int mcs_extractor_set_tie_capture(mcs_extractor*, int depth, int max_ties);
+int mcs_extractor_patch_ties(mcs_extractor*, int back, int* listed, int* recomputed);
 int mcs_describe_fast_bound(const mcs_ocam* cam, int desc_size, double* bound);
 int mcs_selftest_describe_fast(mcs_ctx*, const mcs_ocam* cam, uint64_t seed, int n, double* max_abs_diff);
 int mcs_describe_fast_table(const mcs_ocam* cam, double* table, int* rows, int* row_len, int* e0, int* bins_per_octave, double* info6);

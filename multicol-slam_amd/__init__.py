@@ -212,6 +212,17 @@ class Extractor:
         check(lib().mcs_extractor_fix_ties(self.h, C.byref(n)))
         return n.value
 
+    def set_tie_capture(self, depth, max_ties=0):
+        """pipelined enforcement: a ring of `depth` page-locked capture slots (one per device-kind batch in flight), `max_ties` entries each (0 = 64); depth 0 = off"""
+        check(lib().mcs_extractor_set_tie_capture(self.h, int(depth), int(max_ties)))
+
+    def patch_ties(self, back=1):
+        """recompute the listed keypoints of the device-kind batch `back` calls before the latest one on the host and patch its device rows (waits for that batch
+        only); returns (listed, recomputed)"""
+        a, b_ = C.c_int(), C.c_int()
+        check(lib().mcs_extractor_patch_ties(self.h, int(back), C.byref(a), C.byref(b_)))
+        return a.value, b_.value
+
     def tie_counts(self):
         """(keypoints listed, keypoints recomputed on the host, band in px) since creation"""
         a, b_, band = C.c_uint64(), C.c_uint64(), C.c_double()

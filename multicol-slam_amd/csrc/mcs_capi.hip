@@ -15,9 +15,9 @@
 namespace mcs {
 bool upload_describe_tables(const signed char* pattern);
 void launch_single_distance(const uint8_t* a, const uint8_t* b, const uint8_t* ma, const uint8_t* mb, int dim, int* out, hipStream_t s);
-struct HostLevel { const uint8_t* blur; const uint8_t* raw; int w, h; };
 void describe_host(int mode, int descSize, const signed char* pattern, const OcamDev* cam, int undistort, int level, float levelScale, int row, int col, float angle,
                    const HostLevel& L, uint8_t* desc, uint8_t* mask);   // mcs_tiefix.hip
+void launch_tie_capture(const ExtractBuffers& b, const PyrDesc& hd, int nimg, int maxTies, uint8_t* devOut, hipStream_t s);   // mcs_tiefix.hip
 void launch_selftest_fast_model(const OcamDev* cam, const double* tab, unsigned long long seed, int n, int width, int height, unsigned long long* maxDiff, hipStream_t s);
 static const signed char kPattern[2048] = {
 #include "learned_pattern_64_orb.inc"
@@ -237,6 +237,10 @@ struct mcs_extractor {
 	int describeMode = 0; double guardEps = kDefaultGuardEps;
 	// rounding ties of the exact arithmetic (mcs_tiefix.hip): the batch's listed keypoints, the band (0 = the mode's default, < 0 = list nothing), totals
 	uint32_t* d_tieList = nullptr; double tieBand = 0.0; unsigned long long tieFixed = 0;
+	// pipelined enforcement (mcs_extractor_set_tie_capture): a ring of page-locked capture slots, one per device-kind batch in flight
+	struct TieSlot { uint8_t* host = nullptr; uint8_t* dev = nullptr; hipEvent_t ev = nullptr; ExtractBuffers b{}; int nimg = 0; std::vector<OcamDev> cams; long long seq = -1; bool patched = false; };
+	std::vector<TieSlot> tieRing; int tieMax = 0; long long batchSeq = 0; hipStream_t patchStream = nullptr; uint8_t* h_patchRows = nullptr;
+	unsigned long long tieWindowMisses = 0;
 	// G(s) tables of the cameras seen so far (a rig has a handful), and the batch's distinct tables as the fast pass reads them
 	struct CamFast { OcamDev key; GTabInfo info; std::vector<double> tab; };
 	std::vector<CamFast> camCache;
@@ -636,6 +640,13 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	return MCS_OK;
 }
 
+static void free_tie_capture(mcs_extractor* e) {
+	for (mcs_extractor::TieSlot& t : e->tieRing) { if (t.ev) (void)hipEventDestroy(t.ev); if (t.host) (void)hipHostFree(t.host); }
+	e->tieRing.clear(); e->tieMax = 0;
+	if (e->h_patchRows) { (void)hipHostFree(e->h_patchRows); e->h_patchRows = nullptr; }
+	if (e->patchStream) { (void)hipStreamSynchronize(e->patchStream); (void)hipStreamDestroy(e->patchStream); e->patchStream = nullptr; }
+}
+
 int mcs_extractor_destroy(mcs_extractor* e) {
 	if (!e) return MCS_OK;
 	(void)hipSetDevice(e->ctx->device);
@@ -651,6 +662,7 @@ int mcs_extractor_destroy(mcs_extractor* e) {
 	for (mcs_extractor::Graph& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
 	(void)hipFree(e->d_resMask);
 	if (e->h_status) (void)hipHostFree(e->h_status);
+	free_tie_capture(e);
 	delete e;
 	return MCS_OK;
 }
@@ -957,6 +969,17 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 	if (!replayed) { c->tic("describe"); launch_describe(b, hd, nimg, s); c->toc("describe"); }
 	HIPCHK(hipGetLastError());
 	e->last = b; e->lastN = nimg;
+	if (kind != MCS_MEM_HOST && !e->tieRing.empty()) {
+		// pipelined enforcement: what the host needs of this batch's listed keypoints leaves for page-locked memory right behind the descriptor kernels; the
+		// caller patches the rows one step later (mcs_extractor_patch_ties), while the pyramid buffers already hold the next batch
+		mcs_extractor::TieSlot& t = e->tieRing[(size_t)(e->batchSeq % (long long)e->tieRing.size())];
+		launch_tie_capture(b, hd, nimg, e->tieMax, t.dev, s);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(t.ev, s));
+		t.b = b; t.nimg = nimg; t.seq = e->batchSeq; t.patched = false;
+		if (hd.mode != 0) t.cams = e->h_cams; else t.cams.clear();
+		++e->batchSeq;
+	}
 	if (kind == MCS_MEM_HOST) {
 		const size_t rows = (size_t)nimg * hd.kpCap;
 		int st = 0, nties = 0;
@@ -1076,6 +1099,74 @@ int mcs_extractor_fix_ties(mcs_extractor* e, int* recomputed) {
 	const unsigned long long before = e->tieFixed;
 	if (int r = fix_ties(e, nties, nullptr, nullptr)) return r;
 	if (recomputed) *recomputed = (int)(e->tieFixed - before);
+	return MCS_OK;
+}
+
+int mcs_extractor_set_tie_capture(mcs_extractor* e, int depth, int max_ties) {
+	if (!e || depth < 0 || depth > 16 || max_ties < 0 || max_ties > 4096) return fail(MCS_ERR_INVALID, "depth must be 0..16, max_ties 0..4096 (0 = default 64)");
+	HIPCHK(hipSetDevice(e->ctx->device));
+	HIPCHK(hipStreamSynchronize(e->ctx->stream));
+	free_tie_capture(e);
+	if (depth == 0) return MCS_OK;
+	if (max_ties == 0) max_ties = 64;
+	const size_t bytes = sizeof(TieCaptureHeader) + (size_t)max_ties * sizeof(TieCaptureEntry);
+	e->tieRing.resize(depth);
+	for (mcs_extractor::TieSlot& t : e->tieRing) {
+		if (hipHostMalloc((void**)&t.host, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); free_tie_capture(e); return fail(MCS_ERR_HIP, "page-locked capture slot"); }
+		memset(t.host, 0, sizeof(TieCaptureHeader));
+		t.dev = (uint8_t*)device_view(t.host);
+		if (!t.dev || hipEventCreateWithFlags(&t.ev, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { (void)hipGetLastError(); free_tie_capture(e); return fail(MCS_ERR_HIP, "capture slot: device view / event"); }
+	}
+	if (hipHostMalloc((void**)&e->h_patchRows, (size_t)max_ties * 2 * e->hd.descSize, hipHostMallocDefault) != hipSuccess ||
+	    hipStreamCreateWithFlags(&e->patchStream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); free_tie_capture(e); return fail(MCS_ERR_HIP, "patch stream / staging rows"); }
+	e->tieMax = max_ties;
+	return MCS_OK;
+}
+
+int mcs_extractor_patch_ties(mcs_extractor* e, int back, int* listed, int* recomputed) {
+	if (listed) *listed = 0;
+	if (recomputed) *recomputed = 0;
+	if (!e || back < 0) return fail(MCS_ERR_INVALID, "bad argument");
+	if (e->tieRing.empty()) return fail(MCS_ERR_INVALID, "mcs_extractor_set_tie_capture has not been called");
+	const long long seq = e->batchSeq - 1 - back;
+	if (seq < 0) return MCS_OK;   // no such batch yet (the first steps of a pipeline)
+	mcs_extractor::TieSlot& t = e->tieRing[(size_t)(seq % (long long)e->tieRing.size())];
+	if (t.seq != seq) return fail(MCS_ERR_INVALID, "that batch's capture slot has been reused (capture depth too small for this lag)");
+	HIPCHK(hipSetDevice(e->ctx->device));
+	HIPCHK(hipEventSynchronize(t.ev));
+	const TieCaptureHeader* hdr = reinterpret_cast<const TieCaptureHeader*>(t.host);
+	const int n = hdr->count;
+	if (listed) *listed = n;
+	if (n <= 0 || t.patched) return MCS_OK;
+	if (n > e->tieMax) return fail(MCS_ERR_CAPACITY, "more keypoints inside the tie band than the capture slots hold (mcs_extractor_set_tie_capture max_ties); use mcs_extractor_fix_ties for this band");
+	const PyrDesc& hd = e->hd;
+	const ExtractBuffers& b = t.b;
+	const int wavesPerImage = (hd.kpCap + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
+	int done = 0;
+	for (int i = 0; i < n; ++i) {
+		const TieCaptureEntry* en = reinterpret_cast<const TieCaptureEntry*>(t.host + sizeof(TieCaptureHeader) + (size_t)i * sizeof(TieCaptureEntry));
+		if (en->level < 0 || en->level >= hd.nlevels) continue;
+		const int img = (int)(en->gw / (uint32_t)wavesPerImage), sl = (int)(en->gw - (uint32_t)img * wavesPerImage);
+		const LevelInfo& L = hd.lv[en->level];
+		const int col = (int)(en->rec & 0xFFF) + kMinBorder, row = (int)((en->rec >> 12) & 0xFFF) + kMinBorder;
+		const OcamDev* cam = hd.mode != 0 && (size_t)img < t.cams.size() ? &t.cams[img] : nullptr;
+		if (hd.mode != 0 && !cam) return fail(MCS_ERR_INVALID, "internal: tie capture without camera models");
+		bool miss = false;
+		HostLevel hl{nullptr, nullptr, L.w, L.h, en->patch, row - kTiePatchR, col - kTiePatchR, kTiePatchDim, &miss};
+		uint8_t* dsc = e->h_patchRows + (size_t)done * 2 * hd.descSize;
+		uint8_t* msk = dsc + hd.descSize;
+		describe_host(hd.mode, hd.descSize, kPattern, cam, hd.undistort, en->level, L.scale, row, col, en->angle, hl, dsc, msk);
+		if (miss) { ++e->tieWindowMisses; return fail(MCS_ERR_UNSUPPORTED, "a pattern sample of a listed keypoint lies outside the captured window (camera model with > 1.9x local magnification?)"); }
+		const size_t drow = ((size_t)img * b.outImgPitch + sl) * b.outRowStride;
+		HIPCHK(hipMemcpyAsync(b.out_desc + drow, dsc, hd.descSize, hipMemcpyHostToDevice, e->patchStream));
+		HIPCHK(hipMemcpyAsync(b.out_mask + drow, msk, hd.descSize, hipMemcpyHostToDevice, e->patchStream));
+		++done;
+	}
+	// the rows are in place before this returns: whatever the caller enqueues next (matcher, exchange, download) reads the host's arithmetic
+	HIPCHK(hipStreamSynchronize(e->patchStream));
+	e->tieFixed += (unsigned long long)done;
+	t.patched = true;
+	if (recomputed) *recomputed = done;
 	return MCS_OK;
 }
 

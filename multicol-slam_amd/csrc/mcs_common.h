@@ -149,6 +149,16 @@ struct ExtractBuffers {
 	size_t outImgPitch; int outRowStride;   // descriptor / mask row k of image i at (i * outImgPitch + k) * outRowStride (default kpCap rows, descSize bytes)
 };
 
+// Host recomputation of rounding ties (mcs_tiefix.hip).  HostLevel: either the whole level (tight rows, stride = w, blurred and unblurred, both the size of the
+// level's ROI) or — the pipelined form, k_tie_capture — a square window of Sampler::at values around the keypoint: patch[(r - prow) * pdim + (c - pcol)],
+// `miss` set when a sample falls outside it.
+struct HostLevel { const uint8_t* blur; const uint8_t* raw; int w, h; const uint8_t* patch = nullptr; int prow = 0, pcol = 0, pdim = 0; bool* miss = nullptr; };
+// What k_tie_capture leaves in page-locked memory per batch: a header and up to max_ties entries (slot, level, selected-key record, angle, window of samples)
+constexpr int kTiePatchR = 40;
+constexpr int kTiePatchDim = 2 * kTiePatchR + 1;
+struct TieCaptureHeader { int count; int status; int pad[14]; };
+struct TieCaptureEntry { uint32_t gw; int level; uint32_t rec; float angle; uint8_t patch[kTiePatchDim * kTiePatchDim + 15]; };   // 16 + 6576 bytes
+
 __host__ __device__ inline const uint8_t* level_ptr(const ExtractBuffers& b, const PyrDesc& d, int img, int level, int* stride) {
 	if (level == 0) { *stride = b.img0Stride; return b.img0 + (size_t)img * b.img0Pitch; }
 	*stride = d.lv[level].stride;

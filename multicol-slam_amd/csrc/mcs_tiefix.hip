@@ -19,7 +19,6 @@
 
 namespace mcs {
 
-struct HostLevel { const uint8_t* blur; const uint8_t* raw; int w, h; };   // tight rows (stride = w), both the size of the level's ROI
 
 namespace {
 
@@ -27,6 +26,12 @@ inline int cvRoundH(double v) { return (int)lrint(v); }   // cv::cvRound: round 
 
 // Sampler::at of mcs_describe.hip: inside the level the blurred pyramid; in the 25-px frame the unblurred level with reflect-101 indices; beyond it clamped
 inline int sample(const HostLevel& L, int r, int c) {
+	if (L.patch) {   // the device evaluated Sampler::at for the window (same three cases as below)
+		const unsigned pr = (unsigned)(r - L.prow), pc = (unsigned)(c - L.pcol);
+		if (pr < (unsigned)L.pdim && pc < (unsigned)L.pdim) return L.patch[(size_t)pr * L.pdim + pc];
+		if (L.miss) *L.miss = true;
+		return 0;
+	}
 	if ((unsigned)r < (unsigned)L.h && (unsigned)c < (unsigned)L.w) return L.blur[(size_t)r * L.w + c];
 	r = r < -kEdge ? -kEdge : (r > L.h + kEdge - 1 ? L.h + kEdge - 1 : r);
 	c = c < -kEdge ? -kEdge : (c > L.w + kEdge - 1 ? L.w + kEdge - 1 : c);
@@ -135,6 +140,52 @@ void describe_host(int mode, int descSize, const signed char* pattern, const Oca
 		if (mainBits[k]) desc[k >> 3] |= (uint8_t)(1u << (k & 7));
 		if (mode == 2 && agree[k]) mask[k >> 3] |= (uint8_t)(1u << (k & 7));   // mask bit = both +-20 degree tests agree with the main test (:468-475)
 	}
+}
+
+// ---- the pipelined form (round 6): device-kind batches are consumed on-stream, one step late, while the extractor's pyramid buffers already hold the NEXT
+// batch — so what the host needs of a listed keypoint is captured right behind the descriptor kernels into page-locked memory: its slot, level, position,
+// angle and the (2R + 1)^2 window of Sampler::at values around it (R = kTiePatchR: the pattern's radius is 15 * sqrt(2) = 21.2 px before distortion, and the
+// omni model compresses away from the optical axis).  mcs_extractor_patch_ties (mcs_capi.hip) reads it behind the batch's event.
+__global__ __launch_bounds__(256) void k_tie_capture(ExtractBuffers b, int nimg, int wavesPerImage, int maxTies, uint8_t* __restrict__ out) {
+	const PyrDesc& d = *b.desc;
+	const int n = *b.tieCount;
+	TieCaptureHeader* hdr = reinterpret_cast<TieCaptureHeader*>(out);
+	if (blockIdx.x == 0 && threadIdx.x == 0) { hdr->count = n; hdr->status = *b.status; }
+	const int t = blockIdx.x;
+	if (t >= n || t >= maxTies) return;
+	TieCaptureEntry* en = reinterpret_cast<TieCaptureEntry*>(out + sizeof(TieCaptureHeader) + (size_t)t * sizeof(TieCaptureEntry));
+	const uint32_t gw = b.tieList[t];
+	const int img = (int)(gw / (uint32_t)wavesPerImage), sl = (int)(gw - (uint32_t)img * wavesPerImage);
+	int level = -1, pos = 0, total = 0;
+	if (img < nimg && sl < d.kpCap)
+		for (int l = 0; l < d.nlevels; ++l) { const int c = b.selCount[(size_t)img * d.nlevels + l]; if (sl >= total && sl < total + c) { level = l; pos = sl - total; } total += c; }
+	if (level < 0) { if (threadIdx.x == 0) { en->gw = gw; en->level = -1; } return; }
+	const LevelInfo& L = d.lv[level];
+	const uint32_t rec = b.sel[(size_t)img * d.selPerImage + L.selBase + pos];
+	if (threadIdx.x == 0) { en->gw = gw; en->level = level; en->rec = rec; en->angle = b.selAngle[(size_t)img * d.selPerImage + L.selBase + pos]; }
+	const int col = (int)(rec & 0xFFF) + kMinBorder, row = (int)((rec >> 12) & 0xFFF) + kMinBorder;
+	int rstride = 0;
+	const uint8_t* raw = level_ptr(b, d, img, level, &rstride);
+	const uint8_t* blur = b.blur + (size_t)img * d.pyrBytes + L.off;
+	constexpr int D = 2 * kTiePatchR + 1;
+	for (int i = threadIdx.x; i < D * D; i += 256) {
+		int r = row - kTiePatchR + i / D, c = col - kTiePatchR + i % D;
+		int v;
+		if ((unsigned)r < (unsigned)L.h && (unsigned)c < (unsigned)L.w) v = blur[(size_t)r * L.stride + c];
+		else {   // Sampler::at (mcs_describe.hip): clamped to the 25-px frame, reflect-101 into the unblurred level
+			r = r < -kEdge ? -kEdge : (r > L.h + kEdge - 1 ? L.h + kEdge - 1 : r);
+			c = c < -kEdge ? -kEdge : (c > L.w + kEdge - 1 ? L.w + kEdge - 1 : c);
+			r = r < 0 ? -r : (r >= L.h ? 2 * (L.h - 1) - r : r);
+			c = c < 0 ? -c : (c >= L.w ? 2 * (L.w - 1) - c : c);
+			v = raw[(size_t)r * rstride + c];
+		}
+		en->patch[i] = (uint8_t)v;
+	}
+}
+
+void launch_tie_capture(const ExtractBuffers& b, const PyrDesc& hd, int nimg, int maxTies, uint8_t* devOut, hipStream_t s) {
+	const int wavesPerImage = (hd.kpCap + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
+	hipLaunchKernelGGL(k_tie_capture, dim3(maxTies), dim3(256), 0, s, b, nimg, wavesPerImage, maxTies, devOut);
 }
 
 }  // namespace mcs

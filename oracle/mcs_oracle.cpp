@@ -1850,8 +1850,13 @@ long orc_extract_many(const orc_params* p, int nimg, const uint8_t* const* imgs,
 	return total;
 }
 
-long orc_extract_match_many(const orc_params* p, int nframes, int ncam, const uint8_t* const* imgs, int w, int h, int stride,
-                            const uint8_t* const* masks, const orc_ocam* cams, int threads, double nnratio, int* nmatch, double* seconds) {
+// The same pass with its results handed out (bench.py's in-run check compares EVERY multi-frame and pair of the CPU-baseline sample with the device's
+// outputs): out_nkp[nimg], out_kps[nimg][cap], out_desc / out_mask[nimg][cap][descSize] (cap = nfeatures + 4 * nlevels), out_match[nframes][ncam * cap] = the
+// m12 array of SearchByBoW(frame f, frame f - 1) over frame f's flattened keypoints (camera after camera, valid rows only; index into frame f - 1's flattened
+// rows, -1 none; the tail of each row and row 0 stay -1).  Any of them may be null.
+long orc_extract_match_many_out(const orc_params* p, int nframes, int ncam, const uint8_t* const* imgs, int w, int h, int stride,
+                                const uint8_t* const* masks, const orc_ocam* cams, int threads, double nnratio, int* nmatch, double* seconds,
+                                int* out_nkp, orc_keypoint* out_kps, uint8_t* out_desc, uint8_t* out_mask, int* out_match) {
 	const int nimg = nframes * ncam, cap = p->nfeatures + 4 * p->nlevels, ds = p->descSize;
 	std::vector<orc_keypoint> kps((size_t)nimg * cap);
 	std::vector<int> nkp(nimg, 0);
@@ -1876,6 +1881,7 @@ long orc_extract_match_many(const orc_params* p, int nframes, int ncam, const ui
 			fm[f].insert(fm[f].end(), dmask.begin() + (size_t)i * cap * ds, dmask.begin() + ((size_t)i * cap + nkp[i]) * ds);
 		}
 	nmatch[0] = 0;
+	if (out_match) for (size_t i = 0; i < (size_t)nframes * ncam * cap; ++i) out_match[i] = -1;
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
 	for (int f = 1; f < nframes; ++f) {
 		const int n1 = (int)(fd[f].size() / ds), n2 = (int)(fd[f - 1].size() / ds);
@@ -1883,6 +1889,7 @@ long orc_extract_match_many(const orc_params* p, int nframes, int ncam, const ui
 		std::vector<int> m12(n1 > 0 ? n1 : 1);
 		nmatch[f] = orc_search_kf_kf(fd[f].data(), fm[f].data(), v1.data(), n1, fd[f - 1].data(), fm[f - 1].data(), v2.data(), n2, ds, p->learnMasks,
 		                             nnratio, m12.data());
+		if (out_match) memcpy(out_match + (size_t)f * ncam * cap, m12.data(), sizeof(int) * (size_t)n1);
 	}
 #ifdef _OPENMP
 	double t2 = omp_get_wtime();
@@ -1890,7 +1897,16 @@ long orc_extract_match_many(const orc_params* p, int nframes, int ncam, const ui
 	double t2 = 0;
 #endif
 	if (seconds) { seconds[0] = t1 - t0; seconds[1] = t2 - t1; }
+	if (out_nkp) memcpy(out_nkp, nkp.data(), sizeof(int) * nimg);
+	if (out_kps) memcpy(out_kps, kps.data(), sizeof(orc_keypoint) * kps.size());
+	if (out_desc) memcpy(out_desc, desc.data(), desc.size());
+	if (out_mask) memcpy(out_mask, dmask.data(), dmask.size());
 	return total;
+}
+
+long orc_extract_match_many(const orc_params* p, int nframes, int ncam, const uint8_t* const* imgs, int w, int h, int stride,
+                            const uint8_t* const* masks, const orc_ocam* cams, int threads, double nnratio, int* nmatch, double* seconds) {
+	return orc_extract_match_many_out(p, nframes, ncam, imgs, w, h, stride, masks, cams, threads, nnratio, nmatch, seconds, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

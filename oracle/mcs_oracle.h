@@ -170,6 +170,10 @@ int orc_num_threads(void);
  * nmatch[f] = matches of frame f (nmatch[0] = 0); seconds[0] = extraction wall time, seconds[1] = matching wall time. */
 long orc_extract_match_many(const orc_params* p, int nframes, int ncam, const uint8_t* const* imgs, int w, int h, int stride,
                             const uint8_t* const* masks, const orc_ocam* cams, int threads, double nnratio, int* nmatch, double* seconds);
+/* the same pass, results handed out (cap = nfeatures + 4 * nlevels rows per image; out_match[f][ncam * cap] = m12 of frame f over its flattened valid rows) */
+long orc_extract_match_many_out(const orc_params* p, int nframes, int ncam, const uint8_t* const* imgs, int w, int h, int stride,
+                                const uint8_t* const* masks, const orc_ocam* cams, int threads, double nnratio, int* nmatch, double* seconds,
+                                int* out_nkp, orc_keypoint* out_kps, uint8_t* out_desc, uint8_t* out_mask, int* out_match);
 
 #ifdef __cplusplus
 }
