@@ -50,7 +50,7 @@ os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 import numpy as np  # noqa: E402
 
 MODES = {"orb": (0, 0), "dbrief": (1, 0), "mdbrief": (1, 1)}
-KERNELS = ("pyramid", "fast", "octree", "blur", "describe", "match", "greedy")
+KERNELS = ("pyramid", "fast", "octree", "blur", "describe", "describe_fast", "match", "greedy")
 E2E_H2D, E2E_D2H = "runtime", "2"   # how the e2e leg moves its page-locked buffers unless MCS_E2E_H2D / MCS_E2E_D2H say otherwise (run_e2e): the runtime's SDMA copy in, mcs_copy_narrow with TWO workgroups out (they saturate the link's write direction; more of them stall every other kernel's memory traffic)
 TIE_SLOTS = 256   # entries per capture slot of the in-loop tie enforcement (the default band lists about one keypoint per 64-multi-frame step)
 POOL = 64   # distinct synthetic multi-frames the stream cycles through: 8 scenes of 8 frames each ((3,1)-px shifts), synth.stream_image
@@ -138,6 +138,7 @@ def dry_run(args):
             row = {"workload": name, "config": cfg, "world": world}
             try:
                 row.update(rig.plan_check(args.ncam or ncam, F, world, cap, D, 32, args.topk))
+                row["plan_digest"] = rig.plan_digest(args.ncam or ncam, F, world, cap, D, 32, args.topk).hex()   # what every rank of the real run prints and compares
                 row["image_bytes_per_rank"] = row["images_per_rank"] * W * H
                 row["ok"] = True
             except ValueError as ex:
@@ -404,6 +405,24 @@ class Job:
             self.ex.set_tie_band(float(os.environ["MCS_BENCH_TIE_BAND"]))
         if self.ties_in_loop:
             self.ex.set_tie_capture(self.nsets, TIE_SLOTS)
+        # before the first exchange: every rank prints the digest of the plan it computed from its own arguments (the bytes `--dry-run` prints) and the ranks
+        # compare — an all-gather of 32 bytes; a rank that diverges is named and the run aborts before any buffer is exchanged
+        self.plan_digest = None
+        if e.exchange:
+            dg = rig.plan_digest(sp.ncam, sp.F, e.world, cap, sp.D, 32, sp.topk)
+
+            def gather32(b):
+                t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(e.red_dev)
+                out_t = torch.empty(32 * e.world, dtype=torch.uint8, device=e.red_dev)
+                e.dist.all_gather_into_tensor(out_t, t)
+                return out_t.cpu().numpy().tobytes()
+            print("bench.py: rank %d of %d plan digest %s (%s)" % (e.rank, e.world, dg.hex(), sp.tag), file=sys.stderr)
+            done = watchdog(int(os.environ.get("MCS_BENCH_EXCHANGE_TIMEOUT", "60")), "the plan-digest all-gather (32 bytes)")
+            try:
+                self.plan_digest = rig.check_plan_digests(dg, e.rank, e.world, gather32)
+            except ValueError as ex:
+                raise SystemExit("bench.py: %s" % ex)
+            done()
         # prime the pipeline: the first step() patches, exchanges and matches the multi-frames extracted here
         self.extract(self.sets[self.nsets - 1])
         if e.exchange:
@@ -588,52 +607,63 @@ class Job:
 
 
 def roofline_block(sp, job, kern, feats_local, pairs_local):
-    """`roofline` of the dominant kernel of one step on this rank: algorithmic bytes per launch (SURVEY.md §8d / DESIGN.md §4) over its measured duration"""
+    """`roofline` of the dominant KERNEL of one step on this rank — a single launch, named as the profile names it: algorithmic bytes per launch (SURVEY.md §8d /
+    DESIGN.md §4) over its measured duration.  The keypoint STAGE it belongs to (oct-tree + orientation + records + descriptors) is a sub-key."""
     nimg = job.L
-    per_kp = 845 + 512 * (3 if sp.mode == "mdbrief" else 1) + 28 + 32 + (32 if sp.mode == "mdbrief" else 0)
+    md = sp.mode == "mdbrief"
+    per_kp = 845 + 512 * (3 if md else 1) + 28 + 32 + (32 if md else 0)
     S = [w * h for w, h in job.level_sizes]
     rows = job.lay.rows_frame
     nsets = sp.F if sp.D == 0 else job.nkf * job.FT
     width = 64 if job.masks_on else 32
-    # The per-keypoint bytes of SURVEY.md §8d (orientation disc 845 B + pattern samples + keypoint + descriptor [+ mask]) belong to the KEYPOINT STAGE: the oct-tree
-    # kernel (selection + the orientation of the selected keys in its tail), k_orient_b (records, rays) and the descriptor kernels.  It is priced as one unit
-    # ("keypoints"); "describe" alone carries the bytes without the disc.
     kern = dict(kern)
-    if "octree" in kern and "describe" in kern:
-        kern["keypoints"] = kern["octree"] + kern["describe"]
-    alg = {"keypoints": per_kp * feats_local, "describe": (per_kp - 845) * feats_local, "pyramid": nimg * (sum(S) - S[-1] + sum(S) - S[0]), "fast": nimg * sum(S), "blur": nimg * 2 * sum(S),
+    mfma = "match" in kern and job.lay.desc_size in (16, 32) and not os.environ.get("MCS_MATCH_VALU")   # launch_match(): no count_le, no camera groups here
+    # one entry per KERNEL (pyramid: the seven k_resize_cols launches of the chain, summed): algorithmic bytes per launch.  The descriptor kernel's bytes are the
+    # pattern samples + keypoint record + descriptor (+ mask): the 845-byte orientation disc is read by k_octree's tail, where it is counted.
+    alg = {"describe_fast": (per_kp - 845) * feats_local, "octree": 845 * feats_local, "pyramid": nimg * (sum(S) - S[-1] + sum(S) - S[0]),
+           "fast": nimg * sum(S), "blur": nimg * 2 * sum(S),
            # matcher: every set pair reads its query and train rows once (descriptor + mask) and writes K list entries per query row
            "match": (nsets * 2 * rows * width + nsets * rows * 4 * sp.topk) if "match" in kern else 0}
-    dom = max((k for k in alg if k in kern and not (k == "describe" and "keypoints" in kern)), key=lambda k: kern[k])
+    # (octree: the orientation discs of the selected keys; the candidate lists it selects from are written and read inside the stage, not algorithmic input)
+    names = {"describe_fast": "k_describe" if sp.mode == "orb" else "k_describe_fast", "octree": "k_octree", "pyramid": "k_resize_cols (x%d)" % (len(S) - 1), "fast": "k_fast_cells",
+             "blur": "k_blur", "match": "k_match_mfma" if mfma else "k_match_partial"}
+    pmc_name = {"describe_fast": ("describe_exact",) if sp.mode == "orb" else ("describe",), "octree": ("octree",), "pyramid": ("pyramid",), "fast": ("fast",), "blur": ("blur",), "match": ("match",)}
+    governing = {"describe_fast": "latency of a wave's dependent chains (LDS gathers of the camera table + cross-lane sums) at 4 waves per SIMD; VALU and LDS each ~0.6-0.7 busy",
+                 "octree": "latency (a chain of passes per workgroup; L1 line fills of the orientation tail)", "pyramid": "launch / memory latency of the small levels",
+                 "fast": "VALU issue", "blur": "memory pipeline (load-8 / store-4 per lane)", "match": "matrix-core operand chain + VALU append (waits 45 % of wave cycles)"}
+    single = [k for k in alg if k in kern and k != "pyramid" and kern[k] > 0]
+    dom = max(single, key=lambda k: kern[k])
     ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
-    traffic, valu = pmc_entry(sp.tag, dom)
-    mfma = "match" in kern and job.lay.desc_size in (16, 32) and not os.environ.get("MCS_MATCH_VALU")   # launch_match(): no count_le, no camera groups here
-    kname = {"match": "k_match_mfma" if mfma else "k_match_partial", "describe": "k_describe" if sp.mode == "orb" else "k_describe_fast",
-             "keypoints": "keypoint stage: k_octree (selection + orientation of the selected keys) + " + ("k_describe" if sp.mode == "orb" else "k_orient_b + k_describe_fast + k_describe_list"),
-             "pyramid": "k_resize_level (x7)", "fast": "k_fast_cells (x3)", "blur": "k_blur"}[dom]
-    out = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
+    traffic = pmc_entry_parts(sp.tag, pmc_name[dom])
+    _, valu = pmc_entry(sp.tag, pmc_name[dom][0])
+    out = {"kernel": names[dom], "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
            "frac": round(ach / 8000.0, 5), "traffic": traffic, "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kern[dom], 4),
-           "per_kernel_ms": {k: round(v, 4) for k, v in kern.items() if k != "keypoints"},
-           "per_kernel_alg_GBps": {k: round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) for k in alg if k in kern and kern[k] > 0},
+           "governing_bound": governing[dom],
+           "per_kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+           "per_kernel_alg_GBps": {names[k]: round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) for k in alg if k in kern and kern[k] > 0},
            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the builder's GPU box, committed; fetch = 2 x FETCH_SIZE: "
                              "every read request of this chip's L2 is 128 bytes and is tallied as 64, profiles/r05/pmc_calibration.txt; Infinity-Cache hits are counted)" if traffic else None,
            "traffic_measured_in_this_run": False,
            "traffic_over_algorithmic": round(traffic / alg[dom], 3) if traffic and alg[dom] else None,
-           "note": "no kernel of this path is HBM-bound (descriptor kernel: LDS gather of the camera table + FP64 at 16 lanes/clk; matcher: FP4 MFMA dot products + a VALU-bound K-best selection); "
-                   "the bounds that apply are VALU issue and, for the matcher, the matrix cores: DESIGN.md §6"}
+           "note": "`bound` / `peak` price the kernel against HBM because BASELINE.json asks for that fraction; no kernel of this path is HBM-bound — `governing_bound` names what "
+                   "limits this one, `valu_issue` and (matcher) the matrix-core fraction carry the numbers: DESIGN.md §6"}
     flop_pair = 2 * 8 * job.lay.desc_size * (2 if job.masks_on else 1)   # a pair distance = one dot product over K = 8 * bytes (x2 with masks), DESIGN.md §4c
     if dom == "match" and mfma:   # the dominant kernel runs on the matrix cores: price it against the dense FP4 MFMA peak
         tf = pairs_local * flop_pair / (kern[dom] * 1e-3) / 1e12
         out.update({"bound": "mfma", "achieved": round(tf, 1), "peak": 10000.0, "unit": "TFLOP/s", "frac": round(tf / 10000.0, 4),
                     "alg_flop_per_launch": int(pairs_local * flop_pair), "hbm_alg_GBps": round(ach, 2)})
-    if dom == "keypoints":   # the descriptor kernels alone (the part of the stage that runs with nothing beside it in the overlapped schedule), on their own bytes
-        dk = kern["describe"]
-        out["descriptor_kernels_only"] = {"alg_bytes_per_launch": int(alg["describe"]), "avg_launch_ms": round(dk, 4), "achieved_GBps": round(alg["describe"] / (dk * 1e-3) / 1e9, 2),
-                                          "frac": round(alg["describe"] / (dk * 1e-3) / 1e9 / 8000.0, 5), "traffic": pmc_entry_parts(sp.tag, ("orient_b", "describe", "describe_list", "describe_exact"))}
     if valu:
         peak = 1024 * 2.4e9 / 4 / 1e9
         a = valu / (kern[dom] * 1e-3) / 1e9
         out["valu_issue"] = {"wave_insts_per_launch": int(valu), "achieved": round(a, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s", "frac": round(a / peak, 3)}
+    if "octree" in kern and "describe" in kern:
+        # the keypoint STAGE as one unit on SURVEY §8d's per-keypoint bytes (orientation disc 845 B + pattern samples + keypoint + descriptor [+ mask]): k_octree
+        # (selection + orientation of the selected keys in its tail), k_orient_b (records, rays), the descriptor kernels
+        st_ms, st_b = kern["octree"] + kern["describe"], per_kp * feats_local
+        st_tr, st_valu = pmc_entry(sp.tag, "keypoints")
+        out["stage"] = {"name": "keypoint stage: k_octree + " + ("k_describe" if sp.mode == "orb" else "k_orient_b + k_describe_fast + k_describe_list"), "alg_bytes_per_step": int(st_b),
+                        "ms": round(st_ms, 4), "achieved_GBps": round(st_b / (st_ms * 1e-3) / 1e9, 2), "frac": round(st_b / (st_ms * 1e-3) / 1e9 / 8000.0, 5), "traffic": st_tr,
+                        "traffic_over_algorithmic": round(st_tr / st_b, 3) if st_tr and st_b else None}
     if "match" in kern and pairs_local > 0:
         # 2 x 8 bit-ops (2.4 cycles) + 2 x 8 bit-counts (4.3 cycles) per 64 masked pairs and SIMD (tools/valu_latency.hip): the arithmetic alone
         cyc = (16 * 2.4 + 16 * 4.3) if job.masks_on else (8 * 2.4 + 8 * 4.3)
@@ -685,7 +715,7 @@ def run_job(e, sp, args, steps, warmup, want_roofline=True, check=True):
            "min_distance_to_a_rounding_tie_px_rank0": (tie if tie != float("inf") else None),
            "rounding_tie_band_px": tie_band, "keypoints_listed_within_the_band_all_steps_rank0": int(tie_listed),
            "ties_patched_in_loop": bool(job.ties_in_loop), "ties_listed_at_patch_time_rank0": int(job.ties_listed), "ties_recomputed_on_the_host_in_loop_rank0": int(job.ties_patched),
-           "n_ranks": e.world, "collective_backend": e.backend, "tag": sp.tag,
+           "n_ranks": e.world, "collective_backend": e.backend, "tag": sp.tag, "plan_digest_all_ranks_agree": job.plan_digest,
            "ms_per_step_slowest_rank": round(elapsed_max / steps * 1e3, 4), "ms_per_step_fastest_rank": round(elapsed_min / steps * 1e3, 4),
            "exchange_bytes_received_per_rank_per_step": (0 if not e.exchange else job.ring.bytes_received(e.rank) if job.ring else job.lay.send_bytes * (e.world - 1)),
            "ranks_share_one_gpu": bool(e.share),
@@ -950,42 +980,118 @@ def check_against_oracle(e, sp, job, host=None):
     return not bad
 
 
+def orc_frame(orc, ncam, cap, f):
+    """multi-frame f of the oracle pass as (per-camera counts, strided row positions over ncam * cap rows)"""
+    n = [int(orc["nkp"][f * ncam + c]) for c in range(ncam)]
+    return n, np.concatenate([c * cap + np.arange(n[c]) for c in range(ncam)])
+
+
+def orc_pair(orc, ncam, cap, f, rows_frame):
+    """the oracle's SearchByBoW(KF,KF) of stream multi-frame f against its predecessor (f = 0: the ring's pair (0, POOL - 1), row POOL of the pass) as the device
+    lays it out: an index per strided query row (-1 none), and the match count"""
+    fo = f if f > 0 else POOL
+    _, pq = orc_frame(orc, ncam, cap, fo)
+    _, pt = orc_frame(orc, ncam, cap, fo - 1)
+    m12 = orc["match"][fo, :len(pq)]
+    full = np.full(rows_frame, -1, np.int32)
+    full[pq] = np.where(m12 >= 0, pt[np.maximum(m12, 0)], -1)
+    return full, int(orc["nmatch"][fo])
+
+
 def check_full(e, sp, job, orc):
-    """Every multi-frame and every (frame, predecessor) pair the CPU-baseline pass computed (orc: its outputs, orc_extract_match_many_out) against the host copies of
-    the set the headline loop matched last (job.snapshot): keypoint records, descriptors, masks, counts, match indices and match counts, bit for bit."""
+    """Every multi-frame of the stream's pool and every (frame, predecessor) pair — the ring's (0, POOL - 1) included — as the oracle computed them (orc: the outputs of
+    cpu_baseline's orc_extract_match_many_out pass) against the host copies of the set the headline loop matched last (job.snapshot): keypoint records, descriptors,
+    masks, counts, match indices and match counts, bit for bit."""
     lay, rig, snap = job.lay, e.rig, job.snapshot
-    nf, ocap, ncam, cap = orc["nf"], orc["cap"], sp.ncam, lay.cap
+    ncam, cap = sp.ncam, lay.cap
     G = snap["G"].reshape(lay.images_total, lay.rows_img, lay.row_stride)
     kps = snap["kps"].view(np.uint8).reshape(lay.L, lay.cap, 28)
     match, nmatch = snap["match"].reshape(sp.F, lay.rows_frame), snap["nmatch"]
     mine = {cf: i for i, cf in enumerate(job.slab)}
-    okps = orc["kps"].view(np.uint8).reshape(nf * ncam, ocap, 28)
+    okps = orc["kps"].view(np.uint8).reshape(orc["nf"] * ncam, orc["cap"], 28)
     bad = []
-    pos = {}
-    nf = min(nf, job.FT)
+    nf = min(POOL, job.FT)
     for f in range(nf):
         d, m, v = rig.unpack_frame(lay, G, f)
-        p_ = []
         for c in range(ncam):
             i, lo = f * ncam + c, c * cap
             n = int(orc["nkp"][i])
-            p_.append(lo + np.arange(n))
             if not (int(v[lo:lo + cap].sum()) == n and np.array_equal(d[lo:lo + n], orc["desc"][i, :n]) and np.array_equal(m[lo:lo + n], orc["mask"][i, :n])):
                 bad.append("descriptors/masks/count of frame %d camera %d" % (f, c))
             if (c, f) in mine and not np.array_equal(kps[mine[(c, f)], :n], okps[i, :n]):
                 bad.append("keypoint records of frame %d camera %d" % (f, c))
-        pos[f] = np.concatenate(p_)
     pairs = 0
-    for f in range(1, nf):
-        m12 = orc["match"][f, :len(pos[f])]
-        full = np.full(lay.rows_frame, -1, np.int32)
-        full[pos[f]] = np.where(m12 >= 0, pos[f - 1][np.maximum(m12, 0)], -1)
+    for f in range(0 if job.FT == POOL else 1, nf):
+        full, n = orc_pair(orc, ncam, cap, f, lay.rows_frame)
         pairs += 1
-        if not (int(orc["nmatch"][f]) == int(nmatch[f]) and np.array_equal(match[f], full)):
-            bad.append("match indices of the pair (frame %d, frame %d)" % (f, f - 1))
+        if not (n == int(nmatch[f]) and np.array_equal(match[f], full)):
+            bad.append("match indices of the pair (frame %d, frame %d)" % (f, (f - 1) % job.FT))
     for msg in bad[:20]:
         print("oracle check (full) FAILED [%s]: %s" % (sp.tag, msg), file=sys.stderr)
     return not bad, {"multi_frames": nf, "images": nf * ncam, "pairs": pairs}
+
+
+def check_sweep(sp, orc, pt):
+    """one point of the batch sweep: the raw outputs of the native host's LAST call (its F multi-frames and F pairs) against the oracle pass"""
+    ncam, cap, F = sp.ncam, pt["cap"], pt["multi_frames_per_call"]
+    rows = ncam * cap
+    raw = pt.pop("_raw")
+    nkp = raw["nkp"].reshape(F, ncam)
+    kps, dsc, msk = raw["kps"].reshape(F, rows, 28), raw["desc"].reshape(F, rows, 32), raw["mask"].reshape(F, rows, 32)
+    match, nmatch = raw["match"].reshape(F, rows), raw["nmatch"]
+    okps = orc["kps"].view(np.uint8).reshape(orc["nf"] * ncam, orc["cap"], 28)
+    for j in range(F):
+        f = (pt["first_frame"] + j) % POOL
+        for c in range(ncam):
+            i, lo = f * ncam + c, c * cap
+            n = int(orc["nkp"][i])
+            if not (int(nkp[j, c]) == n and np.array_equal(kps[j, lo:lo + n], okps[i, :n]) and np.array_equal(dsc[j, lo:lo + n], orc["desc"][i, :n])
+                    and np.array_equal(msk[j, lo:lo + n], orc["mask"][i, :n])):
+                return False
+        full, n = orc_pair(orc, ncam, cap, f, rows)
+        if not (n == int(nmatch[j]) and np.array_equal(match[j], full)):
+            return False
+    return True
+
+
+def run_batch_sweep(e, sp, points=(1, 2, 4, 8, 16, 32, 64)):
+    """Throughput as a function of the batch: F multi-frames PER CALL through the boundary the reference has — host buffers in and out, both calls synchronous
+    (the reference presents ONE multi-frame per call: src/cTracking.cpp:206-235, src/cMultiFrame.cpp:92-216).  The native host (host/frame_latency.cpp, `batch F`)
+    stages the call's 3 F images, runs ONE mcs_extract_batch and ONE mcs_search_kf_kf over F (multi-frame, predecessor) pairs, steady clock around the call.
+    The raw outputs of every point's last call are kept for the oracle check (main(): check_sweep against the CPU-baseline pass)."""
+    import subprocess
+    import tempfile
+    mcs, synth = e.mcs, e.synth
+    do_db, masks_on = MODES[sp.mode]
+    NCAM, W, H, nfeat = sp.ncam, sp.W, sp.H, sp.nfeat
+    host = os.path.join(ROOT, "multicol-slam_amd", "host", "frame_latency")
+    if not os.path.exists(host):
+        return {"error": "multicol-slam_amd/host/frame_latency not built (__graft_entry__.build())"}
+    cams = [synth.lafida_cameras()[c % 3] if (W, H) == (754, 480) else synth.scaled_camera(synth.lafida_cameras()[c % 3], W, H) for c in range(NCAM)]
+    d = tempfile.mkdtemp(prefix="mcs_sweep_")
+    np.stack([_IMAGE_CACHE[(W, H, c, f)] if (W, H, c, f) in _IMAGE_CACHE else synth.stream_image(f, c, cams[c], POOL) for c in range(NCAM) for f in range(POOL)]).tofile(d + "/images.bin")
+    np.stack([np.ascontiguousarray(synth.mirror_mask(cams[c])) for c in range(NCAM)]).tofile(d + "/masks.bin")
+    open(d + "/cams.bin", "wb").write(bytes((mcs.Ocam * NCAM)(*[mcs.make_ocam(cams[c]) for c in range(NCAM)])))
+    pts = []
+    for F in points:
+        calls = max(24, min(300, 1600 // F))
+        open(d + "/cfg.txt", "w").write("ncam %d\nwidth %d\nheight %d\nnfeatures %d\nmode %d\nframes %d\nbatch %d\ncalls %d\nwarmup 12\nprestaged 1\ntopk 32\ndevice %d\nimages %s/images.bin\nmasks %s/masks.bin\n"
+                                        "cams %s/cams.bin\nout %s/out\n" % (NCAM, W, H, nfeat, do_db + masks_on, POOL, F, calls, e.local, d, d, d, d))
+        r = subprocess.run([host, d + "/cfg.txt"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            pts.append({"multi_frames_per_call": F, "error": r.stderr[-300:]})
+            continue
+        nat = json.loads(r.stdout.strip().splitlines()[-1])
+        pt = {"multi_frames_per_call": F, "calls": calls, "features_per_call": nat["features_last"], "ms_per_call": nat["total_ms"]["median"], "ms_per_call_p99": nat["total_ms"]["p99"],
+              "extract_ms": nat["extract_ms"]["median"], "match_ms": nat["match_ms"]["median"], "Mfeatures_per_s": round(nat["features_last"] / nat["total_ms"]["median"] / 1e3, 3),
+              "ms_per_multi_frame": round(nat["total_ms"]["median"] / F, 4), "cap": nat["cap"], "first_frame": nat["first_frame"]}
+        pt["_raw"] = {"nkp": np.fromfile(d + "/out.nkp", np.int32), "kps": np.fromfile(d + "/out.kps", np.uint8), "desc": np.fromfile(d + "/out.desc", np.uint8),
+                      "mask": np.fromfile(d + "/out.mask", np.uint8), "match": np.fromfile(d + "/out.match", np.int32), "nmatch": np.fromfile(d + "/out.nmatch", np.int32)}
+        pts.append(pt)
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+    return {"points": pts, "what": "F multi-frames per call, page-locked HOST buffers in (the images lie in page-locked memory as a grabber that owns its buffers delivers them) and out, extraction and SearchByBoW(KF,KF) both synchronous (native C++ host, steady clock "
+                                   "around each call, median); one call = stage 3 F images, ONE mcs_extract_batch, ONE mcs_search_kf_kf over F pairs"}
 
 
 def cpu_baseline(args, e, sp, job):
@@ -1034,17 +1140,23 @@ def cpu_baseline(args, e, sp, job):
     per_frame = tot / nf
     # the reference's own threading: one thread per camera of a multi-frame (#pragma omp parallel for num_threads(nrCams), src/cMultiFrame.cpp:128), the
     # multi-frames one after the other, the matcher single-threaded — NCAM images in flight at any time.  One warm-up, median of 5.
-    # one more pass, untimed, whose outputs leave: the in-run check compares every multi-frame and pair of this sample with the device's (check_full)
+    # one more pass, untimed, whose outputs leave: the in-run checks compare every multi-frame and pair of the stream's pool with the device's (check_full, the
+    # batch sweep).  POOL + 1 multi-frames: the last one is multi-frame 0 again, so that its pair is the ring's (0, POOL - 1).
+    nfo = POOL + 1
     ocap = nfeat + 4 * prm.nlevels
-    orc = {"nf": nf, "cap": ocap, "nkp": np.zeros(nf * NCAM, np.int32), "kps": np.zeros((nf * NCAM, ocap, 7), np.float32), "desc": np.zeros((nf * NCAM, ocap, prm.descSize), np.uint8),
-           "mask": np.zeros((nf * NCAM, ocap, prm.descSize), np.uint8), "match": np.full((nf, NCAM * ocap), -1, np.int32), "nmatch": np.zeros(nf, np.int32)}
-    if prm.nlevels == 8 and prm.descSize == 32:
+    orc = None
+    if prm.descSize == 32:
+        flat_o = [np.ascontiguousarray(_IMAGE_CACHE[(W, H, c, f % POOL)] if (W, H, c, f % POOL) in _IMAGE_CACHE else synth.stream_image(f % POOL, c, job.cams[c], POOL))
+                  for f in range(nfo) for c in range(NCAM)]
+        iptr_o = (C.c_void_p * len(flat_o))(*[a.ctypes.data for a in flat_o])
+        mptr_o = (C.c_void_p * len(flat_o))(*[mk[i % NCAM].ctypes.data for i in range(len(flat_o))])
+        ocs_o = (O.Ocam * len(flat_o))(*[O.make_ocam(job.cams[i % NCAM]) for i in range(len(flat_o))])
+        orc = {"nf": nfo, "cap": ocap, "nkp": np.zeros(nfo * NCAM, np.int32), "kps": np.zeros((nfo * NCAM, ocap, 7), np.float32), "desc": np.zeros((nfo * NCAM, ocap, 32), np.uint8),
+               "mask": np.zeros((nfo * NCAM, ocap, 32), np.uint8), "match": np.full((nfo, NCAM * ocap), -1, np.int32), "nmatch": np.zeros(nfo, np.int32)}
         L.orc_extract_match_many_out.restype = C.c_long
         L.orc_extract_match_many_out.argtypes = L.orc_extract_match_many.argtypes + [C.c_void_p] * 5
-        L.orc_extract_match_many_out(C.byref(prm), nf, NCAM, iptr, W, H, W, mptr, ocs, threads, 0.9, orc["nmatch"].ctypes.data, secs, orc["nkp"].ctypes.data, orc["kps"].ctypes.data,
+        L.orc_extract_match_many_out(C.byref(prm), nfo, NCAM, iptr_o, W, H, W, mptr_o, ocs_o, threads, 0.9, orc["nmatch"].ctypes.data, secs, orc["nkp"].ctypes.data, orc["kps"].ctypes.data,
                                      orc["desc"].ctypes.data, orc["mask"].ctypes.data, orc["match"].ctypes.data)
-    else:
-        orc = None
     nf_f = max(4, min(nf, 12))
     one_pass(nf_f, NCAM)
     rf = sorted((one_pass(nf_f, NCAM) for _ in range(5)), key=lambda r: r[0])[2]
@@ -1253,6 +1365,8 @@ def main():
         s2 = min(args.steps, 10)
         out["e2e"] = run_e2e(e, sp, args.steps, args.warmup, check)
         checks.append(out["e2e"]["oracle_check"])
+        # the PCIe-inclusive rate of the same step (host buffers in and out), beside the resident-input `value`; in `config` so that it is among the keys the driver parses
+        out["config"]["host_boundary_e2e"] = {k: out["e2e"][k] for k in ("value", "unit", "ms_per_step", "oracle_check")}
         sec = []
         for a in (secondary_args(args, workload="db", frames=16), secondary_args(args, mode="orb", nfeatures=400)):
             j2, o2 = run_job(e, Spec(a, e.world), a, s2, 2, check=check)
@@ -1265,6 +1379,8 @@ def main():
         out["secondary"] = sec
         out["latency"] = run_latency(e, sp)
         checks.append(out["latency"]["oracle_check"])
+        if not args.no_cpu_baseline:   # (its oracle check needs the CPU-baseline pass)
+            out["batch_sweep"] = run_batch_sweep(e, sp)
         try:   # a one-rank RCCL group: the code path of the N > 1 runs (the driver's SCALE run) on this box's own RCCL
             force_exchange_world1(e)
             j3, o3 = run_job(e, sp, args, s2, 2, want_roofline=False, check=check)
@@ -1289,6 +1405,26 @@ def main():
             out["config"]["oracle_checked"] = dict(counts, first_pass=out["config"].get("oracle_checked"),
                                                    what="all multi-frames and (frame, predecessor) pairs of the CPU-baseline sample against the set the timed loop matched last")
             checks.append(bool(ok_full))
+        sw = out.get("batch_sweep")
+        if isinstance(sw, dict) and "points" in sw:
+            # where the >= 50x target is crossed: against the all-quota CPU figure, and against that figure scaled linearly to every hardware thread of the host
+            for pt in sw["points"]:
+                if "_raw" in pt:
+                    if check and orc is not None:
+                        pt["oracle_check"] = bool(check_sweep(sp, orc, pt))
+                        checks.append(pt["oracle_check"])
+                    else:
+                        pt.pop("_raw")
+                        pt["oracle_check"] = None
+                if "Mfeatures_per_s" in pt:
+                    pt["vs_cpu_all_quota"] = round(pt["Mfeatures_per_s"] / cpu["value"], 1)
+            full_host = cpu["value"] * cpu["nproc"] / max(cpu["cpu_quota"], 1)
+            ok_pts = [pt for pt in sw["points"] if "Mfeatures_per_s" in pt]
+            sw["cpu_all_quota_Mfeatures_per_s"] = cpu["value"]
+            sw["cpu_scaled_to_all_hardware_threads_Mfeatures_per_s"] = round(full_host, 4)
+            sw["smallest_batch_at_50x_cpu_quota"] = next((pt["multi_frames_per_call"] for pt in ok_pts if pt["Mfeatures_per_s"] >= 50 * cpu["value"]), None)
+            sw["smallest_batch_at_50x_cpu_scaled_to_all_hardware_threads"] = next((pt["multi_frames_per_call"] for pt in ok_pts if pt["Mfeatures_per_s"] >= 50 * full_host), None)
+            out["config"]["batch_sweep_Mfeatures_per_s"] = {str(pt["multi_frames_per_call"]): pt["Mfeatures_per_s"] for pt in ok_pts}
         out["cpu_baseline"] = cpu
         out["speedup_vs_cpu_all_cores"] = round(out["value"] / cpu["value"], 2)
         out["speedup_vs_cpu_reference_threading"] = round(out["value"] / cpu["reference_threading"]["value"], 2)

@@ -31,6 +31,7 @@ using namespace mcs;
 static constexpr double kDefaultGuardEps = 5.9604644775390625e-08;
 // Default bands around the cvRound ties inside which an exact-arithmetic keypoint is recomputed on the host with the host's libm (mcs_tiefix.hip says why these)
 static constexpr double kTieBandOrb = 1e-12, kTieBandDistorted = 1e-9;
+static constexpr int kHostTieSlots = 64;   // entries of an extractor's own capture slot (host-kind batches); more listed keypoints take the whole-level download
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 // The fast pass's table of G(s) = rho(theta) / sqrt(s), theta = atan(p0 / sqrt(s)), for one camera (layout: mcs_common.h kG*), built in long double, with
@@ -214,6 +215,7 @@ static double describe_fast_bound(const mcs_ocam& m, int npoints, const GTabInfo
 std::string& mcs_err() { static thread_local std::string e; return e; }
 
 #include "mcs_host.h"
+#include "mcs_tiecap.h"
 
 struct mcs_extractor {
 	mcs_ctx* ctx = nullptr;
@@ -241,6 +243,7 @@ struct mcs_extractor {
 	struct TieSlot { uint8_t* host = nullptr; uint8_t* dev = nullptr; hipEvent_t ev = nullptr; ExtractBuffers b{}; int nimg = 0; std::vector<OcamDev> cams; long long seq = -1; bool patched = false; };
 	std::vector<TieSlot> tieRing; int tieMax = 0; long long batchSeq = 0; hipStream_t patchStream = nullptr; uint8_t* h_patchRows = nullptr;
 	unsigned long long tieWindowMisses = 0;
+	TieSlot hostTie;   // host-kind batches: the extractor's own capture slot (kHostTieSlots entries)
 	// G(s) tables of the cameras seen so far (a rig has a handful), and the batch's distinct tables as the fast pass reads them
 	struct CamFast { OcamDev key; GTabInfo info; std::vector<double> tab; };
 	std::vector<CamFast> camCache;
@@ -632,6 +635,10 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	HIPCHK(hipMemset(e->d_fbCount, 0, 3 * sizeof(int)));
 	HIPCHK(hipMemset(e->d_fbStats, 0, 2 * sizeof(unsigned long long)));
 	{ const unsigned long long inf = 0x7FF0000000000000ull; HIPCHK(hipMemcpy(e->d_tieMin, &inf, sizeof(inf), hipMemcpyHostToDevice)); }   // +inf: no coordinate seen yet
+	if (hipHostMalloc((void**)&e->hostTie.host, sizeof(TieCaptureHeader) + (size_t)kHostTieSlots * sizeof(TieCaptureEntry), hipHostMallocDefault) == hipSuccess) {
+		memset(e->hostTie.host, 0, sizeof(TieCaptureHeader));
+		e->hostTie.dev = (uint8_t*)device_view(e->hostTie.host);
+	} else { (void)hipGetLastError(); e->hostTie.host = nullptr; }   // (without it host-kind batches take the whole-level download)
 	if (getenv("MCS_DESCRIBE_EXACT")) e->describeMode = 1;   // A/B and debugging: the exact pass for every keypoint
 	HIPCHK(hipMemset(e->d_pyr, 0, B * hd.pyrBytes));
 	HIPCHK(hipMemset(e->d_blur, 0, B * hd.pyrBytes));
@@ -663,6 +670,7 @@ int mcs_extractor_destroy(mcs_extractor* e) {
 	(void)hipFree(e->d_resMask);
 	if (e->h_status) (void)hipHostFree(e->h_status);
 	free_tie_capture(e);
+	if (e->hostTie.host) (void)hipHostFree(e->hostTie.host);
 	delete e;
 	return MCS_OK;
 }
@@ -745,13 +753,60 @@ static int fix_ties(mcs_extractor* e, int nties, uint8_t* h_desc, uint8_t* h_mas
 	return MCS_OK;
 }
 
+// The listed keypoints of a batch from what k_tie_capture left in page-locked memory (mcs_tiefix.hip): entry i -> descriptor | mask rows at rowsOut + i * 2 *
+// descSize, its image and slot in where[i]; returns the number of rows recomputed, < 0 = error code.  No device access at all.
+static int recompute_captured(mcs_extractor* e, const uint8_t* slot, int n, const std::vector<OcamDev>& cams, uint8_t* rowsOut, std::vector<std::pair<int, int> >& where) {
+	const PyrDesc& hd = e->hd;
+	const int wavesPerImage = (hd.kpCap + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
+	where.clear();
+	for (int i = 0; i < n; ++i) {
+		const TieCaptureEntry* en = reinterpret_cast<const TieCaptureEntry*>(slot + sizeof(TieCaptureHeader) + (size_t)i * sizeof(TieCaptureEntry));
+		if (en->level < 0 || en->level >= hd.nlevels) continue;
+		const int img = (int)(en->gw / (uint32_t)wavesPerImage), sl = (int)(en->gw - (uint32_t)img * wavesPerImage);
+		const LevelInfo& L = hd.lv[en->level];
+		const int col = (int)(en->rec & 0xFFF) + kMinBorder, row = (int)((en->rec >> 12) & 0xFFF) + kMinBorder;
+		const OcamDev* cam = hd.mode != 0 && (size_t)img < cams.size() ? &cams[img] : nullptr;
+		if (hd.mode != 0 && !cam) return fail(MCS_ERR_INVALID, "internal: tie capture without camera models");
+		bool miss = false;
+		HostLevel hl{nullptr, nullptr, L.w, L.h, en->patch, row - kTiePatchR, col - kTiePatchR, kTiePatchDim, &miss};
+		uint8_t* dsc = rowsOut + where.size() * 2 * hd.descSize;
+		describe_host(hd.mode, hd.descSize, kPattern, cam, hd.undistort, en->level, L.scale, row, col, en->angle, hl, dsc, dsc + hd.descSize);
+		if (miss) { ++e->tieWindowMisses; return fail(MCS_ERR_UNSUPPORTED, "a pattern sample of a listed keypoint lies outside the captured window (camera model with > 1.9x local magnification?)"); }
+		where.push_back(std::make_pair(img, sl));
+	}
+	return (int)where.size();
+}
+
+// Host-kind batches: the listed keypoints from the extractor's own capture slot (written by k_tie_capture in front of the batch's final synchronisation) — a few
+// microseconds per keypoint, no device access; the whole-level download of fix_ties only when more keypoints are listed than the slot holds (widened bands)
+static int fix_ties_host(mcs_extractor* e, int nties, uint8_t* h_desc, uint8_t* h_mask) {
+	const PyrDesc& hd = e->hd;
+	if (!e->hostTie.host || nties > kHostTieSlots) return fix_ties(e, nties, h_desc, h_mask);
+	std::vector<std::pair<int, int> > where;
+	std::vector<uint8_t> rows((size_t)nties * 2 * hd.descSize);
+	const int done = recompute_captured(e, e->hostTie.host, nties, e->h_cams, rows.data(), where);
+	if (done < 0) return done;
+	for (int i = 0; i < done; ++i) {
+		const size_t r = ((size_t)where[i].first * hd.kpCap + where[i].second) * hd.descSize;
+		if (h_desc) memcpy(h_desc + r, rows.data() + (size_t)i * 2 * hd.descSize, hd.descSize);
+		if (h_mask) memcpy(h_mask + r, rows.data() + (size_t)i * 2 * hd.descSize + hd.descSize, hd.descSize);
+	}
+	e->tieFixed += (unsigned long long)done;
+	return MCS_OK;
+}
+
 namespace mcs {
 // Host-kind outputs in ONE launch: when the caller's output arrays are page-locked (mcs_host_alloc / hipHostMalloc: visible to the device), the valid rows of the
 // five staging arrays, the counts and the batch's status words are written straight into them.  The five hipMemcpyAsync calls this replaces cost ~15 us each for
 // ONE multi-frame (7 us of transfer, 8 of runtime per call), plus two more for the status words: a third of the extraction's latency.
 struct ExtractOut { int32_t* nkp; uint32_t* kps; uint32_t* desc; uint32_t* mask; uint32_t* rays; int* status; };
 __global__ __launch_bounds__(256) void k_extract_out(const int* __restrict__ d_nkp, const uint32_t* __restrict__ kps, const uint32_t* __restrict__ desc, const uint32_t* __restrict__ mask,
-                                                     const uint32_t* __restrict__ rays, const int* __restrict__ d_status, const int* __restrict__ d_ties, ExtractOut o, int kpCap, int descDw) {
+                                                     const uint32_t* __restrict__ rays, const int* __restrict__ d_status, const int* __restrict__ d_ties, ExtractOut o, int kpCap, int descDw,
+                                                     ExtractBuffers b, int nimg, int wavesPerImage, int maxTies, uint8_t* __restrict__ tieOut) {
+	if ((int)blockIdx.y == nimg) {   // the extra grid row: the rounding-tie capture of this batch (mcs_tiecap.h), in the same launch
+		tie_capture_body(b, nimg, wavesPerImage, maxTies, tieOut, blockIdx.x, gridDim.x);
+		return;
+	}
 	const int img = blockIdx.y, n = d_nkp[img], part = blockIdx.x, parts = gridDim.x;
 	auto copy = [&](uint32_t* dst, const uint32_t* src, int rowDw) {   // rows [0, n) of image img: one contiguous run of dwords
 		const size_t base = (size_t)img * kpCap * rowDw;
@@ -966,7 +1021,15 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		c->tic("blur"); launch_blur(b, hd, nimg, s); c->toc("blur");
 	}
 	if (forked) { b.sideStream = c->side; b.evDescFork = c->evDescFork; b.evDescJoin = c->evDescJoin; }   // the side stream is idle again: the main stream has waited for the blur
-	if (!replayed) { c->tic("describe"); launch_describe(b, hd, nimg, s); c->toc("describe"); }
+	if (!replayed) {
+		ExtractBuffers bd = b;
+		if (c->timing) {   // the dominant kernel alone (k_describe_fast; ORB: k_describe), inside the "describe" bracket
+			Timer& t = c->timers["describe_fast"];
+			if (!t.a) { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
+			bd.evFastA = t.a; bd.evFastB = t.b; t.used = true;
+		}
+		c->tic("describe"); launch_describe(bd, hd, nimg, s); c->toc("describe");
+	}
 	HIPCHK(hipGetLastError());
 	e->last = b; e->lastN = nimg;
 	if (kind != MCS_MEM_HOST && !e->tieRing.empty()) {
@@ -988,15 +1051,18 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		static const bool outKernel = !(getenv("MCS_OUT_KERNEL") && atoi(getenv("MCS_OUT_KERNEL")) == 0);   // A/B, tests: 0 = always the runtime's copies
 		if (outKernel && o.nkp && o.kps && o.desc && o.mask && o.status && (o.rays || !rays)) {
 			// page-locked outputs: one launch writes the valid rows (rows past an image's count are left as they are), the counts and the status words
-			hipLaunchKernelGGL(mcs::k_extract_out, dim3(4, nimg), dim3(256), 0, s, e->d_nkp, (const uint32_t*)e->d_kps, (const uint32_t*)e->d_odesc, (const uint32_t*)e->d_omask,
-			                   (const uint32_t*)e->d_rays, e->d_status, e->d_fbCount + 2, o, hd.kpCap, hd.descSize / 4);
+			// (+ one grid row when the extractor has its capture slot: the listed keypoints' windows, usually none)
+			hipLaunchKernelGGL(mcs::k_extract_out, dim3(4, nimg + (e->hostTie.dev ? 1 : 0)), dim3(256), 0, s, e->d_nkp, (const uint32_t*)e->d_kps, (const uint32_t*)e->d_odesc, (const uint32_t*)e->d_omask,
+			                   (const uint32_t*)e->d_rays, e->d_status, e->d_fbCount + 2, o, hd.kpCap, hd.descSize / 4, b, nimg, (hd.kpCap + kSlotAlign - 1) / kSlotAlign * kSlotAlign,
+			                   kHostTieSlots, e->hostTie.dev);
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipStreamSynchronize(s));
 			st = e->h_status[0]; nties = e->h_status[1];
 			if (st != 0) { (void)hipMemset(e->d_status, 0, sizeof(int)); return fail(st, "device capacity exceeded during extraction"); }
-			if (nties > 0) { if (int r = fix_ties(e, nties, desc, descmask)) return r; }
+			if (nties > 0) { if (int r = fix_ties_host(e, nties, desc, descmask)) return r; }
 			return MCS_OK;
 		}
+		if (e->hostTie.dev) launch_tie_capture(b, hd, nimg, kHostTieSlots, e->hostTie.dev, s);
 		HIPCHK(hipMemcpyAsync(nkp, e->d_nkp, nimg * sizeof(int), hipMemcpyDeviceToHost, s));
 		HIPCHK(hipMemcpyAsync(keypoints, e->d_kps, rows * sizeof(mcs_keypoint), hipMemcpyDeviceToHost, s));
 		HIPCHK(hipMemcpyAsync(desc, e->d_odesc, rows * hd.descSize, hipMemcpyDeviceToHost, s));
@@ -1007,7 +1073,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		HIPCHK(hipStreamSynchronize(s));
 		if (st != 0) { (void)hipMemset(e->d_status, 0, sizeof(int)); return fail(st, "device capacity exceeded during extraction"); }
 		// keypoints whose exact arithmetic came within the band of a rounding tie: recomputed here with the host's libm before the results are final
-		if (nties > 0) { if (int r = fix_ties(e, nties, desc, descmask)) return r; }
+		if (nties > 0) { if (int r = fix_ties_host(e, nties, desc, descmask)) return r; }
 	}
 	return MCS_OK;
 }
@@ -1141,26 +1207,14 @@ int mcs_extractor_patch_ties(mcs_extractor* e, int back, int* listed, int* recom
 	if (n > e->tieMax) return fail(MCS_ERR_CAPACITY, "more keypoints inside the tie band than the capture slots hold (mcs_extractor_set_tie_capture max_ties); use mcs_extractor_fix_ties for this band");
 	const PyrDesc& hd = e->hd;
 	const ExtractBuffers& b = t.b;
-	const int wavesPerImage = (hd.kpCap + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
-	int done = 0;
-	for (int i = 0; i < n; ++i) {
-		const TieCaptureEntry* en = reinterpret_cast<const TieCaptureEntry*>(t.host + sizeof(TieCaptureHeader) + (size_t)i * sizeof(TieCaptureEntry));
-		if (en->level < 0 || en->level >= hd.nlevels) continue;
-		const int img = (int)(en->gw / (uint32_t)wavesPerImage), sl = (int)(en->gw - (uint32_t)img * wavesPerImage);
-		const LevelInfo& L = hd.lv[en->level];
-		const int col = (int)(en->rec & 0xFFF) + kMinBorder, row = (int)((en->rec >> 12) & 0xFFF) + kMinBorder;
-		const OcamDev* cam = hd.mode != 0 && (size_t)img < t.cams.size() ? &t.cams[img] : nullptr;
-		if (hd.mode != 0 && !cam) return fail(MCS_ERR_INVALID, "internal: tie capture without camera models");
-		bool miss = false;
-		HostLevel hl{nullptr, nullptr, L.w, L.h, en->patch, row - kTiePatchR, col - kTiePatchR, kTiePatchDim, &miss};
-		uint8_t* dsc = e->h_patchRows + (size_t)done * 2 * hd.descSize;
-		uint8_t* msk = dsc + hd.descSize;
-		describe_host(hd.mode, hd.descSize, kPattern, cam, hd.undistort, en->level, L.scale, row, col, en->angle, hl, dsc, msk);
-		if (miss) { ++e->tieWindowMisses; return fail(MCS_ERR_UNSUPPORTED, "a pattern sample of a listed keypoint lies outside the captured window (camera model with > 1.9x local magnification?)"); }
-		const size_t drow = ((size_t)img * b.outImgPitch + sl) * b.outRowStride;
+	std::vector<std::pair<int, int> > where;
+	const int done = recompute_captured(e, t.host, n, t.cams, e->h_patchRows, where);
+	if (done < 0) return done;
+	for (int i = 0; i < done; ++i) {
+		const uint8_t* dsc = e->h_patchRows + (size_t)i * 2 * hd.descSize;
+		const size_t drow = ((size_t)where[i].first * b.outImgPitch + where[i].second) * b.outRowStride;
 		HIPCHK(hipMemcpyAsync(b.out_desc + drow, dsc, hd.descSize, hipMemcpyHostToDevice, e->patchStream));
-		HIPCHK(hipMemcpyAsync(b.out_mask + drow, msk, hd.descSize, hipMemcpyHostToDevice, e->patchStream));
-		++done;
+		HIPCHK(hipMemcpyAsync(b.out_mask + drow, dsc + hd.descSize, hd.descSize, hipMemcpyHostToDevice, e->patchStream));
 	}
 	// the rows are in place before this returns: whatever the caller enqueues next (matcher, exchange, download) reads the host's arithmetic
 	HIPCHK(hipStreamSynchronize(e->patchStream));

@@ -142,6 +142,7 @@ struct ExtractBuffers {
 	unsigned long long* tieTotal;        // running total (all batches of the extractor)
 	double tieBand;                      // pixels; < 0: nothing is listed
 	hipStream_t sideStream; hipEvent_t evDescFork, evDescJoin;   // optional: the exact pass over preList runs here, beside the fast pass
+	hipEvent_t evFastA, evFastB;         // optional (per-kernel timing passes only): recorded around k_describe_fast / k_describe<0> alone ("describe_fast")
 	double guardEps;                     // half-width of the guard band around the rounding ties
 	int describeMode;                    // 0 fast + exact fallback, 1 exact pass for every keypoint
 	// outputs

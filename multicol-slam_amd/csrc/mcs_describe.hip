@@ -1603,7 +1603,9 @@ static void launch_fast_passes(const ExtractBuffers& b, int nimg, int wavesPerIm
 	// more than the default 64 KB of dynamic LDS per workgroup: the attribute belongs to the function ON THE CURRENT DEVICE, and one process may drive several
 	// devices from several threads (host/rig_host.cpp), so it is set before every launch (as launch_spec in mcs_greedy.hip does), not once per process
 	if (fLds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_describe_fast<MODE, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fLds);
+	if (b.evFastA) (void)hipEventRecord(b.evFastA, s);
 	hipLaunchKernelGGL((k_describe_fast<MODE, NB>), dim3(fblocks), dim3(64 * kFastWaves), fLds, s, b, wavesPerImage, nslots, groupsPerBlock);
+	if (b.evFastB) (void)hipEventRecord(b.evFastB, s);
 	// the fallbacks — a few keypoints on the critical path — by a workgroup each (k_describe_list_split); MCS_LIST_SPLIT=0: one wave each, for A/B
 	static const bool split = !(getenv("MCS_LIST_SPLIT") && atoi(getenv("MCS_LIST_SPLIT")) == 0);
 	typedef SplitGeom<MODE, NB> SG;
@@ -1628,10 +1630,12 @@ static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hi
 			return;
 		}
 	}
+	if (b.evFastA) (void)hipEventRecord(b.evFastA, s);
 	if (nb == 2) hipLaunchKernelGGL((k_describe<MODE, 2>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 	else if (nb == 4) hipLaunchKernelGGL((k_describe<MODE, 4>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 	else if constexpr (MODE == 2) hipLaunchKernelGGL((k_describe_wide<MODE, 8>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
 	else hipLaunchKernelGGL((k_describe<MODE, 8>), dim3(blocks), dim3(64 * wpb), ldsBytes, s, b, wavesPerImage);
+	if (b.evFastB) (void)hipEventRecord(b.evFastB, s);
 }
 
 size_t describe_aux_bytes() { return KpAuxSoA::bytes_per_slot(); }

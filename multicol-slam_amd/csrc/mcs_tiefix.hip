@@ -13,6 +13,7 @@
 // src/cam_model_omni.cpp:49-67, 146-161, include/cam_model_omni.h:127-145.  This is product code (the C ABI's own host side), not the test oracle: nothing here
 // includes, links or calls oracle/.
 #include "mcs_common.h"
+#include "mcs_tiecap.h"
 
 #include <cmath>
 #include <cstring>
@@ -147,45 +148,12 @@ void describe_host(int mode, int descSize, const signed char* pattern, const Oca
 // angle and the (2R + 1)^2 window of Sampler::at values around it (R = kTiePatchR: the pattern's radius is 15 * sqrt(2) = 21.2 px before distortion, and the
 // omni model compresses away from the optical axis).  mcs_extractor_patch_ties (mcs_capi.hip) reads it behind the batch's event.
 __global__ __launch_bounds__(256) void k_tie_capture(ExtractBuffers b, int nimg, int wavesPerImage, int maxTies, uint8_t* __restrict__ out) {
-	const PyrDesc& d = *b.desc;
-	const int n = *b.tieCount;
-	TieCaptureHeader* hdr = reinterpret_cast<TieCaptureHeader*>(out);
-	if (blockIdx.x == 0 && threadIdx.x == 0) { hdr->count = n; hdr->status = *b.status; }
-	const int t = blockIdx.x;
-	if (t >= n || t >= maxTies) return;
-	TieCaptureEntry* en = reinterpret_cast<TieCaptureEntry*>(out + sizeof(TieCaptureHeader) + (size_t)t * sizeof(TieCaptureEntry));
-	const uint32_t gw = b.tieList[t];
-	const int img = (int)(gw / (uint32_t)wavesPerImage), sl = (int)(gw - (uint32_t)img * wavesPerImage);
-	int level = -1, pos = 0, total = 0;
-	if (img < nimg && sl < d.kpCap)
-		for (int l = 0; l < d.nlevels; ++l) { const int c = b.selCount[(size_t)img * d.nlevels + l]; if (sl >= total && sl < total + c) { level = l; pos = sl - total; } total += c; }
-	if (level < 0) { if (threadIdx.x == 0) { en->gw = gw; en->level = -1; } return; }
-	const LevelInfo& L = d.lv[level];
-	const uint32_t rec = b.sel[(size_t)img * d.selPerImage + L.selBase + pos];
-	if (threadIdx.x == 0) { en->gw = gw; en->level = level; en->rec = rec; en->angle = b.selAngle[(size_t)img * d.selPerImage + L.selBase + pos]; }
-	const int col = (int)(rec & 0xFFF) + kMinBorder, row = (int)((rec >> 12) & 0xFFF) + kMinBorder;
-	int rstride = 0;
-	const uint8_t* raw = level_ptr(b, d, img, level, &rstride);
-	const uint8_t* blur = b.blur + (size_t)img * d.pyrBytes + L.off;
-	constexpr int D = 2 * kTiePatchR + 1;
-	for (int i = threadIdx.x; i < D * D; i += 256) {
-		int r = row - kTiePatchR + i / D, c = col - kTiePatchR + i % D;
-		int v;
-		if ((unsigned)r < (unsigned)L.h && (unsigned)c < (unsigned)L.w) v = blur[(size_t)r * L.stride + c];
-		else {   // Sampler::at (mcs_describe.hip): clamped to the 25-px frame, reflect-101 into the unblurred level
-			r = r < -kEdge ? -kEdge : (r > L.h + kEdge - 1 ? L.h + kEdge - 1 : r);
-			c = c < -kEdge ? -kEdge : (c > L.w + kEdge - 1 ? L.w + kEdge - 1 : c);
-			r = r < 0 ? -r : (r >= L.h ? 2 * (L.h - 1) - r : r);
-			c = c < 0 ? -c : (c >= L.w ? 2 * (L.w - 1) - c : c);
-			v = raw[(size_t)r * rstride + c];
-		}
-		en->patch[i] = (uint8_t)v;
-	}
+	tie_capture_body(b, nimg, wavesPerImage, maxTies, out, blockIdx.x, gridDim.x);
 }
 
 void launch_tie_capture(const ExtractBuffers& b, const PyrDesc& hd, int nimg, int maxTies, uint8_t* devOut, hipStream_t s) {
 	const int wavesPerImage = (hd.kpCap + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
-	hipLaunchKernelGGL(k_tie_capture, dim3(maxTies), dim3(256), 0, s, b, nimg, wavesPerImage, maxTies, devOut);
+	hipLaunchKernelGGL(k_tie_capture, dim3(maxTies < 64 ? maxTies : 64), dim3(256), 0, s, b, nimg, wavesPerImage, maxTies, devOut);
 }
 
 }  // namespace mcs

@@ -77,6 +77,38 @@ static std::vector<Run> ring_runs(const Layout& lay, int rank) {
 	return out;
 }
 
+// The plan's digest — the same 32 bytes multicol-slam_amd/rig.py plan_digest computes (four 64-bit FNV-1a hashes over the plan's integers as little-endian int64:
+// arguments, every rank's slab, every ring run or keyframe shard, every frame pair), here from the C++ restatement above.  `bench.py --dry-run` prints it for the
+// plan rig.plan_check has verified; every rank of a run computes it before its first exchange and the ranks compare (rank_main).
+static std::string plan_digest(int ncam, int F, int world, int cap, int D, int ds, int topk) {
+	const Layout lay(ncam, F * world, world, cap, ds);
+	std::vector<int64_t> v = {ncam, F, world, cap, D, ds, topk, lay.L, lay.rows_img, lay.row_stride, (int64_t)lay.block_bytes, (int64_t)lay.send_bytes};
+	for (int r = 0; r < world; ++r)
+		for (int x = r * lay.L; x < (r + 1) * lay.L; ++x) { v.push_back(x / lay.FT); v.push_back(x % lay.FT); }
+	if (D == 0) {
+		for (int r = 0; r < world; ++r) {
+			for (const Run& q : ring_runs(lay, r)) { v.push_back(q.owner); v.push_back(q.src); v.push_back(q.dst); v.push_back(q.n); }
+			for (int f = r * F; f < (r + 1) * F; ++f) { v.push_back(f); v.push_back(((f - 1) % lay.FT + lay.FT) % lay.FT); }
+		}
+	} else {
+		for (int r = 0; r < world; ++r) {
+			std::vector<int64_t> sh;
+			for (int k = 0; k < D; ++k) if (k % world == r) sh.push_back(k);
+			v.push_back((int64_t)sh.size());
+			v.insert(v.end(), sh.begin(), sh.end());
+		}
+	}
+	static const uint64_t bases[4] = {0xCBF29CE484222325ull, 0x84222325CBF29CE4ull, 0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full};
+	std::string hex;
+	for (uint64_t h : bases) {
+		for (int64_t x : v)
+			for (int b = 0; b < 8; ++b) h = (h ^ (uint64_t)(((uint64_t)x >> (8 * b)) & 0xFF)) * 0x100000001B3ull;
+		for (int b = 0; b < 8; ++b) { char t[3]; snprintf(t, sizeof t, "%02x", (unsigned)((h >> (8 * b)) & 0xFF)); hex += t; }
+	}
+	return hex;
+}
+static std::vector<std::string> g_digest;   // per rank, compared before the first exchange
+
 static std::map<std::string, std::string> read_config(const char* path) {
 	std::map<std::string, std::string> m;
 	std::ifstream f(path);
@@ -100,7 +132,8 @@ struct Job {
 
 static pthread_barrier_t g_barrier;
 static std::atomic<int> g_firstExchange{0};   // ranks whose first exchange has completed (the start-up watchdog in main waits for all of them)
-static std::vector<unsigned> g_xconf;   // per rank: which of the context's streams the exchange stream shares a hardware queue with (mcs_ctx_stream_conflicts)
+static std::vector<unsigned> g_xconf;
+static std::vector<long> g_ties;   // rounding-tie rows recomputed on the host inside the loop, per rank   // per rank: which of the context's streams the exchange stream shares a hardware queue with (mcs_ctx_stream_conflicts)
 static std::vector<double> g_ms, g_msAll;   // per rank: its own step time, and the time to the barrier behind the slowest rank
 
 static void rank_main(const Job& J, int rank, ncclComm_t comm) {
@@ -134,8 +167,8 @@ static void rank_main(const Job& J, int rank, ncclComm_t comm) {
 		HIPOK(hipMemcpy(d_msk + i * px, J.masks.data() + c * px, px, hipMemcpyHostToDevice));
 		memcpy(&cam[i], J.cams.data() + (size_t)c * sizeof(mcs_ocam), sizeof(mcs_ocam));
 	}
-	// ---- three buffer sets in rotation (the schedule of bench.py's Job.step): step n extracts set n % 3 and STARTS its exchange on a second stream; the exchange
-	// of step n - 1 had a whole step of kernels to hide behind and is finished (an event wait) before its rows are flagged and matched — as a deferred search
+	// ---- three buffer sets in rotation (the schedule of bench.py's Job.step): step n extracts set n % 3, then patches the rounding-tie rows of set (n - 1) % 3 on
+	// the host and STARTS that set's exchange on a second stream — beside step n's kernels —; its rows are flagged and matched stream-ordered behind it, as a deferred search
 	// (mcs_ctx_set_async_search: lists + greedy pass on the library's own stream beside the next extraction), so results are one step late.  The search that last
 	// read a set is fenced (mcs_ctx_search_fence) before the set is extracted into again: nothing of a search's inputs is overwritten while it runs.
 	constexpr int NS = 3;
@@ -209,7 +242,10 @@ static void rank_main(const Job& J, int rank, ncclComm_t comm) {
 
 	if (!ring) {   // untimed: stored keyframe k = multi-frame k % FT of one pass (as bench.py fills its database)
 		Set& b = sets[0];
-		extract(b); exchange_begin(b); exchange_end(b);
+		extract(b);
+		HIPOK(hipStreamSynchronize(stream));
+		MCSOK(mcs_extractor_fix_ties(ex, nullptr));   // rounding-tie rows of the stored keyframes: the host libm's (synchronous form, untimed pass)
+		exchange_begin(b); exchange_end(b);
 		for (int j = 0; j < nkf; ++j)
 			for (int c = 0; c < J.ncam; ++c) {
 				const size_t x = lay.image_index(c, kfs[j] % FT);
@@ -218,22 +254,46 @@ static void rank_main(const Job& J, int rank, ncclComm_t comm) {
 			}
 		HIPOK(hipStreamSynchronize(stream));
 	}
+	// before the first exchange: this rank's digest of the whole plan, printed and compared across the ranks (a mismatch names the rank and ends the run, exit 7)
+	g_digest[rank] = plan_digest(J.ncam, J.F, J.world, cap, J.D, 32, J.topk);
+	fprintf(stderr, "rig_host: rank %d of %d plan digest %s\n", rank, J.world, g_digest[rank].c_str());
+	pthread_barrier_wait(&g_barrier);
+	for (int r = 0; r < J.world; ++r)
+		if (g_digest[r] != g_digest[0]) {
+			if (rank == 0) fprintf(stderr, "rig_host: PLAN DIGEST MISMATCH — rank %d holds %s, rank 0 holds %s\n", r, g_digest[r].c_str(), g_digest[0].c_str());
+			pthread_barrier_wait(&g_barrier);
+			_exit(7);
+		}
 	MCSOK(mcs_ctx_set_async_search(ctx, 1));
+	// Rounding ties are enforced INSIDE the loop (include/mcs_c.h: mcs_extractor_set_tie_capture): a capture slot per buffer set; the rows of step n - 1 are patched
+	// on the host — behind that batch's event only, the device already runs step n — BEFORE they leave for the other ranks and before their search is enqueued.
+	MCSOK(mcs_extractor_set_tie_capture(ex, NS, 256));
 	int cur = 0;
-	bool pending = false;   // the set before `cur` has an exchange in flight that nobody has matched yet
+	bool pending = false;   // the set before `cur` has been extracted and nobody has exchanged / matched it yet
+	long tiesPatched = 0;
+	auto finish = [&](Set& p) {               // patch (host), exchange, flags, search of the set extracted one call earlier
+		int listed = 0, fixed = 0;
+		MCSOK(mcs_extractor_patch_ties(ex, 1, &listed, &fixed));
+		tiesPatched += fixed;
+		exchange_begin(p); exchange_end(p); match(p);
+	};
 	auto step = [&]() {
 		Set& b = sets[cur];
 		Set& p = sets[(cur + NS - 1) % NS];
 		cur = (cur + 1) % NS;
 		MCSOK(mcs_ctx_search_fence(ctx, 1));   // the search issued before the latest one read the set about to be overwritten (three sets, matching one step late)
-		extract(b);
-		exchange_begin(b);                     // in flight until the NEXT step needs it
-		if (pending) { exchange_end(p); match(p); }
+		extract(b);                            // enqueued FIRST: when the previous extraction ends the device has this one queued, the host wait below costs it nothing
+		if (pending) finish(p);                // its collective runs on the exchange stream beside this step's kernels, the search stream-ordered behind it
 		pending = true;
 	};
-	auto drain = [&]() -> Set& {              // finish the step in flight: its exchange, flags and search; returns the set whose results are complete
+	auto drain = [&]() -> Set& {              // finish the step in flight: its patch, exchange, flags and search; returns the set whose results are complete
 		Set& p = sets[(cur + NS - 1) % NS];
-		if (pending) { exchange_end(p); match(p); pending = false; }
+		if (pending) {
+			int listed = 0, fixed = 0;
+			MCSOK(mcs_extractor_patch_ties(ex, 0, &listed, &fixed));
+			tiesPatched += fixed;
+			exchange_begin(p); exchange_end(p); match(p); pending = false;
+		}
 		MCSOK(mcs_ctx_join(ctx));
 		MCSOK(mcs_ctx_synchronize(ctx));
 		HIPOK(hipStreamSynchronize(xstream));
@@ -253,6 +313,7 @@ static void rank_main(const Job& J, int rank, ncclComm_t comm) {
 	pthread_barrier_wait(&g_barrier);
 	g_msAll[rank] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / std::max(J.steps, 1);
 	Set& R = drain();                          // untimed: the last extracted set through its exchange and search
+	g_ties[rank] = tiesPatched;
 	MCSOK(mcs_extractor_status(ex));
 	uint8_t *d_G = R.G, *d_valid = R.valid; int32_t *d_nkp = R.nkp, *d_match = R.match, *d_nmatch = R.nmatch; mcs_keypoint* d_kps = R.kps;
 
@@ -293,6 +354,14 @@ int main(int argc, char** argv) {
 	Job J;
 	J.ncam = geti("ncam", 3); J.W = geti("width", 754); J.H = geti("height", 480); J.nfeat = geti("nfeatures", 1000); J.mode = geti("mode", 2);
 	J.F = geti("frames", 2); J.D = geti("keyframes", 0); J.steps = geti("steps", 2); J.warmup = geti("warmup", 1); J.topk = geti("topk", 32);
+	for (int i = 2; i < argc; ++i)
+		if (!strcmp(argv[i], "--plan-only")) {   // no device needed: the digest of the plan this configuration would run (`cap N` in the configuration: rows per image)
+			int world = geti("gpus", 1);
+			for (int k = 2; k + 1 < argc; ++k) if (!strcmp(argv[k], "--gpus")) world = atoi(argv[k + 1]);
+			if (world < 1 || (J.ncam * J.F * world) % world) { fprintf(stderr, "bad plan\n"); return 1; }
+			printf("{\"plan_digest\": \"%s\", \"world\": %d}\n", plan_digest(J.ncam, J.F, world, geti("cap", J.nfeat + 24), J.D, 32, J.topk).c_str(), world);
+			return 0;
+		}
 	int ndev = 0;
 	HIPOK(hipGetDeviceCount(&ndev));
 	// `gpus N` in the configuration or `--gpus N` on the command line (the command line wins): the job runs on exactly N GPUs or not at all — a run that quietly
@@ -326,7 +395,7 @@ int main(int argc, char** argv) {
 	});
 	NCCLOK(ncclCommInitAll(comms.data(), J.world, devs.data()));
 	pthread_barrier_init(&g_barrier, nullptr, J.world);
-	g_ms.assign(J.world, 0.0); g_msAll.assign(J.world, 0.0); g_xconf.assign(J.world, 0u);
+	g_ms.assign(J.world, 0.0); g_msAll.assign(J.world, 0.0); g_xconf.assign(J.world, 0u); g_ties.assign(J.world, 0); g_digest.assign(J.world, std::string());
 	std::vector<std::thread> th;
 	for (int r = 0; r < J.world; ++r) th.emplace_back(rank_main, std::cref(J), r, comms[r]);
 	for (auto& t : th) t.join();
@@ -339,7 +408,8 @@ int main(int argc, char** argv) {
 	per += "]";
 	printf("{\"host\": \"rig_host (C++, one process, one thread per GPU, RCCL from ncclCommInitAll; three buffer sets, exchange on its own stream, matching one step late)\", "
 	       "\"n_gpus\": %d, \"steps\": %d, \"ms_per_step\": %.4f, \"ms_per_step_ranks\": %s, "
-	       "\"exchange\": \"%s\", \"exchange_stream_queue_conflicts_rank0\": %u, \"multi_frames_per_step_per_gpu\": %d, \"stored_keyframes\": %d}\n",
-	       J.world, J.steps, ms, per.c_str(), J.D == 0 ? "ncclSend/ncclRecv group (frame ring)" : "ncclAllGather", g_xconf[0], J.F, J.D);
+	       "\"exchange\": \"%s\", \"exchange_stream_queue_conflicts_rank0\": %u, \"multi_frames_per_step_per_gpu\": %d, \"stored_keyframes\": %d, "
+	       "\"ties_patched_in_loop\": true, \"ties_recomputed_on_the_host_rank0\": %ld, \"plan_digest_all_ranks_agree\": \"%s\"}\n",
+	       J.world, J.steps, ms, per.c_str(), J.D == 0 ? "ncclSend/ncclRecv group (frame ring)" : "ncclAllGather", g_xconf[0], J.F, J.D, g_ties[0], g_digest[0].c_str());
 	return 0;
 }

@@ -169,6 +169,55 @@ def plan_check(ncam, frames_per_rank, world, cap, keyframes, desc_size=32, topk=
     return out
 
 
+_FNV_BASES = (0xCBF29CE484222325, 0x84222325CBF29CE4, 0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F)
+
+
+def plan_digest(ncam, frames_per_rank, world, cap, keyframes, desc_size=32, topk=32):
+    """32 bytes that name the WHOLE plan of a multi-GPU run — the arguments, every rank's slab, every transfer run of the ring exchange (owner, source block,
+    destination block, length) or every rank's keyframe shard, every (frame, predecessor) pair and its owner — as four 64-bit FNV-1a hashes (different offset
+    bases) over the plan's integers as little-endian int64.  Every rank computes it from ITS OWN arguments before the first exchange and the ranks compare
+    (check_plan_digests): a rank started with another frame count, world size or library build says so before any buffer is wrong.  host/rig_host.cpp computes the
+    same bytes from its C++ restatement of the layout (tests/test_rig_plan_digest.py compares the two), `bench.py --dry-run` prints them per workload."""
+    lay = RigLayout(ncam, frames_per_rank * world, world, cap, desc_size)
+    ints = [ncam, frames_per_rank, world, cap, keyframes, desc_size, topk, lay.L, lay.rows_img, lay.row_stride, lay.block_bytes, lay.send_bytes]
+    for r in range(world):
+        for c, f in lay.slab(r):
+            ints += [c, f]
+    if keyframes == 0:
+        ex = RingExchange(lay)
+        for r in range(world):
+            for run in ex._runs(r):
+                ints += list(run)
+            for f, p in lay.frame_pairs(r):
+                ints += [f, p]
+    else:
+        for r in range(world):
+            sh = lay.keyframe_shard(keyframes, r)
+            ints += [len(sh)] + sh
+    data = np.asarray(ints, "<i8").tobytes()
+    out = b""
+    for h in _FNV_BASES:
+        for byte in data:
+            h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        out += h.to_bytes(8, "little")
+    return out
+
+
+def check_plan_digests(mine, rank, world, all_gather):
+    """compare the plan digests of all ranks (`all_gather`: 32 bytes -> world * 32 bytes, rank-major); returns the hex digest, raises ValueError naming the ranks whose
+    digest differs from the one most ranks hold"""
+    got = bytes(all_gather(mine))
+    if len(got) != 32 * world:
+        raise ValueError("plan digest exchange returned %d bytes, expected %d" % (len(got), 32 * world))
+    per = [got[32 * r:32 * (r + 1)] for r in range(world)]
+    major = max(set(per), key=per.count)
+    odd = [r for r in range(world) if per[r] != major]
+    if odd:
+        raise ValueError("rig plan digest mismatch: rank(s) %s hold %s, the others %s (rank %d holds %s) — different arguments, world size or build on those ranks"
+                         % (odd, sorted({per[r].hex()[:16] for r in odd}), major.hex()[:16], rank, mine.hex()[:16]))
+    return major.hex()
+
+
 def ring_exchange_begin(ex, rank, send, recv, group=None, self_via_p2p=False):
     """start the ring exchange of one step: send / recv are flat uint8 torch tensors (the rank's send blocks, its local [camera][F + 1] array).  Local runs
     are copied at once (self_via_p2p: sent through the backend like the others — a one-rank RCCL run then exercises the transport); returns the list of

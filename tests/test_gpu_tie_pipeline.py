@@ -112,3 +112,20 @@ def test_pipelined_loop_with_a_wide_band_reproduces_the_oracle(args):
     assert out["oracle_check"] is True and cfg["oracle_checked"]["pairs"] >= 1
     assert cfg["ties_patched_in_loop"] is True and cfg["rounding_tie_band_px"] == 2e-4
     assert cfg["ties_recomputed_on_the_host_in_loop_rank0"] == cfg["ties_listed_at_patch_time_rank0"] > 4 * cfg["descriptor_exact_pass_keypoints_per_step_rank0"] > 0
+
+
+def test_host_kind_batches_recompute_from_the_capture_slot(G):
+    """host-kind mcs_extract_batch with a FEW listed keypoints (<= 64: the extractor's own capture slot, no whole-level download): guard band widened to 1e-6 px so that
+    a dozen keypoints fall back to the exact pass, band 0.5 px so that all of those are listed — they must come back as the oracle's"""
+    imgs, masks, cams = G.frame_inputs(4, 3)
+    ex = G.mcs.Extractor(G.ctx(), 754, 480, max_batch=3, do_dBrief=1, learnMasks=1)
+    ex.set_describe(guard_eps=1e-6)
+    ex.set_tie_band(0.5)
+    out = ex.extract_host(imgs, masks, [G.mcs.make_ocam(c) for c in cams])
+    n_exact = ex.describe_stats()[0]
+    listed, fixed, _ = ex.tie_counts()
+    assert listed == fixed == n_exact and 0 < n_exact <= 64, n_exact
+    for i in range(3):
+        _, ok, od, odm, _ = G.oracle_extract(imgs[i], masks[i], cams[i], do_dBrief=1, learnMasks=1)
+        assert G.first_diff(out[i][1], od) is None and G.first_diff(out[i][2], odm) is None
+    ex.close()
