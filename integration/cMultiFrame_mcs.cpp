@@ -183,17 +183,26 @@ cMultiFrame::cMultiFrame(const std::vector<cv::Mat>& images_, const double& time
 			uint8_t* dst = r.pin + c * plane;
 			if (images[c].isContinuous()) std::memcpy(dst, images[c].data, plane);
 			else for (int y = 0; y < h; ++y) std::memcpy(dst + (size_t)y * w, images[c].ptr<uchar>(y), w);
-			if (r.maskSeen[c] != masks[c].data)
+			// the mask is compared by CONTENT with the staged copy the device holds (a pointer compare misses a mask edited in place, or a new mask allocated at a
+			// freed one's address): one pass of memcmp over 362 KB, ~15 us per camera, against the 35 us upload it saves
+			uint8_t* md = r.pin + r.offMask + c * plane;
+			bool same = r.maskSeen[c] != nullptr;
+			if (masks[c].isContinuous()) same = same && std::memcmp(md, masks[c].data, plane) == 0;
+			else for (int y = 0; y < h && same; ++y) same = std::memcmp(md + (size_t)y * w, masks[c].ptr<uchar>(y), w) == 0;
+			if (!same)
 			{
-				uint8_t* md = r.pin + r.offMask + c * plane;
 				if (masks[c].isContinuous()) std::memcpy(md, masks[c].data, plane);
 				else for (int y = 0; y < h; ++y) std::memcpy(md + (size_t)y * w, masks[c].ptr<uchar>(y), w);
-				r.maskSeen[c] = masks[c].data;
 				masksChanged = true;
 			}
 		}
 		// the mirror masks are per-camera constants: they stay on the device and travel again only when one of them changes
-		if (masksChanged) mcs_dropin::check(mcs_extractor_set_masks(r.ex, nrCams, r.pin + r.offMask, plane, w, MCS_MEM_HOST), "mcs_extractor_set_masks");
+		if (masksChanged)
+		{
+			r.maskSeen.assign(nrCams, nullptr);   // (marked "on the device" only once the upload has succeeded: check() throws)
+			mcs_dropin::check(mcs_extractor_set_masks(r.ex, nrCams, r.pin + r.offMask, plane, w, MCS_MEM_HOST), "mcs_extractor_set_masks");
+			for (int c = 0; c < nrCams; ++c) r.maskSeen[c] = masks[c].data;
+		}
 		int32_t* n = (int32_t*)(r.pin + r.offN);
 		mcs_keypoint* kps = (mcs_keypoint*)(r.pin + r.offKp);
 		uint8_t* desc = r.pin + r.offDesc; uint8_t* dmask = r.pin + r.offDmask;

@@ -16,6 +16,7 @@
 // mdBRIEFextractorOct_mcs.cpp and compares every search with the all-reference build.
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstring>
 #include <set>
 #include <stdexcept>
@@ -24,6 +25,7 @@
 #include "cORBmatcher.h"
 #include "misc.h"
 #include "mcs_c.h"
+#include "mcs_dropin.h"
 
 using namespace std;
 
@@ -532,7 +534,7 @@ namespace
 	{
 		cv::Matx33d sRcw = cConverter::Hom2R(Scw);
 		cv::Vec3d row1(sRcw(0, 0), sRcw(0, 1), sRcw(0, 2));
-		const double inv_scw = 1.0 / cv::sqrt(row1.dot(row1));
+		const double inv_scw = 1.0 / std::sqrt(row1.dot(row1));   // (the reference writes cv::sqrt: the same IEEE square root)
 		cv::Matx33d Rcw = inv_scw * sRcw;
 		cv::Vec3d tcw = inv_scw * cConverter::Hom2T(Scw);
 		camSys.Set_M_t(cConverter::invMat(cConverter::Rt2Hom(Rcw, tcw)));
@@ -836,13 +838,15 @@ int cORBmatcher::SearchByProjection(cMultiFrame& CurrentFrame, cMultiKeyFrame* p
 	// the frame's features with the row the reference compares for each of them (see above)
 	{
 		Flat kf = flatten(pKF, dim, masks);
-		std::vector<int> rowsOfCam(nr, 0);
-		for (int i = 0; i < kf.n; ++i) ++rowsOfCam[kf.cam[i]];
+		int nrKF = nr;   // the keyframe may carry camera indices the current frame does not have (undefined in the reference; bounds-safe here)
+		for (int i = 0; i < kf.n; ++i) nrKF = std::max(nrKF, kf.cam[i] + 1);
+		std::vector<int> rowsOfCam(nrKF, 0);
+		for (int i = 0; i < kf.n; ++i) if (kf.cam[i] >= 0) ++rowsOfCam[kf.cam[i]];
 		for (int i2 = 0; i2 < b.n; ++i2)
 		{
 			std::unordered_map<size_t, int>::const_iterator it = pKF->cont_idx_to_local_cam_idx.find(i2);
 			const int c = b.cam[i2];
-			if (it == pKF->cont_idx_to_local_cam_idx.end() || it->second < 0 || it->second >= rowsOfCam[c]) continue;   // undefined in the reference: the feature's own row stays
+			if (it == pKF->cont_idx_to_local_cam_idx.end() || c < 0 || c >= nrKF || it->second < 0 || it->second >= rowsOfCam[c]) continue;   // undefined in the reference: the feature's own row stays
 			std::memcpy(&b.d[(size_t)i2 * dim], pKF->GetDescriptorRowPtr(c, it->second), dim);
 			if (masks) std::memcpy(&b.m[(size_t)i2 * dim], pKF->GetDescriptorMaskRowPtr(c, it->second), dim);
 		}

@@ -999,21 +999,42 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 			if (g.nimg == nimg && memcmp(&g.key, &b, sizeof(b)) == 0) exec = g.exec;
 		if (exec) ++e->graphHits; else ++e->graphMisses;
 		if (!exec) {
+			// Capture with an error path: whatever fails between Begin and End, the capture is ENDED (a stream left capturing fails every later call on the context) and
+			// the graph destroyed; this call and all later ones of the extractor then enqueue their launches one by one (graphs given up: graphMisses forced high).
 			hipGraph_t graph = nullptr;
-			HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+			hipError_t ge = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+			if (ge == hipSuccess) {
+				launch_pyramid(b, hd, nimg, s);
+				launch_fast(b, hd, nimg, s);
+				launch_octree(b, hd, nimg, s);
+				launch_blur(b, hd, nimg, s);
+				launch_describe(b, hd, nimg, s);
+				const hipError_t le = hipGetLastError();
+				ge = hipStreamEndCapture(s, &graph);
+				if (ge == hipSuccess && le != hipSuccess) ge = le;
+				if (ge == hipSuccess) ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+				if (graph) (void)hipGraphDestroy(graph);
+			}
+			if (ge != hipSuccess) {
+				(void)hipGetLastError();
+				exec = nullptr;
+				e->graphMisses = 1000000;   // no further attempts on this extractor
+			} else {
+				if (e->graphs.size() >= 4) { (void)hipStreamSynchronize(s); (void)hipGraphExecDestroy(e->graphs.front().exec); e->graphs.erase(e->graphs.begin()); }   // a caller that rotates output buffers: a few sets
+				e->graphs.push_back(mcs_extractor::Graph{b, nimg, exec});
+			}
+		}
+		if (!exec) {   // the capture failed: the plain sequence (nothing was enqueued by the failed capture)
 			launch_pyramid(b, hd, nimg, s);
 			launch_fast(b, hd, nimg, s);
 			launch_octree(b, hd, nimg, s);
 			launch_blur(b, hd, nimg, s);
 			launch_describe(b, hd, nimg, s);
-			HIPCHK(hipStreamEndCapture(s, &graph));
-			HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-			(void)hipGraphDestroy(graph);
-			if (e->graphs.size() >= 4) { (void)hipStreamSynchronize(s); (void)hipGraphExecDestroy(e->graphs.front().exec); e->graphs.erase(e->graphs.begin()); }   // a caller that rotates output buffers: a few sets
-			e->graphs.push_back(mcs_extractor::Graph{b, nimg, exec});
-		}
+			replayed = true;   // (the descriptor stage is in: nothing left to launch below)
+		} else {
 		HIPCHK(hipGraphLaunch(exec, s));
 		replayed = true;
+		}
 	} else {
 		c->tic("pyramid"); launch_pyramid(b, hd, nimg, s); c->toc("pyramid");
 		c->tic("fast"); launch_fast(b, hd, nimg, s); c->toc("fast");

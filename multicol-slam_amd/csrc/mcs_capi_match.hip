@@ -259,6 +259,7 @@ static int search_common(mcs_ctx* c, int mode, const SetGrid& sg, const mcs_desc
 	g.toff = sg.toff; g.tmod = sg.tmod;
 	g.thLow = thLow; g.thInclusive = mode == 1 ? 1 : 0; g.ratio = nnratio; g.mode = mode;
 	g.rays1 = rays1; g.rays2 = rays2; g.E = E; g.Epitch = Epitch; g.nrCams = nrCams;
+	{ static const int ms = getenv("MCS_JACOBI_MAX_SWEEPS") ? atoi(getenv("MCS_JACOBI_MAX_SWEEPS")) : 0; g.jacMaxSweeps = ms; }
 	const size_t outN = (size_t)nsets * (mode == 1 ? t->n : q->n);
 	if (kind == MCS_MEM_DEVICE) {
 		g.outMatch = out_match; g.outCount = out_nmatches; g.outFallbacks = out_fallbacks;

@@ -225,6 +225,7 @@ struct GreedyArgs {
 	const double* rays1; const double* rays2; const double* E; int nrCams;
 	size_t Epitch;                           // doubles between the essential-matrix blocks of consecutive sets (0: one block for all sets)
 	int* outMatch; int* outCount; int* outFallbacks;
+	int jacMaxSweeps;                        // k_greedy_jacobi: sweeps + rebuilds before the in-order exact pass takes over (0: default 256; MCS_JACOBI_MAX_SWEEPS for tests)
 };
 void launch_greedy(const GreedyArgs& g, hipStream_t s);
 

@@ -758,9 +758,16 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 		__syncthreads();
 	};
 	// sweep t reads the claims of buffer t & 1 made with tag t (none for t = 0: every row free) and writes the claims of the new outcomes into the other buffer
+	// Budget (round 6): the fixpoint needs as many sweeps as the longest dependency chain — 9 to 14 on real frames — but nothing bounds a chain below nq, every
+	// stable state with undecidable queries costs an exact rescan each, and a rescan that changes an outcome restarts the sweeps: on clustered descriptors that can
+	// reach (undecidable queries) x (chain length) iterations.  Past kMaxSweeps sweeps or nq rescans the loop is given up and the set is resolved IN ORDER by exact
+	// rescans (the sequential greedy itself, about nq passes over the train rows by the whole workgroup), which cannot fail; `converged` says which way it ended.
+	const int maxSweeps = g.jacMaxSweeps > 0 ? g.jacMaxSweeps : 256;
+	bool converged = false;
+	int rescansDone = 0;
 	int nfallback = 0;
 	uint32_t t = 0;
-	for (int guard = 0; guard < 2 * g.nq + 4; ++guard) {
+	for (int guard = 0; guard < maxSweeps && rescansDone <= g.nq; ++guard) {
 		const uint32_t* own = owner + (size_t)(t & 1u) * g.nt;
 		uint32_t* nxt = owner + (size_t)((t + 1u) & 1u) * g.nt;
 		const uint32_t tag = 0xFFFFu - (t & 0xFFFFu), ntag = 0xFFFFu - ((t + 1u) & 0xFFFFu);   // (tags repeat after 65536 sweeps; a sweep count is bounded by nq + passes, far below)
@@ -787,7 +794,8 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 		++t;
 		if (again) continue;
 		// ---- stable: the queries whose lists could not decide, exactly, against the claims of the stable state (= the next buffer: every outcome re-claimed there)
-		if (nr == 0) break;
+		if (nr == 0) { converged = true; break; }
+		rescansDone += nr;
 		bool any = false;
 		auto settle = [&](int qi) {   // (uniform: every thread sees the same old and new outcome)
 			const int na = rescan(nxt, ntag, qi);
@@ -820,7 +828,7 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 			nfallback = nr;
 		}
 		__syncthreads();
-		if (!any) break;
+		if (!any) { converged = true; break; }
 		// a rescan changed an outcome: the claims of buffer `nxt` are stale for that query — rebuild them under a fresh tag by one more pass over the outcomes
 		++t;   // (skip a tag: buffer (t & 1) is `own` again, written with the tag of sweep t)
 		{
@@ -830,6 +838,21 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 			if (tid < 3) { changed[tid] = 0; nRescan[tid] = 0; }
 			__syncthreads();
 		}
+	}
+	if (!converged) {
+		// ---- the budget ran out: the sequential greedy itself.  Query after query in ascending order, each by an exact rescan of the whole train set against the
+		// claims of the queries before it (a fresh buffer and tag: nothing of the sweeps is read), its row claimed before the next one looks.
+		__syncthreads();
+		t += 2;
+		uint32_t* cur = owner + (size_t)(t & 1u) * g.nt;
+		const uint32_t ctag = 0xFFFFu - (t & 0xFFFFu);
+		for (int i = 0; i < g.nq; ++i) {
+			const bool ok = !g.qvalid || g.qvalid[QR(i)] != 0;
+			const int na = ok ? rescan(cur, ctag, i) : -1;   // (uniform over the workgroup; barriers inside)
+			if (tid == 0) { A[i] = na; if (na >= 0) cur[na] = (ctag << 16) | (uint32_t)i; }
+			__syncthreads();
+		}
+		nfallback = g.nq;
 	}
 	// ---- results
 	int nm = 0;
@@ -858,11 +881,32 @@ static void launch_spec(const GreedyArgs& g, hipStream_t s) {
 	hipLaunchKernelGGL((k_greedy_spec<K, DW, MASKED, TRI>), dim3(g.nsets), dim3(64 * (g.nsets >= kManySets ? kSpecWavesMany : kSpecWaves)), lds, s, g);
 }
 
+// how much dynamic LDS a workgroup of this device may ask for beside the kernel's ~4 KB of static arrays (queried once per device; 160 KB per CU on gfx950)
+static size_t jacobi_lds_limit() {
+	static thread_local int dev = -1;
+	static thread_local size_t limit = 0;
+	int d = 0;
+	if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	if (d != dev) {
+		int optin = 0;
+		if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, d) != hipSuccess) { (void)hipGetLastError(); optin = 64 * 1024; }
+		dev = d;
+		limit = optin > 8 * 1024 ? (size_t)optin - 8 * 1024 : 0;
+	}
+	return limit;
+}
+
 template <int K, int DW, bool MASKED>
-static void launch_jacobi(const GreedyArgs& g, hipStream_t s) {
+static bool launch_jacobi(const GreedyArgs& g, hipStream_t s) {   // false: this device cannot give the workgroup its LDS — the caller takes k_greedy_spec
 	const size_t lds = jacobi_lds_words(g.nq, g.nt, K) * 4;
-	if (lds > 60 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy_jacobi<K, DW, MASKED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	if (lds > jacobi_lds_limit()) return false;
+	// (the attribute belongs to the function ON THE CURRENT DEVICE, and one process may drive several devices from several threads: set before every launch that needs it)
+	if (lds > 60 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy_jacobi<K, DW, MASKED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+		(void)hipGetLastError();
+		return false;
+	}
 	hipLaunchKernelGGL((k_greedy_jacobi<K, DW, MASKED>), dim3(g.nsets), dim3(kJacThreads), lds, s, g);
+	return true;
 }
 
 template <int K, int DW>
@@ -872,8 +916,7 @@ static void launch_spec_kd(const GreedyArgs& g, hipStream_t s) {
 	// pairs that takes it (0: never, for A/B and tests)
 	static const int jacSets = getenv("MCS_GREEDY_JACOBI") ? atoi(getenv("MCS_GREEDY_JACOBI")) : 8;
 	if (g.mode != 2 && g.nsets <= jacSets && g.nq < 65536 && jacobi_lds_words(g.nq, g.nt, K) * 4 <= 150 * 1024) {
-		if (masked) launch_jacobi<K, DW, true>(g, s); else launch_jacobi<K, DW, false>(g, s);
-		return;
+		if (masked ? launch_jacobi<K, DW, true>(g, s) : launch_jacobi<K, DW, false>(g, s)) return;
 	}
 	if (g.mode == 2) { if (masked) launch_spec<K, DW, true, true>(g, s); else launch_spec<K, DW, false, true>(g, s); }
 	else if (masked) launch_spec<K, DW, true, false>(g, s);

@@ -65,11 +65,23 @@ def test_chains_of_dependent_queries(G, K, nq, nt, ncl, flips):
     assert int(nm[0]) == en and np.array_equal(out, eo), (K, int(nm[0]), en)
     if K == 1:
         assert int(fb[0]) > 0, "K = 1 on clustered data must force exact rescans"
+    if os.environ.get("MCS_EXPECT_JACOBI_FALLBACK"):   # (set by test_fixpoint_budget_exhausted_...: the in-order pass reports every query)
+        assert int(fb[0]) == nq, (int(fb[0]), nq)
 
 
 def test_both_forms_of_the_greedy_pass_agree_on_the_chains():
     """the same searches in a fresh process with MCS_GREEDY_JACOBI=0 (the chunked form for one pair too)"""
     e = dict(os.environ, MCS_GREEDY_JACOBI="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_greedy_chains.py"), "-m", "gpu", "-q", "-x", "-k", "chains_of_dependent"],
+                       env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+
+
+def test_fixpoint_budget_exhausted_falls_back_to_the_in_order_pass(sweeps="1"):
+    """MCS_JACOBI_MAX_SWEEPS = 1: the fixpoint loop is given up before it can converge (the first sweep always changes outcomes), and the set is resolved in order by exact rescans
+    (k_greedy_jacobi's tail) — same outcomes as the sequential loop, the fallback counter says every query went that way (a loop that ends on its guard
+    must not hand out whatever it holds)"""
+    e = dict(os.environ, MCS_JACOBI_MAX_SWEEPS=sweeps, MCS_EXPECT_JACOBI_FALLBACK="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_greedy_chains.py"), "-m", "gpu", "-q", "-x", "-k", "chains_of_dependent"],
                        env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
