@@ -642,7 +642,7 @@ def roofline_block(sp, job, kern, feats_local, pairs_local):
            "per_kernel_ms": {k: round(v, 4) for k, v in kern.items()},
            "per_kernel_alg_GBps": {names[k]: round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) for k in alg if k in kern and kern[k] > 0},
            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the builder's GPU box, committed; fetch = 2 x FETCH_SIZE: "
-                             "every read request of this chip's L2 is 128 bytes and is tallied as 64, profiles/r05/pmc_calibration.txt; Infinity-Cache hits are counted)" if traffic else None,
+                             "every read request of this chip's L2 is 128 bytes and is tallied as 64, profiles/r06/pmc_calibration.txt; Infinity-Cache hits are counted)" if traffic else None,
            "traffic_measured_in_this_run": False,
            "traffic_over_algorithmic": round(traffic / alg[dom], 3) if traffic and alg[dom] else None,
            "note": "`bound` / `peak` price the kernel against HBM because BASELINE.json asks for that fraction; no kernel of this path is HBM-bound — `governing_bound` names what "

@@ -174,6 +174,10 @@ int mcs_extractor_patch_ties(mcs_extractor*, int back, int* listed, int* recompu
 int mcs_describe_fast_bound(const mcs_ocam* cam, int desc_size, double* bound);
 int mcs_selftest_describe_fast(mcs_ctx*, const mcs_ocam* cam, uint64_t seed, int n, double* max_abs_diff);
 int mcs_describe_fast_table(const mcs_ocam* cam, double* table, int* rows, int* row_len, int* e0, int* bins_per_octave, double* info6);
+/* (host only) the same table as the DEVICE reads it (round 6): `rows` rows of row_bytes = 48 bytes — g0 .. g3 as doubles, g4 g5 g6 as floats (+ 4 bytes of padding): three
+ * 16-byte LDS reads per row instead of seven 8-byte ones; the tail g4 + g5 tau + g6 tau^2 is evaluated in float.  f32_term = what that adds to the coordinates at
+ * most, in pixels (a term of mcs_describe_fast_bound).  Any output may be NULL. */
+int mcs_describe_fast_table_packed(const mcs_ocam* cam, void* packed, int* row_bytes, double* f32_term);
 
 /* mcs_extract_batch (device memory) with the descriptor / mask rows laid out for an exchange: row k of image i is written at
  * desc + (i * out_image_pitch_rows + k) * out_row_stride (descmask alike); 0 = the defaults (capacity rows, descSize bytes).  The camera-sharded rig

@@ -70,7 +70,7 @@ EXPORTS = [
     "mcs_match_topk_batched", "mcs_descriptor_distance", "mcs_descriptor_distance_masked", "mcs_ctx_enable_timing",
     "mcs_ctx_kernel_ms", "mcs_ctx_join", "mcs_ctx_set_async_search", "mcs_ctx_search_fence", "mcs_search_kf_kf", "mcs_search_kf_f", "mcs_search_triangulation", "mcs_search_kf_f_sweep",
     "mcs_search_triangulation_sweep", "mcs_search_kf_kf_ring", "mcs_rows_valid", "mcs_extractor_set_describe", "mcs_extractor_describe_stats", "mcs_extractor_tie_stats", "mcs_extractor_set_tie_band", "mcs_extractor_fix_ties", "mcs_extractor_tie_counts", "mcs_extractor_set_tie_capture", "mcs_extractor_patch_ties", "mcs_describe_fast_bound",
-    "mcs_selftest_describe_fast", "mcs_describe_fast_table", "mcs_extract_batch_strided", "mcs_rig_pack_headers", "mcs_rig_rows_valid",
+    "mcs_selftest_describe_fast", "mcs_describe_fast_table", "mcs_describe_fast_table_packed", "mcs_extract_batch_strided", "mcs_rig_pack_headers", "mcs_rig_rows_valid",
     "mcs_search_by_projection", "mcs_window_match", "mcs_window_best", "mcs_rotation_consistency", "mcs_world_to_cam", "mcs_distinctive_descriptors", "mcs_selftest_shared_reciprocal", "mcs_vocabulary_create", "mcs_vocabulary_destroy", "mcs_bow_transform", "mcs_copy_narrow", "mcs_ctx_result_stream", "mcs_ctx_stream_conflicts", "mcs_ctx_transfer_stream", "mcs_host_alloc", "mcs_host_free",
 ]
 
@@ -134,6 +134,7 @@ def lib():
     L.mcs_describe_fast_bound.argtypes = [C.POINTER(Ocam), C.c_int, C.POINTER(C.c_double)]
     L.mcs_selftest_describe_fast.argtypes = [vp, C.POINTER(Ocam), C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.mcs_describe_fast_table.argtypes = [C.POINTER(Ocam), vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
+    L.mcs_describe_fast_table_packed.argtypes = [C.POINTER(Ocam), vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.mcs_extract_batch.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
     L.mcs_extract_batch_strided.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_int]
     L.mcs_rig_pack_headers.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int]

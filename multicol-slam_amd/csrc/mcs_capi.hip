@@ -57,7 +57,20 @@ struct GTabInfo {
 	double inB = 0;            // max (|G| + 2 |s G'(s)|) * (sqrt(s) + 44): what one relative rounding of the rotated pattern point moves (x G, y G) by — a point
 	                           // at distance n from the axis belongs to a keypoint within n + 22 of it, and the rotated offset is within 22: |terms| <= n + 44
 	double seen = 0;           // largest |row polynomial - G| (times sqrt(s)) at the sample points checked against direct long double evaluation
+	double f32U = INFINITY;    // max sqrt(s) * (what the FLOAT tail of the packed device rows adds: g4, g5, g6 and tau rounded to float, two float FMAs)  [pixels]
 };
+
+// The packed device form of a table (mcs_common.h kGDev*): per row [g0 g1 g2 g3] as doubles, [g4 g5 g6 0] as floats (round to nearest).
+static void pack_g_table(const double* tab, uint8_t* out) {
+	if (!MCS_G_PACKED) { memcpy(out, tab, (size_t)kGTabDoubles * sizeof(double)); return; }   // (the device reads the host's rows as they are)
+	for (int r = 0; r < kGRows; ++r) {
+		double* d = reinterpret_cast<double*>(out + (size_t)r * kGDevRowBytes);
+		const double* g = tab + (size_t)r * kGRow;
+		d[0] = g[0]; d[1] = g[1]; d[2] = g[2]; d[3] = g[3];
+		float* f = reinterpret_cast<float*>(d + 4);
+		f[0] = (float)g[4]; f[1] = (float)g[5]; f[2] = (float)g[6]; f[3] = 0.f;
+	}
+}
 
 static GTabInfo build_g_table(const mcs_ocam& m, double* tab) {
 	typedef long double LD;
@@ -83,7 +96,7 @@ static GTabInfo build_g_table(const mcs_ocam& m, double* tab) {
 		for (int i = n - 1; i >= 0; --i) r = r * th + (LD)m.invP[i];
 		return r / nn;
 	};
-	double tailU = 0, rhoB = 0, dB = 0, lip = 0, inB = 0, seen = 0;
+	double tailU = 0, rhoB = 0, dB = 0, lip = 0, inB = 0, seen = 0, f32U = 0;
 	for (int e = kGE0; e < kGE1; ++e)
 		for (int k = 0; k < (1 << kGM); ++k) {
 			const LD kappa = 1.0L + ((LD)k + 0.5L) / (LD)(1 << kGM), c = ldexpl(kappa, e), sqc = sqrtl(c), zc = p0 / sqc, thc = atanl(zc);
@@ -164,6 +177,20 @@ static GTabInfo build_g_table(const mcs_ocam& m, double* tab) {
 			dB = std::max(dB, sq * gder);
 			lip = std::max(lip, gabs + 2.0 * gder);
 			inB = std::max(inB, (gabs + 2.0 * gder) * (sq + 44.0));
+			// The float tail of the packed rows: T = g4 + g5 tau + g6 tau^2 with g_j and tau rounded to float and two float FMAs — the g6 term meets five
+			// relative perturbations of 2^-24 (its coefficient, tau twice, both FMAs), g5 four, g4 two: |T_float - T| <= 6 * 2^-24 * sum |g_j| |tau|^(j-4) (the 6
+			// and the 1.01 cover the second-order terms); T enters G as T tau^4, the coordinates as sqrt(s) G.  |tau| <= 2^-(kGM+1) in the kernel's variable.
+			// Coefficients that do not fit a float make the table unusable; below the smallest normal float they are worth less than 1e-37 anyway (added).
+			{
+				const double tm = std::ldexp(1.0, -(kGM + 1));
+				double t4 = 0, tp = tm * tm * tm * tm;
+				for (int j = 4; j <= D; ++j) {
+					if (!(std::fabs(row[j]) < 3.0e38) || !std::isfinite((double)(float)row[j])) return info;
+					t4 += std::fabs(row[j]) * tp;
+					tp *= tm;
+				}
+				f32U = std::max(f32U, sq * (6.0 * 1.01 * std::ldexp(1.0, -24) * t4 + 1e-37));
+			}
 			// sanity: the row against G itself at both ends of the bin and in the middle
 			for (int t = -2; t <= 2; ++t) {
 				const LD tau = (LD)t * ldexpl(1.0L, -(kGM + 2)) * (1.0L - 1e-9L), sv = ldexpl(kappa + tau, e);
@@ -172,6 +199,7 @@ static GTabInfo build_g_table(const mcs_ocam& m, double* tab) {
 				seen = std::max(seen, (double)(fabsl(pv - direct(sv)) * sqrtl(sv)));
 			}
 		}
+	info.f32U = f32U * 1.01;
 	info.tailU = tailU; info.rhoB = rhoB * 1.01; info.dB = dB * 1.01; info.lip = lip * 1.01; info.inB = inB * 1.01; info.seen = seen;
 	if (!(seen <= tailU + 64 * 1.1102230246251565e-16 * rhoB)) info.tailU = INFINITY;   // the rows must reproduce G within the bound they claim (plus their own rounding to double)
 	return info;
@@ -184,7 +212,8 @@ static GTabInfo build_g_table(const mcs_ocam& m, double* tab) {
 //           n from the axis (the keypoint lies within n + 22 of it, the rotated offset within 22).  F moves by at most aff * (|G| + 2 |s G'|) per unit of
 //           either input; the product with n + 44 is maximised over the table's rows (inB): near the axis G ~ rho(axis) / n is large where n + 44 is small.
 //   fast    s: 2 roundings (2.01 u relative, G moves by |s G'(s)| per relative unit: dB);  the row: truncated tail (tailU) + coefficients rounded to double +
-//           6 FMAs (13 u of sum |g_j| |eps|^j: rhoB);  x G, y G: u each;  the affine map without the principal point (it cancels against the mean): 2 more
+//           6 FMAs (13 u of sum |g_j| |eps|^j: rhoB; the packed rows run 4 of them in double) + the float tail g4 .. g6 of the packed rows (f32U);  x G, y G: u
+//           each;  the affine map without the principal point (it cancels against the mean): 2 more
 //   ref     atan's argument and atan itself (12 u S' generously: ocml / glibc stay within 2 ulp) + 24 roundings of the Horner chain, 2 divisions, 2 products
 //           (96 u S) + the affine map with the principal point (8 u (|u0| + |v0|));   S = sum |invP_i| (pi/2)^i,  S' = sum i |invP_i| (pi/2)^(i-1)
 //   mean    the same per-point bound, plus the order of the sum: reference npoints - 1 sequential additions and a division, fast 2 NB - 1 per lane, 6 shuffle
@@ -201,11 +230,11 @@ static double describe_fast_bound(const mcs_ocam& m, int npoints, const GTabInfo
 		if (i + 1 < m.invP_deg) Sp += (i + 1) * std::fabs(m.invP[i + 1]) * pw;
 		pw *= hp;
 	}
-	if (!(std::fabs(m.p[0]) > 1e-300) || !std::isfinite(m.p[0]) || !std::isfinite(g.tailU) || !std::isfinite(g.rhoB) || !std::isfinite(g.dB) || !std::isfinite(g.lip) || !std::isfinite(g.inB)) return INFINITY;
+	if (!(std::fabs(m.p[0]) > 1e-300) || !std::isfinite(m.p[0]) || !std::isfinite(g.tailU) || !std::isfinite(g.rhoB) || !std::isfinite(g.dB) || !std::isfinite(g.lip) || !std::isfinite(g.inB) || !std::isfinite(g.f32U)) return INFINITY;
 	const double aff = 1.0 + std::fabs(m.c) + std::fabs(m.d) + std::fabs(m.e), pp = 8 * u * (std::fabs(m.u0) + std::fabs(m.v0));
 	const int nb = npoints / 128;
 	const double inputs = aff * g.inB * (2 * (2 + 3) * u * 1.01);
-	const double fast = aff * (g.tailU + 16 * u * g.rhoB + 2.01 * u * g.dB);
+	const double fast = aff * (g.tailU + 16 * u * g.rhoB + 2.01 * u * g.dB + (MCS_G_PACKED ? g.f32U : 0.0));
 	const double ref = aff * (12 * u * Sp + 96 * u * S) + pp;
 	const double point = inputs + fast + ref;
 	const double total = 2 * point + (npoints + 2 * nb + 7) * u * 20480.0 + 2 * u * 8192.0 + 2.3283064365386963e-10 * 1.001;
@@ -620,7 +649,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 	ALLOC(e->d_fbStats, 2 * sizeof(unsigned long long));   // [0] exact-pass keypoints, [1] tie-listed keypoints
 	ALLOC(e->d_tieMin, sizeof(unsigned long long));
 	ALLOC(e->d_aux, B * slotsPerImage * describe_aux_bytes());
-	ALLOC(e->d_gTab, B * (size_t)kGTabDoubles * sizeof(double));
+	ALLOC(e->d_gTab, B * (size_t)kGDevDoubles * sizeof(double));
 	ALLOC(e->d_nkp, B * sizeof(int));
 	ALLOC(e->d_kps, B * hd.kpCap * sizeof(mcs_keypoint));
 	ALLOC(e->d_odesc, B * hd.kpCap * (size_t)hd.descSize);
@@ -930,8 +959,8 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		if (e->h_cams.size() != hc.size() || memcmp(e->h_cams.data(), hc.data(), sizeof(OcamDev) * hc.size()) != 0) {
 			HIPCHK(hipStreamSynchronize(s));   // the previous batch may still read d_cams / d_gTab
 			HIPCHK(hipMemcpy(e->d_cams, hc.data(), sizeof(OcamDev) * hc.size(), hipMemcpyHostToDevice));
-			std::vector<double> tabs(uniq.size() * (size_t)kGTabDoubles);
-			for (size_t i = 0; i < uniq.size(); ++i) memcpy(&tabs[i * kGTabDoubles], e->camCache[uniq[i]].tab.data(), kGTabDoubles * sizeof(double));
+			std::vector<double> tabs(uniq.size() * (size_t)kGDevDoubles);   // the packed device rows
+			for (size_t i = 0; i < uniq.size(); ++i) pack_g_table(e->camCache[uniq[i]].tab.data(), reinterpret_cast<uint8_t*>(&tabs[i * kGDevDoubles]));
 			HIPCHK(hipMemcpy(e->d_gTab, tabs.data(), tabs.size() * sizeof(double), hipMemcpyHostToDevice));
 			e->h_cams = hc;
 		}
@@ -1276,6 +1305,16 @@ int mcs_describe_fast_table(const mcs_ocam* cam, double* table, int* rows, int* 
 	return MCS_OK;
 }
 
+int mcs_describe_fast_table_packed(const mcs_ocam* cam, void* packed, int* row_bytes, double* f32_term) {
+	if (!cam || cam->invP_deg < 1 || cam->invP_deg > MCS_MAX_POLY || cam->p_deg < 1) return fail(MCS_ERR_INVALID, "bad argument");
+	std::vector<double> tab(kGTabDoubles, 0.0);
+	const GTabInfo g = build_g_table(*cam, tab.data());
+	if (packed) pack_g_table(tab.data(), reinterpret_cast<uint8_t*>(packed));
+	if (row_bytes) *row_bytes = kGDevRowBytes;
+	if (f32_term) *f32_term = MCS_G_PACKED ? g.f32U : 0.0;   // (0: this build's device rows are the doubles themselves)
+	return MCS_OK;
+}
+
 int mcs_selftest_describe_fast(mcs_ctx* c, const mcs_ocam* cam, uint64_t seed, int n, double* max_abs_diff) {
 	if (!c || !cam || !max_abs_diff || n < 1) return fail(MCS_ERR_INVALID, "bad argument");
 	if (cam->p_deg < 1 || cam->p_deg > MCS_MAX_POLY || cam->invP_deg < 1 || cam->invP_deg > MCS_MAX_POLY) return fail(MCS_ERR_INVALID, "bad polynomial degree");
@@ -1291,11 +1330,13 @@ int mcs_selftest_describe_fast(mcs_ctx* c, const mcs_ocam* cam, uint64_t seed, i
 	uint8_t* buf = nullptr;
 	HIPCHK(hipStreamSynchronize(c->stream));
 	const size_t tabOff = (64 + sizeof(OcamDev) + 63) / 64 * 64;
-	HIPCHK(ctx_arena(c, tabOff + kGTabDoubles * sizeof(double), &buf));
+	std::vector<double> packed(kGDevDoubles);
+	pack_g_table(tab.data(), reinterpret_cast<uint8_t*>(packed.data()));
+	HIPCHK(ctx_arena(c, tabOff + kGDevDoubles * sizeof(double), &buf));
 	unsigned long long zero = 0, got = 0;
 	HIPCHK(hipMemcpy(buf, &zero, sizeof(zero), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(buf + 64, &o, sizeof(o), hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(buf + tabOff, tab.data(), kGTabDoubles * sizeof(double), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(buf + tabOff, packed.data(), kGDevDoubles * sizeof(double), hipMemcpyHostToDevice));
 	launch_selftest_fast_model((const OcamDev*)(buf + 64), (const double*)(buf + tabOff), seed, n, cam->width, cam->height, (unsigned long long*)buf, c->stream);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(c->stream));

@@ -87,6 +87,13 @@ struct OcamDev {
 #define MCS_G_E1 24
 #endif
 constexpr int kGM = MCS_G_M, kGDeg = MCS_G_DEG, kGE0 = MCS_G_E0, kGE1 = MCS_G_E1, kGRows = (kGE1 - kGE0) << kGM, kGRow = kGDeg + 1, kGTabDoubles = kGRows * kGRow;
+// ... as the HOST builds it (kGRow doubles per row).  The DEVICE reads a packed form (round 6): 48-byte rows in three 16-byte slots, [g0 g1] [g2 g3] doubles and
+// [g4 g5 g6 0] floats — three ds_read_b128 per row from LDS instead of seven 8-byte loads; the float tail's roundings are bounded by GTabInfo.f32U (mcs_capi.hip).
+#ifndef MCS_G_PACKED
+#define MCS_G_PACKED 0   // 1: the packed rows.  Measured (round 6, profiles/NOTES.md): 27 % fewer LDS-array cycles per keypoint and the kernel 6 % SLOWER (0.521 against
+#endif                   // 0.496 ms): the 16-byte loads want aligned register quads, the one-block keypoint spills 28 registers instead of 1.  0: rows of kGRow doubles.
+static_assert(!MCS_G_PACKED || kGDeg == 6, "the packed device rows hold degree 6");
+constexpr int kGDevRowBytes = MCS_G_PACKED ? 48 : kGRow * 8, kGDevDoubles = kGRows * kGDevRowBytes / 8;
 // The table starts at s = 2^kGE0, i.e. 1/32 pixel from the optical axis: G has a sqrt-type branch point at s = 0 (rho(theta) of a fitted backward polynomial
 // does not vanish exactly on the axis), so only log-spaced bins reach down there.  One keypoint in 200 has the axis inside its pattern's footprint, and of
 // those one in 300 a point within 1/32 px of it: that keypoint takes the exact pass.  (Starting the table at s = 16 sent 1 % of all keypoints there, at
@@ -131,7 +138,7 @@ struct ExtractBuffers {
 	const OcamDev* cams;          // [B] or nullptr
 	int* status;                  // device error word (capacity overflows)
 	// dBRIEF / mdBRIEF: fast pass + exact pass over the fast pass's fallback list (mcs_describe.hip)
-	const double* gTab;                  // [distinct cameras of the batch][kGTabDoubles], indexed by OcamDev.tabIdx
+	const double* gTab;                  // [distinct cameras of the batch][kGDevDoubles] packed rows, indexed by OcamDev.tabIdx
 	void* aux;                           // KpAuxSoA over [B][roundup(kpCap, kSlotAlign)] slots: orientation / undistorted keypoint / pattern angles for the fast pass
 	int* fbCount; uint32_t* fbList;      // keypoint slots (image * wavesPerImage + slot) the fast pass handed to the exact pass, this batch
 	int* preCount; uint32_t* preList;    // ... and the ones k_orient_b sent there before the fast pass ran (camera not served, keypoint next to the optical axis)

@@ -32,6 +32,7 @@
 // Integer pixel offsets that pass the guard are PROVABLY the reference's, so the descriptors stay bit-identical; mcs_extractor_set_describe() can force
 // the exact pass for everything or widen the band (tests/test_gpu_describe_guard.py runs both against the oracle).
 #include "mcs_common.h"
+#include <type_traits>
 #include "mcs_orient.h"
 
 #include <algorithm>
@@ -800,6 +801,23 @@ __device__ __forceinline__ void fast_w2i(const FastCam& C, Tab tab, double xr, d
 	if (MCS_FAST_ABLATE & 16) row = 0;   // A/B: every lane reads the same row (LDS broadcast: no bank conflicts, no gather)
 	const double frac = __hiloint2double((int)((hi & ((1u << (20 - kGM)) - 1u)) | 0x3FF00000u), (int)lo);   // 1 + the mantissa bits below the bin index
 	const double tau = frac - (1.0 + 1.0 / (double)(2 << kGM));                           // exact
+#if MCS_G_PACKED
+	// The row (mcs_common.h kGDev*): 48 bytes in three 16-byte slots — [g0 g1] [g2 g3] as doubles, [g4 g5 g6 0] as floats.  From LDS that is three ds_read_b128
+	// (12 array cycles per wave; the 56-byte rows of doubles went as three ds_read2_b64 + one ds_read_b64: 26, and collided in rows r, r + 16), and rows 16 bytes
+	// aligned at a stride of three slots collide only for r = r' mod 16 within a 16-lane group.  The tail g4 + g5 tau + g6 tau^2 is evaluated in float (its share
+	// of G is below tau^4 = 2^-24 |G|: GTabInfo.f32U bounds what the float roundings add), converted once and carried on in double.
+	typedef double f64x2 __attribute__((ext_vector_type(2)));
+	typedef float f32x4 __attribute__((ext_vector_type(4)));
+	const auto rowp = reinterpret_cast<const uint8_t*>(tab) + row * (unsigned)kGDevRowBytes;
+	const f64x2 g01 = *reinterpret_cast<const f64x2*>(rowp), g23 = *reinterpret_cast<const f64x2*>(rowp + 16);
+	const f32x4 g46 = *reinterpret_cast<const f32x4*>(rowp + 32);
+	const float tf = (float)tau;
+	const float tl = __builtin_fmaf(__builtin_fmaf(g46.z, tf, g46.y), tf, g46.x);
+	double G = __builtin_fma((double)tl, tau, g23.y);
+	G = __builtin_fma(G, tau, g23.x);
+	G = __builtin_fma(G, tau, g01.y);
+	G = __builtin_fma(G, tau, g01.x);
+#else
 	const auto g = tab + row * kGRow;
 	double gc[kGRow];
 #pragma unroll
@@ -807,6 +825,7 @@ __device__ __forceinline__ void fast_w2i(const FastCam& C, Tab tab, double xr, d
 	double G = gc[kGDeg];
 #pragma unroll
 	for (int i = kGDeg - 1; i >= 0; --i) G = __builtin_fma(G, tau, gc[i]);
+#endif
 	const double uu = xr * G, vv = yr * G;
 	u = __builtin_fma(uu, C.c, vv * C.d);
 	v = __builtin_fma(uu, C.e, vv);
@@ -1146,171 +1165,6 @@ __device__ __forceinline__ bool fast_keypoint_u(const ExtractBuffers& b, const F
 	return !__any(bad);
 }
 
-#ifndef MCS_FAST_PIPE
-#define MCS_FAST_PIPE 0   // 1: mdBRIEF keypoints with R <= 6 rounds run the hand-pipelined form below (measured: 492 against 470 us); 0: fast_keypoint_u for everything
-#endif
-// The same keypoint, software-pipelined by hand (mdBRIEF, R <= 6: descriptor sizes 16 and 32).  What bounds the fast pass is neither VALU issue (~0.65 busy) nor
-// the LDS pipe (~0.6): it is the dependent chains of one wave — table-row gather -> Horner, and per pattern wave sum -> rounding -> patch byte -> vals -> gather
-// -> ballot — which the three other waves of the SIMD, all in the same phase, do not cover; the compiler's schedule runs them strictly one after the other.
-// Here the work is cut into chunks that are laid out in the wanted order and separated by scheduling barriers:
-//     chunk (pat, t):   A(pat, t + 1)   rotation, s, row index, tau and the REQUEST of the table row of the next point (row registers double-buffered)
-//                       B(pat, t)       Horner + affine + sums of this point, whose row was requested a chunk ago
-//                       stage k of the TAIL of pattern pat - 1  (k = 0..5: wave sum 1 / wave sum 2 + mean / rounding + patch bytes (two halves) / vals + gather / ballots)
-// so every chain of pattern pat - 1 is issued under the arithmetic of pattern pat (u, v double-buffered); only the last pattern's tail runs bare.
-template <int MODE, int NB, class Ahead>
-__device__ __forceinline__ bool fast_keypoint_p(const ExtractBuffers& b, const FastCam& C, const double* tabLds, const uint8_t* patch,
-                                                double ukx, double uky, const double (&axc)[3], const double (&ays)[3], const UTabs& T,
-                                                unsigned long long (&bitsMain)[NB], unsigned long long (&agree)[NB], Ahead&& ahead) {
-	constexpr int NP = 128 * NB, R = UPat<NB>::R, RW = UPat<NB>::RW, npat = 3;
-	static_assert(MODE == 2 && R <= 6, "the pipelined form is for mdBRIEF with at most six rounds");
-	const double kFix = 1572864.5;
-	const unsigned kHiPatch = 0x4137F000u + 4096u - (unsigned)kPatchR;
-	const unsigned guardUnits = (unsigned)__builtin_ceil(b.guardEps * 4294967296.0);
-	const double gAdd = (double)guardUnits * (1.0 / 4294967296.0);
-#pragma unroll
-	for (int j = 0; j < NB; ++j) { bitsMain[j] = 0ull; agree[j] = ~0ull; }
-	typedef double f64x2 __attribute__((ext_vector_type(2)));
-	typedef const __attribute__((address_space(3))) f64x2 lds_f64x2;
-	typedef const __attribute__((address_space(3))) double lds_f64;
-	typedef const __attribute__((address_space(3))) uint32_t lds_u32;
-	typedef __attribute__((address_space(3))) uint8_t lds_u8;
-	typedef const __attribute__((address_space(3))) uint8_t lds_cu8;
-	unsigned pdo = (unsigned)(uintptr_t)(lds_f64x2*)T.upat, pwo = (unsigned)(uintptr_t)(lds_f64*)T.uw, pgo = (unsigned)(uintptr_t)(lds_u32*)T.gidx;
-	unsigned pvo = (unsigned)(uintptr_t)(lds_u8*)T.vals, plo = (unsigned)(uintptr_t)(lds_cu8*)patch, tbo = (unsigned)(uintptr_t)(lds_f64*)tabLds;
-	int lane = threadIdx.x & 63;
-	asm volatile("" : "+v"(pdo), "+v"(pwo), "+v"(pgo), "+s"(pvo), "+s"(plo), "+s"(tbo), "+v"(lane));
-	lds_f64x2* const pd = (lds_f64x2*)(uintptr_t)pdo;
-	lds_f64* const pw = (lds_f64*)(uintptr_t)pwo;
-	lds_u32* const pg = (lds_u32*)(uintptr_t)pgo;
-	lds_u8* const pv = (lds_u8*)(uintptr_t)pvo;
-	lds_cu8* const pvr = (lds_cu8*)(uintptr_t)pvo;
-	lds_cu8* const pl = (lds_cu8*)(uintptr_t)plo;
-	lds_f64* const tab = (lds_f64*)(uintptr_t)tbo;
-	unsigned top = 0, minlo = 0xFFFFFFFFu, maxrc = 0;
-	bool bad = false;
-	// double-buffered state: the point being evaluated (slot t & 1), the pattern's coordinates (pat & 1)
-	double xr_[2], yr_[2], tau_[2], gc_[2][kGRow], w_[2];
-	double u_[2][R], v_[2][R], sumx = 0.0, sumy = 0.0;
-	// the tail's state
-	double z_ = 0.0, cmx = 0.0, cmy = 0.0;
-	int val[R];
-	int t0_[NB], t1_[NB];
-	auto A = [&](int pat, int t) {   // the request half of fast_w2i
-		const int sl = t & 1;
-		const f64x2 p = pd[64 * t];
-		if (pat == 0 && t == 0) ahead();
-		const double ax = axc[pat], ay = ays[pat];
-		const double xr = __builtin_fma(p.x, ax, __builtin_fma(-p.y, ay, ukx));
-		const double yr = __builtin_fma(p.x, ay, __builtin_fma(p.y, ax, uky));
-		const double s = __builtin_fma(xr, xr, yr * yr);
-		const unsigned hi = (unsigned)__double2hiint(s), lo = (unsigned)__double2loint(s);
-		const unsigned idx = (hi >> (20 - kGM)) - (unsigned)((1023 + kGE0) << kGM);
-		top = max(top, idx);
-		const unsigned row = idx < (unsigned)kGRows ? idx : (unsigned)(kGRows - 1);
-		const double frac = __hiloint2double((int)((hi & ((1u << (20 - kGM)) - 1u)) | 0x3FF00000u), (int)lo);
-		xr_[sl] = xr; yr_[sl] = yr; tau_[sl] = frac - (1.0 + 1.0 / (double)(2 << kGM));
-		lds_f64* const g = tab + row * kGRow;
-#pragma unroll
-		for (int i = 0; i < kGRow; ++i) gc_[sl][i] = g[i];
-		if (t < RW) w_[sl] = pw[64 * t];
-	};
-	auto B = [&](int pat, int t) {   // the arithmetic half
-		const int sl = t & 1, pb = pat & 1;
-		double G = gc_[sl][kGDeg];
-#pragma unroll
-		for (int i = kGDeg - 1; i >= 0; --i) G = __builtin_fma(G, tau_[sl], gc_[sl][i]);
-		const double uu = xr_[sl] * G, vv = yr_[sl] * G;
-		const double u = __builtin_fma(uu, C.c, vv * C.d), v = __builtin_fma(uu, C.e, vv);
-		u_[pb][t] = u; v_[pb][t] = v;
-		if (t < RW) { sumx = __builtin_fma(w_[sl], u, sumx); sumy = __builtin_fma(w_[sl], v, sumy); }
-		else { sumx += u; sumy += v; }
-	};
-	auto round_pt = [&](int q, int t) {
-		const double yx = u_[q & 1][t] + cmx, yy = v_[q & 1][t] + cmy;
-		const unsigned pc = (unsigned)__double2hiint(yx) - kHiPatch, pr = (unsigned)__double2hiint(yy) - kHiPatch;
-		minlo = min(minlo, min((unsigned)__double2loint(yx), (unsigned)__double2loint(yy)));
-		maxrc = max(maxrc, max(pr, pc));
-		const unsigned off = min(pr * (unsigned)kFPitch + pc, (unsigned)(kFPatchBytes - 1));
-		val[t] = (int)pl[off];
-	};
-	double sx_ = 0.0, sy_ = 0.0;   // the finished pattern's lane sums, handed to its tail
-	auto tail = [&](int q, int k) {   // stage k of pattern q's tail
-		if (k == 0) {   // wave sum, first half (wave_sum2_f64): halves, then row pairs
-			const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(sx_), __double2loint(sy_), false, false);
-			const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(sx_), __double2hiint(sy_), false, false);
-			double z = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
-			const auto l2 = __builtin_amdgcn_permlane16_swap(__double2loint(z), __double2loint(z), false, false);
-			const auto h2 = __builtin_amdgcn_permlane16_swap(__double2hiint(z), __double2hiint(z), false, false);
-			z_ = __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
-		} else if (k == 1) {   // second half: the 16 lanes of a row, the totals as scalars, the mean folded into the rounding addends
-			double z = z_;
-			z += dpp_f64<0x128>(z); z += dpp_f64<0x124>(z); z += dpp_f64<0x122>(z); z += dpp_f64<0x121>(z);
-			const double totx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(z), 0), __builtin_amdgcn_readlane(__double2loint(z), 0));
-			const double toty = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(z), 32), __builtin_amdgcn_readlane(__double2loint(z), 32));
-			const double meanX = totx * (1.0 / (double)NP), meanY = toty * (1.0 / (double)NP);
-			bad |= !(fabs(meanX) < 16384.0) || !(fabs(meanY) < 16384.0);
-			cmx = (kFix - meanX) + gAdd; cmy = (kFix - meanY) + gAdd;
-		} else if (k == 2) {
-#pragma unroll
-			for (int t = 0; t < (R + 1) / 2; ++t) round_pt(q, t);
-		} else if (k == 3) {
-#pragma unroll
-			for (int t = (R + 1) / 2; t < R; ++t) round_pt(q, t);
-		} else if (k == 4) {
-	#pragma unroll
-		for (int t = 0; t < R; ++t) pv[64 * t + lane] = (uint8_t)val[t];
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-			for (int j = 0; j < NB; ++j) { const uint32_t g = pg[j]; t0_[j] = pvr[g & 0xFFFFu]; t1_[j] = pvr[g >> 16]; }
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		} else {
-#pragma unroll
-			for (int j = 0; j < NB; ++j) {
-				const unsigned long long bits = __ballot(t0_[j] < t1_[j]);
-				if (q == 0) bitsMain[j] = bits;
-				else agree[j] &= ~(bits ^ bitsMain[j]);
-			}
-		}
-	};
-	constexpr int kStages = 6;
-#pragma unroll
-	for (int pat = 0; pat <= npat; ++pat) {
-		if (pat < npat) A(pat, 0);
-#pragma unroll
-		for (int t = 0; t < R; ++t) {
-			if (pat < npat) {
-				if (t + 1 < R) A(pat, t + 1);
-				B(pat, t);
-			}
-			if (pat > 0) {   // stages [t * kStages / R, (t + 1) * kStages / R) of the previous pattern's tail
-#pragma unroll
-				for (int k = t * kStages / R; k < (t + 1) * kStages / R; ++k) tail(pat - 1, k);
-			}
-			__builtin_amdgcn_sched_barrier(0);
-		}
-		if (pat < npat) { sx_ = sumx; sy_ = sumy; sumx = 0.0; sumy = 0.0; }
-	}
-	bad |= top >= (unsigned)kGRows;
-	bad |= minlo < 2u * guardUnits;
-	bad |= maxrc >= (unsigned)kPatchRows;
-	return !__any(bad);
-}
-
-// Persistent workgroups: a workgroup of kFastWaves waves walks a contiguous range of keypoint GROUPS (kFastWaves consecutive slots of one image, one per
-// wave).  The camera's table is loaded into LDS when the camera changes — once per workgroup for a camera-major batch — and there is no barrier inside the
-// walk.  (One workgroup per 8 keypoints spent half its life in the load -> LDS -> barrier prologue: the kernel without model, sampling and guard took 0.36 of
-// 0.71 ms.  Round 3 hoped the waves of a persistent workgroup would drift apart and hide each other's memory round trips; they do not — next paragraph.)
-// ---- the walk, software-pipelined through LDS-DMA --------------------------------------------------------------------------------------------------
-// A wave alone pays three dependent memory round trips per keypoint (slot record -> patch -> LDS: ~4.5 us against ~10 us of arithmetic), and the waves of a
-// SIMD do NOT hide them for each other: every keypoint costs the same, so waves that start together stay in step — they wait together, then compete for the
-// issue slots together (measured: the walk alone 0.24 ms + the arithmetic 0.48 ms = the 0.70 ms of the whole kernel).  So every wave requests AHEAD, with
-// global_load_lds (global memory -> LDS without passing registers: nothing to hold, nothing to spill): at the top of trip k
-//   * the RECORD of keypoint k + 2 — level / stride, row | col, patch offset, undistorted position, the pattern angles' cos / sin (k_orient_b's field arrays)
-//     and the camera's affine terms and table index — into a 32-dword mailbox of the wave (two mailboxes in turn), one request: lane L fetches dword L;
-//   * the PATCH of keypoint k + 1, whose record arrived a trip ago, into the wave's other patch buffer: dword i = 64 t + lane of the patch (row i / kPatchDw,
-//     dword i % kPatchDw) lands at byte 4 i — the layout patch_store writes.
-// Both have a whole trip to arrive; one s_waitcnt vmcnt(0) at the top of a trip covers them (the compiler does not count LDS-DMA requests: the wait is
-// explicit, and every register load of the trip is consumed before the next requests go out, so that no compiler-placed vmcnt(0) waits for them).
 #ifndef MCS_FAST_DMA
 #define MCS_FAST_DMA 1   // 0: the round-3 walk (slot record by loads, patch through registers), for A/B
 #endif
@@ -1390,7 +1244,7 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 	static_assert(MODE == 1 || MODE == 2, "the fast pass is for the distorted patterns");
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	constexpr size_t kFastWaveLds = fast_wave_lds(NB);
-	double2* const patLds = reinterpret_cast<double2*>(reinterpret_cast<uint8_t*>(lds) + kGTabDoubles * sizeof(double));
+	double2* const patLds = reinterpret_cast<double2*>(reinterpret_cast<uint8_t*>(lds) + kGDevDoubles * sizeof(double));
 	uint8_t* const waveLds = reinterpret_cast<uint8_t*>(patLds) + fast_pat_bytes(NB) + (size_t)wave * kFastWaveLds;
 	uint32_t* const mailBase = reinterpret_cast<uint32_t*>(waveLds + kFastPatchBufs * kFPatchBytes);
 #if MCS_FAST_UNIQ
@@ -1436,6 +1290,24 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 	if (slot_of(0) < 0) nxt.lvl = -1;
 	ask_patch(nxt, 0);
 	ask_record(1);
+	// The walk's ONE wait for vector memory sits at the END of a trip, in front of the trip's output stores (round 6): what it waits for — the next keypoint's patch
+	// and the record after it — was requested a whole keypoint earlier and has long landed, and the stores then have the next trip to complete.  (At the top of the
+	// trip, where it stood, it also waited for the stores just issued: on this chip stores count in vmcnt like loads, a store's round trip per keypoint.)
+#ifndef MCS_FAST_WAIT_TOP
+#define MCS_FAST_WAIT_TOP 1   // 1 (default): the wait at the top of the trip; 0: at its end, in front of the output stores — measured 0.506 against 0.498 ms, not kept
+#endif
+	FastKp cur = nxt;
+	if (!MCS_FAST_WAIT_TOP) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		nxt = mail_read(mailBase + kMailDwords);
+		if (slot_of(1) < 0) nxt.lvl = -1;
+	}
+	auto advance = [&](int k) {   // end of trip k: patch k + 1 and record k + 2 have landed
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		cur = nxt;
+		nxt = mail_read(mailBase + (k & 1) * kMailDwords);   // record k + 2 went into the mailbox record k was read from
+		if (slot_of(k + 2) < 0) nxt.lvl = -1;
+	};
 #endif
 #pragma unroll 1
 	for (int k = 0; k < groupsPerBlock; ++k) {
@@ -1447,10 +1319,10 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 		int lane = threadIdx.x & 63;
 		asm volatile("" : "+v"(lane));   // opaque per trip: nothing derived from the lane id is worth holding in registers across the walk
 #if MCS_FAST_DMA
-		const FastKp me = nxt;
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this keypoint's patch and the next one's record have landed
-		nxt = mail_read(mailBase + ((k + 1) & 1) * kMailDwords);
-		if (slot_of(k + 1) < 0) nxt.lvl = -1;
+#if MCS_FAST_WAIT_TOP
+		advance(k - 1);   // A/B: the wait at the top of the trip (round 5)
+#endif
+		const FastKp me = cur;   // (its patch landed before the previous trip's stores went out: advance())
 		// The requests go out behind this keypoint's first LDS read (inside fast_keypoint), not here: the compiler keeps an s_waitcnt vmcnt(0) in front of that
 		// read (pending flat accesses of the sampler's general path, as its bookkeeping sees the loop) — issued before it, they would be waited for at once.
 		auto ahead = [&]() {
@@ -1467,8 +1339,8 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 		if (tabIdx != curTab) {   // uniform over the workgroup: every wave walks the same groups
 			if (curTab >= 0) __syncthreads();   // nobody reads the old table any more
 			if (!(MCS_FAST_ABLATE & 8)) {
-				const double2* gt = reinterpret_cast<const double2*>(b.gTab + (size_t)tabIdx * kGTabDoubles);
-				constexpr int n2 = kGTabDoubles / 2, trips = (n2 + 64 * kFastWaves - 1) / (64 * kFastWaves);
+				const double2* gt = reinterpret_cast<const double2*>(b.gTab + (size_t)tabIdx * kGDevDoubles);
+				constexpr int n2 = kGDevDoubles / 2, trips = (n2 + 64 * kFastWaves - 1) / (64 * kFastWaves);
 				double2 tv[trips];
 #pragma unroll
 				for (int t = 0; t < trips; ++t) { const int i = t * 64 * kFastWaves + (int)threadIdx.x; tv[t] = i < n2 ? gt[i] : double2{0.0, 0.0}; }
@@ -1479,7 +1351,7 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 			curTab = tabIdx;
 		}
 #if MCS_FAST_DMA
-		if (!me.usable()) { ahead(); continue; }   // nothing here, or already on the exact pass's pre-list
+		if (!me.usable()) { ahead(); if (!MCS_FAST_WAIT_TOP) advance(k); continue; }   // nothing here, or already on the exact pass's pre-list
 		const int level = me.lvl & 0xFF;
 		const int row = me.rc & 0xFFFF, col = (int)((unsigned)me.rc >> 16);
 		const FastCam C = me.C;
@@ -1521,9 +1393,7 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 		UTabs T;
 		T.upat = patLds + lane; T.uw = uwLds + lane; T.gidx = gidxLds + lane * NB; T.vals = waveLds + kFastPatchBufs * kFPatchBytes + kMailBytes;
 #if MCS_FAST_DMA
-		bool ok;
-		if constexpr (MCS_FAST_PIPE && MODE == 2 && UPat<NB>::R <= 6) ok = fast_keypoint_p<MODE, NB>(b, C, tabLds, patchLds, ukx, uky, axc, ays, T, bitsMain, agree, ahead);
-		else ok = fast_keypoint_u<MODE, NB>(b, C, tabLds, patchLds, ukx, uky, axc, ays, T, bitsMain, agree, ahead);
+		const bool ok = fast_keypoint_u<MODE, NB>(b, C, tabLds, patchLds, ukx, uky, axc, ays, T, bitsMain, agree, ahead);
 #else
 		const bool ok = fast_keypoint_u<MODE, NB>(b, C, tabLds, patchLds, ukx, uky, axc, ays, T, bitsMain, agree, [] {});
 #endif
@@ -1531,6 +1401,9 @@ __global__ __launch_bounds__(64 * kFastWaves) void k_describe_fast(ExtractBuffer
 		const bool ok = fast_keypoint<MODE, NB>(b, C, tabLds, sm, row, col, ukx, uky, axc, ays, patLds + lane, bitsMain, agree, ahead);
 #else
 		const bool ok = fast_keypoint<MODE, NB>(b, C, tabLds, sm, row, col, ukx, uky, axc, ays, patLds + lane, bitsMain, agree, [] {});
+#endif
+#if MCS_FAST_DMA
+		if (!MCS_FAST_WAIT_TOP) advance(k);
 #endif
 		if (lane == 0) {
 			if (!ok) { const int at = atomicAdd(b.fbCount, 1); b.fbList[at] = (uint32_t)gwu; }
@@ -1590,7 +1463,7 @@ static void launch_fast_passes(const ExtractBuffers& b, int nimg, int wavesPerIm
 	const int groupsPerBlock = std::max(1, (ngroups + kFastBlocks - 1) / kFastBlocks);
 	int fblocks = (ngroups + groupsPerBlock - 1) / groupsPerBlock;
 	if (fblocks >= kNumXCD) fblocks = (fblocks + kNumXCD - 1) / kNumXCD * kNumXCD;   // whole XCD rounds: the kernel's block -> group mapping is XCD-contiguous
-	const size_t fLds = (size_t)kFastWaves * fast_wave_lds(NB) + kGTabDoubles * sizeof(double) + fast_pat_bytes(NB);
+	const size_t fLds = (size_t)kFastWaves * fast_wave_lds(NB) + kGDevDoubles * sizeof(double) + fast_pat_bytes(NB);
 	// PRECONDITION: fbCount and preCount — neighbours — were cleared by k_octree's first workgroup, i.e. every launch_describe follows a launch_octree of the same
 	// batch on the same stream, and the previous batch's side-stream pre-list kernel has been joined (the evDescJoin wait below); extract_impl in mcs_capi.hip is
 	// the only caller and keeps that order

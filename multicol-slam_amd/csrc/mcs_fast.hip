@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	// suppression walk take the place of `surv`)
 	constexpr int kTileBytes = (AG >= 0 && 2 * CW * CW > kTileRows * kTilePitch) ? 2 * CW * CW : kTileRows * kTilePitch;
 	__shared__ __attribute__((aligned(16))) uint8_t tile[kTileBytes];
-	__shared__ __attribute__((aligned(16))) uint8_t sc[kScRows * kScPitch];
+	__shared__ __attribute__((aligned(16))) uint8_t sc[(kScRows * kScPitch + 15) / 16 * 16];
 	__shared__ uint32_t keepBits[2 * CW];   // NMS + mask verdict per pixel of the cell: two words per row, bit = column
 	__shared__ int rowOff[64];           // exclusive prefix of the kept-pixel counts per row
 	__shared__ int runBase;
@@ -308,7 +308,41 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	int stride;
 	const uint8_t* src = level_ptr(b, d, img, cell.level, &stride);
 	src += (size_t)(cell.y0 - 3) * stride + (cell.x0 - Geo::kTileX);
-	const int tw = cw + Geo::kTileX + 3, th = ch + 6;
+	const int th = ch + 6;
+#ifndef MCS_FAST_STAGE_DMA
+#define MCS_FAST_STAGE_DMA 0   // 1 (A/B, round 6): the tile by LDS-DMA (below) — a quarter fewer VALU instructions in this phase, bit-exact, and SLOWER: 0.345 against 0.337 ms (481 dword requests per cell, each wave's M0 set-up and the wait in front of the barrier)
+#endif
+#if MCS_FAST_STAGE_DMA
+	// Staging by LDS-DMA (round 6): global_load_lds_dword moves a dword per lane from global memory straight into LDS at (uniform base + 4 * lane) — lane c of
+	// the workgroup owns dword c of the tile in row-major order (a tile row = kTilePitch / 4 dwords of the image row starting at x0 - kTileX), so the only VALU
+	// work left is c -> (row, dword) and the global offset: ~6 instructions per thread and trip, no LDS stores, no registers in between.  The kernel is bound by
+	// VALU issue (0.92 busy) and a fifth of its VALU instructions were this copy.  A row's dwords past the image row's end are not requested (the rightmost
+	// cell of a narrow level; they lie beyond the ring and the one dword the compass test reads past it).
+	{
+		constexpr int kRowDw = kTilePitch / 4;
+		constexpr unsigned kRowM = (65536u + kRowDw - 1) / kRowDw;   // c / kRowDw = (c * kRowM) >> 16, exact for c < kTileRows * kRowDw <= 72 * 18
+		static_assert((unsigned)(kTileRows * kRowDw) * (kRowM * kRowDw - 65536u) < 65536u, "row of a tile dword by multiplication");
+		const int availDw = min(kRowDw, (L.w - (cell.x0 - Geo::kTileX) + 3) >> 2);   // dwords of a tile row that start inside the image row (level-ROI coordinates: x0 >= 22 > kTileX)
+		const int ndwTile = kRowDw * th;
+		for (int base = 0; base < ndwTile; base += kFastBS) {   // (uniform trip count: the LDS base of a wave's request is wave-uniform)
+			const int c = base + tid;
+			const unsigned ty = ((unsigned)c * kRowM) >> 16, kx = (unsigned)c - ty * (unsigned)kRowDw;
+			if (c < ndwTile && (int)kx < availDw)
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (ty * (unsigned)stride + 4u * kx)),
+				                                 (__attribute__((address_space(3))) void*)(tile + 4 * (base + (tid & ~63))), 4, 0, 0);
+		}
+	}
+	// the score tile cleared as 16-byte words by one trip, the verdict bitmap as dwords
+	{
+		constexpr int kSc16 = (kScRows * kScPitch + 15) / 16;
+		for (int i = tid; i < kSc16; i += kFastBS) reinterpret_cast<uint4*>(sc)[i] = uint4{0u, 0u, 0u, 0u};
+	}
+	for (int i = tid; i < 2 * ch; i += kFastBS) keepBits[i] = 0;
+	if (tid == 0) { runBase = 0; nSurv = 0; }
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's requests have landed (hipcc does not count LDS-DMA loads in front of a barrier)
+	__syncthreads();
+#else
+	const int tw = cw + Geo::kTileX + 3;
 	const int ndw = (tw + 3) >> 2;   // unaligned dword loads; the <= 3 bytes of over-read per row stay inside the image row
 	// i / ndw by multiplication (CellInfo.rowM = ceil(2^16 / ndw)): ndw <= 17 and i < 17 * 66, so the error term i * (M*ndw - 2^16) < 2^16 and
 	// (i * M) >> 16 is exact; 32-bit offsets keep the address arithmetic out of 64-bit multiplies.
@@ -331,6 +365,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	for (int i = tid; i < 2 * ch; i += kFastBS) keepBits[i] = 0;
 	if (tid == 0) { runBase = 0; nSurv = 0; }
 	__syncthreads();
+#endif
 
 	const int t = d.fastThreshold;
 	const int lane = tid & 63, wave = tid >> 6;

@@ -171,3 +171,52 @@ def test_cameras_the_fast_pass_must_not_serve_get_an_infinite_or_large_bound():
     bad = dict(cam)
     bad["invP"] = list(cam["invP"][:-1]) + [float("nan")]
     assert not np.isfinite(_lib_bound(bad, 32))
+
+
+def test_device_form_of_the_table_and_its_float_tail_term():
+    """mcs_describe_fast_table_packed: the rows as the DEVICE reads them.  Default build: the host's rows of doubles, unchanged, and a zero float term.  A build with
+    MCS_G_PACKED=1 (48-byte rows: g0 .. g3 doubles, g4 .. g6 floats, kept as an A/B switch — it measured slower, profiles/NOTES.md round 6): the doubles must be the
+    table's, the floats its coefficients rounded to nearest, the row polynomial with the tail evaluated in float arithmetic must stay within tailU + f32 term of G, and
+    the term must match its independent derivation (6 relative roundings of 2^-24 on sum |g_j| |tau|^j, j = 4 .. 6, times sqrt(s))."""
+    rng = np.random.default_rng(5)
+    for cam in _cams()[:4]:
+        tab, e0, bpo, info = _table(cam)
+        oc = mcs.make_ocam(cam)
+        rb, f32 = C.c_int(), C.c_double()
+        mcs.check(mcs.lib().mcs_describe_fast_table_packed(C.byref(oc), None, C.byref(rb), C.byref(f32)))
+        raw = np.zeros(tab.shape[0] * rb.value, np.uint8)
+        mcs.check(mcs.lib().mcs_describe_fast_table_packed(C.byref(oc), raw.ctypes.data_as(C.c_void_p), None, None))
+        if rb.value == 8 * tab.shape[1]:
+            assert np.array_equal(raw.view(np.float64).reshape(tab.shape), tab) and f32.value == 0.0
+            continue
+        assert rb.value == 48 and tab.shape[1] == 7
+        rows = raw.reshape(-1, 48)
+        d4 = rows[:, :32].copy().view(np.float64)
+        f4 = rows[:, 32:].copy().view(np.float32)
+        assert np.array_equal(d4, tab[:, :4]) and np.array_equal(f4[:, :3], tab[:, 4:].astype(np.float32)) and not f4[:, 3].any()
+        m = int(np.log2(bpo))
+        noct = tab.shape[0] // bpo
+        s = np.exp2(rng.uniform(e0, e0 + noct, 40000))
+        bits = s.view(np.uint64)
+        idx = ((bits >> np.uint64(32)).astype(np.int64) >> (20 - m)) - ((1023 + e0) << m)
+        frac_bits = (bits & np.uint64((1 << (52 - m)) - 1)) | np.uint64(0x3FF << 52)
+        tau = frac_bits.view(np.float64) - (1.0 + 1.0 / (2 << m))
+        tf = tau.astype(np.float32)
+        # two float FMAs: each product + sum formed in double (exact to well below a float ulp), rounded to float once
+        t1 = (f4[idx, 2].astype(np.float64) * tf + f4[idx, 1]).astype(np.float32)
+        tl = (t1.astype(np.float64) * tf + f4[idx, 0]).astype(np.float32)
+        val = tl.astype(LD)
+        for j in (3, 2, 1, 0):
+            val = val * tau.astype(LD) + d4[idx, j].astype(LD)
+        err = float((np.abs(val - _G(cam, s)) * np.sqrt(s.astype(LD))).max())
+        u = 2.0 ** -53
+        assert err <= info["tailU"] + f32.value + 8 * u * info["rhoB"], (err, info["tailU"], f32.value)
+        # the term itself, row by row
+        tm = 2.0 ** -(m + 1)
+        t4 = sum(np.abs(tab[:, j]) * tm ** j for j in (4, 5, 6))
+        r = np.arange(tab.shape[0])
+        kappa = 1.0 + (r % bpo + 0.5) / bpo
+        sq = np.sqrt(kappa * np.exp2(e0 + r // bpo) * (1 + tm / kappa))
+        want = float((sq * (6 * 1.01 * 2.0 ** -24 * t4 + 1e-37)).max()) * 1.01
+        assert abs(want - f32.value) <= 0.02 * want, (want, f32.value)
+        assert f32.value < 2e-9
