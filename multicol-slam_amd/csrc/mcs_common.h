@@ -90,8 +90,8 @@ constexpr int kGM = MCS_G_M, kGDeg = MCS_G_DEG, kGE0 = MCS_G_E0, kGE1 = MCS_G_E1
 // ... as the HOST builds it (kGRow doubles per row).  The DEVICE reads a packed form (round 6): 48-byte rows in three 16-byte slots, [g0 g1] [g2 g3] doubles and
 // [g4 g5 g6 0] floats — three ds_read_b128 per row from LDS instead of seven 8-byte loads; the float tail's roundings are bounded by GTabInfo.f32U (mcs_capi.hip).
 #ifndef MCS_G_PACKED
-#define MCS_G_PACKED 0   // 1: the packed rows.  Measured (round 6, profiles/NOTES.md): 27 % fewer LDS-array cycles per keypoint and the kernel 6 % SLOWER (0.521 against
-#endif                   // 0.496 ms): the 16-byte loads want aligned register quads, the one-block keypoint spills 28 registers instead of 1.  0: rows of kGRow doubles.
+#define MCS_G_PACKED 1   // 1: the packed rows (three ds_read_b128 per gather: 27 % fewer LDS-array cycles per keypoint).  0 (A/B): rows of kGRow doubles, which the compiler reads as
+#endif                   // three ds_read2_b64 + one ds_read_b64 (half rate).  Round 6: 0.456 against 0.493 ms once the kernel no longer spills (profiles/NOTES.md).
 static_assert(!MCS_G_PACKED || kGDeg == 6, "the packed device rows hold degree 6");
 constexpr int kGDevRowBytes = MCS_G_PACKED ? 48 : kGRow * 8, kGDevDoubles = kGRows * kGDevRowBytes / 8;
 // The table starts at s = 2^kGE0, i.e. 1/32 pixel from the optical axis: G has a sqrt-type branch point at s = 0 (rho(theta) of a fitted backward polynomial

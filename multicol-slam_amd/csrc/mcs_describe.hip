@@ -761,9 +761,12 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // sum, like the shuffle form (describe_fast_bound counts its roundings, not its order).
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
-	const int vl = __double2loint(v), vh = __double2hiint(v);   // old = the source itself: every lane is written (full row / bank masks), no zero to set up
-	const int lo = __builtin_amdgcn_update_dpp(vl, vl, CTRL, 0xF, 0xF, false);
-	const int hi = __builtin_amdgcn_update_dpp(vh, vh, CTRL, 0xF, 0xF, false);
+#ifndef MCS_DPP_OLD_SELF
+#define MCS_DPP_OLD_SELF 0   // 1 (round 5, A/B): old = the source itself — the compiler then copies the source in front of every v_mov_b32_dpp (two extra moves per step)
+#endif
+	const int vl = __double2loint(v), vh = __double2hiint(v);   // a rotation inside the rows of 16: every lane has a source, so with bound_ctrl the old value is dead and no copy is made
+	const int lo = MCS_DPP_OLD_SELF ? __builtin_amdgcn_update_dpp(vl, vl, CTRL, 0xF, 0xF, false) : __builtin_amdgcn_update_dpp(0, vl, CTRL, 0xF, 0xF, true);
+	const int hi = MCS_DPP_OLD_SELF ? __builtin_amdgcn_update_dpp(vh, vh, CTRL, 0xF, 0xF, false) : __builtin_amdgcn_update_dpp(0, vh, CTRL, 0xF, 0xF, true);
 	return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ void wave_sum2_f64(double sx, double sy, double& totx, double& toty) {
@@ -1140,7 +1143,15 @@ __device__ __forceinline__ bool fast_keypoint_u(const ExtractBuffers& b, const F
 			const unsigned pc = (unsigned)__double2hiint(yx) - kHiPatch, pr = (unsigned)__double2hiint(yy) - kHiPatch;   // unsigned: left of / above the patch, NaN: huge
 			if (!(MCS_FAST_ABLATE & 4)) minlo = min(minlo, min((unsigned)__double2loint(yx), (unsigned)__double2loint(yy)));
 			maxrc = max(maxrc, max(pr, pc));
-			const unsigned off = min(pr * (unsigned)kFPitch + pc, (unsigned)(kFPatchBytes - 1));   // (a sample outside the patch: any byte of it, the keypoint leaves below)
+#ifndef MCS_PATCH_OFF_MAD
+#define MCS_PATCH_OFF_MAD 0   // 1 (round 5, A/B): pr * kFPitch + pc as written — pr is an arbitrary 32-bit value, so the compiler takes v_mad_u64_u32 (a quarter-rate 64-bit multiply-add) for it
+#endif
+			// row * 48 + column by two shift-adds (full rate; a wrapped product of a row far outside the patch is clamped like any other: any byte will do, the keypoint leaves below)
+			static_assert(kFPitch == 48 || MCS_PATCH_OFF_MAD, "the shift-add form is for a pitch of 48");
+			unsigned off16 = (pr << 4) + pc;
+			if (!MCS_PATCH_OFF_MAD) asm volatile("" : "+v"(off16));   // (opaque: the compiler otherwise folds the two shift-adds back into the multiply-add)
+			const unsigned offRaw = MCS_PATCH_OFF_MAD ? pr * (unsigned)kFPitch + pc : (pr << 5) + off16;
+			const unsigned off = min(offRaw, (unsigned)(kFPatchBytes - 1));   // (a sample outside the patch: any byte of it, the keypoint leaves below)
 			val[t] = (MCS_FAST_ABLATE & 1) ? (int)off : (int)pl[off];
 		}
 #pragma unroll
