@@ -1144,9 +1144,9 @@ __device__ __forceinline__ bool fast_keypoint_u(const ExtractBuffers& b, const F
 			if (!(MCS_FAST_ABLATE & 4)) minlo = min(minlo, min((unsigned)__double2loint(yx), (unsigned)__double2loint(yy)));
 			maxrc = max(maxrc, max(pr, pc));
 #ifndef MCS_PATCH_OFF_MAD
-#define MCS_PATCH_OFF_MAD 0   // 1 (round 5, A/B): pr * kFPitch + pc as written — pr is an arbitrary 32-bit value, so the compiler takes v_mad_u64_u32 (a quarter-rate 64-bit multiply-add) for it
+#define MCS_PATCH_OFF_MAD 0   // 1 (round 5, A/B): pr * kFPitch + pc as written — pr is an arbitrary 32-bit value, so the compiler takes v_mad_u64_u32 for it: full rate (tools/valu_rate2), but its 64-bit results cost register pairs, and the block sat at the edge of the register file (1 spill; with the packed rows 28)
 #endif
-			// row * 48 + column by two shift-adds (full rate; a wrapped product of a row far outside the patch is clamped like any other: any byte will do, the keypoint leaves below)
+			// row * 48 + column by two shift-adds on 32-bit registers (a wrapped product of a row far outside the patch is clamped like any other: any byte will do, the keypoint leaves below)
 			static_assert(kFPitch == 48 || MCS_PATCH_OFF_MAD, "the shift-add form is for a pitch of 48");
 			unsigned off16 = (pr << 4) + pc;
 			if (!MCS_PATCH_OFF_MAD) asm volatile("" : "+v"(off16));   // (opaque: the compiler otherwise folds the two shift-adds back into the multiply-add)
