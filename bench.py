@@ -249,7 +249,10 @@ def force_exchange_world1(e):
             sk.bind(("127.0.0.1", 0))
             os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             sk.close()
+        done = watchdog(int(os.environ.get("MCS_BENCH_INIT_TIMEOUT", "420")), "the one-rank RCCL group (init_process_group + first barrier)")
         e.dist.init_process_group("nccl", rank=0, world_size=1)
+        e.dist.barrier(device_ids=[e.local])   # the communicator is created HERE (lazily, by the first collective: tens of seconds on a fresh box), not under the 60-s watchdog of the first exchange
+        done()
     e.backend = "nccl"
     e.exchange = True
 
