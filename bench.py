@@ -388,6 +388,24 @@ class Job:
         self.nsets = n_sets or 3
         self.sets = [self._make_set() for _ in range(self.nsets)]
         self.cur = 0
+        # before the first exchange: every rank prints the digest of the plan it computed from its own arguments (the bytes `--dry-run` prints) and the ranks
+        # compare — an all-gather of 32 bytes; a rank that diverges is named and the run aborts before any buffer is exchanged
+        self.plan_digest = None
+        if e.exchange:
+            dg = rig.plan_digest(sp.ncam, sp.F, e.world, cap, sp.D, 32, sp.topk)
+
+            def gather32(b):
+                t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(e.red_dev)
+                out_t = torch.empty(32 * e.world, dtype=torch.uint8, device=e.red_dev)
+                e.dist.all_gather_into_tensor(out_t, t)
+                return out_t.cpu().numpy().tobytes()
+            print("bench.py: rank %d of %d plan digest %s (%s)" % (e.rank, e.world, dg.hex(), sp.tag), file=sys.stderr)
+            done = watchdog(int(os.environ.get("MCS_BENCH_EXCHANGE_TIMEOUT", "60")), "the plan-digest all-gather (32 bytes)")
+            try:
+                self.plan_digest = rig.check_plan_digests(dg, e.rank, e.world, gather32)
+            except ValueError as ex:
+                raise SystemExit("bench.py: %s" % ex)
+            done()
         # stored keyframes of this rank (database sweeps): contiguous sets of ncam*cap rows, filled once from an untimed pass
         self.kfs = lay.keyframe_shard(sp.D, e.rank) if sp.D > 0 else []
         self.nkf = len(self.kfs)
@@ -408,24 +426,6 @@ class Job:
             self.ex.set_tie_band(float(os.environ["MCS_BENCH_TIE_BAND"]))
         if self.ties_in_loop:
             self.ex.set_tie_capture(self.nsets, TIE_SLOTS)
-        # before the first exchange: every rank prints the digest of the plan it computed from its own arguments (the bytes `--dry-run` prints) and the ranks
-        # compare — an all-gather of 32 bytes; a rank that diverges is named and the run aborts before any buffer is exchanged
-        self.plan_digest = None
-        if e.exchange:
-            dg = rig.plan_digest(sp.ncam, sp.F, e.world, cap, sp.D, 32, sp.topk)
-
-            def gather32(b):
-                t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(e.red_dev)
-                out_t = torch.empty(32 * e.world, dtype=torch.uint8, device=e.red_dev)
-                e.dist.all_gather_into_tensor(out_t, t)
-                return out_t.cpu().numpy().tobytes()
-            print("bench.py: rank %d of %d plan digest %s (%s)" % (e.rank, e.world, dg.hex(), sp.tag), file=sys.stderr)
-            done = watchdog(int(os.environ.get("MCS_BENCH_EXCHANGE_TIMEOUT", "60")), "the plan-digest all-gather (32 bytes)")
-            try:
-                self.plan_digest = rig.check_plan_digests(dg, e.rank, e.world, gather32)
-            except ValueError as ex:
-                raise SystemExit("bench.py: %s" % ex)
-            done()
         # prime the pipeline: the first step() patches, exchanges and matches the multi-frames extracted here
         self.extract(self.sets[self.nsets - 1])
         if e.exchange:
