@@ -342,6 +342,33 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's requests have landed (hipcc does not count LDS-DMA loads in front of a barrier)
 	__syncthreads();
 #else
+#ifndef MCS_FAST_STAGE16
+#define MCS_FAST_STAGE16 1   // 0 (A/B): the round-5 staging for every cell (two dwords per thread and trip)
+#endif
+	// Staging in 16-byte chunks (round 6): a tile row (kTilePitch bytes of the image row from x0 - kTileX) is ceil(kTilePitch / 16) chunks, the last one pulled back to end
+	// with the row (its leading bytes then duplicate the chunk before it: same bytes to the same LDS addresses); a thread loads one chunk (one unaligned 16-byte load)
+	// and stores it as four dwords.  The index arithmetic is paid per 16 bytes instead of per 4: this phase was a fifth of the kernel's VALU instructions, and the kernel is
+	// bound by VALU issue.  Only for cells whose tile rows end inside the image row (cw >= kTilePitch - 26 for FAST: every cell of the usual 30-px grid with the 40-px
+	// instance); the rest — a wide instance serving a level of narrow cells — take the dword loop below.
+	const bool stage16 = MCS_FAST_STAGE16 && (cell.x0 - Geo::kTileX + kTilePitch <= L.w);
+	if (stage16) {
+		constexpr int kChunks = (kTilePitch + 15) / 16, kLast = kTilePitch - 16;   // kTilePitch is a multiple of 4, >= 16
+		static_assert((kChunks & (kChunks - 1)) == 0 || kChunks == 3 || kChunks == 5 || kChunks == 6, "chunks per row");
+		const int nch = kChunks * th;
+		for (int c = tid; c < nch; c += kFastBS) {
+			const unsigned ty = kChunks == 4 ? (unsigned)c >> 2 : kChunks == 8 ? (unsigned)c >> 3 : (unsigned)c / (unsigned)kChunks;   // (a constant divisor: multiply + shift)
+			const unsigned k = (unsigned)c - ty * (unsigned)kChunks;
+			const unsigned xo = min(16u * k, (unsigned)kLast);
+			uint4 v;
+			__builtin_memcpy(&v, src + (ty * (unsigned)stride + xo), 16);
+			uint32_t* dstw = reinterpret_cast<uint32_t*>(&tile[ty * kTilePitch + xo]);
+			dstw[0] = v.x; dstw[1] = v.y; dstw[2] = v.z; dstw[3] = v.w;
+		}
+		for (int i = tid; i < (kScRows * kScPitch + 15) / 16; i += kFastBS) reinterpret_cast<uint4*>(sc)[i] = uint4{0u, 0u, 0u, 0u};   // the score tile cleared as 16-byte words
+		for (int i = tid; i < 2 * ch; i += kFastBS) keepBits[i] = 0;
+		if (tid == 0) { runBase = 0; nSurv = 0; }
+		__syncthreads();
+	} else {
 	const int tw = cw + Geo::kTileX + 3;
 	const int ndw = (tw + 3) >> 2;   // unaligned dword loads; the <= 3 bytes of over-read per row stay inside the image row
 	// i / ndw by multiplication (CellInfo.rowM = ceil(2^16 / ndw)): ndw <= 17 and i < 17 * 66, so the error term i * (M*ndw - 2^16) < 2^16 and
@@ -365,6 +392,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	for (int i = tid; i < 2 * ch; i += kFastBS) keepBits[i] = 0;
 	if (tid == 0) { runBase = 0; nSurv = 0; }
 	__syncthreads();
+	}
 #endif
 
 	const int t = d.fastThreshold;
