@@ -290,6 +290,14 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	__shared__ int nSurv;
 	__shared__ unsigned short surv[CW * CW];   // codes of the pixels that pass the compass test
 	constexpr int QR = AG >= 0 ? AgastGeom<AG < 0 ? 3 : AG>::R : 3;   // radius of the compass test
+#ifndef MCS_FAST_ORDERED
+#define MCS_FAST_ORDERED 1   // 0 (A/B): the round-5 form — survivors appended by atomics in any order, verdict bitmap + row prefix + a second loop for the emission
+#endif
+	// FAST on the 16-pixel ring: the survivor list is kept in ROW-MAJOR order (round 6), so that a kept survivor's place in the output is the number of kept survivors in
+	// front of it in the list — non-max suppression, mask and emission are then ONE loop with a ballot, where a verdict bitmap, a row prefix and a second loop stood
+	constexpr bool kOrdered = MCS_FAST_ORDERED && P == 16 && MCS_FAST_SEG16 && AG < 0;
+	__shared__ int waveTot[kFastBS / 64];
+	int listRun = 0;   // survivors listed by the trips so far (uniform)
 
 	// XCD-aware mapping: hardware places block i on XCD i%8; give every XCD a contiguous run of cells so that the
 	// overlapping cell rings / shared cache lines of neighbouring cells hit the same L2.
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 		constexpr int kSc16 = (kScRows * kScPitch + 15) / 16;
 		for (int i = tid; i < kSc16; i += kFastBS) reinterpret_cast<uint4*>(sc)[i] = uint4{0u, 0u, 0u, 0u};
 	}
-	for (int i = tid; i < 2 * ch; i += kFastBS) keepBits[i] = 0;
+	if (!kOrdered) for (int i = tid; i < 2 * ch; i += kFastBS) keepBits[i] = 0;
 	if (tid == 0) { runBase = 0; nSurv = 0; }
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's requests have landed (hipcc does not count LDS-DMA loads in front of a barrier)
 	__syncthreads();
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 			dstw[0] = v.x; dstw[1] = v.y; dstw[2] = v.z; dstw[3] = v.w;
 		}
 		for (int i = tid; i < (kScRows * kScPitch + 15) / 16; i += kFastBS) reinterpret_cast<uint4*>(sc)[i] = uint4{0u, 0u, 0u, 0u};   // the score tile cleared as 16-byte words
-		for (int i = tid; i < 2 * ch; i += kFastBS) keepBits[i] = 0;
+		if (!kOrdered) for (int i = tid; i < 2 * ch; i += kFastBS) keepBits[i] = 0;
 		if (tid == 0) { runBase = 0; nSurv = 0; }
 		__syncthreads();
 	} else {
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 	}
 	const int sh = ch + 2;
 	for (int i = tid; i < sh * (kScPitch / 4); i += kFastBS) reinterpret_cast<uint32_t*>(sc)[i] = 0;   // score tile cleared as dwords
-	for (int i = tid; i < 2 * ch; i += kFastBS) keepBits[i] = 0;
+	if (!kOrdered) for (int i = tid; i < 2 * ch; i += kFastBS) keepBits[i] = 0;
 	if (tid == 0) { runBase = 0; nSurv = 0; }
 	__syncthreads();
 	}
@@ -429,7 +437,18 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 			const int incl = wave_incl_scan(cnt);
 			const int total = __builtin_amdgcn_readlane(incl, 63);
 			int wbase = 0;
-			if (lane == 0 && total) wbase = atomicAdd(&nSurv, total);
+			if constexpr (kOrdered) {
+				// list space in (trip, wave, lane) order = the segments' row-major order: the waves' totals meet in LDS (one barrier per trip: a cell of up to 40 x 40 is one
+				// trip) instead of racing for an atomic — pass 3 below then ranks the kept survivors by list position alone
+				if (lane == 0) waveTot[wave] = total;
+				__syncthreads();
+				int before = 0, all = 0;
+#pragma unroll
+				for (int w = 0; w < kFastBS / 64; ++w) { const int tw_ = waveTot[w]; before += w < wave ? tw_ : 0; all += tw_; }
+				wbase = listRun + before;
+				listRun += all;
+				if (base + kFastBS < nseg) __syncthreads();   // (waveTot is rewritten by the next trip; pass 3 reuses it behind the barriers in between)
+			} else if (lane == 0 && total) wbase = atomicAdd(&nSurv, total);
 			int pos = __builtin_amdgcn_readfirstlane(wbase) + incl - cnt;
 			while (bits) {
 				const int j = __builtin_ctz(bits);
@@ -486,7 +505,7 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 		}
 	}
 	__syncthreads();
-	const int ns = nSurv;
+	const int ns = kOrdered ? listRun : nSurv;
 	if constexpr (P == 16) {
 		for (int i = 2 * tid; i < ns; i += 2 * kFastBS) {
 			const int pa = surv[i], pb = surv[i + 1 < ns ? i + 1 : i];
@@ -608,6 +627,41 @@ __global__ __launch_bounds__(kFastBS) void k_fast_cells(ExtractBuffers b, int ni
 			emit(i < n && flags[i] == -1, word(i));
 		}
 		if (lane == 0) *countOut = run;
+		return;
+	}
+	if constexpr (kOrdered) {
+		// pass 3, ordered list: suppression + mask + emission in one loop.  A trip covers kFastBS consecutive list entries; the kept ones among them leave in list order:
+		// a ballot per wave, the waves' counts through LDS (one barrier per trip; 113 survivors per cell on the bench stream: one trip)
+		int run = 0;
+		for (int base = 0; base < ns; base += kFastBS) {
+			const int i = base + tid;
+			bool keep = false;
+			uint32_t rec = 0;
+			if (i < ns) {
+				const int p = surv[i];
+				const int py = p >> 6, px = p & 63;
+				const uint8_t* q = &sc[(py + 1) * kScPitch + px + 1];
+				const int s0 = q[0];
+				const int nb = max(max(max((int)q[-1], (int)q[1]), max((int)q[-kScPitch - 1], (int)q[-kScPitch])),
+				                   max(max((int)q[-kScPitch + 1], (int)q[kScPitch - 1]), max((int)q[kScPitch], (int)q[kScPitch + 1])));
+				keep = s0 > nb;   // strictly greater than all 8 neighbours (a score of 0 never is)
+				if (keep && mask) {   // KeyPointsFilter::runByPixelsMask on the (nearest-neighbour) mask pyramid
+					const int mx = mapX[cell.x0 + px], my = mapY[cell.y0 + py];
+					keep = mask[(size_t)my * b.mask0Stride + mx] != 0;
+				}
+				rec = (uint32_t)(cell.x0 + px - kMinBorder) | ((uint32_t)(cell.y0 + py - kMinBorder) << 12) | ((uint32_t)s0 << 24);
+			}
+			const unsigned long long bal = __ballot(keep);
+			if (lane == 0) waveTot[wave] = __popcll(bal);
+			__syncthreads();
+			int before = 0, all = 0;
+#pragma unroll
+			for (int w = 0; w < kFastBS / 64; ++w) { const int tw_ = waveTot[w]; before += w < wave ? tw_ : 0; all += tw_; }
+			if (keep) slots[run + before + __popcll(bal & ((1ull << lane) - 1ull))] = rec;
+			run += all;
+			if (base + kFastBS < ns) __syncthreads();   // (waveTot is rewritten by the next trip)
+		}
+		if (tid == 0) *countOut = run;
 		return;
 	}
 	// pass 3a: non-max suppression + mirror mask, only for the pixels that have a score at all (the compass survivors); the verdicts go
