@@ -386,6 +386,7 @@ class Job:
         # then enqueues the exchange and the (deferred) search of set n - 1, which run beside the extraction of set n.  Three sets: being extracted, being
         # exchanged / matched, still read by the search issued one call earlier.
         self.nsets = n_sets or 3
+        self.xs = torch.cuda.Stream(device=dev) if e.exchange and e.backend == "nccl" else None   # where collectives are issued from (exchange_begin)
         self.sets = [self._make_set() for _ in range(self.nsets)]
         self.cur = 0
         # before the first exchange: every rank prints the digest of the plan it computed from its own arguments (the bytes `--dry-run` prints) and the ranks
@@ -458,6 +459,8 @@ class Job:
         b.send = torch.zeros(lay.send_bytes, dtype=torch.uint8, device=dev) if e.exchange else b.G   # no exchange: the slab IS the whole array
         b.valid = torch.zeros(view.images_total * lay.rows_img, dtype=torch.uint8, device=dev)
         b.nkp = torch.zeros(lay.L, dtype=torch.int32, device=dev)
+        if self.xs is not None:
+            b.ev_done, b.ev_x = torch.cuda.Event(), torch.cuda.Event()
         b.nkp_all = torch.zeros(view.images_total, dtype=torch.int32, device=dev)
         b.kps = torch.zeros((lay.L * self.cap, 7), dtype=torch.float32, device=dev)
         b.rays = torch.zeros((lay.L * self.cap, 3), dtype=torch.float64, device=dev)
@@ -485,12 +488,26 @@ class Job:
         self.ex.extract_strided(lay.L, self.d_imgs[img_buf].data_ptr(), W * H, W, self.d_masks.data_ptr(), W * H, W, self.camarr, b.nkp.data_ptr(),
                                 b.kps.data_ptr(), sp_, sp_ + lay.desc_size, b.rays.data_ptr(), lay.rows_img, lay.row_stride)
         mcs.check(lib.mcs_rig_pack_headers(e.ctx.h, C.c_void_p(b.nkp.data_ptr()), lay.L, self.cap, C.c_void_p(sp_), lay.row_stride))
+        if self.xs is not None:
+            b.ev_done.record(e.stream)
 
     def exchange_begin(self, b):
-        """the one exchange step: descriptor | mask | count blocks of every rank's slab.  RCCL: asynchronous (its own stream, ordered behind the extraction)."""
+        """the one exchange step: descriptor | mask | count blocks of every rank's slab.  RCCL: asynchronous, and issued from a side stream that waits for THIS
+        set's extraction only: torch orders a collective behind everything on the stream it is issued from, and in the pipelined step order the extraction of the
+        next slab is already enqueued on the main stream — issued from there the exchange would start when that extraction ends and sit on the critical path."""
         e = self.e
         if not e.exchange:
             return None
+        if self.xs is not None:
+            self.xs.wait_event(b.ev_done)
+            with e.torch.cuda.stream(self.xs):
+                w = self._exchange_begin(b)
+                b.ev_x.record(self.xs)
+            return w
+        return self._exchange_begin(b)
+
+    def _exchange_begin(self, b):
+        e = self.e
         if self.ring is not None:   # point to point: only the blocks this rank's pairs read
             if e.backend == "nccl":   # at world size 1 the rank's own blocks go through RCCL as well (a self send / receive), so that the path runs there
                 return e.rig.ring_exchange_begin(self.ring, e.rank, b.send, b.G, self_via_p2p=e.world == 1)
@@ -519,6 +536,8 @@ class Job:
             e.rig.ring_exchange_end(work)
         elif work is not None:
             work.wait()                                        # a stream-side wait: later work on our stream is ordered behind the collective
+        if self.xs is not None:
+            e.stream.wait_event(b.ev_x)                        # (and behind the local copies of the ring exchange, made on the side stream)
         mcs.check(lib.mcs_rig_rows_valid(e.ctx.h, C.c_void_p(b.G.data_ptr()), self.view.images_total, self.cap, lay.row_stride, C.c_void_p(b.valid.data_ptr()),
                                          C.c_void_p(b.nkp_all.data_ptr())))
 
@@ -567,8 +586,9 @@ class Job:
 
     def step(self, img_buf=0):
         """One step = one extraction, one exchange, one matching pass per call, pipelined: enqueue the extraction of this step's slab; wait (host) for the
-        PREVIOUS step's capture event and patch its rounding-tie rows; start that slab's exchange (N > 1; the collective runs beside this step's kernels) and,
-        stream-ordered behind it, match those multi-frames on the deferred streams.  The device never waits for the host: when the previous extraction ends,
+        PREVIOUS step's capture event and patch its rounding-tie rows; start that slab's exchange (N > 1; issued from the side stream, so the collective runs
+        beside this step's kernels: the main stream meets it only AFTER this step's extraction, when it has long finished) and, stream-ordered behind it, match
+        those multi-frames on the deferred streams.  The device never waits for the host: when the previous extraction ends,
         this one is already queued.  Results one step late."""
         b = self.sets[self.cur]
         p = self.sets[(self.cur - 1) % self.nsets]   # the set extracted in the previous call

@@ -990,6 +990,23 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 			launch_fast(b, hd, nimg, s, 1, hd.nlevels);
 		} else {
 		static const int sched = getenv("MCS_SCHED") ? atoi(getenv("MCS_SCHED")) : 3;   // launch order; 3 (default) since round 4, the others for A/B
+		if (sched == 5) {   // as 3, with the chain on the MAIN stream: no cross-stream event in front of the first resize and none between the chain and FAST; the blur forks
+			launch_pyramid(b, hd, nimg, s, 1, hd.nlevels);
+			HIPCHK(hipEventRecord(c->evPyr, s));
+			HIPCHK(hipStreamWaitEvent(c->side, c->evPyr, 0));
+			launch_blur(b, hd, nimg, c->side);
+			HIPCHK(hipEventRecord(c->evBlur, c->side));
+			launch_fast(b, hd, nimg, s, 0, hd.nlevels);
+		} else if (sched == 6) {   // FAST alone, the blur beside the oct-trees (latency-bound: one workgroup per image and level, the level-0 ones set its time)
+			launch_pyramid(b, hd, nimg, c->side, 1, hd.nlevels);
+			HIPCHK(hipEventRecord(c->evPyr, c->side));
+			HIPCHK(hipStreamWaitEvent(s, c->evPyr, 0));
+			launch_fast(b, hd, nimg, s, 0, hd.nlevels);
+			HIPCHK(hipEventRecord(c->evPyr1, s));
+			HIPCHK(hipStreamWaitEvent(c->side, c->evPyr1, 0));
+			launch_blur(b, hd, nimg, c->side);
+			HIPCHK(hipEventRecord(c->evBlur, c->side));
+		} else {
 		launch_pyramid(b, hd, nimg, c->side, 1, 2);
 		HIPCHK(hipEventRecord(c->evPyr1, c->side));
 		launch_pyramid(b, hd, nimg, c->side, 2, hd.nlevels);
@@ -1014,6 +1031,7 @@ static int extract_impl(mcs_extractor* e, int nimg, const uint8_t* images, size_
 		launch_fast(b, hd, nimg, s, 1, 2);
 		HIPCHK(hipStreamWaitEvent(s, c->evPyr, 0));
 		launch_fast(b, hd, nimg, s, 2, hd.nlevels);
+		}
 		}
 		}
 		// (holding the previous step's deferred matcher back until here, so that it runs beside the oct-tree / orientation / descriptor kernels instead of
