@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void k_greedy_spec(GreedyArgs g) {
 constexpr int kJacBatch = 4;   // undecidable queries rescanned per pass over the train rows
 constexpr int kJacOwn = 3, kJacExt = MCS_JAC_EXT;   // queries per thread whose list entries 8 .. 8 + kJacExt - 1 sit in registers (sets of up to 3072 queries: all of them)
 constexpr int kJacThreads = 1024, kJacCache = 8;   // list entries per query kept in LDS (a walk beyond them reads the list in memory: a dependent round trip per entry)
-__host__ __device__ constexpr size_t jacobi_lds_words(int nq, int nt, int K) { return (size_t)2 * nt + nq + (size_t)(K < kJacCache ? K : kJacCache) * nq + nq; }
+__host__ __device__ constexpr size_t jacobi_lds_words(int nq, int nt, int K) { return (size_t)2 * (nt + 1) + nq + (size_t)(K < kJacCache ? K : kJacCache) * nq + nq; }
 template <int K, int DW, bool MASKED>
 __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 	// LDS: owner[2][nt] — the lowest query that takes a row, as  (0xFFFF - sweep tag) << 16 | query  under atomicMin: entries of older sweeps compare larger and are
@@ -538,8 +538,9 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 	extern __shared__ uint32_t greedy_lds[];
 	constexpr int C = K < kJacCache ? K : kJacCache;
 	uint32_t* owner = greedy_lds;
-	int* A = reinterpret_cast<int*>(greedy_lds + 2 * (size_t)g.nt);
-	uint32_t* head = greedy_lds + 2 * (size_t)g.nt + g.nq;
+	const int nt1 = g.nt + 1;   // a claim buffer = nt rows + one sentinel slot that always reads 0 ("taken for everybody"): where list entries past a list's end point
+	int* A = reinterpret_cast<int*>(greedy_lds + 2 * (size_t)nt1);
+	uint32_t* head = greedy_lds + 2 * (size_t)nt1 + g.nq;
 	uint32_t* lastK = head + (size_t)C * g.nq;
 	__shared__ int changed[3], nRescan[3], rescanQ[3][64];   // per sweep, slot = sweep % 3: a slot is cleared two sweeps before it is used (one barrier per sweep)
 	__shared__ uint32_t partA[kJacThreads / 64], partB[kJacThreads / 64];
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 	const bool grouped = g.qgroup != nullptr && g.tgroup != nullptr;
 	const uint32_t* keys = g.keys + (size_t)set * K * g.nq;   // [K][nq]
 	int* outM = g.outMatch + (size_t)set * (g.mode == 1 ? g.nt : g.nq);
-	for (int j = tid; j < 2 * g.nt; j += kJacThreads) owner[j] = EMPTY;
+	for (int j = tid; j < 2 * nt1; j += kJacThreads) owner[j] = (j == g.nt || j == 2 * nt1 - 1) ? 0u : EMPTY;
 	if (g.mode == 1) for (int j = tid; j < g.nt; j += kJacThreads) outM[j] = -1;
 	for (int i = tid; i < g.nq; i += kJacThreads) {
 		const bool ok = !g.qvalid || g.qvalid[QR(i)] != 0;   // a query without a map point never takes a row: an empty list
@@ -569,7 +570,9 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 	}
 	__syncthreads();
 	// decision of query i from its list under "taken = a lower query claims the row in buffer `own` with tag `tag`": 0 none, 1 takes *row, 2 the list cannot decide
-	auto taken = [&](const uint32_t* own, uint32_t tag, int row, int i) { const uint32_t v = own[row]; return (v >> 16) == tag && (v & 0xFFFFu) < (uint32_t)i; };
+	// "taken for query i" in ONE unsigned compare (round 6): tags fall from sweep to sweep and a buffer is always read with the newest tag it holds, so a claim word of an
+	// older sweep (larger tag), and EMPTY, compare ABOVE (tag << 16 | i), and so does a current claim by a query >= i; only current claims by lower queries fall below
+	auto taken = [&](const uint32_t* own, uint32_t tag, int row, int i) { return own[row] < ((tag << 16) | (uint32_t)i); };
 	// the rules on (free rows found, best, second, the list's K-th entry): 0 none, 1 take the best row, 2 the list cannot decide
 	auto verdict = [&](int n, int best, int bestIdx, int second, uint32_t last) {
 		const bool full = last != EMPTY;
@@ -585,32 +588,25 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 		}
 		return (g.thInclusive ? dK <= g.thLow : dK < g.thLow) ? 2 : 0;
 	};
+	// The sweeps are bound by the INSTRUCTION COUNT of this function (3000 queries on the four SIMDs of one CU: 5 - 10 us per sweep at ~200 instructions per query, the LDS
+	// round trips hidden by the other waves), so it is written for few instructions: the C cached entries and their claim words in two batches of LDS reads, then ONE
+	// pass from the last entry to the first that keeps the (first, second) free entries seen so far — a free entry e becomes the first and pushes the old first to second:
+	// two selects per entry under the entry's compare mask, no counters, no halves (every wave met a lane that needed the second half anyway).
 	auto decide = [&](const uint32_t* own, uint32_t tag, int i, int* row, const uint32_t* ext = nullptr) {   // ext: entries C .. C + kJacExt - 1 of the list, held by the caller
-		int n = 0, best = 0x7FFFFFFF, second = 0x7FFFFFFF, bestIdx = -1;
-		// the cached head in two halves: a half's entries and their claim words are requested together (two LDS round trips per half), then picked in registers;
-		// the second half only if the first did not yield two free rows (the lists are sorted and most rows are free: seldom)
-		constexpr int H = C >= 8 ? C / 2 : C;
-		uint32_t kk[C];
-		auto half = [&](auto e0c) {
-			constexpr int e0 = decltype(e0c)::value;
-			uint32_t vv[H];
+		const uint32_t lim = (tag << 16) | (uint32_t)i;
+		uint32_t kk[C], vv[C];
 #pragma unroll
-			for (int e = 0; e < H; ++e) kk[e0 + e] = head[(size_t)(e0 + e) * g.nq + i];
+		for (int e = 0; e < C; ++e) kk[e] = head[(size_t)e * g.nq + i];
 #pragma unroll
-			for (int e = 0; e < H; ++e) vv[e] = own[kk[e0 + e] != EMPTY ? (kk[e0 + e] & 0xFFFFFu) : 0u];
+		for (int e = 0; e < C; ++e) vv[e] = own[min(kk[e] & 0xFFFFFu, (uint32_t)g.nt)];   // EMPTY -> the buffer's sentinel slot [nt] = 0: "taken" for everybody
+		uint32_t k1 = EMPTY, k2 = EMPTY;   // the first and the second free entry (keys: distance << 20 | row; the lists are sorted, EMPTY pads their ends)
 #pragma unroll
-			for (int e = 0; e < H; ++e) {
-				const uint32_t k = kk[e0 + e], v = vv[e];
-				const bool fr = k != EMPTY && !((v >> 16) == tag && (v & 0xFFFFu) < (uint32_t)i);
-				const bool t0 = fr && n == 0, t1 = fr && n == 1;
-				best = t0 ? (int)(k >> 20) : best; bestIdx = t0 ? (int)(k & 0xFFFFFu) : bestIdx;
-				second = t1 ? (int)(k >> 20) : second;
-				n += (fr && n < 2) ? 1 : 0;
-			}
-		};
-		half(std::integral_constant<int, 0>());
-		if (H < C) { if (n < 2 && kk[H - 1] != EMPTY) half(std::integral_constant<int, H>()); else kk[C - 1] = EMPTY; }
-		if (n < 2 && kk[C - 1] != EMPTY) {   // beyond the cached head (a query whose nearest rows are mostly taken by lower queries: the late ones)
+		for (int e = C - 1; e >= 0; --e) {
+			const bool fr = vv[e] >= lim;
+			k2 = fr ? k1 : k2;
+			k1 = fr ? kk[e] : k1;
+		}
+		if (k2 == EMPTY && kk[C - 1] != EMPTY) {   // fewer than two free rows in the cached head and the list goes on (a query whose nearest rows are mostly taken by lower queries: the late ones)
 			// several entries per round trip (entry by entry this was a dependent memory round trip each, and the slowest lane of the workgroup sets the pace of every
 			// sweep: 13 us per sweep): first the caller's register copy of entries C .. C + kJacExt - 1, then the list in memory, eight at a time
 			bool ended = false;
@@ -620,27 +616,26 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 #pragma unroll
 				for (int u = 0; u < W; ++u) vb[u] = own[kb[u] != EMPTY ? (kb[u] & 0xFFFFFu) : 0u];
 #pragma unroll
-				for (int u = 0; u < W; ++u) {
-					const uint32_t k = kb[u], v = vb[u];
-					ended = ended || k == EMPTY;
-					const bool fr = !ended && !((v >> 16) == tag && (v & 0xFFFFu) < (uint32_t)i);
-					const bool t0 = fr && n == 0, t1 = fr && n == 1;
-					best = t0 ? (int)(k >> 20) : best; bestIdx = t0 ? (int)(k & 0xFFFFFu) : bestIdx;
-					second = t1 ? (int)(k >> 20) : second;
-					n += (fr && n < 2) ? 1 : 0;
+				for (int u = 0; u < W; ++u) {   // in list order: the first free entry fills k1, the next k2
+					ended = ended || kb[u] == EMPTY;
+					const bool fr = !ended && vb[u] >= lim;
+					const bool t0 = fr && k1 == EMPTY, t1 = fr && !t0 && k2 == EMPTY;
+					k1 = t0 ? kb[u] : k1;
+					k2 = t1 ? kb[u] : k2;
 				}
 			};
 			int e0 = C;
 			if (ext) { batch(ext, std::integral_constant<int, kJacExt>()); e0 = C + kJacExt; }
-			for (; e0 < K && n < 2 && !ended; e0 += 8) {
+			for (; e0 < K && k2 == EMPTY && !ended; e0 += 8) {
 				uint32_t k8[8];
 #pragma unroll
 				for (int u = 0; u < 8; ++u) k8[u] = e0 + u < K ? keys[(size_t)(e0 + u) * g.nq + i] : EMPTY;
 				batch(k8, std::integral_constant<int, 8>());
 			}
 		}
-		*row = bestIdx;
-		return verdict(n, best, bestIdx, second, lastK[i]);
+		const int n = (k1 != EMPTY ? 1 : 0) + (k2 != EMPTY ? 1 : 0);
+		*row = k1 != EMPTY ? (int)(k1 & 0xFFFFFu) : -1;
+		return verdict(n, k1 != EMPTY ? (int)(k1 >> 20) : 0x7FFFFFFF, *row, k2 != EMPTY ? (int)(k2 >> 20) : 0x7FFFFFFF, lastK[i]);
 	};
 	// exact rescan of query qi by the whole workgroup: the two smallest keys among the eligible rows no lower query takes -> the query's outcome
 	auto rescan = [&](const uint32_t* own, uint32_t tag, int qi) -> int {
@@ -729,7 +724,7 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 #pragma unroll
 			for (int bb = 0; bb < kJacBatch; ++bb) {
 				if (bb < nb) {
-					const bool ok = valid && !((v >> 16) == tag && (v & 0xFFFFu) < (uint32_t)bqi[bb]) && (!grouped || tg == bgrp[bb]);
+					const bool ok = valid && !(v < ((tag << 16) | (uint32_t)bqi[bb])) && (!grouped || tg == bgrp[bb]);   // (`taken`, on the word already loaded)
 					const uint32_t k = ok ? (((uint32_t)hamming_g<DW, MASKED>(bq[bb], bq[bb] + DW, tw, MASKED ? mw : tw) << 20) | (uint32_t)j) : EMPTY;
 					if (k < a[bb]) { b2[bb] = a[bb]; a[bb] = k; } else if (k < b2[bb]) b2[bb] = k;
 				}
@@ -768,8 +763,8 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 	int nfallback = 0;
 	uint32_t t = 0;
 	for (int guard = 0; guard < maxSweeps && rescansDone <= g.nq; ++guard) {
-		const uint32_t* own = owner + (size_t)(t & 1u) * g.nt;
-		uint32_t* nxt = owner + (size_t)((t + 1u) & 1u) * g.nt;
+		const uint32_t* own = owner + (size_t)(t & 1u) * nt1;
+		uint32_t* nxt = owner + (size_t)((t + 1u) & 1u) * nt1;
 		const uint32_t tag = 0xFFFFu - (t & 0xFFFFu), ntag = 0xFFFFu - ((t + 1u) & 0xFFFFu);   // (tags repeat after 65536 sweeps; a sweep count is bounded by nq + passes, far below)
 		const int slot = (int)(t % 3u);
 		bool ch = false;
@@ -832,7 +827,7 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 		// a rescan changed an outcome: the claims of buffer `nxt` are stale for that query — rebuild them under a fresh tag by one more pass over the outcomes
 		++t;   // (skip a tag: buffer (t & 1) is `own` again, written with the tag of sweep t)
 		{
-			uint32_t* cur = owner + (size_t)(t & 1u) * g.nt;
+			uint32_t* cur = owner + (size_t)(t & 1u) * nt1;
 			const uint32_t ctag = 0xFFFFu - (t & 0xFFFFu);
 			for (int i = tid; i < g.nq; i += kJacThreads) { const int r = A[i]; if (r >= 0) atomicMin(&cur[r], (ctag << 16) | (uint32_t)i); }
 			if (tid < 3) { changed[tid] = 0; nRescan[tid] = 0; }
@@ -844,7 +839,7 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 		// claims of the queries before it (a fresh buffer and tag: nothing of the sweeps is read), its row claimed before the next one looks.
 		__syncthreads();
 		t += 2;
-		uint32_t* cur = owner + (size_t)(t & 1u) * g.nt;
+		uint32_t* cur = owner + (size_t)(t & 1u) * nt1;
 		const uint32_t ctag = 0xFFFFu - (t & 0xFFFFu);
 		for (int i = 0; i < g.nq; ++i) {
 			const bool ok = !g.qvalid || g.qvalid[QR(i)] != 0;

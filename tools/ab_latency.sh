@@ -11,6 +11,6 @@ e = bench.setup(args)
 sp = bench.Spec(args, 1)
 r = bench.run_latency(e, sp, calls=300, py_calls=40)
 n = r.get("native", {})
-print("%-8s" % sys.argv[0] if False else "", os.environ["MCS_HIP_LIB"].split("_")[-1], "median", r.get("median_ms"), "p99", r.get("p99_ms"), "extract", n.get("extract_ms", {}).get("median"), "match", n.get("match_ms", {}).get("median"), "match p90", n.get("match_ms", {}).get("p90"), "check", r.get("oracle_check"))
+print("%-8s" % sys.argv[0] if False else "", os.environ["MCS_HIP_LIB"].split("_")[-1], "median", r.get("median_ms"), "p99", r.get("p99_ms"), "extract", n.get("extract_ms", {}).get("median"), "match", n.get("match_ms", {}).get("median"), "match p90", n.get("match_ms", {}).get("p90"), "check", r.get("oracle_check"), "rescans_last", n.get("rescans_last"), "matches_last", n.get("matches_last"))
 PY
 done
