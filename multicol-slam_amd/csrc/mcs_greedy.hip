@@ -757,6 +757,14 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 	// stable state with undecidable queries costs an exact rescan each, and a rescan that changes an outcome restarts the sweeps: on clustered descriptors that can
 	// reach (undecidable queries) x (chain length) iterations.  Past kMaxSweeps sweeps or nq rescans the loop is given up and the set is resolved IN ORDER by exact
 	// rescans (the sequential greedy itself, about nq passes over the train rows by the whole workgroup), which cannot fail; `converged` says which way it ended.
+#ifdef MCS_JAC_DEBUG   // A/B builds only: device timestamps (100 MHz) of the sweeps, printed by thread 0 (tools/jd_probe.py)
+	long long stamp[40]; int nstamp = 0;
+	const long long tStart = (long long)wall_clock64();
+#define JSTAMP() do { if (nstamp < 40) stamp[nstamp++] = (long long)wall_clock64() - tStart; } while (0)
+#else
+#define JSTAMP() do {} while (0)
+#endif
+	JSTAMP();
 	const int maxSweeps = g.jacMaxSweeps > 0 ? g.jacMaxSweeps : 256;
 	bool converged = false;
 	int rescansDone = 0;
@@ -783,6 +791,7 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 		for (int i = tid + kJacOwn * kJacThreads; i < g.nq; i += kJacThreads) one(i, nullptr);
 		if (ch) changed[slot] = 1;
 		__syncthreads();
+		JSTAMP();
 		const bool again = changed[slot] != 0;
 		const int nr = nRescan[slot];
 		if (tid == 0) { const int s2 = (int)((t + 2u) % 3u); changed[s2] = 0; nRescan[s2] = 0; }   // the flags of the sweep after the next (last read before this barrier, next written after the next one)
@@ -849,6 +858,7 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 		}
 		nfallback = g.nq;
 	}
+	JSTAMP();
 	// ---- results
 	int nm = 0;
 	for (int i = tid; i < g.nq; i += kJacThreads) {
@@ -865,6 +875,12 @@ __global__ __launch_bounds__(kJacThreads) void k_greedy_jacobi(GreedyArgs g) {
 		int tot = 0;
 		for (int w = 0; w < kJacThreads / 64; ++w) tot += (int)partA[w];
 		g.outCount[set] = tot;
+#ifdef MCS_JAC_DEBUG
+		JSTAMP();
+		printf("jac: sweeps %d fb %d stamps(10ns):", (int)t, nfallback);
+		for (int k = 0; k < nstamp; ++k) printf(" %lld", stamp[k]);
+		printf("\n");
+#endif
 		if (g.outFallbacks) g.outFallbacks[set] = nfallback;
 	}
 }
