@@ -93,7 +93,11 @@ int mcs_ctx_search_fence(mcs_ctx*, int lag);
 
 /* ------------------------------------------------------------------ extractor
  * An extractor is built for one image size and a maximum batch (images per launch).  It owns the device pyramid,
- * candidate and keypoint buffers (sized once; nothing is allocated per call).                                         */
+ * candidate and keypoint buffers (sized once; nothing is allocated per call).
+ * MCS_ERR_UNSUPPORTED at creation: more than 32 oct-tree roots on a level (nIni = round(width / height) of the processed area: panoramas wider than 32:1) or more than
+ * 2045 features on one level.  A level with NO root (nIni = 0: more than twice as tall as wide, e.g. the small top levels of a portrait image) yields no keypoint: the
+ * reference divides by nIni there and indexes an empty root vector as soon as the level has a candidate (DistributeOctTree, src/mdBRIEFextractorOct.cpp:641-661,
+ * undefined); its one defined outcome, a level without candidates, is "nothing from this level", which is also the oracle's reading.                          */
 int mcs_extractor_create(mcs_ctx*, const mcs_extractor_params*, int width, int height, int max_batch, mcs_extractor** out);
 int mcs_extractor_destroy(mcs_extractor*);
 int mcs_extractor_kp_capacity(const mcs_extractor*, int* cap);  /* rows per image in the outputs: sum over levels of max(nfeatures_level + 3, 4 * oct-tree roots);

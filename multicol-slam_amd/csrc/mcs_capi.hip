@@ -539,11 +539,15 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 		selBase += L.selCap;
 		// oct-tree roots (:641-661)
 		L.nIni = cvRound_(wd / ht);
-		if (L.nIni < 1 || L.nIni > kMaxRoots || L.nfeat + 3 > kMaxNodes) {
+		if (L.nIni > kMaxRoots || L.nfeat + 3 > kMaxNodes) {
 			delete e;
-			return fail(MCS_ERR_UNSUPPORTED, "aspect ratio / features per level outside the oct-tree kernel's capacity (nIni in [1,32], nfeatures_level+3 <= 2048)");
+			return fail(MCS_ERR_UNSUPPORTED, "aspect ratio / features per level outside the oct-tree kernel's capacity (nIni <= 32, nfeatures_level+3 <= 2048)");
 		}
-		L.hX = wd / L.nIni;
+		// nIni = 0 (a level more than twice as tall as wide, e.g. the small top levels of a portrait image): the reference divides by it and, as soon as the level has a
+		// candidate, indexes an empty root vector (:641-661, undefined).  Its only defined outcome — a level without candidates — is "no keypoint on this level", and that
+		// is what such a level yields here whatever it holds (the oracle reads it the same way, oracle/mcs_oracle.cpp DistributeOctTree).
+		if (L.nIni < 1) L.nIni = 0;
+		L.hX = L.nIni > 0 ? wd / L.nIni : wd;
 		for (int i = 0; i <= L.nIni; ++i) L.rootX[i] = (int)(L.hX * static_cast<double>(i));
 		L.scale = (float)sc[l];
 		L.kpSize = (float)(int)(kPatchSize * sc[l]);

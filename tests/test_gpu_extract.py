@@ -108,6 +108,28 @@ def test_small_levels_with_cells_wider_than_40_px(G):
     ex.close()
 
 
+@pytest.mark.parametrize("w,h,sf,nl", [(275, 605, 1.2, 2), (345, 532, 1.5, 6), (376, 704, 1.2, 4)])
+def test_portrait_levels_without_an_octree_root(G, w, h, sf, nl):
+    """levels more than twice as tall as wide have nIni = round(width / height) = 0 oct-tree roots (reference :641-661 divides by it; defined only for a level
+    without candidates: nothing from that level — the oracle's reading, and the library's since round 6; before, such extractors were refused).  275x605: every level;
+    the others: the top levels only, the rest of the pyramid extracts as usual"""
+    cam = G.synth.scaled_camera(G.cams3()[0], w, h)
+    rng = np.random.default_rng(w)
+    imgs = [G.synth.synth_image(0, 0, cam), rng.integers(0, 256, (h, w)).astype(np.uint8)]
+    kw = dict(nfeatures=500, scaleFactor=sf, nlevels=nl, fastThreshold=12, do_dBrief=1, learnMasks=1)
+    ex = G.mcs.Extractor(G.ctx(), w, h, max_batch=2, **kw)
+    res = ex.extract_host(imgs, None, [G.mcs.make_ocam(cam)] * 2)
+    total = 0
+    for im, r in zip(imgs, res):
+        oex = G.O.Extractor(**kw)
+        oex.cap = max(oex.cap, ex.cap)
+        kps, d, dm = oex(im, None, G.O.make_ocam(cam))
+        assert G.first_diff(r[0], kps) is None and G.first_diff(r[1], d) is None and G.first_diff(r[2], dm) is None, (w, h)
+        total += len(kps)
+    assert (total == 0) == (w == 275), total
+    ex.close()
+
+
 def test_empty_image_gives_no_keypoints(G):
     ex = G.mcs.Extractor(G.ctx(), 754, 480, max_batch=1)
     res = ex.extract_host([np.zeros((480, 754), np.uint8)], None, None, want_rays=False)
