@@ -545,7 +545,7 @@ int mcs_extractor_create(mcs_ctx* ctx, const mcs_extractor_params* p, int width,
 		}
 		// nIni = 0 (a level more than twice as tall as wide, e.g. the small top levels of a portrait image): the reference divides by it and, as soon as the level has a
 		// candidate, indexes an empty root vector (:641-661, undefined).  Its only defined outcome — a level without candidates — is "no keypoint on this level", and that
-		// is what such a level yields here whatever it holds (the oracle reads it the same way, oracle/mcs_oracle.cpp DistributeOctTree).
+		// is what such a level yields here whatever it holds (tests/test_gpu_extract.py::test_portrait_levels_without_an_octree_root).
 		if (L.nIni < 1) L.nIni = 0;
 		L.hX = L.nIni > 0 ? wd / L.nIni : wd;
 		for (int i = 0; i <= L.nIni; ++i) L.rootX[i] = (int)(L.hX * static_cast<double>(i));

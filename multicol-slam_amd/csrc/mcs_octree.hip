@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_octree(ExtractBuffers b, int nimg, int 
 	}
 	__syncthreads();
 	if (tid == 0) *denseCount = n;
-	if (n == 0 || Lv.nIni < 1) { if (tid == 0) *selCount = 0; return; }   // (no root: a level more than twice as tall as wide — the oracle's reading of :641, see mcs_capi.hip)
+	if (n == 0 || Lv.nIni < 1) { if (tid == 0) *selCount = 0; return; }   // (no root: a level more than twice as tall as wide, see mcs_capi.hip)
 	OCT_T(1);
 	// keys of small levels live in LDS for the passes below (each pass walks all keys twice; from HBM that is the kernel's latency)
 	const bool inLds = n <= KCACHE;
