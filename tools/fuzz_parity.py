@@ -74,8 +74,9 @@ def one_case(rng, idx):
     cam = synth.scaled_camera(base[ci], W, H)
     if rng.random() < 0.3:   # the principal point off the scaled one
         cam["u0"] += float(rng.uniform(-20, 20)); cam["v0"] += float(rng.uniform(-20, 20))
-    kw = dict(nfeatures=nf, scaleFactor=sf, nlevels=nl, fastThreshold=th, useAgast=agast, fastAgastType=atype, **MODES[mode])
-    desc = "case %d: %dx%d sf=%.2f nl=%d nf=%d th=%d mode=%s agast=%d/%d img=%s mask=%s cam=%d" % (idx, W, H, sf, nl, nf, th, mode, agast, atype, ikind, mkind, ci)
+    ds = int(rng.choice([32, 32, 32, 16, 64]))
+    kw = dict(nfeatures=nf, scaleFactor=sf, nlevels=nl, fastThreshold=th, useAgast=agast, fastAgastType=atype, descSize=ds, **MODES[mode])
+    desc = "case %d: %dx%d sf=%.2f nl=%d nf=%d th=%d mode=%s ds=%d agast=%d/%d img=%s mask=%s cam=%d" % (idx, W, H, sf, nl, nf, th, mode, ds, agast, atype, ikind, mkind, ci)
     imgs = [image(rng, ikind, cam, f, ci) for f in (0, 1)]
     try:
         ex = mcs.Extractor(G.ctx(), W, H, max_batch=2, **kw)
@@ -130,16 +131,16 @@ def one_case(rng, idx):
         vq, vt = (rng.random(nq) < 0.85).astype(np.uint8), (rng.random(nt) < 0.85).astype(np.uint8)
         ratio = float(rng.choice([0.6, 0.75, 0.9, 1.0]))
         K = int(rng.choice([32, 32, 8, 2]))
-        q = cap_mod.DescSet(P(dq), P(mq) if masked else None, P(vq), None, nq, 32)
-        t = cap_mod.DescSet(P(dt), P(mt) if masked else None, P(vt), None, nt, 32)
+        q = cap_mod.DescSet(P(dq), P(mq) if masked else None, P(vq), None, nq, ds)
+        t = cap_mod.DescSet(P(dt), P(mt) if masked else None, P(vt), None, nt, ds)
         m12 = np.full(nq, -7, np.int32); nm = np.zeros(1, np.int32); fb = np.zeros(1, np.int32)
-        cap_mod.check(lib.mcs_search_kf_kf(ctx.h, 1, C.byref(q), 0, C.byref(t), 0, 32, ratio, K, cap_mod.MEM_HOST, P(m12), P(nm), P(fb)))
+        cap_mod.check(lib.mcs_search_kf_kf(ctx.h, 1, C.byref(q), 0, C.byref(t), 0, ds, ratio, K, cap_mod.MEM_HOST, P(m12), P(nm), P(fb)))
         en, e12 = O.search_kf_kf(dq, mq, vq, dt, mt, vt, masked, ratio)
         if int(nm[0]) != en or not np.array_equal(m12, e12):
             return desc + " -> search_kf_kf ratio=%.2f K=%d: %d matches, oracle %d" % (ratio, K, int(nm[0]), en), nkp
-        t2 = cap_mod.DescSet(P(dt), P(mt) if masked else None, None, None, nt, 32)
+        t2 = cap_mod.DescSet(P(dt), P(mt) if masked else None, None, None, nt, ds)
         out = np.full(nt, -7, np.int32)
-        cap_mod.check(lib.mcs_search_kf_f(ctx.h, 1, C.byref(q), 0, C.byref(t2), 0, 32, ratio, K, cap_mod.MEM_HOST, P(out), P(nm), P(fb)))
+        cap_mod.check(lib.mcs_search_kf_f(ctx.h, 1, C.byref(q), 0, C.byref(t2), 0, ds, ratio, K, cap_mod.MEM_HOST, P(out), P(nm), P(fb)))
         en, eo = O.search_kf_f(dq, mq, vq, dt, mt, masked, ratio)
         if int(nm[0]) != en or not np.array_equal(out, eo):
             return desc + " -> search_kf_f ratio=%.2f K=%d: %d matches, oracle %d" % (ratio, K, int(nm[0]), en), nkp
