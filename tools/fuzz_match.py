@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Randomised matcher parity on the GPU box (not a test: `python tools/fuzz_match.py [seconds] [seed]`).  Random set sizes (0, 1, ragged, thousands), descriptor
+sizes, K, masks, eligibility flags, ratios; descriptors drawn as clusters of near-duplicates (ties everywhere: the order is by train index, the greedy pass
+runs long chains and exact rescans) or as random rows; one or several set pairs per call.
+  * mcs_match_topk (Context.match_topk): distances and indices against numpy brute force;
+  * mcs_search_kf_kf / mcs_search_kf_f with nsets pairs laid out at a row pitch: every pair against the oracle's sequential loops (src/cORBmatcher.cpp:885-966, :179-323).
+One line per failing case with what reproduces it; exit code 1 if any failed.  The oracle is the checker here, as in tests/."""
+import ctypes as C
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gpu_common as G   # noqa: E402
+
+O = G.O
+mcs = G.mcs
+cap = importlib.import_module("multicol-slam_amd._capi")
+P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+
+
+def popcnt(a):
+    return np.unpackbits(a, axis=-1).sum(-1).astype(np.int32)
+
+
+def brute(qd, td, qm=None, tm=None):
+    out = np.empty((len(qd), len(td)), np.int32)
+    for s in range(0, len(qd), 32):
+        x = qd[s:s + 32, None, :] ^ td[None, :, :]
+        out[s:s + 32] = popcnt(x) if qm is None else (popcnt(x & qm[s:s + 32, None, :]) + popcnt(x & tm[None, :, :])) // 2
+    return out
+
+
+def topk_ref(D, K, elig):
+    nq, nt = D.shape
+    big = np.int64(1) << 40
+    key = D.astype(np.int64) * (1 << 20) + np.arange(nt)[None, :]
+    key = np.where(elig, key, big)
+    if nt < K:
+        key = np.concatenate([key, np.full((nq, K - nt), big)], 1)
+    order = np.argsort(key, axis=1, kind="stable")[:, :K]
+    kk = np.take_along_axis(key, order, 1)
+    return np.where(kk >= big, 0x7FFFFFFF, kk >> 20).astype(np.int32), np.where(kk >= big, -1, order).astype(np.int32)
+
+
+def rows(rng, n, dim, style, protos):
+    if style == "random" or n == 0:
+        return rng.integers(0, 256, (n, dim)).astype(np.uint8)
+    d = protos[rng.integers(0, len(protos), n)].copy()
+    flips = int(rng.choice([0, 1, 2, 6]))
+    for _ in range(flips):
+        b = rng.integers(0, 8 * dim, n)
+        d[np.arange(n), b >> 3] ^= (1 << (b & 7)).astype(np.uint8)
+    return d
+
+
+def size(rng):
+    r = rng.random()
+    if r < 0.08:
+        return int(rng.integers(0, 3))
+    if r < 0.5:
+        return int(rng.integers(3, 400))
+    return int(rng.integers(400, 3300))
+
+
+def case_topk(rng, idx):
+    dim = int(rng.choice([32, 32, 16, 64]))
+    K = int(rng.choice([1, 2, 4, 8, 16, 32]))
+    nq, nt = max(size(rng), 1), max(size(rng), 1)
+    style = str(rng.choice(["random", "clusters"]))
+    protos = rng.integers(0, 256, (int(rng.integers(1, 40)), dim)).astype(np.uint8)
+    masked = rng.random() < 0.5
+    qd, td = rows(rng, nq, dim, style, protos), rows(rng, nt, dim, style, protos)
+    qm = rng.integers(0, 256, (nq, dim)).astype(np.uint8) if masked else None
+    tm = rng.integers(0, 256, (nt, dim)).astype(np.uint8) if masked else None
+    qv = (rng.random(nq) < 0.9).astype(np.uint8) if rng.random() < 0.5 else None
+    tv = (rng.random(nt) < 0.8).astype(np.uint8) if rng.random() < 0.5 else None
+    desc = "topk case %d: dim=%d K=%d nq=%d nt=%d %s masked=%d qv=%d tv=%d" % (idx, dim, K, nq, nt, style, masked, qv is not None, tv is not None)
+    dist, ix, _ = G.ctx().match_topk(qd, td, K, -1, qm=qm, tm=tm, qvalid=qv, tvalid=tv)
+    elig = np.ones((nq, nt), bool)
+    if qv is not None:
+        elig &= qv[:, None] != 0
+    if tv is not None:
+        elig &= tv[None, :] != 0
+    ed, ei = topk_ref(brute(qd, td, qm, tm), K, elig)
+    e = G.first_diff(dist, ed) or G.first_diff(ix, ei)
+    return (desc + " -> " + e) if e else None
+
+
+def case_search(rng, idx):
+    dim = int(rng.choice([32, 32, 64]))
+    K = int(rng.choice([1, 2, 8, 32, 32]))
+    nsets = int(rng.choice([1, 1, 2, 3, 6, 12]))
+    nq, nt = size(rng), size(rng)
+    if nsets > 3:
+        nq, nt = min(nq, 900), min(nt, 900)
+    style = str(rng.choice(["random", "clusters", "clusters"]))
+    masked = rng.random() < 0.5
+    ratio = float(rng.choice([0.6, 0.8, 0.9, 1.0]))
+    pq, pt = nq + int(rng.integers(0, 5)), nt + int(rng.integers(0, 5))   # row pitch between the sets of a call
+    protos = rng.integers(0, 256, (int(rng.integers(1, 40)), dim)).astype(np.uint8)
+    Q = np.zeros((nsets, max(pq, 1), dim), np.uint8); T = np.zeros((nsets, max(pt, 1), dim), np.uint8)
+    QM = np.full_like(Q, 255); TM = np.full_like(T, 255)
+    QV = np.zeros((nsets, max(pq, 1)), np.uint8); TV = np.zeros((nsets, max(pt, 1)), np.uint8)
+    for s in range(nsets):
+        Q[s, :nq], T[s, :nt] = rows(rng, nq, dim, style, protos), rows(rng, nt, dim, style, protos)
+        if masked:
+            QM[s, :nq], TM[s, :nt] = rng.integers(0, 256, (nq, dim)), rng.integers(0, 256, (nt, dim))
+        QV[s, :nq], TV[s, :nt] = rng.random(nq) < 0.9, rng.random(nt) < 0.85
+    desc = "search case %d: dim=%d K=%d nsets=%d nq=%d nt=%d pitch=%d/%d %s masked=%d ratio=%.2f" % (idx, dim, K, nsets, nq, nt, pq, pt, style, masked, ratio)
+    lib, ctx = mcs.lib(), G.ctx()
+    q = cap.DescSet(P(Q), P(QM) if masked else None, P(QV), None, nq, dim)
+    t = cap.DescSet(P(T), P(TM) if masked else None, P(TV), None, nt, dim)
+    m12 = np.full((nsets, max(nq, 1)), -7, np.int32); nm = np.zeros(nsets, np.int32); fb = np.zeros(nsets, np.int32)
+    rc = lib.mcs_search_kf_kf(ctx.h, nsets, C.byref(q), Q.shape[1], C.byref(t), T.shape[1], dim, ratio, K, cap.MEM_HOST, P(m12), P(nm), P(fb))
+    if rc != 0:
+        return desc + " -> mcs_search_kf_kf rc %d (%s)" % (rc, lib.mcs_last_error().decode()[:120])
+    for s in range(nsets):
+        en, e12 = O.search_kf_kf(np.ascontiguousarray(Q[s, :nq]), np.ascontiguousarray(QM[s, :nq]), np.ascontiguousarray(QV[s, :nq]),
+                                 np.ascontiguousarray(T[s, :nt]), np.ascontiguousarray(TM[s, :nt]), np.ascontiguousarray(TV[s, :nt]), masked, ratio)
+        if int(nm[s]) != en or not np.array_equal(m12.reshape(-1)[s * nq:(s + 1) * nq] if nq else m12[s, :0], e12):
+            return desc + " -> kf_kf set %d: %d matches, oracle %d" % (s, int(nm[s]), en)
+    t2 = cap.DescSet(P(T), P(TM) if masked else None, None, None, nt, dim)
+    out = np.full((nsets, max(nt, 1)), -7, np.int32)
+    rc = lib.mcs_search_kf_f(ctx.h, nsets, C.byref(q), Q.shape[1], C.byref(t2), T.shape[1], dim, ratio, K, cap.MEM_HOST, P(out), P(nm), P(fb))
+    if rc != 0:
+        return desc + " -> mcs_search_kf_f rc %d (%s)" % (rc, lib.mcs_last_error().decode()[:120])
+    for s in range(nsets):
+        en, eo = O.search_kf_f(np.ascontiguousarray(Q[s, :nq]), np.ascontiguousarray(QM[s, :nq]), np.ascontiguousarray(QV[s, :nq]),
+                               np.ascontiguousarray(T[s, :nt]), np.ascontiguousarray(TM[s, :nt]), masked, ratio)
+        if int(nm[s]) != en or not np.array_equal(out.reshape(-1)[s * nt:(s + 1) * nt] if nt else out[s, :0], eo):
+            return desc + " -> kf_f set %d: %d matches, oracle %d" % (s, int(nm[s]), en)
+    return None
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    n = bad = 0
+    while time.time() - t0 < budget:
+        try:
+            err = (case_topk if n % 3 == 0 else case_search)(rng, n)
+        except Exception as ex:   # an error code of the library is a finding too
+            err = "case %d raised %s: %s" % (n, type(ex).__name__, str(ex)[:200])
+        n += 1
+        if err:
+            bad += 1
+            print("FAIL", err, flush=True)
+            if bad >= 20:
+                break
+    print("fuzz_match: seed %d, %d cases, %d failures, %.0f s" % (seed, n, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
