@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Randomised parity of the grid-window matchers on the GPU box (not a test: `python tools/fuzz_window.py [seconds] [seed]`): WindowSearch, SearchForInitialization and
+SearchByProjection(Cur, Last, th) of cORBmatcher (src/cORBmatcher.cpp:326-726, 1990-2118) through the reference-named host classes, on frame pairs of the synthetic rig
+with random motion, feature budgets, windows, level ranges, ratios, masks, map-point / outlier patterns and probe positions (inside, outside, on the border), against
+the oracle.  One line per failing case; exit code 1 if any failed.  The oracle is the checker here, as in tests/."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gpu_common as G   # noqa: E402
+import test_gpu_window as TW   # noqa: E402  (its scaffolding: MP, rot_y, small_motion, oview, world_points)
+
+FE = importlib.import_module("multicol-slam_amd.frontend")
+O = G.O
+STATS = {"WindowSearch": [0, 0], "SearchForInitialization": [0, 0], "SearchByProjection": [0, 0]}   # cases, matches
+
+
+def make_frames(rng):
+    cams = G.cams3()
+    models = [FE.cCamModelGeneral_.from_dict(c, G.synth.mirror_mask(c)) for c in cams]
+    M_c = []
+    for c in range(3):
+        M = TW.rot_y(120.0 * c + float(rng.uniform(-5, 5)))
+        M[:3, 3] = [0.1 * np.cos(c * 2.1), 0.02 * c, 0.1 * np.sin(c * 2.1)]
+        M_c.append(M)
+    nf = int(rng.choice([300, 1000, 1000, 2000]))
+    nl = int(rng.choice([4, 8, 8]))
+    ex = FE.mdBRIEFextractorOct(nf, 1.2, nl, 25, 0, 0, 32, 20, False, 2, True, True, 32, ctx=G.ctx())
+    f0 = int(rng.integers(0, 6))
+    out = []
+    for k in range(2):
+        f = f0 + k
+        rig = FE.cMultiCamSys_(models, M_c, TW.small_motion(*rng.uniform(-0.6, 0.6, 3), rng.uniform(-0.03, 0.03, 3)))
+        out.append(FE.cMultiFrame(G.synth.synth_multiframe(f, cams), 0.04 * f, [ex] * 3, None, rig, f))
+    return cams, out
+
+
+def case(rng, idx, cams, fr):
+    Fa, Fb = fr if rng.random() < 0.5 else fr[::-1]
+    masks = bool(rng.random() < 0.5)
+    ratio = float(rng.choice([0.6, 0.8, 0.9, 1.0]))
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        window = int(rng.choice([1, 5, 20, 60, 150, 400]))
+        minlvl = int(rng.integers(0, 6)); maxlvl = int(rng.choice([2**31 - 1, 2**31 - 1, int(rng.integers(0, 8))]))
+        Fa.mvpMapPoints = [TW.MP(i, bad=rng.random() < 0.05) if rng.random() < 0.7 else None for i in range(Fa.totalN)]
+        has = np.array([m is not None and not m.bad for m in Fa.mvpMapPoints], np.uint8)
+        desc = "WindowSearch case %d: window=%d levels=[%d,%d] masks=%d ratio=%.2f" % (idx, window, minlvl, maxlvl, masks, ratio)
+        try:
+            m = FE.cORBmatcher(ratio, False, 32, masks, ctx=G.ctx())
+            n, _ = m.WindowSearch(Fa, Fb, window, minlvl, maxlvl)
+            v1, _k1 = TW.oview(G, Fa, masks)
+            v2, _k2 = TW.oview(G, Fb, masks)
+            en, e21 = O.window_search(v1, has, v2, window, minlvl, maxlvl if maxlvl < 2**31 - 1 else -1, ratio, 32, masks)
+            STATS["WindowSearch"][0] += 1; STATS["WindowSearch"][1] += en
+            if n != en or not np.array_equal(m.last_matches21, e21):
+                return desc + " -> %d matches, oracle %d, %d entries differ" % (n, en, int((m.last_matches21 != e21).sum()))
+        finally:
+            Fa.mvpMapPoints = [None] * Fa.totalN
+    elif kind == 1:
+        window = int(rng.choice([1, 10, 30, 100, 300]))
+        prev = np.stack([Fa.mvKeys["x"], Fa.mvKeys["y"]], axis=1).astype(np.float64)
+        prev += rng.normal(0, float(rng.choice([0.0, 2.0, 30.0])), prev.shape)
+        k = min(len(prev), 12)
+        prev[:k] = np.array([[-100, 5], [5, -100], [3000, 10], [10, 3000], [0, 0], [753.9, 479.9], [377, 240], [754, 480], [-0.5, -0.5], [753.5, 479.5], [1e9, 1e9],
+                             [np.nextafter(754.0, 0), 0.0]])[:k]
+        desc = "SearchForInitialization case %d: window=%d masks=%d ratio=%.2f" % (idx, window, masks, ratio)
+        m = FE.cORBmatcher(ratio, False, 32, masks, ctx=G.ctx())
+        got_prev = prev.copy()
+        n, m12 = m.SearchForInitialization(Fa, Fb, got_prev, window)
+        v1, _k1 = TW.oview(G, Fa, masks)
+        v2, _k2 = TW.oview(G, Fb, masks)
+        en, e12, eprev = O.search_for_initialization(v1, v2, prev, window, ratio, 32, masks)
+        STATS["SearchForInitialization"][0] += 1; STATS["SearchForInitialization"][1] += en
+        if n != en or not np.array_equal(m12, e12) or not np.array_equal(got_prev, eprev):
+            return desc + " -> %d matches, oracle %d, %d entries differ" % (n, en, int((m12 != e12).sum()))
+    else:
+        Last, Cur = Fa, Fb
+        th = float(rng.choice([3.0, 7.0, 15.0, 50.0, 120.0]))
+        idxs = rng.permutation(Last.totalN)[:int(rng.uniform(0.2, 0.95) * Last.totalN)]
+        pts = TW.world_points(Last, rng, idxs)
+        Last.mvpMapPoints = [TW.MP(i, pts[i], bad=rng.random() < 0.04) if i in pts else None for i in range(Last.totalN)]
+        Last.mvbOutlier = [bool(rng.random() < 0.1) for _ in range(Last.totalN)]
+        Cur.mvpMapPoints = [TW.MP(-1) if rng.random() < 0.1 else None for _ in range(Cur.totalN)]
+        pre = np.array([mp is not None for mp in Cur.mvpMapPoints], np.uint8)
+        desc = "SearchByProjection(Cur,Last) case %d: th=%.0f masks=%d ratio=%.2f points=%d" % (idx, th, masks, ratio, len(pts))
+        try:
+            m = FE.cORBmatcher(ratio, False, 32, masks, ctx=G.ctx())
+            n = m.SearchByProjection(Cur, Last, th)
+            P = np.zeros((Last.totalN, 3))
+            for i, p in pts.items():
+                P[i] = p
+            euv, efl = O.world_to_cam(np.stack(Cur.camSystem.MtMc_inv), cams, [G.synth.mirror_mask(c) for c in cams], P, Last.keypoint_to_cam)
+            lastMP = np.array([mp is not None and not mp.bad for mp in Last.mvpMapPoints], np.uint8)
+            vc, _kc = TW.oview(G, Cur, masks)
+            vl, _kl = TW.oview(G, Last, masks)
+            en, ecur, eas = O.search_by_projection_last(vc, pre, vl, lastMP, np.array(Last.mvbOutlier, np.uint8), euv, efl & 1, Cur.mvScaleFactors, th, 32, masks)
+            got = np.array([mp.i if (mp is not None and not pre[j]) else -1 for j, mp in enumerate(Cur.mvpMapPoints)], np.int32)
+            STATS["SearchByProjection"][0] += 1; STATS["SearchByProjection"][1] += en
+            if n != en or not np.array_equal(got, ecur):
+                return desc + " -> %d matches, oracle %d, %d entries differ" % (n, en, int((got != ecur).sum()))
+        finally:
+            Last.mvbOutlier = [False] * Last.totalN
+            Last.mvpMapPoints = [None] * Last.totalN
+            Cur.mvpMapPoints = [None] * Cur.totalN
+    return None
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    n = bad = 0
+    cams, fr = make_frames(rng)
+    while time.time() - t0 < budget:
+        if n and n % 40 == 0:
+            cams, fr = make_frames(rng)
+        try:
+            err = case(rng, n, cams, fr)
+        except Exception as ex:
+            err = "case %d raised %s: %s" % (n, type(ex).__name__, str(ex)[:300])
+        n += 1
+        if err:
+            bad += 1
+            print("FAIL", err, flush=True)
+            if bad >= 20:
+                break
+    print("fuzz_window: seed %d, %d cases, %d failures, %.0f s; cases / matches per search: %s" % (seed, n, bad, time.time() - t0, STATS))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
