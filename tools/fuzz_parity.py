@@ -89,6 +89,15 @@ def one_case(rng, idx):
         except AssertionError as oe_err:
             REFUSED.append("%dx%d nl=%d nf=%d: oracle fails too (%s)" % (W, H, nl, nf, oe_err))
         return None, 0
+    knobs = ""
+    if mode != "orb":   # the descriptor stage's switches: every setting must give the same bits
+        if rng.random() < 0.25:
+            ex.set_describe(exact_only=True); knobs += " exact_only"
+        elif rng.random() < 0.3:
+            ge = float(rng.choice([1e-6, 1e-4, 1e-2])); ex.set_describe(exact_only=False, guard_eps=ge); knobs += " guard=%g" % ge
+        if rng.random() < 0.3:
+            tb = float(rng.choice([2e-4, 0.5, -1.0])); ex.set_tie_band(tb); knobs += " tie_band=%g" % tb
+    desc += knobs
     m = mask_of(rng, mkind, cam)
     masks = [m, m]
     oc = mcs.make_ocam(cam)
