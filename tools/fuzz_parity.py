@@ -127,6 +127,33 @@ def one_case(rng, idx):
                 return desc + " -> image %d %s: %s" % (i, name, e), 0
         sets.append((np.ascontiguousarray(d), np.ascontiguousarray(dm)))
         nkp += len(kps)
+    # the same two images as two device-kind batches back to back (strided rows as the rig's exchange blocks, a capture ring of two slots, the first batch patched when
+    # the pyramid already holds the second): rows, counts and keypoints must be the host-kind call's, i.e. the oracle's
+    if rng.random() < 0.5:
+        cap_rows = ex.cap
+        pitch_rows = cap_rows + int(rng.integers(0, 3)); stride = 2 * ds + int(rng.choice([0, 0, 16]))
+        ex.set_tie_capture(2, 4096)
+        dimg = [G.DevBuf(im[None]) for im in imgs]
+        dmsk = G.DevBuf(m[None]) if m is not None else None
+        outs = []
+        for i in range(2):
+            o = dict(nkp=G.DevBuf(np.zeros(1, np.int32)), kps=G.DevBuf(np.zeros((1, cap_rows), cap_mod.KP_DTYPE)), rows=G.DevBuf(np.zeros((pitch_rows, stride), np.uint8)),
+                     rays=G.DevBuf(np.zeros((1, cap_rows, 3), np.float64)))
+            ex.extract_strided(1, dimg[i].ptr.value, W * H, W, dmsk.ptr.value if dmsk else 0, W * H, W, [oc], o["nkp"].ptr.value, o["kps"].ptr.value, o["rows"].ptr.value,
+                               o["rows"].ptr.value + ds, o["rays"].ptr.value, pitch_rows, stride)
+            outs.append(o)
+        G.ctx().synchronize()
+        for back, i in ((1, 0), (0, 1)):
+            ex.patch_ties(back)
+            gk, gd, gm, gr = res[i]
+            n = int(outs[i]["nkp"].read()[0])
+            rws = outs[i]["rows"].read()
+            if n != len(gk):
+                return desc + " -> device-kind batch %d: %d keypoints, host-kind %d" % (i, n, len(gk)), 0
+            e = G.first_diff(rws[:n, :ds], gd) or G.first_diff(rws[:n, ds:2 * ds], gm) or G.first_diff(outs[i]["kps"].read()[0, :n], gk) \
+                or G.first_diff(outs[i]["rays"].read()[0, :n].view(np.uint64), gr.view(np.uint64))
+            if e:
+                return desc + " -> device-kind batch %d (pitch %d, stride %d): %s" % (i, pitch_rows, stride, e), 0
     ex.close()
     # the two frames against each other: SearchByBoW(KF,KF) with a random eligibility and ratio, SearchByBoW(KF,F)
     (dq, mq), (dt, mt) = sets
