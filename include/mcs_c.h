@@ -260,7 +260,8 @@ int mcs_search_triangulation(mcs_ctx*, int nsets, const mcs_desc_set* kf1, size_
  *     block for all pairs, >= 9*nrCams*nrCams otherwise).                                                                                             */
 /* mcs_search_kf_kf_ring  a stream of multi-frames, each matched (SearchByBoW(KF,KF) semantics) against the one before it — BASELINE configs[1] on the
  *     gathered buffer of the camera-sharded rig: `frames` describes frame 0 of a ring of nframes_total frames lying pitch_rows rows apart (device memory);
- *     pair s = (frame first + s, frame (first + s - 1) mod nframes_total), s = 0 .. count-1;  match12[s*n + i], nmatches[s] as in mcs_search_kf_kf. */
+ *     pair s = (frame first + s, frame (first + s - 1) mod nframes_total), s = 0 .. count-1;  match12[s*n + i], nmatches[s] as in mcs_search_kf_kf.
+ *     nframes_total >= 2, first >= 0, count >= 1, first + count <= nframes_total (only the predecessor wraps); MCS_ERR_INVALID otherwise. */
 int mcs_search_kf_kf_ring(mcs_ctx*, int nframes_total, int first, int count, const mcs_desc_set* frames, size_t pitch_rows, int dim, double nnratio, int K,
                           mcs_mem_kind kind, int32_t* match12, int32_t* nmatches, int32_t* fallbacks);
 int mcs_search_kf_f_sweep(mcs_ctx*, int nkf, const mcs_desc_set* kf, size_t pitchKF_rows, int nframes, const mcs_desc_set* frame, size_t pitchF_rows,

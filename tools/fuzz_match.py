@@ -138,6 +138,65 @@ def case_search(rng, idx):
     return None
 
 
+def case_sweep(rng, idx):
+    """mcs_search_kf_f_sweep: nframes frames x nkf keyframes in one call (pair f*nkf + k), host memory; mcs_search_kf_kf_ring: every frame of a ring against the one
+    before it (device memory), from a random first frame"""
+    dim = 32
+    K = int(rng.choice([2, 8, 32]))
+    nkf, nfr = int(rng.integers(1, 7)), int(rng.integers(1, 6))
+    nk, nf = min(size(rng), 1200), min(size(rng), 1200)
+    style = str(rng.choice(["random", "clusters", "clusters"]))
+    masked = rng.random() < 0.5
+    ratio = float(rng.choice([0.7, 0.9, 1.0]))
+    pk, pf = nk + int(rng.integers(0, 4)), nf + int(rng.integers(0, 4))
+    protos = rng.integers(0, 256, (int(rng.integers(1, 40)), dim)).astype(np.uint8)
+    KD = np.zeros((nkf, max(pk, 1), dim), np.uint8); FD = np.zeros((nfr, max(pf, 1), dim), np.uint8)
+    KM = np.full_like(KD, 255); FM = np.full_like(FD, 255)
+    KV = np.zeros((nkf, max(pk, 1)), np.uint8)
+    for k in range(nkf):
+        KD[k, :nk] = rows(rng, nk, dim, style, protos); KV[k, :nk] = rng.random(nk) < 0.9
+        if masked:
+            KM[k, :nk] = rng.integers(0, 256, (nk, dim))
+    for f in range(nfr):
+        FD[f, :nf] = rows(rng, nf, dim, style, protos)
+        if masked:
+            FM[f, :nf] = rng.integers(0, 256, (nf, dim))
+    desc = "sweep case %d: K=%d nkf=%d nframes=%d nk=%d nf=%d pitch=%d/%d %s masked=%d ratio=%.2f" % (idx, K, nkf, nfr, nk, nf, pk, pf, style, masked, ratio)
+    lib, ctx = mcs.lib(), G.ctx()
+    q = cap.DescSet(P(KD), P(KM) if masked else None, P(KV), None, nk, dim)
+    t = cap.DescSet(P(FD), P(FM) if masked else None, None, None, nf, dim)
+    out = np.full((nfr * nkf, max(nf, 1)), -7, np.int32); nm = np.zeros(nfr * nkf, np.int32); fb = np.zeros(nfr * nkf, np.int32)
+    rc = lib.mcs_search_kf_f_sweep(ctx.h, nkf, C.byref(q), KD.shape[1], nfr, C.byref(t), FD.shape[1], dim, ratio, K, cap.MEM_HOST, P(out), P(nm), P(fb))
+    if rc != 0:
+        return desc + " -> mcs_search_kf_f_sweep rc %d (%s)" % (rc, lib.mcs_last_error().decode()[:120])
+    for f in range(nfr):
+        for k in range(nkf):
+            s_ = f * nkf + k
+            en, eo = O.search_kf_f(np.ascontiguousarray(KD[k, :nk]), np.ascontiguousarray(KM[k, :nk]), np.ascontiguousarray(KV[k, :nk]),
+                                   np.ascontiguousarray(FD[f, :nf]), np.ascontiguousarray(FM[f, :nf]), masked, ratio)
+            if int(nm[s_]) != en or not np.array_equal(out.reshape(-1)[s_ * nf:(s_ + 1) * nf] if nf else out[s_, :0], eo):
+                return desc + " -> pair (frame %d, keyframe %d): %d matches, oracle %d" % (f, k, int(nm[s_]), en)
+    # the ring over the keyframe array (eligibility on both sides), device memory
+    if nk == 0 or nkf < 2:   # (a ring has at least two frames; first + count <= nframes_total: only the predecessor wraps)
+        return None
+    first = int(rng.integers(0, nkf)); count = int(rng.integers(1, nkf - first + 1))
+    dK, dM, dV = G.DevBuf(KD), G.DevBuf(KM), G.DevBuf(KV)
+    fr = cap.DescSet(dK.ptr, dM.ptr if masked else None, dV.ptr, None, nk, dim)
+    m12 = G.DevBuf(np.full((count, nk), -7, np.int32)); dn = G.DevBuf(np.zeros(count, np.int32)); dfb = G.DevBuf(np.zeros(count, np.int32))
+    rc = lib.mcs_search_kf_kf_ring(ctx.h, nkf, first, count, C.byref(fr), KD.shape[1], dim, ratio, K, cap.MEM_DEVICE, m12.ptr, dn.ptr, dfb.ptr)
+    if rc != 0:
+        return desc + " -> mcs_search_kf_kf_ring rc %d (%s)" % (rc, lib.mcs_last_error().decode()[:120])
+    G.ctx().synchronize()
+    gm, gn = m12.read(), dn.read()
+    for s_ in range(count):
+        a, b = (first + s_) % nkf, (first + s_ - 1) % nkf
+        en, e12 = O.search_kf_kf(np.ascontiguousarray(KD[a, :nk]), np.ascontiguousarray(KM[a, :nk]), np.ascontiguousarray(KV[a, :nk]),
+                                 np.ascontiguousarray(KD[b, :nk]), np.ascontiguousarray(KM[b, :nk]), np.ascontiguousarray(KV[b, :nk]), masked, ratio)
+        if int(gn[s_]) != en or not np.array_equal(gm[s_], e12):
+            return desc + " -> ring first=%d count=%d pair %d (frames %d, %d): %d matches, oracle %d" % (first, count, s_, a, b, int(gn[s_]), en)
+    return None
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -146,7 +205,7 @@ def main():
     n = bad = 0
     while time.time() - t0 < budget:
         try:
-            err = (case_topk if n % 3 == 0 else case_search)(rng, n)
+            err = (case_topk, case_search, case_search, case_sweep)[n % 4](rng, n)
         except Exception as ex:   # an error code of the library is a finding too
             err = "case %d raised %s: %s" % (n, type(ex).__name__, str(ex)[:200])
         n += 1
