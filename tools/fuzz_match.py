@@ -197,6 +197,63 @@ def case_sweep(rng, idx):
     return None
 
 
+def _unit(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+def case_triangulation(rng, idx):
+    """mcs_search_triangulation: queries = features WITHOUT a map point, camera groups, the epipolar test on rays and essential matrices (src/cORBmatcher.cpp:968-1155);
+    nsets neighbour keyframes against one shared current keyframe (pitch1 = 0) or pairwise"""
+    dim = 32
+    K = int(rng.choice([2, 8, 32]))
+    NC = int(rng.integers(1, 5))
+    nsets = int(rng.choice([1, 1, 3, 8]))
+    n1, n2 = min(max(size(rng), 1), 1500), min(max(size(rng), 1), 1500)
+    masked = rng.random() < 0.5
+    shared = rng.random() < 0.5
+    s1 = 1 if shared else nsets
+    p1, p2 = n1 + int(rng.integers(0, 4)), n2 + int(rng.integers(0, 4))
+    d1 = rng.integers(0, 256, (s1, p1, dim), dtype=np.uint8)
+    m1 = rng.integers(0, 256, (s1, p1, dim), dtype=np.uint8) if masked else np.full((s1, p1, dim), 255, np.uint8)
+    mp1 = (rng.random((s1, p1)) < 0.4).astype(np.uint8)
+    cam1 = rng.integers(0, NC, (s1, p1)).astype(np.int32)
+    rays1 = _unit(rng.normal(size=(s1, p1, 3)) * [0.5, 0.5, 0.2] + [0, 0, 1.0])
+    d2 = np.zeros((nsets, p2, dim), np.uint8)
+    m2 = rng.integers(0, 256, (nsets, p2, dim), dtype=np.uint8) if masked else np.full((nsets, p2, dim), 255, np.uint8)
+    mp2 = (rng.random((nsets, p2)) < 0.3).astype(np.uint8)
+    cam2 = np.zeros((nsets, p2), np.int32)
+    rays2 = np.zeros((nsets, p2, 3)); rays2[..., 2] = 1.0
+    for k in range(nsets):
+        a = 0 if shared else k
+        pick = rng.integers(0, n1, n2)
+        flip = (rng.random((n2, dim)) < 0.06) * rng.integers(0, 256, (n2, dim))
+        d2[k, :n2] = d1[a, pick] ^ flip.astype(np.uint8)
+        cam2[k, :n2] = np.where(rng.random(n2) < 0.85, cam1[a, pick], rng.integers(0, NC, n2))
+        rays2[k, :n2] = _unit(rays1[a, pick] + rng.normal(size=(n2, 3)) * np.where(rng.random((n2, 1)) < 0.6, 0.003, 0.2))
+    E = rng.normal(size=(NC, NC, 3, 3))
+    for c in range(NC):
+        t = np.array([0.05, 0.01 * c, 0.002])
+        E[c, c] = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = np.ascontiguousarray(E)
+    v1, v2 = (1 - mp1).astype(np.uint8), (1 - mp2).astype(np.uint8)
+    desc = "triangulation case %d: K=%d NC=%d nsets=%d n1=%d n2=%d shared=%d masked=%d" % (idx, K, NC, nsets, n1, n2, shared, masked)
+    lib, ctx = mcs.lib(), G.ctx()
+    q = cap.DescSet(P(d1), P(m1) if masked else None, P(v1), P(cam1), n1, dim)
+    t_ = cap.DescSet(P(d2), P(m2) if masked else None, P(v2), P(cam2), n2, dim)
+    m12 = np.full((nsets, n1), -7, np.int32); nm = np.full(nsets, -7, np.int32); fb = np.zeros(nsets, np.int32)
+    rc = lib.mcs_search_triangulation(ctx.h, nsets, C.byref(q), 0 if shared else p1, C.byref(t_), p2, P(rays1), P(rays2), P(E), NC, dim, K, cap.MEM_HOST, P(m12), P(nm), P(fb))
+    if rc != 0:
+        return desc + " -> rc %d (%s)" % (rc, lib.mcs_last_error().decode()[:120])
+    for k in range(nsets):
+        a = 0 if shared else k
+        en, e12 = O.search_triangulation(np.ascontiguousarray(d1[a, :n1]), np.ascontiguousarray(m1[a, :n1]), np.ascontiguousarray(mp1[a, :n1]), np.ascontiguousarray(cam1[a, :n1]),
+                                         np.ascontiguousarray(rays1[a, :n1]), np.ascontiguousarray(d2[k, :n2]), np.ascontiguousarray(m2[k, :n2]), np.ascontiguousarray(mp2[k, :n2]),
+                                         np.ascontiguousarray(cam2[k, :n2]), np.ascontiguousarray(rays2[k, :n2]), E.reshape(NC * NC, 9), NC, masked)
+        if int(nm[k]) != en or not np.array_equal(m12[k], e12):
+            return desc + " -> set %d: %d matches, oracle %d, %d entries differ" % (k, int(nm[k]), en, int((m12[k] != e12).sum()))
+    return None
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -205,7 +262,7 @@ def main():
     n = bad = 0
     while time.time() - t0 < budget:
         try:
-            err = (case_topk, case_search, case_search, case_sweep)[n % 4](rng, n)
+            err = (case_topk, case_search, case_triangulation, case_sweep, case_search)[n % 5](rng, n)
         except Exception as ex:   # an error code of the library is a finding too
             err = "case %d raised %s: %s" % (n, type(ex).__name__, str(ex)[:200])
         n += 1
