@@ -254,6 +254,43 @@ def case_triangulation(rng, idx):
     return None
 
 
+def case_bow(rng, idx):
+    """the vocabulary-restricted SearchByBoW(KF, F) (src/cORBmatcher.cpp:179-323): a keyframe feature only meets frame features of the same FeatureVector node — through
+    mcs_search_kf_f with the node id as `group`, keyframe rows in (node, index) order as the reference walks them (frontend.cORBmatcher.SearchByBoW)"""
+    dim = 32
+    K = int(rng.choice([2, 8, 32]))
+    nk, nf = min(max(size(rng), 1), 2500), min(max(size(rng), 1), 2500)
+    style = str(rng.choice(["random", "clusters", "clusters"]))
+    masked = rng.random() < 0.5
+    ratio = float(rng.choice([0.7, 0.9, 1.0]))
+    nnodes = int(rng.choice([1, 3, 20, 80]))
+    protos = rng.integers(0, 256, (int(rng.integers(1, 40)), dim)).astype(np.uint8)
+    dk, df = rows(rng, nk, dim, style, protos), rows(rng, nf, dim, style, protos)
+    mk = rng.integers(0, 256, (nk, dim)).astype(np.uint8) if masked else np.full((nk, dim), 255, np.uint8)
+    mf = rng.integers(0, 256, (nf, dim)).astype(np.uint8) if masked else np.full((nf, dim), 255, np.uint8)
+    vk = (rng.random(nk) < 0.85).astype(np.uint8)
+    nodek = np.where(rng.random(nk) < 0.9, rng.integers(0, nnodes, nk), -1).astype(np.int32)   # -1: a stopped word, the feature is in no node
+    nodef = np.where(rng.random(nf) < 0.9, rng.integers(0, nnodes, nf), -1).astype(np.int32)
+    desc = "bow case %d: K=%d nk=%d nf=%d nodes=%d %s masked=%d ratio=%.2f" % (idx, K, nk, nf, nnodes, style, masked, ratio)
+    order = np.array([i for nd in sorted(set(nodek[nodek >= 0].tolist())) for i in np.nonzero(nodek == nd)[0]], np.int64)
+    if len(order) == 0:
+        return None
+    gk = np.ascontiguousarray(nodek[order]); vf = (nodef >= 0).astype(np.uint8)
+    qd, qm, qv = np.ascontiguousarray(dk[order]), np.ascontiguousarray(mk[order]), np.ascontiguousarray(vk[order])
+    lib, ctx = mcs.lib(), G.ctx()
+    q = cap.DescSet(P(qd), P(qm) if masked else None, P(qv), P(gk), len(order), dim)
+    t = cap.DescSet(P(df), P(mf) if masked else None, P(vf), P(nodef), nf, dim)
+    mF = np.full(nf, -7, np.int32); nm = np.zeros(1, np.int32); fb = np.zeros(1, np.int32)
+    rc = lib.mcs_search_kf_f(ctx.h, 1, C.byref(q), 0, C.byref(t), 0, dim, ratio, K, cap.MEM_HOST, P(mF), P(nm), P(fb))
+    if rc != 0:
+        return desc + " -> rc %d (%s)" % (rc, lib.mcs_last_error().decode()[:120])
+    got = np.where(mF >= 0, order[np.maximum(mF, 0)], -1).astype(np.int32)
+    en, em = O.search_kf_f_bow(dk, mk if masked else None, vk, nodek, df, mf if masked else None, nodef, masked, ratio)
+    if int(nm[0]) != en or not np.array_equal(got, em):
+        return desc + " -> %d matches, oracle %d, %d entries differ" % (int(nm[0]), en, int((got != em).sum()))
+    return None
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -262,7 +299,7 @@ def main():
     n = bad = 0
     while time.time() - t0 < budget:
         try:
-            err = (case_topk, case_search, case_triangulation, case_sweep, case_search)[n % 5](rng, n)
+            err = (case_topk, case_search, case_triangulation, case_sweep, case_bow, case_search)[n % 6](rng, n)
         except Exception as ex:   # an error code of the library is a finding too
             err = "case %d raised %s: %s" % (n, type(ex).__name__, str(ex)[:200])
         n += 1
