@@ -15,10 +15,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gpu_common as G   # noqa: E402
 import test_gpu_window as TW   # noqa: E402  (its scaffolding: MP, rot_y, small_motion, oview, world_points)
+import test_gpu_frontend as TF   # noqa: E402  (TrackedMP: a map point as cMultiFrame::isInFrustum leaves it)
 
 FE = importlib.import_module("multicol-slam_amd.frontend")
 O = G.O
-STATS = {"WindowSearch": [0, 0], "SearchForInitialization": [0, 0], "SearchByProjection": [0, 0]}   # cases, matches
+STATS = {"WindowSearch": [0, 0], "SearchForInitialization": [0, 0], "SearchByProjection": [0, 0], "SearchByProjection(F,MapPoints)": [0, 0]}   # cases, matches
 
 
 def make_frames(rng):
@@ -45,7 +46,7 @@ def case(rng, idx, cams, fr):
     Fa, Fb = fr if rng.random() < 0.5 else fr[::-1]
     masks = bool(rng.random() < 0.5)
     ratio = float(rng.choice([0.6, 0.8, 0.9, 1.0]))
-    kind = int(rng.integers(0, 3))
+    kind = int(rng.integers(0, 4))
     if kind == 0:
         window = int(rng.choice([1, 5, 20, 60, 150, 400]))
         minlvl = int(rng.integers(0, 6)); maxlvl = int(rng.choice([2**31 - 1, 2**31 - 1, int(rng.integers(0, 8))]))
@@ -80,6 +81,58 @@ def case(rng, idx, cams, fr):
         STATS["SearchForInitialization"][0] += 1; STATS["SearchForInitialization"][1] += en
         if n != en or not np.array_equal(m12, e12) or not np.array_equal(got_prev, eprev):
             return desc + " -> %d matches, oracle %d, %d entries differ" % (n, en, int((m12 != e12).sum()))
+    elif kind == 3:
+        # SearchByProjection(F, vpMapPoints, th) (src/cORBmatcher.cpp:67-166) incl. GetFeaturesInArea / PosInGrid / RadiusByViewingCos: map points = features of Fa with
+        # the position a motion model would predict in Fb (shift + noise), a scale level near their octave, a viewing cosine; some in view of two cameras, some bad,
+        # some far outside or on the border
+        th = float(rng.choice([1.0, 3.0, 7.0, 15.0, 40.0]))
+        sigma = float(rng.choice([0.5, 1.5, 6.0]))
+        da, ma = Fa.all_descriptors(), Fa.all_masks()
+        nlv = len(Fb.mvScaleFactors)
+        mps = []
+        for i in rng.permutation(Fa.totalN)[:int(rng.uniform(0.1, 0.9) * Fa.totalN)]:
+            kp = Fa.mvKeys[i]
+            cam = int(Fa.keypoint_to_cam[i])
+            mp = TF.TrackedMP(int(i), da[i], ma[i], 3)
+            mp.bad = rng.random() < 0.03
+            for c in ([cam] if rng.random() < 0.9 else [cam, (cam + 1) % 3]):
+                mp.mbTrackInView[c] = True
+                mp.mTrackProjX[c] = float(kp["x"]) + 3.0 + rng.normal(0, sigma)
+                mp.mTrackProjY[c] = float(kp["y"]) + 1.0 + rng.normal(0, sigma)
+                mp.mnTrackScaleLevel[c] = int(np.clip(kp["octave"] + rng.integers(-1, 2), 0, nlv - 1))
+                mp.mTrackViewCos[c] = float(rng.choice([0.9995, 0.998, 0.99, 0.5]))
+            mps.append(mp)
+        for k, (x, y) in enumerate([(-500.0, 10.0), (2000.0, 100.0), (5.0, 5.0), (750.0, 478.0), (377.0, -90.0), (0.0, 0.0), (753.99, 479.99), (754.0, 480.0)]):
+            mp = TF.TrackedMP(10000 + k, da[k % len(da)], ma[k % len(ma)], 3)
+            mp.mbTrackInView[k % 3] = True
+            mp.mTrackProjX[k % 3], mp.mTrackProjY[k % 3], mp.mnTrackScaleLevel[k % 3], mp.mTrackViewCos[k % 3] = x, y, k % nlv, 0.999
+            mps.append(mp)
+        Fb.mvpMapPoints = [TF.MP(-1) if rng.random() < 0.1 else None for _ in range(Fb.totalN)]
+        pre = [m_ is not None for m_ in Fb.mvpMapPoints]
+        desc = "SearchByProjection(F,MapPoints) case %d: th=%.0f sigma=%.1f masks=%d ratio=%.2f points=%d" % (idx, th, sigma, masks, ratio, len(mps))
+        try:
+            px, py, vc, lv, pc, pd, pm, owner = [], [], [], [], [], [], [], []
+            for mp in mps:
+                if mp.isBad():
+                    continue
+                for c in range(3):
+                    if mp.mbTrackInView[c]:
+                        px.append(mp.mTrackProjX[c]); py.append(mp.mTrackProjY[c]); vc.append(mp.mTrackViewCos[c]); lv.append(mp.mnTrackScaleLevel[c])
+                        pc.append(c); pd.append(mp.desc); pm.append(mp.mask); owner.append(mp.i)
+            arr = lambda v, t: np.ascontiguousarray(v, t)   # noqa: E731
+            en, ematch = O.search_by_projection(arr(px, np.float64), arr(py, np.float64), arr(vc, np.float64), arr(lv, np.int32), arr(pc, np.int32),
+                                                arr(np.stack(pd), np.uint8), arr(np.stack(pm), np.uint8), arr(Fb.mvKeys, Fb.mvKeys.dtype),
+                                                arr(Fb.all_descriptors(), np.uint8), arr(Fb.all_masks(), np.uint8), arr(Fb.keypoint_to_cam, np.int32), np.array(pre, np.uint8),
+                                                arr(Fb.mnMaxX, np.int32), arr(Fb.mnMaxY, np.int32), arr(Fb.mvScaleFactors, np.float64), th, ratio, masks)
+            m = FE.cORBmatcher(ratio, False, 32, masks, ctx=G.ctx())
+            n = m.SearchByProjection(Fb, mps, th)
+            exp = {int(j): owner[p_] for p_, j in enumerate(ematch) if j >= 0}
+            got = {j: mp.i for j, mp in enumerate(Fb.mvpMapPoints) if mp is not None and not pre[j]}
+            STATS["SearchByProjection(F,MapPoints)"][0] += 1; STATS["SearchByProjection(F,MapPoints)"][1] += en
+            if n != en or got != exp:
+                return desc + " -> %d matches, oracle %d, %d assignments differ" % (n, en, len(set(got.items()) ^ set(exp.items())))
+        finally:
+            Fb.mvpMapPoints = [None] * Fb.totalN
     else:
         Last, Cur = Fa, Fb
         th = float(rng.choice([3.0, 7.0, 15.0, 50.0, 120.0]))
