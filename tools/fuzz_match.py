@@ -291,6 +291,29 @@ def case_bow(rng, idx):
     return None
 
 
+def case_distinct(rng, idx):
+    """cMapPoint::ComputeDistinctiveDescriptors (src/cMapPoint.cpp:294-382): per map point the observation with the least median distance to the others — a batch of
+    points with 0 .. 300 observations each, noisy copies of one descriptor, exact duplicates (ties), optional masks"""
+    FE = importlib.import_module("multicol-slam_amd.frontend")
+    dim = int(rng.choice([32, 32, 16, 64]))
+    masks = bool(rng.random() < 0.5)
+    obs = []
+    for n in [0, 1, 2, 3] + list(rng.integers(2, int(rng.choice([10, 40, 300])), int(rng.integers(1, 200)))):
+        n = int(n)
+        base = rng.integers(0, 256, dim, dtype=np.uint8)
+        d = np.repeat(base[None], n, axis=0)
+        d = d ^ np.packbits(rng.random((n, dim * 8)) < rng.uniform(0.0, 0.3), axis=1, bitorder="little")
+        if n > 4 and rng.random() < 0.3:
+            d[rng.integers(0, n)] = d[0]
+        m = (rng.integers(0, 256, (n, dim), dtype=np.uint8) | rng.integers(0, 256, (n, dim), dtype=np.uint8)) if masks else None
+        obs.append((d, m))
+    got = FE.ComputeDistinctiveDescriptorsBatch(obs, dim, G.ctx())
+    exp = np.array([O.distinctive_descriptor(d, m) for d, m in obs], np.int32)
+    if not np.array_equal(got, exp):
+        return "distinct case %d: dim=%d masks=%d points=%d -> %d differ, first %s" % (idx, dim, masks, len(obs), int((got != exp).sum()), np.flatnonzero(got != exp)[:5])
+    return None
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -299,7 +322,7 @@ def main():
     n = bad = 0
     while time.time() - t0 < budget:
         try:
-            err = (case_topk, case_search, case_triangulation, case_sweep, case_bow, case_search)[n % 6](rng, n)
+            err = (case_topk, case_search, case_triangulation, case_sweep, case_bow, case_search, case_distinct)[n % 7](rng, n)
         except Exception as ex:   # an error code of the library is a finding too
             err = "case %d raised %s: %s" % (n, type(ex).__name__, str(ex)[:200])
         n += 1

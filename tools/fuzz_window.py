@@ -19,7 +19,7 @@ import test_gpu_frontend as TF   # noqa: E402  (TrackedMP: a map point as cMulti
 
 FE = importlib.import_module("multicol-slam_amd.frontend")
 O = G.O
-STATS = {"WindowSearch": [0, 0], "SearchForInitialization": [0, 0], "SearchByProjection": [0, 0], "SearchByProjection(F,MapPoints)": [0, 0]}   # cases, matches
+STATS = {"WindowSearch": [0, 0], "SearchForInitialization": [0, 0], "SearchByProjection": [0, 0], "SearchByProjection(F,MapPoints)": [0, 0], "BestInWindows": [0, 0]}   # cases, matches
 
 
 def make_frames(rng):
@@ -46,7 +46,7 @@ def case(rng, idx, cams, fr):
     Fa, Fb = fr if rng.random() < 0.5 else fr[::-1]
     masks = bool(rng.random() < 0.5)
     ratio = float(rng.choice([0.6, 0.8, 0.9, 1.0]))
-    kind = int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5))
     if kind == 0:
         window = int(rng.choice([1, 5, 20, 60, 150, 400]))
         minlvl = int(rng.integers(0, 6)); maxlvl = int(rng.choice([2**31 - 1, 2**31 - 1, int(rng.integers(0, 8))]))
@@ -81,6 +81,38 @@ def case(rng, idx, cams, fr):
         STATS["SearchForInitialization"][0] += 1; STATS["SearchForInitialization"][1] += en
         if n != en or not np.array_equal(m12, e12) or not np.array_equal(got_prev, eprev):
             return desc + " -> %d matches, oracle %d, %d entries differ" % (n, en, int((m12 != e12).sum()))
+    elif kind == 4:
+        # mcs_window_best: the search loop of Fuse / SearchBySim3 / SearchForTriangulationBetweenCameras / the relocalisation SearchByProjection (src/cORBmatcher.cpp:1158-1988,
+        # 2120-2392): per probe the closest feature inside a window of radius r over a level range, optionally skipping and taking features
+        nlv = len(Fb.mvScaleFactors)
+        npr = int(rng.integers(1, Fa.totalN + 1))
+        idxs = rng.permutation(Fa.totalN)[:npr]
+        k = Fa.mvKeys[idxs]
+        sig = float(rng.choice([0.5, 1.0, 5.0]))
+        x = k["x"].astype(np.float64) + 2.0 + rng.normal(0, sig, npr)
+        y = k["y"].astype(np.float64) + 1.0 + rng.normal(0, sig, npr)
+        lvl = np.clip(k["octave"] + rng.integers(-1, 2, npr), 0, nlv - 1).astype(np.int32)
+        th = float(rng.choice([1.0, 3.0, 6.0, 10.0, 40.0]))
+        r = th * np.asarray(Fb.mvScaleFactors)[lvl]
+        q = min(npr, 6)
+        x[:q], y[:q] = [-300, 5000, 3, 377, 0, 753.99][:q], [10, 10, 3, 2000, 0, 479.99][:q]
+        cam = Fa.keypoint_to_cam[idxs].astype(np.int32)
+        if npr > 40:
+            cam[5:40] = (cam[5:40] + 1) % 3
+        lo = lvl - int(rng.integers(0, 3)); hi = lvl + int(rng.integers(0, 3))
+        d, mk = Fa.all_descriptors()[idxs], Fa.all_masks()[idxs]
+        assigned = (rng.random(Fb.totalN) < 0.15).astype(np.uint8)
+        maxd = int(rng.choice([0, 16, 32, 48, 96, 256]))
+        skip = bool(rng.random() < 0.5)
+        desc = "BestInWindows case %d: probes=%d th=%.0f levels=-%d/+%d maxd=%d skip=%d masks=%d" % (idx, npr, th, int((lvl - lo)[0]), int((hi - lvl)[0]), maxd, skip, masks)
+        matcher = FE.cORBmatcher(ratio, False, 32, masks, ctx=G.ctx())
+        asg = assigned.copy()
+        match, dist, n = matcher.BestInWindows(x, y, r, lo, hi, cam, d, mk, Fb, maxd, skip, asg)
+        v, _keep = O.frame_view(Fb.mvKeys, Fb.all_descriptors(), Fb.all_masks() if masks else None, Fb.keypoint_to_cam, Fb.mnMaxX, Fb.mnMaxY)
+        en, ematch, edist, easg = O.window_best(x, y, r, lo, hi, cam, d, mk if masks else None, v, assigned, maxd, skip, 32, masks)
+        STATS["BestInWindows"][0] += 1; STATS["BestInWindows"][1] += en
+        if n != en or not np.array_equal(match, ematch) or not np.array_equal(dist, edist) or not np.array_equal(asg, easg if skip else assigned):
+            return desc + " -> %d matches, oracle %d, %d entries differ" % (n, en, int((match != ematch).sum()))
     elif kind == 3:
         # SearchByProjection(F, vpMapPoints, th) (src/cORBmatcher.cpp:67-166) incl. GetFeaturesInArea / PosInGrid / RadiusByViewingCos: map points = features of Fa with
         # the position a motion model would predict in Fb (shift + noise), a scale level near their octave, a viewing cosine; some in view of two cameras, some bad,
