@@ -870,6 +870,23 @@ __global__ __launch_bounds__(256) void k_orient_b(ExtractBuffers b, int wavesPer
 	A.rc[gw] = row | (col << 16);
 	A.poff[gw] = (unsigned)(L.off + (size_t)(row - kPatchR) * L.stride + (col - kPatchR));   // the fast pass requests the next keypoint's patch from this alone
 	const int lvlWord = level | (L.stride << 16);                                            // (level coordinates < 4096: the stride fits 15 bits)
+	if constexpr (MODE == 0) {
+		// ORB (round 6): what is identical in all 64 lanes of the descriptor wave — the ray of the keypoint and the rotation's cos / sin, ~350 of the ~700
+		// instructions the wave spent per keypoint — is done here by ONE thread; k_describe_orb only stages the patch and forms the 256 bits.  Same statements as
+		// describe_wave<0> (cameras are optional in ORB mode: no ray without them).
+		if (b.cams && b.rays) {
+			double rx, ry, rz;
+			img2world(b.cams[img], (double)pxf, (double)pyf, rx, ry, rz);
+			double* rp = b.rays + ((size_t)img * d.kpCap + s) * 3;
+			rp[0] = rx; rp[1] = ry; rp[2] = rz;
+		}
+		const float DEG2RADf = (float)3.1415926535897932384626433832795 / 180.f;
+		const double a0 = (double)(angle * DEG2RADf);
+		double* D = A.d8 + gw;
+		D[(size_t)2 * nslots] = cos(a0); D[(size_t)3 * nslots] = sin(a0);
+		A.lvl[gw] = lvlWord;
+		return;
+	}
 	const OcamDev& cam = b.cams[img];
 	double rayx, rayy, rayz;
 	img2world(cam, (double)pxf, (double)pyf, rayx, rayy, rayz);
@@ -1466,6 +1483,55 @@ void launch_selftest_fast_model(const OcamDev* cam, const double* tab, unsigned 
 	hipLaunchKernelGGL(k_selftest_fast_model, dim3((n + 255) / 256), dim3(256), 0, s, cam, tab, seed, n, width, height, maxDiff);
 }
 
+// ORB descriptors of a batch prepared by k_orient_b<0>: a wave per output row stages the blurred patch and forms NB x 64 bits (computeOrbDescriptor,
+// src/mdBRIEFextractorOct.cpp:1203-1242 via describe_wave<0>'s statements: double rotation, cvRound, tie watch)
+template <int NB>
+__global__ __launch_bounds__(256) void k_describe_orb(ExtractBuffers b, int wavesPerImage, int nslots) {
+	extern __shared__ double orb_lds[];
+	const PyrDesc& d = *b.desc;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+	if (gw >= nslots) return;
+	KpAuxSoA A; A.carve(b.aux, nslots);
+	const int lw = __builtin_amdgcn_readfirstlane(A.lvl[gw]);
+	if (lw < 0) return;
+	const int level = lw & 0xFF;
+	const int rc = __builtin_amdgcn_readfirstlane(A.rc[gw]);
+	const int row = rc & 0xFFFF, col = (int)((unsigned)rc >> 16);
+	const int img = gw / wavesPerImage, out = gw - img * wavesPerImage;
+	const double ax = uniform_f64(A.d8 + (size_t)2 * nslots + gw), ay = uniform_f64(A.d8 + (size_t)3 * nslots + gw);
+	const LevelInfo& L = d.lv[level];
+	uint8_t* patch = reinterpret_cast<uint8_t*>(orb_lds) + (size_t)wave * kPatchBytes;
+	Sampler sm = {};
+	int rstride;
+	sm.raw = level_ptr(b, d, img, level, &rstride); sm.rstride = rstride; sm.w = L.w; sm.h = L.h;
+	sm.blur = b.blur + (size_t)img * d.pyrBytes + L.off; sm.bstride = L.stride;
+	uint32_t pv[kPatchTrips];
+	patch_load(sm.blur, sm.bstride, row, col, pv);
+	patch_store(patch, pv);
+	sm.patch = patch; sm.prow = row - kPatchR; sm.pcol = col - kPatchR;
+	uint8_t* dout = b.out_desc + ((size_t)img * b.outImgPitch + out) * b.outRowStride;
+	uint8_t* mout = b.out_mask + ((size_t)img * b.outImgPitch + out) * b.outRowStride;
+	double tie = 0.0;
+#pragma unroll
+	for (int j = 0; j < NB; ++j) {
+		const int k = j * 64 + lane;
+		const double x0 = c_pattern[4 * k], y0 = c_pattern[4 * k + 1], x1 = c_pattern[4 * k + 2], y1 = c_pattern[4 * k + 3];
+		const double fx0 = x0 * ax - y0 * ay, fy0 = x0 * ay + y0 * ax, fx1 = x1 * ax - y1 * ay, fy1 = x1 * ay + y1 * ax;
+		const int ix0 = __double2int_rn(fx0), iy0 = __double2int_rn(fy0);
+		const int ix1 = __double2int_rn(fx1), iy1 = __double2int_rn(fy1);
+		tie = fmax(fmax(tie, fmax(tie_frac(fx0), tie_frac(fy0))), fmax(tie_frac(fx1), tie_frac(fy1)));
+		int t0, t1;
+		sm.pair(row, col, iy0, ix0, iy1, ix1, t0, t1);
+		const unsigned long long bits = __ballot(t0 < t1);
+		if (lane == 0) {
+			*reinterpret_cast<unsigned long long*>(dout + 8 * j) = bits;
+			*reinterpret_cast<unsigned long long*>(mout + 8 * j) = 0ull;   // descriptorMasks = zeros (:1216)
+		}
+	}
+	tie_commit(b, gw, tie);
+}
+
 template <int MODE, int NB>
 static void launch_fast_passes(const ExtractBuffers& b, int nimg, int wavesPerImage, size_t listLds, hipStream_t s) {
 	const int nslots = nimg * wavesPerImage, ngroups = nslots / kFastWaves, lblocks = std::min(nslots, 2048);
@@ -1511,6 +1577,19 @@ static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hi
 			if (nb == 2) launch_fast_passes<MODE, 2>(b, nimg, wavesPerImage, ldsBytes, s);
 			else if (nb == 4) launch_fast_passes<MODE, 4>(b, nimg, wavesPerImage, ldsBytes, s);
 			else launch_fast_passes<MODE, 8>(b, nimg, wavesPerImage, ldsBytes, s);
+			return;
+		}
+	}
+	if constexpr (MODE == 0) {
+		static const bool orbSplit = !(getenv("MCS_ORB_SPLIT") && atoi(getenv("MCS_ORB_SPLIT")) == 0);   // 0: the one-kernel form (A/B, tests)
+		if (orbSplit && b.aux) {
+			const int nslots = nimg * wavesPerImage;
+			hipLaunchKernelGGL((k_orient_b<0>), dim3((nslots + 255) / 256), dim3(256), 0, s, b, wavesPerImage, nslots);
+			if (b.evFastA) (void)hipEventRecord(b.evFastA, s);
+			if (nb == 2) hipLaunchKernelGGL((k_describe_orb<2>), dim3(blocks), dim3(256), ldsBytes, s, b, wavesPerImage, nslots);
+			else if (nb == 4) hipLaunchKernelGGL((k_describe_orb<4>), dim3(blocks), dim3(256), ldsBytes, s, b, wavesPerImage, nslots);
+			else hipLaunchKernelGGL((k_describe_orb<8>), dim3(blocks), dim3(256), ldsBytes, s, b, wavesPerImage, nslots);
+			if (b.evFastB) (void)hipEventRecord(b.evFastB, s);
 			return;
 		}
 	}

@@ -63,3 +63,12 @@ def test_run_time_switches_do_not_change_any_output():
                 {"MCS_PYR_CHAIN": "1", "MCS_NO_OVERLAP": "1"}, {"MCS_PYR_TILES": "1"}, {"MCS_LIST_SPLIT": "0"}, {"MCS_GRAPHS": "0"}, {"MCS_GREEDY_JACOBI": "0"}, {"MCS_OUT_KERNEL": "0"}):
         got, n = _run(env)
         assert (got, n) == (ref, nmatch), env
+
+
+def test_orb_one_kernel_form_still_reproduces_the_oracle():
+    """MCS_ORB_SPLIT=0: ORB descriptors by the one-kernel form (describe_wave<0>: ray, rotation and bits in the descriptor wave) instead of k_orient_b<0> + k_describe_orb
+    (round 6) — the end-to-end ORB parity tests in a fresh process with the switch"""
+    e = dict(os.environ, MCS_ORB_SPLIT="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_extract.py"), "-m", "gpu", "-q", "-x", "-k", "end_to_end_bit_exact or no_mask_and_odd"],
+                       env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
