@@ -1582,7 +1582,9 @@ static void launch_mode(const ExtractBuffers& b, const PyrDesc& hd, int nimg, hi
 	}
 	if constexpr (MODE == 0) {
 		static const bool orbSplit = !(getenv("MCS_ORB_SPLIT") && atoi(getenv("MCS_ORB_SPLIT")) == 0);   // 0: the one-kernel form (A/B, tests)
-		if (orbSplit && b.aux) {
+		// (a small batch — one multi-frame per call — is launch-bound: the one-kernel form saves a launch there and its redundant arithmetic costs nothing on an idle chip)
+		static const bool orbForce = getenv("MCS_ORB_SPLIT") != nullptr;   // "1": the split form for every batch size (tests)
+		if (orbSplit && b.aux && (orbForce || nimg * wavesPerImage >= 8192)) {
 			const int nslots = nimg * wavesPerImage;
 			hipLaunchKernelGGL((k_orient_b<0>), dim3((nslots + 255) / 256), dim3(256), 0, s, b, wavesPerImage, nslots);
 			if (b.evFastA) (void)hipEventRecord(b.evFastA, s);

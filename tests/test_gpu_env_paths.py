@@ -65,10 +65,12 @@ def test_run_time_switches_do_not_change_any_output():
         assert (got, n) == (ref, nmatch), env
 
 
-def test_orb_one_kernel_form_still_reproduces_the_oracle():
-    """MCS_ORB_SPLIT=0: ORB descriptors by the one-kernel form (describe_wave<0>: ray, rotation and bits in the descriptor wave) instead of k_orient_b<0> + k_describe_orb
-    (round 6) — the end-to-end ORB parity tests in a fresh process with the switch"""
-    e = dict(os.environ, MCS_ORB_SPLIT="0")
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_both_forms_of_the_orb_descriptor_reproduce_the_oracle(split):
+    """ORB descriptors come from k_orient_b<0> + k_describe_orb (round 6: the keypoint's ray and rotation by one thread, the bits by a lean wave) for batches of 8192 rows
+    and more, from the one-kernel form (describe_wave<0>) below that; MCS_ORB_SPLIT = 1 / 0 forces either for every size — the end-to-end ORB parity tests (3-image
+    batches) in a fresh process with each"""
+    e = dict(os.environ, MCS_ORB_SPLIT=split)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_extract.py"), "-m", "gpu", "-q", "-x", "-k", "end_to_end_bit_exact or no_mask_and_odd"],
                        env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
